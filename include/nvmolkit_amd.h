@@ -1,0 +1,127 @@
+/*
+ * nvmolkit_amd.h — C ABI of the MI355X (gfx950) hot-path library `libnvmolkit_amd.so`.
+ *
+ * This is the drop-in boundary for the batched data-parallel hot path of nvMolKit
+ * (fingerprint similarity / Butina clustering / Morgan fingerprints / force fields /
+ * BFGS / ETKDG).  The reference has no C ABI: its Boost.Python modules call C++
+ * directly (see INTEGRATION.md for the binding a maintainer would add).  Every entry
+ * point below names the reference interface it replaces (paths are into the reference
+ * repository, `file:line`).
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative NVMK_ERR_* code on failure; the message of the
+ *     most recent failure on the calling thread is returned by nvmk_last_error();
+ *   - no exception crosses the boundary, no torch / C++ types appear in a signature;
+ *   - pointers named d_* are DEVICE pointers valid on the current HIP device, h_* are
+ *     HOST pointers; the library never allocates a caller-visible output;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); work is
+ *     enqueued asynchronously on it unless the function is documented as blocking;
+ *   - callable concurrently from different host threads on different streams.
+ */
+#ifndef NVMOLKIT_AMD_H
+#define NVMOLKIT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVMK_OK 0
+#define NVMK_ERR_INVALID_ARGUMENT (-1) /* maps to Python ValueError (reference: std::invalid_argument) */
+#define NVMK_ERR_HIP (-2)              /* HIP runtime failure (reference: CudaBadReturnCode, src/utils/cuda_error_check.h:28-46) */
+#define NVMK_ERR_OUT_OF_MEMORY (-3)    /* reference: std::runtime_error("Not enough memory…"), src/similarity.cpp:137-139 */
+#define NVMK_ERR_UNSUPPORTED (-4)
+#define NVMK_ERR_INTERNAL (-5)
+
+/* Similarity metric selector (reference: enum SimilarityType, src/similarity_kernels.cu). */
+#define NVMK_METRIC_TANIMOTO 0
+#define NVMK_METRIC_COSINE 1
+
+/* ---- library / device info ------------------------------------------------------------------ */
+
+/* Message of the last failure on this thread ("" if none).  Never NULL. */
+const char* nvmk_last_error(void);
+/* ABI version of this header: (major << 16) | minor. */
+int nvmk_abi_version(void);
+/* Number of visible HIP devices (reference: src/utils/device.h countCudaDevices). */
+int nvmk_device_count(int* count);
+/* Free / total bytes on the current device (reference: getDeviceFreeMemory, src/utils/device.h). */
+int nvmk_device_memory(size_t* free_bytes, size_t* total_bytes);
+
+/* ---- S1/S2: dense N x M cross-similarity ------------------------------------------------------
+ * Replaces launchCrossTanimotoSimilarity / launchCrossCosineSimilarity
+ * (src/similarity_kernels.cu:505-582, :727-799) and their callers
+ * crossTanimotoSimilarityGpuResult / crossCosineSimilarityGpuResult (src/similarity.cpp:38-58, :260-280).
+ *
+ *   d_a   : nA rows of `fp_bits/32` uint32 words, row-major (bit j of a fingerprint = bit j%32 of word j/32)
+ *   d_b   : nB rows, same width
+ *   d_out : nA x nB doubles, row stride `ld_out` elements (pass nB for a dense matrix)
+ *
+ *   tanimoto: out[i][j] = c / max(1, pa + pb - c),   c = popcount(a_i & b_j)   (double division)
+ *   cosine  : out[i][j] = (c == 0 || pa*pb == 0) ? 0 : c / sqrt((double)pa * (double)pb)
+ * (the reference's SIMT formulas, src/similarity_kernels.cu:350-364).
+ * fp_bits must be a positive multiple of 32.  nA == 0 or nB == 0 is a no-op.
+ */
+int nvmk_cross_tanimoto_f64(const uint32_t* d_a, int64_t nA, const uint32_t* d_b, int64_t nB, int fp_bits,
+                            double* d_out, int64_t ld_out, void* stream);
+int nvmk_cross_cosine_f64(const uint32_t* d_a, int64_t nA, const uint32_t* d_b, int64_t nB, int fp_bits,
+                          double* d_out, int64_t ld_out, void* stream);
+
+/* ---- S4: memory-constrained cross-similarity returned on the host --------------------------------
+ * Replaces crossTanimotoSimilarityCPUResult / crossCosineSimilarityCPUResult -> crossSimilarityImpl
+ * (src/similarity.cpp:105-254, :282-297; CrossSimilarityOptions src/similarity.h:29-32).
+ * Blocking.  `h_out` is nA*nB doubles on the host (any pageable or pinned memory).
+ * max_device_bytes < 0 means "use the free memory of the current device".  When the matrix does
+ * not fit, rows of `a` are processed in chunks of max(32, floor(((max/2)*0.9/8)/(32*nB))*32) rows on two
+ * streams with double-buffered pinned staging; if 32 rows do not fit -> NVMK_ERR_OUT_OF_MEMORY.
+ */
+int nvmk_cross_similarity_host_f64(int metric, const uint32_t* d_a, int64_t nA, const uint32_t* d_b, int64_t nB,
+                                   int fp_bits, double* h_out, int64_t max_device_bytes);
+
+/* ---- B2 building blocks: matrix-free neighbour counting -----------------------------------------
+ * Replaces update_neighbor_counts / _update_neighbor_count_kernel (nvmolkit/_fusedButina.py:99-179, :249-289).
+ * For every row i of x: counts[i] += sign * #{ j : float32(sim(x_i, y_j)) >= thr_f32 and denom > 0 }.
+ * sim is evaluated in float32 exactly as the reference does (float(c) / float(denom)).
+ * sign must be +1 or -1.  d_x_rows / d_y_rows are optional row-index lists (NULL = rows 0..n-1):
+ * the logical row r of x is the physical row d_x_rows[r] of d_x, which lets a caller keep the
+ * fingerprint matrix in place instead of compacting it every round.  counts is indexed by the
+ * PHYSICAL row (counts[d_x_rows[r]]), i.e. it stays aligned with d_x across rounds.
+ */
+int nvmk_neighbor_counts(int metric, const uint32_t* d_x, const int32_t* d_x_rows, int64_t nX, const uint32_t* d_y,
+                         const int32_t* d_y_rows, int64_t nY, int fp_bits, float threshold, int sign,
+                         int32_t* d_counts, void* stream);
+
+/* ---- B2: fused (matrix-free) Taylor-Butina -------------------------------------------------------
+ * Replaces fused_butina (nvmolkit/clustering.py:99-189).  Blocking.
+ *   d_x              : N x fp_bits/32 words
+ *   cutoff           : distance cutoff in [0,1]; neighbour <=> float32(sim) >= float32(1 - cutoff)
+ *   h_cluster_indices: N int32; members grouped by cluster, cluster k = [h_offsets[k], h_offsets[k+1]),
+ *                      centroid FIRST inside each group
+ *   h_offsets        : N+1 int64 capacity; first *n_clusters+1 entries valid (h_offsets[0] = 0),
+ *                      i.e. the reference's cumulative `cluster_sizes` list
+ *   h_centroids      : N int32 capacity, first *n_clusters entries valid
+ * Cluster sizes are non-increasing up to the singleton tail, ties are broken toward the highest
+ * row index (clustering.py:159).
+ */
+int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, double cutoff,
+                      int32_t* h_cluster_indices, int64_t* h_offsets, int32_t* h_centroids, int64_t* n_clusters,
+                      void* stream);
+
+/* ---- B1: Taylor-Butina on a dense matrix ----------------------------------------------------------
+ * Replaces butinaGpu(span<const double>, ...) and butinaGpu(span<const uint8_t>, ...)
+ * (src/butina.cu:1017-1071).  Blocking (the reference also synchronises the stream before returning,
+ * src/butina.cu:1006-1014).
+ *   d_dist      : N x N doubles (neighbour <=> dist <= cutoff, src/butina.cu:1043-1051), or NULL
+ *   d_hit       : N x N uint8 adjacency (used when d_dist is NULL)
+ *   d_clusters  : N int32 out; cluster ids, id 0 = largest cluster, ties by ascending original id
+ *   d_centroids : N int32 capacity out or NULL; centroid row of each cluster id
+ */
+int nvmk_butina_dense(const double* d_dist, const uint8_t* d_hit, int64_t N, double cutoff, int neighborlist_max_size,
+                      int32_t* d_clusters, int32_t* d_centroids, int64_t* h_n_clusters, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVMOLKIT_AMD_H */

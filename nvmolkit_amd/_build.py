@@ -1,0 +1,100 @@
+"""Build libnvmolkit_amd.so in-tree with hipcc for gfx950.
+
+The library is a plain C-ABI shared object (see include/nvmolkit_amd.h); it is built with an
+explicit hipcc command rather than torch.utils.cpp_extension because nothing in it depends on
+torch.  hipcc cross-compiles without a GPU, so this runs in the CPU-only build container too.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC_DIR = PKG_DIR / "csrc"
+LIB_DIR = PKG_DIR / "lib"
+LIB_PATH = LIB_DIR / "libnvmolkit_amd.so"
+OBJ_DIR = PKG_DIR / "build"
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH and /opt/rocm/bin/hipcc)")
+
+
+def sources() -> list[Path]:
+    return sorted(list(CSRC_DIR.glob("*.hip")) + list(CSRC_DIR.glob("*.cpp")))
+
+
+def _digest(paths: list[Path]) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
+def _deps() -> list[Path]:
+    return sorted(list(CSRC_DIR.glob("*.h")) + list(CSRC_DIR.glob("*.hpp")) + [PKG_DIR.parent / "include" / "nvmolkit_amd.h"])
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every source under csrc/ into lib/libnvmolkit_amd.so (incremental per file)."""
+    LIB_DIR.mkdir(exist_ok=True)
+    OBJ_DIR.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    common = [
+        hipcc,
+        f"--offload-arch={ARCH}",
+        "-O3",
+        "-std=c++17",
+        "-fPIC",
+        
+        "-Wall",
+        "-Wno-unused-function",
+        f"-I{PKG_DIR.parent / 'include'}",
+    ]
+    dep_digest = _digest(_deps())
+    objs: list[Path] = []
+    relink = force or not LIB_PATH.exists()
+    for src in sources():
+        obj = OBJ_DIR / (src.name + ".o")
+        stamp = OBJ_DIR / (src.name + ".sha")
+        digest = _digest([src]) + dep_digest
+        if force or not obj.exists() or not stamp.exists() or stamp.read_text() != digest:
+            cmd = common + (["-x", "hip"] if src.suffix == ".hip" else []) + ["-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+            stamp.write_text(digest)
+            relink = True
+        objs.append(obj)
+    if relink:
+        cmd = [
+            hipcc,
+            f"--offload-arch={ARCH}",
+            "-shared",
+            "-fPIC",
+            
+            "-o",
+            str(LIB_PATH),
+            *map(str, objs),
+            "-Wl,-rpath,/opt/rocm/lib",
+            "-Wl,--no-undefined",
+            "-lpthread",
+        ]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

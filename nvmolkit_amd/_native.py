@@ -1,0 +1,102 @@
+"""ctypes binding of libnvmolkit_amd.so (the C ABI declared in include/nvmolkit_amd.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load, every
+operator raises.  ``import torch`` happens before the library is opened so that the HIP runtime
+torch ships (same SONAME, libamdhip64.so.7) is the one both share — device pointers and streams
+created by torch are then directly usable by the kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import torch  # noqa: F401  (must be imported before the HIP library is dlopen'ed, see module docstring)
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libnvmolkit_amd.so"
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_HIP = -2
+ERR_OUT_OF_MEMORY = -3
+ERR_UNSUPPORTED = -4
+ERR_INTERNAL = -5
+
+METRIC_TANIMOTO = 0
+METRIC_COSINE = 1
+
+
+class NativeLibraryError(ImportError):
+    """libnvmolkit_amd.so is missing or could not be loaded."""
+
+
+_lib: ctypes.CDLL | None = None
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+
+# name -> (restype, argtypes); every symbol declared in include/nvmolkit_amd.h appears here.
+SIGNATURES: dict[str, tuple] = {
+    "nvmk_last_error": (ctypes.c_char_p, []),
+    "nvmk_abi_version": (_int, []),
+    "nvmk_device_count": (_int, [ctypes.POINTER(_int)]),
+    "nvmk_device_memory": (_int, [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "nvmk_cross_tanimoto_f64": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _vp]),
+    "nvmk_cross_cosine_f64": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _vp]),
+    "nvmk_cross_similarity_host_f64": (_int, [_int, _vp, _i64, _vp, _i64, _int, _vp, _i64]),
+    "nvmk_neighbor_counts": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _i64, _int, ctypes.c_float, _int, _vp, _vp]),
+    "nvmk_butina_fused": (_int, [_int, _vp, _i64, _int, ctypes.c_double, _vp, _vp, _vp, ctypes.POINTER(_i64), _vp]),
+    "nvmk_butina_dense": (_int, [_vp, _vp, _i64, ctypes.c_double, _int, _vp, _vp, ctypes.POINTER(_i64), _vp]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the native library; raises NativeLibraryError if it is not built."""
+    global _lib
+    if _lib is None:
+        path = Path(os.environ.get("NVMOLKIT_AMD_LIB", LIB_PATH))
+        if not path.exists():
+            raise NativeLibraryError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `python nvmolkit_amd/_build.py`); there is no CPU fallback."
+            )
+        try:
+            L = ctypes.CDLL(str(path))
+        except OSError as exc:  # pragma: no cover - depends on the host
+            raise NativeLibraryError(f"could not load {path}: {exc}") from exc
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().nvmk_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str = "") -> None:
+    """Translate an ABI return code into the exception type the reference's bindings raise."""
+    if rc == OK:
+        return
+    msg = last_error() or f"{what} failed with code {rc}"
+    if rc == ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)  # reference: std::invalid_argument -> ValueError (Boost.Python translation)
+    if rc == ERR_OUT_OF_MEMORY:
+        raise RuntimeError(msg)  # reference: std::runtime_error("Not enough memory ...")
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def stream_ptr(stream) -> int:
+    """``torch.cuda.Stream | None`` -> raw hipStream_t value (reference: nvmolkit/similarity.py:66)."""
+    if stream is not None and not isinstance(stream, torch.cuda.Stream):
+        raise TypeError(f"stream must be a torch.cuda.Stream or None, got {type(stream).__name__}")
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return int(s.cuda_stream)

@@ -1,0 +1,917 @@
+// Matrix-free neighbour counting, fused Taylor-Butina and dense-matrix Taylor-Butina — gfx950.
+//
+// Replaces (reference paths):
+//   nvmolkit/_fusedButina.py:99-179   _update_neighbor_count_kernel (Triton + PTX popc)
+//   nvmolkit/_fusedButina.py:182-246  _extract_cluster_singleton_kernel
+//   nvmolkit/clustering.py:99-189     fused_butina (Python loop, one host sync per cluster)
+//   src/butina.cu:913-1071            butinaGpu (dense matrix, CUDA-graph WHILE loops)
+//
+// Design notes (MI355X-first, not a translation):
+//   * neighbour counting reuses the dense kernel's 128x128 LDS tile / 8x8 register tile, but a
+//     workgroup keeps its A tile resident and walks a STRIP of B tiles, prefetching the next B tile
+//     into registers while the popcount loop runs; row counts live in registers for the whole strip
+//     and are flushed with one atomic per row per strip.
+//   * the reference's per-pair float32 division is replaced by a table: for Tanimoto the predicate
+//     float(c)/float(pa+pb-c) >= thr is monotone in c for fixed s = pa+pb, so tmin[s] = the smallest
+//     such c is built once per call (with real float32 divisions, so the predicate is bit-identical)
+//     and the per-pair work is one LDS lookup and one compare.
+//   * the fused Butina loop runs on the device: argmax / extract+compact / subtract kernels are
+//     enqueued in batches and the host reads one status word per batch instead of syncing per cluster.
+//   * the fingerprint matrix is never compacted; kernels gather rows through index lists.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace nvmk {
+namespace butina {
+
+constexpr int      TM       = 128;
+constexpr int      TN       = 128;
+constexpr int      NT       = 256;
+constexpr int      STRIP    = 32;      // B tiles walked by one workgroup
+constexpr uint16_t NEVER    = 0xFFFF;  // table sentinel: no c satisfies the predicate
+
+__device__ __forceinline__ void bcnt_acc(int& acc, const unsigned x) {
+  asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+}
+
+__device__ __forceinline__ void popc4(const uint4 a, const uint4 b, int& acc) {
+  bcnt_acc(acc, a.x & b.x);
+  bcnt_acc(acc, a.y & b.y);
+  bcnt_acc(acc, a.z & b.z);
+  bcnt_acc(acc, a.w & b.w);
+}
+
+__device__ __forceinline__ int popc_u4(const uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+
+// float32 neighbour predicate, exactly the oracle's / reference's (nvmolkit/_fusedButina.py:160-173).
+template <int METRIC> __device__ __forceinline__ bool is_neighbor(const int c, const int pa, const int pb, const float thr) {
+  if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+    const int u = pa + pb - c;
+    if (u <= 0) return false;
+    return static_cast<float>(c) / static_cast<float>(u) >= thr;
+  } else {
+    const float denom = sqrtf(static_cast<float>(pa) * static_cast<float>(pb));
+    if (!(denom > 0.0f)) return false;
+    return static_cast<float>(c) / denom >= thr;
+  }
+}
+
+// tmin[s], s = pa + pb in [0, 2*F]: smallest c with float(c)/float(s-c) >= thr (NEVER if none);
+// entries (2F, 3F+1] are NEVER so that a sentinel popcount of 2F+1 disables a padded column.
+__global__ void build_tanimoto_table_kernel(uint16_t* __restrict__ table, const int F, const float thr) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > 3 * F + 1) return;
+  uint16_t v = NEVER;
+  if (s >= 1 && s <= 2 * F) {
+    // predicate is monotone non-decreasing in c on [0, s-1]
+    int lo = 0, hi = s;  // answer in [lo, hi], hi == s means none
+    while (lo < hi) {
+      const int  mid = (lo + hi) >> 1;
+      const bool ok  = static_cast<float>(mid) / static_cast<float>(s - mid) >= thr;
+      if (ok) {
+        hi = mid;
+      } else {
+        lo = mid + 1;
+      }
+    }
+    if (lo < s) v = static_cast<uint16_t>(lo);
+  }
+  table[s] = v;
+}
+
+// ---- staging helpers -------------------------------------------------------------------------
+
+template <int S> struct Geo {
+  static constexpr int SWZ      = (S < 16 ? S : 16) - 1;  // swizzle mask on the low slot bits
+  static constexpr int ROWBYTES = S * 16;
+  static constexpr int PIECES   = TM * S;
+  static constexpr int PASSES   = (PIECES + NT - 1) / NT;
+};
+
+// Load this thread's pieces of a 128-row tile into registers.  Rows are gathered through `rows`
+// (NULL = identity); rows past n are clamped to row n-1 (never stored / counted).
+template <int S>
+__device__ __forceinline__ void tile_fetch(uint4 (&v)[Geo<S>::PASSES], const uint4* __restrict__ g,
+                                           const int32_t* __restrict__ rows, const int64_t row0, const int64_t n,
+                                           const int tid) {
+#pragma unroll
+  for (int t = 0; t < Geo<S>::PASSES; ++t) {
+    const int p    = tid + t * NT;
+    const int row  = (p < Geo<S>::PIECES) ? p / S : 0;
+    const int slot = p % S;
+    int64_t   r    = row0 + row;
+    r              = r < n ? r : n - 1;
+    const int64_t phys = rows ? static_cast<int64_t>(rows[r]) : r;
+    v[t]               = g[phys * S + slot];
+  }
+}
+
+// Write fetched pieces to swizzled LDS; per-row popcounts go to pc[] (rows >= valid rows get `padPc`).
+template <int S>
+__device__ __forceinline__ void tile_commit(const uint4 (&v)[Geo<S>::PASSES], char* lds, int* pc, const int64_t row0,
+                                            const int64_t n, const int padPc, const int tid) {
+#pragma unroll
+  for (int t = 0; t < Geo<S>::PASSES; ++t) {
+    const int  p     = tid + t * NT;
+    const bool valid = p < Geo<S>::PIECES;
+    const int  row   = valid ? p / S : 0;
+    const int  slot  = p % S;
+    if (valid) {
+      const int sw = slot ^ ((row >> 2) & Geo<S>::SWZ);
+      *reinterpret_cast<uint4*>(lds + (row * S + sw) * 16) = v[t];
+    }
+    int cnt = popc_u4(v[t]);
+#pragma unroll
+    for (int o = (S < 64 ? S : 64) / 2; o > 0; o >>= 1) {
+      cnt += __shfl_xor(cnt, o);
+    }
+    if (valid && slot == 0) {
+      pc[row] = (row0 + row < n) ? cnt : padPc;
+    }
+  }
+}
+
+// counts[xrow] += sign * #{ y rows that are neighbours of x row }.
+// grid = (strips, tilesM): blockIdx.y = A tile, blockIdx.x = strip of STRIP B tiles.
+// nXdev / nYdev: optional device-side row counts (the Butina loop launches with host-side upper
+// bounds and lets the kernel read the true sizes); NULL = use nX / nY.
+template <int S, int METRIC>
+__global__ __launch_bounds__(NT, 2) void neighbor_count_kernel(const uint4* __restrict__ X,
+                                                               const int32_t* __restrict__ xRows,
+                                                               int64_t       nX,
+                                                               const int32_t* __restrict__ nXdev,
+                                                               const uint4* __restrict__ Y,
+                                                               const int32_t* __restrict__ yRows,
+                                                               int64_t       nY,
+                                                               const int32_t* __restrict__ nYdev,
+                                                               const uint16_t* __restrict__ table,
+                                                               const int     F,
+                                                               const float   thr,
+                                                               const int     sign,
+                                                               int32_t* __restrict__ counts) {
+  using G                = Geo<S>;
+  constexpr int ROWBYTES = G::ROWBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char*     sA   = smem;
+  char*     sB   = smem + TM * ROWBYTES;
+  int*      pcA  = reinterpret_cast<int*>(smem + (TM + TN) * ROWBYTES);
+  int*      pcB  = pcA + TM;
+  uint16_t* sTab = reinterpret_cast<uint16_t*>(pcB + TN);
+
+  if (nXdev) nX = *nXdev;
+  if (nYdev) nY = *nYdev;
+  const int64_t rowA0  = static_cast<int64_t>(blockIdx.y) * TM;
+  const int64_t tilesN = (nY + TN - 1) / TN;
+  const int64_t jt0    = static_cast<int64_t>(blockIdx.x) * STRIP;
+  if (rowA0 >= nX || jt0 >= tilesN) {
+    return;
+  }
+  const int64_t jt1 = (jt0 + STRIP < tilesN) ? jt0 + STRIP : tilesN;
+
+  const int tid = threadIdx.x;
+  const int tx  = tid & 15;
+  const int ty  = tid >> 4;
+  const int ra  = ty * 8;
+
+  uint4 pre[G::PASSES];
+  tile_fetch<S>(pre, X, xRows, rowA0, nX, tid);
+  tile_commit<S>(pre, sA, pcA, rowA0, nX, 0, tid);
+  if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+    for (int k = tid; k <= 3 * F + 1; k += NT) {
+      sTab[k] = table[k];
+    }
+  }
+  tile_fetch<S>(pre, Y, yRows, jt0 * TN, nY, tid);
+
+  const unsigned preA0 = static_cast<unsigned>(ra * ROWBYTES) | (static_cast<unsigned>((ra >> 2) & G::SWZ) << 4);
+  const unsigned preA1 =
+    static_cast<unsigned>((ra + 4) * ROWBYTES) | (static_cast<unsigned>(((ra + 4) >> 2) & G::SWZ) << 4);
+  const unsigned preB = static_cast<unsigned>(tx * 4 * ROWBYTES) | (static_cast<unsigned>(tx & G::SWZ) << 4);
+
+  int rowcnt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rowcnt[i] = 0;
+  const int padPc = (METRIC == NVMK_METRIC_TANIMOTO) ? 2 * F + 1 : 0;
+
+  for (int64_t jt = jt0; jt < jt1; ++jt) {
+    __syncthreads();  // previous tile fully consumed (and, first time, sA / sTab visible after the next barrier)
+    tile_commit<S>(pre, sB, pcB, jt * TN, nY, padPc, tid);
+    __syncthreads();
+    if (jt + 1 < jt1) {
+      tile_fetch<S>(pre, Y, yRows, (jt + 1) * TN, nY, tid);  // in flight during the popcount loop
+    }
+
+    int acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+    }
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (int s = 0; s < S; ++s) {
+      // slot s of a row lives at (s & ~SWZ) | ((s ^ g(row)) & SWZ): XOR only touches the low bits
+      const unsigned sx  = static_cast<unsigned>(s) << 4;
+      const char*    pa0 = sA + (preA0 ^ sx);
+      const char*    pa1 = sA + (preA1 ^ sx);
+      const char*    pb  = sB + (preB ^ sx);
+      uint4          a[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i]     = *reinterpret_cast<const uint4*>(pa0 + i * ROWBYTES);
+        a[i + 4] = *reinterpret_cast<const uint4*>(pa1 + i * ROWBYTES);
+      }
+      uint4 bv = *reinterpret_cast<const uint4*>(pb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        uint4 bn = bv;
+        if (j < 7) {
+          bn = *reinterpret_cast<const uint4*>(pb + (((j + 1) & 3) + 64 * ((j + 1) >> 2)) * ROWBYTES);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          popc4(a[i], bv, acc[i][j]);
+        }
+        bv = bn;
+      }
+    }
+
+    // threshold the 8x8 counts
+    int pbv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pbv[j] = pcB[tx * 4 + (j & 3) + 64 * (j >> 2)];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int pav = pcA[ra + i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+          const int t = sTab[pav + pbv[j]];
+          rowcnt[i] += (acc[i][j] >= t) ? 1 : 0;
+        } else {
+          rowcnt[i] += is_neighbor<METRIC>(acc[i][j], pav, pbv[j], thr) ? 1 : 0;
+        }
+      }
+    }
+  }
+
+  // flush: reduce over the 16 lanes that share a row, one atomic per row per strip
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int v = rowcnt[i];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    const int64_t r = rowA0 + ra + i;
+    if (tx == 0 && r < nX && v != 0) {
+      const int64_t phys = xRows ? static_cast<int64_t>(xRows[r]) : r;
+      atomicAdd(&counts[phys], sign * v);
+    }
+  }
+}
+
+// Fallback for widths without an LDS-tiled instantiation: one wave per x row, lanes stride y rows.
+template <int METRIC>
+__global__ __launch_bounds__(NT) void neighbor_count_generic_kernel(const uint32_t* __restrict__ X,
+                                                                    const int32_t* __restrict__ xRows,
+                                                                    int64_t       nX,
+                                                                    const int32_t* __restrict__ nXdev,
+                                                                    const uint32_t* __restrict__ Y,
+                                                                    const int32_t* __restrict__ yRows,
+                                                                    int64_t       nY,
+                                                                    const int32_t* __restrict__ nYdev,
+                                                                    const int     W,
+                                                                    const float   thr,
+                                                                    const int     sign,
+                                                                    int32_t* __restrict__ counts) {
+  if (nXdev) nX = *nXdev;
+  if (nYdev) nY = *nYdev;
+  const int     lane = threadIdx.x & 63;
+  const int64_t r    = static_cast<int64_t>(blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
+  if (r >= nX) return;
+  const int64_t   px = xRows ? static_cast<int64_t>(xRows[r]) : r;
+  const uint32_t* x  = X + px * W;
+  int             pa = 0;
+  for (int k = 0; k < W; ++k) pa += __popc(x[k]);
+  int n = 0;
+  for (int64_t j = lane; j < nY; j += 64) {
+    const int64_t   py = yRows ? static_cast<int64_t>(yRows[j]) : j;
+    const uint32_t* y  = Y + py * W;
+    int             c = 0, pb = 0;
+    for (int k = 0; k < W; ++k) {
+      c += __popc(x[k] & y[k]);
+      pb += __popc(y[k]);
+    }
+    n += is_neighbor<METRIC>(c, pa, pb, thr) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+  if (lane == 0 && n != 0) atomicAdd(&counts[px], sign * n);
+}
+
+struct CountPlan {
+  int             metric;
+  int             fpBits;
+  float           thr;
+  const uint16_t* table;  // device, Tanimoto only
+};
+
+template <int METRIC>
+int launch_counts_t(const CountPlan& plan, const uint32_t* x, const int32_t* xRows, int64_t nX, const int32_t* nXdev,
+                    const uint32_t* y, const int32_t* yRows, int64_t nY, const int32_t* nYdev, int sign,
+                    int32_t* counts, hipStream_t stream) {
+  if (nX <= 0 || nY <= 0) return NVMK_OK;
+  const int  W       = plan.fpBits / 32;
+  const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+  const int  S       = W / 4;
+  const bool tiled   = aligned && (W % 4 == 0) && (S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32);
+  if (!tiled) {
+    const int64_t blocks = ceil_div<int64_t>(nX, NT / 64);
+    NVMK_REQUIRE(blocks <= 0x7fffffffLL, "neighbor counts: too many rows for the generic path");
+    hipLaunchKernelGGL(neighbor_count_generic_kernel<METRIC>, dim3(static_cast<unsigned>(blocks)), dim3(NT), 0, stream,
+                       x, xRows, nX, nXdev, y, yRows, nY, nYdev, W, plan.thr, sign, counts);
+    NVMK_LAUNCH_CHECK();
+    return NVMK_OK;
+  }
+  const int64_t tilesM = ceil_div<int64_t>(nX, TM);
+  const int64_t strips = ceil_div<int64_t>(ceil_div<int64_t>(nY, TN), STRIP);
+  NVMK_REQUIRE(tilesM <= 65535 && strips <= 0x7fffffffLL, "neighbor counts: too many rows for one launch (%lld)",
+               (long long)nX);
+  const dim3   grid(static_cast<unsigned>(strips), static_cast<unsigned>(tilesM));
+  const size_t tabBytes = (METRIC == NVMK_METRIC_TANIMOTO) ? (static_cast<size_t>(3 * plan.fpBits + 2) * 2 + 15) / 16 * 16 : 0;
+  const size_t shmem    = static_cast<size_t>(TM + TN) * S * 16 + (TM + TN) * 4 + tabBytes;
+  const auto*  x4       = reinterpret_cast<const uint4*>(x);
+  const auto*  y4       = reinterpret_cast<const uint4*>(y);
+#define NVMK_NC_LAUNCH(SS)                                                                                          \
+  hipLaunchKernelGGL((neighbor_count_kernel<SS, METRIC>), grid, dim3(NT), shmem, stream, x4, xRows, nX, nXdev, y4,  \
+                     yRows, nY, nYdev, plan.table, plan.fpBits, plan.thr, sign, counts)
+  switch (S) {
+    case 1: NVMK_NC_LAUNCH(1); break;
+    case 2: NVMK_NC_LAUNCH(2); break;
+    case 4: NVMK_NC_LAUNCH(4); break;
+    case 8: NVMK_NC_LAUNCH(8); break;
+    case 16: NVMK_NC_LAUNCH(16); break;
+    default: NVMK_NC_LAUNCH(32); break;
+  }
+#undef NVMK_NC_LAUNCH
+  NVMK_LAUNCH_CHECK();
+  return NVMK_OK;
+}
+
+int launch_counts(const CountPlan& plan, const uint32_t* x, const int32_t* xRows, int64_t nX, const int32_t* nXdev,
+                  const uint32_t* y, const int32_t* yRows, int64_t nY, const int32_t* nYdev, int sign, int32_t* counts,
+                  hipStream_t stream) {
+  return plan.metric == NVMK_METRIC_TANIMOTO ?
+           launch_counts_t<NVMK_METRIC_TANIMOTO>(plan, x, xRows, nX, nXdev, y, yRows, nY, nYdev, sign, counts, stream) :
+           launch_counts_t<NVMK_METRIC_COSINE>(plan, x, xRows, nX, nXdev, y, yRows, nY, nYdev, sign, counts, stream);
+}
+
+int make_plan(CountPlan& plan, StreamScratch& tableMem, int metric, int fpBits, float thr, hipStream_t stream) {
+  NVMK_REQUIRE(metric == NVMK_METRIC_TANIMOTO || metric == NVMK_METRIC_COSINE, "unknown metric %d", metric);
+  NVMK_REQUIRE(fpBits > 0 && fpBits % 32 == 0, "fp_bits must be a positive multiple of 32, got %d", fpBits);
+  NVMK_REQUIRE(fpBits <= 16384, "fp_bits > 16384 is not supported by the neighbour kernels (got %d)", fpBits);
+  plan.metric = metric;
+  plan.fpBits = fpBits;
+  plan.thr    = thr;
+  plan.table  = nullptr;
+  if (metric == NVMK_METRIC_TANIMOTO) {
+    const int entries = 3 * fpBits + 2;
+    NVMK_HIP_CHECK(tableMem.alloc(static_cast<size_t>(entries) * sizeof(uint16_t), stream));
+    hipLaunchKernelGGL(build_tanimoto_table_kernel, dim3(ceil_div(entries, 256)), dim3(256), 0, stream,
+                       tableMem.as<uint16_t>(), fpBits, thr);
+    NVMK_LAUNCH_CHECK();
+    plan.table = tableMem.as<uint16_t>();
+  }
+  return NVMK_OK;
+}
+
+// ===================== fused Butina: device-resident round loop ================================
+
+// Device-side loop state (one struct in global memory, zeroed before use).
+struct LoopState {
+  unsigned long long bestKey[2];  // ((u64)count << 32) | row, ping-pong by round parity
+  int32_t            nAlive;      // live rows in the current alive list
+  int32_t            nRemoved;    // members of the cluster extracted this round (size of `removed`)
+  int32_t            front;       // next free slot at the front of clusterIndices (greedy clusters)
+  int32_t            back;        // next free slot at the back (harvested singletons), counts down
+  int32_t            nClusters;   // greedy clusters written so far
+  int32_t            done;        // set when the max degree reaches 0 or nothing is alive
+  int32_t            lastMax;     // degree of the most recent centroid (upper bound for later rounds)
+  int32_t            finalParity; // which alive list holds the degree-0 leftovers when done
+};
+
+__global__ void init_state_kernel(LoopState* __restrict__ st, const int32_t n) {
+  st->bestKey[0]  = 0ull;
+  st->bestKey[1]  = 0ull;
+  st->nAlive      = n;
+  st->nRemoved    = 0;
+  st->front       = 0;
+  st->back        = n - 1;
+  st->nClusters   = 0;
+  st->done        = 0;
+  st->lastMax     = n;
+  st->finalParity = 0;
+}
+
+__global__ void iota_kernel(int32_t* __restrict__ rows, const int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) rows[i] = static_cast<int32_t>(i);
+}
+
+// argmax over the alive list with ties toward the HIGHEST row (clustering.py:159).
+// Also resets the other parity's key for the next round.
+__global__ __launch_bounds__(NT) void argmax_kernel(LoopState* __restrict__ st, const int32_t* __restrict__ alive,
+                                                    const int32_t* __restrict__ counts, const int parity) {
+  if (st->done) return;
+  const int n = st->nAlive;
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->bestKey[parity ^ 1] = 0ull;
+  unsigned long long best = 0ull;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NT + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * NT) {
+    const int32_t r = alive[i];
+    const int32_t c = counts[r];
+    if (c > 0) {
+      const unsigned long long key = (static_cast<unsigned long long>(c) << 32) | static_cast<unsigned>(r);
+      best                         = key > best ? key : best;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(best, o);
+    best                           = other > best ? other : best;
+  }
+  __shared__ unsigned long long wbest[NT / 64];
+  if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < NT / 64; ++w) best = wbest[w] > best ? wbest[w] : best;
+    if (best != 0ull) atomicMax(&st->bestKey[parity], best);
+  }
+}
+
+// One round of extraction (nvmolkit/_fusedButina.py:182-246) fused with alive-list compaction:
+//   neighbours of the centroid -> cluster (front of clusterIndices) and the `removed` list;
+//   other rows with degree 1   -> singleton tail (back of clusterIndices);
+//   everything else            -> next alive list.
+// 16 lanes cooperate on one row (16 B each for 2048-bit fingerprints, looping for wider ones).
+template <int METRIC>
+__global__ __launch_bounds__(NT) void extract_kernel(LoopState* __restrict__ st, const uint4* __restrict__ X, const int W4,
+                                                     const int32_t* __restrict__ aliveIn, int32_t* __restrict__ aliveOut,
+                                                     int32_t* __restrict__ nAliveOut, int32_t* __restrict__ removed,
+                                                     const int32_t* __restrict__ counts,
+                                                     int32_t* __restrict__ clusterIndices, const float thr,
+                                                     const int parity) {
+  if (st->done) return;
+  const unsigned long long key = st->bestKey[parity];
+  if (key == 0ull) return;  // handled by finish_round_kernel
+  const int     centroid = static_cast<int>(key & 0xffffffffull);
+  const int     n        = st->nAlive;
+  const int     sub      = threadIdx.x & 15;
+  const int64_t slotRow  = (static_cast<int64_t>(blockIdx.x) * NT + threadIdx.x) >> 4;
+  const int64_t stride   = (static_cast<int64_t>(gridDim.x) * NT) >> 4;
+  for (int64_t i0 = 0; i0 < n; i0 += stride) {
+    const int64_t i     = i0 + slotRow;
+    const bool    valid = i < n;
+    const int32_t r     = valid ? aliveIn[i] : centroid;
+    int           c = 0, pa = 0, pb = 0;
+    for (int k = sub; k < W4; k += 16) {
+      const uint4 cv = X[static_cast<int64_t>(centroid) * W4 + k];
+      const uint4 rv = X[static_cast<int64_t>(r) * W4 + k];
+      pa += popc_u4(cv);
+      pb += popc_u4(rv);
+      c += __popc(cv.x & rv.x) + __popc(cv.y & rv.y) + __popc(cv.z & rv.z) + __popc(cv.w & rv.w);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      c += __shfl_xor(c, o);
+      pa += __shfl_xor(pa, o);
+      pb += __shfl_xor(pb, o);
+    }
+    if (valid && sub == 0) {
+      const bool nb = (r == centroid) || is_neighbor<METRIC>(c, pa, pb, thr);
+      if (nb) {
+        const int slot              = atomicAdd(&st->front, 1);
+        clusterIndices[slot]        = r;
+        removed[atomicAdd(&st->nRemoved, 1)] = r;
+      } else if (counts[r] == 1) {
+        const int slot       = atomicSub(&st->back, 1);
+        clusterIndices[slot] = r;
+      } else {
+        aliveOut[atomicAdd(nAliveOut, 1)] = r;
+      }
+    }
+  }
+}
+
+// Bookkeeping between extract and subtract (single thread): record the cluster, roll the alive
+// count, detect termination.
+__global__ void finish_round_kernel(LoopState* __restrict__ st, int32_t* __restrict__ nAliveNext,
+                                    int32_t* __restrict__ offsets, int32_t* __restrict__ centroids, const int parity) {
+  if (st->done) return;
+  const unsigned long long key = st->bestKey[parity];
+  if (key == 0ull) {  // max degree 0 (or nothing alive): stop; leftovers sit in this round's INPUT list
+    st->done        = 1;
+    st->finalParity = parity;
+    return;
+  }
+  st->lastMax       = static_cast<int32_t>(key >> 32);
+  const int k       = st->nClusters;
+  centroids[k]      = static_cast<int32_t>(key & 0xffffffffull);
+  offsets[k + 1]    = st->front;
+  st->nClusters     = k + 1;
+  st->nAlive        = *nAliveNext;
+  if (st->nAlive == 0) {
+    st->done        = 1;
+    st->finalParity = parity ^ 1;
+  }
+}
+
+// After subtract: reset the per-round counters for the next round.
+__global__ void reset_round_kernel(LoopState* __restrict__ st, int32_t* __restrict__ nAliveNextOfNextRound) {
+  st->nRemoved             = 0;
+  *nAliveNextOfNextRound   = 0;
+}
+
+template <int METRIC>
+int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_t* h_idx, int64_t* h_offsets,
+               int32_t* h_centroids, int64_t* n_clusters, hipStream_t stream) {
+  const int   W   = fpBits / 32;
+  const float thr = static_cast<float>(1.0 - cutoff);  // clustering.py:149
+  NVMK_REQUIRE(N <= 0x7fffffffLL, "fused butina: N too large (%lld)", (long long)N);
+  NVMK_REQUIRE(W % 4 == 0 && reinterpret_cast<uintptr_t>(d_x) % 16 == 0,
+               "fused butina: fp_bits must be a multiple of 128 and the matrix 16-byte aligned");
+
+  StreamScratch tableMem, mem;
+  CountPlan     plan;
+  int           rc = make_plan(plan, tableMem, METRIC, fpBits, thr, stream);
+  if (rc != NVMK_OK) return rc;
+
+  // one scratch block: state | nAliveNext[2] | counts | alive[2] | removed | clusterIndices | offsets | centroids
+  const size_t n      = static_cast<size_t>(N);
+  const size_t ints   = 64 + n * 7 + 8;
+  NVMK_HIP_CHECK(mem.alloc(ints * sizeof(int32_t), stream));
+  auto*    base       = mem.as<int32_t>();
+  auto*    st         = reinterpret_cast<LoopState*>(base);
+  int32_t* nAliveNext = base + 32;  // [2]
+  int32_t* counts     = base + 64;
+  int32_t* alive0     = counts + n;
+  int32_t* alive1     = alive0 + n;
+  int32_t* removed    = alive1 + n;
+  int32_t* clusterIdx = removed + n;
+  int32_t* offsets    = clusterIdx + n;  // n + 1 entries
+  int32_t* centroids  = offsets + n + 1;
+  NVMK_HIP_CHECK(hipMemsetAsync(base, 0, (64 + n) * sizeof(int32_t), stream));  // state + nAliveNext + counts
+  NVMK_HIP_CHECK(hipMemsetAsync(offsets, 0, sizeof(int32_t), stream));
+  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, st, static_cast<int32_t>(N));
+  hipLaunchKernelGGL(iota_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream, alive0,
+                     N);
+  NVMK_LAUNCH_CHECK();
+
+  // first pass: all-vs-all degrees
+  rc = launch_counts(plan, d_x, nullptr, N, nullptr, d_x, nullptr, N, nullptr, +1, counts, stream);
+  if (rc != NVMK_OK) return rc;
+
+  // round loop, enqueued in batches; the host only reads the state word between batches
+  const auto* x4        = reinterpret_cast<const uint4*>(d_x);
+  int64_t     aliveHost = N;  // upper bound on the device-side nAlive
+  int64_t     maxDegree = N;  // upper bound on any later cluster size (degrees only decrease)
+  int64_t     round     = 0;
+  LoopState   snap{};
+  int         batch = 1;      // first sync after one round: learns the real max degree
+  for (;;) {
+    for (int b = 0; b < batch; ++b, ++round) {
+      const int      parity   = static_cast<int>(round & 1);
+      const int32_t* aliveIn  = parity ? alive1 : alive0;
+      int32_t*       aliveOut = parity ? alive0 : alive1;
+      const unsigned rowBlocks =
+        static_cast<unsigned>(std::min<int64_t>(ceil_div<int64_t>(aliveHost, NT), 4096));
+      const unsigned exBlocks =
+        static_cast<unsigned>(std::min<int64_t>(ceil_div<int64_t>(aliveHost * 16, NT), 16384));
+      hipLaunchKernelGGL(argmax_kernel, dim3(rowBlocks), dim3(NT), 0, stream, st, aliveIn, counts, parity);
+      hipLaunchKernelGGL((extract_kernel<METRIC>), dim3(exBlocks), dim3(NT), 0, stream, st, x4, W / 4, aliveIn,
+                         aliveOut, &nAliveNext[parity], removed, counts, clusterIdx, thr, parity);
+      hipLaunchKernelGGL(finish_round_kernel, dim3(1), dim3(1), 0, stream, st, &nAliveNext[parity], offsets, centroids,
+                         parity);
+      // subtract the removed members' contribution from the survivors (device-side sizes)
+      rc = launch_counts(plan, d_x, aliveOut, aliveHost, &st->nAlive, d_x, removed, maxDegree, &st->nRemoved, -1,
+                         counts, stream);
+      if (rc != NVMK_OK) return rc;
+      hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, stream, st, &nAliveNext[parity ^ 1]);
+      NVMK_LAUNCH_CHECK();
+    }
+    NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    if (snap.done) break;
+    aliveHost = snap.nAlive;
+    maxDegree = std::max<int64_t>(1, snap.lastMax);
+    batch     = 32;
+  }
+
+  // ---- read back and canonicalise on the host (member order from atomics is unspecified) ----
+  const int64_t nGreedy = snap.nClusters;
+  std::vector<int32_t> idx(n), offs(static_cast<size_t>(nGreedy) + 1), cent(static_cast<size_t>(nGreedy));
+  NVMK_HIP_CHECK(hipMemcpyAsync(idx.data(), clusterIdx, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  NVMK_HIP_CHECK(hipMemcpyAsync(offs.data(), offsets, offs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  if (nGreedy > 0) {
+    NVMK_HIP_CHECK(hipMemcpyAsync(cent.data(), centroids, cent.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  }
+  // rows still alive when the loop stopped have degree 0 (all-zero fingerprints)
+  const int32_t* aliveFinal = snap.finalParity ? alive1 : alive0;
+  std::vector<int32_t> leftovers(static_cast<size_t>(snap.nAlive));
+  if (snap.nAlive > 0) {
+    NVMK_HIP_CHECK(hipMemcpyAsync(leftovers.data(), aliveFinal, leftovers.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                  stream));
+  }
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+
+  int64_t pos = 0;
+  h_offsets[0] = 0;
+  for (int64_t k = 0; k < nGreedy; ++k) {
+    const int32_t c    = cent[static_cast<size_t>(k)];
+    int32_t*      dst  = h_idx + pos;
+    int64_t       m    = 0;
+    dst[m++]           = c;
+    for (int32_t q = offs[static_cast<size_t>(k)]; q < offs[static_cast<size_t>(k) + 1]; ++q) {
+      if (idx[static_cast<size_t>(q)] != c) dst[m++] = idx[static_cast<size_t>(q)];
+    }
+    std::sort(dst + 1, dst + m);
+    h_centroids[k] = c;
+    pos += m;
+    h_offsets[k + 1] = pos;
+  }
+  std::vector<int32_t> singles(idx.begin() + (snap.back + 1), idx.end());
+  singles.insert(singles.end(), leftovers.begin(), leftovers.end());
+  std::sort(singles.begin(), singles.end());
+  int64_t k = nGreedy;
+  for (const int32_t s : singles) {
+    h_idx[pos++]   = s;
+    h_centroids[k] = s;
+    h_offsets[++k] = pos;
+  }
+  if (pos != N) {
+    set_last_error("fused butina: internal accounting error (%lld of %lld rows assigned)", (long long)pos, (long long)N);
+    return NVMK_ERR_INTERNAL;
+  }
+  *n_clusters = k;
+  return NVMK_OK;
+}
+
+// ===================== dense-matrix Butina =====================================================
+
+// hit = dist <= cutoff (src/butina.cu:1043-1051), written row-major AND transposed so that both
+// "row of i" and "column of i" are contiguous (the matrix need not be symmetric).
+__global__ __launch_bounds__(NT) void threshold_transpose_kernel(const double* __restrict__ dist,
+                                                                 const uint8_t* __restrict__ hitIn,
+                                                                 uint8_t* __restrict__ hit, uint8_t* __restrict__ hitT,
+                                                                 const int64_t N, const double cutoff) {
+  __shared__ uint8_t tile[64][65];
+  const int64_t      r0 = static_cast<int64_t>(blockIdx.y) * 64;
+  const int64_t      c0 = static_cast<int64_t>(blockIdx.x) * 64;
+  const int          tx = threadIdx.x & 63;
+  const int          ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += NT / 64) {
+    const int64_t r = r0 + rr, c = c0 + tx;
+    uint8_t       h = 0;
+    if (r < N && c < N) {
+      h              = dist ? static_cast<uint8_t>(dist[r * N + c] <= cutoff) : static_cast<uint8_t>(hitIn[r * N + c] != 0);
+      hit[r * N + c] = h;
+    }
+    tile[rr][tx] = h;
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += NT / 64) {
+    const int64_t c = c0 + cc, r = r0 + tx;
+    if (r < N && c < N) hitT[c * N + r] = tile[tx][cc];
+  }
+}
+
+// counts[i] = #{j : hit[i][j]} (all points unassigned at the start), one wave per row.
+__global__ __launch_bounds__(NT) void dense_degree_kernel(const uint8_t* __restrict__ hit, const int64_t N,
+                                                          int32_t* __restrict__ counts) {
+  const int64_t r    = static_cast<int64_t>(blockIdx.x) * (NT / 64) + (threadIdx.x >> 6);
+  const int     lane = threadIdx.x & 63;
+  if (r >= N) return;
+  int n = 0;
+  for (int64_t j = lane; j < N; j += 64) n += hit[r * N + j] ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+  if (lane == 0) counts[r] = n;
+}
+
+struct DenseState {
+  unsigned long long bestKey[2];
+  int32_t            nClusters;
+  int32_t            nMembers;
+  int32_t            done;
+  int32_t            pad;
+};
+
+// argmax over unassigned points with ties toward the highest index (lastArgMaxKernel, src/butina.cu:464-481).
+__global__ __launch_bounds__(NT) void dense_argmax_kernel(DenseState* __restrict__ st, const int32_t* __restrict__ counts,
+                                                          const int32_t* __restrict__ clusters, const int64_t N,
+                                                          const int parity) {
+  if (st->done) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->bestKey[parity ^ 1] = 0ull;
+  unsigned long long best = 0ull;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NT + threadIdx.x; i < N; i += static_cast<int64_t>(gridDim.x) * NT) {
+    if (clusters[i] < 0) {
+      const unsigned long long key =
+        (static_cast<unsigned long long>(static_cast<unsigned>(counts[i])) << 32) | static_cast<unsigned>(i);
+      best = key > best ? key : best;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(best, o);
+    best                           = other > best ? other : best;
+  }
+  __shared__ unsigned long long wbest[NT / 64];
+  if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < NT / 64; ++w) best = wbest[w] > best ? wbest[w] : best;
+    if (best != 0ull) atomicMax(&st->bestKey[parity], best);
+  }
+}
+
+// Assign the centroid's unassigned neighbours (src/butina.cu:241-269) and list them in `members`.
+__global__ __launch_bounds__(NT) void dense_assign_kernel(DenseState* __restrict__ st, const uint8_t* __restrict__ hit,
+                                                          int32_t* __restrict__ clusters, int32_t* __restrict__ members,
+                                                          int32_t* __restrict__ centroids, const int64_t N,
+                                                          const int parity) {
+  if (st->done) return;
+  const unsigned long long key = st->bestKey[parity];
+  const int                sz  = static_cast<int>(key >> 32);
+  if (sz < 2) return;  // kMinLoopSizeForAssignment (src/butina.cu:34); dense_finish marks done
+  const int64_t c   = static_cast<int64_t>(key & 0xffffffffull);
+  const int     cid = st->nClusters;
+  const int64_t i   = static_cast<int64_t>(blockIdx.x) * NT + threadIdx.x;
+  if (i < N && clusters[i] < 0 && (hit[c * N + i] || i == c)) {
+    clusters[i]                           = cid;
+    members[atomicAdd(&st->nMembers, 1)] = static_cast<int32_t>(i);
+  }
+  if (i == 0) centroids[cid] = static_cast<int32_t>(c);
+}
+
+// counts[i] -= #{m in members : hit[i][m]} for unassigned i, using the transposed matrix so that a
+// member's column is contiguous.  grid.y strides the members.
+__global__ __launch_bounds__(NT) void dense_subtract_kernel(const DenseState* __restrict__ st,
+                                                            const uint8_t* __restrict__ hitT,
+                                                            const int32_t* __restrict__ clusters,
+                                                            const int32_t* __restrict__ members,
+                                                            int32_t* __restrict__ counts, const int64_t N,
+                                                            const int parity) {
+  if (st->done) return;
+  if (static_cast<int>(st->bestKey[parity] >> 32) < 2) return;
+  const int     nM = st->nMembers;
+  const int64_t i  = static_cast<int64_t>(blockIdx.x) * NT + threadIdx.x;
+  if (i >= N || clusters[i] >= 0) return;
+  int dec = 0;
+  for (int m = blockIdx.y; m < nM; m += gridDim.y) {
+    dec += hitT[static_cast<int64_t>(members[m]) * N + i] ? 1 : 0;
+  }
+  if (dec) atomicSub(&counts[i], dec);
+}
+
+__global__ void dense_finish_kernel(DenseState* __restrict__ st, const int parity) {
+  if (st->done) return;
+  if (static_cast<int>(st->bestKey[parity] >> 32) < 2) {
+    st->done = 1;
+    return;
+  }
+  st->nClusters += 1;
+  st->nMembers = 0;
+}
+
+}  // namespace butina
+}  // namespace nvmk
+
+using namespace nvmk;
+using namespace nvmk::butina;
+
+extern "C" {
+
+int nvmk_neighbor_counts(int metric, const uint32_t* d_x, const int32_t* d_x_rows, int64_t nX, const uint32_t* d_y,
+                         const int32_t* d_y_rows, int64_t nY, int fp_bits, float threshold, int sign,
+                         int32_t* d_counts, void* stream) {
+  NVMK_REQUIRE(sign == 1 || sign == -1, "neighbor counts: sign must be +1 or -1, got %d", sign);
+  NVMK_REQUIRE(nX >= 0 && nY >= 0, "neighbor counts: negative row count");
+  if (nX == 0 || nY == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_x && d_y && d_counts, "neighbor counts: NULL buffer");
+  StreamScratch tableMem;
+  CountPlan     plan;
+  const int     rc = make_plan(plan, tableMem, metric, fp_bits, threshold, as_stream(stream));
+  if (rc != NVMK_OK) return rc;
+  return launch_counts(plan, d_x, d_x_rows, nX, nullptr, d_y, d_y_rows, nY, nullptr, sign, d_counts, as_stream(stream));
+}
+
+int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, double cutoff,
+                      int32_t* h_cluster_indices, int64_t* h_offsets, int32_t* h_centroids, int64_t* n_clusters,
+                      void* stream) {
+  NVMK_REQUIRE(metric == NVMK_METRIC_TANIMOTO || metric == NVMK_METRIC_COSINE, "unknown metric %d", metric);
+  NVMK_REQUIRE(cutoff >= 0.0 && cutoff <= 1.0, "cutoff must be in [0, 1], got %g", cutoff);
+  NVMK_REQUIRE(fp_bits > 0 && fp_bits % 32 == 0, "fp_bits must be a positive multiple of 32, got %d", fp_bits);
+  NVMK_REQUIRE(N >= 0, "negative N");
+  NVMK_REQUIRE(h_offsets && n_clusters, "NULL output");
+  h_offsets[0] = 0;
+  *n_clusters  = 0;
+  if (N == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_x && h_cluster_indices && h_centroids, "NULL buffer");
+  return metric == NVMK_METRIC_TANIMOTO ?
+           fused_impl<NVMK_METRIC_TANIMOTO>(d_x, N, fp_bits, cutoff, h_cluster_indices, h_offsets, h_centroids,
+                                            n_clusters, as_stream(stream)) :
+           fused_impl<NVMK_METRIC_COSINE>(d_x, N, fp_bits, cutoff, h_cluster_indices, h_offsets, h_centroids,
+                                          n_clusters, as_stream(stream));
+}
+
+int nvmk_butina_dense(const double* d_dist, const uint8_t* d_hit, int64_t N, double cutoff, int neighborlist_max_size,
+                      int32_t* d_clusters, int32_t* d_centroids, int64_t* h_n_clusters, void* stream_) {
+  // neighborlist_max_size only tunes the reference's small-cluster phase (src/butina.cu:975-1004); it is
+  // validated for API compatibility (nvmolkit/clustering.py:79-82) and otherwise unused here.
+  const int nl = neighborlist_max_size;
+  NVMK_REQUIRE(nl == 8 || nl == 16 || nl == 24 || nl == 32 || nl == 64 || nl == 128,
+               "neighborlistMaxSize must be 8, 16, 24, 32, 64, or 128. Got: %d", nl);
+  NVMK_REQUIRE(N >= 0 && N <= 0x7fffffffLL, "butina: bad N %lld", (long long)N);
+  if (h_n_clusters) *h_n_clusters = 0;
+  if (N == 0) return NVMK_OK;
+  NVMK_REQUIRE((d_dist != nullptr) != (d_hit != nullptr), "butina: pass exactly one of d_dist / d_hit");
+  NVMK_REQUIRE(d_clusters != nullptr, "butina: d_clusters is NULL");
+  hipStream_t  stream = as_stream(stream_);
+  const size_t n      = static_cast<size_t>(N);
+
+  StreamScratch matMem, mem;
+  NVMK_HIP_CHECK(matMem.alloc(2 * n * n, stream));
+  uint8_t* hit  = matMem.as<uint8_t>();
+  uint8_t* hitT = hit + n * n;
+  NVMK_HIP_CHECK(mem.alloc((16 + 3 * n) * sizeof(int32_t), stream));
+  auto*    st        = mem.as<DenseState>();
+  int32_t* counts    = mem.as<int32_t>() + 16;
+  int32_t* members   = counts + n;
+  int32_t* centroids = members + n;
+  NVMK_HIP_CHECK(hipMemsetAsync(st, 0, 16 * sizeof(int32_t), stream));
+  NVMK_HIP_CHECK(hipMemsetAsync(d_clusters, 0xff, n * sizeof(int32_t), stream));  // -1
+
+  const unsigned t64 = static_cast<unsigned>(ceil_div<int64_t>(N, 64));
+  NVMK_REQUIRE(t64 <= 65535, "butina: N too large for the dense path (%lld)", (long long)N);
+  hipLaunchKernelGGL(threshold_transpose_kernel, dim3(t64, t64), dim3(NT), 0, stream, d_dist, d_hit, hit, hitT, N, cutoff);
+  hipLaunchKernelGGL(dense_degree_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, NT / 64))), dim3(NT), 0, stream,
+                     hit, N, counts);
+  NVMK_LAUNCH_CHECK();
+
+  const unsigned nb = static_cast<unsigned>(ceil_div<int64_t>(N, NT));
+  const unsigned ab = std::min(nb, 1024u);
+  DenseState     snap{};
+  int64_t        round = 0;
+  for (;;) {
+    for (int b = 0; b < 32; ++b, ++round) {
+      const int parity = static_cast<int>(round & 1);
+      hipLaunchKernelGGL(dense_argmax_kernel, dim3(ab), dim3(NT), 0, stream, st, counts, d_clusters, N, parity);
+      hipLaunchKernelGGL(dense_assign_kernel, dim3(nb), dim3(NT), 0, stream, st, hit, d_clusters, members, centroids, N,
+                         parity);
+      hipLaunchKernelGGL(dense_subtract_kernel, dim3(nb, 16), dim3(NT), 0, stream, st, hitT, d_clusters, members, counts,
+                         N, parity);
+      hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(1), 0, stream, st, parity);
+    }
+    NVMK_LAUNCH_CHECK();
+    NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    if (snap.done) break;
+  }
+
+  // singletons (ascending index) + renumber by descending size, stable by original id
+  // (assignSingletonIdsKernel src/butina.cu:281-307, renumberClustersBySize :369-448) — O(N) on the host.
+  std::vector<int32_t> cl(n), cent(n);
+  NVMK_HIP_CHECK(hipMemcpyAsync(cl.data(), d_clusters, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  NVMK_HIP_CHECK(hipMemcpyAsync(cent.data(), centroids, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+  int64_t nC = snap.nClusters;
+  for (size_t i = 0; i < n; ++i) {
+    if (cl[i] < 0) {
+      cl[i]                          = static_cast<int32_t>(nC);
+      cent[static_cast<size_t>(nC++)] = static_cast<int32_t>(i);
+    }
+  }
+  std::vector<int64_t> sizes(static_cast<size_t>(nC), 0);
+  for (size_t i = 0; i < n; ++i) sizes[static_cast<size_t>(cl[i])]++;
+  std::vector<int32_t> order(static_cast<size_t>(nC));
+  for (int64_t c = 0; c < nC; ++c) order[static_cast<size_t>(c)] = static_cast<int32_t>(c);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int32_t a, int32_t b) { return sizes[static_cast<size_t>(a)] > sizes[static_cast<size_t>(b)]; });
+  std::vector<int32_t> remap(static_cast<size_t>(nC)), newCent(static_cast<size_t>(nC));
+  for (int64_t newId = 0; newId < nC; ++newId) {
+    remap[static_cast<size_t>(order[static_cast<size_t>(newId)])] = static_cast<int32_t>(newId);
+    newCent[static_cast<size_t>(newId)]                           = cent[static_cast<size_t>(order[static_cast<size_t>(newId)])];
+  }
+  for (size_t i = 0; i < n; ++i) cl[i] = remap[static_cast<size_t>(cl[i])];
+  NVMK_HIP_CHECK(hipMemcpyAsync(d_clusters, cl.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  if (d_centroids) {
+    NVMK_HIP_CHECK(hipMemcpyAsync(d_centroids, newCent.data(), static_cast<size_t>(nC) * sizeof(int32_t),
+                                  hipMemcpyHostToDevice, stream));
+  }
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors die at return
+  if (h_n_clusters) *h_n_clusters = nC;
+  return NVMK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// Shared host-side helpers for libnvmolkit_amd.so: thread-local error slot, HIP error
+// checks that return ABI error codes instead of throwing, small RAII wrappers.
+// Counterpart of the reference's src/utils/cuda_error_check.h and src/utils/device.h,
+// redesigned around a C ABI (no exceptions cross the boundary).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/nvmolkit_amd.h"
+
+namespace nvmk {
+
+void set_last_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void clear_last_error();
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename T> inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
+
+// Device scratch that is allocated and released in stream order.
+struct StreamScratch {
+  void*       ptr    = nullptr;
+  hipStream_t stream = nullptr;
+  StreamScratch()    = default;
+  StreamScratch(const StreamScratch&)            = delete;
+  StreamScratch& operator=(const StreamScratch&) = delete;
+  hipError_t     alloc(size_t bytes, hipStream_t s) {
+    stream = s;
+    return hipMallocAsync(&ptr, bytes > 0 ? bytes : 1, s);
+  }
+  ~StreamScratch() {
+    if (ptr != nullptr) {
+      (void)hipFreeAsync(ptr, stream);
+    }
+  }
+  template <typename T> T* as() const { return static_cast<T*>(ptr); }
+};
+
+}  // namespace nvmk
+
+#define NVMK_HIP_CHECK(expr)                                                                              \
+  do {                                                                                                    \
+    hipError_t nvmk_e_ = (expr);                                                                          \
+    if (nvmk_e_ != hipSuccess) {                                                                          \
+      ::nvmk::set_last_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(nvmk_e_), __FILE__, __LINE__); \
+      return (nvmk_e_ == hipErrorOutOfMemory) ? NVMK_ERR_OUT_OF_MEMORY : NVMK_ERR_HIP;                     \
+    }                                                                                                     \
+  } while (0)
+
+#define NVMK_REQUIRE(cond, ...)               \
+  do {                                        \
+    if (!(cond)) {                            \
+      ::nvmk::set_last_error(__VA_ARGS__);    \
+      return NVMK_ERR_INVALID_ARGUMENT;       \
+    }                                         \
+  } while (0)
+
+#define NVMK_LAUNCH_CHECK() NVMK_HIP_CHECK(hipGetLastError())

@@ -1,0 +1,191 @@
+"""CPU oracle for the nvMolKit hot path — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package; the product (``nvmolkit_amd``) never does.  The arithmetic lives in the C files next
+to this module (each function cites the reference lines it restates); this module is the ctypes
+loader plus numpy-friendly wrappers.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+_LIB_PATH = _DIR / "liboracle.so"
+
+TANIMOTO = 0
+COSINE = 1
+
+
+def _host_stamp() -> str:
+    """The library is built with -march=native, so it is rebuilt when the host CPU changes
+    (the build container and the GPU box have different CPUs)."""
+    try:
+        txt = Path("/proc/cpuinfo").read_text()
+        keep = [ln for ln in txt.splitlines() if ln.startswith(("model name", "flags"))][:2]
+        return hashlib.sha256("\n".join(keep).encode()).hexdigest()
+    except OSError:
+        return "unknown"
+
+
+def build(force: bool = False) -> Path:
+    """Compile oracle/*.c with gcc (a few seconds)."""
+    srcs = sorted(_DIR.glob("oracle_*.c"))
+    stamp = _DIR / "liboracle.stamp"
+    want = _host_stamp()
+    stale = (force or not _LIB_PATH.exists() or not stamp.exists() or stamp.read_text() != want or
+             any(s.stat().st_mtime > _LIB_PATH.stat().st_mtime for s in srcs))
+    if stale:
+        subprocess.run(["make", "-C", str(_DIR), "-B", "liboracle.so"], check=True, capture_output=True)
+        stamp.write_text(want)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(str(_LIB_PATH))
+        _declare(_lib)
+    return _lib
+
+
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def _declare(L: ctypes.CDLL) -> None:
+    L.orc_num_threads.restype = ctypes.c_int
+    L.orc_cross_similarity_f64.argtypes = [ctypes.c_int, _u32p, ctypes.c_int64, _u32p, ctypes.c_int64, ctypes.c_int,
+                                           _f64p, ctypes.c_int64, ctypes.c_int]
+    L.orc_cross_similarity_f64.restype = None
+    L.orc_cross_intersection_i32.argtypes = [_u32p, ctypes.c_int64, _u32p, ctypes.c_int64, ctypes.c_int, _i32p]
+    L.orc_cross_intersection_i32.restype = None
+    L.orc_neighbor_counts.argtypes = [ctypes.c_int, _u32p, ctypes.c_int64, _u32p, ctypes.c_int64, ctypes.c_int,
+                                      ctypes.c_float, ctypes.c_int, _i32p]
+    L.orc_neighbor_counts.restype = None
+    L.orc_butina_fused.argtypes = [ctypes.c_int, _u32p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, _i32p, _i64p,
+                                   _i32p]
+    L.orc_butina_fused.restype = ctypes.c_int64
+    L.orc_butina_dense.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, _i32p,
+                                   ctypes.c_void_p]
+    L.orc_butina_dense.restype = ctypes.c_int64
+
+
+def _as_u32(x) -> np.ndarray:
+    a = np.ascontiguousarray(x)
+    if a.dtype == np.int32:
+        a = a.view(np.uint32)
+    if a.dtype != np.uint32:
+        raise TypeError(f"fingerprints must be uint32/int32 words, got {a.dtype}")
+    if a.ndim != 2:
+        raise ValueError("fingerprints must be 2-D (n, words)")
+    return a
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())
+
+
+def cross_similarity(a, b=None, metric: int = TANIMOTO, threads: int = 0) -> np.ndarray:
+    """N x M float64 similarity matrix (reference: src/similarity_kernels.cu:350-364)."""
+    a = _as_u32(a)
+    b = a if b is None else _as_u32(b)
+    if a.shape[1] != b.shape[1]:
+        raise ValueError("fingerprint width mismatch")
+    out = np.empty((a.shape[0], b.shape[0]), dtype=np.float64)
+    lib().orc_cross_similarity_f64(metric, a, a.shape[0], b, b.shape[0], a.shape[1], out, b.shape[0], threads)
+    return out
+
+
+def cross_intersection(a, b=None) -> np.ndarray:
+    a = _as_u32(a)
+    b = a if b is None else _as_u32(b)
+    out = np.empty((a.shape[0], b.shape[0]), dtype=np.int32)
+    lib().orc_cross_intersection_i32(a, a.shape[0], b, b.shape[0], a.shape[1], out)
+    return out
+
+
+def neighbor_counts(x, y, threshold: float, sign: int = 1, metric: int = TANIMOTO, counts=None) -> np.ndarray:
+    x = _as_u32(x)
+    y = _as_u32(y)
+    if counts is None:
+        counts = np.zeros(x.shape[0], dtype=np.int32)
+    lib().orc_neighbor_counts(metric, x, x.shape[0], y, y.shape[0], x.shape[1], np.float32(threshold), sign, counts)
+    return counts
+
+
+def butina_fused(x, cutoff: float, metric: int = TANIMOTO):
+    """Returns (clusters: list[tuple[int]], cumulative sizes, centroids) like fused_butina."""
+    x = _as_u32(x)
+    n = x.shape[0]
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    cent = np.zeros(max(n, 1), dtype=np.int32)
+    nc = lib().orc_butina_fused(metric, x, n, x.shape[1], float(cutoff), idx, offs, cent)
+    clusters = [tuple(int(v) for v in idx[offs[k]:offs[k + 1]]) for k in range(nc)]
+    return clusters, [int(v) for v in offs[:nc + 1]], [int(v) for v in cent[:nc]]
+
+
+def butina_dense(dist=None, cutoff: float = 0.0, hit=None):
+    """Returns (cluster ids int32[N], centroids int32[n_clusters])."""
+    if dist is not None:
+        d = np.ascontiguousarray(dist, dtype=np.float64)
+        n = d.shape[0]
+        dptr, hptr = d.ctypes.data, None
+    else:
+        h = np.ascontiguousarray(hit, dtype=np.uint8)
+        n = h.shape[0]
+        dptr, hptr = None, h.ctypes.data
+    clusters = np.empty(max(n, 1), dtype=np.int32)
+    cent = np.empty(max(n, 1), dtype=np.int32)
+    nc = lib().orc_butina_dense(dptr, hptr, n, float(cutoff), clusters, cent.ctypes.data)
+    return clusters[:n], cent[:nc]
+
+
+# ---- numpy restatements (independent of the C code; used to cross-check it) -------------------
+
+
+def unpack_bits(words) -> np.ndarray:
+    """(n, W) u32 -> (n, 32*W) bool; bit j of a fingerprint = bit j%32 of word j//32
+    (nvmolkit/fingerprints.py:25-72)."""
+    w = _as_u32(words)
+    shifts = np.arange(32, dtype=np.uint32)
+    return ((w[:, :, None] >> shifts) & 1).astype(bool).reshape(w.shape[0], -1)
+
+
+def pack_bits(bits) -> np.ndarray:
+    b = np.ascontiguousarray(bits).astype(np.uint32)
+    n, nb = b.shape
+    pad = (-nb) % 32
+    if pad:
+        b = np.concatenate([b, np.zeros((n, pad), dtype=np.uint32)], axis=1)
+    b = b.reshape(n, -1, 32)
+    return (b << np.arange(32, dtype=np.uint32)).sum(axis=2, dtype=np.uint32)
+
+
+def cross_similarity_numpy(a, b=None, metric: int = TANIMOTO) -> np.ndarray:
+    """Bit-unpack restatement, as the reference's own test does (nvmolkit/tests/test_clustering.py:166-180)."""
+    ua = unpack_bits(a).astype(np.int64)
+    ub = ua if b is None else unpack_bits(b).astype(np.int64)
+    inter = ua @ ub.T
+    pa = ua.sum(1)[:, None]
+    pb = ub.sum(1)[None, :]
+    if metric == TANIMOTO:
+        union = np.maximum(pa + pb - inter, 1)
+        return inter.astype(np.float64) / union.astype(np.float64)
+    denom = np.sqrt(pa.astype(np.float64) * pb.astype(np.float64))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = np.where((inter == 0) | (denom == 0), 0.0, inter / denom)
+    return out

@@ -1,0 +1,311 @@
+/*
+ * oracle_similarity.c — CPU restatement of the reference's fingerprint-similarity and Butina paths.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is imported, linked or executed by the product
+ * (nvmolkit_amd/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and
+ * only as the checker / the timed CPU baseline.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - Tanimoto / cosine: closed-form on integers (popcounts) followed by ONE IEEE-754 double
+ *     division / sqrt, identical to RDKit's TanimotoSimilarity / CosineSimilarity on ExplicitBitVect
+ *     and to the reference's SIMT kernel (src/similarity_kernels.cu:350-364).  Pinned against the
+ *     reference's numpy bit-unpack restatement (nvmolkit/tests/test_clustering.py:166-180) and the
+ *     hand-computed vectors in tests/golden/.
+ *   - Butina: pinned by the reference's own property checker (tests/test_butina.cpp:96-153,
+ *     nvmolkit/tests/test_clustering.py:23-51) and the 10x10 known answer (tests/test_butina.cpp:241-273).
+ *
+ * Each function cites the reference lines it follows.  Paths are into the reference repository.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_TANIMOTO 0
+#define ORC_COSINE 1
+
+static inline int popc_and(const uint32_t* a, const uint32_t* b, int W) {
+  int c = 0;
+  int k = 0;
+  for (; k + 1 < W; k += 2) {
+    uint64_t x, y;
+    memcpy(&x, a + k, 8);
+    memcpy(&y, b + k, 8);
+    c += __builtin_popcountll(x & y);
+  }
+  for (; k < W; ++k) {
+    c += __builtin_popcount(a[k] & b[k]);
+  }
+  return c;
+}
+
+static inline int popc_row(const uint32_t* a, int W) {
+  int c = 0;
+  for (int k = 0; k < W; ++k) {
+    c += __builtin_popcount(a[k]);
+  }
+  return c;
+}
+
+/* src/similarity_kernels.cu:350-364 (SIMT epilogue, T_out = double). */
+static inline double finish_f64(int metric, int c, int pa, int pb) {
+  if (metric == ORC_TANIMOTO) {
+    int u = pa + pb - c;
+    if (u < 1) u = 1;
+    return (double)c / (double)u;
+  }
+  double denom = sqrt((double)pa * (double)pb);
+  return (c == 0 || denom == 0.0) ? 0.0 : (double)c / denom;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* out[i*ld + j] for i < nA, j < nB.  Follows launchCrossTanimotoSimilarity / launchCrossCosineSimilarity
+ * (src/similarity_kernels.cu:505-582, :727-799), SIMT arithmetic.  `threads` <= 0 means all cores. */
+void orc_cross_similarity_f64(int metric, const uint32_t* a, int64_t nA, const uint32_t* b, int64_t nB, int W,
+                              double* out, int64_t ld, int threads) {
+  int* pb = (int*)malloc(sizeof(int) * (size_t)(nB > 0 ? nB : 1));
+  for (int64_t j = 0; j < nB; ++j) pb[j] = popc_row(b + j * W, W);
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(threads)
+#endif
+  for (int64_t i = 0; i < nA; ++i) {
+    const uint32_t* ai = a + i * W;
+    const int       pa = popc_row(ai, W);
+    for (int64_t j = 0; j < nB; ++j) {
+      const int c     = popc_and(ai, b + j * W, W);
+      out[i * ld + j] = finish_f64(metric, c, pa, pb[j]);
+    }
+  }
+  free(pb);
+}
+
+/* Integer intersection counts only (for bit-exact checks independent of the division). */
+void orc_cross_intersection_i32(const uint32_t* a, int64_t nA, const uint32_t* b, int64_t nB, int W, int32_t* out) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int64_t i = 0; i < nA; ++i) {
+    for (int64_t j = 0; j < nB; ++j) {
+      out[i * nB + j] = popc_and(a + i * W, b + j * W, W);
+    }
+  }
+}
+
+/* float32 neighbour predicate of the fused path: nvmolkit/_fusedButina.py:160-173
+ * (denom > 0, similarity = float(dots) / float(denom), neighbour <=> similarity >= threshold). */
+static inline int is_neighbor_f32(int metric, int c, int pa, int pb, float thr) {
+  float denom;
+  if (metric == ORC_TANIMOTO) {
+    const int u = pa + pb - c;
+    if (u <= 0) return 0;
+    denom = (float)u;
+  } else {
+    denom = sqrtf((float)pa * (float)pb);
+    if (!(denom > 0.0f)) return 0;
+  }
+  const float sim = (float)c / denom;
+  return sim >= thr;
+}
+
+/* counts[i] += sign * #{j : neighbour(x_i, y_j)}  — update_neighbor_counts, nvmolkit/_fusedButina.py:249-289. */
+void orc_neighbor_counts(int metric, const uint32_t* x, int64_t nX, const uint32_t* y, int64_t nY, int W, float thr,
+                         int sign, int32_t* counts) {
+  int* py = (int*)malloc(sizeof(int) * (size_t)(nY > 0 ? nY : 1));
+  for (int64_t j = 0; j < nY; ++j) py[j] = popc_row(y + j * W, W);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int64_t i = 0; i < nX; ++i) {
+    const uint32_t* xi = x + i * W;
+    const int       px = popc_row(xi, W);
+    int             n  = 0;
+    for (int64_t j = 0; j < nY; ++j) {
+      n += is_neighbor_f32(metric, popc_and(xi, y + j * W, W), px, py[j], thr);
+    }
+    counts[i] += sign * n;
+  }
+  free(py);
+}
+
+/*
+ * Matrix-free Taylor-Butina — fused_butina, nvmolkit/clustering.py:99-189 with
+ * nvmolkit/_fusedButina.py:182-246 for the per-round extraction.
+ *
+ * Stated directly on the definition (O(N^2) adjacency bits, so for small N only):
+ *   repeat: degree[i] = #free neighbours of free row i (self included when its own denom > 0);
+ *           stop when max degree == 0; centroid = LAST row with the max degree (clustering.py:159);
+ *           cluster = centroid + its free neighbours; additionally every free non-member whose
+ *           degree is 1 is harvested as a singleton (_fusedButina.py:240-244).
+ * Output convention of this build (the reference's member order comes from atomics and is
+ * unspecified): greedy clusters in the order found, centroid first then members ascending;
+ * singleton tail ascending by row.  Rows with degree 0 (all-zero fingerprints) are appended to the
+ * singleton tail (the reference leaves them unwritten — clustering.py:171-175 reads zeros there).
+ * Returns the number of clusters; offsets has n_clusters+1 entries.
+ */
+int64_t orc_butina_fused(int metric, const uint32_t* x, int64_t N, int W, double cutoff, int32_t* cluster_indices,
+                         int64_t* offsets, int32_t* centroids) {
+  const float thr = (float)(1.0 - cutoff); /* clustering.py:149, passed to the kernel as f32 */
+  uint8_t*    adj = (uint8_t*)calloc((size_t)(N * N > 0 ? N * N : 1), 1);
+  int*        pc  = (int*)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
+  for (int64_t i = 0; i < N; ++i) pc[i] = popc_row(x + i * W, W);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int64_t i = 0; i < N; ++i) {
+    for (int64_t j = 0; j < N; ++j) {
+      adj[i * N + j] = (uint8_t)is_neighbor_f32(metric, popc_and(x + i * W, x + j * W, W), pc[i], pc[j], thr);
+    }
+  }
+  uint8_t* is_free   = (uint8_t*)malloc((size_t)(N > 0 ? N : 1));
+  int32_t* degree    = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  int32_t* singles   = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  int64_t  nSingles  = 0;
+  int64_t  nClusters = 0;
+  int64_t  pos       = 0;
+  memset(is_free, 1, (size_t)N);
+  offsets[0] = 0;
+  for (;;) {
+    int32_t best = 0;
+    int64_t arg  = -1;
+    for (int64_t i = 0; i < N; ++i) {
+      degree[i] = 0;
+      if (!is_free[i]) continue;
+      int32_t d = 0;
+      for (int64_t j = 0; j < N; ++j) d += (is_free[j] && adj[i * N + j]);
+      degree[i] = d;
+      if (d >= best && d > 0) {
+        best = d;
+        arg  = i;
+      }
+    }
+    if (arg < 0) break;
+    centroids[nClusters]   = (int32_t)arg;
+    cluster_indices[pos++] = (int32_t)arg;
+    for (int64_t j = 0; j < N; ++j) {
+      if (j != arg && is_free[j] && adj[arg * N + j]) cluster_indices[pos++] = (int32_t)j;
+    }
+    /* singleton harvest uses the degrees of THIS round (before removal) */
+    for (int64_t j = 0; j < N; ++j) {
+      if (is_free[j] && j != arg && !adj[arg * N + j] && degree[j] == 1) {
+        singles[nSingles++] = (int32_t)j;
+        is_free[j]          = 0;
+      }
+    }
+    for (int64_t j = 0; j < N; ++j) {
+      if (adj[arg * N + j]) is_free[j] = 0;
+    }
+    is_free[arg]         = 0;
+    offsets[++nClusters] = pos;
+  }
+  for (int64_t j = 0; j < N; ++j) {
+    if (is_free[j]) singles[nSingles++] = (int32_t)j; /* degree-0 rows */
+  }
+  /* ascending singleton tail */
+  for (int64_t a = 1; a < nSingles; ++a) {
+    int32_t v = singles[a];
+    int64_t b = a - 1;
+    while (b >= 0 && singles[b] > v) {
+      singles[b + 1] = singles[b];
+      --b;
+    }
+    singles[b + 1] = v;
+  }
+  for (int64_t s = 0; s < nSingles; ++s) {
+    centroids[nClusters]   = singles[s];
+    cluster_indices[pos++] = singles[s];
+    offsets[++nClusters]   = pos;
+  }
+  free(adj);
+  free(pc);
+  free(is_free);
+  free(degree);
+  free(singles);
+  return nClusters;
+}
+
+/*
+ * Taylor-Butina on a dense matrix — butinaGpu, src/butina.cu:913-1071.
+ *   hit[i][j] = dist[i][j] <= cutoff                      (:1043-1051)
+ *   loop while the largest unassigned neighbourhood has >= 2 members (kMinLoopSizeForAssignment, :34):
+ *     centroid = LAST index with the largest count (lastArgMaxKernel :464-481), assign it and its
+ *     unassigned neighbours the next cluster id (:241-269);
+ *   remaining points become singletons in ascending index order (:281-307 — the reference's order is
+ *   an atomic race; ascending is this build's convention);
+ *   renumber: id 0 = largest cluster, stable by original id (:369-448).
+ * `hit` may be NULL (then dist/cutoff are used) or dist may be NULL (then hit is used).
+ */
+int64_t orc_butina_dense(const double* dist, const uint8_t* hit_in, int64_t N, double cutoff, int32_t* clusters,
+                         int32_t* centroids_out) {
+  uint8_t* hit = (uint8_t*)malloc((size_t)(N * N > 0 ? N * N : 1));
+  for (int64_t k = 0; k < N * N; ++k) hit[k] = dist ? (uint8_t)(dist[k] <= cutoff) : (uint8_t)(hit_in[k] != 0);
+  int32_t* cent = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  for (int64_t i = 0; i < N; ++i) clusters[i] = -1;
+  int64_t next = 0;
+  for (;;) {
+    int32_t best = -1;
+    int64_t arg  = -1;
+    for (int64_t i = 0; i < N; ++i) {
+      int32_t d = 0;
+      if (clusters[i] < 0) {
+        for (int64_t j = 0; j < N; ++j) d += (hit[i * N + j] && clusters[j] < 0);
+      }
+      if (d >= best) {
+        best = d;
+        arg  = i;
+      }
+    }
+    if (best < 2) break;
+    for (int64_t j = 0; j < N; ++j) {
+      if (hit[arg * N + j] && clusters[j] < 0) clusters[j] = (int32_t)next;
+    }
+    clusters[arg] = (int32_t)next;
+    cent[next++]  = (int32_t)arg;
+  }
+  for (int64_t i = 0; i < N; ++i) {
+    if (clusters[i] < 0) {
+      clusters[i]  = (int32_t)next;
+      cent[next++] = (int32_t)i;
+    }
+  }
+  /* renumber by descending size, stable by original id */
+  int64_t  nC    = next;
+  int64_t* sizes = (int64_t*)calloc((size_t)(nC > 0 ? nC : 1), sizeof(int64_t));
+  int64_t* order = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nC > 0 ? nC : 1));
+  int32_t* remap = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nC > 0 ? nC : 1));
+  for (int64_t i = 0; i < N; ++i) sizes[clusters[i]]++;
+  for (int64_t c = 0; c < nC; ++c) order[c] = c;
+  /* stable insertion sort is O(nC^2); use a counting pass by size instead */
+  {
+    int64_t maxSize = 0;
+    for (int64_t c = 0; c < nC; ++c)
+      if (sizes[c] > maxSize) maxSize = sizes[c];
+    int64_t* start = (int64_t*)calloc((size_t)(maxSize + 2), sizeof(int64_t));
+    for (int64_t c = 0; c < nC; ++c) start[maxSize - sizes[c] + 1]++;
+    for (int64_t s = 1; s <= maxSize + 1; ++s) start[s] += start[s - 1];
+    for (int64_t c = 0; c < nC; ++c) order[start[maxSize - sizes[c]]++] = c;
+    free(start);
+  }
+  for (int64_t newId = 0; newId < nC; ++newId) remap[order[newId]] = (int32_t)newId;
+  for (int64_t i = 0; i < N; ++i) clusters[i] = remap[clusters[i]];
+  if (centroids_out) {
+    for (int64_t newId = 0; newId < nC; ++newId) centroids_out[newId] = cent[order[newId]];
+  }
+  free(hit);
+  free(cent);
+  free(sizes);
+  free(order);
+  free(remap);
+  return nC;
+}

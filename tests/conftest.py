@@ -1,0 +1,29 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def native_lib():
+    """Build (if needed) and load libnvmolkit_amd.so; the C ABI loads without a GPU."""
+    from nvmolkit_amd import _build, _native
+
+    _build.build()
+    return _native.lib()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return ROOT / "tests" / "golden"

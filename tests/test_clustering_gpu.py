@@ -1,0 +1,151 @@
+"""GPU parity: neighbour counting, fused Butina and dense Butina vs the CPU oracle and the
+reference's property checkers (tests/test_butina.cpp:96-153, nvmolkit/tests/test_clustering.py)."""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from nvmolkit_amd.clustering import butina, fused_butina, update_neighbor_counts
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+METRICS = {"tanimoto": oracle.TANIMOTO, "cosine": oracle.COSINE}
+
+
+def dev(words: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(words.view(np.int32)).cuda()
+
+
+@pytest.mark.parametrize("metric", ["tanimoto", "cosine"])
+@pytest.mark.parametrize("words", [4, 16, 32, 64, 128, 12, 3])
+@pytest.mark.parametrize("thr", [0.0, 0.3, 0.55, 0.7, 1.0])
+def test_neighbor_counts_match_oracle(metric, words, thr):
+    x = util.clustered_fingerprints(391, words, 9, max_flips=10, density=0.15, seed=words)
+    y = util.clustered_fingerprints(5000 if words == 64 else 263, words, 9, max_flips=10, density=0.15, seed=words)
+    counts = torch.zeros(len(x), dtype=torch.int32, device="cuda")
+    update_neighbor_counts(dev(x), dev(y), counts, thr, metric=metric)
+    want = oracle.neighbor_counts(x, y, thr, metric=METRICS[metric])
+    assert np.array_equal(counts.cpu().numpy(), want)
+    update_neighbor_counts(dev(x), dev(y), counts, thr, subtract=True, metric=metric)
+    assert not counts.any()
+
+
+def test_neighbor_counts_threshold_boundaries():
+    """Exact float32 boundary behaviour: pairs whose similarity equals the threshold are neighbours."""
+    words = 4
+    bits = np.zeros((4, 128), dtype=bool)
+    bits[0, :10] = True           # |a| = 10
+    bits[1, :7] = True            # c = 7, u = 10 -> 0.7
+    bits[2, :3] = True            # 0.3
+    bits[3, 5:15] = True          # c = 5, u = 15 -> 1/3
+    x = util.pack_bits(bits)
+    for thr in (np.float32(0.7), np.float32(7) / np.float32(10), np.nextafter(np.float32(0.7), np.float32(1)),
+                np.float32(1) / np.float32(3), np.nextafter(np.float32(1) / np.float32(3), np.float32(0))):
+        counts = torch.zeros(4, dtype=torch.int32, device="cuda")
+        update_neighbor_counts(dev(x), dev(x), counts, float(thr))
+        assert np.array_equal(counts.cpu().numpy(), oracle.neighbor_counts(x, x, thr)), thr
+
+
+@pytest.mark.parametrize("metric", ["tanimoto", "cosine"])
+@pytest.mark.parametrize("key,cutoff", [("clustered_300x32", 0.4), ("clustered_500x64", 0.3), ("clustered_500x64", 0.7),
+                                        ("random_128x64", 0.5)])
+def test_fused_butina_equals_oracle(golden_dir, key, cutoff, metric):
+    x = np.load(golden_dir / "fingerprints_small.npz")[key]
+    clusters, sizes, cent = fused_butina(dev(x), cutoff, return_centroids=True, metric=metric)
+    w_clusters, w_sizes, w_cent = oracle.butina_fused(x, cutoff, metric=METRICS[metric])
+    assert sizes == w_sizes and cent == w_cent and clusters == w_clusters
+    util.check_partition(clusters, len(x))
+
+
+@pytest.mark.parametrize("n,words,centres", [(2000, 64, 40), (3001, 32, 100)])
+def test_fused_butina_larger_vs_oracle(n, words, centres):
+    x = util.clustered_fingerprints(n, words, centres, seed=n)
+    got = fused_butina(dev(x), 0.35, return_centroids=True)
+    want = oracle.butina_fused(x, 0.35)
+    assert got[1] == want[1] and got[2] == want[2] and got[0] == want[0]
+
+
+def test_fused_butina_edge_cases():
+    one = dev(util.random_fingerprints(1, 32))
+    assert fused_butina(one, 0.5) == ([(0,)], [0, 1])
+    same = dev(np.repeat(util.random_fingerprints(1, 32), 50, axis=0))
+    cl, sizes = fused_butina(same, 0.5)
+    assert len(cl) == 1 and set(cl[0]) == set(range(50)) and sizes == [0, 50]
+    rnd = dev(util.random_fingerprints(50, 32, density=0.5))
+    cl, _ = fused_butina(rnd, 0.001)
+    assert len(cl) == 50 and all(len(c) == 1 for c in cl)
+    zeros = torch.zeros((5, 4), dtype=torch.int32, device="cuda")
+    cl, sizes = fused_butina(zeros, 0.5)
+    assert sorted(c[0] for c in cl) == list(range(5)) and sizes[-1] == 5
+    empty = torch.zeros((0, 4), dtype=torch.int32, device="cuda")
+    assert fused_butina(empty, 0.5) == ([], [0])
+
+
+def test_fused_butina_argument_validation():
+    x = dev(util.random_fingerprints(10, 4))
+    with pytest.raises(ValueError):
+        fused_butina(x, 1.5)
+    with pytest.raises(ValueError):
+        fused_butina(x, 0.5, metric="dice")
+    with pytest.raises(TypeError):
+        fused_butina(x, 0.5, stream=3)
+    with pytest.raises(ValueError):
+        fused_butina(x.to(torch.int64), 0.5)
+    with pytest.raises(ValueError):
+        fused_butina(x.cpu(), 0.5)
+
+
+@pytest.mark.parametrize("size,nl", [(s, n) for s in (1, 10, 100, 1000) for n in (8, 64, 128)])
+def test_butina_dense_properties(size, nl):
+    rng = np.random.default_rng(42)
+    d = rng.random((size, size))
+    d = np.abs(d - d.T)
+    cutoff = 0.1
+    res, cent = butina(torch.from_numpy(d).cuda(), cutoff, neighborlist_max_size=nl, return_centroids=True)
+    labels = res.numpy()
+    hit = d <= cutoff
+    util.check_labels_valid(hit, labels)
+    clusters = [tuple(np.flatnonzero(labels == c)) for c in range(labels.max() + 1)]
+    util.check_greedy_butina(hit, clusters)
+    w_labels, w_cent = oracle.butina_dense(d, cutoff)
+    assert np.array_equal(labels, w_labels) and np.array_equal(cent.numpy(), w_cent)
+
+
+def test_butina_dense_known_answer(golden_dir):
+    g = np.load(golden_dir / "butina_10x10.npz")
+    res, cent = butina(torch.from_numpy(g["dist"]).cuda(), float(g["cutoff"]), return_centroids=True)
+    labels, cent = res.numpy(), cent.numpy()
+    assert len(cent) == 5
+    assert sorted(np.flatnonzero(labels == 0)) == [0, 1, 2, 3] and cent[0] == 0
+    assert sorted(np.flatnonzero(labels == 1)) == [4, 5, 6] and cent[1] == 4
+    for cid in range(2, 5):
+        m = np.flatnonzero(labels == cid)
+        assert len(m) == 1 and cent[cid] == m[0]
+
+
+def test_butina_dense_edges_and_validation():
+    n = 50
+    assert (butina(torch.zeros((n, n), dtype=torch.float64, device="cuda"), 0.5).numpy() == 0).all()
+    d = torch.ones((n, n), dtype=torch.float64, device="cuda") - torch.eye(n, dtype=torch.float64, device="cuda")
+    assert np.array_equal(butina(d, 0.5).numpy(), np.arange(n))
+    with pytest.raises(ValueError):
+        butina(d, 0.5, neighborlist_max_size=7)
+    with pytest.raises(TypeError):
+        butina(d, 0.5, stream=1)
+    with pytest.raises(ValueError):
+        butina(d[:, :10], 0.5)
+
+
+def test_fused_matches_dense_on_same_data():
+    """Consistency across the two Butina paths: same adjacency -> same greedy clusters."""
+    x = util.clustered_fingerprints(600, 64, 15, seed=5)
+    cutoff = 0.4
+    clusters, _ = fused_butina(dev(x), cutoff)
+    inter = oracle.cross_intersection(x)
+    pc = inter.diagonal()
+    den = (pc[:, None] + pc[None, :] - inter).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        hit = (inter.astype(np.float32) / den >= np.float32(1.0 - cutoff)) & (den > 0)
+    util.check_greedy_butina(hit, clusters)
