@@ -69,6 +69,23 @@ int nvmk_cross_tanimoto_f64(const uint32_t* d_a, int64_t nA, const uint32_t* d_b
 int nvmk_cross_cosine_f64(const uint32_t* d_a, int64_t nA, const uint32_t* d_b, int64_t nB, int fp_bits,
                           double* d_out, int64_t ld_out, void* stream);
 
+/* ---- S1 (matrix-core formulation): prepared FP4 fingerprint sets ------------------------------------
+ * The reference computes popcount(a & b) on NVIDIA's 1-bit tensor-core MMA (src/similarity_kernels.cu:96-240,
+ * src/utils/macros_ptx.cuh:137-211).  The MI355X counterpart expands every fingerprint bit once into an FP4
+ * (e2m1) nibble and runs the N x M x K work on v_mfma_scale_f32_32x32x64_f8f6f4 (exact: products are 0/1, f32
+ * accumulation is exact below 2^24).  nvmk_cross_tanimoto_f64 / nvmk_cross_cosine_f64 do this internally;
+ * these entry points let a caller that reuses a fingerprint set (row-chunked 1M x 1M, Butina rounds) expand it once.
+ *   nvmk_fp4_workspace_bytes : device bytes needed for a prepared set of n fingerprints (0 on bad arguments)
+ *   nvmk_fp4_prepare         : expand d_in (n x fp_bits/32 words) into d_workspace (also stores row popcounts)
+ *   nvmk_cross_similarity_prepared_f64 : rows [a_row0, a_row0 + a_rows) of prepared set A (a_row0 % 128 == 0)
+ *                              against all nB rows of prepared set B; output as nvmk_cross_tanimoto_f64.
+ */
+size_t nvmk_fp4_workspace_bytes(int64_t n, int fp_bits);
+int nvmk_fp4_prepare(const uint32_t* d_in, int64_t n, int fp_bits, void* d_workspace, void* stream);
+int nvmk_cross_similarity_prepared_f64(int metric, const void* d_ws_a, int64_t nA_total, int64_t a_row0, int64_t a_rows,
+                                       const void* d_ws_b, int64_t nB, int fp_bits, double* d_out, int64_t ld_out,
+                                       void* stream);
+
 /* ---- S4: memory-constrained cross-similarity returned on the host --------------------------------
  * Replaces crossTanimotoSimilarityCPUResult / crossCosineSimilarityCPUResult -> crossSimilarityImpl
  * (src/similarity.cpp:105-254, :282-297; CrossSimilarityOptions src/similarity.h:29-32).

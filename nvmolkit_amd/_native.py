@@ -46,6 +46,9 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_device_memory": (_int, [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "nvmk_cross_tanimoto_f64": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _vp]),
     "nvmk_cross_cosine_f64": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _vp]),
+    "nvmk_fp4_workspace_bytes": (ctypes.c_size_t, [_i64, _int]),
+    "nvmk_fp4_prepare": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "nvmk_cross_similarity_prepared_f64": (_int, [_int, _vp, _i64, _i64, _i64, _vp, _i64, _int, _vp, _i64, _vp]),
     "nvmk_cross_similarity_host_f64": (_int, [_int, _vp, _i64, _vp, _i64, _int, _vp, _i64]),
     "nvmk_neighbor_counts": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _i64, _int, ctypes.c_float, _int, _vp, _vp]),
     "nvmk_butina_fused": (_int, [_int, _vp, _i64, _int, ctypes.c_double, _vp, _vp, _vp, ctypes.POINTER(_i64), _vp]),

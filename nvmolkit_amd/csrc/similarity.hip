@@ -18,7 +18,11 @@
 //     32 contiguous bytes per lane and 512 contiguous bytes per 16 lanes (full 128-B lines);
 //   * workgroup -> tile map walks the A tiles fastest inside groups of 64 tile-rows, so the 8
 //     XCD L2s each keep 1/8 of the A group resident while B tiles stream through.
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
+#include "fp4.h"
 
 namespace nvmk {
 namespace sim {
@@ -246,6 +250,39 @@ __global__ __launch_bounds__(NT) void cross_sim_generic_kernel(const uint32_t* _
   out[row * ld + col] = finish<METRIC>(c, pa, pb);
 }
 
+// Path selection.  The matrix-core formulation (similarity_mfma.hip) pays an O(nA + nB) expansion and
+// wins by ~3x once the O(nA * nB) term dominates; the VALU popcount kernel below serves small problems
+// (e.g. 1 x M "BulkTanimoto" calls) and widths/alignments the FP4 path does not take.
+// NVMK_SIM_PATH = auto | valu | mfma overrides (used by the A/B benchmarks and the parity tests).
+enum class Path { kAuto, kValu, kMfma };
+
+inline Path path_override() {
+  const char* e = std::getenv("NVMK_SIM_PATH");
+  if (e == nullptr) return Path::kAuto;
+  if (std::strcmp(e, "valu") == 0) return Path::kValu;
+  if (std::strcmp(e, "mfma") == 0) return Path::kMfma;
+  return Path::kAuto;
+}
+
+template <int METRIC>
+int launch_mfma(const uint32_t* a, int64_t nA, const uint32_t* b, int64_t nB, int fpBits, double* out, int64_t ld,
+                hipStream_t stream) {
+  const bool          same = (a == b && nA == nB);
+  const fp4::Layout   LA   = fp4::layout(nA, fpBits);
+  const fp4::Layout   LB   = fp4::layout(nB, fpBits);
+  StreamScratch       wsA, wsB;
+  NVMK_HIP_CHECK(wsA.alloc(LA.bytes, stream));
+  int rc = fp4::prepare(a, nullptr, nA, fpBits, wsA.ptr, stream);
+  if (rc != NVMK_OK) return rc;
+  if (!same) {
+    NVMK_HIP_CHECK(wsB.alloc(LB.bytes, stream));
+    rc = fp4::prepare(b, nullptr, nB, fpBits, wsB.ptr, stream);
+    if (rc != NVMK_OK) return rc;
+  }
+  return fp4::launch_dense(METRIC, fp4::view(wsA.ptr, nA, fpBits), fp4::view(same ? wsA.ptr : wsB.ptr, nB, fpBits), out,
+                           ld, stream);
+}
+
 template <int METRIC>
 int launch(const uint32_t* a, int64_t nA, const uint32_t* b, int64_t nB, int fpBits, double* out, int64_t ld,
            hipStream_t stream) {
@@ -259,6 +296,14 @@ int launch(const uint32_t* a, int64_t nA, const uint32_t* b, int64_t nB, int fpB
   NVMK_REQUIRE(ld >= nB, "cross similarity: ld_out (%lld) < nB (%lld)", (long long)ld, (long long)nB);
   const int  W       = fpBits / 32;
   const bool aligned = (reinterpret_cast<uintptr_t>(a) % 16 == 0) && (reinterpret_cast<uintptr_t>(b) % 16 == 0);
+  {
+    const Path   p       = path_override();
+    const double pairs   = static_cast<double>(nA) * static_cast<double>(nB);
+    const bool   worthIt = pairs >= 4.0e6 && nA >= 64 && nB >= 64 && W >= 4;
+    if (p == Path::kMfma || (p == Path::kAuto && worthIt)) {
+      return launch_mfma<METRIC>(a, nA, b, nB, fpBits, out, ld, stream);
+    }
+  }
   if (W % 4 != 0 || !aligned) {
     const dim3 grid(static_cast<unsigned>(ceil_div<int64_t>(nB, 64)), static_cast<unsigned>(ceil_div<int64_t>(nA, 4)));
     NVMK_REQUIRE(ceil_div<int64_t>(nA, 4) <= 65535 * 1024LL, "cross similarity: generic path supports at most %lld rows",

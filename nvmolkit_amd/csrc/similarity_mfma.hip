@@ -1,0 +1,284 @@
+// Matrix-core (FP4 MFMA) formulation of fingerprint cross-similarity and neighbour counting — gfx950.
+//
+// See fp4.h for why popcount(a & b) maps exactly onto v_mfma_scale_f32_32x32x64_f8f6f4 and for the
+// prepared-set layout.  Replaces the same reference kernels as similarity.hip
+// (src/similarity_kernels.cu:96-240 is the reference's own tensor-core formulation) and the Triton
+// neighbour-count kernel (nvmolkit/_fusedButina.py:99-179).
+//
+// Kernel shape: 256 threads = 4 wave64 in a 2 x 2 arrangement, workgroup tile 128 x 128, wave tile
+// 64 x 64 = 2 x 2 MFMA blocks of 32 x 32 (4 accumulators of 16 VGPRs).  K is walked in LDS chunks of
+// 16 words (512 fingerprint bits = 256 B of FP4 per row): per chunk each operand tile is 32 KB, one
+// workgroup uses 64 KB so two workgroups share a CU and cover each other's global->LDS latency.  A
+// k-step (64 bits) is one MFMA per block: lanes 0-31 hold word 2t of rows 0-31, lanes 32-63 word 2t+1;
+// which nibble carries which k is irrelevant because both operands use the same expansion.
+// LDS rows are XOR-swizzled in 16-byte slots by (row & 15): every ds_read_b128 lane group touches 16
+// different slots of the 256-byte bank row (rows 0-3, 12-15, 20-27 -> row & 15 all distinct).
+#include "fp4.h"
+
+namespace nvmk {
+namespace fp4 {
+
+namespace {
+
+constexpr int TM  = 128;
+constexpr int TN  = 128;
+constexpr int NT  = 256;
+constexpr int KCW = WORD_PAD;       // words per chunk
+constexpr int CHUNK_ROW_BYTES = KCW * 16;  // 256
+constexpr int GROUP_TM = 64;        // tile-rows per scheduling group (see similarity.hip)
+
+typedef int   v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t spread8(uint32_t x) {  // bit k of the low byte -> 0x2 in nibble k
+  x = (x | (x << 12)) & 0x000F000Fu;
+  x = (x | (x << 6)) & 0x03030303u;
+  x = (x | (x << 3)) & 0x11111111u;
+  return x << 1;
+}
+
+// 16 lanes per fingerprint: lane s expands words s, s+16, ... and the group reduces the popcount.
+__global__ __launch_bounds__(NT) void prepare_kernel(const uint32_t* __restrict__ in, const int32_t* __restrict__ rows,
+                                                     const int64_t n, const int64_t nPad, const int W, const int Wp,
+                                                     int32_t* __restrict__ popc, uint4* __restrict__ out) {
+  const int64_t gid = static_cast<int64_t>(blockIdx.x) * NT + threadIdx.x;
+  const int64_t row = gid >> 4;
+  const int     sub = static_cast<int>(gid & 15);
+  if (row >= nPad) return;
+  const bool      live = row < n;
+  const int64_t   src  = live ? (rows ? static_cast<int64_t>(rows[row]) : row) : 0;
+  const uint32_t* r    = in + src * W;
+  int             cnt  = 0;
+  for (int w = sub; w < Wp; w += 16) {
+    const uint32_t word = (live && w < W) ? r[w] : 0u;
+    cnt += __popc(word);
+    uint4 e;
+    e.x               = spread8(word & 0xffu);
+    e.y               = spread8((word >> 8) & 0xffu);
+    e.z               = spread8((word >> 16) & 0xffu);
+    e.w               = spread8(word >> 24);
+    out[row * Wp + w] = e;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (sub == 0) popc[row] = cnt;
+}
+
+__device__ __forceinline__ v16f mfma_fp4(const uint4 a, const uint4 b, const v16f c) {
+  const v8i av = {static_cast<int>(a.x), static_cast<int>(a.y), static_cast<int>(a.z), static_cast<int>(a.w), 0, 0, 0, 0};
+  const v8i bv = {static_cast<int>(b.x), static_cast<int>(b.y), static_cast<int>(b.z), static_cast<int>(b.w), 0, 0, 0, 0};
+  // cbsz = blgp = 4 selects FP4 e2m1 for A and B; E8M0 scale 0x7f = 2^0
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+template <int METRIC> __device__ __forceinline__ double finish(const int c, const int pa, const int pb) {
+  if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+    const int u = pa + pb - c;
+    return static_cast<double>(c) / static_cast<double>(u > 1 ? u : 1);
+  } else {
+    const double denom = sqrt(static_cast<double>(pa) * static_cast<double>(pb));
+    return (c == 0 || denom == 0.0) ? 0.0 : static_cast<double>(c) / denom;
+  }
+}
+
+// Stage one 128-row x 256-byte chunk: 8 x 16 B per thread, held in 8 NAMED registers per operand.
+// (Arrays indexed inside unrolled helper loops ended up in scratch memory with this compiler —
+// 272 B/lane and a store/reload of the whole prefetch per chunk — hence the X-macro spelling.)
+#define NVMK_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define NVMK_DECL_STAGE(P) uint4 P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7
+#define NVMK_FETCH_ONE(P, base, t) P##t = (base)[static_cast<int64_t>((tid + (t)*NT) >> 4) * Wp + ((tid + (t)*NT) & 15)];
+#define NVMK_FETCH(P, base)                                                                    \
+  NVMK_FETCH_ONE(P, base, 0) NVMK_FETCH_ONE(P, base, 1) NVMK_FETCH_ONE(P, base, 2) NVMK_FETCH_ONE(P, base, 3) \
+  NVMK_FETCH_ONE(P, base, 4) NVMK_FETCH_ONE(P, base, 5) NVMK_FETCH_ONE(P, base, 6) NVMK_FETCH_ONE(P, base, 7)
+#define NVMK_COMMIT_ONE(P, lds, t)                                                                       \
+  *reinterpret_cast<uint4*>((lds) + ((tid + (t)*NT) >> 4) * CHUNK_ROW_BYTES +                              \
+                            (((((tid + (t)*NT) & 15)) ^ (((tid + (t)*NT) >> 4) & 15)) << 4)) = P##t;
+#define NVMK_COMMIT(P, lds)                                                                          \
+  NVMK_COMMIT_ONE(P, lds, 0) NVMK_COMMIT_ONE(P, lds, 1) NVMK_COMMIT_ONE(P, lds, 2) NVMK_COMMIT_ONE(P, lds, 3) \
+  NVMK_COMMIT_ONE(P, lds, 4) NVMK_COMMIT_ONE(P, lds, 5) NVMK_COMMIT_ONE(P, lds, 6) NVMK_COMMIT_ONE(P, lds, 7)
+
+// One K chunk of MFMAs for this wave's 64 x 64 tile.
+__device__ __forceinline__ void chunk_mma(v16f (&acc)[2][2], const char* sA, const char* sB, const int wm, const int wn,
+                                          const int lane) {
+  const int      l31   = lane & 31;
+  const int      half  = lane >> 5;
+  const unsigned rowA0 = static_cast<unsigned>(wm * 64 + l31);
+  const unsigned rowB0 = static_cast<unsigned>(wn * 64 + l31);
+  // rows +32 keep (row & 15), so one swizzle term serves both blocks of an operand
+  const unsigned baseA = rowA0 * CHUNK_ROW_BYTES;
+  const unsigned baseB = rowB0 * CHUNK_ROW_BYTES;
+  const unsigned swA   = rowA0 & 15;
+  const unsigned swB   = rowB0 & 15;
+#pragma unroll
+  for (int ks = 0; ks < KCW / 2; ++ks) {
+    const unsigned slot = static_cast<unsigned>(ks * 2 + half);
+    const unsigned offA = baseA + ((slot ^ swA) << 4);
+    const unsigned offB = baseB + ((slot ^ swB) << 4);
+    const uint4    a0   = *reinterpret_cast<const uint4*>(sA + offA);
+    const uint4    a1   = *reinterpret_cast<const uint4*>(sA + offA + 32 * CHUNK_ROW_BYTES);
+    const uint4    b0   = *reinterpret_cast<const uint4*>(sB + offB);
+    const uint4    b1   = *reinterpret_cast<const uint4*>(sB + offB + 32 * CHUNK_ROW_BYTES);
+    acc[0][0]           = mfma_fp4(a0, b0, acc[0][0]);
+    acc[0][1]           = mfma_fp4(a0, b1, acc[0][1]);
+    acc[1][0]           = mfma_fp4(a1, b0, acc[1][0]);
+    acc[1][1]           = mfma_fp4(a1, b1, acc[1][1]);
+  }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __restrict__ A, const int32_t* __restrict__ popA,
+                                                               const int64_t nA, const uint4* __restrict__ B,
+                                                               const int32_t* __restrict__ popB, const int64_t nB,
+                                                               const int Wp, double* __restrict__ out, const int64_t ld,
+                                                               const unsigned tilesM, const unsigned tilesN) {
+  __shared__ __attribute__((aligned(16))) char smem[(TM + TN) * CHUNK_ROW_BYTES + (TM + TN) * 4];
+  char* sA  = smem;
+  char* sB  = smem + TM * CHUNK_ROW_BYTES;
+  int*  pcA = reinterpret_cast<int*>(smem + (TM + TN) * CHUNK_ROW_BYTES);
+  int*  pcB = pcA + TM;
+
+  const unsigned firstM = blockIdx.y * GROUP_TM;
+  const unsigned remM   = tilesM - firstM;
+  const unsigned gm     = remM < GROUP_TM ? remM : GROUP_TM;
+  const unsigned tile_n = blockIdx.x / gm;
+  const unsigned tile_m = firstM + (blockIdx.x - tile_n * gm);
+  if (tile_n >= tilesN) return;
+
+  const int     tid   = threadIdx.x;
+  const int     lane  = tid & 63;
+  const int     wave  = tid >> 6;
+  const int     wm    = wave >> 1;
+  const int     wn    = wave & 1;
+  const int64_t rowA0 = static_cast<int64_t>(tile_m) * TM;
+  const int64_t rowB0 = static_cast<int64_t>(tile_n) * TN;
+  const int     nChunks = Wp / KCW;
+
+  if (tid < TM) {
+    pcA[tid] = popA[rowA0 + tid];
+  } else {
+    pcB[tid - TM] = popB[rowB0 + tid - TM];
+  }
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    }
+  }
+
+  NVMK_DECL_STAGE(ra);
+  NVMK_DECL_STAGE(rb);
+  const uint4* gA = A + rowA0 * Wp;  // chunk c of this tile starts at gA + c * KCW
+  const uint4* gB = B + rowB0 * Wp;
+  NVMK_FETCH(ra, gA)
+  NVMK_FETCH(rb, gB)
+  for (int ch = 0; ch < nChunks; ++ch) {
+    if (ch > 0) __syncthreads();
+    NVMK_COMMIT(ra, sA)
+    NVMK_COMMIT(rb, sB)
+    __syncthreads();
+    if (ch + 1 < nChunks) {  // next chunk's global loads fly under this chunk's MFMAs
+      NVMK_FETCH(ra, gA + (ch + 1) * KCW)
+      NVMK_FETCH(rb, gB + (ch + 1) * KCW)
+    }
+    chunk_mma(acc, sA, sB, wm, wn, lane);
+  }
+
+  // epilogue: D[i][j], i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), j = lane & 31 inside each 32 x 32 block
+  const bool full = (rowA0 + TM <= nA) && (rowB0 + TN <= nB);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int     jl  = wn * 64 + ni * 32 + (lane & 31);
+    const int64_t col = rowB0 + jl;
+    const int     pbv = pcB[jl];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int     il  = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t row = rowA0 + il;
+        const double  v   = finish<METRIC>(static_cast<int>(acc[mi][ni][r]), pcA[il], pbv);
+        if (full || (row < nA && col < nB)) {
+          __builtin_nontemporal_store(v, out + row * ld + col);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int prepare(const uint32_t* d_in, const int32_t* d_rows, int64_t n, int fpBits, void* ws, hipStream_t stream) {
+  NVMK_REQUIRE(fpBits > 0 && fpBits % 32 == 0, "fp_bits must be a positive multiple of 32, got %d", fpBits);
+  NVMK_REQUIRE(n >= 0, "negative row count");
+  if (n == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_in != nullptr && ws != nullptr, "fp4 prepare: NULL buffer");
+  const Layout  L      = layout(n, fpBits);
+  auto*         popc   = static_cast<int32_t*>(ws);
+  auto*         rows   = reinterpret_cast<uint4*>(static_cast<char*>(ws) + L.rowsOffset);
+  const int64_t blocks = ceil_div<int64_t>(L.nPad * 16, NT);
+  NVMK_REQUIRE(blocks <= 0x7fffffffLL, "fp4 prepare: too many rows (%lld)", (long long)n);
+  hipLaunchKernelGGL(prepare_kernel, dim3(static_cast<unsigned>(blocks)), dim3(NT), 0, stream, d_in, d_rows, n, L.nPad,
+                     L.W, L.Wp, popc, rows);
+  NVMK_LAUNCH_CHECK();
+  return NVMK_OK;
+}
+
+int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, int64_t ld, hipStream_t stream) {
+  if (A.L.n == 0 || B.L.n == 0) return NVMK_OK;
+  NVMK_REQUIRE(A.L.Wp == B.L.Wp && A.L.W == B.L.W, "prepared sets have different fingerprint widths");
+  NVMK_REQUIRE(out != nullptr && ld >= B.L.n, "cross similarity: bad output buffer / ld_out");
+  const int64_t tilesM = A.L.nPad / TM;
+  const int64_t tilesN = B.L.nPad / TN;
+  const int64_t groups = ceil_div<int64_t>(tilesM, GROUP_TM);
+  NVMK_REQUIRE(groups <= 65535 && GROUP_TM * tilesN <= 0x7fffffffLL,
+               "cross similarity: problem too large for one launch (%lld x %lld tiles)", (long long)tilesM,
+               (long long)tilesN);
+  const dim3 grid(static_cast<unsigned>(GROUP_TM * tilesN), static_cast<unsigned>(groups));
+  if (metric == NVMK_METRIC_TANIMOTO) {
+    hipLaunchKernelGGL(cross_sim_mfma_kernel<NVMK_METRIC_TANIMOTO>, grid, dim3(NT), 0, stream, A.rows, A.popc, A.L.n, B.rows,
+                       B.popc, B.L.n, A.L.Wp, out, ld, static_cast<unsigned>(tilesM), static_cast<unsigned>(tilesN));
+  } else {
+    hipLaunchKernelGGL(cross_sim_mfma_kernel<NVMK_METRIC_COSINE>, grid, dim3(NT), 0, stream, A.rows, A.popc, A.L.n, B.rows,
+                       B.popc, B.L.n, A.L.Wp, out, ld, static_cast<unsigned>(tilesM), static_cast<unsigned>(tilesN));
+  }
+  NVMK_LAUNCH_CHECK();
+  return NVMK_OK;
+}
+
+}  // namespace fp4
+}  // namespace nvmk
+
+extern "C" {
+
+size_t nvmk_fp4_workspace_bytes(int64_t n, int fp_bits) {
+  if (n < 0 || fp_bits <= 0 || fp_bits % 32 != 0) return 0;
+  return nvmk::fp4::layout(n, fp_bits).bytes;
+}
+
+int nvmk_fp4_prepare(const uint32_t* d_in, int64_t n, int fp_bits, void* d_workspace, void* stream) {
+  return nvmk::fp4::prepare(d_in, nullptr, n, fp_bits, d_workspace, nvmk::as_stream(stream));
+}
+
+int nvmk_cross_similarity_prepared_f64(int metric, const void* d_ws_a, int64_t nA_total, int64_t a_row0, int64_t a_rows,
+                                       const void* d_ws_b, int64_t nB, int fp_bits, double* d_out, int64_t ld_out,
+                                       void* stream) {
+  NVMK_REQUIRE(metric == NVMK_METRIC_TANIMOTO || metric == NVMK_METRIC_COSINE, "unknown metric %d", metric);
+  NVMK_REQUIRE(fp_bits > 0 && fp_bits % 32 == 0, "fp_bits must be a positive multiple of 32, got %d", fp_bits);
+  NVMK_REQUIRE(nA_total >= 0 && nB >= 0 && a_row0 >= 0 && a_rows >= 0 && a_row0 + a_rows <= nA_total,
+               "bad row range [%lld, +%lld) of %lld", (long long)a_row0, (long long)a_rows, (long long)nA_total);
+  NVMK_REQUIRE(a_row0 % nvmk::fp4::ROW_PAD == 0, "a_row0 must be a multiple of %d", nvmk::fp4::ROW_PAD);
+  if (a_rows == 0 || nB == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_ws_a && d_ws_b && d_out, "NULL buffer");
+  nvmk::fp4::Prepared A = nvmk::fp4::view(d_ws_a, nA_total, fp_bits);
+  A.popc += a_row0;
+  A.rows += a_row0 * A.L.Wp;
+  A.L.n    = a_rows;
+  A.L.nPad = (a_rows + nvmk::fp4::ROW_PAD - 1) / nvmk::fp4::ROW_PAD * nvmk::fp4::ROW_PAD;
+  return nvmk::fp4::launch_dense(metric, A, nvmk::fp4::view(d_ws_b, nB, fp_bits), d_out, ld_out, nvmk::as_stream(stream));
+}
+
+}  // extern "C"

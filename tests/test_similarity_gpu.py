@@ -14,6 +14,14 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["valu", "mfma", "auto"], autouse=True)
+def sim_path(request, monkeypatch):
+    """Every parity case runs on the VALU popcount kernel, on the FP4 matrix-core kernel, and on the
+    library's automatic choice (NVMK_SIM_PATH is read by nvmolkit_amd/csrc/similarity.hip per call)."""
+    monkeypatch.setenv("NVMK_SIM_PATH", request.param)
+    return request.param
+
 FUNCS = {"tanimoto": (crossTanimotoSimilarity, oracle.TANIMOTO), "cosine": (crossCosineSimilarity, oracle.COSINE)}
 
 
@@ -148,3 +156,28 @@ def test_full_size_properties_2048bit():
     rows = np.arange(0, n, 97)
     want = oracle.cross_similarity(a[rows], a)
     assert np.array_equal(t[torch.from_numpy(rows).cuda()].cpu().numpy(), want)
+
+
+def test_prepared_set_api_row_chunks(native_lib):
+    """nvmk_fp4_prepare + nvmk_cross_similarity_prepared_f64 on row chunks == one-shot oracle matrix."""
+    from nvmolkit_amd import _native
+
+    a = util.clustered_fingerprints(1000, 64, 30, seed=31)
+    b = util.clustered_fingerprints(777, 64, 30, seed=32)
+    xa, xb = dev(a), dev(b)
+    wa = torch.empty(native_lib.nvmk_fp4_workspace_bytes(len(a), 2048), dtype=torch.uint8, device="cuda")
+    wb = torch.empty(native_lib.nvmk_fp4_workspace_bytes(len(b), 2048), dtype=torch.uint8, device="cuda")
+    sptr = _native.stream_ptr(None)
+    _native.check(native_lib.nvmk_fp4_prepare(xa.data_ptr(), len(a), 2048, wa.data_ptr(), sptr))
+    _native.check(native_lib.nvmk_fp4_prepare(xb.data_ptr(), len(b), 2048, wb.data_ptr(), sptr))
+    want = oracle.cross_similarity(a, b)
+    for chunk in (128, 384):
+        out = torch.full((len(a), len(b)), -1.0, dtype=torch.float64, device="cuda")
+        for r0 in range(0, len(a), chunk):
+            rows = min(chunk, len(a) - r0)
+            _native.check(native_lib.nvmk_cross_similarity_prepared_f64(0, wa.data_ptr(), len(a), r0, rows, wb.data_ptr(),
+                                                                        len(b), 2048, out[r0].data_ptr(), len(b), sptr))
+        assert np.array_equal(out.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        _native.check(native_lib.nvmk_cross_similarity_prepared_f64(0, wa.data_ptr(), len(a), 5, 10, wb.data_ptr(), len(b),
+                                                                    2048, out.data_ptr(), len(b), sptr))
