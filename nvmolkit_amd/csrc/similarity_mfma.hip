@@ -13,6 +13,8 @@
 // which nibble carries which k is irrelevant because both operands use the same expansion.
 // LDS rows are XOR-swizzled in 16-byte slots by (row & 15): every ds_read_b128 lane group touches 16
 // different slots of the 256-byte bank row (rows 0-3, 12-15, 20-27 -> row & 15 all distinct).
+#include <cstdlib>
+
 #include "fp4.h"
 
 namespace nvmk {
@@ -20,12 +22,10 @@ namespace fp4 {
 
 namespace {
 
-constexpr int TM  = 128;
-constexpr int TN  = 128;
-constexpr int NT  = 256;
-constexpr int KCW = WORD_PAD;       // words per chunk
-constexpr int CHUNK_ROW_BYTES = KCW * 16;  // 256
-constexpr int GROUP_TM = 64;        // tile-rows per scheduling group (see similarity.hip)
+constexpr int TM       = 128;
+constexpr int TN       = 128;
+constexpr int NT       = 256;
+constexpr int GROUP_TM = 64;  // tile-rows per scheduling group (see similarity.hip)
 
 typedef int   v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -71,53 +71,42 @@ __device__ __forceinline__ v16f mfma_fp4(const uint4 a, const uint4 b, const v16
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
-template <int METRIC> __device__ __forceinline__ double finish(const int c, const int pa, const int pb) {
-  if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-    const int u = pa + pb - c;
-    return static_cast<double>(c) / static_cast<double>(u > 1 ? u : 1);
-  } else {
-    const double denom = sqrt(static_cast<double>(pa) * static_cast<double>(pb));
-    return (c == 0 || denom == 0.0) ? 0.0 : static_cast<double>(c) / denom;
+// Geometry of one LDS K-chunk of KCW words: KCW 16-byte slots per row, XOR-swizzled so that the 16 lanes
+// of a ds_read_b128 lane group (16 rows with distinct row & 15) land on 16 different slots of the
+// 256-byte bank row.  KCW = 16: one row per bank row, slot ^= row & 15.  KCW = 8: two rows per bank row
+// (row & 1 picks the half), slot ^= (row >> 1) & 7.
+template <int KCW> struct Chunk {
+  static constexpr int ROWBYTES = KCW * 16;
+  static constexpr int LOG      = (KCW == 16) ? 4 : 3;
+  static constexpr int T        = TM * KCW / NT;  // 16-byte pieces per thread per operand
+  __device__ static __forceinline__ unsigned swz(const unsigned row) {
+    return (KCW == 16) ? (row & 15u) : ((row >> 1) & 7u);
   }
-}
-
-// Stage one 128-row x 256-byte chunk: 8 x 16 B per thread, held in 8 NAMED registers per operand.
-// (Arrays indexed inside unrolled helper loops ended up in scratch memory with this compiler —
-// 272 B/lane and a store/reload of the whole prefetch per chunk — hence the X-macro spelling.)
-#define NVMK_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-#define NVMK_DECL_STAGE(P) uint4 P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7
-#define NVMK_FETCH_ONE(P, base, t) P##t = (base)[static_cast<int64_t>((tid + (t)*NT) >> 4) * Wp + ((tid + (t)*NT) & 15)];
-#define NVMK_FETCH(P, base)                                                                    \
-  NVMK_FETCH_ONE(P, base, 0) NVMK_FETCH_ONE(P, base, 1) NVMK_FETCH_ONE(P, base, 2) NVMK_FETCH_ONE(P, base, 3) \
-  NVMK_FETCH_ONE(P, base, 4) NVMK_FETCH_ONE(P, base, 5) NVMK_FETCH_ONE(P, base, 6) NVMK_FETCH_ONE(P, base, 7)
-#define NVMK_COMMIT_ONE(P, lds, t)                                                                       \
-  *reinterpret_cast<uint4*>((lds) + ((tid + (t)*NT) >> 4) * CHUNK_ROW_BYTES +                              \
-                            (((((tid + (t)*NT) & 15)) ^ (((tid + (t)*NT) >> 4) & 15)) << 4)) = P##t;
-#define NVMK_COMMIT(P, lds)                                                                          \
-  NVMK_COMMIT_ONE(P, lds, 0) NVMK_COMMIT_ONE(P, lds, 1) NVMK_COMMIT_ONE(P, lds, 2) NVMK_COMMIT_ONE(P, lds, 3) \
-  NVMK_COMMIT_ONE(P, lds, 4) NVMK_COMMIT_ONE(P, lds, 5) NVMK_COMMIT_ONE(P, lds, 6) NVMK_COMMIT_ONE(P, lds, 7)
+};
 
 // One K chunk of MFMAs for this wave's 64 x 64 tile.
+template <int KCW>
 __device__ __forceinline__ void chunk_mma(v16f (&acc)[2][2], const char* sA, const char* sB, const int wm, const int wn,
                                           const int lane) {
-  const int      l31   = lane & 31;
-  const int      half  = lane >> 5;
-  const unsigned rowA0 = static_cast<unsigned>(wm * 64 + l31);
-  const unsigned rowB0 = static_cast<unsigned>(wn * 64 + l31);
-  // rows +32 keep (row & 15), so one swizzle term serves both blocks of an operand
-  const unsigned baseA = rowA0 * CHUNK_ROW_BYTES;
-  const unsigned baseB = rowB0 * CHUNK_ROW_BYTES;
-  const unsigned swA   = rowA0 & 15;
-  const unsigned swB   = rowB0 & 15;
+  using C               = Chunk<KCW>;
+  const int      l31    = lane & 31;
+  const unsigned half   = static_cast<unsigned>(lane >> 5);
+  const unsigned rowA0  = static_cast<unsigned>(wm * 64 + l31);
+  const unsigned rowB0  = static_cast<unsigned>(wn * 64 + l31);
+  // rows +32 keep the swizzle term, so one term serves both blocks of an operand
+  const unsigned baseA  = rowA0 * C::ROWBYTES;
+  const unsigned baseB  = rowB0 * C::ROWBYTES;
+  const unsigned swA    = C::swz(rowA0);
+  const unsigned swB    = C::swz(rowB0);
 #pragma unroll
   for (int ks = 0; ks < KCW / 2; ++ks) {
-    const unsigned slot = static_cast<unsigned>(ks * 2 + half);
+    const unsigned slot = static_cast<unsigned>(ks * 2) + half;
     const unsigned offA = baseA + ((slot ^ swA) << 4);
     const unsigned offB = baseB + ((slot ^ swB) << 4);
     const uint4    a0   = *reinterpret_cast<const uint4*>(sA + offA);
-    const uint4    a1   = *reinterpret_cast<const uint4*>(sA + offA + 32 * CHUNK_ROW_BYTES);
+    const uint4    a1   = *reinterpret_cast<const uint4*>(sA + offA + 32 * C::ROWBYTES);
     const uint4    b0   = *reinterpret_cast<const uint4*>(sB + offB);
-    const uint4    b1   = *reinterpret_cast<const uint4*>(sB + offB + 32 * CHUNK_ROW_BYTES);
+    const uint4    b1   = *reinterpret_cast<const uint4*>(sB + offB + 32 * C::ROWBYTES);
     acc[0][0]           = mfma_fp4(a0, b0, acc[0][0]);
     acc[0][1]           = mfma_fp4(a0, b1, acc[0][1]);
     acc[1][0]           = mfma_fp4(a1, b0, acc[1][0]);
@@ -125,17 +114,74 @@ __device__ __forceinline__ void chunk_mma(v16f (&acc)[2][2], const char* sA, con
   }
 }
 
-template <int METRIC>
+// Staging registers are NAMED scalars (arrays indexed in helper loops were kept in scratch memory by
+// this compiler: 272 B/lane and a store/reload of the whole prefetch per chunk).
+#define NVMK_STAGE_DECL(P) uint4 P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7
+#define NVMK_PIECE_ROW(t) ((tid + (t)*NT) >> C::LOG)
+#define NVMK_PIECE_SLOT(t) ((tid + (t)*NT) & (KCW - 1))
+#define NVMK_FETCH_ONE(P, base, t) \
+  if ((t) < C::T) P##t = (base)[static_cast<int64_t>(NVMK_PIECE_ROW(t)) * Wp + NVMK_PIECE_SLOT(t)];
+#define NVMK_FETCH(P, base)                                                                                \
+  NVMK_FETCH_ONE(P, base, 0) NVMK_FETCH_ONE(P, base, 1) NVMK_FETCH_ONE(P, base, 2) NVMK_FETCH_ONE(P, base, 3) \
+  NVMK_FETCH_ONE(P, base, 4) NVMK_FETCH_ONE(P, base, 5) NVMK_FETCH_ONE(P, base, 6) NVMK_FETCH_ONE(P, base, 7)
+#define NVMK_COMMIT_ONE(P, lds, t)                                                         \
+  if ((t) < C::T)                                                                          \
+    *reinterpret_cast<uint4*>((lds) + NVMK_PIECE_ROW(t) * C::ROWBYTES +                      \
+                              ((NVMK_PIECE_SLOT(t) ^ C::swz(NVMK_PIECE_ROW(t))) << 4)) = P##t;
+#define NVMK_COMMIT(P, lds)                                                                                \
+  NVMK_COMMIT_ONE(P, lds, 0) NVMK_COMMIT_ONE(P, lds, 1) NVMK_COMMIT_ONE(P, lds, 2) NVMK_COMMIT_ONE(P, lds, 3) \
+  NVMK_COMMIT_ONE(P, lds, 4) NVMK_COMMIT_ONE(P, lds, 5) NVMK_COMMIT_ONE(P, lds, 6) NVMK_COMMIT_ONE(P, lds, 7)
+
+// Shared main loop: accumulates this workgroup's 128 x 128 tile of intersection counts.
+#define NVMK_MFMA_MAINLOOP(A, B, rowA0, rowB0)                                               \
+  NVMK_STAGE_DECL(ra);                                                                       \
+  NVMK_STAGE_DECL(rb);                                                                       \
+  {                                                                                          \
+    const uint4* gA = (A) + (rowA0)*Wp;                                                      \
+    const uint4* gB = (B) + (rowB0)*Wp;                                                      \
+    const int    nChunks = Wp / KCW;                                                         \
+    NVMK_FETCH(ra, gA)                                                                       \
+    NVMK_FETCH(rb, gB)                                                                       \
+    for (int ch = 0; ch < nChunks; ++ch) {                                                   \
+      if (ch > 0) __syncthreads();                                                           \
+      NVMK_COMMIT(ra, sA)                                                                    \
+      NVMK_COMMIT(rb, sB)                                                                    \
+      __syncthreads();                                                                       \
+      if (ch + 1 < nChunks) { /* next chunk's global loads fly under this chunk's MFMAs */   \
+        NVMK_FETCH(ra, gA + (ch + 1) * KCW)                                                  \
+        NVMK_FETCH(rb, gB + (ch + 1) * KCW)                                                  \
+      }                                                                                      \
+      chunk_mma<KCW>(acc, sA, sB, wm, wn, lane);                                             \
+    }                                                                                        \
+  }
+
+// Tanimoto ratio c / u for integers 0 <= c <= u via a table of correctly rounded reciprocals and one
+// fma correction step: q0 = c * r, e = fma(-q0, u, c), q = fma(e, r, q0).  Equal to the IEEE division
+// for every 1 <= u <= 16384 (exhaustive check: oracle_similarity.c orc_check_reciprocal_division and
+// tests/test_oracle_similarity.py); 5 double ops instead of the ~13 of v_div_scale/v_rcp/v_div_fmas.
+__device__ __forceinline__ double ratio_by_table(const int c, const int u, const double* rtab) {
+  const double r  = rtab[u];
+  const double cd = static_cast<double>(c);
+  const double ud = static_cast<double>(u);
+  const double q0 = __dmul_rn(cd, r);
+  const double e  = __fma_rn(-q0, ud, cd);
+  return __fma_rn(e, r, q0);
+}
+
+template <int KCW, int METRIC, bool TABLE>
 __global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __restrict__ A, const int32_t* __restrict__ popA,
                                                                const int64_t nA, const uint4* __restrict__ B,
                                                                const int32_t* __restrict__ popB, const int64_t nB,
-                                                               const int Wp, double* __restrict__ out, const int64_t ld,
-                                                               const unsigned tilesM, const unsigned tilesN) {
-  __shared__ __attribute__((aligned(16))) char smem[(TM + TN) * CHUNK_ROW_BYTES + (TM + TN) * 4];
-  char* sA  = smem;
-  char* sB  = smem + TM * CHUNK_ROW_BYTES;
-  int*  pcA = reinterpret_cast<int*>(smem + (TM + TN) * CHUNK_ROW_BYTES);
-  int*  pcB = pcA + TM;
+                                                               const int Wp, const int F, double* __restrict__ out,
+                                                               const int64_t ld, const unsigned tilesM,
+                                                               const unsigned tilesN) {
+  using C = Chunk<KCW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char*   sA   = smem;
+  char*   sB   = smem + TM * C::ROWBYTES;
+  int*    pcA  = reinterpret_cast<int*>(smem + (TM + TN) * C::ROWBYTES);
+  int*    pcB  = pcA + TM;
+  double* rtab = reinterpret_cast<double*>(pcB + TN);  // [F + 1], TABLE only
 
   const unsigned firstM = blockIdx.y * GROUP_TM;
   const unsigned remM   = tilesM - firstM;
@@ -151,12 +197,14 @@ __global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __re
   const int     wn    = wave & 1;
   const int64_t rowA0 = static_cast<int64_t>(tile_m) * TM;
   const int64_t rowB0 = static_cast<int64_t>(tile_n) * TN;
-  const int     nChunks = Wp / KCW;
 
   if (tid < TM) {
     pcA[tid] = popA[rowA0 + tid];
   } else {
     pcB[tid - TM] = popB[rowB0 + tid - TM];
+  }
+  if constexpr (TABLE) {
+    for (int u = tid; u <= F; u += NT) rtab[u] = 1.0 / static_cast<double>(u > 1 ? u : 1);
   }
 
   v16f acc[2][2];
@@ -169,23 +217,7 @@ __global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __re
     }
   }
 
-  NVMK_DECL_STAGE(ra);
-  NVMK_DECL_STAGE(rb);
-  const uint4* gA = A + rowA0 * Wp;  // chunk c of this tile starts at gA + c * KCW
-  const uint4* gB = B + rowB0 * Wp;
-  NVMK_FETCH(ra, gA)
-  NVMK_FETCH(rb, gB)
-  for (int ch = 0; ch < nChunks; ++ch) {
-    if (ch > 0) __syncthreads();
-    NVMK_COMMIT(ra, sA)
-    NVMK_COMMIT(rb, sB)
-    __syncthreads();
-    if (ch + 1 < nChunks) {  // next chunk's global loads fly under this chunk's MFMAs
-      NVMK_FETCH(ra, gA + (ch + 1) * KCW)
-      NVMK_FETCH(rb, gB + (ch + 1) * KCW)
-    }
-    chunk_mma(acc, sA, sB, wm, wn, lane);
-  }
+  NVMK_MFMA_MAINLOOP(A, B, rowA0, rowB0)
 
   // epilogue: D[i][j], i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), j = lane & 31 inside each 32 x 32 block
   const bool full = (rowA0 + TM <= nA) && (rowB0 + TN <= nB);
@@ -200,7 +232,21 @@ __global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __re
       for (int r = 0; r < 16; ++r) {
         const int     il  = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int64_t row = rowA0 + il;
-        const double  v   = finish<METRIC>(static_cast<int>(acc[mi][ni][r]), pcA[il], pbv);
+        const int     c   = static_cast<int>(acc[mi][ni][r]);
+        const int     pav = pcA[il];
+        double        v;
+        if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+          const int u  = pav + pbv - c;
+          const int u1 = u > 1 ? u : 1;
+          if constexpr (TABLE) {
+            v = ratio_by_table(c, u1, rtab);
+          } else {
+            v = static_cast<double>(c) / static_cast<double>(u1);
+          }
+        } else {
+          const double denom = sqrt(static_cast<double>(pav) * static_cast<double>(pbv));
+          v                  = (c == 0 || denom == 0.0) ? 0.0 : static_cast<double>(c) / denom;
+        }
         if (full || (row < nA && col < nB)) {
           __builtin_nontemporal_store(v, out + row * ld + col);
         }
@@ -227,6 +273,22 @@ int prepare(const uint32_t* d_in, const int32_t* d_rows, int64_t n, int fpBits, 
   return NVMK_OK;
 }
 
+template <int KCW, int METRIC, bool TABLE>
+int launch_dense_t(const Prepared& A, const Prepared& B, double* out, int64_t ld, dim3 grid, unsigned tilesM,
+                   unsigned tilesN, hipStream_t stream) {
+  const int    F     = A.L.W * 32;
+  const size_t shmem = static_cast<size_t>(TM + TN) * KCW * 16 + (TM + TN) * 4 + (TABLE ? (static_cast<size_t>(F) + 1) * 8 : 0);
+  auto         kern  = cross_sim_mfma_kernel<KCW, METRIC, TABLE>;
+  if (shmem > 64 * 1024) {
+    NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(shmem)));
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NT), shmem, stream, A.rows, A.popc, A.L.n, B.rows, B.popc, B.L.n, A.L.Wp, F, out, ld,
+                     tilesM, tilesN);
+  NVMK_LAUNCH_CHECK();
+  return NVMK_OK;
+}
+
 int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, int64_t ld, hipStream_t stream) {
   if (A.L.n == 0 || B.L.n == 0) return NVMK_OK;
   NVMK_REQUIRE(A.L.Wp == B.L.Wp && A.L.W == B.L.W, "prepared sets have different fingerprint widths");
@@ -237,16 +299,22 @@ int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, 
   NVMK_REQUIRE(groups <= 65535 && GROUP_TM * tilesN <= 0x7fffffffLL,
                "cross similarity: problem too large for one launch (%lld x %lld tiles)", (long long)tilesM,
                (long long)tilesN);
-  const dim3 grid(static_cast<unsigned>(GROUP_TM * tilesN), static_cast<unsigned>(groups));
+  const dim3     grid(static_cast<unsigned>(GROUP_TM * tilesN), static_cast<unsigned>(groups));
+  const unsigned tm = static_cast<unsigned>(tilesM), tn = static_cast<unsigned>(tilesN);
+  // K-chunk of 8 words: 32 KB of operand tiles + the reciprocal table -> 3 workgroups per CU.
+  // NVMK_MFMA_KCW=16 selects the 16-word chunk (2 workgroups per CU) for A/B experiments.
+  static const int kcw = [] {
+    const char* e = std::getenv("NVMK_MFMA_KCW");
+    return (e != nullptr && std::atoi(e) == 16) ? 16 : 8;
+  }();
+  const bool table = (A.L.W * 32 <= 8192);  // table is 8 (F + 1) bytes of LDS; validated exhaustively up to u = 16384
   if (metric == NVMK_METRIC_TANIMOTO) {
-    hipLaunchKernelGGL(cross_sim_mfma_kernel<NVMK_METRIC_TANIMOTO>, grid, dim3(NT), 0, stream, A.rows, A.popc, A.L.n, B.rows,
-                       B.popc, B.L.n, A.L.Wp, out, ld, static_cast<unsigned>(tilesM), static_cast<unsigned>(tilesN));
-  } else {
-    hipLaunchKernelGGL(cross_sim_mfma_kernel<NVMK_METRIC_COSINE>, grid, dim3(NT), 0, stream, A.rows, A.popc, A.L.n, B.rows,
-                       B.popc, B.L.n, A.L.Wp, out, ld, static_cast<unsigned>(tilesM), static_cast<unsigned>(tilesN));
+    if (kcw == 16) return launch_dense_t<16, NVMK_METRIC_TANIMOTO, false>(A, B, out, ld, grid, tm, tn, stream);
+    return table ? launch_dense_t<8, NVMK_METRIC_TANIMOTO, true>(A, B, out, ld, grid, tm, tn, stream) :
+                   launch_dense_t<8, NVMK_METRIC_TANIMOTO, false>(A, B, out, ld, grid, tm, tn, stream);
   }
-  NVMK_LAUNCH_CHECK();
-  return NVMK_OK;
+  if (kcw == 16) return launch_dense_t<16, NVMK_METRIC_COSINE, false>(A, B, out, ld, grid, tm, tn, stream);
+  return launch_dense_t<8, NVMK_METRIC_COSINE, false>(A, B, out, ld, grid, tm, tn, stream);
 }
 
 }  // namespace fp4

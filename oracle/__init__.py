@@ -81,6 +81,8 @@ def _declare(L: ctypes.CDLL) -> None:
     L.orc_butina_dense.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, _i32p,
                                    ctypes.c_void_p]
     L.orc_butina_dense.restype = ctypes.c_int64
+    L.orc_check_reciprocal_division.argtypes = [ctypes.c_int]
+    L.orc_check_reciprocal_division.restype = ctypes.c_int64
 
 
 def _as_u32(x) -> np.ndarray:
@@ -124,6 +126,11 @@ def neighbor_counts(x, y, threshold: float, sign: int = 1, metric: int = TANIMOT
         counts = np.zeros(x.shape[0], dtype=np.int32)
     lib().orc_neighbor_counts(metric, x, x.shape[0], y, y.shape[0], x.shape[1], np.float32(threshold), sign, counts)
     return counts
+
+
+def check_reciprocal_division(umax: int) -> int:
+    """Number of (c, u) pairs where the table-reciprocal division differs from IEEE c / u (must be 0)."""
+    return int(lib().orc_check_reciprocal_division(int(umax)))
 
 
 def butina_fused(x, cutoff: float, metric: int = TANIMOTO):

@@ -309,3 +309,29 @@ int64_t orc_butina_dense(const double* dist, const uint8_t* hit_in, int64_t N, d
   free(remap);
   return nC;
 }
+
+/*
+ * Exhaustive check of the reciprocal-table division used by the HIP epilogue (not reference
+ * arithmetic: it validates an implementation shortcut against IEEE division).
+ *   r  = RN(1 / u)                    (table entry, computed with a real division)
+ *   q0 = RN(c * r);  e = fma(-q0, u, c);  q = fma(e, r, q0)
+ * Returns the number of (c, u) pairs, 0 <= c <= u, 1 <= u <= umax, for which q != (double)c / (double)u.
+ */
+int64_t orc_check_reciprocal_division(int umax) {
+  int64_t bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : bad)
+#endif
+  for (int u = 1; u <= umax; ++u) {
+    const double ud = (double)u;
+    const double r  = 1.0 / ud;
+    for (int c = 0; c <= u; ++c) {
+      const double cd = (double)c;
+      const double q0 = cd * r;
+      const double e  = fma(-q0, ud, cd);
+      const double q  = fma(e, r, q0);
+      if (q != cd / ud) ++bad;
+    }
+  }
+  return bad;
+}
