@@ -21,7 +21,11 @@
 #include <algorithm>
 #include <vector>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
+#include "fp4.h"
 
 namespace nvmk {
 namespace butina {
@@ -59,10 +63,10 @@ template <int METRIC> __device__ __forceinline__ bool is_neighbor(const int c, c
 }
 
 // tmin[s], s = pa + pb in [0, 2*F]: smallest c with float(c)/float(s-c) >= thr (NEVER if none);
-// entries (2F, 3F+1] are NEVER so that a sentinel popcount of 2F+1 disables a padded column.
+// entries (2F, 4F+2] are NEVER so that a sentinel popcount of 2F+1 disables a padded row or column.
 __global__ void build_tanimoto_table_kernel(uint16_t* __restrict__ table, const int F, const float thr) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s > 3 * F + 1) return;
+  if (s > 4 * F + 2) return;
   uint16_t v = NEVER;
   if (s >= 1 && s <= 2 * F) {
     // predicate is monotone non-decreasing in c on [0, s-1]
@@ -311,6 +315,15 @@ __global__ __launch_bounds__(NT) void neighbor_count_generic_kernel(const uint32
   if (lane == 0 && n != 0) atomicAdd(&counts[px], sign * n);
 }
 
+inline bool force_valu() {
+  const char* e = std::getenv("NVMK_SIM_PATH");
+  return e != nullptr && std::strcmp(e, "valu") == 0;
+}
+inline bool force_mfma() {
+  const char* e = std::getenv("NVMK_SIM_PATH");
+  return e != nullptr && std::strcmp(e, "mfma") == 0;
+}
+
 struct CountPlan {
   int             metric;
   int             fpBits;
@@ -377,7 +390,7 @@ int make_plan(CountPlan& plan, StreamScratch& tableMem, int metric, int fpBits, 
   plan.thr    = thr;
   plan.table  = nullptr;
   if (metric == NVMK_METRIC_TANIMOTO) {
-    const int entries = 3 * fpBits + 2;
+    const int entries = 4 * fpBits + 3;
     NVMK_HIP_CHECK(tableMem.alloc(static_cast<size_t>(entries) * sizeof(uint16_t), stream));
     hipLaunchKernelGGL(build_tanimoto_table_kernel, dim3(ceil_div(entries, 256)), dim3(256), 0, stream,
                        tableMem.as<uint16_t>(), fpBits, thr);
@@ -568,8 +581,39 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
                      N);
   NVMK_LAUNCH_CHECK();
 
-  // first pass: all-vs-all degrees
-  rc = launch_counts(plan, d_x, nullptr, N, nullptr, d_x, nullptr, N, nullptr, +1, counts, stream);
+  // Matrix-core path: expand the whole set to FP4 once (4x the packed bytes); every counting pass then
+  // gathers rows of it through the alive / removed index lists.  NVMK_SIM_PATH=valu keeps the v_bcnt kernels.
+  const bool    useMfma = !force_valu() && (force_mfma() || N >= 2048);
+  StreamScratch fp4Mem;
+  fp4::Prepared PX{};
+  if (useMfma) {
+    NVMK_HIP_CHECK(fp4Mem.alloc(fp4::layout(N, fpBits).bytes, stream));
+    rc = fp4::prepare(d_x, nullptr, N, fpBits, fp4Mem.ptr, stream);
+    if (rc != NVMK_OK) return rc;
+    PX = fp4::view(fp4Mem.ptr, N, fpBits);
+  }
+  auto count_pass = [&](const int32_t* xRows, int64_t nX, const int32_t* nXdev, const int32_t* yRows, int64_t nY,
+                        const int32_t* nYdev, int sign, bool symmetric) -> int {
+    if (useMfma) {
+      fp4::CountArgs a{};
+      a.metric    = METRIC;
+      a.thr       = thr;
+      a.table     = plan.table;
+      a.sign      = sign;
+      a.xRows     = xRows;
+      a.nX        = nX;
+      a.nXdev     = nXdev;
+      a.yRows     = yRows;
+      a.nY        = nY;
+      a.nYdev     = nYdev;
+      a.symmetric = symmetric;
+      return fp4::launch_counts(a, PX, PX, counts, stream);
+    }
+    return launch_counts(plan, d_x, xRows, nX, nXdev, d_x, yRows, nY, nYdev, sign, counts, stream);
+  };
+
+  // first pass: all-vs-all degrees (upper triangle of tiles only on the matrix-core path)
+  rc = count_pass(nullptr, N, nullptr, nullptr, N, nullptr, +1, true);
   if (rc != NVMK_OK) return rc;
 
   // round loop, enqueued in batches; the host only reads the state word between batches
@@ -594,8 +638,7 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
       hipLaunchKernelGGL(finish_round_kernel, dim3(1), dim3(1), 0, stream, st, &nAliveNext[parity], offsets, centroids,
                          parity);
       // subtract the removed members' contribution from the survivors (device-side sizes)
-      rc = launch_counts(plan, d_x, aliveOut, aliveHost, &st->nAlive, d_x, removed, maxDegree, &st->nRemoved, -1,
-                         counts, stream);
+      rc = count_pass(aliveOut, aliveHost, &st->nAlive, removed, maxDegree, &st->nRemoved, -1, false);
       if (rc != NVMK_OK) return rc;
       hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, stream, st, &nAliveNext[parity ^ 1]);
       NVMK_LAUNCH_CHECK();
@@ -803,7 +846,29 @@ int nvmk_neighbor_counts(int metric, const uint32_t* d_x, const int32_t* d_x_row
   CountPlan     plan;
   const int     rc = make_plan(plan, tableMem, metric, fp_bits, threshold, as_stream(stream));
   if (rc != NVMK_OK) return rc;
-  return launch_counts(plan, d_x, d_x_rows, nX, nullptr, d_y, d_y_rows, nY, nullptr, sign, d_counts, as_stream(stream));
+  hipStream_t  s       = as_stream(stream);
+  const double pairs   = static_cast<double>(nX) * static_cast<double>(nY);
+  const bool   useMfma = !force_valu() && (force_mfma() || (pairs >= 4.0e6 && nX >= 64 && nY >= 64));
+  if (!useMfma) {
+    return launch_counts(plan, d_x, d_x_rows, nX, nullptr, d_y, d_y_rows, nY, nullptr, sign, d_counts, s);
+  }
+  // gather + expand both operands into compact prepared sets; counts stay indexed by the caller's row ids
+  StreamScratch wsX, wsY;
+  NVMK_HIP_CHECK(wsX.alloc(fp4::layout(nX, fp_bits).bytes, s));
+  NVMK_HIP_CHECK(wsY.alloc(fp4::layout(nY, fp_bits).bytes, s));
+  int rc2 = fp4::prepare(d_x, d_x_rows, nX, fp_bits, wsX.ptr, s);
+  if (rc2 != NVMK_OK) return rc2;
+  rc2 = fp4::prepare(d_y, d_y_rows, nY, fp_bits, wsY.ptr, s);
+  if (rc2 != NVMK_OK) return rc2;
+  fp4::CountArgs a{};
+  a.metric = metric;
+  a.thr    = threshold;
+  a.table  = plan.table;
+  a.sign   = sign;
+  a.xIds   = d_x_rows;
+  a.nX     = nX;
+  a.nY     = nY;
+  return fp4::launch_counts(a, fp4::view(wsX.ptr, nX, fp_bits), fp4::view(wsY.ptr, nY, fp_bits), d_counts, s);
 }
 
 int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, double cutoff,

@@ -63,17 +63,22 @@ int prepare(const uint32_t* d_in, const int32_t* d_rows, int64_t n, int fpBits, 
 // Dense similarity on prepared sets.  metric = NVMK_METRIC_*.
 int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, int64_t ld, hipStream_t stream);
 
-// counts[row] += sign * #neighbours for prepared x against prepared y.  xIds/yIds map tile rows to the
-// caller's row ids for the counts array (NULL = identity).  `symmetric`: x and y are the same set and
-// only the upper triangle of tiles is evaluated, both row and column counts are credited.
+// counts[id(x row)] += sign * #{ y rows that are neighbours } on prepared sets (matrix-core twin of
+// butina.hip's neighbor_count_kernel).  Rows may be gathered through index lists (NULL = identity); the
+// counts array is indexed by the PHYSICAL row id.  `symmetric`: x and y are the same un-gathered set, only
+// tiles on or above the diagonal are evaluated and off-diagonal tiles credit both their rows and columns.
 struct CountArgs {
   int             metric;
   float           thr;
-  const uint16_t* table;     // Tanimoto threshold table (see butina.hip), device
-  int             fpBits;
+  const uint16_t* table;    // Tanimoto threshold table with 4F + 3 entries (butina.hip), device
   int             sign;
-  const int32_t*  xIds;      // counts index of x row r (NULL: r)
-  const int32_t*  nXdev;     // optional device-side row counts
+  const int32_t*  xRows;    // logical -> physical row of X (NULL: identity)
+  const int32_t*  xIds;     // logical row -> index into counts (NULL: the physical row)
+  int64_t         nX;       // logical rows of x (host-side upper bound when nXdev is set)
+  const int32_t*  nXdev;    // optional device-side row count
+  const int32_t*  yRows;
+  const int32_t*  yIds;     // used in symmetric mode only (column credits)
+  int64_t         nY;
   const int32_t*  nYdev;
   bool            symmetric;
 };

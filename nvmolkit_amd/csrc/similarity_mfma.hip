@@ -13,6 +13,7 @@
 // which nibble carries which k is irrelevant because both operands use the same expansion.
 // LDS rows are XOR-swizzled in 16-byte slots by (row & 15): every ds_read_b128 lane group touches 16
 // different slots of the 256-byte bank row (rows 0-3, 12-15, 20-27 -> row & 15 all distinct).
+#include <algorithm>
 #include <cstdlib>
 
 #include "fp4.h"
@@ -260,6 +261,195 @@ __global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __re
   }
 }
 
+
+// ---- neighbour counting on the matrix cores ------------------------------------------------------
+// Same main loop as the dense kernel (8-word chunks), but the epilogue thresholds the exact counts with
+// the Tanimoto table tmin[pa + pb] (see butina.hip) and reduces them to per-row (and, in symmetric mode,
+// per-column) neighbour counts: registers -> 32-lane shuffle reduction -> LDS -> one global atomic per row.
+// Rows are gathered through optional index lists so the Butina loop never compacts the fingerprint matrix.
+
+__device__ __forceinline__ bool cosine_neighbor(const int c, const int pa, const int pb, const float thr) {
+  const float denom = sqrtf(static_cast<float>(pa) * static_cast<float>(pb));
+  if (!(denom > 0.0f)) return false;
+  return static_cast<float>(c) / denom >= thr;
+}
+
+#define NVMK_FETCH4(P, base, o, k)  \
+  P##0 = (base)[o##0 + (k)];        \
+  P##1 = (base)[o##1 + (k)];        \
+  P##2 = (base)[o##2 + (k)];        \
+  P##3 = (base)[o##3 + (k)];
+#define NVMK_COMMIT4(P, lds) NVMK_COMMIT_ONE(P, lds, 0) NVMK_COMMIT_ONE(P, lds, 1) NVMK_COMMIT_ONE(P, lds, 2) NVMK_COMMIT_ONE(P, lds, 3)
+
+template <int METRIC>
+__global__ __launch_bounds__(NT, 2) void neighbor_count_mfma_kernel(
+  const uint4* __restrict__ X, const int32_t* __restrict__ popX, const int32_t* __restrict__ xRows,
+  const int32_t* __restrict__ xIds, int64_t nX,
+  const int32_t* __restrict__ nXdev, const uint4* __restrict__ Y, const int32_t* __restrict__ popY,
+  const int32_t* __restrict__ yRows, const int32_t* __restrict__ yIds, int64_t nY, const int32_t* __restrict__ nYdev, const int Wp, const int F,
+  const uint16_t* __restrict__ table, const float thr, const int sign, const int symmetric, int32_t* __restrict__ counts, const unsigned superN) {
+  constexpr int KCW = 8;
+  using C           = Chunk<KCW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char*     sA     = smem;
+  char*     sB     = smem + TM * C::ROWBYTES;
+  int*      pcA    = reinterpret_cast<int*>(smem + (TM + TN) * C::ROWBYTES);
+  int*      pcB    = pcA + TM;
+  int*      idA    = pcB + TN;
+  int*      idB    = idA + TM;
+  int*      cidA   = idB + TN;   // counts index of each row
+  int*      cidB   = cidA + TM;
+  int*      rowsum = cidB + TN;
+  int*      colsum = rowsum + TM;
+  uint16_t* sTab   = reinterpret_cast<uint16_t*>(colsum + TN);
+
+  if (nXdev) nX = *nXdev;
+  if (nYdev) nY = *nYdev;
+  const unsigned tilesM = static_cast<unsigned>((nX + TM - 1) / TM);
+  const unsigned tilesN = static_cast<unsigned>((nY + TN - 1) / TN);
+  // supertile map over the HOST-side upper bounds (gridDim), exits against the device-side sizes
+  const unsigned sm     = blockIdx.y / superN;
+  const unsigned sn     = blockIdx.y - sm * superN;
+  const unsigned tile_m = sm * SUPER + blockIdx.x / SUPER;
+  const unsigned tile_n = sn * SUPER + (blockIdx.x & (SUPER - 1));
+  if (tile_m >= tilesM || tile_n >= tilesN) return;
+  if (symmetric && tile_n < tile_m) return;
+  const bool creditCols = symmetric && tile_n > tile_m;
+
+  const int     tid   = threadIdx.x;
+  const int     lane  = tid & 63;
+  const int     wave  = tid >> 6;
+  const int     wm    = wave >> 1;
+  const int     wn    = wave & 1;
+  const int64_t rowA0 = static_cast<int64_t>(tile_m) * TM;
+  const int64_t rowB0 = static_cast<int64_t>(tile_n) * TN;
+  const int     SENT  = (METRIC == NVMK_METRIC_TANIMOTO) ? 2 * F + 1 : 0;  // popcount of a padded row
+
+  if (tid < TM) {
+    const int64_t r     = rowA0 + tid;
+    const bool    valid = r < nX;
+    const int64_t rc    = valid ? r : nX - 1;
+    const int     phys  = xRows ? xRows[rc] : static_cast<int>(rc);
+    idA[tid]            = phys;
+    cidA[tid]           = xIds ? xIds[rc] : phys;
+    pcA[tid]            = valid ? popX[phys] : SENT;
+    rowsum[tid]         = 0;
+  } else {
+    const int     t     = tid - TM;
+    const int64_t r     = rowB0 + t;
+    const bool    valid = r < nY;
+    const int64_t rc    = valid ? r : nY - 1;
+    const int     phys  = yRows ? yRows[rc] : static_cast<int>(rc);
+    idB[t]              = phys;
+    cidB[t]             = yIds ? yIds[rc] : phys;
+    pcB[t]              = valid ? popY[phys] : SENT;
+    colsum[t]           = 0;
+  }
+  if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+    for (int k = tid; k <= 4 * F + 2; k += NT) sTab[k] = table[k];
+  }
+  __syncthreads();
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    }
+  }
+
+  {
+    // gathered row offsets of this thread's 4 + 4 staging pieces
+    const int64_t oa0 = static_cast<int64_t>(idA[NVMK_PIECE_ROW(0)]) * Wp + NVMK_PIECE_SLOT(0);
+    const int64_t oa1 = static_cast<int64_t>(idA[NVMK_PIECE_ROW(1)]) * Wp + NVMK_PIECE_SLOT(1);
+    const int64_t oa2 = static_cast<int64_t>(idA[NVMK_PIECE_ROW(2)]) * Wp + NVMK_PIECE_SLOT(2);
+    const int64_t oa3 = static_cast<int64_t>(idA[NVMK_PIECE_ROW(3)]) * Wp + NVMK_PIECE_SLOT(3);
+    const int64_t ob0 = static_cast<int64_t>(idB[NVMK_PIECE_ROW(0)]) * Wp + NVMK_PIECE_SLOT(0);
+    const int64_t ob1 = static_cast<int64_t>(idB[NVMK_PIECE_ROW(1)]) * Wp + NVMK_PIECE_SLOT(1);
+    const int64_t ob2 = static_cast<int64_t>(idB[NVMK_PIECE_ROW(2)]) * Wp + NVMK_PIECE_SLOT(2);
+    const int64_t ob3 = static_cast<int64_t>(idB[NVMK_PIECE_ROW(3)]) * Wp + NVMK_PIECE_SLOT(3);
+    uint4         ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const int     nChunks = Wp / KCW;
+    NVMK_FETCH4(ra, X, oa, 0)
+    NVMK_FETCH4(rb, Y, ob, 0)
+    for (int ch = 0; ch < nChunks; ++ch) {
+      if (ch > 0) __syncthreads();
+      NVMK_COMMIT4(ra, sA)
+      NVMK_COMMIT4(rb, sB)
+      __syncthreads();
+      if (ch + 1 < nChunks) {
+        NVMK_FETCH4(ra, X, oa, (ch + 1) * KCW)
+        NVMK_FETCH4(rb, Y, ob, (ch + 1) * KCW)
+      }
+      chunk_mma<KCW>(acc, sA, sB, wm, wn, lane);
+    }
+  }
+
+  int rc[2][16];
+  int cc[2] = {0, 0};
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rc[mi][r] = 0;
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int jl  = wn * 64 + ni * 32 + (lane & 31);
+    const int pbv = pcB[jl];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int il  = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int c   = static_cast<int>(acc[mi][ni][r]);
+        const int pav = pcA[il];
+        bool      p;
+        if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+          p = c >= static_cast<int>(sTab[pav + pbv]);
+        } else {
+          p = cosine_neighbor(c, pav, pbv, thr);
+        }
+        rc[mi][r] += p ? 1 : 0;
+        cc[ni] += p ? 1 : 0;
+      }
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int v = rc[mi][r];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      if ((lane & 31) == 0 && v != 0) {
+        atomicAdd(&rowsum[wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)], v);
+      }
+    }
+  }
+  if (creditCols) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      int v = cc[ni];
+      v += __shfl_xor(v, 32);
+      if (lane < 32 && v != 0) atomicAdd(&colsum[wn * 64 + ni * 32 + lane], v);
+    }
+  }
+  __syncthreads();
+  if (tid < TM) {
+    const int v = rowsum[tid];
+    if (v != 0 && rowA0 + tid < nX) atomicAdd(&counts[cidA[tid]], sign * v);
+  } else if (creditCols) {
+    const int t = tid - TM;
+    const int v = colsum[t];
+    if (v != 0 && rowB0 + t < nY) atomicAdd(&counts[cidB[t]], sign * v);
+  }
+}
+
 }  // namespace
 
 int prepare(const uint32_t* d_in, const int32_t* d_rows, int64_t n, int fpBits, void* ws, hipStream_t stream) {
@@ -319,6 +509,34 @@ int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, 
   }
   if (kcw == 16) return launch_dense_t<16, NVMK_METRIC_COSINE, false>(A, B, out, ld, grid, tm, tn, stream);
   return launch_dense_t<8, NVMK_METRIC_COSINE, false>(A, B, out, ld, grid, tm, tn, stream);
+}
+
+int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int32_t* counts, hipStream_t stream) {
+  if (a.nX <= 0 || a.nY <= 0) return NVMK_OK;
+  NVMK_REQUIRE(X.L.Wp == Y.L.Wp && X.L.W == Y.L.W, "prepared sets have different fingerprint widths");
+  NVMK_REQUIRE(counts != nullptr, "neighbor counts: NULL counts");
+  const int     F       = X.L.W * 32;
+  const int64_t tilesM  = ceil_div<int64_t>(a.nX, TM);
+  const int64_t tilesN  = ceil_div<int64_t>(a.nY, TN);
+  const int64_t superM  = ceil_div<int64_t>(tilesM, SUPER);
+  const int64_t superN  = ceil_div<int64_t>(tilesN, SUPER);
+  NVMK_REQUIRE(superM * superN <= 65535 && superN <= 65535, "neighbor counts: problem too large for one launch");
+  const dim3   grid(static_cast<unsigned>(SUPER * SUPER), static_cast<unsigned>(superM * superN), 1);
+  const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + 8 * 128 * 4 +
+                       (a.metric == NVMK_METRIC_TANIMOTO ? (static_cast<size_t>(4 * F + 3) * 2 + 15) / 16 * 16 : 0);
+  NVMK_REQUIRE(shmem <= 160 * 1024, "neighbor counts: fp_bits %d needs %zu bytes of LDS", F, shmem);
+  auto kernT = neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO>;
+  auto kernC = neighbor_count_mfma_kernel<NVMK_METRIC_COSINE>;
+  auto kern  = (a.metric == NVMK_METRIC_TANIMOTO) ? kernT : kernC;
+  if (shmem > 64 * 1024) {
+    NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(shmem)));
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NT), shmem, stream, X.rows, X.popc, a.xRows, a.xIds, a.nX, a.nXdev, Y.rows, Y.popc,
+                     a.yRows, a.yIds, a.nY, a.nYdev, X.L.Wp, F, a.table, a.thr, a.sign, a.symmetric ? 1 : 0, counts,
+                     static_cast<unsigned>(superN));
+  NVMK_LAUNCH_CHECK();
+  return NVMK_OK;
 }
 
 }  // namespace fp4

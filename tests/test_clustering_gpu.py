@@ -11,6 +11,14 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["valu", "mfma", "auto"], autouse=True)
+def sim_path(request, monkeypatch):
+    """Neighbour counting / fused Butina run on the v_bcnt kernels, on the FP4 matrix-core kernels and on
+    the library's automatic choice (NVMK_SIM_PATH is read per call by butina.hip)."""
+    monkeypatch.setenv("NVMK_SIM_PATH", request.param)
+    return request.param
+
 METRICS = {"tanimoto": oracle.TANIMOTO, "cosine": oracle.COSINE}
 
 
@@ -59,7 +67,7 @@ def test_fused_butina_equals_oracle(golden_dir, key, cutoff, metric):
     util.check_partition(clusters, len(x))
 
 
-@pytest.mark.parametrize("n,words,centres", [(2000, 64, 40), (3001, 32, 100)])
+@pytest.mark.parametrize("n,words,centres", [(2000, 64, 40), (3001, 32, 100), (4500, 64, 300)])
 def test_fused_butina_larger_vs_oracle(n, words, centres):
     x = util.clustered_fingerprints(n, words, centres, seed=n)
     got = fused_butina(dev(x), 0.35, return_centroids=True)
