@@ -287,7 +287,8 @@ __global__ __launch_bounds__(NT, 2) void neighbor_count_mfma_kernel(
   const int32_t* __restrict__ xIds, int64_t nX,
   const int32_t* __restrict__ nXdev, const uint4* __restrict__ Y, const int32_t* __restrict__ popY,
   const int32_t* __restrict__ yRows, const int32_t* __restrict__ yIds, int64_t nY, const int32_t* __restrict__ nYdev, const int Wp, const int F,
-  const uint16_t* __restrict__ table, const float thr, const int sign, const int symmetric, int32_t* __restrict__ counts, const unsigned superN) {
+  const uint16_t* __restrict__ table, const float thr, const int sign, const int symmetric, int32_t* __restrict__ counts, const unsigned superN,
+  const unsigned superW) {
   constexpr int KCW = 8;
   using C           = Chunk<KCW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -307,11 +308,13 @@ __global__ __launch_bounds__(NT, 2) void neighbor_count_mfma_kernel(
   if (nYdev) nY = *nYdev;
   const unsigned tilesM = static_cast<unsigned>((nX + TM - 1) / TM);
   const unsigned tilesN = static_cast<unsigned>((nY + TN - 1) / TN);
-  // supertile map over the HOST-side upper bounds (gridDim), exits against the device-side sizes
+  // supertile map over the HOST-side upper bounds (gridDim), exits against the device-side sizes.  A
+  // supertile is SUPER x superW tiles; superW < SUPER for skinny problems (a Butina subtract pass has one
+  // column tile: a square 64 x 64 map would launch 63 empty workgroups per working one).
   const unsigned sm     = blockIdx.y / superN;
   const unsigned sn     = blockIdx.y - sm * superN;
-  const unsigned tile_m = sm * SUPER + blockIdx.x / SUPER;
-  const unsigned tile_n = sn * SUPER + (blockIdx.x & (SUPER - 1));
+  const unsigned tile_m = sm * SUPER + blockIdx.x / superW;
+  const unsigned tile_n = sn * superW + (blockIdx.x - (blockIdx.x / superW) * superW);
   if (tile_m >= tilesM || tile_n >= tilesN) return;
   if (symmetric && tile_n < tile_m) return;
   const bool creditCols = symmetric && tile_n > tile_m;
@@ -518,10 +521,11 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   const int     F       = X.L.W * 32;
   const int64_t tilesM  = ceil_div<int64_t>(a.nX, TM);
   const int64_t tilesN  = ceil_div<int64_t>(a.nY, TN);
+  const int64_t superW  = std::min<int64_t>(tilesN, SUPER);
   const int64_t superM  = ceil_div<int64_t>(tilesM, SUPER);
-  const int64_t superN  = ceil_div<int64_t>(tilesN, SUPER);
+  const int64_t superN  = ceil_div<int64_t>(tilesN, superW);
   NVMK_REQUIRE(superM * superN <= 65535 && superN <= 65535, "neighbor counts: problem too large for one launch");
-  const dim3   grid(static_cast<unsigned>(SUPER * SUPER), static_cast<unsigned>(superM * superN), 1);
+  const dim3   grid(static_cast<unsigned>(SUPER * superW), static_cast<unsigned>(superM * superN), 1);
   const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + 8 * 128 * 4 +
                        (a.metric == NVMK_METRIC_TANIMOTO ? (static_cast<size_t>(4 * F + 3) * 2 + 15) / 16 * 16 : 0);
   NVMK_REQUIRE(shmem <= 160 * 1024, "neighbor counts: fp_bits %d needs %zu bytes of LDS", F, shmem);
@@ -534,7 +538,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   }
   hipLaunchKernelGGL(kern, grid, dim3(NT), shmem, stream, X.rows, X.popc, a.xRows, a.xIds, a.nX, a.nXdev, Y.rows, Y.popc,
                      a.yRows, a.yIds, a.nY, a.nYdev, X.L.Wp, F, a.table, a.thr, a.sign, a.symmetric ? 1 : 0, counts,
-                     static_cast<unsigned>(superN));
+                     static_cast<unsigned>(superN), static_cast<unsigned>(superW));
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }
