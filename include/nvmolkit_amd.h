@@ -138,6 +138,27 @@ int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, d
 int nvmk_butina_dense(const double* d_dist, const uint8_t* d_hit, int64_t N, double cutoff, int neighborlist_max_size,
                       int32_t* d_clusters, int32_t* d_centroids, int64_t* h_n_clusters, void* stream);
 
+/* ---- M2: Morgan fingerprints from flattened invariants ----------------------------------------------
+ * Replaces launchMorganFingerprintKernelBatch / morganFingerprintKernelBatch<maxAtoms, fpSize>
+ * (src/morgan_fingerprint_kernels.cu:151-485; buffers MorganGPUBuffersBatch, morgan_fingerprint_kernels.h:30-42).
+ * Inputs are the arrays produced by MorganInvariantsGenerator::ComputeInvariantsInto
+ * (src/morgan_fingerprint_common.cpp:43-124), one slot of `max_atoms` entries per molecule:
+ *   d_atom_inv   [n_mols*max_atoms] u32   atom invariants
+ *   d_bond_inv   [n_mols*max_atoms] u32   bond invariants (bond type), indexed by bond id
+ *   d_bond_idx   [n_mols*max_atoms*8] i16 bond ids incident to each atom, -1 padded
+ *   d_bond_other [n_mols*max_atoms*8] i16 neighbour atom id across that bond, -1 padded
+ *   d_n_atoms    [n_mols] i16
+ *   d_out_idx    [n_mols] i32            output row of each molecule (NULL = identity)
+ *   d_out        rows of fp_bits/32 u32  (rows are OVERWRITTEN for the listed molecules)
+ * max_atoms in {32, 64, 128, 256} (the reference computes molecules of >= 128 atoms on the CPU,
+ * src/morgan_fingerprint_gpu.cpp:181-188, :296-304; here the 256 bucket keeps them on the GPU);
+ * fp_bits in {128, 256, 512, 1024, 2048, 4096}; radius in [0, 8].  Atoms and bonds of a molecule must both be
+ * < max_atoms (the reference's bucketing rule, src/morgan_fingerprint_common.cpp:71-73).
+ */
+int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uint32_t* d_bond_inv, const int16_t* d_bond_idx,
+                                const int16_t* d_bond_other, const int16_t* d_n_atoms, const int32_t* d_out_idx,
+                                int64_t n_mols, int max_atoms, int radius, int fp_bits, uint32_t* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,7 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_cross_similarity_host_f64": (_int, [_int, _vp, _i64, _vp, _i64, _int, _vp, _i64]),
     "nvmk_neighbor_counts": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _i64, _int, ctypes.c_float, _int, _vp, _vp]),
     "nvmk_butina_fused": (_int, [_int, _vp, _i64, _int, ctypes.c_double, _vp, _vp, _vp, ctypes.POINTER(_i64), _vp]),
+    "nvmk_morgan_from_invariants": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "nvmk_butina_dense": (_int, [_vp, _vp, _i64, ctypes.c_double, _int, _vp, _vp, ctypes.POINTER(_i64), _vp]),
 }
 

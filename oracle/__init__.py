@@ -81,6 +81,14 @@ def _declare(L: ctypes.CDLL) -> None:
     L.orc_butina_dense.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, _i32p,
                                    ctypes.c_void_p]
     L.orc_butina_dense.restype = ctypes.c_int64
+    _i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+    L.orc_morgan_hash_vector.argtypes = [_u32p, ctypes.c_int]
+    L.orc_morgan_hash_vector.restype = ctypes.c_uint32
+    L.orc_morgan_environments.argtypes = [_u32p, _u32p, _i16p, _i16p, ctypes.c_int, ctypes.c_int, _u32p, _i32p]
+    L.orc_morgan_environments.restype = ctypes.c_int
+    L.orc_morgan_fingerprints.argtypes = [_u32p, _u32p, _i16p, _i16p, _i16p, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, _u32p]
+    L.orc_morgan_fingerprints.restype = None
     L.orc_check_reciprocal_division.argtypes = [ctypes.c_int]
     L.orc_check_reciprocal_division.restype = ctypes.c_int64
 
@@ -195,4 +203,40 @@ def cross_similarity_numpy(a, b=None, metric: int = TANIMOTO) -> np.ndarray:
     denom = np.sqrt(pa.astype(np.float64) * pb.astype(np.float64))
     with np.errstate(divide="ignore", invalid="ignore"):
         out = np.where((inter == 0) | (denom == 0), 0.0, inter / denom)
+    return out
+
+
+# ---- Morgan fingerprints on flattened graphs (oracle_morgan.c) ---------------------------------
+
+
+def morgan_hash_vector(components) -> int:
+    """gboost::hash<std::vector<uint32_t>> with a 32-bit seed (src/morgan_fingerprint_common.cpp:54,121)."""
+    v = np.ascontiguousarray(np.asarray(components, dtype=np.int64).astype(np.uint32))
+    return int(lib().orc_morgan_hash_vector(v, len(v)))
+
+
+def morgan_environments(atom_inv, bond_inv, bond_idx, bond_other, n_atoms: int, radius: int):
+    """(codes, layers) of one molecule: the unfolded bit ids RDKit calls atom environments."""
+    atom_inv = np.ascontiguousarray(atom_inv, dtype=np.uint32)
+    bond_inv = np.ascontiguousarray(bond_inv, dtype=np.uint32)
+    bond_idx = np.ascontiguousarray(bond_idx, dtype=np.int16)
+    bond_other = np.ascontiguousarray(bond_other, dtype=np.int16)
+    cap = max(1, (radius + 1) * max(n_atoms, 1))
+    codes = np.zeros(cap, dtype=np.uint32)
+    layers = np.zeros(cap, dtype=np.int32)
+    n = lib().orc_morgan_environments(atom_inv, bond_inv, bond_idx, bond_other, n_atoms, radius, codes, layers)
+    return codes[:n].copy(), layers[:n].copy()
+
+
+def morgan_fingerprints(atom_inv, bond_inv, bond_idx, bond_other, n_atoms, stride: int, radius: int,
+                        fp_bits: int) -> np.ndarray:
+    """Batch in the ComputeInvariantsInto layout -> (n_mols, fp_bits/32) uint32 bit vectors."""
+    n_atoms = np.ascontiguousarray(n_atoms, dtype=np.int16)
+    n_mols = len(n_atoms)
+    out = np.zeros((n_mols, fp_bits // 32), dtype=np.uint32)
+    lib().orc_morgan_fingerprints(np.ascontiguousarray(atom_inv, dtype=np.uint32),
+                                  np.ascontiguousarray(bond_inv, dtype=np.uint32),
+                                  np.ascontiguousarray(bond_idx, dtype=np.int16),
+                                  np.ascontiguousarray(bond_other, dtype=np.int16), n_atoms, n_mols, stride, radius,
+                                  fp_bits, out)
     return out

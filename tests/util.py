@@ -86,3 +86,86 @@ def check_labels_valid(hit: np.ndarray, labels: np.ndarray) -> None:
     for c in clusters:
         ok = any(all(hit[cen, m] for m in c if m != cen) for cen in c)
         assert ok, "cluster without a valid centroid"
+
+
+# ---- flattened molecular graphs for the Morgan path ------------------------------------------------
+# Layout of MorganInvariantsGenerator::ComputeInvariantsInto (reference src/morgan_fingerprint_common.cpp:43-124).
+
+BOND_SINGLE, BOND_DOUBLE, BOND_TRIPLE, BOND_AROMATIC = 1, 2, 3, 12  # RDKit::Bond::BondType values
+MAX_BONDS_PER_ATOM = 8
+
+
+def atom_invariant(z: int, heavy_degree: int, n_h: int, charge: int = 0, delta_mass: int = 0, in_ring: bool = False,
+                   neighbor_h: int = 0) -> int:
+    """[Z, degree + Hs, total Hs incl. H neighbours, formal charge, int(mass - avg mass)] (+ [1] if in a ring),
+    hashed with hash_range on uint32 (src/morgan_fingerprint_common.cpp:96-121)."""
+    import oracle
+
+    comps = [z, heavy_degree + n_h, n_h + neighbor_h, charge & 0xFFFFFFFF, delta_mass & 0xFFFFFFFF]
+    if in_ring:
+        comps.append(1)
+    return oracle.morgan_hash_vector(comps)
+
+
+def flatten_molecules(mols, stride: int):
+    """mols: list of (atoms, bonds); atoms = [(Z, nH, charge, in_ring)], bonds = [(i, j, type)].
+    Returns (atom_inv, bond_inv, bond_idx, bond_other, n_atoms) numpy arrays in the reference layout."""
+    n = len(mols)
+    atom_inv = np.zeros((n, stride), dtype=np.uint32)
+    bond_inv = np.zeros((n, stride), dtype=np.uint32)
+    bond_idx = np.full((n, stride, MAX_BONDS_PER_ATOM), -1, dtype=np.int16)
+    bond_other = np.full((n, stride, MAX_BONDS_PER_ATOM), -1, dtype=np.int16)
+    n_atoms = np.zeros(n, dtype=np.int16)
+    for m, (atoms, bonds) in enumerate(mols):
+        assert len(atoms) < stride and len(bonds) < stride, "reference buckets require atoms, bonds < maxAtoms"
+        n_atoms[m] = len(atoms)
+        deg = [0] * len(atoms)
+        for b, (i, j, t) in enumerate(bonds):
+            bond_inv[m, b] = t
+            for a, o in ((i, j), (j, i)):
+                assert deg[a] < MAX_BONDS_PER_ATOM
+                bond_idx[m, a, deg[a]] = b
+                bond_other[m, a, deg[a]] = o
+                deg[a] += 1
+        for a, (z, nh, q, ring) in enumerate(atoms):
+            atom_inv[m, a] = atom_invariant(z, deg[a], nh, q, 0, ring)
+    return atom_inv, bond_inv, bond_idx, bond_other, n_atoms
+
+
+def random_molecule(rng, n_atoms: int, ring_closures: int = 2, symmetric: bool = False):
+    """Random connected graph with valence <= 4: a random tree plus a few ring closures.  `symmetric`
+    draws few distinct atom types so that duplicate environments (the dedup logic) are exercised."""
+    zs = [6, 6, 6, 7, 8] if symmetric else [6, 6, 6, 6, 7, 8, 9, 16, 17]
+    deg = [0] * n_atoms
+    bonds = []
+    for a in range(1, n_atoms):
+        cand = [p for p in range(a) if deg[p] < 3]
+        p = cand[rng.integers(len(cand))] if cand else int(np.argmin(deg[:a]))
+        bonds.append((p, a, BOND_SINGLE if rng.random() < 0.8 else BOND_DOUBLE))
+        deg[p] += 1
+        deg[a] += 1
+    ring = [False] * n_atoms
+    existing = {(min(i, j), max(i, j)) for i, j, _ in bonds}
+    for _ in range(ring_closures):
+        i, j = sorted(rng.integers(0, n_atoms, size=2).tolist())
+        if i != j and (i, j) not in existing and deg[i] < 4 and deg[j] < 4 and len(bonds) < n_atoms - 1 + ring_closures:
+            bonds.append((i, j, BOND_AROMATIC if rng.random() < 0.5 else BOND_SINGLE))
+            existing.add((i, j))
+            deg[i] += 1
+            deg[j] += 1
+            ring[i] = ring[j] = True
+    atoms = []
+    for a in range(n_atoms):
+        z = zs[rng.integers(len(zs))]
+        atoms.append((z, max(0, 4 - deg[a] - (z - 6 if z in (7, 8, 9) else 0)) if z != 17 else 0, 0, ring[a]))
+    return atoms, bonds
+
+
+def random_molecule_batch(n_mols: int, stride: int, seed: int = SEED, min_atoms: int = 1, symmetric: bool = False):
+    rng = np.random.default_rng(seed)
+    mols = []
+    for _ in range(n_mols):
+        hi = stride - 3
+        n = int(rng.integers(min_atoms, max(min_atoms + 1, hi)))
+        mols.append(random_molecule(rng, n, ring_closures=min(2, max(0, stride - 1 - n)), symmetric=symmetric))
+    return mols
