@@ -159,6 +159,64 @@ int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uint32_t* d_bo
                                 const int16_t* d_bond_other, const int16_t* d_n_atoms, const int32_t* d_out_idx,
                                 int64_t n_mols, int max_atoms, int radius, int fp_bits, uint32_t* d_out, void* stream);
 
+/* ---- F1-F4 / N1-N2: batched force fields and the fused BFGS minimiser ---------------------------------
+ * Replaces the BatchedForcefield interface (src/forcefields/batched_forcefield.h:74-149: computeEnergy /
+ * computeGradients with an active-system mask), the block-per-molecule kernels (src/forcefields/mmff_kernels.cu:
+ * 1064-1157, dist_geom_kernels_device.cuh:832-1355) and the fused per-molecule BFGS
+ * (src/minimizer/bfgs_minimize_permol_kernels.cu:426-745; BfgsBatchMinimizer::minimize, bfgs_minimize.cu:978-1084).
+ *
+ * A batch is `n_systems` independent systems (conformers); system s owns atoms [atom_starts[s], atom_starts[s+1])
+ * of the position array, `dim` doubles per atom (dim = 3 for MMFF, 4 for DG / ETK / QUARTIC).  Term tables are the
+ * flattened arrays the reference builds in rdkit_extensions/ (SoA + CSR): group g holds the terms of one type for
+ * all systems, terms of system s are [starts[s], starts[s+1]); `idx` has n_idx LOCAL atom indices per term and
+ * `par` n_par doubles per term, both interleaved per term:
+ *   NVMK_FF_DG   (src/forcefields/dist_geom.h:31-56)    w0 = chiral weight, w1 = fourth-dimension weight
+ *     g0 distance violation  idx(i, j)        par(lb2, ub2, weight)
+ *     g1 chiral volume       idx(1, 2, 3, 4)  par(volLower, volUpper)
+ *     g2 fourth dimension    idx(i)           -
+ *   NVMK_FF_ETK  (dist_geom.h:73-130)
+ *     g0 experimental torsion idx(1..4) par(fc[6], sign[6])      g1 inversion idx(1..4) par(C0, C1, C2, k)
+ *     g2 1-2 distance idx(i, j) par(minLen, maxLen, k)           g3 1-3 distance (same)
+ *     g4 1-3 angle idx(1, 2, 3) par(minAngle, maxAngle) [deg]    g5 long-range distance (as g2)
+ *   NVMK_FF_MMFF (src/forcefields/mmff.h:37-145)
+ *     g0 bond idx(i, j) par(r0, kb)                 g1 angle idx(1,2,3) par(theta0, ka, isLinear)
+ *     g2 stretch-bend idx(1,2,3) par(theta0, r0ij, r0kj, kbaIJK, kbaKJI)   g3 out-of-plane idx(1..4) par(koop)
+ *     g4 torsion idx(1..4) par(V1, V2, V3)          g5 vdW idx(i, j) par(R*, eps)
+ *     g6 electrostatic idx(i, j) par(qi*qj/D, dielModel, is1_4)
+ *   NVMK_FF_QUARTIC: the synthetic field of the reference's BFGS tests (tests/test_bfgs_minimizer.cu:823-860),
+ *     E = sum (x_p - p)^4 over global coordinate index p; w0 != 0 includes every atom's 4th coordinate.
+ * All pointers inside the struct are DEVICE pointers; the struct itself is passed by host pointer.
+ */
+#define NVMK_FF_DG 0
+#define NVMK_FF_ETK 1
+#define NVMK_FF_MMFF 2
+#define NVMK_FF_QUARTIC 3
+
+typedef struct nvmk_ff_group {
+  const int32_t* starts; /* [n_systems + 1] */
+  const int32_t* idx;
+  const double*  par;
+} nvmk_ff_group;
+
+typedef struct nvmk_ff_batch {
+  int32_t        kind;
+  int32_t        n_systems;
+  const int32_t* atom_starts; /* device, [n_systems + 1] */
+  nvmk_ff_group  groups[8];
+} nvmk_ff_batch;
+
+/* energies[s] / gradient (same layout as d_pos) of every system with d_active[s] != 0 (NULL = all). */
+int nvmk_ff_energy(const nvmk_ff_batch* batch, double w0, double w1, const double* d_pos, const uint8_t* d_active,
+                   double* d_energies, void* stream);
+int nvmk_ff_gradient(const nvmk_ff_batch* batch, double w0, double w1, const double* d_pos, const uint8_t* d_active,
+                     double* d_grad, void* stream);
+/* Minimises every active system in place.  h_atom_starts is a HOST copy of atom_starts (sizes the per-system
+ * inverse Hessians).  d_statuses[s] = 0 converged / 1 not (reference: statuses_, 0 == converged), d_iters optional.
+ * Blocking.  Constants as the reference (FUNCTOL 1e-4, MOVETOL 1e-7, TOLX 1.2e-7, EPS 3e-8, <= 1000 line-search steps). */
+int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts, double w0, double w1, int max_iters,
+                       double grad_tol, int scale_grads, double* d_pos, const uint8_t* d_active, double* d_energies,
+                       int16_t* d_statuses, int32_t* d_iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,8 +53,26 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_neighbor_counts": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _i64, _int, ctypes.c_float, _int, _vp, _vp]),
     "nvmk_butina_fused": (_int, [_int, _vp, _i64, _int, ctypes.c_double, _vp, _vp, _vp, ctypes.POINTER(_i64), _vp]),
     "nvmk_morgan_from_invariants": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
+    "nvmk_ff_energy": (_int, [_vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),
+    "nvmk_ff_gradient": (_int, [_vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),
+    "nvmk_bfgs_minimize": (_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _int, ctypes.c_double, _int, _vp, _vp, _vp,
+                                  _vp, _vp, _vp]),
     "nvmk_butina_dense": (_int, [_vp, _vp, _i64, ctypes.c_double, _int, _vp, _vp, ctypes.POINTER(_i64), _vp]),
 }
+
+
+class FFGroup(ctypes.Structure):
+    _fields_ = [("starts", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("par", ctypes.c_void_p)]
+
+
+class FFBatch(ctypes.Structure):
+    """Mirror of ``nvmk_ff_batch`` (include/nvmolkit_amd.h)."""
+
+    _fields_ = [("kind", ctypes.c_int32), ("n_systems", ctypes.c_int32), ("atom_starts", ctypes.c_void_p),
+                ("groups", FFGroup * 8)]
+
+
+FF_DG, FF_ETK, FF_MMFF, FF_QUARTIC = 0, 1, 2, 3
 
 
 def lib() -> ctypes.CDLL:

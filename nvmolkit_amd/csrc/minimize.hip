@@ -1,0 +1,704 @@
+// Batched force-field evaluation and fused per-system BFGS minimisation — gfx950.
+//
+// Replaces (reference paths):
+//   src/minimizer/bfgs_minimize_permol_kernels.cu:35-745   bfgsMinimizeKernel (whole BFGS in one launch)
+//   src/minimizer/bfgs_minimize.cu:978-1084                BfgsBatchMinimizer::minimize (host-driven variant)
+//   src/forcefields/{dist_geom,mmff}_kernels*.cu           combinedEnergies / combinedGrad block-per-molecule kernels
+// The optimiser is RDKit's BFGS (the reference restates ForceFields/BFGSOpt.h): identity inverse Hessian,
+// gradient scaling 0.1 then halving while max > 10, backtracking cubic line search (FUNCTOL 1e-4, MOVETOL 1e-7,
+// at most 1000 steps), TOLX = 1.2e-7, BFGS update guarded by fac^2 > EPS |dg|^2 |xi|^2 with EPS = 3e-8
+// (bfgs_minimize_permol_kernels.cu:29-33, :304-407).
+//
+// MI355X design: one 256-thread workgroup per system; positions, gradient, direction, trial positions and
+// gradient difference live in LDS for the whole minimisation; all arithmetic is fp64; term tables are read
+// straight from HBM/L2 (they are shared by the conformers of a molecule); the inverse Hessian is the only
+// per-system state in HBM.  Term loops are thread-strided over a generic table layout (see nvmolkit_amd.h):
+// every term group is {CSR starts, interleaved local atom indices, interleaved double parameters}.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "ff_terms.h"
+
+namespace nvmk {
+namespace minim {
+
+using namespace nvmk::ff;
+
+constexpr int NT = 256;
+
+struct Group {
+  const int32_t* starts;
+  const int32_t* idx;
+  const double*  par;
+};
+struct Batch {
+  int            kind;
+  int            nSystems;
+  const int32_t* atomStarts;
+  Group          g[8];
+};
+
+template <int KIND> struct Dim {
+  static constexpr int value = (KIND == NVMK_FF_MMFF) ? 3 : 4;
+};
+
+// ---- block reductions -----------------------------------------------------------------------------
+enum class Op { kSum, kMax, kMin };
+template <Op OP> __device__ __forceinline__ double combine(const double a, const double b) {
+  if constexpr (OP == Op::kSum) return a + b;
+  if constexpr (OP == Op::kMax) return a > b ? a : b;
+  return a < b ? a : b;
+}
+// All threads receive the result.  `red` is NT/64 + 1 doubles of LDS.
+template <Op OP> __device__ __forceinline__ double block_reduce(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = combine<OP>(v, __shfl_xor(v, o));
+  __syncthreads();  // protect `red` from the previous use
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) r = combine<OP>(r, red[w]);
+  return r;
+}
+
+// ---- per-system energy / gradient -----------------------------------------------------------------
+// pos / grad are the system's own arrays (LDS or global), DIM doubles per atom.  Every thread walks its
+// share of each term group; energy() returns the thread's partial sum, grad() accumulates with atomics.
+
+template <int NP, int DIM, int NA>
+__device__ __forceinline__ void scatter(const Dual<NP>& e, const int (&atoms)[NA], double* grad, const double scale) {
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double g = scale * e.d[3 * m + c];
+      if (g != 0.0) atomicAdd(&grad[atoms[m] * DIM + c], g);
+    }
+  }
+}
+
+template <int DIM> __device__ __forceinline__ double pair_dist2(const double* pos, const int i, const int j, const int ndim, double (&d)[4]) {
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    d[c] = (c < ndim) ? pos[i * DIM + c] - pos[j * DIM + c] : 0.0;
+    s += d[c] * d[c];
+  }
+  return s;
+}
+
+template <int DIM> __device__ __forceinline__ void pair_push(double* grad, const int i, const int j, const int ndim, const double (&d)[4], const double f) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < ndim) {
+      const double g = f * d[c];
+      atomicAdd(&grad[i * DIM + c], g);
+      atomicAdd(&grad[j * DIM + c], -g);
+    }
+  }
+}
+
+// GRAD = false: returns the energy partial.  GRAD = true: accumulates the gradient, returns 0.
+template <int KIND, bool GRAD>
+__device__ double system_eval(const Batch& b, const int sys, const double* pos, double* grad, const double w0, const double w1,
+                              const int globalCoordStart) {
+  constexpr int DIM = Dim<KIND>::value;
+  const int     tid = threadIdx.x;
+  double        e   = 0.0;
+  (void)grad;
+  (void)w0;
+  (void)w1;
+  (void)globalCoordStart;
+
+  if constexpr (KIND == NVMK_FF_QUARTIC) {
+    // test field of the reference's BFGS suite (tests/test_bfgs_minimizer.cu:823-860): sum (x_p - p)^4 over the
+    // GLOBAL coordinate index p; w0 != 0 includes the 4th coordinate of every atom
+    const int n = (b.atomStarts[sys + 1] - b.atomStarts[sys]) * 4;
+    for (int p = tid; p < n; p += NT) {
+      if ((p & 3) == 3 && w0 == 0.0) continue;
+      const double diff = pos[p] - static_cast<double>(globalCoordStart + p);
+      if constexpr (GRAD) {
+        grad[p] += 4.0 * diff * diff * diff;
+      } else {
+        e += diff * diff * diff * diff;
+      }
+    }
+    return e;
+  }
+
+  if constexpr (KIND == NVMK_FF_DG) {
+    {  // distance violations, all 4 dimensions (dist_geom_kernels_device.cuh:37-95)
+      const Group& g = b.g[0];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
+        double       d[4];
+        const double d2 = pair_dist2<DIM>(pos, i, j, 4, d);
+        double       et, dE;
+        dist_violation(d2, g.par[3 * t], g.par[3 * t + 1], g.par[3 * t + 2], et, dE);
+        if constexpr (GRAD) {
+          if (dE != 0.0) pair_push<DIM>(grad, i, j, 4, d, 2.0 * dE);
+        } else {
+          e += et;
+        }
+      }
+    }
+    {  // chiral volumes, weight w0 (:97-207); RDKit's gradient is half the derivative
+      const Group& g = b.g[1];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
+        if constexpr (GRAD) {
+          using D       = Dual<12>;
+          const D   vol = chiral_volume(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                        Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3));
+          const D   ev  = chiral_violation(vol, g.par[2 * t], g.par[2 * t + 1], w0);
+          scatter<12, DIM, 4>(ev, a, grad, 0.5);
+        } else {
+          const double vol = chiral_volume(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                                           Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3));
+          e += chiral_violation(vol, g.par[2 * t], g.par[2 * t + 1], w0);
+        }
+      }
+    }
+    {  // fourth dimension, weight w1 (:209-231): E = w x4^2, RDKit gradient w x4
+      const Group& g = b.g[2];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int    i = g.idx[t];
+        const double x = pos[i * DIM + 3];
+        if constexpr (GRAD) {
+          atomicAdd(&grad[i * DIM + 3], w1 * x);
+        } else {
+          e += w1 * x * x;
+        }
+      }
+    }
+    return e;
+  }
+
+  if constexpr (KIND == NVMK_FF_ETK) {
+    {  // experimental torsions: 6 force constants + 6 signs per term (:237-313, :447-575)
+      const Group& g = b.g[0];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
+        const double* fc   = g.par + 12 * t;
+        bool          ok;
+        if constexpr (GRAD) {
+          using D   = Dual<12>;
+          const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                   Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
+          if (ok) scatter<12, DIM, 4>(torsion_m6(c, fc, fc + 6), a, grad, 1.0);
+        } else {
+          const double c = cos_dihedral(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                                        Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), ok);
+          e += torsion_m6(ok ? c : 0.0, fc, fc + 6);  // degenerate: cosPhi = 0 (:286-288)
+        }
+      }
+    }
+    {  // improper torsions / inversions: C0, C1, C2, k (:315-366, :577-694)
+      const Group& g = b.g[1];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
+        const double* p    = g.par + 4 * t;
+        if constexpr (GRAD) {
+          using D = Dual<12>;
+          scatter<12, DIM, 4>(inversion(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                        Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0], p[1], p[2],
+                                        p[3]),
+                              a, grad, 1.0);
+        } else {
+          e += inversion(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                         Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), p[0], p[1], p[2], p[3]);
+        }
+      }
+    }
+    // flat-bottom distance restraints in 3-D: groups 2 (1-2), 3 (1-3), 5 (long range) (:368-392, :696-729)
+#pragma unroll
+    for (int gi = 2; gi <= 5; ++gi) {
+      if (gi == 4) continue;
+      const Group& g = b.g[gi];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
+        double       d[4];
+        const double dist = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
+        double       et, dE;
+        dist_constraint(dist, g.par[3 * t], g.par[3 * t + 1], g.par[3 * t + 2], et, dE);
+        if constexpr (GRAD) {
+          if (dE != 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / (dist > 1.0e-8 ? dist : 1.0e-8));
+        } else {
+          e += et;
+        }
+      }
+    }
+    {  // 1-3 angle restraints, force constant 1 (:394-445, :731-830)
+      const Group& g = b.g[4];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
+        if constexpr (GRAD) {
+          using D = Dual<9>;
+          scatter<9, DIM, 3>(angle_constraint(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                              Loader<D, DIM>::get(pos, a[2], 2), g.par[2 * t], g.par[2 * t + 1], 1.0),
+                             a, grad, 1.0);
+        } else {
+          e += angle_constraint(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                                Loader<double, DIM>::get(pos, a[2], 2), g.par[2 * t], g.par[2 * t + 1], 1.0);
+        }
+      }
+    }
+    return e;
+  }
+
+  if constexpr (KIND == NVMK_FF_MMFF) {
+    {  // bond stretch: r0, kb
+      const Group& g = b.g[0];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
+        double       d[4];
+        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
+        double       et, dE;
+        mmff_bond(r, g.par[2 * t], g.par[2 * t + 1], et, dE);
+        if constexpr (GRAD) {
+          if (r > 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / r);
+        } else {
+          e += et;
+        }
+      }
+    }
+    {  // angle bend: theta0, ka, isLinear
+      const Group& g = b.g[1];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
+        const double* p    = g.par + 3 * t;
+        if constexpr (GRAD) {
+          using D = Dual<9>;
+          scatter<9, DIM, 3>(mmff_angle(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                        Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], p[2] != 0.0),
+                             a, grad, 1.0);
+        } else {
+          e += mmff_angle(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                          Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], p[2] != 0.0);
+        }
+      }
+    }
+    {  // stretch-bend: theta0, r0ij, r0kj, kbaIJK, kbaKJI
+      const Group& g = b.g[2];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
+        const double* p    = g.par + 5 * t;
+        if constexpr (GRAD) {
+          using D = Dual<9>;
+          scatter<9, DIM, 3>(mmff_stretch_bend(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                               Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], p[2], p[3], p[4]),
+                             a, grad, 1.0);
+        } else {
+          e += mmff_stretch_bend(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                                 Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], p[2], p[3], p[4]);
+        }
+      }
+    }
+    {  // out-of-plane: koop
+      const Group& g = b.g[3];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
+        if constexpr (GRAD) {
+          using D = Dual<12>;
+          scatter<12, DIM, 4>(mmff_oop(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                       Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), g.par[t]),
+                              a, grad, 1.0);
+        } else {
+          e += mmff_oop(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                        Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), g.par[t]);
+        }
+      }
+    }
+    {  // torsion: V1, V2, V3
+      const Group& g = b.g[4];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
+        const double* p    = g.par + 3 * t;
+        bool          ok;
+        if constexpr (GRAD) {
+          using D   = Dual<12>;
+          const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                   Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
+          if (ok) scatter<12, DIM, 4>(mmff_torsion(c, p[0], p[1], p[2]), a, grad, 1.0);
+        } else {
+          const double c = cos_dihedral(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                                        Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), ok);
+          e += mmff_torsion(ok ? c : 0.0, p[0], p[1], p[2]);
+        }
+      }
+    }
+    {  // van der Waals: R*, eps
+      const Group& g = b.g[5];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
+        double       d[4];
+        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
+        double       et, dE;
+        mmff_vdw(r, g.par[2 * t], g.par[2 * t + 1], et, dE);
+        if constexpr (GRAD) {
+          if (r > 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / r);
+        } else {
+          e += et;
+        }
+      }
+    }
+    {  // electrostatics: chargeTerm, dielModel, is1_4
+      const Group& g = b.g[6];
+      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+        const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
+        double       d[4];
+        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
+        double       et, dE;
+        mmff_ele(r, g.par[3 * t], static_cast<int>(g.par[3 * t + 1]), g.par[3 * t + 2] != 0.0, et, dE);
+        if constexpr (GRAD) {
+          if (r > 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / r);
+        } else {
+          e += et;
+        }
+      }
+    }
+    return e;
+  }
+  return e;
+}
+
+// ---- stand-alone energy / gradient kernels (one workgroup per system) -----------------------------
+template <int KIND>
+__global__ __launch_bounds__(NT) void energy_kernel(const Batch b, const double* __restrict__ pos, const double w0, const double w1,
+                                                    const uint8_t* __restrict__ active, double* __restrict__ energies) {
+  constexpr int DIM = Dim<KIND>::value;
+  __shared__ double red[NT / 64 + 1];
+  const int         sys = blockIdx.x;
+  if (active && !active[sys]) return;
+  const int    a0 = b.atomStarts[sys];
+  const double e  = system_eval<KIND, false>(b, sys, pos + static_cast<int64_t>(a0) * DIM, nullptr, w0, w1, a0 * DIM);
+  const double s  = block_reduce<Op::kSum>(e, red);
+  if (threadIdx.x == 0) energies[sys] = s;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(NT) void grad_kernel(const Batch b, const double* __restrict__ pos, const double w0, const double w1,
+                                                  const uint8_t* __restrict__ active, double* __restrict__ grad) {
+  constexpr int DIM = Dim<KIND>::value;
+  const int     sys = blockIdx.x;
+  if (active && !active[sys]) return;
+  const int a0 = b.atomStarts[sys];
+  const int n  = (b.atomStarts[sys + 1] - a0) * DIM;
+  double*   g  = grad + static_cast<int64_t>(a0) * DIM;
+  for (int p = threadIdx.x; p < n; p += NT) g[p] = 0.0;
+  __syncthreads();
+  system_eval<KIND, true>(b, sys, pos + static_cast<int64_t>(a0) * DIM, g, w0, w1, a0 * DIM);
+}
+
+// ---- fused BFGS -----------------------------------------------------------------------------------
+constexpr double FUNCTOL       = 1.0e-4;
+constexpr double MOVETOL       = 1.0e-7;
+constexpr double TOLX          = 4.0 * 3.0e-8;
+constexpr double EPS_HESS      = 3.0e-8;
+constexpr int    MAX_LS_ITERS  = 1000;
+
+template <int KIND>
+__global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
+                                                  const int maxIters, const double gradTol, const int scaleGrads,
+                                                  const uint8_t* __restrict__ active, const int64_t* __restrict__ hessStarts,
+                                                  double* __restrict__ hessians, double* __restrict__ energies,
+                                                  int16_t* __restrict__ statuses, int32_t* __restrict__ itersOut) {
+  constexpr int DIM = Dim<KIND>::value;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int sys = blockIdx.x;
+  if (active && !active[sys]) return;
+  const int tid = threadIdx.x;
+  const int a0  = b.atomStarts[sys];
+  const int n   = (b.atomStarts[sys + 1] - a0) * DIM;
+  double*   gpos = positions + static_cast<int64_t>(a0) * DIM;
+  double*   H    = hessians + hessStarts[sys];
+
+  double* pos   = reinterpret_cast<double*>(smem);
+  double* grad  = pos + n;
+  double* dir   = grad + n;   // xi
+  double* trial = dir + n;    // line-search positions, later H * dGrad
+  double* dGrad = trial + n;
+  double* oldp  = dGrad + n;
+  double* red   = oldp + n;   // NT/64 + 1
+
+  if (n == 0) {
+    if (tid == 0) {
+      energies[sys] = 0.0;
+      if (statuses) statuses[sys] = 0;
+      if (itersOut) itersOut[sys] = 0;
+    }
+    return;
+  }
+
+  for (int i = tid; i < n; i += NT) pos[i] = gpos[i];
+  for (int64_t i = tid; i < static_cast<int64_t>(n) * n; i += NT) H[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) H[static_cast<int64_t>(i) * n + i] = 1.0;
+
+  auto energy_at = [&](const double* p) -> double {
+    return block_reduce<Op::kSum>(system_eval<KIND, false>(b, sys, p, nullptr, w0, w1, a0 * DIM), red);
+  };
+  double gradScale = 1.0;
+  auto   grad_at   = [&](const double* p) {
+    for (int i = tid; i < n; i += NT) grad[i] = 0.0;
+    __syncthreads();
+    system_eval<KIND, true>(b, sys, p, grad, w0, w1, a0 * DIM);
+    __syncthreads();
+    // gradient scaling (bfgs_minimize_permol_kernels.cu:239-275; |g| rule of RDKit >= 2025.09)
+    gradScale = scaleGrads ? 0.1 : 1.0;
+    double mx = 0.0;
+    for (int i = tid; i < n; i += NT) {
+      if (scaleGrads) grad[i] *= gradScale;
+      mx = fmax(mx, fabs(grad[i]));
+    }
+    mx = block_reduce<Op::kMax>(mx, red);
+    if (scaleGrads && mx > 10.0) {
+      while (mx * gradScale > 10.0) gradScale *= 0.5;
+      for (int i = tid; i < n; i += NT) grad[i] *= gradScale;
+    }
+    __syncthreads();
+  };
+
+  double prevE = energy_at(pos);
+  grad_at(pos);
+  for (int i = tid; i < n; i += NT) dir[i] = -grad[i];
+  double sumsq = 0.0;
+  for (int i = tid; i < n; i += NT) sumsq += pos[i] * pos[i];
+  sumsq                 = block_reduce<Op::kSum>(sumsq, red);
+  const double maxStep2 = 1.0e4 * fmax(sumsq, static_cast<double>(n) * static_cast<double>(n));
+
+  bool converged = false;
+  int  iter      = 0;
+  while (!converged && iter < maxIters) {
+    for (int i = tid; i < n; i += NT) oldp[i] = pos[i];
+    // ---- line search set-up (:54-136)
+    double s = 0.0;
+    for (int i = tid; i < n; i += NT) s += dir[i] * dir[i];
+    s = block_reduce<Op::kSum>(s, red);
+    if (s > maxStep2) {
+      const double sc = sqrt(maxStep2 / s);
+      for (int i = tid; i < n; i += NT) dir[i] *= sc;
+    }
+    __syncthreads();
+    double slope = 0.0, test = 0.0;
+    for (int i = tid; i < n; i += NT) {
+      slope += dir[i] * grad[i];
+      test = fmax(test, fabs(dir[i]) / fmax(fabs(pos[i]), 1.0));
+    }
+    slope                  = block_reduce<Op::kSum>(slope, red);
+    test                   = block_reduce<Op::kMax>(test, red);
+    const double lambdaMin = MOVETOL / (test > 0.0 ? test : 1.0e-20);
+    // ---- backtracking line search (:147-196)
+    double lambda = 1.0, lambda2 = 0.0, e2 = 0.0, newE = prevE;
+    for (int ls = 0; ls < MAX_LS_ITERS; ++ls) {
+      for (int i = tid; i < n; i += NT) trial[i] = oldp[i] + lambda * dir[i];
+      __syncthreads();
+      newE               = energy_at(trial);
+      const double eDiff = newE - prevE;
+      if (lambda < lambdaMin || eDiff <= FUNCTOL * lambda * slope) break;
+      double tmp;
+      if (ls == 0) {
+        tmp = -slope / (2.0 * (eDiff - slope));
+      } else {
+        const double rhs1 = eDiff - lambda * slope;
+        const double rhs2 = e2 - prevE - lambda2 * slope;
+        const double a    = (rhs1 / (lambda * lambda) - rhs2 / (lambda2 * lambda2)) / (lambda - lambda2);
+        const double bq   = (-lambda2 * rhs1 / (lambda * lambda) + lambda * rhs2 / (lambda2 * lambda2)) / (lambda - lambda2);
+        if (a == 0.0) {
+          tmp = -slope / (2.0 * bq);
+        } else {
+          const double disc = bq * bq - 3.0 * a * slope;
+          if (disc < 0.0) {
+            tmp = 0.5 * lambda;
+          } else if (bq <= 0.0) {
+            tmp = (-bq + sqrt(disc)) / (3.0 * a);
+          } else {
+            tmp = -slope / (bq + sqrt(disc));
+          }
+        }
+        tmp = fmin(tmp, 0.5 * lambda);
+      }
+      lambda2 = lambda;
+      e2      = newE;
+      lambda  = fmax(tmp, 0.1 * lambda);
+    }
+    // ---- accept the step, TOLX test (:198-229)
+    double stepTest = 0.0;
+    for (int i = tid; i < n; i += NT) {
+      pos[i]   = trial[i];
+      dir[i]   = trial[i] - oldp[i];
+      dGrad[i] = grad[i];
+      stepTest = fmax(stepTest, fabs(dir[i]) / fmax(fabs(trial[i]), 1.0));
+    }
+    stepTest = block_reduce<Op::kMax>(stepTest, red);
+    prevE    = newE;  // energy of the coordinates that are returned (the reference reports the pre-step energy when
+                      // TOLX fires, :680-687; the step is below 1.2e-7 relative there)
+    if (stepTest < TOLX) {
+      converged = true;
+      break;
+    }
+    // ---- new gradient, gradient test (:277-303)
+    grad_at(pos);
+    double gTest = 0.0;
+    for (int i = tid; i < n; i += NT) {
+      dGrad[i] = grad[i] - dGrad[i];
+      gTest    = fmax(gTest, fabs(grad[i]) * fmax(fabs(pos[i]), 1.0));
+    }
+    gTest = block_reduce<Op::kMax>(gTest, red) / fmax(prevE * gradScale, 1.0);
+    if (gTest < gradTol) {
+      converged = true;
+      break;
+    }
+    // ---- BFGS update of the inverse Hessian, new direction (:304-407)
+    for (int r = tid; r < n; r += NT) {
+      double acc = 0.0;
+      for (int c = 0; c < n; ++c) acc += H[static_cast<int64_t>(c) * n + r] * dGrad[c];
+      trial[r] = acc;  // hessDGrad
+    }
+    __syncthreads();
+    double fac = 0.0, fae = 0.0, sumDG = 0.0, sumXi = 0.0;
+    for (int i = tid; i < n; i += NT) {
+      fac += dGrad[i] * dir[i];
+      fae += dGrad[i] * trial[i];
+      sumDG += dGrad[i] * dGrad[i];
+      sumXi += dir[i] * dir[i];
+    }
+    fac   = block_reduce<Op::kSum>(fac, red);
+    fae   = block_reduce<Op::kSum>(fae, red);
+    sumDG = block_reduce<Op::kSum>(sumDG, red);
+    sumXi = block_reduce<Op::kSum>(sumXi, red);
+    if (fac > 0.0 && fac * fac > EPS_HESS * sumDG * sumXi) {
+      const double rfac = 1.0 / fac, fad = 1.0 / fae;
+      for (int i = tid; i < n; i += NT) dGrad[i] = rfac * dir[i] - fad * trial[i];
+      __syncthreads();
+      for (int r = tid; r < n; r += NT) {
+        const double pxi = rfac * dir[r], hdgi = fad * trial[r], dgi = fae * dGrad[r];
+        for (int c = 0; c < n; ++c) {
+          H[static_cast<int64_t>(c) * n + r] += pxi * dir[c] - hdgi * trial[c] + dgi * dGrad[c];
+        }
+      }
+      __syncthreads();
+    }
+    for (int r = tid; r < n; r += NT) {
+      double acc = 0.0;
+      for (int c = 0; c < n; ++c) acc += H[static_cast<int64_t>(c) * n + r] * grad[c];
+      oldp[r] = -acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) dir[i] = oldp[i];
+    __syncthreads();
+    ++iter;
+  }
+  for (int i = tid; i < n; i += NT) gpos[i] = pos[i];
+  if (tid == 0) {
+    energies[sys] = prevE;
+    if (statuses) statuses[sys] = converged ? 0 : 1;
+    if (itersOut) itersOut[sys] = iter;
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+
+int to_batch(const nvmk_ff_batch* in, Batch& out) {
+  NVMK_REQUIRE(in != nullptr, "ff: NULL batch");
+  NVMK_REQUIRE(in->kind >= NVMK_FF_DG && in->kind <= NVMK_FF_QUARTIC, "ff: unknown force-field kind %d", in->kind);
+  NVMK_REQUIRE(in->n_systems >= 0, "ff: negative system count");
+  NVMK_REQUIRE(in->n_systems == 0 || in->atom_starts != nullptr, "ff: NULL atom_starts");
+  static const int nGroups[4] = {3, 6, 7, 0};
+  out.kind       = in->kind;
+  out.nSystems   = in->n_systems;
+  out.atomStarts = in->atom_starts;
+  for (int g = 0; g < 8; ++g) {
+    out.g[g] = {in->groups[g].starts, in->groups[g].idx, in->groups[g].par};
+    if (g < nGroups[in->kind] && in->n_systems > 0) {
+      NVMK_REQUIRE(in->groups[g].starts != nullptr, "ff: term group %d of kind %d has NULL starts", g, in->kind);
+    }
+  }
+  return NVMK_OK;
+}
+
+#define NVMK_FF_DISPATCH(kind, CALL)               \
+  switch (kind) {                                  \
+    case NVMK_FF_DG: { constexpr int K = NVMK_FF_DG; CALL; break; }           \
+    case NVMK_FF_ETK: { constexpr int K = NVMK_FF_ETK; CALL; break; }         \
+    case NVMK_FF_MMFF: { constexpr int K = NVMK_FF_MMFF; CALL; break; }       \
+    default: { constexpr int K = NVMK_FF_QUARTIC; CALL; break; }              \
+  }
+
+}  // namespace minim
+}  // namespace nvmk
+
+using namespace nvmk;
+using namespace nvmk::minim;
+
+extern "C" {
+
+int nvmk_ff_energy(const nvmk_ff_batch* batch, double w0, double w1, const double* d_pos, const uint8_t* d_active,
+                   double* d_energies, void* stream) {
+  Batch b;
+  int   rc = to_batch(batch, b);
+  if (rc != NVMK_OK) return rc;
+  if (b.nSystems == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_pos && d_energies, "ff energy: NULL buffer");
+  NVMK_FF_DISPATCH(b.kind, hipLaunchKernelGGL(energy_kernel<K>, dim3(b.nSystems), dim3(NT), 0, as_stream(stream), b, d_pos, w0, w1,
+                                              d_active, d_energies));
+  NVMK_LAUNCH_CHECK();
+  return NVMK_OK;
+}
+
+int nvmk_ff_gradient(const nvmk_ff_batch* batch, double w0, double w1, const double* d_pos, const uint8_t* d_active,
+                     double* d_grad, void* stream) {
+  Batch b;
+  int   rc = to_batch(batch, b);
+  if (rc != NVMK_OK) return rc;
+  if (b.nSystems == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_pos && d_grad, "ff gradient: NULL buffer");
+  NVMK_FF_DISPATCH(b.kind, hipLaunchKernelGGL(grad_kernel<K>, dim3(b.nSystems), dim3(NT), 0, as_stream(stream), b, d_pos, w0, w1,
+                                              d_active, d_grad));
+  NVMK_LAUNCH_CHECK();
+  return NVMK_OK;
+}
+
+int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts, double w0, double w1, int max_iters,
+                       double grad_tol, int scale_grads, double* d_pos, const uint8_t* d_active, double* d_energies,
+                       int16_t* d_statuses, int32_t* d_iters, void* stream_) {
+  Batch b;
+  int   rc = to_batch(batch, b);
+  if (rc != NVMK_OK) return rc;
+  if (b.nSystems == 0) return NVMK_OK;
+  NVMK_REQUIRE(h_atom_starts && d_pos && d_energies, "bfgs: NULL buffer");
+  NVMK_REQUIRE(max_iters >= 0, "bfgs: negative iteration count");
+  hipStream_t stream = as_stream(stream_);
+  const int   dim    = (b.kind == NVMK_FF_MMFF) ? 3 : 4;
+  // inverse-Hessian offsets (n^2 doubles per system) and the LDS need of the largest system
+  std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
+  int                  maxN = 0;
+  for (int s = 0; s < b.nSystems; ++s) {
+    const int64_t n = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
+    NVMK_REQUIRE(n >= 0, "bfgs: atom_starts must be non-decreasing");
+    hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + n * n;
+    maxN                           = std::max<int>(maxN, static_cast<int>(n));
+  }
+  const size_t shmem = (6 * static_cast<size_t>(maxN) + NT / 64 + 1) * sizeof(double);
+  NVMK_REQUIRE(shmem <= 160 * 1024, "bfgs: a system with %d coordinates needs %zu bytes of LDS (max 160 KiB)", maxN, shmem);
+  StreamScratch hessMem, startsMem;
+  NVMK_HIP_CHECK(hessMem.alloc(static_cast<size_t>(hs.back()) * sizeof(double), stream));
+  NVMK_HIP_CHECK(startsMem.alloc(hs.size() * sizeof(int64_t), stream));
+  NVMK_HIP_CHECK(hipMemcpyAsync(startsMem.ptr, hs.data(), hs.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+  NVMK_FF_DISPATCH(b.kind, {
+    auto kern = bfgs_kernel<K>;
+    if (shmem > 64 * 1024) {
+      NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(shmem)));
+    }
+    hipLaunchKernelGGL(kern, dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters, grad_tol, scale_grads,
+                       d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies, d_statuses, d_iters);
+  });
+  NVMK_LAUNCH_CHECK();
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // `hs` (pageable) must outlive its async copy; scratch is freed in stream order
+  return NVMK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+"""CPU oracle for the force-field / BFGS path — TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+numpy restatements of the term energies (vectorised over the terms of ONE system), a finite-difference
+gradient, and a plain-Python RDKit-style BFGS.  Each function cites the reference lines it follows.
+
+Pinning status: "parity unpinned" against RDKit force-field contribs (RDKit's typing / parameter tables are
+needed to produce real term lists; neither the build nor the GPU image has RDKit).  Pinned without RDKit:
+  * analytic gradients of the product against central finite differences of THESE energies (tolerance 1e-6
+    relative), with the two RDKit conventions where the "gradient" is half the derivative (chiral volume,
+    fourth dimension) applied explicitly;
+  * closed-form values of single terms (zero inside bounds, known geometry) in tests/test_oracle_ff.py;
+  * BFGS: the reference's RDKit-free quartic test (tests/test_bfgs_minimizer.cu:823-1029, converge to x_p = p).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+RAD2DEG = 180.0 / np.pi
+DEG2RAD = np.pi / 180.0
+MDYNE_A_TO_KCAL = 143.9325
+
+# group layouts (n_idx, n_par) per force-field kind — must match include/nvmolkit_amd.h
+DG, ETK, MMFF, QUARTIC = 0, 1, 2, 3
+LAYOUT = {
+    DG: [(2, 3), (4, 2), (1, 0)],
+    ETK: [(4, 12), (4, 4), (2, 3), (2, 3), (3, 2), (2, 3)],
+    MMFF: [(2, 2), (3, 3), (3, 5), (4, 1), (4, 3), (2, 2), (2, 3)],
+    QUARTIC: [],
+}
+DIM = {DG: 4, ETK: 4, MMFF: 3, QUARTIC: 4}
+
+
+def _xyz(pos, idx):
+    return pos[idx][:, :3]
+
+
+def _cos_angle(p1, p2, p3):
+    r1, r2 = p1 - p2, p3 - p2
+    l1, l2 = (r1 * r1).sum(1), (r2 * r2).sum(1)
+    ok = (l1 > 1e-16) & (l2 > 1e-16)
+    c = np.zeros(len(p1))
+    c[ok] = np.clip((r1[ok] * r2[ok]).sum(1) / np.sqrt(l1[ok] * l2[ok]), -1.0, 1.0)
+    return c, ok
+
+
+def _cos_dihedral(p1, p2, p3, p4):
+    r1, r2, r4 = p1 - p2, p3 - p2, p4 - p3
+    t1, t2 = np.cross(r1, r2), np.cross(-r2, r4)
+    d = (t1 * t1).sum(1) * (t2 * t2).sum(1)
+    ok = d > 1e-16
+    c = np.zeros(len(p1))
+    c[ok] = np.clip((t1[ok] * t2[ok]).sum(1) / np.sqrt(d[ok]), -1.0, 1.0)
+    return c, ok
+
+
+# ---- DG (src/forcefields/dist_geom_kernels_device.cuh:37-231) ---------------------------------------
+
+def dg_terms(pos, groups, chiral_w, fourth_w):
+    """Per-group energy arrays of one system; pos is (n_atoms, 4)."""
+    out = []
+    idx, par = groups[0]
+    d2 = ((pos[idx[:, 0]] - pos[idx[:, 1]]) ** 2).sum(1)  # all four dimensions (:43-45)
+    lb2, ub2, w = par[:, 0], par[:, 1], par[:, 2]
+    val = np.where(d2 > ub2, d2 / ub2 - 1.0, np.where(d2 < lb2, 2.0 * lb2 / (lb2 + d2) - 1.0, 0.0))
+    out.append(w * np.maximum(val, 0.0) ** 2)
+    idx, par = groups[1]
+    p1, p2, p3, p4 = (_xyz(pos, idx[:, k]) for k in range(4))
+    vol = ((p1 - p4) * np.cross(p2 - p4, p3 - p4)).sum(1)  # (:97-130)
+    lo, hi = par[:, 0], par[:, 1]
+    out.append(chiral_w * np.where(vol < lo, (vol - lo) ** 2, np.where(vol > hi, (vol - hi) ** 2, 0.0)))
+    idx, _ = groups[2]
+    out.append(fourth_w * pos[idx[:, 0], 3] ** 2)  # (:209-217)
+    return out
+
+
+# ---- ETK (dist_geom_kernels_device.cuh:237-445) -----------------------------------------------------
+
+def _flat_bottom_dist(pos, idx, par):
+    d = np.sqrt(((_xyz(pos, idx[:, 0]) - _xyz(pos, idx[:, 1])) ** 2).sum(1))
+    lo, hi, k = par[:, 0], par[:, 1], par[:, 2]
+    diff = np.where(d < lo, lo - d, np.where(d > hi, d - hi, 0.0))
+    return 0.5 * k * diff * diff  # (:368-392)
+
+
+def etk_terms(pos, groups):
+    out = []
+    idx, par = groups[0]
+    c, _ = _cos_dihedral(*(_xyz(pos, idx[:, k]) for k in range(4)))  # degenerate -> cosPhi = 0 (:286-288)
+    cheb = [c, 2 * c**2 - 1, 4 * c**3 - 3 * c, 8 * c**4 - 8 * c**2 + 1, 16 * c**5 - 20 * c**3 + 5 * c,
+            32 * c**6 - 48 * c**4 + 18 * c**2 - 1]
+    out.append(sum(par[:, k] * (1.0 + par[:, 6 + k] * cheb[k]) for k in range(6)))  # (:237-258)
+    idx, par = groups[1]
+    p1, p2, p3, p4 = (_xyz(pos, idx[:, k]) for k in range(4))
+    rji, rjk, rjl = p1 - p2, p3 - p2, p4 - p2
+    n = np.cross(rji, rjk)
+    ln, ll = (n * n).sum(1), (rjl * rjl).sum(1)
+    ok = (ln > 1e-16 * (rji * rji).sum(1) * (rjk * rjk).sum(1)) & (ll > 1e-16) & ((rji * rji).sum(1) > 1e-16) & ((rjk * rjk).sum(1) > 1e-16)
+    cos_y = np.zeros(len(idx))
+    cos_y[ok] = np.clip((n[ok] * rjl[ok]).sum(1) / np.sqrt(ln[ok] * ll[ok]), -1.0, 1.0)
+    sin_y_sq = np.maximum(1.0 - cos_y**2, 1e-16)
+    out.append(par[:, 3] * (par[:, 0] + par[:, 1] * np.sqrt(sin_y_sq) + par[:, 2] * (2.0 * sin_y_sq - 1.0)))  # (:345-366)
+    out.append(_flat_bottom_dist(pos, *groups[2]))
+    out.append(_flat_bottom_dist(pos, *groups[3]))
+    idx, par = groups[4]
+    c, ok = _cos_angle(*(_xyz(pos, idx[:, k]) for k in range(3)))
+    theta = RAD2DEG * np.arccos(c)
+    term = np.where(theta < par[:, 0], theta - par[:, 0], np.where(theta > par[:, 1], theta - par[:, 1], 0.0))
+    out.append(np.where(ok, term * term, 0.0))  # force constant 1 (:394-445, defaultAngleForceConstant)
+    out.append(_flat_bottom_dist(pos, *groups[5]))
+    return out
+
+
+# ---- MMFF94 (src/forcefields/mmff_kernels_device.cuh:28-660) ----------------------------------------
+
+def mmff_terms(pos, groups):
+    out = []
+    idx, par = groups[0]
+    r = np.sqrt(((pos[idx[:, 0]] - pos[idx[:, 1]]) ** 2).sum(1))
+    dr = r - par[:, 0]
+    cs = -2.0
+    out.append(0.5 * MDYNE_A_TO_KCAL * par[:, 1] * dr**2 * (1.0 + cs * dr + 7.0 / 12.0 * cs * cs * dr**2))
+    idx, par = groups[1]
+    c, ok = _cos_angle(*(pos[idx[:, k]] for k in range(3)))
+    dt = RAD2DEG * np.arccos(c) - par[:, 0]
+    bend = 0.5 * MDYNE_A_TO_KCAL * DEG2RAD**2 * par[:, 1] * dt**2 * (1.0 - 0.4 * DEG2RAD * dt)
+    out.append(np.where(ok, np.where(par[:, 2] != 0, MDYNE_A_TO_KCAL * par[:, 1] * (1.0 + c), bend), 0.0))
+    idx, par = groups[2]
+    p1, p2, p3 = (pos[idx[:, k]] for k in range(3))
+    d1, d2 = np.sqrt(((p1 - p2) ** 2).sum(1)), np.sqrt(((p3 - p2) ** 2).sum(1))
+    c, ok = _cos_angle(p1, p2, p3)
+    dt = RAD2DEG * np.arccos(c) - par[:, 0]
+    out.append(np.where(ok, 2.51210 * dt * ((d1 - par[:, 1]) * par[:, 3] + (d2 - par[:, 2]) * par[:, 4]), 0.0))
+    idx, par = groups[3]
+    p1, p2, p3, p4 = (pos[idx[:, k]] for k in range(4))
+    n = np.cross(p1 - p2, p3 - p2)
+    rjl = p4 - p2
+    ln, ll = (n * n).sum(1), (rjl * rjl).sum(1)
+    ok = (ln > 1e-16) & (ll > 1e-16)
+    s = np.zeros(len(idx))
+    s[ok] = np.clip((n[ok] * rjl[ok]).sum(1) / np.sqrt(ln[ok] * ll[ok]), -1.0, 1.0)
+    chi = RAD2DEG * np.arcsin(s)
+    out.append(0.5 * MDYNE_A_TO_KCAL * DEG2RAD**2 * par[:, 0] * chi**2)
+    idx, par = groups[4]
+    c, _ = _cos_dihedral(*(pos[idx[:, k]] for k in range(4)))
+    out.append(0.5 * (par[:, 0] * (1.0 + c) + par[:, 1] * (1.0 - (2 * c**2 - 1)) + par[:, 2] * (1.0 + (4 * c**3 - 3 * c))))
+    idx, par = groups[5]
+    r = np.sqrt(((pos[idx[:, 0]] - pos[idx[:, 1]]) ** 2).sum(1))
+    rs, eps = par[:, 0], par[:, 1]
+    out.append(eps * (1.07 * rs / (r + 0.07 * rs)) ** 7 * (1.12 * rs**7 / (r**7 + 0.12 * rs**7) - 2.0))
+    idx, par = groups[6]
+    r = np.sqrt(((pos[idx[:, 0]] - pos[idx[:, 1]]) ** 2).sum(1)) + 0.05
+    e = 332.0716 * par[:, 0] / np.where(par[:, 1] == 2, r * r, r)
+    out.append(np.where(par[:, 2] != 0, 0.75 * e, e))
+    return out
+
+
+def system_energy(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: float = 1.0, coord_start: int = 0,
+                  per_group: bool = False):
+    """Energy of one system.  pos: (n_atoms, DIM[kind]); groups: list of (idx (n, n_idx) int, par (n, n_par))."""
+    if kind == QUARTIC:
+        target = coord_start + np.arange(pos.size).reshape(pos.shape)
+        diff = pos - target
+        if w0 == 0.0:
+            diff = diff[:, :3]
+        return float((diff**4).sum())
+    parts = {DG: lambda: dg_terms(pos, groups, w0, w1), ETK: lambda: etk_terms(pos, groups),
+             MMFF: lambda: mmff_terms(pos, groups)}[kind]()
+    if per_group:
+        return [float(p.sum()) for p in parts]
+    return float(sum(p.sum() for p in parts))
+
+
+def system_gradient(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: float = 1.0, coord_start: int = 0,
+                    h: float = 1e-5) -> np.ndarray:
+    """Central finite differences of system_energy, with RDKit's half-gradient convention for the chiral and
+    fourth-dimension terms of the DG field (dist_geom_kernels_device.cuh:172-176, :229)."""
+    def fd(energy_fn):
+        g = np.zeros_like(pos)
+        for a in range(pos.shape[0]):
+            for c in range(pos.shape[1]):
+                p = pos.copy()
+                p[a, c] += h
+                ep = energy_fn(p)
+                p[a, c] -= 2 * h
+                g[a, c] = (ep - energy_fn(p)) / (2 * h)
+        return g
+
+    if kind != DG:
+        return fd(lambda p: system_energy(kind, p, groups, w0, w1, coord_start))
+    empty = [(np.zeros((0, n), dtype=np.int64), np.zeros((0, m))) for n, m in LAYOUT[DG]]
+    only = lambda k: [groups[i] if i == k else empty[i] for i in range(3)]  # noqa: E731
+    return (fd(lambda p: system_energy(DG, p, only(0), w0, w1)) + 0.5 * fd(lambda p: system_energy(DG, p, only(1), w0, w1)) +
+            0.5 * fd(lambda p: system_energy(DG, p, only(2), w0, w1)))
+
+
+# ---- BFGS (src/minimizer/bfgs_minimize_permol_kernels.cu:35-745, i.e. RDKit BFGSOpt.h) --------------
+
+FUNCTOL, MOVETOL, TOLX, EPS = 1e-4, 1e-7, 4 * 3e-8, 3e-8
+
+
+def bfgs_minimize(energy, gradient, x0: np.ndarray, max_iters: int = 200, grad_tol: float = 1e-4, scale_grads: bool = True):
+    """Returns (x, energy, converged, iterations).  energy(x) -> float, gradient(x) -> array like x (flat)."""
+    x = np.array(x0, dtype=np.float64).ravel().copy()
+    n = x.size
+
+    def scaled_grad(p):
+        g = np.array(gradient(p), dtype=np.float64).ravel()
+        scale = 0.1 if scale_grads else 1.0
+        if scale_grads:
+            g = g * scale
+        mx = np.abs(g).max() if n else 0.0
+        if scale_grads and mx > 10.0:
+            while mx * scale > 10.0:
+                scale *= 0.5
+            g = g * scale
+        return g, scale
+
+    e_prev = energy(x)
+    g, gscale = scaled_grad(x)
+    d = -g
+    hinv = np.eye(n)
+    max_step2 = 1e4 * max(float((x * x).sum()), float(n) * n)
+    converged = False
+    it = 0
+    while not converged and it < max_iters:
+        old = x.copy()
+        s = float((d * d).sum())
+        if s > max_step2:
+            d = d * np.sqrt(max_step2 / s)
+        slope = float((d * g).sum())
+        test = float((np.abs(d) / np.maximum(np.abs(x), 1.0)).max())
+        lam_min = MOVETOL / (test if test > 0 else 1e-20)
+        lam, lam2, e2, e_new = 1.0, 0.0, 0.0, e_prev
+        trial = old
+        for ls in range(1000):
+            trial = old + lam * d
+            e_new = energy(trial)
+            e_diff = e_new - e_prev
+            if lam < lam_min or e_diff <= FUNCTOL * lam * slope:
+                break
+            if ls == 0:
+                tmp = -slope / (2.0 * (e_diff - slope))
+            else:
+                rhs1 = e_diff - lam * slope
+                rhs2 = e2 - e_prev - lam2 * slope
+                a = (rhs1 / lam**2 - rhs2 / lam2**2) / (lam - lam2)
+                b = (-lam2 * rhs1 / lam**2 + lam * rhs2 / lam2**2) / (lam - lam2)
+                if a == 0.0:
+                    tmp = -slope / (2.0 * b)
+                else:
+                    disc = b * b - 3.0 * a * slope
+                    if disc < 0.0:
+                        tmp = 0.5 * lam
+                    elif b <= 0.0:
+                        tmp = (-b + np.sqrt(disc)) / (3.0 * a)
+                    else:
+                        tmp = -slope / (b + np.sqrt(disc))
+                tmp = min(tmp, 0.5 * lam)
+            lam2, e2 = lam, e_new
+            lam = max(tmp, 0.1 * lam)
+        x = trial
+        xi = x - old
+        e_prev = e_new
+        if float((np.abs(xi) / np.maximum(np.abs(x), 1.0)).max()) < TOLX:
+            converged = True
+            break
+        g_old = g
+        g, gscale = scaled_grad(x)
+        dg = g - g_old
+        if float((np.abs(g) * np.maximum(np.abs(x), 1.0)).max()) / max(e_prev * gscale, 1.0) < grad_tol:
+            converged = True
+            break
+        hdg = hinv @ dg
+        fac, fae = float(dg @ xi), float(dg @ hdg)
+        if fac > 0 and fac * fac > EPS * float(dg @ dg) * float(xi @ xi):
+            fac, fad = 1.0 / fac, 1.0 / fae
+            dgv = fac * xi - fad * hdg
+            hinv = hinv + fac * np.outer(xi, xi) - fad * np.outer(hdg, hdg) + fae * np.outer(dgv, dgv)
+        d = -(hinv @ g)
+        it += 1
+    return x.reshape(np.shape(x0)), e_prev, converged, it

@@ -1,0 +1,103 @@
+"""Pins the force-field / BFGS oracle (oracle/ff.py) without RDKit: closed-form single terms and the reference's
+RDKit-free quartic BFGS case (tests/test_bfgs_minimizer.cu:823-1029, :1139-1147)."""
+
+import numpy as np
+import pytest
+
+from oracle import ff
+from tests import util
+
+
+def test_dg_terms_closed_form():
+    pos = np.array([[0.0, 0, 0, 0], [2.0, 0, 0, 0], [0, 1.0, 0, 0.5], [0, 0, 1.0, 0]])
+    e = np.zeros((0, 2), dtype=int)
+    inside = [(np.array([[0, 1]]), np.array([[1.0, 9.0, 1.0]])), (np.zeros((0, 4), int), np.zeros((0, 2))), (np.zeros((0, 1), int), np.zeros((0, 0)))]
+    assert ff.system_energy(ff.DG, pos, inside) == 0.0                       # lb2 <= d2 = 4 <= ub2
+    over = [(np.array([[0, 1]]), np.array([[1.0, 2.0, 3.0]])), inside[1], inside[2]]
+    assert ff.system_energy(ff.DG, pos, over) == pytest.approx(3.0 * (4.0 / 2.0 - 1.0) ** 2)
+    under = [(np.array([[0, 1]]), np.array([[16.0, 25.0, 1.0]])), inside[1], inside[2]]
+    assert ff.system_energy(ff.DG, pos, under) == pytest.approx((2 * 16.0 / (16.0 + 4.0) - 1.0) ** 2)
+    # chiral volume of (e_x*2, e_y, e_z) about the origin = 2; bounds [3, 4] -> w (2 - 3)^2
+    chiral = [(e, np.zeros((0, 3))), (np.array([[1, 2, 3, 0]]), np.array([[3.0, 4.0]])), inside[2]]
+    assert ff.system_energy(ff.DG, pos, chiral, w0=0.2) == pytest.approx(0.2)
+    fourth = [(e, np.zeros((0, 3))), inside[1], (np.array([[2]]), np.zeros((1, 0)))]
+    assert ff.system_energy(ff.DG, pos, fourth, w1=0.1) == pytest.approx(0.1 * 0.25)
+
+
+def test_mmff_terms_closed_form():
+    pos = np.array([[0.0, 0, 0], [1.5, 0, 0], [1.5, 1.2, 0], [3.0, 1.2, 0.0]])
+    empty = lambda n, m: (np.zeros((0, n), int), np.zeros((0, m)))  # noqa: E731
+    groups = [empty(n, m) for n, m in ff.LAYOUT[ff.MMFF]]
+    g = list(groups)
+    g[0] = (np.array([[0, 1]]), np.array([[1.5, 5.0]]))
+    assert ff.system_energy(ff.MMFF, pos, g) == 0.0                          # bond at rest length
+    g[0] = (np.array([[0, 1]]), np.array([[1.4, 5.0]]))
+    dr = 0.1
+    assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(143.9325 / 2 * 5.0 * dr**2 * (1 - 2 * dr + 7 / 12 * 4 * dr**2))
+    g = list(groups)
+    g[1] = (np.array([[0, 1, 2]]), np.array([[90.0, 0.8, 0.0]]))
+    assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(0.0, abs=1e-20)  # right angle at rest
+    g[1] = (np.array([[0, 1, 2]]), np.array([[90.0, 0.8, 1.0]]))
+    assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(143.9325 * 0.8)  # linear form, cos = 0
+    g = list(groups)
+    g[4] = (np.array([[0, 1, 2, 3]]), np.array([[1.0, 2.0, 3.0]]))           # trans dihedral: cos(phi) = -1
+    assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(0.5 * (0 + 0 + 0))
+    g = list(groups)
+    g[6] = (np.array([[0, 1]]), np.array([[0.25, 1.0, 1.0]]))
+    assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(0.75 * 332.0716 * 0.25 / 1.55)
+
+
+def test_etk_terms_closed_form():
+    pos = np.zeros((4, 4))
+    pos[:, :3] = [[0, 0, 0], [1.5, 0, 0], [1.5, 1.2, 0], [1.5, 1.2, 1.0]]    # dihedral 90 deg -> cos = 0
+    empty = lambda n, m: (np.zeros((0, n), int), np.zeros((0, m)))  # noqa: E731
+    groups = [empty(n, m) for n, m in ff.LAYOUT[ff.ETK]]
+    g = list(groups)
+    fc = np.array([[1.0, 2, 3, 4, 5, 6, 1, 1, 1, 1, 1, 1]])
+    g[0] = (np.array([[0, 1, 2, 3]]), fc)
+    # cos k*90deg = 0, -1, 0, 1, 0, -1
+    assert ff.system_energy(ff.ETK, pos, g) == pytest.approx(1 + 2 * 0 + 3 + 4 * 2 + 5 + 6 * 0)
+    g = list(groups)
+    g[2] = (np.array([[0, 1]]), np.array([[1.0, 1.2, 100.0]]))
+    assert ff.system_energy(ff.ETK, pos, g) == pytest.approx(0.5 * 100 * 0.3**2)
+    g[2] = (np.array([[0, 1]]), np.array([[1.0, 2.0, 100.0]]))
+    assert ff.system_energy(ff.ETK, pos, g) == 0.0
+    g = list(groups)
+    g[4] = (np.array([[0, 1, 2]]), np.array([[100.0, 120.0]]))
+    assert ff.system_energy(ff.ETK, pos, g) == pytest.approx(10.0**2)
+
+
+@pytest.mark.parametrize("kind", [ff.DG, ff.ETK, ff.MMFF])
+def test_finite_difference_gradient_is_self_consistent(kind):
+    rng = np.random.default_rng(kind)
+    pos, groups = util.random_ff_system(kind, 9, rng)
+    g1 = ff.system_gradient(kind, pos, groups, 0.7, 0.3, h=1e-5)
+    g2 = ff.system_gradient(kind, pos, groups, 0.7, 0.3, h=2e-5)
+    assert np.allclose(g1, g2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("last_dim", [True, False])
+def test_bfgs_quartic_known_answer(last_dim):
+    # systems atomStarts = {0, 3, 10, 12}, dim 4, start p + U(-2, 2); converge to x_p = p within 0.1
+    starts = [0, 3, 10, 12]
+    rng = np.random.default_rng(42)
+    for s in range(3):
+        n = (starts[s + 1] - starts[s]) * 4
+        c0 = starts[s] * 4
+        x0 = c0 + np.arange(n) + rng.uniform(-2, 2, size=n)
+        shape = (n // 4, 4)
+        w0 = 1.0 if last_dim else 0.0
+        e = lambda x: ff.system_energy(ff.QUARTIC, x.reshape(shape), [], w0, 0.0, c0)  # noqa: E731
+
+        def g(x):
+            d = x - (c0 + np.arange(n))
+            gr = 4 * d**3
+            if not last_dim:
+                gr.reshape(shape)[:, 3] = 0.0
+            return gr
+
+        x, energy, conv, iters = ff.bfgs_minimize(e, g, x0, max_iters=400, grad_tol=1e-5, scale_grads=False)
+        target = c0 + np.arange(n)
+        mask = np.ones(n, bool) if last_dim else (np.arange(n) % 4 != 3)
+        assert np.abs(x - target)[mask].max() < 0.1
+        assert energy < 1e-3
