@@ -176,7 +176,7 @@ int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uint32_t* d_bo
  *     g2 fourth dimension    idx(i)           -
  *   NVMK_FF_ETK  (dist_geom.h:73-130)
  *     g0 experimental torsion idx(1..4) par(fc[6], sign[6])      g1 inversion idx(1..4) par(C0, C1, C2, k)
- *     g2 1-2 distance idx(i, j) par(minLen, maxLen, k)           g3 1-3 distance (same)
+ *     g2 1-2 distance idx(i, j) par(minLen, maxLen, k, pinned)   g3 1-3 distance (same; pinned = isImproperConstrained)
  *     g4 1-3 angle idx(1, 2, 3) par(minAngle, maxAngle) [deg]    g5 long-range distance (as g2)
  *   NVMK_FF_MMFF (src/forcefields/mmff.h:37-145)
  *     g0 bond idx(i, j) par(r0, kb)                 g1 angle idx(1,2,3) par(theta0, ka, isLinear)
@@ -203,6 +203,18 @@ typedef struct nvmk_ff_batch {
   int32_t        n_systems;
   const int32_t* atom_starts; /* device, [n_systems + 1] */
   nvmk_ff_group  groups[8];
+  /* Optional (NULL / 0 = unused).  system_mol: the term tables are per MOLECULE and system s reads row
+   * system_mol[s] of every `starts` array — conformers of one molecule share one copy of the tables (the
+   * reference replicates them per conformer, src/forcefields/mmff.h:327-344).  group_mask: bit g enables group g
+   * (0 = all; used for the ETK planarity energy = impropers only).  etk_ref12/13: per-system reference distances
+   * of the ETK 1-2 / 1-3 restraints, laid out like the system's terms; bounds become ref +- (max - min) / 2
+   * (updateReferencePositionsKernel, src/etkdg_stage_etk_minimization.cu:32-64). */
+  const int32_t* system_mol;
+  uint32_t       group_mask;
+  const int32_t* etk_ref12_starts;
+  const double*  etk_ref12;
+  const int32_t* etk_ref13_starts;
+  const double*  etk_ref13;
 } nvmk_ff_batch;
 
 /* energies[s] / gradient (same layout as d_pos) of every system with d_active[s] != 0 (NULL = all). */
@@ -216,6 +228,72 @@ int nvmk_ff_gradient(const nvmk_ff_batch* batch, double w0, double w1, const dou
 int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts, double w0, double w1, int max_iters,
                        double grad_tol, int scale_grads, double* d_pos, const uint8_t* d_active, double* d_energies,
                        int16_t* d_statuses, int32_t* d_iters, void* stream);
+
+/* ---- E1: ETKDG attempt scheduler -------------------------------------------------------------------------
+ * Replaces nvMolKit::detail::Scheduler (src/etkdg_impl.h:223-280, src/etkdg_impl.cpp:272-326): round-robin dispatch
+ * of molecule ids, at most confs_per_mol * max_iterations attempts per molecule, oversubscription once every
+ * molecule has had confs_per_mol attempts.  Thread-safe.  create() returns NULL (and sets the error slot) unless all
+ * three parameters are > 0.  dispatch() writes up to batch_size ids; record() takes -1 for a failed attempt. */
+void* nvmk_scheduler_create(int n_mols, int confs_per_mol, int max_iterations);
+void  nvmk_scheduler_destroy(void* scheduler);
+int   nvmk_scheduler_dispatch(void* scheduler, int batch_size, int32_t* h_mol_ids_out, int* n_out);
+int   nvmk_scheduler_record(void* scheduler, const int32_t* h_mol_ids, const int16_t* h_finished_on_iteration, int n);
+
+/* ---- E2-E8: batched ETKDG embedding on flattened molecules -----------------------------------------------
+ * Replaces nvMolKit::embedMolecules (src/etkdg.cpp:90-484) downstream of RDKit: the caller supplies, per UNIQUE
+ * molecule, the DG and ETK term groups (layouts of nvmk_ff_batch, `starts` indexed by molecule) and the list of
+ * stereochemistry checks that RDKit's EmbedArgs hold (tetrahedralCarbons, chiralCenters, doubleBondEnds,
+ * stereoDoubleBonds; src/embedder_utils.cpp:229-347).  Stage order, weights and thresholds are the reference's
+ * (src/etkdg.cpp:331-419): random 4-D coordinates -> DG minimise (1.0, 0.1, 400 iters, E/atom < 0.05) -> tetrahedral
+ * check -> [first chiral check] -> DG minimise (0.2, 1.0, 200) -> [ETK minimise 300 + planarity] -> double-bond
+ * geometry -> [final chiral volume, chiral distances, chiral centre-in-volume, double-bond stereo].
+ *
+ * Stereo check term = kind + 5 local atom indices + 2 doubles:
+ *   NVMK_CHECK_TETRAHEDRAL           idx(centre, n1, n2, n3, n4 or centre)  par(inFusedSmallRings, -)
+ *   NVMK_CHECK_CHIRAL_VOLUME         idx(-, 1, 2, 3, 4)                     par(volLower, volUpper)
+ *   NVMK_CHECK_CHIRAL_DISTANCE       idx(i, j, -, -, -)                     par(lower, upper)
+ *   NVMK_CHECK_CHIRAL_CENTER_VOLUME  idx as TETRAHEDRAL                     -
+ *   NVMK_CHECK_DOUBLE_BOND_STEREO    idx(0, 1, 2, 3, -)                     par(sign, -)
+ *   NVMK_CHECK_DOUBLE_BOND_GEOMETRY  idx(0, 1, 2, -, -)                     -
+ * Output: conformer c of molecule m starts at d_coords[3 * (confs_per_mol * sum_{k<m} n_atoms[k] + c * n_atoms[m])],
+ * h_conf_counts[m] conformers are valid.  h_stage_failures (optional, NVMK_ETKDG_N_STAGES ints) totals failures per
+ * stage (the reference's ETKDGContext::totalFailures).  Blocking. */
+#define NVMK_CHECK_TETRAHEDRAL 0
+#define NVMK_CHECK_CHIRAL_VOLUME 1
+#define NVMK_CHECK_CHIRAL_DISTANCE 2
+#define NVMK_CHECK_CHIRAL_CENTER_VOLUME 3
+#define NVMK_CHECK_DOUBLE_BOND_STEREO 4
+#define NVMK_CHECK_DOUBLE_BOND_GEOMETRY 5
+#define NVMK_ETKDG_N_STAGES 11
+
+typedef struct nvmk_etkdg_molset {
+  int32_t        n_mols;
+  const int32_t* h_n_atoms;        /* HOST [n_mols] */
+  nvmk_ff_group  dg[3];            /* DEVICE, starts [n_mols + 1] */
+  nvmk_ff_group  etk[6];           /* DEVICE, starts [n_mols + 1]; may be all-NULL when the ETK stage is off */
+  const int32_t* check_starts;     /* DEVICE [n_mols + 1], NULL = no checks */
+  const int32_t* check_kind;
+  const int32_t* check_idx;        /* 5 per term */
+  const double*  check_par;        /* 2 per term */
+  const int32_t* num_impropers;    /* DEVICE [n_mols] (planarity tolerance 0.7 * num_impropers) */
+  const int32_t* h_etk_d12_counts; /* HOST [n_mols]: terms of etk[2] / etk[3] per molecule */
+  const int32_t* h_etk_d13_counts;
+} nvmk_etkdg_molset;
+
+typedef struct nvmk_etkdg_params {
+  int32_t  confs_per_mol;
+  int32_t  max_iterations;     /* attempts per conformer (reference: 10 x atoms when -1, src/etkdg.cpp:71-85,195-197) */
+  int32_t  batch_size;         /* conformer attempts per batch (reference default 500) */
+  int32_t  use_exp_torsions;   /* EmbedParameters::useExpTorsionAnglePrefs */
+  int32_t  use_basic_knowledge;
+  int32_t  enforce_chirality;
+  double   box_size;           /* 5 * boxSizeMult, or -boxSizeMult if negative (etkdg_stage_coordgen.cu:101-106) */
+  double   force_tol;          /* EmbedParameters::optimizerForceTol */
+  uint64_t seed;
+} nvmk_etkdg_params;
+
+int nvmk_etkdg_embed(const nvmk_etkdg_molset* mols, const nvmk_etkdg_params* params, double* d_coords,
+                     int32_t* h_conf_counts, int32_t* h_stage_failures, void* stream);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,11 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_ff_gradient": (_int, [_vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "nvmk_bfgs_minimize": (_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _int, ctypes.c_double, _int, _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
+    "nvmk_scheduler_create": (_vp, [_int, _int, _int]),
+    "nvmk_scheduler_destroy": (None, [_vp]),
+    "nvmk_scheduler_dispatch": (_int, [_vp, _int, _vp, ctypes.POINTER(_int)]),
+    "nvmk_scheduler_record": (_int, [_vp, _vp, _vp, _int]),
+    "nvmk_etkdg_embed": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "nvmk_butina_dense": (_int, [_vp, _vp, _i64, ctypes.c_double, _int, _vp, _vp, ctypes.POINTER(_i64), _vp]),
 }
 
@@ -69,10 +74,35 @@ class FFBatch(ctypes.Structure):
     """Mirror of ``nvmk_ff_batch`` (include/nvmolkit_amd.h)."""
 
     _fields_ = [("kind", ctypes.c_int32), ("n_systems", ctypes.c_int32), ("atom_starts", ctypes.c_void_p),
-                ("groups", FFGroup * 8)]
+                ("groups", FFGroup * 8), ("system_mol", ctypes.c_void_p), ("group_mask", ctypes.c_uint32),
+                ("etk_ref12_starts", ctypes.c_void_p), ("etk_ref12", ctypes.c_void_p),
+                ("etk_ref13_starts", ctypes.c_void_p), ("etk_ref13", ctypes.c_void_p)]
 
 
 FF_DG, FF_ETK, FF_MMFF, FF_QUARTIC = 0, 1, 2, 3
+
+
+class EtkdgMolset(ctypes.Structure):
+    """Mirror of ``nvmk_etkdg_molset``."""
+
+    _fields_ = [("n_mols", ctypes.c_int32), ("h_n_atoms", ctypes.c_void_p), ("dg", FFGroup * 3), ("etk", FFGroup * 6),
+                ("check_starts", ctypes.c_void_p), ("check_kind", ctypes.c_void_p), ("check_idx", ctypes.c_void_p),
+                ("check_par", ctypes.c_void_p), ("num_impropers", ctypes.c_void_p),
+                ("h_etk_d12_counts", ctypes.c_void_p), ("h_etk_d13_counts", ctypes.c_void_p)]
+
+
+class EtkdgParams(ctypes.Structure):
+    """Mirror of ``nvmk_etkdg_params``."""
+
+    _fields_ = [("confs_per_mol", ctypes.c_int32), ("max_iterations", ctypes.c_int32), ("batch_size", ctypes.c_int32),
+                ("use_exp_torsions", ctypes.c_int32), ("use_basic_knowledge", ctypes.c_int32),
+                ("enforce_chirality", ctypes.c_int32), ("box_size", ctypes.c_double), ("force_tol", ctypes.c_double),
+                ("seed", ctypes.c_uint64)]
+
+
+CHECK_TETRAHEDRAL, CHECK_CHIRAL_VOLUME, CHECK_CHIRAL_DISTANCE = 0, 1, 2
+CHECK_CHIRAL_CENTER_VOLUME, CHECK_DOUBLE_BOND_STEREO, CHECK_DOUBLE_BOND_GEOMETRY = 3, 4, 5
+ETKDG_N_STAGES = 11
 
 
 def lib() -> ctypes.CDLL:

@@ -1,0 +1,535 @@
+// Batched ETKDG conformer embedding: scheduler, stage pipeline and stereochemistry checks — gfx950.
+//
+// Replaces (reference paths):
+//   src/etkdg_impl.{h,cpp}:223-326      Scheduler (dispatch / record)
+//   src/etkdg_impl.cpp:111-159          ETKDGDriver::iterate (stage loop, failure collection)
+//   src/etkdg_kernels.cu:20-70          setRunFilter / collectAndFilterFailures / getFinished kernels
+//   src/etkdg_stage_coordgen.cu:83-127  random 4-D start coordinates
+//   src/etkdg_stage_distgeom_minimize.cu:177-249, src/etkdg_stage_etk_minimization.cu:204-266  minimisation stages
+//   src/etkdg_stage_stereochem_checks.cu:25-442  tetrahedral / chiral / double-bond checks
+//   src/etkdg.cpp:331-419               stage order of embedMolecules
+//   src/conformer/etkdg_device_collect.cu  4-D -> 3-D packing of accepted conformers
+//
+// Inputs are FLATTENED per-molecule term tables: the bounds matrix, chiral sets and experimental
+// torsions are RDKit's and arrive as DG / ETK term groups plus a list of stereo checks.  All conformers of a
+// molecule share one copy of its tables on the device (nvmk_ff_batch.system_mol); a batch is described only by
+// its atom offsets and molecule ids.  Start coordinates come from a counter-based generator on the device
+// (the reference draws them on the host from RDKit's global RNG and copies them over: parity with RDKit is
+// statistical on this path).
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <vector>
+
+#include "common.h"
+
+namespace nvmk {
+namespace etkdg {
+
+// ---- scheduler (src/etkdg_impl.cpp:272-326) -------------------------------------------------------------
+class Scheduler {
+ public:
+  Scheduler(int nMols, int confsPerMol, int maxIterations)
+      : confs_(confsPerMol), maxTries_(maxIterations * confsPerMol), completed_(static_cast<size_t>(nMols), 0),
+        attempts_(static_cast<size_t>(nMols), 0) {}
+
+  std::vector<int> dispatch(int batchSize) {
+    std::vector<int>            ids;
+    const std::lock_guard<std::mutex> lock(mutex_);
+    size_t                      prev = 1;
+    while (static_cast<int>(ids.size()) < batchSize && prev != ids.size()) {
+      prev            = ids.size();
+      const int limit = std::min(maxTries_, confs_ * round_);
+      for (size_t m = 0; m < completed_.size(); ++m) {
+        while (completed_[m] < confs_ && attempts_[m] < limit) {
+          if (static_cast<int>(ids.size()) >= batchSize) break;
+          ids.push_back(static_cast<int>(m));
+          ++attempts_[m];
+        }
+      }
+      if (attempts_.back() == limit) ++round_;
+    }
+    return ids;
+  }
+
+  int record(const int* molIds, const int16_t* finishedOnIteration, int n) {
+    const std::lock_guard<std::mutex> lock(mutex_);
+    for (int i = 0; i < n; ++i) {
+      if (molIds[i] < 0 || molIds[i] >= static_cast<int>(completed_.size())) return -1;
+    }
+    for (int i = 0; i < n; ++i) completed_[static_cast<size_t>(molIds[i])] += finishedOnIteration[i] == -1 ? 0 : 1;
+    return 0;
+  }
+
+ private:
+  std::mutex       mutex_;
+  int              confs_;
+  int              maxTries_;
+  int              round_ = 1;
+  std::vector<int> completed_;
+  std::vector<int> attempts_;
+};
+
+// ---- control kernels (src/etkdg_kernels.cu:20-70) -------------------------------------------------------
+__global__ void set_run_filter_kernel(const int n, uint8_t* __restrict__ active, const int16_t* __restrict__ finishedOn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) active[i] = finishedOn[i] < 0;
+}
+__global__ void collect_failures_kernel(const int n, const uint8_t* __restrict__ failed, uint8_t* __restrict__ active,
+                                        int16_t* __restrict__ failSum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && active[i] && failed[i]) {
+    active[i] = 0;
+    failSum[i] += 1;
+  }
+}
+__global__ void mark_finished_kernel(const int n, const int iteration, const uint8_t* __restrict__ active,
+                                     int16_t* __restrict__ finishedOn, int* __restrict__ newlyFinished) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && finishedOn[i] == -1 && active[i]) {
+    finishedOn[i] = static_cast<int16_t>(iteration);
+    atomicAdd(newlyFinished, 1);
+  }
+}
+
+// ---- start coordinates ----------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+// (rng - 0.5) * boxSize per coordinate of every ACTIVE system (src/etkdg_stage_coordgen.cu:100-121)
+__global__ void random_coords_kernel(const int nSystems, const int32_t* __restrict__ atomStarts, const uint8_t* __restrict__ active,
+                                     const uint64_t seed, const uint64_t attemptBase, const double boxSize,
+                                     double* __restrict__ pos) {
+  const int sys = blockIdx.x;
+  if (sys >= nSystems || !active[sys]) return;
+  const int c0 = atomStarts[sys] * 4, c1 = atomStarts[sys + 1] * 4;
+  for (int c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
+    const uint64_t h = splitmix64(splitmix64(seed ^ ((attemptBase + sys) * 0x9e3779b97f4a7c15ull)) + static_cast<uint64_t>(c - c0));
+    const double   u = static_cast<double>(h >> 11) * (1.0 / 9007199254740992.0);
+    pos[c]           = (u - 0.5) * boxSize;
+  }
+}
+
+// E / atom >= 0.05 after the first minimisation fails the attempt (etkdg_stage_distgeom_minimize.cu:36-51)
+__global__ void energy_per_atom_check_kernel(const int n, const double* __restrict__ energies, const int32_t* __restrict__ atomStarts,
+                                             uint8_t* __restrict__ failed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int na = atomStarts[i + 1] - atomStarts[i];
+    if (na > 0 && energies[i] / na >= 0.05) failed[i] = 1;
+  }
+}
+// planarity: improper-torsion energy > 0.7 * numImpropers fails (etkdg_stage_etk_minimization.cu:66-87)
+__global__ void planar_check_kernel(const int n, const double* __restrict__ energies, const int32_t* __restrict__ sysMol,
+                                    const int32_t* __restrict__ numImpropers, const uint8_t* __restrict__ active,
+                                    uint8_t* __restrict__ failed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && active[i] && energies[i] > 0.7 * numImpropers[sysMol[i]]) failed[i] = 1;
+}
+// reference distances of the 1-2 / 1-3 restraints = current 3-D distances (etkdg_stage_etk_minimization.cu:32-64)
+__global__ void reference_distance_kernel(const int nSystems, const int32_t* __restrict__ atomStarts,
+                                          const int32_t* __restrict__ sysMol, const int32_t* __restrict__ termStarts,
+                                          const int32_t* __restrict__ termIdx, const int32_t* __restrict__ refStarts,
+                                          const double* __restrict__ pos, double* __restrict__ ref) {
+  const int sys = blockIdx.x;
+  if (sys >= nSystems) return;
+  const int     m  = sysMol[sys];
+  const int     t0 = termStarts[m], t1 = termStarts[m + 1];
+  const double* p  = pos + static_cast<int64_t>(atomStarts[sys]) * 4;
+  for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    const int    i = termIdx[2 * t], j = termIdx[2 * t + 1];
+    const double dx = p[4 * i] - p[4 * j], dy = p[4 * i + 1] - p[4 * j + 1], dz = p[4 * i + 2] - p[4 * j + 2];
+    ref[refStarts[sys] + t - t0] = sqrt(dx * dx + dy * dy + dz * dz);
+  }
+}
+
+// ---- stereochemistry checks (src/etkdg_stage_stereochem_checks.cu:25-442) -------------------------------
+struct P3 {
+  double x, y, z;
+};
+__device__ __forceinline__ P3 sub(const P3 a, const P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ P3 crs(const P3 a, const P3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ double dt(const P3 a, const P3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ P3 unit(const P3 a) {
+  const double l = sqrt(dt(a, a));
+  return l > 0.0 ? P3{a.x / l, a.y / l, a.z / l} : a;
+}
+__device__ __forceinline__ P3 atom(const double* p, const int a) { return {p[4 * a], p[4 * a + 1], p[4 * a + 2]}; }
+
+// is p0 on the same side of plane (v1, v2, v3) as v4, with both clear of the plane by `tol`? (:25-50)
+__device__ __forceinline__ bool same_side(const double tol, const P3 v1, const P3 v2, const P3 v3, const P3 v4, const P3 p0) {
+  const P3     n  = crs(sub(v2, v1), sub(v3, v1));
+  const double d1 = dt(n, sub(v4, v1));
+  const double d2 = dt(n, sub(p0, v1));
+  if (fabs(d1) < tol || fabs(d2) < tol) return false;
+  return !((d1 < 0.0) ^ (d2 < 0.0));
+}
+
+// centre 0 with neighbours 1-4 (a centre with three neighbours repeats itself as idx4)
+__device__ bool tetrahedral_ok(const double* p, const int32_t* ix, const bool volumeTest, const bool fusedSmallRings, const double tol) {
+  const P3 p0 = atom(p, ix[0]), p1 = atom(p, ix[1]), p2 = atom(p, ix[2]), p3 = atom(p, ix[3]), p4 = atom(p, ix[4]);
+  if (volumeTest) {  // all four normalised triple products above MIN_TETRAHEDRAL_CHIRAL_VOL = 0.5 (x 0.25 in fused small rings)
+    const P3     d1 = unit(sub(p0, p1)), d2 = unit(sub(p0, p2)), d3 = unit(sub(p0, p3)), d4 = unit(sub(p0, p4));
+    const double lim = (fusedSmallRings ? 0.25 : 1.0) * 0.50;
+    if (fabs(dt(crs(d1, d2), d3)) < lim) return false;
+    if (fabs(dt(crs(d1, d2), d4)) < lim) return false;
+    if (fabs(dt(crs(d1, d3), d4)) < lim) return false;
+    if (fabs(dt(crs(d2, d3), d4)) < lim) return false;
+  }
+  if (ix[0] == ix[4]) return true;
+  return same_side(tol, p1, p2, p3, p4, p0) && same_side(tol, p2, p3, p4, p1, p0) && same_side(tol, p3, p4, p1, p2, p0) &&
+         same_side(tol, p4, p1, p2, p3, p0);
+}
+
+__global__ void stereo_check_kernel(const int nSystems, const int32_t* __restrict__ atomStarts, const int32_t* __restrict__ sysMol,
+                                    const int32_t* __restrict__ checkStarts, const int32_t* __restrict__ checkKind,
+                                    const int32_t* __restrict__ checkIdx, const double* __restrict__ checkPar, const int kind,
+                                    const double* __restrict__ pos, const uint8_t* __restrict__ active, uint8_t* __restrict__ failed) {
+  const int sys = blockIdx.x;
+  if (sys >= nSystems || !active[sys]) return;
+  const int     m = sysMol[sys];
+  const double* p = pos + static_cast<int64_t>(atomStarts[sys]) * 4;
+  for (int t = checkStarts[m] + threadIdx.x; t < checkStarts[m + 1]; t += blockDim.x) {
+    if (checkKind[t] != kind) continue;
+    const int32_t* ix   = checkIdx + 5 * t;
+    const double   a    = checkPar[2 * t], b = checkPar[2 * t + 1];
+    bool           fail = false;
+    switch (kind) {
+      case NVMK_CHECK_TETRAHEDRAL: fail = !tetrahedral_ok(p, ix, true, a != 0.0, 0.3); break;
+      case NVMK_CHECK_CHIRAL_CENTER_VOLUME: fail = !tetrahedral_ok(p, ix, false, false, 0.1); break;
+      case NVMK_CHECK_CHIRAL_VOLUME: {  // idx1..4 + [lb, ub] (:229-259)
+        const P3     p4  = atom(p, ix[4]);
+        const double vol = dt(sub(atom(p, ix[1]), p4), crs(sub(atom(p, ix[2]), p4), sub(atom(p, ix[3]), p4)));
+        const bool   oppA = signbit(vol) != signbit(a), oppB = signbit(vol) != signbit(b);
+        fail = (a > 0 && vol < a && (vol / a < 0.8 || oppA)) || (b < 0 && vol > b && (vol / b < 0.8 || oppB));
+        break;
+      }
+      case NVMK_CHECK_CHIRAL_DISTANCE: {  // |d - bound| > 0.1 ub outside [lb, ub] (:261-301)
+        const P3     d    = sub(atom(p, ix[0]), atom(p, ix[1]));
+        const double dist = sqrt(dt(d, d));
+        fail = (dist < a && fabs(dist - a) > 0.1 * b) || (dist > b && fabs(dist - b) > 0.1 * b);
+        break;
+      }
+      case NVMK_CHECK_DOUBLE_BOND_STEREO: {  // dihedral 0-1-2-3 on the side given by sign = a (:303-377)
+        const P3     p0 = atom(p, ix[0]), p1 = atom(p, ix[1]), p2 = atom(p, ix[2]), p3 = atom(p, ix[3]);
+        const P3     r1 = sub(p2, p1), c1 = crs(sub(p0, p1), r1), c2 = crs(sub(p3, p2), r1);
+        const double dot   = dt(c1, c2) / sqrt(dt(c1, c1) * dt(c2, c2));
+        const double angle = dot <= -1.0 ? 3.14159265358979323846 : (dot >= 1.0 ? 0.0 : acos(dot));
+        fail               = (angle - 1.57079632679489661923) * a < 0.0;
+        break;
+      }
+      case NVMK_CHECK_DOUBLE_BOND_GEOMETRY: {  // 0-1-2 must not be linear (:379-442)
+        const P3 u = unit(sub(atom(p, ix[1]), atom(p, ix[0]))), v = unit(sub(atom(p, ix[1]), atom(p, ix[2])));
+        fail       = (dt(u, v) + 1.0) < 1.0e-3;
+        break;
+      }
+      default: break;
+    }
+    if (fail) failed[sys] = 1;
+  }
+}
+
+// accepted conformers -> 3-D output slots (src/conformer/etkdg_device_collect.cu packKernel4DTo3D)
+__global__ void pack_kernel(const int nCopies, const int32_t* __restrict__ srcSystem, const int64_t* __restrict__ dstOffset,
+                            const int32_t* __restrict__ atomStarts, const double* __restrict__ pos, double* __restrict__ out) {
+  const int k = blockIdx.x;
+  if (k >= nCopies) return;
+  const int     sys = srcSystem[k];
+  const int     a0 = atomStarts[sys], na = atomStarts[sys + 1] - a0;
+  const double* p  = pos + static_cast<int64_t>(a0) * 4;
+  double*       o  = out + dstOffset[k];
+  for (int a = threadIdx.x; a < na; a += blockDim.x) {
+    o[3 * a]     = p[4 * a];
+    o[3 * a + 1] = p[4 * a + 1];
+    o[3 * a + 2] = p[4 * a + 2];
+  }
+}
+
+template <typename T> struct DevBuf {
+  T*          p = nullptr;
+  size_t      n = 0;
+  hipError_t  ensure(size_t count) {
+    if (count <= n) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+inline unsigned blocks(int n, int b = 256) { return static_cast<unsigned>((n + b - 1) / b); }
+
+}  // namespace etkdg
+}  // namespace nvmk
+
+using namespace nvmk;
+using namespace nvmk::etkdg;
+
+extern "C" {
+
+// ---- scheduler handle (exposed so the reference's exact dispatch sequences can be tested) ----------------
+void* nvmk_scheduler_create(int n_mols, int confs_per_mol, int max_iterations) {
+  if (n_mols <= 0 || confs_per_mol <= 0 || max_iterations <= 0) {
+    set_last_error("All parameters must be greater than 0.");  // src/etkdg_impl.cpp:277-279
+    return nullptr;
+  }
+  return new Scheduler(n_mols, confs_per_mol, max_iterations);
+}
+void nvmk_scheduler_destroy(void* s) { delete static_cast<Scheduler*>(s); }
+int  nvmk_scheduler_dispatch(void* s, int batch_size, int32_t* h_mol_ids_out, int* n_out) {
+  NVMK_REQUIRE(s && n_out && (batch_size <= 0 || h_mol_ids_out), "scheduler dispatch: NULL argument");
+  const std::vector<int> ids = static_cast<Scheduler*>(s)->dispatch(batch_size);
+  for (size_t i = 0; i < ids.size(); ++i) h_mol_ids_out[i] = ids[i];
+  *n_out = static_cast<int>(ids.size());
+  return NVMK_OK;
+}
+int nvmk_scheduler_record(void* s, const int32_t* h_mol_ids, const int16_t* h_finished_on_iteration, int n) {
+  NVMK_REQUIRE(s && (n == 0 || (h_mol_ids && h_finished_on_iteration)), "scheduler record: NULL argument");
+  NVMK_REQUIRE(static_cast<Scheduler*>(s)->record(h_mol_ids, h_finished_on_iteration, n) == 0, "molId is out of range");
+  return NVMK_OK;
+}
+
+int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, double* d_coords, int32_t* h_conf_counts,
+                     int32_t* h_stage_failures, void* stream_) {
+  NVMK_REQUIRE(ms && prm && h_conf_counts, "etkdg: NULL argument");
+  NVMK_REQUIRE(ms->n_mols >= 0, "etkdg: negative molecule count");
+  if (h_stage_failures) std::memset(h_stage_failures, 0, sizeof(int32_t) * NVMK_ETKDG_N_STAGES);
+  if (ms->n_mols == 0) return NVMK_OK;
+  NVMK_REQUIRE(ms->h_n_atoms && d_coords, "etkdg: NULL buffer");
+  NVMK_REQUIRE(prm->confs_per_mol > 0 && prm->max_iterations > 0 && prm->batch_size > 0,
+               "etkdg: confs_per_mol, max_iterations and batch_size must be > 0");
+  hipStream_t stream = as_stream(stream_);
+  const int   nMols  = ms->n_mols;
+  const bool  useEtk = prm->use_exp_torsions != 0 || prm->use_basic_knowledge != 0;
+  if (useEtk) NVMK_REQUIRE(ms->h_etk_d12_counts && ms->h_etk_d13_counts, "etkdg: ETK stage needs h_etk_d12/13_counts");
+  if (prm->use_basic_knowledge) NVMK_REQUIRE(ms->num_impropers, "etkdg: basic-knowledge planarity check needs num_impropers");
+
+  std::vector<int64_t> slotStart(static_cast<size_t>(nMols) + 1, 0);
+  for (int m = 0; m < nMols; ++m) {
+    NVMK_REQUIRE(ms->h_n_atoms[m] >= 0, "etkdg: negative atom count");
+    slotStart[static_cast<size_t>(m) + 1] =
+      slotStart[static_cast<size_t>(m)] + static_cast<int64_t>(ms->h_n_atoms[m]) * prm->confs_per_mol * 3;
+    h_conf_counts[m] = 0;
+  }
+
+  Scheduler sched(nMols, prm->confs_per_mol, prm->max_iterations);
+  DevBuf<int32_t>  dAtomStarts, dSysMol, dRef12Starts, dRef13Starts, dSrcSys;
+  DevBuf<int64_t>  dDstOff;
+  DevBuf<double>   dPos, dEnergies, dRef12, dRef13;
+  DevBuf<uint8_t>  dActive, dFailed, dSub;
+  DevBuf<int16_t>  dFinished, dStatuses, dFailSum;
+  DevBuf<int>      dCount;
+  NVMK_HIP_CHECK(dCount.ensure(1));
+  uint64_t attemptBase = 0;
+
+  for (;;) {
+    const std::vector<int> ids = sched.dispatch(prm->batch_size);
+    if (ids.empty()) break;
+    const int nSys = static_cast<int>(ids.size());
+    std::vector<int32_t> atomStarts(static_cast<size_t>(nSys) + 1, 0), r12(static_cast<size_t>(nSys) + 1, 0),
+      r13(static_cast<size_t>(nSys) + 1, 0);
+    for (int s = 0; s < nSys; ++s) {
+      const int m = ids[static_cast<size_t>(s)];
+      atomStarts[static_cast<size_t>(s) + 1] = atomStarts[static_cast<size_t>(s)] + ms->h_n_atoms[m];
+      if (useEtk) {
+        r12[static_cast<size_t>(s) + 1] = r12[static_cast<size_t>(s)] + ms->h_etk_d12_counts[m];
+        r13[static_cast<size_t>(s) + 1] = r13[static_cast<size_t>(s)] + ms->h_etk_d13_counts[m];
+      }
+    }
+    const int nAtoms = atomStarts.back();
+    NVMK_HIP_CHECK(dAtomStarts.ensure(atomStarts.size()));
+    NVMK_HIP_CHECK(dSysMol.ensure(static_cast<size_t>(nSys)));
+    NVMK_HIP_CHECK(dPos.ensure(static_cast<size_t>(nAtoms) * 4));
+    NVMK_HIP_CHECK(dEnergies.ensure(static_cast<size_t>(nSys)));
+    NVMK_HIP_CHECK(dActive.ensure(static_cast<size_t>(nSys)));
+    NVMK_HIP_CHECK(dFailed.ensure(static_cast<size_t>(nSys)));
+    NVMK_HIP_CHECK(dSub.ensure(static_cast<size_t>(nSys)));
+    NVMK_HIP_CHECK(dFinished.ensure(static_cast<size_t>(nSys)));
+    NVMK_HIP_CHECK(dStatuses.ensure(static_cast<size_t>(nSys)));
+    NVMK_HIP_CHECK(dFailSum.ensure(static_cast<size_t>(nSys) * NVMK_ETKDG_N_STAGES));
+    NVMK_HIP_CHECK(hipMemcpyAsync(dAtomStarts.p, atomStarts.data(), atomStarts.size() * 4, hipMemcpyHostToDevice, stream));
+    NVMK_HIP_CHECK(hipMemcpyAsync(dSysMol.p, ids.data(), static_cast<size_t>(nSys) * 4, hipMemcpyHostToDevice, stream));
+    NVMK_HIP_CHECK(hipMemsetAsync(dFinished.p, 0xff, static_cast<size_t>(nSys) * 2, stream));  // -1
+    NVMK_HIP_CHECK(hipMemsetAsync(dFailSum.p, 0, static_cast<size_t>(nSys) * NVMK_ETKDG_N_STAGES * 2, stream));
+    if (useEtk) {
+      NVMK_HIP_CHECK(dRef12Starts.ensure(r12.size()));
+      NVMK_HIP_CHECK(dRef13Starts.ensure(r13.size()));
+      NVMK_HIP_CHECK(dRef12.ensure(static_cast<size_t>(r12.back())));
+      NVMK_HIP_CHECK(dRef13.ensure(static_cast<size_t>(r13.back())));
+      NVMK_HIP_CHECK(hipMemcpyAsync(dRef12Starts.p, r12.data(), r12.size() * 4, hipMemcpyHostToDevice, stream));
+      NVMK_HIP_CHECK(hipMemcpyAsync(dRef13Starts.p, r13.data(), r13.size() * 4, hipMemcpyHostToDevice, stream));
+    }
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors are reused below
+
+    nvmk_ff_batch dg{};
+    dg.kind = NVMK_FF_DG;
+    dg.n_systems   = nSys;
+    dg.atom_starts = dAtomStarts.p;
+    dg.system_mol  = dSysMol.p;
+    for (int g = 0; g < 3; ++g) dg.groups[g] = ms->dg[g];
+    nvmk_ff_batch etk{};
+    etk.kind = NVMK_FF_ETK;
+    etk.n_systems   = nSys;
+    etk.atom_starts = dAtomStarts.p;
+    etk.system_mol  = dSysMol.p;
+    for (int g = 0; g < 6; ++g) etk.groups[g] = ms->etk[g];
+
+    int  stage = 0;
+    auto begin_stage = [&]() -> int {
+      NVMK_HIP_CHECK(hipMemsetAsync(dFailed.p, 0, static_cast<size_t>(nSys), stream));
+      return NVMK_OK;
+    };
+    auto end_stage = [&]() -> int {
+      hipLaunchKernelGGL(collect_failures_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, dFailed.p, dActive.p,
+                         dFailSum.p + static_cast<size_t>(stage) * nSys);
+      NVMK_LAUNCH_CHECK();
+      ++stage;
+      return NVMK_OK;
+    };
+    // BFGS on the active systems, repeated while any of them is unconverged (repeatUntilConverged,
+    // etkdg_stage_distgeom_minimize.cu:53-58); `repeat` false = one call (ETK stage)
+    auto minimize = [&](const nvmk_ff_batch& b, double w0, double w1, int iters, bool repeat) -> int {
+      std::vector<uint8_t> act(static_cast<size_t>(nSys));
+      std::vector<int16_t> st(static_cast<size_t>(nSys));
+      NVMK_HIP_CHECK(hipMemcpyAsync(dSub.p, dActive.p, static_cast<size_t>(nSys), hipMemcpyDeviceToDevice, stream));
+      for (int rep = 0; rep < 50; ++rep) {
+        int rc = nvmk_bfgs_minimize(&b, atomStarts.data(), w0, w1, iters, prm->force_tol, 1, dPos.p, dSub.p, dEnergies.p,
+                                    dStatuses.p, nullptr, stream);
+        if (rc != NVMK_OK) return rc;
+        if (!repeat) break;
+        NVMK_HIP_CHECK(hipMemcpyAsync(act.data(), dSub.p, act.size(), hipMemcpyDeviceToHost, stream));
+        NVMK_HIP_CHECK(hipMemcpyAsync(st.data(), dStatuses.p, st.size() * 2, hipMemcpyDeviceToHost, stream));
+        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+        bool more = false;
+        for (int s = 0; s < nSys; ++s) {
+          act[static_cast<size_t>(s)] = act[static_cast<size_t>(s)] && st[static_cast<size_t>(s)] != 0;
+          more                        = more || act[static_cast<size_t>(s)];
+        }
+        if (!more) break;
+        NVMK_HIP_CHECK(hipMemcpyAsync(dSub.p, act.data(), act.size(), hipMemcpyHostToDevice, stream));
+        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+      }
+      return NVMK_OK;
+    };
+    auto check = [&](int kind) -> int {
+      if (ms->check_starts == nullptr) return NVMK_OK;
+      hipLaunchKernelGGL(stereo_check_kernel, dim3(nSys), dim3(64), 0, stream, nSys, dAtomStarts.p, dSysMol.p, ms->check_starts,
+                         ms->check_kind, ms->check_idx, ms->check_par, kind, dPos.p, dActive.p, dFailed.p);
+      NVMK_LAUNCH_CHECK();
+      return NVMK_OK;
+    };
+#define NVMK_TRY(expr)             \
+  do {                             \
+    const int rc_ = (expr);        \
+    if (rc_ != NVMK_OK) return rc_; \
+  } while (0)
+
+    hipLaunchKernelGGL(set_run_filter_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, dActive.p, dFinished.p);
+    // stage 0: random start coordinates
+    NVMK_TRY(begin_stage());
+    hipLaunchKernelGGL(random_coords_kernel, dim3(nSys), dim3(64), 0, stream, nSys, dAtomStarts.p, dActive.p, prm->seed, attemptBase,
+                       prm->box_size, dPos.p);
+    NVMK_TRY(end_stage());
+    // stage 1: first minimisation (chiral 1.0, 4th dim 0.1, 400 iterations) + energy check
+    NVMK_TRY(begin_stage());
+    NVMK_TRY(minimize(dg, 1.0, 0.1, 400, true));
+    NVMK_TRY(nvmk_ff_energy(&dg, 1.0, 0.1, dPos.p, nullptr, dEnergies.p, stream));
+    hipLaunchKernelGGL(energy_per_atom_check_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, dEnergies.p, dAtomStarts.p,
+                       dFailed.p);
+    NVMK_TRY(end_stage());
+    // stage 2: tetrahedral centres; stage 3: first chiral check
+    NVMK_TRY(begin_stage());
+    NVMK_TRY(check(NVMK_CHECK_TETRAHEDRAL));
+    NVMK_TRY(end_stage());
+    NVMK_TRY(begin_stage());
+    if (prm->enforce_chirality) NVMK_TRY(check(NVMK_CHECK_CHIRAL_VOLUME));
+    NVMK_TRY(end_stage());
+    // stage 4: fourth-dimension minimisation (chiral 0.2, 4th dim 1.0, 200 iterations)
+    NVMK_TRY(begin_stage());
+    NVMK_TRY(minimize(dg, 0.2, 1.0, 200, true));
+    NVMK_TRY(end_stage());
+    // stage 5: ETK minimisation (300 iterations) + planarity check
+    NVMK_TRY(begin_stage());
+    if (useEtk) {
+      hipLaunchKernelGGL(reference_distance_kernel, dim3(nSys), dim3(64), 0, stream, nSys, dAtomStarts.p, dSysMol.p,
+                         ms->etk[2].starts, ms->etk[2].idx, dRef12Starts.p, dPos.p, dRef12.p);
+      hipLaunchKernelGGL(reference_distance_kernel, dim3(nSys), dim3(64), 0, stream, nSys, dAtomStarts.p, dSysMol.p,
+                         ms->etk[3].starts, ms->etk[3].idx, dRef13Starts.p, dPos.p, dRef13.p);
+      etk.etk_ref12_starts = dRef12Starts.p;
+      etk.etk_ref12        = dRef12.p;
+      etk.etk_ref13_starts = dRef13Starts.p;
+      etk.etk_ref13        = dRef13.p;
+      etk.group_mask       = prm->use_basic_knowledge ? 0x3fu : 0x3du;  // plain mode drops the improper terms (ETKTerm::PLAIN)
+      NVMK_TRY(minimize(etk, 1.0, 1.0, 300, false));
+      if (prm->use_basic_knowledge) {
+        nvmk_ff_batch planar = etk;
+        planar.group_mask    = 0x2u;
+        NVMK_TRY(nvmk_ff_energy(&planar, 1.0, 1.0, dPos.p, nullptr, dEnergies.p, stream));
+        hipLaunchKernelGGL(planar_check_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, dEnergies.p, dSysMol.p,
+                           ms->num_impropers, dActive.p, dFailed.p);
+      }
+    }
+    NVMK_TRY(end_stage());
+    // stages 6-10: final geometry / chirality checks
+    NVMK_TRY(begin_stage());
+    NVMK_TRY(check(NVMK_CHECK_DOUBLE_BOND_GEOMETRY));
+    NVMK_TRY(end_stage());
+    const int finals[4] = {NVMK_CHECK_CHIRAL_VOLUME, NVMK_CHECK_CHIRAL_DISTANCE, NVMK_CHECK_CHIRAL_CENTER_VOLUME,
+                           NVMK_CHECK_DOUBLE_BOND_STEREO};
+    for (int k = 0; k < 4; ++k) {
+      NVMK_TRY(begin_stage());
+      if (prm->enforce_chirality) NVMK_TRY(check(finals[k]));
+      NVMK_TRY(end_stage());
+    }
+#undef NVMK_TRY
+    // finished = still active after every stage (getFinishedKernels, iteration 0 of this batch)
+    NVMK_HIP_CHECK(hipMemsetAsync(dCount.p, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(mark_finished_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, 0, dActive.p, dFinished.p, dCount.p);
+    NVMK_LAUNCH_CHECK();
+    std::vector<int16_t> finished(static_cast<size_t>(nSys));
+    std::vector<int16_t> failSum(static_cast<size_t>(nSys) * NVMK_ETKDG_N_STAGES);
+    NVMK_HIP_CHECK(hipMemcpyAsync(finished.data(), dFinished.p, finished.size() * 2, hipMemcpyDeviceToHost, stream));
+    NVMK_HIP_CHECK(hipMemcpyAsync(failSum.data(), dFailSum.p, failSum.size() * 2, hipMemcpyDeviceToHost, stream));
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    if (h_stage_failures) {
+      for (int st = 0; st < NVMK_ETKDG_N_STAGES; ++st) {
+        for (int s = 0; s < nSys; ++s) h_stage_failures[st] += failSum[static_cast<size_t>(st) * nSys + s];
+      }
+    }
+    sched.record(ids.data(), finished.data(), nSys);
+    // copy accepted conformers into their output slots (extras beyond confs_per_mol are dropped)
+    std::vector<int32_t> src;
+    std::vector<int64_t> dst;
+    for (int s = 0; s < nSys; ++s) {
+      const int m = ids[static_cast<size_t>(s)];
+      if (finished[static_cast<size_t>(s)] >= 0 && h_conf_counts[m] < prm->confs_per_mol) {
+        src.push_back(s);
+        dst.push_back(slotStart[static_cast<size_t>(m)] + static_cast<int64_t>(h_conf_counts[m]) * ms->h_n_atoms[m] * 3);
+        ++h_conf_counts[m];
+      }
+    }
+    if (!src.empty()) {
+      NVMK_HIP_CHECK(dSrcSys.ensure(src.size()));
+      NVMK_HIP_CHECK(dDstOff.ensure(dst.size()));
+      NVMK_HIP_CHECK(hipMemcpyAsync(dSrcSys.p, src.data(), src.size() * 4, hipMemcpyHostToDevice, stream));
+      NVMK_HIP_CHECK(hipMemcpyAsync(dDstOff.p, dst.data(), dst.size() * 8, hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(pack_kernel, dim3(static_cast<unsigned>(src.size())), dim3(64), 0, stream, static_cast<int>(src.size()),
+                         dSrcSys.p, dDstOff.p, dAtomStarts.p, dPos.p, d_coords);
+      NVMK_LAUNCH_CHECK();
+      NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    attemptBase += static_cast<uint64_t>(nSys);
+  }
+  return NVMK_OK;
+}
+
+}  // extern "C"

@@ -37,6 +37,12 @@ struct Batch {
   int            nSystems;
   const int32_t* atomStarts;
   Group          g[8];
+  const int32_t* sysMol;      // optional: term tables are per MOLECULE and system s uses row sysMol[s] of every `starts`
+  unsigned       groupMask;   // bit g set = evaluate term group g
+  // ETK only, optional: per-system reference distances for the 1-2 / 1-3 restraints (the reference re-centres
+  // those bounds on the current geometry before the ETK minimisation, etkdg_stage_etk_minimization.cu:32-64)
+  const int32_t* refStarts[2];
+  const double*  ref[2];
 };
 
 template <int KIND> struct Dim {
@@ -106,8 +112,10 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
                               const int globalCoordStart) {
   constexpr int DIM = Dim<KIND>::value;
   const int     tid = threadIdx.x;
+  const int     ms  = b.sysMol ? b.sysMol[sys] : sys;  // row of the term tables
   double        e   = 0.0;
   (void)grad;
+  (void)ms;
   (void)w0;
   (void)w1;
   (void)globalCoordStart;
@@ -128,10 +136,11 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
     return e;
   }
 
+  auto on = [&](const int gi) { return (b.groupMask >> gi) & 1u; };
   if constexpr (KIND == NVMK_FF_DG) {
-    {  // distance violations, all 4 dimensions (dist_geom_kernels_device.cuh:37-95)
+    if (on(0)) {  // distance violations, all 4 dimensions (dist_geom_kernels_device.cuh:37-95)
       const Group& g = b.g[0];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
         double       d[4];
         const double d2 = pair_dist2<DIM>(pos, i, j, 4, d);
@@ -144,9 +153,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // chiral volumes, weight w0 (:97-207); RDKit's gradient is half the derivative
+    if (on(1)) {  // chiral volumes, weight w0 (:97-207); RDKit's gradient is half the derivative
       const Group& g = b.g[1];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
         if constexpr (GRAD) {
           using D       = Dual<12>;
@@ -161,9 +170,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // fourth dimension, weight w1 (:209-231): E = w x4^2, RDKit gradient w x4
+    if (on(2)) {  // fourth dimension, weight w1 (:209-231): E = w x4^2, RDKit gradient w x4
       const Group& g = b.g[2];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int    i = g.idx[t];
         const double x = pos[i * DIM + 3];
         if constexpr (GRAD) {
@@ -177,9 +186,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
   }
 
   if constexpr (KIND == NVMK_FF_ETK) {
-    {  // experimental torsions: 6 force constants + 6 signs per term (:237-313, :447-575)
+    if (on(0)) {  // experimental torsions: 6 force constants + 6 signs per term (:237-313, :447-575)
       const Group& g = b.g[0];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
         const double* fc   = g.par + 12 * t;
         bool          ok;
@@ -195,9 +204,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // improper torsions / inversions: C0, C1, C2, k (:315-366, :577-694)
+    if (on(1)) {  // improper torsions / inversions: C0, C1, C2, k (:315-366, :577-694)
       const Group& g = b.g[1];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
         const double* p    = g.par + 4 * t;
         if constexpr (GRAD) {
@@ -215,14 +224,24 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
     // flat-bottom distance restraints in 3-D: groups 2 (1-2), 3 (1-3), 5 (long range) (:368-392, :696-729)
 #pragma unroll
     for (int gi = 2; gi <= 5; ++gi) {
-      if (gi == 4) continue;
+      if (gi == 4 || !on(gi)) continue;
       const Group& g = b.g[gi];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      // 1-2 / 1-3 restraints may be re-centred per system: bounds = ref +- (max - min) / 2 unless the term's 4th
+      // parameter pins the table bounds (isImproperConstrained, dist_geom.h:103-110)
+      const double* ref = (gi <= 3 && b.ref[gi - 2]) ? b.ref[gi - 2] + b.refStarts[gi - 2][sys] : nullptr;
+      const int     t0  = g.starts[ms];
+      for (int t = t0 + tid; t < g.starts[ms + 1]; t += NT) {
         const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
         double       d[4];
         const double dist = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
-        double       et, dE;
-        dist_constraint(dist, g.par[3 * t], g.par[3 * t + 1], g.par[3 * t + 2], et, dE);
+        double       lo = g.par[4 * t], hi = g.par[4 * t + 1];
+        if (ref && g.par[4 * t + 3] == 0.0) {
+          const double half = 0.5 * (hi - lo);
+          lo                = ref[t - t0] - half;
+          hi                = ref[t - t0] + half;
+        }
+        double et, dE;
+        dist_constraint(dist, lo, hi, g.par[4 * t + 2], et, dE);
         if constexpr (GRAD) {
           if (dE != 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / (dist > 1.0e-8 ? dist : 1.0e-8));
         } else {
@@ -230,9 +249,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // 1-3 angle restraints, force constant 1 (:394-445, :731-830)
+    if (on(4)) {  // 1-3 angle restraints, force constant 1 (:394-445, :731-830)
       const Group& g = b.g[4];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
         if constexpr (GRAD) {
           using D = Dual<9>;
@@ -249,9 +268,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
   }
 
   if constexpr (KIND == NVMK_FF_MMFF) {
-    {  // bond stretch: r0, kb
+    if (on(0)) {  // bond stretch: r0, kb
       const Group& g = b.g[0];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
         double       d[4];
         const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
@@ -264,9 +283,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // angle bend: theta0, ka, isLinear
+    if (on(1)) {  // angle bend: theta0, ka, isLinear
       const Group& g = b.g[1];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
         const double* p    = g.par + 3 * t;
         if constexpr (GRAD) {
@@ -280,9 +299,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // stretch-bend: theta0, r0ij, r0kj, kbaIJK, kbaKJI
+    if (on(2)) {  // stretch-bend: theta0, r0ij, r0kj, kbaIJK, kbaKJI
       const Group& g = b.g[2];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
         const double* p    = g.par + 5 * t;
         if constexpr (GRAD) {
@@ -296,9 +315,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // out-of-plane: koop
+    if (on(3)) {  // out-of-plane: koop
       const Group& g = b.g[3];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
         if constexpr (GRAD) {
           using D = Dual<12>;
@@ -311,9 +330,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // torsion: V1, V2, V3
+    if (on(4)) {  // torsion: V1, V2, V3
       const Group& g = b.g[4];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
         const double* p    = g.par + 3 * t;
         bool          ok;
@@ -329,9 +348,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // van der Waals: R*, eps
+    if (on(5)) {  // van der Waals: R*, eps
       const Group& g = b.g[5];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
         double       d[4];
         const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
@@ -344,9 +363,9 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
         }
       }
     }
-    {  // electrostatics: chargeTerm, dielModel, is1_4
+    if (on(6)) {  // electrostatics: chargeTerm, dielModel, is1_4
       const Group& g = b.g[6];
-      for (int t = g.starts[sys] + tid; t < g.starts[sys + 1]; t += NT) {
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
         double       d[4];
         const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
@@ -607,9 +626,15 @@ int to_batch(const nvmk_ff_batch* in, Batch& out) {
   NVMK_REQUIRE(in->n_systems >= 0, "ff: negative system count");
   NVMK_REQUIRE(in->n_systems == 0 || in->atom_starts != nullptr, "ff: NULL atom_starts");
   static const int nGroups[4] = {3, 6, 7, 0};
-  out.kind       = in->kind;
-  out.nSystems   = in->n_systems;
-  out.atomStarts = in->atom_starts;
+  out.kind         = in->kind;
+  out.nSystems     = in->n_systems;
+  out.atomStarts   = in->atom_starts;
+  out.sysMol       = in->system_mol;
+  out.groupMask    = in->group_mask ? in->group_mask : 0xffu;
+  out.refStarts[0] = in->etk_ref12_starts;
+  out.refStarts[1] = in->etk_ref13_starts;
+  out.ref[0]       = in->etk_ref12;
+  out.ref[1]       = in->etk_ref13;
   for (int g = 0; g < 8; ++g) {
     out.g[g] = {in->groups[g].starts, in->groups[g].idx, in->groups[g].par};
     if (g < nGroups[in->kind] && in->n_systems > 0) {

@@ -1,0 +1,176 @@
+"""Batched ETKDG conformer embedding on the GPU (reference API: nvmolkit/embedMolecules.py:55-158).
+
+Two entry points:
+  * :func:`EmbedMolecules` — the reference's signature, taking RDKit molecules.  All chemistry perception
+    (bounds matrix, chiral sets, experimental torsions) is RDKit's, so this adapter needs RDKit.
+  * :func:`embed_flat` — the flattened-term seam the kernels actually consume; what the adapter feeds, and what
+    the test-suite and benchmarks drive directly.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from nvmolkit_amd import _native
+from nvmolkit_amd.forcefield import GROUP_LAYOUT, DG, ETK
+from nvmolkit_amd.types import CoordinateOutput, HardwareOptions
+
+N_STAGES = _native.ETKDG_N_STAGES
+STAGE_NAMES = ["coordgen", "first minimization", "tetrahedral check", "first chiral check", "fourth dimension minimization",
+               "ETK minimization", "double bond geometry", "final chiral check", "chiral distance matrix",
+               "chiral centre volume", "double bond stereo"]
+
+
+@dataclass
+class FlatMolecule:
+    """One molecule in flattened form: term groups with LOCAL atom indices (layouts: include/nvmolkit_amd.h)."""
+
+    n_atoms: int
+    dg: Sequence[tuple]                       # 3 x (idx (n, n_idx), par (n, n_par))
+    etk: Sequence[tuple] | None = None        # 6 x (idx, par) or None when the ETK stage is off
+    checks: Sequence[tuple] = field(default_factory=list)  # (kind, idx[5], par[2])
+    num_impropers: int = 0
+
+
+class FlatMoleculeSet:
+    """Unique molecules resident on the device, ready for :func:`embed_flat`."""
+
+    def __init__(self, mols: Sequence[FlatMolecule], device="cuda"):
+        self.device = torch.device(device)
+        self.mols = list(mols)
+        self.n_atoms = np.array([m.n_atoms for m in self.mols], dtype=np.int32)
+        self._keep: list = []
+        self.c = _native.EtkdgMolset()
+        self.c.n_mols = len(self.mols)
+        self.c.h_n_atoms = self.n_atoms.ctypes.data
+        self.has_etk = bool(self.mols) and all(m.etk is not None for m in self.mols)
+        self._fill_groups(self.c.dg, GROUP_LAYOUT[DG], [m.dg for m in self.mols])
+        if self.has_etk:
+            counts = self._fill_groups(self.c.etk, GROUP_LAYOUT[ETK], [m.etk for m in self.mols])
+            self.d12 = np.ascontiguousarray(counts[2], dtype=np.int32)
+            self.d13 = np.ascontiguousarray(counts[3], dtype=np.int32)
+            self.c.h_etk_d12_counts = self.d12.ctypes.data
+            self.c.h_etk_d13_counts = self.d13.ctypes.data
+        starts = np.zeros(len(self.mols) + 1, dtype=np.int32)
+        kinds, idxs, pars = [], [], []
+        for i, m in enumerate(self.mols):
+            starts[i + 1] = starts[i] + len(m.checks)
+            for kind, idx, par in m.checks:
+                kinds.append(kind)
+                idxs.append(list(idx) + [0] * (5 - len(idx)))
+                pars.append(list(par) + [0.0] * (2 - len(par)))
+        if kinds:
+            t = [self._dev(starts), self._dev(np.array(kinds, dtype=np.int32)), self._dev(np.array(idxs, dtype=np.int32)),
+                 self._dev(np.array(pars, dtype=np.float64))]
+            self.c.check_starts, self.c.check_kind, self.c.check_idx, self.c.check_par = (x.data_ptr() for x in t)
+        self.c.num_impropers = self._dev(np.array([m.num_impropers for m in self.mols], dtype=np.int32)).data_ptr()
+
+    def _dev(self, arr: np.ndarray) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        self._keep.append(t)
+        return t
+
+    def _fill_groups(self, c_groups, layout, per_mol_groups):
+        counts = []
+        for g, (n_idx, n_par) in enumerate(layout):
+            starts = np.zeros(len(per_mol_groups) + 1, dtype=np.int32)
+            idx_all, par_all = [], []
+            for i, groups in enumerate(per_mol_groups):
+                idx, par = groups[g]
+                idx = np.asarray(idx, dtype=np.int32).reshape(-1, n_idx)
+                par = np.asarray(par, dtype=np.float64).reshape(len(idx), n_par)
+                starts[i + 1] = starts[i] + len(idx)
+                idx_all.append(idx)
+                par_all.append(par)
+            counts.append(np.diff(starts))
+            idx_cat = np.concatenate(idx_all) if idx_all else np.zeros((0, n_idx), np.int32)
+            par_cat = np.concatenate(par_all) if par_all else np.zeros((0, n_par))
+            c_groups[g].starts = self._dev(starts).data_ptr()
+            c_groups[g].idx = self._dev(idx_cat).data_ptr() if idx_cat.size else None
+            c_groups[g].par = self._dev(par_cat).data_ptr() if par_cat.size else None
+        return counts
+
+
+@dataclass
+class FlatEmbedResult:
+    coords: torch.Tensor            # flat float64, conformer c of molecule m at slot_starts[m] + 3 * c * n_atoms[m]
+    conf_counts: np.ndarray         # conformers produced per molecule
+    slot_starts: np.ndarray
+    stage_failures: np.ndarray      # total failures per stage (STAGE_NAMES)
+    n_atoms: np.ndarray
+
+    def conformers(self, m: int) -> torch.Tensor:
+        """(n_confs, n_atoms, 3) coordinates of molecule m."""
+        n = int(self.n_atoms[m])
+        k = int(self.conf_counts[m])
+        s = int(self.slot_starts[m])
+        return self.coords[s:s + 3 * n * k].reshape(k, n, 3)
+
+
+def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterations: int = -1, batch_size: int = 500,
+               use_exp_torsions: bool = True, use_basic_knowledge: bool = True, enforce_chirality: bool = True,
+               box_size_mult: float = 2.0, force_tol: float = 1e-3, seed: int = 42, stream=None) -> FlatEmbedResult:
+    """ETKDG on flattened molecules (reference pipeline: src/etkdg.cpp:90-484 downstream of RDKit)."""
+    sptr = _native.stream_ptr(stream)
+    if confs_per_molecule <= 0:
+        raise ValueError("confsPerMolecule must be greater than 0")
+    n_atoms = molset.n_atoms
+    if max_iterations == -1:  # src/etkdg.cpp:71-85,195-197: 10 x the largest molecule
+        max_iterations = 10 * int(n_atoms.max()) if len(n_atoms) else 1
+    if max_iterations <= 0:
+        raise ValueError("maxIterations must be greater than 0 (or -1 for automatic)")
+    etk_on = (use_exp_torsions or use_basic_knowledge)
+    if etk_on and not molset.has_etk:
+        raise ValueError("the ETK stage needs ETK term groups on every molecule")
+    prm = _native.EtkdgParams()
+    prm.confs_per_mol = int(confs_per_molecule)
+    prm.max_iterations = int(max_iterations)
+    prm.batch_size = int(batch_size) if batch_size > 0 else 500
+    prm.use_exp_torsions = int(bool(use_exp_torsions))
+    prm.use_basic_knowledge = int(bool(use_basic_knowledge))
+    prm.enforce_chirality = int(bool(enforce_chirality))
+    prm.box_size = 5.0 * box_size_mult if box_size_mult > 0 else -box_size_mult
+    prm.force_tol = float(force_tol)
+    prm.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    slot_starts = np.zeros(len(n_atoms) + 1, dtype=np.int64)
+    slot_starts[1:] = np.cumsum(n_atoms.astype(np.int64) * confs_per_molecule * 3)
+    coords = torch.zeros(int(slot_starts[-1]), dtype=torch.float64, device=molset.device)
+    counts = np.zeros(len(n_atoms), dtype=np.int32)
+    fails = np.zeros(N_STAGES, dtype=np.int32)
+    with torch.cuda.device(molset.device):
+        rc = _native.lib().nvmk_etkdg_embed(ctypes.byref(molset.c), ctypes.byref(prm), coords.data_ptr(), counts.ctypes.data,
+                                            fails.ctypes.data, sptr)
+    _native.check(rc, "nvmk_etkdg_embed")
+    return FlatEmbedResult(coords, counts, slot_starts[:-1], fails, n_atoms)
+
+
+def EmbedMolecules(molecules, params, confsPerMolecule: int = 1, maxIterations: int = -1,
+                   hardwareOptions: HardwareOptions | None = None, output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS,
+                   targetGpu: int | None = None):
+    """Embed multiple molecules with multiple conformers on the GPU (reference: nvmolkit/embedMolecules.py:55-158).
+
+    The RDKit -> flattened-term adapter (bounds matrix with triangle smoothing, chiral sets, experimental torsions:
+    src/embedder_utils.cpp:229-347, rdkit_extensions/dist_geom_flattened_builder.cpp) depends on RDKit internals
+    (``EmbedArgs``) that have no Python API; it belongs in a C++ extension built where RDKit is installed
+    (INTEGRATION.md).  Without it this entry point validates its arguments like the reference and then raises.
+    """
+    if confsPerMolecule <= 0:
+        raise ValueError("confsPerMolecule must be greater than 0")
+    if maxIterations < -1 or maxIterations == 0:
+        raise ValueError("maxIterations must be -1 (automatic) or greater than 0")
+    if not getattr(params, "useRandomCoords", False):
+        raise ValueError("ETKDG requires useRandomCoords=True")  # nvmolkit/embedMolecules.py:146-147
+    if output is CoordinateOutput.DEVICE and getattr(params, "pruneRmsThresh", -1.0) > 0:
+        raise ValueError("RMS pruning is not supported with DEVICE output")
+    try:
+        import rdkit  # noqa: F401
+    except ImportError as exc:
+        raise ImportError("EmbedMolecules needs RDKit for chemistry perception; use embed_flat() with flattened "
+                          "term tables, or build the RDKit adapter described in INTEGRATION.md") from exc
+    raise NotImplementedError("the RDKit EmbedArgs -> flattened-term adapter is not built in this environment "
+                              "(see INTEGRATION.md); embed_flat() is the supported entry point")

@@ -21,7 +21,7 @@ DG, ETK, MMFF, QUARTIC = _native.FF_DG, _native.FF_ETK, _native.FF_MMFF, _native
 #: (n_idx, n_par) of every term group, per kind (see include/nvmolkit_amd.h)
 GROUP_LAYOUT = {
     DG: [(2, 3), (4, 2), (1, 0)],
-    ETK: [(4, 12), (4, 4), (2, 3), (2, 3), (3, 2), (2, 3)],
+    ETK: [(4, 12), (4, 4), (2, 4), (2, 4), (3, 2), (2, 4)],
     MMFF: [(2, 2), (3, 3), (3, 5), (4, 1), (4, 3), (2, 2), (2, 3)],
     QUARTIC: [],
 }

@@ -24,7 +24,7 @@ MDYNE_A_TO_KCAL = 143.9325
 DG, ETK, MMFF, QUARTIC = 0, 1, 2, 3
 LAYOUT = {
     DG: [(2, 3), (4, 2), (1, 0)],
-    ETK: [(4, 12), (4, 4), (2, 3), (2, 3), (3, 2), (2, 3)],
+    ETK: [(4, 12), (4, 4), (2, 4), (2, 4), (3, 2), (2, 4)],
     MMFF: [(2, 2), (3, 3), (3, 5), (4, 1), (4, 3), (2, 2), (2, 3)],
     QUARTIC: [],
 }

@@ -1,0 +1,112 @@
+"""GPU tests of the ETKDG pipeline on flattened synthetic molecules.  Parity with RDKit is statistical on this
+path, so — like nvmolkit/tests/test_embed_molecules.py:115-187 — the checks are: requested
+conformer counts are reached, the distance bounds are satisfied, the DG energy per atom is below the stage
+threshold, infeasible molecules fail in the right stage and are bounded by confs x maxIterations attempts."""
+
+import numpy as np
+import pytest
+import torch
+
+from nvmolkit_amd.embedMolecules import STAGE_NAMES, FlatMolecule, FlatMoleculeSet, embed_flat
+from nvmolkit_amd.forcefield import DG, FlatForcefieldBatch
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def build(sizes, seed, with_etk=True):
+    rng = np.random.default_rng(seed)
+    mols, refs, bounds = [], [], []
+    for n in sizes:
+        fields, ref, b = util.synthetic_embed_molecule(rng, n, with_etk)
+        mols.append(FlatMolecule(**fields))
+        refs.append(ref)
+        bounds.append(b)
+    return FlatMoleculeSet(mols), mols, refs, bounds
+
+
+@pytest.mark.parametrize("etk", [True, False])
+def test_embedding_satisfies_bounds(etk):
+    sizes = [4, 6, 9, 12, 17, 25, 33]
+    molset, mols, refs, bounds = build(sizes, seed=7, with_etk=etk)
+    confs = 3
+    res = embed_flat(molset, confs_per_molecule=confs, max_iterations=20, use_exp_torsions=etk, use_basic_knowledge=etk,
+                     enforce_chirality=False, seed=123)
+    assert res.conf_counts.tolist() == [confs] * len(sizes), dict(zip(STAGE_NAMES, res.stage_failures.tolist()))
+    for m, (pairs, lb, ub) in enumerate(bounds):
+        xyz = res.conformers(m).cpu().numpy()
+        assert xyz.shape == (confs, sizes[m], 3) and np.isfinite(xyz).all()
+        for c in range(confs):
+            d = np.sqrt(((xyz[c, pairs[:, 0]] - xyz[c, pairs[:, 1]]) ** 2).sum(1))
+            viol = np.maximum(np.maximum(lb - d, d - ub), 0.0)
+            assert (viol / ub).max() < 0.1 and viol.max() < 0.5, (m, c, viol.max())
+        # conformers of one molecule come from different random starts
+        if sizes[m] > 4:
+            assert not np.allclose(xyz[0], xyz[1])
+
+
+def test_dg_energy_of_embedded_conformers_is_below_stage_threshold():
+    sizes = [8, 14, 21]
+    molset, mols, _, _ = build(sizes, seed=11, with_etk=False)
+    res = embed_flat(molset, confs_per_molecule=2, max_iterations=20, use_exp_torsions=False, use_basic_knowledge=False,
+                     enforce_chirality=False, seed=5)
+    assert (res.conf_counts == 2).all()
+    # re-evaluate the DG field (4th coordinate = 0) on the returned 3-D coordinates
+    systems = []
+    for m, mol in enumerate(mols):
+        for c in range(2):
+            xyz = res.conformers(m)[c].cpu().numpy()
+            systems.append((np.concatenate([xyz, np.zeros((len(xyz), 1))], 1), mol.dg))
+    a_s, flat, groups = util.build_ff_batch_arrays(DG, systems)
+    e = FlatForcefieldBatch(DG, a_s, groups).compute_energy(torch.from_numpy(flat).cuda(), 1.0, 0.1).cpu().numpy()
+    per_atom = e / np.repeat(sizes, 2)
+    assert (per_atom < 0.05).all(), per_atom
+
+
+def test_infeasible_molecule_fails_in_first_minimisation_and_is_bounded():
+    # three atoms whose bounds violate the triangle inequality: no embedding exists
+    pairs = np.array([[0, 1], [1, 2], [0, 2]])
+    dg = [(pairs, np.array([[0.9, 1.1, 1.0], [0.9, 1.1, 1.0], [24.0, 26.0, 1.0]])), (np.zeros((0, 4), int), np.zeros((0, 2))),
+          (np.arange(3).reshape(-1, 1), np.zeros((3, 0)))]
+    good, _, _ = util.synthetic_embed_molecule(np.random.default_rng(1), 7, with_etk=False)
+    # the infeasible molecule goes LAST: the reference scheduler only opens the next oversubscription round when the
+    # last molecule has used up the current one (src/etkdg_impl.cpp:318-320)
+    molset = FlatMoleculeSet([FlatMolecule(**good), FlatMolecule(3, dg)])
+    res = embed_flat(molset, confs_per_molecule=2, max_iterations=3, use_exp_torsions=False, use_basic_knowledge=False,
+                     enforce_chirality=False, batch_size=4)
+    assert res.conf_counts.tolist() == [2, 0]
+    assert res.stage_failures[1] == 2 * 3            # confs x maxIterations attempts, all failing the energy check
+    assert res.stage_failures[[0, 2, 3, 4]].sum() == 0
+
+
+def test_stereo_checks_reject_and_count():
+    # a tetrahedral-centre check on a planar square arrangement can never pass: centre 0 with neighbours 1-4 whose
+    # bounds force them into a plane through the centre
+    fields, _, _ = util.synthetic_embed_molecule(np.random.default_rng(3), 5, with_etk=False)
+    pts = np.array([[0, 0, 0], [1.5, 0, 0], [-1.5, 0, 0], [0, 1.5, 0], [0, -1.5, 0.0]])
+    pairs = np.array([(i, j) for i in range(5) for j in range(i + 1, 5)])
+    d = np.sqrt(((pts[pairs[:, 0]] - pts[pairs[:, 1]]) ** 2).sum(1))
+    fields["dg"] = [(pairs, np.stack([(d - 0.01) ** 2, (d + 0.01) ** 2, np.ones(len(d))], 1)), fields["dg"][1],
+                    (np.arange(5).reshape(-1, 1), np.zeros((5, 0)))]
+    fields["checks"] = [(0, (0, 1, 2, 3, 4), (0.0, 0.0))]
+    molset = FlatMoleculeSet([FlatMolecule(**fields)])
+    res = embed_flat(molset, confs_per_molecule=1, max_iterations=4, use_exp_torsions=False, use_basic_knowledge=False,
+                     enforce_chirality=False)
+    assert res.conf_counts.tolist() == [0]
+    assert res.stage_failures[2] + res.stage_failures[1] == 4 and res.stage_failures[2] >= 1
+
+
+def test_seed_reproducibility_and_validation():
+    molset, *_ = build([6, 10], seed=2, with_etk=True)
+    a = embed_flat(molset, 2, 10, enforce_chirality=False, seed=9)
+    b = embed_flat(molset, 2, 10, enforce_chirality=False, seed=9)
+    assert torch.equal(a.coords, b.coords)
+    c = embed_flat(molset, 2, 10, enforce_chirality=False, seed=10)
+    assert not torch.equal(a.coords, c.coords)
+    with pytest.raises(ValueError):
+        embed_flat(molset, 0)
+    with pytest.raises(TypeError):
+        embed_flat(molset, 1, stream=2)
+    no_etk, *_ = build([5], seed=1, with_etk=False)
+    with pytest.raises(ValueError):
+        embed_flat(no_etk, 1)  # ETK stage requested, no ETK terms

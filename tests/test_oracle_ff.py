@@ -58,9 +58,9 @@ def test_etk_terms_closed_form():
     # cos k*90deg = 0, -1, 0, 1, 0, -1
     assert ff.system_energy(ff.ETK, pos, g) == pytest.approx(1 + 2 * 0 + 3 + 4 * 2 + 5 + 6 * 0)
     g = list(groups)
-    g[2] = (np.array([[0, 1]]), np.array([[1.0, 1.2, 100.0]]))
+    g[2] = (np.array([[0, 1]]), np.array([[1.0, 1.2, 100.0, 0.0]]))
     assert ff.system_energy(ff.ETK, pos, g) == pytest.approx(0.5 * 100 * 0.3**2)
-    g[2] = (np.array([[0, 1]]), np.array([[1.0, 2.0, 100.0]]))
+    g[2] = (np.array([[0, 1]]), np.array([[1.0, 2.0, 100.0, 0.0]]))
     assert ff.system_energy(ff.ETK, pos, g) == 0.0
     g = list(groups)
     g[4] = (np.array([[0, 1, 2]]), np.array([[100.0, 120.0]]))

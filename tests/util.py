@@ -230,7 +230,7 @@ def random_ff_system(kind: int, n_atoms: int, rng):
         def flat_bottom(ix, k):
             dd = np.sqrt(((pos[ix[:, 0], :3] - pos[ix[:, 1], :3]) ** 2).sum(1)) if len(ix) else np.zeros(0)
             lo_ = dd * rng.uniform(0.8, 1.15, size=len(dd))
-            return np.stack([lo_, lo_ * rng.uniform(1.0, 1.2, size=len(dd)), np.full(len(dd), k)], 1) if len(dd) else np.zeros((0, 3))
+            return np.stack([lo_, lo_ * rng.uniform(1.0, 1.2, size=len(dd)), np.full(len(dd), k), np.zeros(len(dd))], 1) if len(dd) else np.zeros((0, 4))
 
         d13 = np.array([(i, i + 2) for i in range(n - 2)], dtype=np.int64).reshape(-1, 2)
         ang_lo = rng.uniform(60, 130, size=len(chain3))
@@ -273,3 +273,37 @@ def build_ff_batch_arrays(kind: int, systems):
         groups.append((starts, np.concatenate(idx_all) if idx_all else np.zeros((0, n_idx), np.int32),
                        np.concatenate(par_all) if par_all else np.zeros((0, n_par))))
     return atom_starts, flat, groups
+
+
+# ---- synthetic molecules for the ETKDG pipeline -------------------------------------------------------
+
+def synthetic_embed_molecule(rng, n_atoms: int, with_etk: bool = True):
+    """A chain molecule whose distance bounds are derived from a hidden reference geometry, so a feasible
+    embedding exists (up to mirror image).  Returns (FlatMolecule fields dict, reference coordinates)."""
+    ref = _chain_positions(rng, n_atoms, 3)
+    n = n_atoms
+    pairs = np.array([(i, j) for i in range(n) for j in range(i + 1, n)], dtype=np.int64).reshape(-1, 2)
+    d = np.sqrt(((ref[pairs[:, 0]] - ref[pairs[:, 1]]) ** 2).sum(1)) if len(pairs) else np.zeros(0)
+    sep = (pairs[:, 1] - pairs[:, 0]) if len(pairs) else np.zeros(0, dtype=np.int64)
+    tol = np.minimum(0.02 * sep.astype(float) ** 2, 1.0)
+    lb, ub = np.maximum(d - tol, 0.5), d + tol
+    dg = [(pairs, np.stack([lb**2, ub**2, np.ones(len(d))], 1) if len(d) else np.zeros((0, 3))),
+          (np.zeros((0, 4), np.int64), np.zeros((0, 2))),
+          (np.arange(n, dtype=np.int64).reshape(-1, 1), np.zeros((n, 0)))]
+    etk = None
+    if with_etk:
+        def fb(mask, k):
+            return pairs[mask], np.stack([lb[mask], ub[mask], np.full(mask.sum(), k), np.zeros(mask.sum())], 1)
+
+        chain3 = np.array([(i, i + 1, i + 2) for i in range(n - 2)], dtype=np.int64).reshape(-1, 3)
+        ang = []
+        for i, j, k in chain3:
+            a, b = ref[i] - ref[j], ref[k] - ref[j]
+            ang.append(np.degrees(np.arccos(np.clip(a @ b / np.linalg.norm(a) / np.linalg.norm(b), -1, 1))))
+        ang = np.array(ang).reshape(-1)
+        chain4 = np.array([(i, i + 1, i + 2, i + 3) for i in range(n - 3)], dtype=np.int64).reshape(-1, 4)
+        tors = np.concatenate([rng.uniform(0.0, 0.2, size=(len(chain4), 6)), rng.choice([-1.0, 1.0], size=(len(chain4), 6))], 1)
+        etk = [(chain4, tors), (np.zeros((0, 4), np.int64), np.zeros((0, 4))), fb(sep == 1, 100.0), fb(sep == 2, 100.0),
+               (chain3, np.stack([ang - 5.0, ang + 5.0], 1) if len(ang) else np.zeros((0, 2))), fb(sep >= 3, 10.0)]
+    checks = [(5, (i, i + 1, i + 2), ()) for i in range(n - 2)]  # NVMK_CHECK_DOUBLE_BOND_GEOMETRY: never linear here
+    return dict(n_atoms=n, dg=dg, etk=etk, checks=checks, num_impropers=0), ref, (pairs, lb, ub)
