@@ -139,13 +139,13 @@ def main() -> None:
     # inputs resident in HBM before the timed region
     queries = synth_fingerprints(n_q, words, device, SEED + 1 + rank)
     if distributed:
-        shard = (n_ref + world - 1) // world
-        lo, hi = min(rank * shard, n_ref), min((rank + 1) * shard, n_ref)
+        from nvmolkit_amd.distributed import all_gather_rows, shard_bounds
+
+        lo, hi = shard_bounds(n_ref, world, rank)
         ref_full_seeded = synth_fingerprints(n_ref, words, device, SEED)  # same seed on every rank
-        ref_shard = torch.zeros((shard, words), dtype=torch.int32, device=device)
-        ref_shard[: hi - lo] = ref_full_seeded[lo:hi]
+        ref_shard = ref_full_seeded[lo:hi].contiguous()
         del ref_full_seeded
-        ref_gathered = torch.empty((shard * world, words), dtype=torch.int32, device=device)
+        ref_gathered = all_gather_rows(ref_shard, n_ref)
     else:
         ref_shard = None
         ref_gathered = synth_fingerprints(n_ref, words, device, SEED)
@@ -162,8 +162,9 @@ def main() -> None:
         os.environ["NVMK_SIM_PATH"] = "valu"
 
     def step() -> None:
+        nonlocal ref_gathered
         if distributed:
-            dist.all_gather_into_tensor(ref_gathered, ref_shard)  # RCCL over xGMI, 256 MB total at 1M x 2048 bit
+            ref_gathered = all_gather_rows(ref_shard, n_ref)  # ONE RCCL all-gather over xGMI, 256 MB total at 1M x 2048 bit
         ref_ptr = ref_gathered.data_ptr()
         if use_mfma:
             # the bit -> FP4 expansion of both operands is part of the step (O(N + M), inside the timed region)

@@ -1,0 +1,191 @@
+"""Batched MMFF94 conformer optimisation on the GPU (reference API: nvmolkit/mmffOptimization.py:60-201).
+
+``MMFFOptimizeMoleculesConfs`` keeps the reference's signature and error behaviour; the RDKit -> flattened-term
+adapter below is the Python counterpart of ``constructForcefieldContribs``
+(rdkit_extensions/mmff_flattened_builder.cpp:41-541).  It needs RDKit (atom typing and parameter tables are
+RDKit's) and could not be exercised in the RDKit-less build / GPU images — the tested seam is
+:func:`optimize_flat`.
+"""
+
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch
+from nvmolkit_amd.types import CoordinateOutput, HardwareOptions
+
+_LINEAR_MMFF_TYPES = frozenset({4, 53, 61})  # MMFFPROP.PAR rows with linh = 1 (CSP, =N=, NR%)
+_TORSION_BOND_SMARTS = "[!$([D1]);!$([#1])]~[!$([D1]);!$([#1])]"  # RDKit DefaultTorsionBondSmarts
+
+
+def optimize_flat(atom_starts, groups, positions: torch.Tensor, max_iters: int = 200, grad_tol: float = 1e-4,
+                  system_mol=None):
+    """Minimise flattened MMFF systems in place; returns (energies, converged) tensors.
+
+    ``groups`` are the 7 MMFF term groups (include/nvmolkit_amd.h).  gradTol 1e-4 is fixed on the reference's path
+    (src/minimizer/bfgs_mmff.cpp:327)."""
+    batch = FlatForcefieldBatch(MMFF, atom_starts, groups, device=positions.device)
+    energies, statuses, _ = batch.minimize(positions, max_iters=max_iters, grad_tol=grad_tol, scale_grads=True)
+    return energies, statuses == 0
+
+
+def flatten_mmff_from_rdkit(mol, props, conf_id: int = -1, non_bonded_threshold: float = 100.0,
+                            ignore_interfrag_interactions: bool = True):
+    """RDKit molecule -> the 7 MMFF term groups (local atom indices).  UNTESTED without RDKit (see module docstring)."""
+    from rdkit import Chem
+
+    n = mol.GetNumAtoms()
+    bonds, angles, strbend, oops, tors, vdw, ele = ([] for _ in range(7))
+    for b in mol.GetBonds():  # addBonds, mmff_flattened_builder.cpp:41-59
+        i, j = b.GetBeginAtomIdx(), b.GetEndAtomIdx()
+        p = props.GetMMFFBondStretchParams(mol, i, j)
+        if p:
+            bonds.append((i, j, p[2], p[1]))  # r0, kb
+    for j in range(n):  # addAngles :122-168, addStretchBend :170-237
+        aj = mol.GetAtomWithIdx(j)
+        if aj.GetDegree() == 1:
+            continue
+        linear = props.GetMMFFAtomType(j) in _LINEAR_MMFF_TYPES
+        nbrs = [a.GetIdx() for a in aj.GetNeighbors()]
+        for x in range(len(nbrs)):
+            for y in range(x + 1, len(nbrs)):
+                i, k = nbrs[x], nbrs[y]
+                pa = props.GetMMFFAngleBendParams(mol, i, j, k)
+                if pa:
+                    angles.append((i, j, k, pa[2], pa[1], 1.0 if linear else 0.0))
+                if linear:
+                    continue
+                ps = props.GetMMFFStretchBendParams(mol, i, j, k)
+                b1, b2 = props.GetMMFFBondStretchParams(mol, i, j), props.GetMMFFBondStretchParams(mol, k, j)
+                if ps and pa and b1 and b2:
+                    strbend.append((i, j, k, pa[2], b1[2], b2[2], ps[1], ps[2]))
+    for j in range(n):  # addOop :239-296: three permutations per trigonal centre
+        aj = mol.GetAtomWithIdx(j)
+        if aj.GetDegree() != 3:
+            continue
+        a, c, d = (x.GetIdx() for x in aj.GetNeighbors())
+        koop = props.GetMMFFOopBendParams(mol, a, j, c, d)
+        if koop is None:
+            continue
+        for i1, i3, i4 in ((a, c, d), (a, d, c), (c, d, a)):
+            oops.append((i1, j, i3, i4, koop))
+    query = Chem.MolFromSmarts(_TORSION_BOND_SMARTS)  # addTorsions :298-371
+    sp23 = (Chem.HybridizationType.SP2, Chem.HybridizationType.SP3)
+    for j, k in mol.GetSubstructMatches(query):
+        aj, ak = mol.GetAtomWithIdx(j), mol.GetAtomWithIdx(k)
+        if aj.GetHybridization() not in sp23 or ak.GetHybridization() not in sp23:
+            continue
+        for bi in aj.GetBonds():
+            i = bi.GetOtherAtomIdx(j)
+            if i == k:
+                continue
+            for bl in ak.GetBonds():
+                l_ = bl.GetOtherAtomIdx(k)
+                if l_ == j or l_ == i:
+                    continue
+                p = props.GetMMFFTorsionParams(mol, i, j, k, l_)
+                if p:
+                    tors.append((i, j, k, l_, p[1], p[2], p[3]))
+    # non-bonded pairs: relation >= 1-4, within the threshold, same fragment (:373-470)
+    dm = Chem.GetDistanceMatrix(mol)
+    xyz = mol.GetConformer(conf_id).GetPositions()
+    frags = np.zeros(n, dtype=int)
+    if ignore_interfrag_interactions:
+        for f, atoms in enumerate(Chem.GetMolFrags(mol)):
+            frags[list(atoms)] = f
+    charges = [props.GetMMFFPartialCharge(i) for i in range(n)]
+    for i in range(n):
+        for j in range(i + 1, n):
+            if frags[i] != frags[j] or dm[i, j] < 3:
+                continue
+            if np.linalg.norm(xyz[i] - xyz[j]) > non_bonded_threshold:
+                continue
+            pv = props.GetMMFFVdWParams(i, j)
+            if pv:
+                vdw.append((i, j, pv[2], pv[3]))
+            if abs(charges[i]) > 1e-10 and abs(charges[j]) > 1e-10:
+                ele.append((i, j, charges[i] * charges[j], 1.0, 1.0 if dm[i, j] == 3 else 0.0))  # constant dielectric, D = 1
+
+    def split(rows, n_idx, n_par):
+        a = np.array(rows, dtype=np.float64).reshape(-1, n_idx + n_par)
+        return a[:, :n_idx].astype(np.int32), a[:, n_idx:]
+
+    return [split(bonds, 2, 2), split(angles, 3, 3), split(strbend, 3, 5), split(oops, 4, 1), split(tors, 4, 3),
+            split(vdw, 2, 2), split(ele, 2, 3)]
+
+
+def MMFFOptimizeMoleculesConfs(molecules, maxIters: int = 200, properties=None, nonBondedThreshold=100.0,
+                               ignoreInterfragInteractions=True, hardwareOptions: HardwareOptions | None = None,
+                               output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, targetGpu: int = -1):
+    """Optimise every conformer of every molecule with MMFF94 + BFGS on the GPU.
+
+    Same contract as the reference (nvmolkit/mmffOptimization.py:60-201): conformers are updated in place and a
+    list of per-conformer energies per molecule is returned; ``ValueError(message, {"none": [...], "no_params":
+    [...]})`` for ``None`` entries or molecules without MMFF parameters."""
+    if not molecules:
+        if output == CoordinateOutput.DEVICE:
+            raise ValueError("MMFFOptimizeMoleculesConfs(output=DEVICE) requires at least one molecule")
+        return []
+    try:
+        from rdkit.Chem import rdForceFieldHelpers as ffh
+    except ImportError as exc:
+        raise ImportError("MMFFOptimizeMoleculesConfs needs RDKit for MMFF typing; use optimize_flat() with "
+                          "flattened term tables") from exc
+    none_idx = [i for i, m in enumerate(molecules) if m is None]
+    no_params = [i for i, m in enumerate(molecules) if m is not None and not ffh.MMFFHasAllMoleculeParams(m)]
+    if none_idx or no_params:
+        parts = []
+        if none_idx:
+            parts.append(f"None at indices {none_idx}")
+        if no_params:
+            parts.append(f"lacking MMFF atom types at indices {no_params}")
+        raise ValueError("; ".join(parts), {"none": none_idx, "no_params": no_params})
+
+    def per_mol(value, name):
+        if isinstance(value, Sequence) and not isinstance(value, (str, bytes)) and not hasattr(value, "SetMMFFVariant"):
+            if len(value) != len(molecules):
+                raise ValueError(f"Expected {len(molecules)} values for {name}, got {len(value)}")
+            return list(value)
+        return [value] * len(molecules)
+
+    props = [p if p is not None else ffh.MMFFGetMoleculeProperties(m) for m, p in zip(molecules, per_mol(properties, "properties"))]
+    thresholds = per_mol(nonBondedThreshold, "nonBondedThreshold")
+    interfrag = per_mol(ignoreInterfragInteractions, "ignoreInterfragInteractions")
+    if output == CoordinateOutput.DEVICE:
+        raise NotImplementedError("DEVICE output (Device3DResult) is not built yet; see DESIGN.md 'next'")
+    batch_size = hardwareOptions.batchSize if hardwareOptions and hardwareOptions.batchSize > 0 else 500
+    systems = [(mi, conf.GetId()) for mi, m in enumerate(molecules) for conf in m.GetConformers()]
+    flat = {}
+    results = [[] for _ in molecules]
+    for lo in range(0, len(systems), batch_size):  # batches of 500 conformers (src/minimizer/bfgs_mmff.cpp:139-157)
+        chunk = systems[lo:lo + batch_size]
+        atom_starts, pos, groups_by_sys = [0], [], []
+        for mi, cid in chunk:
+            m = molecules[mi]
+            if mi not in flat:  # flattened once per unique molecule, on its first conformer (bfgs_mmff.cpp:159,195-201)
+                flat[mi] = flatten_mmff_from_rdkit(m, props[mi], cid, float(thresholds[mi]), bool(interfrag[mi]))
+            groups_by_sys.append(flat[mi])
+            atom_starts.append(atom_starts[-1] + m.GetNumAtoms())
+            pos.append(np.asarray(m.GetConformer(cid).GetPositions(), dtype=np.float64).reshape(-1))
+        groups = []
+        for g in range(7):
+            starts = np.zeros(len(chunk) + 1, dtype=np.int32)
+            for s, gs in enumerate(groups_by_sys):
+                starts[s + 1] = starts[s] + len(gs[g][0])
+            groups.append((starts, np.concatenate([gs[g][0] for gs in groups_by_sys]),
+                           np.concatenate([gs[g][1] for gs in groups_by_sys])))
+        positions = torch.from_numpy(np.concatenate(pos)).cuda()
+        energies, _ = optimize_flat(np.array(atom_starts, dtype=np.int32), groups, positions, max_iters=maxIters)
+        out = positions.cpu().numpy()
+        from rdkit.Geometry import Point3D
+
+        for s, (mi, cid) in enumerate(chunk):
+            xyz = out[atom_starts[s] * 3:atom_starts[s + 1] * 3].reshape(-1, 3)
+            conf = molecules[mi].GetConformer(cid)
+            for a, (x, y, z) in enumerate(xyz):
+                conf.SetAtomPosition(a, Point3D(float(x), float(y), float(z)))
+            results[mi].append(float(energies[s]))
+    return results

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Throughput of the conformer path on synthetic flattened molecules (BASELINE.json configs[2] shape):
+ETKDG with numConfs conformers per molecule, then MMFF94 optimisation of every conformer.
+Usage: python tools/bench_conformers.py [--mols 1000] [--confs 10] [--mean-atoms 48]"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from nvmolkit_amd.embedMolecules import STAGE_NAMES, FlatMolecule, FlatMoleculeSet, embed_flat  # noqa: E402
+from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch  # noqa: E402
+from oracle import ff as off  # noqa: E402  (layout constants only; nothing from the oracle is executed on the timed path)
+from tests import util  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--mols", type=int, default=1000)
+ap.add_argument("--confs", type=int, default=10)
+ap.add_argument("--mean-atoms", type=int, default=48)
+ap.add_argument("--batch-size", type=int, default=500)
+ap.add_argument("--mmff-iters", type=int, default=200)
+args = ap.parse_args()
+rng = np.random.default_rng(20260926)
+sizes = np.clip(rng.normal(args.mean_atoms, 12, size=args.mols).round().astype(int), 12, 96)
+t0 = time.perf_counter()
+mols = [FlatMolecule(**util.synthetic_embed_molecule(rng, int(n), with_etk=True)[0]) for n in sizes]
+molset = FlatMoleculeSet(mols)
+t_prep = time.perf_counter() - t0
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+res = embed_flat(molset, confs_per_molecule=args.confs, max_iterations=10, batch_size=args.batch_size, enforce_chirality=False, seed=1)
+torch.cuda.synchronize()
+t_embed = time.perf_counter() - t0
+n_conf = int(res.conf_counts.sum())
+
+# MMFF: one synthetic term table per molecule, shared by its conformers (system_mol)
+t0 = time.perf_counter()
+mm = [util.random_ff_system(MMFF, int(n), rng) for n in sizes]
+a_s, flat, groups = util.build_ff_batch_arrays(MMFF, mm)
+t_prep2 = time.perf_counter() - t0
+total_iters = 0
+t_mmff = 0.0
+done = 0
+for lo in range(0, args.mols, max(1, args.batch_size // args.confs)):
+    hi = min(args.mols, lo + max(1, args.batch_size // args.confs))
+    sub = [mm[i] for i in range(lo, hi) for _ in range(args.confs)]
+    sa, sf, sg = util.build_ff_batch_arrays(MMFF, sub)
+    noise = rng.normal(scale=0.05, size=sf.shape)
+    pos = torch.from_numpy(sf + noise).cuda()
+    batch = FlatForcefieldBatch(MMFF, sa, sg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e, st, it = batch.minimize(pos, max_iters=args.mmff_iters, grad_tol=1e-4)
+    torch.cuda.synchronize()
+    t_mmff += time.perf_counter() - t0
+    total_iters += int(it.sum())
+    done += len(sub)
+print(json.dumps({
+    "mols": args.mols, "confs_per_mol": args.confs, "mean_atoms": float(sizes.mean()),
+    "etkdg_s": t_embed, "etkdg_conformers": n_conf, "etkdg_confs_per_s": n_conf / t_embed,
+    "etkdg_stage_failures": dict(zip(STAGE_NAMES, res.stage_failures.tolist())),
+    "mmff_s": t_mmff, "mmff_conformers": done, "mmff_confs_per_s": done / t_mmff, "mmff_bfgs_iterations": total_iters,
+    "mols_per_s_etkdg_plus_mmff": args.mols / (t_embed + t_mmff), "host_prep_s": t_prep + t_prep2}))
