@@ -74,20 +74,32 @@ int orc_num_threads(void) {
  * (src/similarity_kernels.cu:505-582, :727-799), SIMT arithmetic.  `threads` <= 0 means all cores. */
 void orc_cross_similarity_f64(int metric, const uint32_t* a, int64_t nA, const uint32_t* b, int64_t nB, int W,
                               double* out, int64_t ld, int threads) {
+  int* pa = (int*)malloc(sizeof(int) * (size_t)(nA > 0 ? nA : 1));
   int* pb = (int*)malloc(sizeof(int) * (size_t)(nB > 0 ? nB : 1));
+  for (int64_t i = 0; i < nA; ++i) pa[i] = popc_row(a + i * W, W);
   for (int64_t j = 0; j < nB; ++j) pb[j] = popc_row(b + j * W, W);
+  /* cache blocking only (the arithmetic per pair is unchanged): a thread owns a block of B rows that stays in its
+   * cache while it sweeps blocks of A rows, so B is streamed from DRAM once per call instead of once per A row */
+  const int64_t JB = 256, IB = 64;
+  const int64_t nJB = (nB + JB - 1) / JB;
 #ifdef _OPENMP
   if (threads <= 0) threads = omp_get_max_threads();
-#pragma omp parallel for schedule(static) num_threads(threads)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
 #endif
-  for (int64_t i = 0; i < nA; ++i) {
-    const uint32_t* ai = a + i * W;
-    const int       pa = popc_row(ai, W);
-    for (int64_t j = 0; j < nB; ++j) {
-      const int c     = popc_and(ai, b + j * W, W);
-      out[i * ld + j] = finish_f64(metric, c, pa, pb[j]);
+  for (int64_t jb = 0; jb < nJB; ++jb) {
+    const int64_t j0 = jb * JB, j1 = (j0 + JB < nB) ? j0 + JB : nB;
+    for (int64_t i0 = 0; i0 < nA; i0 += IB) {
+      const int64_t i1 = (i0 + IB < nA) ? i0 + IB : nA;
+      for (int64_t i = i0; i < i1; ++i) {
+        const uint32_t* ai = a + i * W;
+        for (int64_t j = j0; j < j1; ++j) {
+          const int c     = popc_and(ai, b + j * W, W);
+          out[i * ld + j] = finish_f64(metric, c, pa[i], pb[j]);
+        }
+      }
     }
   }
+  free(pa);
   free(pb);
 }
 

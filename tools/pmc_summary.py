@@ -23,13 +23,14 @@ for f in glob.glob(f"{d}/trace/**/*_kernel_stats.csv", recursive=True):
 c = out["counters"]
 g = lambda k: c.get(k, {}).get("mean_per_dispatch")
 if g("GRBM_GUI_ACTIVE") and "stats" in out:
-    out["effective_clock_GHz"] = g("GRBM_GUI_ACTIVE") / float(out["stats"]["AverageNs"])
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    out["effective_clock_GHz"] = g("GRBM_GUI_ACTIVE") / 8.0 / float(out["stats"]["AverageNs"])
 if g("SQ_WAVE_CYCLES"):
     for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_LDS"):
         if g(k):
             out[f"{k}/SQ_WAVE_CYCLES"] = g(k) / g("SQ_WAVE_CYCLES")
 if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("GRBM_GUI_ACTIVE"):
-    out["MfmaUtil_pct"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") * 1024) * 100  # 256 CU x 4 SIMD
+    out["MfmaUtil_pct"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") / 8.0 * 1024) * 100  # 256 CU x 4 SIMD
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)
