@@ -7,14 +7,15 @@
 //
 // Kernel shape: 256 threads = 4 wave64 in a 2 x 2 arrangement, workgroup tile 128 x 128, wave tile
 // 64 x 64 = 2 x 2 MFMA blocks of 32 x 32 (4 accumulators of 16 VGPRs).  K is walked in LDS chunks of
-// 16 words (512 fingerprint bits = 256 B of FP4 per row): per chunk each operand tile is 32 KB, one
-// workgroup uses 64 KB so two workgroups share a CU and cover each other's global->LDS latency.  A
-// k-step (64 bits) is one MFMA per block: lanes 0-31 hold word 2t of rows 0-31, lanes 32-63 word 2t+1;
-// which nibble carries which k is irrelevant because both operands use the same expansion.
-// LDS rows are XOR-swizzled in 16-byte slots by (row & 15): every ds_read_b128 lane group touches 16
-// different slots of the 256-byte bank row (rows 0-3, 12-15, 20-27 -> row & 15 all distinct).
+// 8 words (256 fingerprint bits = 128 B of FP4 per row): per chunk each operand tile is 16 KB, one
+// workgroup uses 33 KB so FOUR workgroups (16 waves) share a CU and cover each other's global->LDS latency
+// and store drain.  A k-step (64 bits) is one MFMA per block: lanes 0-31 hold word 2t of rows 0-31, lanes
+// 32-63 word 2t+1; which nibble carries which k is irrelevant because both operands use the same expansion.
+// LDS rows are XOR-swizzled in 16-byte slots: every ds_read_b128 lane group touches 16 different slots of the
+// 256-byte bank row.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fp4.h"
 
@@ -78,10 +79,10 @@ __device__ __forceinline__ v16f mfma_fp4(const uint4 a, const uint4 b, const v16
 // (row & 1 picks the half), slot ^= (row >> 1) & 7.
 template <int KCW> struct Chunk {
   static constexpr int ROWBYTES = KCW * 16;
-  static constexpr int LOG      = (KCW == 16) ? 4 : 3;
+  static constexpr int LOG      = (KCW == 16) ? 4 : (KCW == 8 ? 3 : 2);
   static constexpr int T        = TM * KCW / NT;  // 16-byte pieces per thread per operand
   __device__ static __forceinline__ unsigned swz(const unsigned row) {
-    return (KCW == 16) ? (row & 15u) : ((row >> 1) & 7u);
+    return (KCW == 16) ? (row & 15u) : (KCW == 8 ? ((row >> 1) & 7u) : ((row >> 2) & 3u));
   }
 };
 
@@ -115,74 +116,61 @@ __device__ __forceinline__ void chunk_mma(v16f (&acc)[2][2], const char* sA, con
   }
 }
 
-// Staging registers are NAMED scalars (arrays indexed in helper loops were kept in scratch memory by
-// this compiler: 272 B/lane and a store/reload of the whole prefetch per chunk).
-#define NVMK_STAGE_DECL(P) uint4 P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7
+// Register-staged pieces (neighbour-count kernel): NAMED scalars, because arrays indexed in helper loops were
+// kept in scratch memory by this compiler (272 B/lane and a store/reload of the whole prefetch per chunk).
 #define NVMK_PIECE_ROW(t) ((tid + (t)*NT) >> C::LOG)
 #define NVMK_PIECE_SLOT(t) ((tid + (t)*NT) & (KCW - 1))
-#define NVMK_FETCH_ONE(P, base, t) \
-  if ((t) < C::T) P##t = (base)[static_cast<int64_t>(NVMK_PIECE_ROW(t)) * Wp + NVMK_PIECE_SLOT(t)];
-#define NVMK_FETCH(P, base)                                                                                \
-  NVMK_FETCH_ONE(P, base, 0) NVMK_FETCH_ONE(P, base, 1) NVMK_FETCH_ONE(P, base, 2) NVMK_FETCH_ONE(P, base, 3) \
-  NVMK_FETCH_ONE(P, base, 4) NVMK_FETCH_ONE(P, base, 5) NVMK_FETCH_ONE(P, base, 6) NVMK_FETCH_ONE(P, base, 7)
 #define NVMK_COMMIT_ONE(P, lds, t)                                                         \
   if ((t) < C::T)                                                                          \
     *reinterpret_cast<uint4*>((lds) + NVMK_PIECE_ROW(t) * C::ROWBYTES +                      \
                               ((NVMK_PIECE_SLOT(t) ^ C::swz(NVMK_PIECE_ROW(t))) << 4)) = P##t;
-#define NVMK_COMMIT(P, lds)                                                                                \
-  NVMK_COMMIT_ONE(P, lds, 0) NVMK_COMMIT_ONE(P, lds, 1) NVMK_COMMIT_ONE(P, lds, 2) NVMK_COMMIT_ONE(P, lds, 3) \
-  NVMK_COMMIT_ONE(P, lds, 4) NVMK_COMMIT_ONE(P, lds, 5) NVMK_COMMIT_ONE(P, lds, 6) NVMK_COMMIT_ONE(P, lds, 7)
 
-// Shared main loop: accumulates this workgroup's 128 x 128 tile of intersection counts.
-#define NVMK_MFMA_MAINLOOP(A, B, rowA0, rowB0)                                               \
-  NVMK_STAGE_DECL(ra);                                                                       \
-  NVMK_STAGE_DECL(rb);                                                                       \
-  {                                                                                          \
-    const uint4* gA = (A) + (rowA0)*Wp;                                                      \
-    const uint4* gB = (B) + (rowB0)*Wp;                                                      \
-    const int    nChunks = Wp / KCW;                                                         \
-    NVMK_FETCH(ra, gA)                                                                       \
-    NVMK_FETCH(rb, gB)                                                                       \
-    for (int ch = 0; ch < nChunks; ++ch) {                                                   \
-      if (ch > 0) __syncthreads();                                                           \
-      NVMK_COMMIT(ra, sA)                                                                    \
-      NVMK_COMMIT(rb, sB)                                                                    \
-      __syncthreads();                                                                       \
-      if (ch + 1 < nChunks) { /* next chunk's global loads fly under this chunk's MFMAs */   \
-        NVMK_FETCH(ra, gA + (ch + 1) * KCW)                                                  \
-        NVMK_FETCH(rb, gB + (ch + 1) * KCW)                                                  \
-      }                                                                                      \
-      chunk_mma<KCW>(acc, sA, sB, wm, wn, lane);                                             \
-    }                                                                                        \
-  }
+// ---- dense cross-similarity ----------------------------------------------------------------------
+// Operand chunks go global -> LDS directly (global_load_lds_dwordx4: 1 KB per wave instruction, no staging
+// VGPRs, no ds_write pass).  The DMA destination is wave-uniform base + lane * 16, so the LDS image is linear in
+// "piece" order and the XOR swizzle is applied to the per-lane SOURCE slot instead (slot ^ swz(row) is an
+// involution; chunk_mma applies the same one on the read side).  110 VGPRs and 33 KB of LDS -> 4 workgroups
+// per CU.  Measured alternatives at 1M x 1M, 2048 bits (T pairs/s): VGPR-staged loads + ds_write with a
+// reciprocal table in LDS, 3 workgroups/CU 0.54; this kernel 0.60; double-buffered 8-word chunks (65 KB, 2
+// workgroups/CU) 0.53; double-buffered 4-word chunks 0.56; single-buffered 4-word chunks at 5 workgroups/CU
+// 0.57; plain instead of nontemporal stores 0.47 (the output stream evicts the operand blocks from L2).
+// A pure store kernel with this tile/lane pattern reaches 5.44 TB/s (tools/ubench_store.hip), this kernel 4.9.
+//
+// The Tanimoto ratio needs no table: r0 = v_rcp_f32(u) (1 ulp), one Newton step in f64 (relative error
+// < 2^-44), then q0 = c r, e = fma(-q0, u, c), q = fma(e, r, q0): the value before the last rounding is
+// within 2^-88 relative of c / u, and a quotient of integers < 2^24 is either exactly representable or
+// > 2^-80 (relative) away from every rounding boundary, so q is the correctly rounded IEEE quotient.
+// Checked exhaustively for u <= 16384 on the CPU for every possible 1-ulp seed (oracle_similarity.c
+// orc_check_newton_division) and for u <= 4096 on the device
+// (tests/test_similarity_gpu.py::test_prefix_fingerprints_exhaust_all_ratios).
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void*       lptr_t;
 
-// Tanimoto ratio c / u for integers 0 <= c <= u via a table of correctly rounded reciprocals and one
-// fma correction step: q0 = c * r, e = fma(-q0, u, c), q = fma(e, r, q0).  Equal to the IEEE division
-// for every 1 <= u <= 16384 (exhaustive check: oracle_similarity.c orc_check_reciprocal_division and
-// tests/test_oracle_similarity.py); 5 double ops instead of the ~13 of v_div_scale/v_rcp/v_div_fmas.
-__device__ __forceinline__ double ratio_by_table(const int c, const int u, const double* rtab) {
-  const double r  = rtab[u];
-  const double cd = static_cast<double>(c);
+__device__ __forceinline__ double ratio_by_newton(const int c, const int u) {
   const double ud = static_cast<double>(u);
+  const double cd = static_cast<double>(c);
+  const double r0 = static_cast<double>(__builtin_amdgcn_rcpf(static_cast<float>(u)));
+  const double r  = __fma_rn(__fma_rn(-ud, r0, 1.0), r0, r0);
   const double q0 = __dmul_rn(cd, r);
   const double e  = __fma_rn(-q0, ud, cd);
   return __fma_rn(e, r, q0);
 }
 
-template <int KCW, int METRIC, bool TABLE>
-__global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __restrict__ A, const int32_t* __restrict__ popA,
+template <int METRIC>
+__global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __restrict__ A, const int32_t* __restrict__ popA,
                                                                const int64_t nA, const uint4* __restrict__ B,
                                                                const int32_t* __restrict__ popB, const int64_t nB,
-                                                               const int Wp, const int F, double* __restrict__ out,
-                                                               const int64_t ld, const unsigned tilesM,
-                                                               const unsigned tilesN) {
-  using C = Chunk<KCW>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char*   sA   = smem;
-  char*   sB   = smem + TM * C::ROWBYTES;
-  int*    pcA  = reinterpret_cast<int*>(smem + (TM + TN) * C::ROWBYTES);
-  int*    pcB  = pcA + TM;
-  double* rtab = reinterpret_cast<double*>(pcB + TN);  // [F + 1], TABLE only
+                                                               const int Wp, double* __restrict__ out, const int64_t ld,
+                                                               const unsigned tilesM, const unsigned tilesN) {
+  constexpr int KCW = 8;
+  constexpr int PPW = KCW / 2;   // DMA pieces (1 KB wave instructions) per wave per operand
+  constexpr int RPP = 64 / KCW;  // rows per piece
+  using C           = Chunk<KCW>;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* sA  = smem;
+  char* sB  = smem + TM * C::ROWBYTES;
+  int*  pcA = reinterpret_cast<int*>(smem + (TM + TN) * C::ROWBYTES);
+  int*  pcB = pcA + TM;
 
   // Workgroup -> tile map: blockIdx.y walks 64 x 64-tile supertiles, blockIdx.x walks a supertile with
   // tile_n fastest.  Inside a supertile both operand blocks (8 MB each) stay in L2 / Infinity Cache, so only
@@ -198,7 +186,7 @@ __global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __re
 
   const int     tid   = threadIdx.x;
   const int     lane  = tid & 63;
-  const int     wave  = tid >> 6;
+  const int     wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int     wm    = wave >> 1;
   const int     wn    = wave & 1;
   const int64_t rowA0 = static_cast<int64_t>(tile_m) * TM;
@@ -208,9 +196,6 @@ __global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __re
     pcA[tid] = popA[rowA0 + tid];
   } else {
     pcB[tid - TM] = popB[rowB0 + tid - TM];
-  }
-  if constexpr (TABLE) {
-    for (int u = tid; u <= F; u += NT) rtab[u] = 1.0 / static_cast<double>(u > 1 ? u : 1);
   }
 
   v16f acc[2][2];
@@ -223,44 +208,79 @@ __global__ __launch_bounds__(NT, 2) void cross_sim_mfma_kernel(const uint4* __re
     }
   }
 
-  NVMK_MFMA_MAINLOOP(A, B, rowA0, rowB0)
-
-  // epilogue: D[i][j], i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), j = lane & 31 inside each 32 x 32 block
-  const bool full = (rowA0 + TM <= nA) && (rowB0 + TN <= nB);
+  {
+    // piece p = (wave * PPW + t) * 64 + lane lands at LDS byte 16 p: row p / KCW, physical slot p % KCW;
+    // the swizzle term differs per piece (row + RPP t) and is folded in per t
+    const unsigned prow    = static_cast<unsigned>(wave * 32 + (lane >> C::LOG));
+    const int64_t  rowStep = static_cast<int64_t>(RPP) * Wp;
+    const uint4*   gA      = A + (rowA0 + prow) * Wp;
+    const uint4*   gB      = B + (rowB0 + prow) * Wp;
+    const int      nChunks = Wp / KCW;
+    for (int ch = 0; ch < nChunks; ++ch) {
+      if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int     jl  = wn * 64 + ni * 32 + (lane & 31);
-    const int64_t col = rowB0 + jl;
-    const int     pbv = pcB[jl];
+      for (int t = 0; t < PPW; ++t) {
+        const unsigned slot = (static_cast<unsigned>(lane) & (KCW - 1u)) ^ C::swz(prow + RPP * t);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gA + t * rowStep + ch * KCW + slot),
+                                         (lptr_t)(sA + (wave * PPW + t) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < PPW; ++t) {
+        const unsigned slot = (static_cast<unsigned>(lane) & (KCW - 1u)) ^ C::swz(prow + RPP * t);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gB + t * rowStep + ch * KCW + slot),
+                                         (lptr_t)(sB + (wave * PPW + t) * 1024), 16, 0, 0);
+      }
+      __syncthreads();  // hipcc drains vmcnt before the barrier: the chunk has landed for every wave
+      chunk_mma<KCW>(acc, sA, sB, wm, wn, lane);
+    }
+  }
+
+  // Epilogue: D[i][j], i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), j = lane & 31 inside each 32 x 32 block.
+  // Addresses are a wave-uniform 64-bit row base plus one 32-bit per-lane byte offset; interior tiles take the
+  // branch-free path so the 64 divisions and stores of a lane interleave.
+  const bool     full    = (rowA0 + TM <= nA) && (rowB0 + TN <= nB);
+  const unsigned hi      = static_cast<unsigned>(lane >> 5);
+  const unsigned laneOff = (hi * 4u * static_cast<unsigned>(ld) + static_cast<unsigned>(lane & 31)) * 8u;
+  char*          waveOut = reinterpret_cast<char*>(out + (rowA0 + wm * 64) * ld + rowB0 + wn * 64);
+  auto value = [&](const int c, const int pav, const int pbv) -> double {
+    if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+      const int u = pav + pbv - c;
+      return ratio_by_newton(c, u > 1 ? u : 1);
+    } else {
+      const double denom = sqrt(static_cast<double>(pav) * static_cast<double>(pbv));
+      return (c == 0 || denom == 0.0) ? 0.0 : static_cast<double>(c) / denom;
+    }
+  };
+  const int pb0 = pcB[wn * 64 + (lane & 31)];
+  const int pb1 = pcB[wn * 64 + 32 + (lane & 31)];
+  auto emit = [&](auto fullTag) {
+    constexpr bool FULL = decltype(fullTag)::value;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int     il  = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int64_t row = rowA0 + il;
-        const int     c   = static_cast<int>(acc[mi][ni][r]);
-        const int     pav = pcA[il];
-        double        v;
-        if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-          const int u  = pav + pbv - c;
-          const int u1 = u > 1 ? u : 1;
-          if constexpr (TABLE) {
-            v = ratio_by_table(c, u1, rtab);
-          } else {
-            v = static_cast<double>(c) / static_cast<double>(u1);
+        const int il0    = mi * 32 + (r & 3) + 8 * (r >> 2);  // + 4 hi: this lane's row inside the wave tile
+        const int pav    = pcA[wm * 64 + il0 + 4 * static_cast<int>(hi)];
+        char*     rowOut = waveOut + static_cast<int64_t>(il0) * ld * 8;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const double v   = value(static_cast<int>(acc[mi][ni][r]), pav, ni ? pb1 : pb0);
+          double*      dst = reinterpret_cast<double*>(rowOut + ni * 256 + laneOff);
+          if (FULL || (rowA0 + wm * 64 + il0 + 4 * static_cast<int>(hi) < nA &&
+                       rowB0 + wn * 64 + ni * 32 + (lane & 31) < nB)) {
+            // nontemporal: the 8 B/pair output stream must not evict the operand blocks from L2
+            __builtin_nontemporal_store(v, dst);
           }
-        } else {
-          const double denom = sqrt(static_cast<double>(pav) * static_cast<double>(pbv));
-          v                  = (c == 0 || denom == 0.0) ? 0.0 : static_cast<double>(c) / denom;
-        }
-        if (full || (row < nA && col < nB)) {
-          __builtin_nontemporal_store(v, out + row * ld + col);
         }
       }
     }
+  };
+  if (full) {
+    emit(std::true_type{});
+  } else {
+    emit(std::false_type{});
   }
 }
-
 
 // ---- neighbour counting on the matrix cores ------------------------------------------------------
 // Same main loop as the dense kernel (8-word chunks), but the epilogue thresholds the exact counts with
@@ -471,18 +491,12 @@ int prepare(const uint32_t* d_in, const int32_t* d_rows, int64_t n, int fpBits, 
   return NVMK_OK;
 }
 
-template <int KCW, int METRIC, bool TABLE>
+template <int METRIC>
 int launch_dense_t(const Prepared& A, const Prepared& B, double* out, int64_t ld, dim3 grid, unsigned tilesM,
                    unsigned tilesN, hipStream_t stream) {
-  const int    F     = A.L.W * 32;
-  const size_t shmem = static_cast<size_t>(TM + TN) * KCW * 16 + (TM + TN) * 4 + (TABLE ? (static_cast<size_t>(F) + 1) * 8 : 0);
-  auto         kern  = cross_sim_mfma_kernel<KCW, METRIC, TABLE>;
-  if (shmem > 64 * 1024) {
-    NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(shmem)));
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(NT), shmem, stream, A.rows, A.popc, A.L.n, B.rows, B.popc, B.L.n, A.L.Wp, F, out, ld,
-                     tilesM, tilesN);
+  const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + (TM + TN) * 4;
+  hipLaunchKernelGGL(cross_sim_mfma_kernel<METRIC>, grid, dim3(NT), shmem, stream, A.rows, A.popc, A.L.n, B.rows, B.popc,
+                     B.L.n, A.L.Wp, out, ld, tilesM, tilesN);
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }
@@ -491,6 +505,9 @@ int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, 
   if (A.L.n == 0 || B.L.n == 0) return NVMK_OK;
   NVMK_REQUIRE(A.L.Wp == B.L.Wp && A.L.W == B.L.W, "prepared sets have different fingerprint widths");
   NVMK_REQUIRE(out != nullptr && ld >= B.L.n, "cross similarity: bad output buffer / ld_out");
+  // the epilogue keeps 4 rows * ld * 8 bytes in a 32-bit lane offset; popcounts must stay exact in f32
+  NVMK_REQUIRE(ld < (int64_t{1} << 26), "cross similarity: ld_out %lld too large (max 2^26 - 1)", (long long)ld);
+  NVMK_REQUIRE(A.L.W * 32 < (1 << 24), "cross similarity: fingerprints too wide for the matrix-core path");
   const int64_t tilesM = A.L.nPad / TM;
   const int64_t tilesN = B.L.nPad / TN;
   const int64_t supers = ceil_div<int64_t>(tilesM, SUPER) * ceil_div<int64_t>(tilesN, SUPER);
@@ -498,20 +515,8 @@ int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, 
                (long long)tilesM, (long long)tilesN);
   const dim3     grid(static_cast<unsigned>(SUPER * SUPER), static_cast<unsigned>(supers));
   const unsigned tm = static_cast<unsigned>(tilesM), tn = static_cast<unsigned>(tilesN);
-  // K-chunk of 8 words: 32 KB of operand tiles + the reciprocal table -> 3 workgroups per CU.
-  // NVMK_MFMA_KCW=16 selects the 16-word chunk (2 workgroups per CU) for A/B experiments.
-  static const int kcw = [] {
-    const char* e = std::getenv("NVMK_MFMA_KCW");
-    return (e != nullptr && std::atoi(e) == 16) ? 16 : 8;
-  }();
-  const bool table = (A.L.W * 32 <= 8192);  // table is 8 (F + 1) bytes of LDS; validated exhaustively up to u = 16384
-  if (metric == NVMK_METRIC_TANIMOTO) {
-    if (kcw == 16) return launch_dense_t<16, NVMK_METRIC_TANIMOTO, false>(A, B, out, ld, grid, tm, tn, stream);
-    return table ? launch_dense_t<8, NVMK_METRIC_TANIMOTO, true>(A, B, out, ld, grid, tm, tn, stream) :
-                   launch_dense_t<8, NVMK_METRIC_TANIMOTO, false>(A, B, out, ld, grid, tm, tn, stream);
-  }
-  if (kcw == 16) return launch_dense_t<16, NVMK_METRIC_COSINE, false>(A, B, out, ld, grid, tm, tn, stream);
-  return launch_dense_t<8, NVMK_METRIC_COSINE, false>(A, B, out, ld, grid, tm, tn, stream);
+  if (metric == NVMK_METRIC_TANIMOTO) return launch_dense_t<NVMK_METRIC_TANIMOTO>(A, B, out, ld, grid, tm, tn, stream);
+  return launch_dense_t<NVMK_METRIC_COSINE>(A, B, out, ld, grid, tm, tn, stream);
 }
 
 int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int32_t* counts, hipStream_t stream) {

@@ -89,8 +89,8 @@ def _declare(L: ctypes.CDLL) -> None:
     L.orc_morgan_fingerprints.argtypes = [_u32p, _u32p, _i16p, _i16p, _i16p, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, _u32p]
     L.orc_morgan_fingerprints.restype = None
-    L.orc_check_reciprocal_division.argtypes = [ctypes.c_int]
-    L.orc_check_reciprocal_division.restype = ctypes.c_int64
+    L.orc_check_newton_division.argtypes = [ctypes.c_int]
+    L.orc_check_newton_division.restype = ctypes.c_int64
 
 
 def _as_u32(x) -> np.ndarray:
@@ -136,9 +136,9 @@ def neighbor_counts(x, y, threshold: float, sign: int = 1, metric: int = TANIMOT
     return counts
 
 
-def check_reciprocal_division(umax: int) -> int:
-    """Number of (c, u) pairs where the table-reciprocal division differs from IEEE c / u (must be 0)."""
-    return int(lib().orc_check_reciprocal_division(int(umax)))
+def check_newton_division(umax: int) -> int:
+    """Number of (c, u) pairs where the rcp_f32 + Newton division shortcut differs from IEEE c / u (must be 0)."""
+    return int(lib().orc_check_newton_division(int(umax)))
 
 
 def butina_fused(x, cutoff: float, metric: int = TANIMOTO):

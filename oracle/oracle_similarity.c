@@ -323,26 +323,33 @@ int64_t orc_butina_dense(const double* dist, const uint8_t* hit_in, int64_t N, d
 }
 
 /*
- * Exhaustive check of the reciprocal-table division used by the HIP epilogue (not reference
- * arithmetic: it validates an implementation shortcut against IEEE division).
- *   r  = RN(1 / u)                    (table entry, computed with a real division)
+ * Exhaustive check of the division shortcut used by the HIP epilogue (not reference arithmetic: it
+ * validates an implementation shortcut against IEEE division).  The device computes
+ *   r0 = v_rcp_f32((float)u)          (hardware reciprocal, accurate to 1 ulp of f32)
+ *   r  = fma(fma(-u, r0, 1), r0, r0)  (one Newton step in f64)
  *   q0 = RN(c * r);  e = fma(-q0, u, c);  q = fma(e, r, q0)
- * Returns the number of (c, u) pairs, 0 <= c <= u, 1 <= u <= umax, for which q != (double)c / (double)u.
+ * A 1-ulp reciprocal is one of the three floats around RN_f32(1 / u), so all three seeds are tried.
+ * Returns the number of (seed, c, u) triples, 0 <= c <= u, 1 <= u <= umax, for which q != (double)c / (double)u.
  */
-int64_t orc_check_reciprocal_division(int umax) {
+int64_t orc_check_newton_division(int umax) {
   int64_t bad = 0;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : bad)
 #endif
   for (int u = 1; u <= umax; ++u) {
-    const double ud = (double)u;
-    const double r  = 1.0 / ud;
-    for (int c = 0; c <= u; ++c) {
-      const double cd = (double)c;
-      const double q0 = cd * r;
-      const double e  = fma(-q0, ud, cd);
-      const double q  = fma(e, r, q0);
-      if (q != cd / ud) ++bad;
+    const double ud    = (double)u;
+    const float  rn    = 1.0f / (float)u;
+    const float  seeds[3] = {nextafterf(rn, 0.0f), rn, nextafterf(rn, 2.0f)};
+    for (int k = 0; k < 3; ++k) {
+      const double r0 = (double)seeds[k];
+      const double r  = fma(fma(-ud, r0, 1.0), r0, r0);
+      for (int c = 0; c <= u; ++c) {
+        const double cd = (double)c;
+        const double q0 = cd * r;
+        const double e  = fma(-q0, ud, cd);
+        const double q  = fma(e, r, q0);
+        if (q != cd / ud) ++bad;
+      }
     }
   }
   return bad;

@@ -137,3 +137,10 @@ def test_butina_fused_edge_cases():
     zeros = np.zeros((5, 4), dtype=np.uint32)  # degree-0 rows become singletons
     cl, sizes, _ = oracle.butina_fused(zeros, 0.5)
     assert sorted(c[0] for c in cl) == list(range(5)) and sizes[-1] == 5
+
+
+def test_division_shortcut_of_hip_epilogue_is_exact():
+    """rcp_f32 seed (any of the three floats within 1 ulp) + one f64 Newton step + fma correction equals the IEEE
+    quotient for every 0 <= c <= u <= 16384 (the device side is covered by
+    tests/test_similarity_gpu.py::test_prefix_fingerprints_exhaust_all_ratios)."""
+    assert oracle.check_newton_division(16384) == 0

@@ -143,6 +143,26 @@ def test_memory_constrained_paths(metric):
         fn(dev(a), dev(b), max_device_memory_bytes=1024)  # 32 rows do not fit
 
 
+@pytest.mark.parametrize("words", [32, 64, 128])
+def test_prefix_fingerprints_exhaust_all_ratios(words):
+    """Row i = the first i bits set: the (F+1) x (F+1) matrix contains EVERY ratio c / u with 0 <= c <= u <= F
+    (c = min(i, j), u = max(i, j)), so the matrix-core kernel's division shortcut (Newton step from
+    v_rcp_f32) is checked exhaustively against the IEEE quotient."""
+    bits = words * 32
+    n = bits + 1
+    idx = np.arange(n)
+    full = idx[:, None] // 32 > np.arange(words)[None, :]
+    part = idx[:, None] // 32 == np.arange(words)[None, :]
+    rem = (np.uint64(1) << (idx % 32).astype(np.uint64)) - np.uint64(1)
+    fp = np.where(full, np.uint32(0xFFFFFFFF), np.where(part, rem[:, None].astype(np.uint32), np.uint32(0))).astype(np.uint32)
+    assert np.array_equal(np.unpackbits(fp.view(np.uint8), axis=1).sum(axis=1), idx)
+    got = crossTanimotoSimilarity(dev(fp)).torch().cpu().numpy()
+    lo = np.minimum(idx[:, None], idx[None, :]).astype(np.float64)
+    hi = np.maximum(idx[:, None], idx[None, :]).astype(np.float64)
+    want = np.divide(lo, hi, out=np.zeros_like(lo), where=hi > 0)
+    assert np.array_equal(got, want)
+
+
 def test_full_size_properties_2048bit():
     """BASELINE-size width at a GPU-sized N: size-independent properties instead of an oracle matrix."""
     n = 8192
