@@ -166,7 +166,7 @@ int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uint32_t* d_bo
  * (src/minimizer/bfgs_minimize_permol_kernels.cu:426-745; BfgsBatchMinimizer::minimize, bfgs_minimize.cu:978-1084).
  *
  * A batch is `n_systems` independent systems (conformers); system s owns atoms [atom_starts[s], atom_starts[s+1])
- * of the position array, `dim` doubles per atom (dim = 3 for MMFF, 4 for DG / ETK / QUARTIC).  Term tables are the
+ * of the position array, `dim` doubles per atom (dim = 3 for MMFF / UFF, 4 for DG / ETK / QUARTIC).  Term tables are the
  * flattened arrays the reference builds in rdkit_extensions/ (SoA + CSR): group g holds the terms of one type for
  * all systems, terms of system s are [starts[s], starts[s+1]); `idx` has n_idx LOCAL atom indices per term and
  * `par` n_par doubles per term, both interleaved per term:
@@ -183,6 +183,10 @@ int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uint32_t* d_bo
  *     g2 stretch-bend idx(1,2,3) par(theta0, r0ij, r0kj, kbaIJK, kbaKJI)   g3 out-of-plane idx(1..4) par(koop)
  *     g4 torsion idx(1..4) par(V1, V2, V3)          g5 vdW idx(i, j) par(R*, eps)
  *     g6 electrostatic idx(i, j) par(qi*qj/D, dielModel, is1_4)
+ *   NVMK_FF_UFF  (src/forcefields/uff.h:27-67; term math src/forcefields/uff_kernels_device.cuh:37-580)
+ *     g0 bond idx(i, j) par(restLen, k)             g1 angle idx(1,2,3) par(theta0, k, order, C0, C1, C2)
+ *     g2 torsion idx(1..4) par(k, order, cosTerm)   g3 inversion idx(1..4) par(k, C0, C1, C2)
+ *     g4 vdW idx(i, j) par(x_ij, wellDepth, threshold)
  *   NVMK_FF_QUARTIC: the synthetic field of the reference's BFGS tests (tests/test_bfgs_minimizer.cu:823-860),
  *     E = sum (x_p - p)^4 over global coordinate index p; w0 != 0 includes every atom's 4th coordinate.
  * All pointers inside the struct are DEVICE pointers; the struct itself is passed by host pointer.
@@ -191,6 +195,7 @@ int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uint32_t* d_bo
 #define NVMK_FF_ETK 1
 #define NVMK_FF_MMFF 2
 #define NVMK_FF_QUARTIC 3
+#define NVMK_FF_UFF 4
 
 typedef struct nvmk_ff_group {
   const int32_t* starts; /* [n_systems + 1] */

@@ -79,7 +79,7 @@ class FFBatch(ctypes.Structure):
                 ("etk_ref13_starts", ctypes.c_void_p), ("etk_ref13", ctypes.c_void_p)]
 
 
-FF_DG, FF_ETK, FF_MMFF, FF_QUARTIC = 0, 1, 2, 3
+FF_DG, FF_ETK, FF_MMFF, FF_QUARTIC, FF_UFF = 0, 1, 2, 3, 4
 
 
 class EtkdgMolset(ctypes.Structure):

@@ -1,0 +1,81 @@
+"""RDKit conformers <-> flattened conformer batches for the MMFF / UFF optimisers.
+
+The Python counterpart of the reference's ``flattenConformers`` / ``writeBackResults``
+(src/minimizer/bfgs_common.cpp:42-105) and of the batch loop of ``MMFFMinimizeMoleculesConfs`` /
+``UFFMinimizeMoleculesConfs`` (src/minimizer/bfgs_mmff.cpp:139-328, bfgs_uff.cpp:36-255).  Needs RDKit molecules, so
+it is exercised only where RDKit is installed; the force-field work it drives (``FlatForcefieldBatch.minimize`` with
+per-molecule tables shared through ``system_mol``) is what the GPU tests cover.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from nvmolkit_amd.forcefield import FlatForcefieldBatch, stack_molecule_tables
+from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
+
+DEFAULT_BATCH = 500  # conformers per launch (src/minimizer/bfgs_common.cpp: batchSize default)
+
+
+def optimize_rdkit_conformers(kind: int, molecules, flatten, max_iters: int, grad_tol: float,
+                              hardware_options: HardwareOptions | None, output: CoordinateOutput, target_gpu: int):
+    """Minimise every conformer of every molecule.  ``flatten(mol_index, conf_id)`` returns the molecule's term groups
+    and is called once per molecule, on its first conformer (bfgs_mmff.cpp:159,195-201)."""
+    batch_size = hardware_options.batchSize if hardware_options and hardware_options.batchSize > 0 else DEFAULT_BATCH
+    gpu_ids = list(hardware_options.gpuIds) if hardware_options and hardware_options.gpuIds else [torch.cuda.current_device()]
+    device_out = output == CoordinateOutput.DEVICE
+    if device_out:
+        if target_gpu is None or target_gpu < 0:
+            target_gpu = gpu_ids[0]
+        if target_gpu not in gpu_ids:
+            raise ValueError(f"targetGpu {target_gpu} is not in the configured set of execution GPUs; pass it via "
+                             "hardwareOptions.gpuIds first.")
+    systems = [(mi, ci, conf.GetId()) for mi, m in enumerate(molecules) for ci, conf in enumerate(m.GetConformers())]
+    tables = {}
+    results = [[] for _ in molecules]
+    kept = []
+    for b, lo in enumerate(range(0, len(systems), batch_size)):
+        chunk = systems[lo:lo + batch_size]
+        device = torch.device("cuda", gpu_ids[b % len(gpu_ids)])  # batches round-robin over the configured GPUs
+        local, atom_starts, pos, system_mol = {}, [0], [], []
+        for mi, _, cid in chunk:
+            m = molecules[mi]
+            if mi not in tables:
+                tables[mi] = flatten(mi, cid)
+            system_mol.append(local.setdefault(mi, len(local)))
+            atom_starts.append(atom_starts[-1] + m.GetNumAtoms())
+            pos.append(np.asarray(m.GetConformer(cid).GetPositions(), dtype=np.float64).reshape(-1))
+        groups = stack_molecule_tables(kind, [tables[mi] for mi in local])
+        positions = torch.from_numpy(np.concatenate(pos)).to(device)
+        batch = FlatForcefieldBatch(kind, np.array(atom_starts, dtype=np.int32), groups, device=device,
+                                    system_mol=np.array(system_mol, dtype=np.int32))
+        energies, statuses, _ = batch.minimize(positions, max_iters=max_iters, grad_tol=grad_tol, scale_grads=True)
+        if device_out:
+            kept.append((chunk, atom_starts, positions, energies, statuses))
+            continue
+        out, e = positions.cpu().numpy(), energies.cpu().numpy()
+        for s, (mi, _, cid) in enumerate(chunk):
+            conf = molecules[mi].GetConformer(cid)
+            xyz = out[atom_starts[s] * 3:atom_starts[s + 1] * 3].reshape(-1, 3)
+            if hasattr(conf, "SetPositions"):  # RDKit >= 2022.09
+                conf.SetPositions(np.ascontiguousarray(xyz))
+            else:
+                from rdkit.Geometry import Point3D
+
+                for a, (x, y, z) in enumerate(xyz):
+                    conf.SetAtomPosition(a, Point3D(float(x), float(y), float(z)))
+            results[mi].append(float(e[s]))
+    if not device_out:
+        return results
+    # consolidate on the target GPU in input order (detail::finalizeOnTarget, src/conformer/device_coord_collector.cpp)
+    tgt = torch.device("cuda", target_gpu)
+    values = torch.cat([k[2].to(tgt) for k in kept]).view(-1, 3) if kept else torch.zeros((0, 3), dtype=torch.float64, device=tgt)
+    sizes = np.concatenate([np.diff(k[1]) for k in kept]) if kept else np.zeros(0, dtype=np.int64)
+    atom_starts = np.zeros(len(sizes) + 1, dtype=np.int32)
+    atom_starts[1:] = np.cumsum(sizes)
+    mk = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(tgt)  # noqa: E731
+    return Device3DResult(values, mk(atom_starts, np.int32), mk([s[0] for s in systems], np.int32),
+                          mk([s[1] for s in systems], np.int32), target_gpu, len(molecules),
+                          energies=torch.cat([k[3].to(tgt) for k in kept]) if kept else torch.zeros(0, dtype=torch.float64, device=tgt),
+                          converged=torch.cat([(k[4] == 0).to(torch.int8).to(tgt) for k in kept]) if kept else torch.zeros(0, dtype=torch.int8, device=tgt))

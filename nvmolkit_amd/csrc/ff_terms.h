@@ -7,6 +7,8 @@
 //          distance and angle constraints)
 //   MMFF : src/forcefields/mmff_kernels_device.cuh:28-660        (MMFF94 stretch, bend, stretch-bend, Wilson oop,
 //          torsion, buffered 14-7 vdW, buffered Coulomb)
+//   UFF  : src/forcefields/uff_kernels_device.cuh:37-580         (harmonic stretch, cosine-harmonic / Fourier bend
+//          with the near-zero-angle correction, Fourier torsion, inversion, thresholded 12-6)
 //
 // Implementation is this build's own:
 //   * the reference mixes float and double inside a term; here everything is double;
@@ -351,6 +353,96 @@ __device__ __forceinline__ void mmff_ele(const double r, const double chargeTerm
     e     = s * 332.0716 * chargeTerm / rb;
     dE_dr = -e / rb;
   }
+}
+
+// ---- UFF terms (uff_kernels_device.cuh:37-580) --------------------------------------------------
+
+// chain() on a plain double (energy-only instantiation of the templated terms)
+__device__ __forceinline__ double chain(const double, const double f, const double) { return f; }
+
+// harmonic stretch: E(r) and dE/dr
+__device__ __forceinline__ void uff_bond(const double r, const double r0, const double k, double& e, double& dE_dr) {
+  const double dr = r - r0;
+  e               = 0.5 * k * dr * dr;
+  dE_dr           = k * dr;
+}
+
+// Angle bend as a polynomial of c = cos(theta) (sin^2 = 1 - c^2), uff_kernels_device.cuh:78-108:
+//   order 0: k (C0 + C1 cos(theta) + C2 cos(2 theta));  order n = 1..4: k (1 - cos(n theta)) / n^2 with the linear
+//   case written 1 + cos(theta); plus exp(-20 (theta - theta0 + 0.25)) when order is 1..4 and cos(theta) > 0.866
+//   (:167-170).  Orders outside 0..4 give k / order^2 (reference `default:` branch).
+template <typename T>
+__device__ __forceinline__ T uff_angle(const Vec3<T>& p1, const Vec3<T>& p2, const Vec3<T>& p3, const double theta0, const double k,
+                                       const int order, const double C0, const double C1, const double C2) {
+  bool    ok;
+  const T c = cos_angle(p1, p2, p3, ok);
+  if (!ok) return c * 0.0;  // zero-length arm: no energy, no gradient (:157-159, :190-192)
+  const T c2 = c * c;
+  const T s2 = 1.0 - c2;
+  T       e;
+  if (order == 0) {
+    e = k * (C0 + C1 * c + C2 * (c2 - s2));
+  } else {
+    T f;
+    switch (order) {
+      case 1: f = -c; break;
+      case 2: f = c2 - s2; break;
+      case 3: f = c * (c2 - 3.0 * s2); break;
+      case 4: f = c2 * c2 - 6.0 * c2 * s2 + s2 * s2; break;
+      default: f = c * 0.0; break;
+    }
+    e = (k / static_cast<double>(order * order)) * (1.0 - f);
+    if (order < 5 && value(c) > 0.8660) {
+      const T      theta = acos_(c);
+      const double ex    = exp(-20.0 * (value(theta) - theta0 + 0.25));
+      e                  = e + chain(theta - theta0, ex, -20.0 * ex);
+    }
+  }
+  return e;
+}
+// Fourier torsion k/2 (1 - cosTerm cos(n phi)), n in {2, 3, 6}, as a polynomial of c = cos(phi) (:302-326).
+// Other orders: energy 0, no gradient.
+template <typename T> __device__ __forceinline__ T uff_torsion(const T c, const double k, const int order, const double cosTerm) {
+  const T s2 = 1.0 - c * c;
+  T       cn;
+  switch (order) {
+    case 2: cn = 1.0 - 2.0 * s2; break;
+    case 3: cn = c * (c * c - 3.0 * s2); break;
+    case 6: cn = 1.0 + s2 * (-32.0 * s2 * s2 + 48.0 * s2 - 18.0); break;
+    default: return c * 0.0;
+  }
+  return 0.5 * k * (1.0 - cosTerm * cn);
+}
+
+// Inversion, value as `inversion` above.  The GRADIENT keeps a convention of the reference (inherited from RDKit's
+// UFF Inversion contrib): its dE/dW is -k (C1 cosY - 4 C2 cosY sinY) (uff_kernels_device.cuh:497), i.e. the C2 part
+// has the opposite sign of the true derivative of the energy it reports.  Coordinates after minimisation must match
+// that minimiser, so the derivative carried here is k (C1 - 4 C2 sinY) d(sinY) while the value stays
+// k (C0 + C1 sinY + C2 (2 sinY^2 - 1)).  (C2 != 0 only for group-15 centres; C, N, O use C2 = 0.)
+__device__ __forceinline__ double uff_inversion(const Vec3<double>& p1, const Vec3<double>& p2, const Vec3<double>& p3,
+                                                const Vec3<double>& p4, const double k, const double C0, const double C1,
+                                                const double C2) {
+  return inversion(p1, p2, p3, p4, C0, C1, C2, k);
+}
+template <int NP>
+__device__ __forceinline__ Dual<NP> uff_inversion(const Vec3<Dual<NP>>& p1, const Vec3<Dual<NP>>& p2, const Vec3<Dual<NP>>& p3,
+                                                  const Vec3<Dual<NP>>& p4, const double k, const double C0, const double C1,
+                                                  const double C2) {
+  // sinY with its derivative: inversion() with C0 = 0, C1 = 1, C2 = 0, k = 1 IS sinY (or the constant 1 when degenerate)
+  const Dual<NP> sinY = inversion(p1, p2, p3, p4, 0.0, 1.0, 0.0, 1.0);
+  return chain(sinY, k * (C0 + C1 * sinY.v + C2 * (2.0 * sinY.v * sinY.v - 1.0)), k * (C1 - 4.0 * C2 * sinY.v));
+}
+
+// 12-6 with a distance cutoff: E(r), dE/dr; zero beyond `threshold` (:527-580)
+__device__ __forceinline__ void uff_vdw(const double r, const double xij, const double wellDepth, const double threshold, double& e,
+                                        double& dE_dr) {
+  e     = 0.0;
+  dE_dr = 0.0;
+  if (r > threshold || r <= 0.0) return;
+  const double q  = xij / r;
+  const double q2 = q * q, q6 = q2 * q2 * q2, q12 = q6 * q6;
+  e               = wellDepth * (q12 - 2.0 * q6);
+  dE_dr           = 12.0 * wellDepth / xij * (q6 * q - q12 * q);
 }
 
 }  // namespace ff

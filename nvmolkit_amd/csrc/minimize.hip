@@ -46,7 +46,7 @@ struct Batch {
 };
 
 template <int KIND> struct Dim {
-  static constexpr int value = (KIND == NVMK_FF_MMFF) ? 3 : 4;
+  static constexpr int value = (KIND == NVMK_FF_MMFF || KIND == NVMK_FF_UFF) ? 3 : 4;
 };
 
 // ---- block reductions -----------------------------------------------------------------------------
@@ -380,6 +380,104 @@ __device__ double system_eval(const Batch& b, const int sys, const double* pos, 
     }
     return e;
   }
+
+  if constexpr (KIND == NVMK_FF_UFF) {
+    if (on(0)) {  // bond stretch: r0, k
+      const Group& g = b.g[0];
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
+        const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
+        double       d[4];
+        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
+        double       et, dE;
+        uff_bond(r, g.par[2 * t], g.par[2 * t + 1], et, dE);
+        if constexpr (GRAD) {
+          if (r > 0.0) {
+            pair_push<DIM>(grad, i, j, 3, d, dE / r);
+          } else {  // coincident atoms: the reference pushes them apart along (1, 1, 1) with k / 100 (:56-58)
+            const double one[4] = {1.0, 1.0, 1.0, 0.0};
+            pair_push<DIM>(grad, i, j, 3, one, g.par[2 * t + 1] * 0.01);
+          }
+        } else {
+          e += et;
+        }
+      }
+    }
+    if (on(1)) {  // angle bend: theta0, k, order, C0, C1, C2
+      const Group& g = b.g[1];
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
+        const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
+        const double* p    = g.par + 6 * t;
+        const int     ord  = static_cast<int>(p[2]);
+        if constexpr (GRAD) {
+          using D = Dual<9>;
+          scatter<9, DIM, 3>(uff_angle(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                       Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], ord, p[3], p[4], p[5]),
+                             a, grad, 1.0);
+        } else {
+          e += uff_angle(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                         Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], ord, p[3], p[4], p[5]);
+        }
+      }
+    }
+    if (on(2)) {  // torsion: k, order, cosTerm
+      const Group& g = b.g[2];
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
+        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
+        const double* p    = g.par + 3 * t;
+        const int     ord  = static_cast<int>(p[1]);
+        bool          ok;
+        if constexpr (GRAD) {
+          using D   = Dual<12>;
+          const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                   Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
+          if (ok) scatter<12, DIM, 4>(uff_torsion(c, p[0], ord, p[2]), a, grad, 1.0);
+        } else {
+          const double c = cos_dihedral(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                                        Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), ok);
+          e += uff_torsion(ok ? c : 0.0, p[0], ord, p[2]);  // collinear: cos(phi) := 0 (:271-273)
+        }
+      }
+    }
+    if (on(3)) {  // inversion: k, C0, C1, C2
+      const Group& g = b.g[3];
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
+        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
+        const double* p    = g.par + 4 * t;
+        if constexpr (GRAD) {
+          using D = Dual<12>;
+          scatter<12, DIM, 4>(uff_inversion(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                            Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0], p[1],
+                                            p[2], p[3]),
+                              a, grad, 1.0);
+        } else {
+          e += uff_inversion(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                             Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), p[0], p[1], p[2],
+                             p[3]);
+        }
+      }
+    }
+    if (on(4)) {  // van der Waals: x_ij, wellDepth, threshold
+      const Group& g = b.g[4];
+      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
+        const int    i = g.idx[2 * t], j = g.idx[2 * t + 1];
+        double       d[4];
+        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
+        double       et, dE;
+        uff_vdw(r, g.par[3 * t], g.par[3 * t + 1], g.par[3 * t + 2], et, dE);
+        if constexpr (GRAD) {
+          if (r > 0.0) {
+            if (dE != 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / r);
+          } else if (r <= g.par[3 * t + 2]) {  // coincident atoms inside the cutoff: +-100 per component (:552-560)
+            const double one[4] = {1.0, 1.0, 1.0, 0.0};
+            pair_push<DIM>(grad, i, j, 3, one, 100.0);
+          }
+        } else {
+          e += et;
+        }
+      }
+    }
+    return e;
+  }
   return e;
 }
 
@@ -622,10 +720,10 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
 
 int to_batch(const nvmk_ff_batch* in, Batch& out) {
   NVMK_REQUIRE(in != nullptr, "ff: NULL batch");
-  NVMK_REQUIRE(in->kind >= NVMK_FF_DG && in->kind <= NVMK_FF_QUARTIC, "ff: unknown force-field kind %d", in->kind);
+  NVMK_REQUIRE(in->kind >= NVMK_FF_DG && in->kind <= NVMK_FF_UFF, "ff: unknown force-field kind %d", in->kind);
   NVMK_REQUIRE(in->n_systems >= 0, "ff: negative system count");
   NVMK_REQUIRE(in->n_systems == 0 || in->atom_starts != nullptr, "ff: NULL atom_starts");
-  static const int nGroups[4] = {3, 6, 7, 0};
+  static const int nGroups[5] = {3, 6, 7, 0, 5};
   out.kind         = in->kind;
   out.nSystems     = in->n_systems;
   out.atomStarts   = in->atom_starts;
@@ -649,6 +747,7 @@ int to_batch(const nvmk_ff_batch* in, Batch& out) {
     case NVMK_FF_DG: { constexpr int K = NVMK_FF_DG; CALL; break; }           \
     case NVMK_FF_ETK: { constexpr int K = NVMK_FF_ETK; CALL; break; }         \
     case NVMK_FF_MMFF: { constexpr int K = NVMK_FF_MMFF; CALL; break; }       \
+    case NVMK_FF_UFF: { constexpr int K = NVMK_FF_UFF; CALL; break; }         \
     default: { constexpr int K = NVMK_FF_QUARTIC; CALL; break; }              \
   }
 
@@ -696,7 +795,7 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   NVMK_REQUIRE(h_atom_starts && d_pos && d_energies, "bfgs: NULL buffer");
   NVMK_REQUIRE(max_iters >= 0, "bfgs: negative iteration count");
   hipStream_t stream = as_stream(stream_);
-  const int   dim    = (b.kind == NVMK_FF_MMFF) ? 3 : 4;
+  const int   dim    = (b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_UFF) ? 3 : 4;
   // inverse-Hessian offsets (n^2 doubles per system) and the LDS need of the largest system
   std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
   int                  maxN = 0;

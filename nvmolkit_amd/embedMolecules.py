@@ -18,7 +18,7 @@ import torch
 
 from nvmolkit_amd import _native
 from nvmolkit_amd.forcefield import GROUP_LAYOUT, DG, ETK
-from nvmolkit_amd.types import CoordinateOutput, HardwareOptions
+from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
 N_STAGES = _native.ETKDG_N_STAGES
 STAGE_NAMES = ["coordgen", "first minimization", "tetrahedral check", "first chiral check", "fourth dimension minimization",
@@ -111,11 +111,35 @@ class FlatEmbedResult:
         s = int(self.slot_starts[m])
         return self.coords[s:s + 3 * n * k].reshape(k, n, 3)
 
+    def to_device_result(self) -> Device3DResult:
+        """Compact the per-molecule slots into the flat CSR form of :class:`Device3DResult` on the same GPU
+        (reference: DeviceCoordCollector / finalizeOnTarget, src/conformer/device_coord_collector.cpp:30-150)."""
+        dev = self.coords.device
+        counts = self.conf_counts.astype(np.int64)
+        n_atoms = self.n_atoms.astype(np.int64)
+        mol_of_conf = np.repeat(np.arange(len(counts)), counts)
+        conf_of_conf = np.arange(len(mol_of_conf)) - np.repeat(np.cumsum(counts) - counts, counts)
+        sizes = n_atoms[mol_of_conf]
+        atom_starts = np.zeros(len(sizes) + 1, dtype=np.int64)
+        atom_starts[1:] = np.cumsum(sizes)
+        src_row0 = self.slot_starts[mol_of_conf] // 3 + conf_of_conf * sizes  # first source row of every conformer
+        sizes_t = torch.from_numpy(sizes).to(dev)
+        rows = (torch.repeat_interleave(torch.from_numpy(src_row0 - atom_starts[:-1]).to(dev), sizes_t) +
+                torch.arange(int(atom_starts[-1]), device=dev))
+        values = self.coords.view(-1, 3)[rows]
+        i32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(dev)  # noqa: E731
+        return Device3DResult(values, i32(atom_starts), i32(mol_of_conf), i32(conf_of_conf),
+                              dev.index if dev.index is not None else torch.cuda.current_device(), len(counts))
+
 
 def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterations: int = -1, batch_size: int = 500,
                use_exp_torsions: bool = True, use_basic_knowledge: bool = True, enforce_chirality: bool = True,
-               box_size_mult: float = 2.0, force_tol: float = 1e-3, seed: int = 42, stream=None) -> FlatEmbedResult:
-    """ETKDG on flattened molecules (reference pipeline: src/etkdg.cpp:90-484 downstream of RDKit)."""
+               box_size_mult: float = 2.0, force_tol: float = 1e-3, seed: int = 42, stream=None,
+               output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS):
+    """ETKDG on flattened molecules (reference pipeline: src/etkdg.cpp:90-484 downstream of RDKit).
+
+    Returns a :class:`FlatEmbedResult`, or with ``output=CoordinateOutput.DEVICE`` a :class:`Device3DResult` that the
+    MMFF / UFF ``optimize_device`` entry points consume without a host round trip."""
     sptr = _native.stream_ptr(stream)
     if confs_per_molecule <= 0:
         raise ValueError("confsPerMolecule must be greater than 0")
@@ -146,7 +170,8 @@ def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterati
         rc = _native.lib().nvmk_etkdg_embed(ctypes.byref(molset.c), ctypes.byref(prm), coords.data_ptr(), counts.ctypes.data,
                                             fails.ctypes.data, sptr)
     _native.check(rc, "nvmk_etkdg_embed")
-    return FlatEmbedResult(coords, counts, slot_starts[:-1], fails, n_atoms)
+    res = FlatEmbedResult(coords, counts, slot_starts[:-1], fails, n_atoms)
+    return res.to_device_result() if output == CoordinateOutput.DEVICE else res
 
 
 def EmbedMolecules(molecules, params, confsPerMolecule: int = 1, maxIterations: int = -1,

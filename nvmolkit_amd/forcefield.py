@@ -16,29 +16,35 @@ import numpy as np
 import torch
 
 from nvmolkit_amd import _native
+from nvmolkit_amd.types import Device3DResult
 
-DG, ETK, MMFF, QUARTIC = _native.FF_DG, _native.FF_ETK, _native.FF_MMFF, _native.FF_QUARTIC
+DG, ETK, MMFF, QUARTIC, UFF = _native.FF_DG, _native.FF_ETK, _native.FF_MMFF, _native.FF_QUARTIC, _native.FF_UFF
 #: (n_idx, n_par) of every term group, per kind (see include/nvmolkit_amd.h)
 GROUP_LAYOUT = {
     DG: [(2, 3), (4, 2), (1, 0)],
     ETK: [(4, 12), (4, 4), (2, 4), (2, 4), (3, 2), (2, 4)],
     MMFF: [(2, 2), (3, 3), (3, 5), (4, 1), (4, 3), (2, 2), (2, 3)],
     QUARTIC: [],
+    UFF: [(2, 2), (3, 6), (4, 3), (4, 4), (2, 3)],
 }
-DIM = {DG: 4, ETK: 4, MMFF: 3, QUARTIC: 4}
+DIM = {DG: 4, ETK: 4, MMFF: 3, QUARTIC: 4, UFF: 3}
 
 
 class FlatForcefieldBatch:
     """`n_systems` independent systems with their term tables resident on one GPU.
 
     Args:
-        kind: DG, ETK, MMFF or QUARTIC.
+        kind: DG, ETK, MMFF, UFF or QUARTIC.
         atom_starts: (n_systems + 1,) CSR offsets of each system's atoms.
         groups: one ``(starts, idx, par)`` triple per term group of the kind — ``starts`` (n_systems + 1,),
             ``idx`` (n_terms, n_idx) LOCAL atom indices, ``par`` (n_terms, n_par) float64.
+        system_mol: optional (n_systems,) int32 (host array or tensor on ``device``).  When given, the term tables are
+            stored once per MOLECULE (``starts`` has n_mols + 1 entries) and system s uses row ``system_mol[s]``: the
+            conformers of one molecule share their tables (the reference flattens once per unique molecule and
+            copies, src/minimizer/bfgs_mmff.cpp:159,195-201).
     """
 
-    def __init__(self, kind: int, atom_starts, groups: Sequence[tuple], device="cuda"):
+    def __init__(self, kind: int, atom_starts, groups: Sequence[tuple], device="cuda", system_mol=None):
         if kind not in GROUP_LAYOUT:
             raise ValueError(f"unknown force-field kind {kind}")
         layout = GROUP_LAYOUT[kind]
@@ -56,11 +62,22 @@ class FlatForcefieldBatch:
         self._c.kind = kind
         self._c.n_systems = self.n_systems
         self._c.atom_starts = self._keep[0].data_ptr()
+        n_rows = self.n_systems
+        if system_mol is not None:
+            sm = system_mol if isinstance(system_mol, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(system_mol, dtype=np.int32))
+            sm = sm.to(device=self.device, dtype=torch.int32).contiguous()
+            if sm.numel() != self.n_systems:
+                raise ValueError("system_mol must have one entry per system")
+            self._keep.append(sm)
+            self._c.system_mol = sm.data_ptr()
+            n_rows = None  # validated against the tables below
         for g, ((n_idx, n_par), (starts, idx, par)) in enumerate(zip(layout, groups)):
             starts = np.ascontiguousarray(starts, dtype=np.int32)
             idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, n_idx)
             par = (np.ascontiguousarray(par, dtype=np.float64).reshape(-1, n_par) if n_par else np.zeros((len(idx), 0)))
-            if len(starts) != self.n_systems + 1 or (len(starts) and starts[-1] != len(idx)) or len(par) != len(idx):
+            if n_rows is None:
+                n_rows = len(starts) - 1
+            if len(starts) != n_rows + 1 or (len(starts) and starts[-1] != len(idx)) or len(par) != len(idx):
                 raise ValueError(f"term group {g}: inconsistent starts / idx / par sizes")
             t = [torch.from_numpy(starts).to(self.device), torch.from_numpy(idx.copy()).to(self.device),
                  torch.from_numpy(np.ascontiguousarray(par)).to(self.device)]
@@ -126,3 +143,46 @@ class FlatForcefieldBatch:
                                               statuses.data_ptr(), iters.data_ptr(), _native.stream_ptr(stream))
         _native.check(rc, "nvmk_bfgs_minimize")
         return energies, statuses, iters
+
+
+def stack_molecule_tables(kind: int, tables: Sequence[Sequence[tuple]]):
+    """Per-molecule term tables ``tables[m][g] = (idx, par)`` -> the ``(starts, idx, par)`` groups of a batch whose
+    rows are MOLECULES (to be used with ``system_mol``)."""
+    layout = GROUP_LAYOUT[kind]
+    groups = []
+    for g, (n_idx, n_par) in enumerate(layout):
+        starts = np.zeros(len(tables) + 1, dtype=np.int32)
+        for m, t in enumerate(tables):
+            if len(t) != len(layout):
+                raise ValueError(f"molecule {m}: kind {kind} needs {len(layout)} term groups, got {len(t)}")
+            starts[m + 1] = starts[m] + len(t[g][0])
+        idx = (np.concatenate([np.asarray(t[g][0], dtype=np.int32).reshape(-1, n_idx) for t in tables])
+               if tables else np.zeros((0, n_idx), dtype=np.int32))
+        par = (np.concatenate([np.asarray(t[g][1], dtype=np.float64).reshape(-1, n_par) for t in tables])
+               if tables else np.zeros((0, n_par)))
+        groups.append((starts, idx, par))
+    return groups
+
+
+def minimize_device_conformers(kind: int, tables, conformers: Device3DResult, max_iters: int, grad_tol: float = 1e-4,
+                               stream=None) -> Device3DResult:
+    """BFGS-minimise every conformer of a :class:`Device3DResult` without leaving the GPU.
+
+    The counterpart of the reference's ``deviceInput`` path (src/minimizer/bfgs_mmff.cpp:41-328 with
+    ``detail::broadcastDeviceInputBatch``; nvmolkit/types.py:197-319): coordinates produced by ETKDG are consumed
+    where they are, the term tables are stored once per molecule and shared by its conformers, and the result is a
+    new ``Device3DResult`` carrying ``energies`` and ``converged``.  The input result is left untouched."""
+    if kind not in (MMFF, UFF):
+        raise ValueError("minimize_device_conformers supports the MMFF and UFF kinds")
+    if len(tables) != conformers.n_mols:
+        raise ValueError(f"expected term tables for {conformers.n_mols} molecules, got {len(tables)}")
+    values = conformers.values.torch()
+    device = values.device
+    atom_starts = conformers.atom_starts.torch()
+    mols = conformers.mol_indices.torch().to(torch.int32)
+    batch = FlatForcefieldBatch(kind, atom_starts.cpu().numpy(), stack_molecule_tables(kind, tables), device=device,
+                                system_mol=mols)
+    pos = values.reshape(-1).clone()
+    energies, statuses, _ = batch.minimize(pos, max_iters=max_iters, grad_tol=grad_tol, scale_grads=True, stream=stream)
+    return Device3DResult(pos.view(-1, 3), atom_starts, conformers.mol_indices, conformers.conf_indices,
+                          conformers.gpu_id, conformers.n_mols, energies=energies, converged=(statuses == 0).to(torch.int8))

@@ -14,8 +14,8 @@ from typing import Sequence
 import numpy as np
 import torch
 
-from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch
-from nvmolkit_amd.types import CoordinateOutput, HardwareOptions
+from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch, minimize_device_conformers
+from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
 _LINEAR_MMFF_TYPES = frozenset({4, 53, 61})  # MMFFPROP.PAR rows with linh = 1 (CSP, =N=, NR%)
 _TORSION_BOND_SMARTS = "[!$([D1]);!$([#1])]~[!$([D1]);!$([#1])]"  # RDKit DefaultTorsionBondSmarts
@@ -25,11 +25,19 @@ def optimize_flat(atom_starts, groups, positions: torch.Tensor, max_iters: int =
                   system_mol=None):
     """Minimise flattened MMFF systems in place; returns (energies, converged) tensors.
 
-    ``groups`` are the 7 MMFF term groups (include/nvmolkit_amd.h).  gradTol 1e-4 is fixed on the reference's path
+    ``groups`` are the 7 MMFF term groups (include/nvmolkit_amd.h); with ``system_mol`` their rows are molecules and
+    conformer s uses row ``system_mol[s]``.  gradTol 1e-4 is fixed on the reference's path
     (src/minimizer/bfgs_mmff.cpp:327)."""
-    batch = FlatForcefieldBatch(MMFF, atom_starts, groups, device=positions.device)
+    batch = FlatForcefieldBatch(MMFF, atom_starts, groups, device=positions.device, system_mol=system_mol)
     energies, statuses, _ = batch.minimize(positions, max_iters=max_iters, grad_tol=grad_tol, scale_grads=True)
     return energies, statuses == 0
+
+
+def optimize_device(tables, conformers: Device3DResult, max_iters: int = 200, grad_tol: float = 1e-4) -> Device3DResult:
+    """MMFF-minimise the conformers of a :class:`Device3DResult` (e.g. ``embed_flat(..., output=DEVICE)``) on the GPU
+    they live on; ``tables[m]`` are the 7 MMFF term groups ``(idx, par)`` of input molecule m.  DEVICE in, DEVICE out
+    (reference: MMFFOptimizeMoleculesConfs(..., output=DEVICE) fed by a ``deviceInput``)."""
+    return minimize_device_conformers(MMFF, tables, conformers, max_iters, grad_tol)
 
 
 def flatten_mmff_from_rdkit(mol, props, conf_id: int = -1, non_bonded_threshold: float = 100.0,
@@ -122,9 +130,10 @@ def MMFFOptimizeMoleculesConfs(molecules, maxIters: int = 200, properties=None, 
                                output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, targetGpu: int = -1):
     """Optimise every conformer of every molecule with MMFF94 + BFGS on the GPU.
 
-    Same contract as the reference (nvmolkit/mmffOptimization.py:60-201): conformers are updated in place and a
-    list of per-conformer energies per molecule is returned; ``ValueError(message, {"none": [...], "no_params":
-    [...]})`` for ``None`` entries or molecules without MMFF parameters."""
+    Same contract as the reference (nvmolkit/mmffOptimization.py:60-201): ``RDKIT_CONFORMERS`` updates the conformers
+    in place and returns a list of per-conformer energies per molecule, ``DEVICE`` returns a :class:`Device3DResult`;
+    ``ValueError(message, {"none": [...], "no_params": [...]})`` for ``None`` entries or molecules without MMFF
+    parameters."""
     if not molecules:
         if output == CoordinateOutput.DEVICE:
             raise ValueError("MMFFOptimizeMoleculesConfs(output=DEVICE) requires at least one molecule")
@@ -154,38 +163,9 @@ def MMFFOptimizeMoleculesConfs(molecules, maxIters: int = 200, properties=None, 
     props = [p if p is not None else ffh.MMFFGetMoleculeProperties(m) for m, p in zip(molecules, per_mol(properties, "properties"))]
     thresholds = per_mol(nonBondedThreshold, "nonBondedThreshold")
     interfrag = per_mol(ignoreInterfragInteractions, "ignoreInterfragInteractions")
-    if output == CoordinateOutput.DEVICE:
-        raise NotImplementedError("DEVICE output (Device3DResult) is not built yet; see DESIGN.md 'next'")
-    batch_size = hardwareOptions.batchSize if hardwareOptions and hardwareOptions.batchSize > 0 else 500
-    systems = [(mi, conf.GetId()) for mi, m in enumerate(molecules) for conf in m.GetConformers()]
-    flat = {}
-    results = [[] for _ in molecules]
-    for lo in range(0, len(systems), batch_size):  # batches of 500 conformers (src/minimizer/bfgs_mmff.cpp:139-157)
-        chunk = systems[lo:lo + batch_size]
-        atom_starts, pos, groups_by_sys = [0], [], []
-        for mi, cid in chunk:
-            m = molecules[mi]
-            if mi not in flat:  # flattened once per unique molecule, on its first conformer (bfgs_mmff.cpp:159,195-201)
-                flat[mi] = flatten_mmff_from_rdkit(m, props[mi], cid, float(thresholds[mi]), bool(interfrag[mi]))
-            groups_by_sys.append(flat[mi])
-            atom_starts.append(atom_starts[-1] + m.GetNumAtoms())
-            pos.append(np.asarray(m.GetConformer(cid).GetPositions(), dtype=np.float64).reshape(-1))
-        groups = []
-        for g in range(7):
-            starts = np.zeros(len(chunk) + 1, dtype=np.int32)
-            for s, gs in enumerate(groups_by_sys):
-                starts[s + 1] = starts[s] + len(gs[g][0])
-            groups.append((starts, np.concatenate([gs[g][0] for gs in groups_by_sys]),
-                           np.concatenate([gs[g][1] for gs in groups_by_sys])))
-        positions = torch.from_numpy(np.concatenate(pos)).cuda()
-        energies, _ = optimize_flat(np.array(atom_starts, dtype=np.int32), groups, positions, max_iters=maxIters)
-        out = positions.cpu().numpy()
-        from rdkit.Geometry import Point3D
+    from nvmolkit_amd._rdkit_confs import optimize_rdkit_conformers
 
-        for s, (mi, cid) in enumerate(chunk):
-            xyz = out[atom_starts[s] * 3:atom_starts[s + 1] * 3].reshape(-1, 3)
-            conf = molecules[mi].GetConformer(cid)
-            for a, (x, y, z) in enumerate(xyz):
-                conf.SetAtomPosition(a, Point3D(float(x), float(y), float(z)))
-            results[mi].append(float(energies[s]))
-    return results
+    return optimize_rdkit_conformers(
+        MMFF, molecules,
+        lambda mi, cid: flatten_mmff_from_rdkit(molecules[mi], props[mi], cid, float(thresholds[mi]), bool(interfrag[mi])),
+        int(maxIters), 1e-4, hardwareOptions, output, targetGpu)

@@ -3,7 +3,7 @@
 from __future__ import annotations
 
 from enum import Enum
-from typing import Any, Iterable, List, Optional
+from typing import Any, Iterable, List, NamedTuple, Optional
 
 import torch
 
@@ -117,3 +117,82 @@ class CoordinateOutput(Enum):
 
     RDKIT_CONFORMERS = "rdkit"
     DEVICE = "device"
+
+
+class Dense3DResult(NamedTuple):
+    """Padded dense view of a :class:`Device3DResult` (reference: nvmolkit/types.py:180-194).
+
+    ``values`` (n_mols, max_confs, max_atoms, 3) float64 with ``pad_value`` in the padding, ``conf_mask``
+    (n_mols, max_confs) and ``atom_mask`` (n_mols, max_confs, max_atoms), True where the data is real."""
+
+    values: torch.Tensor
+    conf_mask: torch.Tensor
+    atom_mask: torch.Tensor
+
+
+class Device3DResult:
+    """Flat, GPU-resident conformer coordinates (+ energies / convergence after a minimisation).
+
+    Same fields and meaning as the reference's ``Device3DResult`` (nvmolkit/types.py:197-246) over
+    ``DeviceCoordResult`` (src/conformer/device_coord_result.h:58-67): conformer ``i`` owns rows
+    ``values[atom_starts[i]:atom_starts[i+1]]`` of the (total_atoms, 3) float64 ``values``; ``mol_indices[i]`` is its
+    input molecule and ``conf_indices[i]`` its index within that molecule; ``n_mols`` counts the input molecules,
+    including those without conformers.  All buffers live on GPU ``gpu_id`` and are wrapped as
+    :class:`AsyncGpuResult`; synchronise before reading them on the host.
+    """
+
+    def __init__(self, values, atom_starts, mol_indices, conf_indices, gpu_id: int, n_mols: int, energies=None,
+                 converged=None) -> None:
+        wrap = lambda x: x if (x is None or isinstance(x, AsyncGpuResult)) else AsyncGpuResult(x)  # noqa: E731
+        self.values = wrap(values)
+        self.atom_starts = wrap(atom_starts)
+        self.mol_indices = wrap(mol_indices)
+        self.conf_indices = wrap(conf_indices)
+        self.energies = wrap(energies)
+        self.converged = wrap(converged)
+        self.gpu_id = int(gpu_id)
+        self.n_mols = int(n_mols)
+        n_conf = self.mol_indices.torch().numel()
+        if self.atom_starts.torch().numel() != n_conf + 1 or self.conf_indices.torch().numel() != n_conf:
+            raise ValueError("atom_starts / mol_indices / conf_indices sizes are inconsistent")
+
+    @property
+    def num_conformers(self) -> int:
+        return int(self.atom_starts.torch().numel()) - 1
+
+    def per_molecule(self) -> List[List[torch.Tensor]]:
+        """``result[m][k]``: (n_atoms, 3) view (no copy) of the k-th conformer of input molecule m; molecules without
+        conformers get an empty list.  Reading the index tensors synchronises."""
+        values = self.values.torch()
+        bounds = self.atom_starts.torch().tolist()
+        out: List[List[torch.Tensor]] = [[] for _ in range(self.n_mols)]
+        for c, m in enumerate(self.mol_indices.torch().tolist()):
+            out[m].append(values[bounds[c]:bounds[c + 1]])
+        return out
+
+    def dense(self, pad_value: float = float("nan")) -> Dense3DResult:
+        """Scatter into a padded (n_mols, max_confs, max_atoms, 3) tensor; masks mark the real entries."""
+        values = self.values.torch()
+        dev = values.device
+        starts = self.atom_starts.torch().to(torch.int64)
+        mols = self.mol_indices.torch().to(torch.int64)
+        confs = self.conf_indices.torch().to(torch.int64)
+        if mols.numel() == 0:
+            return Dense3DResult(torch.full((self.n_mols, 0, 0, 3), pad_value, dtype=values.dtype, device=dev),
+                                 torch.zeros((self.n_mols, 0), dtype=torch.bool, device=dev),
+                                 torch.zeros((self.n_mols, 0, 0), dtype=torch.bool, device=dev))
+        n_atoms = starts[1:] - starts[:-1]
+        max_confs = int(confs.max().item()) + 1
+        max_atoms = int(n_atoms.max().item())
+        # flat slot of every atom row in the (n_mols * max_confs * max_atoms) grid
+        conf_of_row = torch.repeat_interleave(torch.arange(mols.numel(), device=dev), n_atoms)
+        atom_of_row = torch.arange(values.shape[0], device=dev) - starts[conf_of_row]
+        slot = (mols[conf_of_row] * max_confs + confs[conf_of_row]) * max_atoms + atom_of_row
+        dense = torch.full((self.n_mols * max_confs * max_atoms, 3), pad_value, dtype=values.dtype, device=dev)
+        dense[slot] = values
+        atom_mask = torch.zeros(self.n_mols * max_confs * max_atoms, dtype=torch.bool, device=dev)
+        atom_mask[slot] = True
+        conf_mask = torch.zeros(self.n_mols * max_confs, dtype=torch.bool, device=dev)
+        conf_mask[mols * max_confs + confs] = True
+        return Dense3DResult(dense.view(self.n_mols, max_confs, max_atoms, 3), conf_mask.view(self.n_mols, max_confs),
+                             atom_mask.view(self.n_mols, max_confs, max_atoms))

@@ -9,6 +9,9 @@ needed to produce real term lists; neither the build nor the GPU image has RDKit
     relative), with the two RDKit conventions where the "gradient" is half the derivative (chiral volume,
     fourth dimension) applied explicitly;
   * closed-form values of single terms (zero inside bounds, known geometry) in tests/test_oracle_ff.py;
+  * UFF: every angle order, torsion periodicity and the vdW cutoff in closed form; the reference's analytic inversion
+    gradient restated (uff_inversion_gradient_reference) and shown to equal the finite difference of the energy with
+    the C2 part negated, which is the convention system_gradient(UFF) applies;
   * BFGS: the reference's RDKit-free quartic test (tests/test_bfgs_minimizer.cu:823-1029, converge to x_p = p).
 """
 
@@ -21,14 +24,15 @@ DEG2RAD = np.pi / 180.0
 MDYNE_A_TO_KCAL = 143.9325
 
 # group layouts (n_idx, n_par) per force-field kind — must match include/nvmolkit_amd.h
-DG, ETK, MMFF, QUARTIC = 0, 1, 2, 3
+DG, ETK, MMFF, QUARTIC, UFF = 0, 1, 2, 3, 4
 LAYOUT = {
     DG: [(2, 3), (4, 2), (1, 0)],
     ETK: [(4, 12), (4, 4), (2, 4), (2, 4), (3, 2), (2, 4)],
     MMFF: [(2, 2), (3, 3), (3, 5), (4, 1), (4, 3), (2, 2), (2, 3)],
     QUARTIC: [],
+    UFF: [(2, 2), (3, 6), (4, 3), (4, 4), (2, 3)],
 }
-DIM = {DG: 4, ETK: 4, MMFF: 3, QUARTIC: 4}
+DIM = {DG: 4, ETK: 4, MMFF: 3, QUARTIC: 4, UFF: 3}
 
 
 def _xyz(pos, idx):
@@ -155,6 +159,83 @@ def mmff_terms(pos, groups):
     return out
 
 
+# ---- UFF (src/forcefields/uff_kernels_device.cuh:37-580) ---------------------------------------------
+
+def _uff_sin_y(p1, p2, p3, p4):
+    """sinY of the inversion term (uffCalculateCosY :391-424 + :437-438); degenerate geometry -> cosY = 0."""
+    rji, rjk, rjl = p1 - p2, p3 - p2, p4 - p2
+    li, lk, ll = (rji * rji).sum(1), (rjk * rjk).sum(1), (rjl * rjl).sum(1)
+    n = np.cross(rji, rjk)
+    ln = (n * n).sum(1)
+    ok = (li >= 1e-16) & (lk >= 1e-16) & (ll >= 1e-16) & (ln >= 1e-16 * li * lk)
+    cos_y = np.zeros(len(p1))
+    cos_y[ok] = np.clip((n[ok] * rjl[ok]).sum(1) / np.sqrt(ln[ok] * ll[ok]), -1.0, 1.0)
+    return np.sqrt(np.maximum(1.0 - cos_y * cos_y, 0.0))
+
+
+def uff_terms(pos, groups, gradient_convention: bool = False):
+    """Per-group energies.  gradient_convention=True flips the sign of the inversion C2 part: the finite difference
+    of THAT function is what the reference's analytic inversion gradient computes (its dE/dW,
+    uff_kernels_device.cuh:497, has the C2 part with the opposite sign of the derivative of its own energy;
+    `uff_inversion_gradient_reference` below restates the formula and tests/test_oracle_ff.py checks the claim)."""
+    out = []
+    idx, par = groups[0]
+    r = np.sqrt(((pos[idx[:, 0]] - pos[idx[:, 1]]) ** 2).sum(1))
+    out.append(0.5 * par[:, 1] * (r - par[:, 0]) ** 2)                                           # :37-45
+    idx, par = groups[1]
+    c, ok = _cos_angle(*(pos[idx[:, k]] for k in range(3)))
+    s2 = 1.0 - c * c
+    theta0, k, order = par[:, 0], par[:, 1], par[:, 2].astype(np.int64)
+    c2t = c * c - s2
+    f = np.select([order == 1, order == 2, order == 3, order == 4],
+                  [-c, c2t, c * (c * c - 3.0 * s2), c**4 - 6.0 * c * c * s2 + s2 * s2], default=0.0)
+    e = np.where(order == 0, par[:, 3] + par[:, 4] * c + par[:, 5] * c2t, (1.0 - f) / np.maximum(order, 1) ** 2) * k  # :78-108
+    corr = (order > 0) & (order < 5) & (c > 0.8660)                                               # :167-170
+    e = e + np.where(corr, np.exp(-20.0 * (np.arccos(c) - theta0 + 0.25)), 0.0)
+    out.append(np.where(ok, e, 0.0))
+    idx, par = groups[2]
+    c, _ = _cos_dihedral(*(pos[idx[:, k]] for k in range(4)))
+    s2 = 1.0 - c * c
+    order = par[:, 1].astype(np.int64)
+    cn = np.select([order == 2, order == 3, order == 6],
+                   [1.0 - 2.0 * s2, c * (c * c - 3.0 * s2), 1.0 + s2 * (-32.0 * s2 * s2 + 48.0 * s2 - 18.0)], default=np.nan)
+    out.append(np.where(np.isnan(cn), 0.0, 0.5 * par[:, 0] * (1.0 - par[:, 2] * np.nan_to_num(cn))))  # :302-326
+    idx, par = groups[3]
+    sin_y = _uff_sin_y(*(pos[idx[:, k]] for k in range(4)))
+    c2sign = -1.0 if gradient_convention else 1.0
+    out.append(par[:, 0] * (par[:, 1] + par[:, 2] * sin_y + c2sign * par[:, 3] * (2.0 * sin_y * sin_y - 1.0)))  # :426-440
+    idx, par = groups[4]
+    r = np.sqrt(((pos[idx[:, 0]] - pos[idx[:, 1]]) ** 2).sum(1))
+    inside = (r <= par[:, 2]) & (r > 0.0)
+    q6 = (par[:, 0] / np.where(inside, r, 1.0)) ** 6
+    out.append(np.where(inside, par[:, 1] * (q6 * q6 - 2.0 * q6), 0.0))                           # :527-540
+    return out
+
+
+def uff_inversion_gradient_reference(pos, idx, par):
+    """The reference's analytic inversion gradient, restated term by term (uff_kernels_device.cuh:442-525), for ONE
+    term: idx (4,), par (k, C0, C1, C2).  Returns (4, 3)."""
+    p1, p2, p3, p4 = (pos[i][:3] for i in idx)
+    k, _, c1, c2 = par
+    rji, rjk, rjl = p1 - p2, p3 - p2, p4 - p2
+    dji, djk, djl = (np.linalg.norm(v) for v in (rji, rjk, rjl))
+    rji, rjk, rjl = rji / dji, rjk / djk, rjl / djl
+    n = np.cross(-rji, rjk)
+    n = n / np.linalg.norm(n)
+    cos_y = float(np.clip(n.dot(rjl), -1.0, 1.0))
+    sin_y = max(np.sqrt(1.0 - cos_y * cos_y), 1e-8)
+    cos_t = float(np.clip(rji.dot(rjk), -1.0, 1.0))
+    sin_t_sq = 1.0 - cos_t * cos_t
+    sin_t = max(np.sqrt(sin_t_sq), 1e-8)
+    de_dw = -k * (c1 * cos_y - 4.0 * c2 * cos_y * sin_y)
+    t1, t2, t3 = np.cross(rjl, rjk), np.cross(rji, rjl), np.cross(rjk, rji)
+    term1, term2 = sin_y * sin_t, cos_y / (sin_y * sin_t_sq)
+    tg1 = (t1 / term1 - (rji - rjk * cos_t) * term2) / dji
+    tg3 = (t2 / term1 - (rjk - rji * cos_t) * term2) / djk
+    tg4 = (t3 / term1 - rjl * cos_y / sin_y) / djl
+    return np.array([de_dw * tg1, -de_dw * (tg1 + tg3 + tg4), de_dw * tg3, de_dw * tg4])
+
+
 def system_energy(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: float = 1.0, coord_start: int = 0,
                   per_group: bool = False):
     """Energy of one system.  pos: (n_atoms, DIM[kind]); groups: list of (idx (n, n_idx) int, par (n, n_par))."""
@@ -165,7 +246,7 @@ def system_energy(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: float
             diff = diff[:, :3]
         return float((diff**4).sum())
     parts = {DG: lambda: dg_terms(pos, groups, w0, w1), ETK: lambda: etk_terms(pos, groups),
-             MMFF: lambda: mmff_terms(pos, groups)}[kind]()
+             MMFF: lambda: mmff_terms(pos, groups), UFF: lambda: uff_terms(pos, groups)}[kind]()
     if per_group:
         return [float(p.sum()) for p in parts]
     return float(sum(p.sum() for p in parts))
@@ -174,7 +255,8 @@ def system_energy(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: float
 def system_gradient(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: float = 1.0, coord_start: int = 0,
                     h: float = 1e-5) -> np.ndarray:
     """Central finite differences of system_energy, with RDKit's half-gradient convention for the chiral and
-    fourth-dimension terms of the DG field (dist_geom_kernels_device.cuh:172-176, :229)."""
+    fourth-dimension terms of the DG field (dist_geom_kernels_device.cuh:172-176, :229) and the reference's sign
+    convention for the C2 part of the UFF inversion gradient (uff_kernels_device.cuh:497)."""
     def fd(energy_fn):
         g = np.zeros_like(pos)
         for a in range(pos.shape[0]):
@@ -186,6 +268,8 @@ def system_gradient(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: flo
                 g[a, c] = (ep - energy_fn(p)) / (2 * h)
         return g
 
+    if kind == UFF:  # the inversion gradient follows the reference's sign convention for its C2 part (see uff_terms)
+        return fd(lambda p: float(sum(t.sum() for t in uff_terms(p, groups, gradient_convention=True))))
     if kind != DG:
         return fd(lambda p: system_energy(kind, p, groups, w0, w1, coord_start))
     empty = [(np.zeros((0, n), dtype=np.int64), np.zeros((0, m))) for n, m in LAYOUT[DG]]

@@ -47,6 +47,71 @@ def test_mmff_terms_closed_form():
     assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(0.75 * 332.0716 * 0.25 / 1.55)
 
 
+def test_uff_terms_closed_form():
+    """Hand-computable UFF values (functional forms of reference src/forcefields/uff_kernels_device.cuh:37-580)."""
+    pos = np.array([[0.0, 0, 0], [1.5, 0, 0], [1.5, 1.2, 0], [1.5, 1.2, 1.0]])
+    empty = lambda n, m: (np.zeros((0, n), int), np.zeros((0, m)))  # noqa: E731
+    groups = [empty(n, m) for n, m in ff.LAYOUT[ff.UFF]]
+    g = list(groups)
+    g[0] = (np.array([[0, 1]]), np.array([[1.3, 700.0]]))
+    assert ff.system_energy(ff.UFF, pos, g) == pytest.approx(0.5 * 700.0 * 0.2**2)
+    # right angle 0-1-2: cos = 0, cos 2t = -1, cos 3t = 0, cos 4t = 1
+    for order, want in [(0, 100.0 * (0.3 + 0.0 - 0.2)), (1, 100.0 * 1.0), (2, 100.0 * 2.0 / 4.0), (3, 100.0 / 9.0), (4, 0.0)]:
+        g = list(groups)
+        g[1] = (np.array([[0, 1, 2]]), np.array([[1.9, 100.0, order, 0.3, 0.5, 0.2]]))
+        assert ff.system_energy(ff.UFF, pos, g) == pytest.approx(want, abs=1e-12)
+    # 20 degree angle (cos > 0.866) with order 2: base term + exp(-20 (theta - theta0 + 0.25))
+    th = np.deg2rad(20.0)
+    p20 = np.array([[np.cos(th), np.sin(th), 0.0], [0, 0, 0], [1.0, 0, 0]])
+    g = list(groups)
+    g[1] = (np.array([[0, 1, 2]]), np.array([[0.5, 80.0, 2, 0, 0, 0]]))
+    assert ff.system_energy(ff.UFF, p20, g) == pytest.approx(80.0 * (1 - np.cos(2 * th)) / 4 + np.exp(-20 * (th - 0.5 + 0.25)))
+    g[1] = (np.array([[0, 1, 2]]), np.array([[0.5, 80.0, 0, 1.0, 2.0, 3.0]]))  # order 0 never gets the correction
+    assert ff.system_energy(ff.UFF, p20, g) == pytest.approx(80.0 * (1 + 2 * np.cos(th) + 3 * np.cos(2 * th)))
+    # dihedral 0-1-2-3 is 90 degrees: cos 2p = -1, cos 3p = 0, cos 6p = -1
+    for order, cosn in [(2, -1.0), (3, 0.0), (6, -1.0), (4, None)]:
+        g = list(groups)
+        g[2] = (np.array([[0, 1, 2, 3]]), np.array([[7.0, order, -1.0]]))
+        assert ff.system_energy(ff.UFF, pos, g) == pytest.approx(0.0 if cosn is None else 3.5 * (1 + cosn), abs=1e-12)
+    # inversion: apex 3 perpendicular to the plane (0, 1, 2) about centre... use centre 2 with arms 1, 3 and apex 0
+    pinv = np.array([[0.0, 0, 0], [1.0, 0, 0], [0, 1.0, 0], [0.3, 0.3, 0.0]])   # planar: cosY = 0, sinY = 1
+    g = list(groups)
+    g[3] = (np.array([[1, 0, 2, 3]]), np.array([[6.0, 1.0, -1.0, 0.0]]))
+    assert ff.system_energy(ff.UFF, pinv, g) == pytest.approx(0.0, abs=1e-12)     # sp2 centre in its plane
+    g[3] = (np.array([[1, 0, 2, 3]]), np.array([[6.0, 0.2, 0.3, 0.4]]))
+    assert ff.system_energy(ff.UFF, pinv, g) == pytest.approx(6.0 * (0.2 + 0.3 + 0.4))
+    # 12-6: minimum -D at r = x_ij, zero beyond the threshold
+    g = list(groups)
+    g[4] = (np.array([[0, 1]]), np.array([[1.5, 0.2, 10.0]]))
+    assert ff.system_energy(ff.UFF, pos, g) == pytest.approx(-0.2)
+    g[4] = (np.array([[0, 1]]), np.array([[1.5, 0.2, 1.4]]))
+    assert ff.system_energy(ff.UFF, pos, g) == 0.0
+
+
+def test_uff_inversion_gradient_convention_matches_reference_formula():
+    """The reference's analytic inversion gradient (restated in oracle/ff.py) equals the finite difference of the
+    energy with the C2 part NEGATED, and differs from the derivative of the reported energy when C2 != 0."""
+    rng = np.random.default_rng(3)
+    empty = lambda n, m: (np.zeros((0, n), int), np.zeros((0, m)))  # noqa: E731
+    for c0, c1, c2 in [(1.0, -1.0, 0.0), (0.3, -0.7, 1.0), (0.0, 0.0, 1.0)]:
+        pos = rng.normal(size=(4, 3))
+        idx, par = np.array([0, 1, 2, 3]), np.array([2.5, c0, c1, c2])
+        groups = [empty(n, m) for n, m in ff.LAYOUT[ff.UFF]]
+        groups[3] = (idx[None, :], par[None, :])
+        analytic = ff.uff_inversion_gradient_reference(pos, idx, par)
+        conv = ff.system_gradient(ff.UFF, pos, groups, h=1e-6)
+        assert np.allclose(analytic, conv, rtol=1e-6, atol=1e-7)
+        true = np.zeros_like(pos)
+        for a in range(4):
+            for c in range(3):
+                q = pos.copy()
+                q[a, c] += 1e-6
+                ep = ff.system_energy(ff.UFF, q, groups)
+                q[a, c] -= 2e-6
+                true[a, c] = (ep - ff.system_energy(ff.UFF, q, groups)) / 2e-6
+        assert np.allclose(analytic, true, rtol=1e-5, atol=1e-6) == (c2 == 0.0)
+
+
 def test_etk_terms_closed_form():
     pos = np.zeros((4, 4))
     pos[:, :3] = [[0, 0, 0], [1.5, 0, 0], [1.5, 1.2, 0], [1.5, 1.2, 1.0]]    # dihedral 90 deg -> cos = 0
@@ -67,7 +132,7 @@ def test_etk_terms_closed_form():
     assert ff.system_energy(ff.ETK, pos, g) == pytest.approx(10.0**2)
 
 
-@pytest.mark.parametrize("kind", [ff.DG, ff.ETK, ff.MMFF])
+@pytest.mark.parametrize("kind", [ff.DG, ff.ETK, ff.MMFF, ff.UFF])
 def test_finite_difference_gradient_is_self_consistent(kind):
     rng = np.random.default_rng(kind)
     pos, groups = util.random_ff_system(kind, 9, rng)

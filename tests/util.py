@@ -237,6 +237,28 @@ def random_ff_system(kind: int, n_atoms: int, rng):
         return pos, [(chain4, tors_par), (imp, imp_par), (chain2, flat_bottom(chain2, 100.0)), (d13, flat_bottom(d13, 100.0)),
                      (chain3, np.stack([ang_lo, ang_lo + rng.uniform(0, 40, size=len(chain3))], 1) if len(chain3) else np.zeros((0, 2))),
                      (far, flat_bottom(far, 10.0))]
+    if kind == off.UFF:
+        # UFF (reference src/forcefields/uff.h:27-67): every angle order 0..4, torsion orders 2 / 3 / 6, inversions with
+        # C2 = 0 (C, N, O centres) and C2 != 0 (group-15 centres), vdW cutoffs that exclude some of the pairs
+        bond_par = np.stack([rng.uniform(1.0, 1.6, len(chain2)), rng.uniform(300.0, 900.0, len(chain2))], 1) if len(chain2) else np.zeros((0, 2))
+        order = rng.integers(0, 5, size=len(chain3)).astype(float)
+        th0 = np.deg2rad(rng.uniform(95, 125, len(chain3)))
+        s0, c0 = np.sin(th0), np.cos(th0)
+        c2 = 1.0 / (4.0 * np.maximum(s0 * s0, 1e-8))
+        ang_par = np.stack([th0, rng.uniform(50.0, 200.0, len(chain3)), order, c2 * (2.0 * c0 * c0 + 1.0), -4.0 * c2 * c0, c2], 1) \
+            if len(chain3) else np.zeros((0, 6))
+        tors_par = np.stack([rng.uniform(0.5, 10.0, len(chain4)), rng.choice([2.0, 3.0, 6.0], size=len(chain4)),
+                             rng.choice([-1.0, 1.0], size=len(chain4))], 1) if len(chain4) else np.zeros((0, 3))
+        inv = quads(max(2, n // 4))
+        grp15 = rng.random(len(inv)) < 0.5
+        w0 = np.deg2rad(rng.uniform(80, 95, len(inv)))
+        inv_par = np.stack([rng.uniform(2.0, 25.0, len(inv)), np.where(grp15, 4.0 * np.cos(w0) ** 2 - np.cos(2 * w0), 1.0),
+                            np.where(grp15, -4.0 * np.cos(w0), -1.0), np.where(grp15, 1.0, 0.0)], 1) if len(inv) else np.zeros((0, 4))
+        dfar = np.sqrt(((pos[far[:, 0], :3] - pos[far[:, 1], :3]) ** 2).sum(1)) if len(far) else np.zeros(0)
+        xij = rng.uniform(3.0, 4.2, len(far))
+        thr = np.where(rng.random(len(far)) < 0.25, dfar * 0.9, xij * 10.0)  # a quarter of the pairs sit beyond their cutoff
+        vdw_par = np.stack([xij, rng.uniform(0.02, 0.3, len(far)), thr], 1) if len(far) else np.zeros((0, 3))
+        return pos, [(chain2, bond_par), (chain3, ang_par), (chain4, tors_par), (inv, inv_par), (far, vdw_par)]
     # MMFF
     bond_par = np.stack([rng.uniform(1.0, 1.6, len(chain2)), rng.uniform(3.0, 8.0, len(chain2))], 1) if len(chain2) else np.zeros((0, 2))
     ang_par = np.stack([rng.uniform(100, 125, len(chain3)), rng.uniform(0.4, 1.2, len(chain3)),
