@@ -17,6 +17,9 @@
 #include <algorithm>
 #include <vector>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "ff_terms.h"
 
@@ -516,12 +519,112 @@ constexpr double TOLX          = 4.0 * 3.0e-8;
 constexpr double EPS_HESS      = 3.0e-8;
 constexpr int    MAX_LS_ITERS  = 1000;
 
-template <int KIND>
+// ---- inverse-Hessian passes ------------------------------------------------------------------------
+// H is a dense row-major n x ld matrix in global memory (ld = n rounded up to even, so every row is 16-byte
+// aligned; the pad column stays 0).  A pass streams it once with the whole workgroup: 32 lanes span 64 consecutive
+// doubles of a row (512 B per half-wave), 8 row groups per workgroup, HU rows per thread in flight as independent
+// 16-byte loads, per-row sums finished with a 32-lane shuffle reduction.  (The first version gave each thread one
+// row and a serial loop over its n entries: ~200 us per BFGS iteration at n = 192, 99 % of the conformer pipeline.)
+constexpr int HTX = 32;
+constexpr int HTY = NT / HTX;
+constexpr int HU  = 8;
+
+__device__ __forceinline__ double half_wave_sum(double v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// y = sign * H v          (v, y: LDS vectors of n doubles; y must not alias v)
+__device__ __forceinline__ void hess_matvec(const double* __restrict__ H, const int n, const int ld, const double* v, double* y,
+                                            const double sign) {
+  const int tx = threadIdx.x & (HTX - 1), ty = threadIdx.x / HTX;
+  for (int r0 = 0; r0 < n; r0 += HTY * HU) {
+    double acc[HU];
+#pragma unroll
+    for (int u = 0; u < HU; ++u) acc[u] = 0.0;
+    for (int c = 2 * tx; c < n; c += 2 * HTX) {
+      const double v0 = v[c];
+      const double v1 = (c + 1 < n) ? v[c + 1] : 0.0;
+#pragma unroll
+      for (int u = 0; u < HU; ++u) {
+        const int r = r0 + ty + HTY * u;
+        if (r < n) {
+          const double2 h = *reinterpret_cast<const double2*>(H + static_cast<int64_t>(r) * ld + c);
+          acc[u] += h.x * v0 + h.y * v1;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      const int    r = r0 + ty + HTY * u;
+      const double t = half_wave_sum(acc[u]);
+      if (tx == 0 && r < n) y[r] = sign * t;
+    }
+  }
+}
+
+// H[r][c] += a_r xi[c] - b_r hdg[c] + d_r u[c]  with  a = rfac xi, b = fad hdg, d = fae u   (the BFGS rank-2 update of
+// RDKit's BFGSOpt.h), fused with the product of the UPDATED matrix with g:  y = -H' g.
+__device__ __forceinline__ void hess_update_matvec(double* __restrict__ H, const int n, const int ld, const bool update,
+                                                   const double rfac, const double fad, const double fae, const double* xi,
+                                                   const double* hdg, const double* uu, const double* g, double* y) {
+  constexpr int U  = 4;
+  const int     tx = threadIdx.x & (HTX - 1), ty = threadIdx.x / HTX;
+  for (int r0 = 0; r0 < n; r0 += HTY * U) {
+    double acc[U], ar[U], br[U], dr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r  = r0 + ty + HTY * u;
+      const int rc = r < n ? r : n - 1;
+      acc[u]       = 0.0;
+      ar[u]        = rfac * xi[rc];
+      br[u]        = fad * hdg[rc];
+      dr[u]        = fae * uu[rc];
+    }
+    for (int c = 2 * tx; c < n; c += 2 * HTX) {
+      const bool   two = c + 1 < n;
+      const double x0 = xi[c], h0 = hdg[c], u0 = uu[c], g0 = g[c];
+      const double x1 = two ? xi[c + 1] : 0.0, h1 = two ? hdg[c + 1] : 0.0, u1 = two ? uu[c + 1] : 0.0, g1 = two ? g[c + 1] : 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + ty + HTY * u;
+        if (r < n) {
+          double2* p = reinterpret_cast<double2*>(H + static_cast<int64_t>(r) * ld + c);
+          double2  h = *p;
+          if (update) {
+            h.x += ar[u] * x0 - br[u] * h0 + dr[u] * u0;
+            h.y += ar[u] * x1 - br[u] * h1 + dr[u] * u1;  // pad column: all of x1, h1, u1 are 0
+            *p = h;
+          }
+          acc[u] += h.x * g0 + h.y * g1;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int    r = r0 + ty + HTY * u;
+      const double t = half_wave_sum(acc[u]);
+      if (tx == 0 && r < n) y[r] = -t;
+    }
+  }
+}
+
+// PROFILE (NVMK_BFGS_PROFILE=1, DG and MMFF only): thread 0 accumulates wall-clock ticks (100 MHz) per phase into
+// prof[sys * 8 + k]: 0 line-search energy evaluations, 1 gradient, 2 H dGrad product, 3 update + direction,
+// 4 whole kernel, 5 iterations, 6 energy evaluations.
+template <int KIND, bool PROFILE = false>
 __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
                                                   const int maxIters, const double gradTol, const int scaleGrads,
                                                   const uint8_t* __restrict__ active, const int64_t* __restrict__ hessStarts,
                                                   double* __restrict__ hessians, double* __restrict__ energies,
-                                                  int16_t* __restrict__ statuses, int32_t* __restrict__ itersOut) {
+                                                  int16_t* __restrict__ statuses, int32_t* __restrict__ itersOut,
+                                                  int64_t* __restrict__ prof) {
+  int64_t tk[7] = {0, 0, 0, 0, 0, 0, 0};
+  auto    now   = [&]() -> int64_t { return PROFILE ? static_cast<int64_t>(wall_clock64()) : 0; };
+  const int64_t tStart = now();
+  (void)tk;
+  (void)tStart;
   constexpr int DIM = Dim<KIND>::value;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int sys = blockIdx.x;
@@ -549,10 +652,16 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
     return;
   }
 
+  const int ld = (n + 1) & ~1;
   for (int i = tid; i < n; i += NT) pos[i] = gpos[i];
-  for (int64_t i = tid; i < static_cast<int64_t>(n) * n; i += NT) H[i] = 0.0;
-  __syncthreads();
-  for (int i = tid; i < n; i += NT) H[static_cast<int64_t>(i) * n + i] = 1.0;
+  {
+    double2* H2 = reinterpret_cast<double2*>(H);
+    for (int64_t i = tid; i < static_cast<int64_t>(n) * ld / 2; i += NT) {
+      const int64_t e = 2 * i;
+      const int     r = static_cast<int>(e / ld), c = static_cast<int>(e - static_cast<int64_t>(r) * ld);
+      H2[i]           = make_double2(r == c ? 1.0 : 0.0, r == c + 1 ? 1.0 : 0.0);
+    }
+  }
 
   auto energy_at = [&](const double* p) -> double {
     return block_reduce<Op::kSum>(system_eval<KIND, false>(b, sys, p, nullptr, w0, w1, a0 * DIM), red);
@@ -612,7 +721,10 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
     for (int ls = 0; ls < MAX_LS_ITERS; ++ls) {
       for (int i = tid; i < n; i += NT) trial[i] = oldp[i] + lambda * dir[i];
       __syncthreads();
-      newE               = energy_at(trial);
+      const int64_t tE = now();
+      newE             = energy_at(trial);
+      tk[0] += now() - tE;
+      tk[6] += 1;
       const double eDiff = newE - prevE;
       if (lambda < lambdaMin || eDiff <= FUNCTOL * lambda * slope) break;
       double tmp;
@@ -657,7 +769,9 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
       break;
     }
     // ---- new gradient, gradient test (:277-303)
+    const int64_t tG = now();
     grad_at(pos);
+    tk[1] += now() - tG;
     double gTest = 0.0;
     for (int i = tid; i < n; i += NT) {
       dGrad[i] = grad[i] - dGrad[i];
@@ -669,12 +783,10 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
       break;
     }
     // ---- BFGS update of the inverse Hessian, new direction (:304-407)
-    for (int r = tid; r < n; r += NT) {
-      double acc = 0.0;
-      for (int c = 0; c < n; ++c) acc += H[static_cast<int64_t>(c) * n + r] * dGrad[c];
-      trial[r] = acc;  // hessDGrad
-    }
+    const int64_t tH = now();
+    hess_matvec(H, n, ld, dGrad, trial, 1.0);  // hessDGrad
     __syncthreads();
+    tk[2] += now() - tH;
     double fac = 0.0, fae = 0.0, sumDG = 0.0, sumXi = 0.0;
     for (int i = tid; i < n; i += NT) {
       fac += dGrad[i] * dir[i];
@@ -686,24 +798,16 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
     fae   = block_reduce<Op::kSum>(fae, red);
     sumDG = block_reduce<Op::kSum>(sumDG, red);
     sumXi = block_reduce<Op::kSum>(sumXi, red);
-    if (fac > 0.0 && fac * fac > EPS_HESS * sumDG * sumXi) {
-      const double rfac = 1.0 / fac, fad = 1.0 / fae;
+    const bool   update = fac > 0.0 && fac * fac > EPS_HESS * sumDG * sumXi;
+    const double rfac = update ? 1.0 / fac : 0.0, fad = update ? 1.0 / fae : 0.0;
+    if (update) {
       for (int i = tid; i < n; i += NT) dGrad[i] = rfac * dir[i] - fad * trial[i];
-      __syncthreads();
-      for (int r = tid; r < n; r += NT) {
-        const double pxi = rfac * dir[r], hdgi = fad * trial[r], dgi = fae * dGrad[r];
-        for (int c = 0; c < n; ++c) {
-          H[static_cast<int64_t>(c) * n + r] += pxi * dir[c] - hdgi * trial[c] + dgi * dGrad[c];
-        }
-      }
-      __syncthreads();
-    }
-    for (int r = tid; r < n; r += NT) {
-      double acc = 0.0;
-      for (int c = 0; c < n; ++c) acc += H[static_cast<int64_t>(c) * n + r] * grad[c];
-      oldp[r] = -acc;
     }
     __syncthreads();
+    const int64_t tU = now();
+    hess_update_matvec(H, n, ld, update, rfac, fad, fae, dir, trial, dGrad, grad, oldp);
+    __syncthreads();
+    tk[3] += now() - tU;
     for (int i = tid; i < n; i += NT) dir[i] = oldp[i];
     __syncthreads();
     ++iter;
@@ -713,6 +817,11 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
     energies[sys] = prevE;
     if (statuses) statuses[sys] = converged ? 0 : 1;
     if (itersOut) itersOut[sys] = iter;
+    if constexpr (PROFILE) {
+      tk[4] = now() - tStart;
+      tk[5] = iter;
+      for (int k = 0; k < 7; ++k) prof[static_cast<int64_t>(sys) * 8 + k] = tk[k];
+    }
   }
 }
 
@@ -796,13 +905,13 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   NVMK_REQUIRE(max_iters >= 0, "bfgs: negative iteration count");
   hipStream_t stream = as_stream(stream_);
   const int   dim    = (b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_UFF) ? 3 : 4;
-  // inverse-Hessian offsets (n^2 doubles per system) and the LDS need of the largest system
+  // inverse-Hessian offsets (n x ld doubles per system) and the LDS need of the largest system
   std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
   int                  maxN = 0;
   for (int s = 0; s < b.nSystems; ++s) {
     const int64_t n = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
     NVMK_REQUIRE(n >= 0, "bfgs: atom_starts must be non-decreasing");
-    hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + n * n;
+    hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + n * ((n + 1) & ~int64_t{1});  // rows padded to even length
     maxN                           = std::max<int>(maxN, static_cast<int>(n));
   }
   const size_t shmem = (6 * static_cast<size_t>(maxN) + NT / 64 + 1) * sizeof(double);
@@ -811,6 +920,47 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   NVMK_HIP_CHECK(hessMem.alloc(static_cast<size_t>(hs.back()) * sizeof(double), stream));
   NVMK_HIP_CHECK(startsMem.alloc(hs.size() * sizeof(int64_t), stream));
   NVMK_HIP_CHECK(hipMemcpyAsync(startsMem.ptr, hs.data(), hs.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+  static const bool profile = [] {
+    const char* e = std::getenv("NVMK_BFGS_PROFILE");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (profile && (b.kind == NVMK_FF_DG || b.kind == NVMK_FF_MMFF)) {
+    StreamScratch profMem;
+    const size_t  words = static_cast<size_t>(b.nSystems) * 8;
+    NVMK_HIP_CHECK(profMem.alloc(words * sizeof(int64_t), stream));
+    NVMK_HIP_CHECK(hipMemsetAsync(profMem.ptr, 0, words * sizeof(int64_t), stream));
+    if (b.kind == NVMK_FF_DG) {
+      hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_DG, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters,
+                         grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies, d_statuses,
+                         d_iters, profMem.as<int64_t>());
+    } else {
+      hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_MMFF, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1,
+                         max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies,
+                         d_statuses, d_iters, profMem.as<int64_t>());
+    }
+    NVMK_LAUNCH_CHECK();
+    std::vector<int64_t> h(words);
+    NVMK_HIP_CHECK(hipMemcpyAsync(h.data(), profMem.ptr, words * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    double  sum[7] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t ran = 0, longest = 0;
+    for (int sI = 0; sI < b.nSystems; ++sI) {
+      if (h[static_cast<size_t>(sI) * 8 + 4] == 0) continue;
+      ++ran;
+      longest = std::max(longest, h[static_cast<size_t>(sI) * 8 + 4]);
+      for (int k = 0; k < 7; ++k) sum[k] += static_cast<double>(h[static_cast<size_t>(sI) * 8 + k]);
+    }
+    if (ran > 0) {
+      const double us = 0.01;  // 100 MHz ticks
+      std::fprintf(stderr,
+                   "[nvmk bfgs profile] kind %d systems %lld: per system mean %.1f us (max %.1f us), iterations %.1f, energy evals "
+                   "%.1f | per iteration: line-search energy %.1f us, gradient %.1f us, H*dGrad %.1f us, update+direction %.1f us\n",
+                   b.kind, (long long)ran, sum[4] / ran * us, longest * us, sum[5] / ran, sum[6] / ran,
+                   sum[0] / std::max(sum[5], 1.0) * us, sum[1] / std::max(sum[5], 1.0) * us, sum[2] / std::max(sum[5], 1.0) * us,
+                   sum[3] / std::max(sum[5], 1.0) * us);
+    }
+    return NVMK_OK;
+  }
   NVMK_FF_DISPATCH(b.kind, {
     auto kern = bfgs_kernel<K>;
     if (shmem > 64 * 1024) {
@@ -818,7 +968,8 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
                                          static_cast<int>(shmem)));
     }
     hipLaunchKernelGGL(kern, dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters, grad_tol, scale_grads,
-                       d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies, d_statuses, d_iters);
+                       d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies, d_statuses, d_iters,
+                       static_cast<int64_t*>(nullptr));
   });
   NVMK_LAUNCH_CHECK();
   NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // `hs` (pageable) must outlive its async copy; scratch is freed in stream order

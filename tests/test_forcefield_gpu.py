@@ -96,7 +96,22 @@ def test_bfgs_converged_systems_are_idempotent():
 @pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
 def test_bfgs_lowers_energy_and_matches_oracle_minimiser(kind):
     sizes = [4, 6, 9, 13]
-    systems, batch, pos = make_batch(kind, sizes, seed=kind + 21)
+    if kind == UFF:
+        # group-15 inversions (C2 != 0) make the reference's gradient field non-conservative (see
+        # ff_terms.h uff_inversion): a minimiser then stops wherever its line search gives up, which is not
+        # comparable between implementations.  The comparison uses sp2-type inversions (C0, C1, C2 = 1, -1, 0) only,
+        # and bend orders whose minima are near the ~110 degree start geometry (general and 120-degree forms):
+        # a random order-1/2/4 bend starts on a plateau of its cosine and even the oracle's result then depends on
+        # its finite-difference step (34.70 / 34.62 / 35.38 for h = 1e-5 / 1e-6 / 1e-7 on the first system).
+        rng = np.random.default_rng(kind + 21)
+        systems = [util.random_ff_system(kind, n, rng) for n in sizes]
+        for _, g in systems:
+            g[3][1][:, 1:] = (1.0, -1.0, 0.0)
+            g[1][1][:, 2] = np.where(g[1][1][:, 2] == 0, 0.0, 3.0)
+        atom_starts, flat, groups = util.build_ff_batch_arrays(kind, systems)
+        batch, pos = FlatForcefieldBatch(kind, atom_starts, groups), torch.from_numpy(flat).cuda()
+    else:
+        systems, batch, pos = make_batch(kind, sizes, seed=kind + 21)
     w0, w1 = W[kind]
     e0 = batch.compute_energy(pos, w0, w1).cpu().numpy()
     energies, statuses, iters = batch.minimize(pos, max_iters=300, grad_tol=1e-4, scale_grads=True, w0=w0, w1=w1)
@@ -106,21 +121,6 @@ def test_bfgs_lowers_energy_and_matches_oracle_minimiser(kind):
     np.testing.assert_allclose(batch.compute_energy(pos, w0, w1).cpu().numpy(), e1, rtol=1e-9, atol=1e-9)
     # the same algorithm in plain numpy from the same start reaches the same minimum (trajectories are
     # chaotic in the last digits, so compare energies, as the reference does: 1e-3 after minimisation)
-    if kind == UFF:
-        # the UFF surface of random tables (3 torsion periodicities, inversions) has many shallow basins and two
-        # implementations that differ in the last digit pick different ones from a far start: restart both from
-        # a small perturbation of the minimum just found, so that they share a basin
-        rng = np.random.default_rng(77)
-        flat = pos.cpu().numpy() + 1e-3 * rng.normal(size=pos.numel())
-        off_ = 0
-        restarted = []
-        for p, g in systems:
-            restarted.append((flat[off_:off_ + p.size].reshape(p.shape).copy(), g))
-            off_ += p.size
-        systems = restarted
-        pos = torch.from_numpy(flat).cuda()
-        energies, statuses, iters = batch.minimize(pos, max_iters=300, grad_tol=1e-4, scale_grads=True, w0=w0, w1=w1)
-        e1 = energies.cpu().numpy()
     for s, (p, g) in enumerate(systems[:3]):
         shape = p.shape
         e_fn = lambda x: off.system_energy(kind, x.reshape(shape), g, w0, w1)  # noqa: E731
