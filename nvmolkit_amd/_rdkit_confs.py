@@ -15,7 +15,7 @@ import torch
 from nvmolkit_amd.forcefield import FlatForcefieldBatch, stack_molecule_tables
 from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
-DEFAULT_BATCH = 500  # conformers per launch (src/minimizer/bfgs_common.cpp: batchSize default)
+DEFAULT_BATCH = 4096  # conformers per launch when HardwareOptions.batchSize is -1 (the reference uses 500; see embedMolecules.AUTO_BATCH_SIZE)
 
 
 def optimize_rdkit_conformers(kind: int, molecules, flatten, max_iters: int, grad_tol: float,

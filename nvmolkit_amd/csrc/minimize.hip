@@ -111,7 +111,7 @@ template <int DIM> __device__ __forceinline__ void pair_push(double* grad, const
 
 // GRAD = false: returns the energy partial.  GRAD = true: accumulates the gradient, returns 0.
 template <int KIND, bool GRAD>
-__device__ double system_eval(const Batch& b, const int sys, const double* pos, double* grad, const double w0, const double w1,
+__device__ __forceinline__ double system_eval(const Batch& b, const int sys, const double* pos, double* grad, const double w0, const double w1,
                               const int globalCoordStart) {
   constexpr int DIM = Dim<KIND>::value;
   const int     tid = threadIdx.x;
@@ -519,15 +519,24 @@ constexpr double TOLX          = 4.0 * 3.0e-8;
 constexpr double EPS_HESS      = 3.0e-8;
 constexpr int    MAX_LS_ITERS  = 1000;
 
-// ---- inverse-Hessian passes ------------------------------------------------------------------------
-// H is a dense row-major n x ld matrix in global memory (ld = n rounded up to even, so every row is 16-byte
-// aligned; the pad column stays 0).  A pass streams it once with the whole workgroup: 32 lanes span 64 consecutive
-// doubles of a row (512 B per half-wave), 8 row groups per workgroup, HU rows per thread in flight as independent
-// 16-byte loads, per-row sums finished with a 32-lane shuffle reduction.  (The first version gave each thread one
-// row and a serial loop over its n entries: ~200 us per BFGS iteration at n = 192, 99 % of the conformer pipeline.)
+// ---- inverse-Hessian pass -------------------------------------------------------------------------
+// The inverse Hessian is symmetric: only its lower triangle is stored, row r holding columns 0..r padded to an even
+// length (rows stay 16-byte aligned, the pad entry stays 0).  ONE pass per BFGS iteration streams it once with the
+// whole workgroup: it applies the rank-2 update that the PREVIOUS iteration left pending
+//     H += rfac xi xi^T - fad hdg hdg^T + fae u u^T          (RDKit BFGSOpt.h; u = rfac xi - fad hdg)
+// writes the element back, and accumulates t = H g for the current gradient.  The two products the textbook loop
+// needs per iteration follow from t without touching the matrix again:
+//     H dGrad       = H g_new - H g_old = t - hg                       (hg = H g of the previous iterate, kept in LDS)
+//     H_new g_new   = t + rfac xi (xi.g) - fad hdg (hdg.g) + fae u (u.g)
+// so the traffic per iteration is one read + one write of n (n + 2) / 2 doubles instead of two reads + one write of
+// n^2 (measured before: 47 + 75 us of a 134 us iteration at n = 192, and the 512 resident workgroups together were
+// pulling 3-4 TB/s of Hessian traffic from HBM).
+// Work split: 32 lanes span 64 consecutive columns of a row, 8 row groups per workgroup, HU rows per lane in flight
+// as independent 16-byte loads.  Row sums finish with a 32-lane shuffle reduction; the mirrored (column) sums of the
+// HU rows of a batch share their column and are combined in registers before they touch LDS.
 constexpr int HTX = 32;
 constexpr int HTY = NT / HTX;
-constexpr int HU  = 8;
+constexpr int HU  = 4;
 
 __device__ __forceinline__ double half_wave_sum(double v) {
 #pragma unroll
@@ -535,86 +544,90 @@ __device__ __forceinline__ double half_wave_sum(double v) {
   return v;
 }
 
-// y = sign * H v          (v, y: LDS vectors of n doubles; y must not alias v)
-__device__ __forceinline__ void hess_matvec(const double* __restrict__ H, const int n, const int ld, const double* v, double* y,
-                                            const double sign) {
+__host__ __device__ __forceinline__ int64_t hess_row_offset(const int64_t r) {  // rows 0..r-1, each padded to even length
+  return (r & 1) ? (r + 1) * (r + 1) / 2 : r * (r + 2) / 2;
+}
+
+// `part` is (1 + HTY) n doubles of LDS scratch: row sums, then one slab of mirrored-entry sums per row group; it must be
+// zero on entry (and visible to the workgroup).  On exit (after a barrier) t = H g.  No atomics: every partial sum
+// has a single writer and the final sum runs in a fixed order, so the minimiser is reproducible run to run.
+__device__ __forceinline__ void hess_pass(double* __restrict__ H, const int n, const bool pending, const double rfac,
+                                          const double fad, const double fae, const double* xi, const double* hdg,
+                                          const double* uu, const double* g, double* t, double* part) {
   const int tx = threadIdx.x & (HTX - 1), ty = threadIdx.x / HTX;
   for (int r0 = 0; r0 < n; r0 += HTY * HU) {
-    double acc[HU];
+    double  racc[HU], ar[HU], br[HU], dr[HU], gr[HU];
+    int     row[HU];
+    int64_t off[HU];
 #pragma unroll
-    for (int u = 0; u < HU; ++u) acc[u] = 0.0;
-    for (int c = 2 * tx; c < n; c += 2 * HTX) {
-      const double v0 = v[c];
-      const double v1 = (c + 1 < n) ? v[c + 1] : 0.0;
-#pragma unroll
-      for (int u = 0; u < HU; ++u) {
-        const int r = r0 + ty + HTY * u;
-        if (r < n) {
-          const double2 h = *reinterpret_cast<const double2*>(H + static_cast<int64_t>(r) * ld + c);
-          acc[u] += h.x * v0 + h.y * v1;
+    for (int u = 0; u < HU; ++u) {
+      const int r  = r0 + ty + HTY * u;
+      row[u]       = r < n ? r : -1;
+      const int rc = r < n ? r : 0;
+      off[u]       = hess_row_offset(rc);
+      racc[u]      = 0.0;
+      gr[u]        = g[rc];
+      ar[u]        = pending ? rfac * xi[rc] : 0.0;
+      br[u]        = pending ? fad * hdg[rc] : 0.0;
+      dr[u]        = pending ? fae * uu[rc] : 0.0;
+    }
+    const int rmax = min(n - 1, r0 + ty + HTY * (HU - 1));
+    for (int c = 2 * tx; c <= rmax; c += 2 * HTX) {
+      const bool   two = c + 1 < n;
+      const double g0 = g[c], g1 = two ? g[c + 1] : 0.0;
+      double       x0 = 0.0, x1 = 0.0, h0 = 0.0, h1 = 0.0, u0 = 0.0, u1 = 0.0;
+      if (pending) {
+        x0 = xi[c];
+        h0 = hdg[c];
+        u0 = uu[c];
+        if (two) {
+          x1 = xi[c + 1];
+          h1 = hdg[c + 1];
+          u1 = uu[c + 1];
         }
       }
+      double col0 = 0.0, col1 = 0.0;
+#pragma unroll
+      for (int u = 0; u < HU; ++u) {
+        if (c <= row[u]) {
+          double2*   p    = reinterpret_cast<double2*>(H + off[u] + c);
+          double2    h    = *p;
+          const bool has1 = c + 1 <= row[u];
+          if (pending) {
+            h.x += ar[u] * x0 - br[u] * h0 + dr[u] * u0;
+            if (has1) h.y += ar[u] * x1 - br[u] * h1 + dr[u] * u1;  // the pad entry stays 0
+            *p = h;
+          }
+          racc[u] += h.x * g0 + (has1 ? h.y * g1 : 0.0);
+          if (c < row[u]) col0 += h.x * gr[u];      // mirrored entries (strictly below the diagonal)
+          if (c + 1 < row[u]) col1 += h.y * gr[u];
+        }
+      }
+      // (row group ty, column c) has exactly one writer: plain read-modify-write, summation order fixed
+      double* mine = part + (1 + ty) * n;
+      mine[c] += col0;
+      if (two) mine[c + 1] += col1;
     }
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
-      const int    r = r0 + ty + HTY * u;
-      const double t = half_wave_sum(acc[u]);
-      if (tx == 0 && r < n) y[r] = sign * t;
+      const double v = half_wave_sum(racc[u]);
+      if (tx == 0 && row[u] >= 0) part[row[u]] = v;  // row sums: one writer per row
     }
   }
-}
-
-// H[r][c] += a_r xi[c] - b_r hdg[c] + d_r u[c]  with  a = rfac xi, b = fad hdg, d = fae u   (the BFGS rank-2 update of
-// RDKit's BFGSOpt.h), fused with the product of the UPDATED matrix with g:  y = -H' g.
-__device__ __forceinline__ void hess_update_matvec(double* __restrict__ H, const int n, const int ld, const bool update,
-                                                   const double rfac, const double fad, const double fae, const double* xi,
-                                                   const double* hdg, const double* uu, const double* g, double* y) {
-  constexpr int U  = 4;
-  const int     tx = threadIdx.x & (HTX - 1), ty = threadIdx.x / HTX;
-  for (int r0 = 0; r0 < n; r0 += HTY * U) {
-    double acc[U], ar[U], br[U], dr[U];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += NT) {
+    double v = part[i];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r  = r0 + ty + HTY * u;
-      const int rc = r < n ? r : n - 1;
-      acc[u]       = 0.0;
-      ar[u]        = rfac * xi[rc];
-      br[u]        = fad * hdg[rc];
-      dr[u]        = fae * uu[rc];
-    }
-    for (int c = 2 * tx; c < n; c += 2 * HTX) {
-      const bool   two = c + 1 < n;
-      const double x0 = xi[c], h0 = hdg[c], u0 = uu[c], g0 = g[c];
-      const double x1 = two ? xi[c + 1] : 0.0, h1 = two ? hdg[c + 1] : 0.0, u1 = two ? uu[c + 1] : 0.0, g1 = two ? g[c + 1] : 0.0;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int r = r0 + ty + HTY * u;
-        if (r < n) {
-          double2* p = reinterpret_cast<double2*>(H + static_cast<int64_t>(r) * ld + c);
-          double2  h = *p;
-          if (update) {
-            h.x += ar[u] * x0 - br[u] * h0 + dr[u] * u0;
-            h.y += ar[u] * x1 - br[u] * h1 + dr[u] * u1;  // pad column: all of x1, h1, u1 are 0
-            *p = h;
-          }
-          acc[u] += h.x * g0 + h.y * g1;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int    r = r0 + ty + HTY * u;
-      const double t = half_wave_sum(acc[u]);
-      if (tx == 0 && r < n) y[r] = -t;
-    }
+    for (int k = 1; k <= HTY; ++k) v += part[k * n + i];
+    t[i] = v;
   }
 }
 
 // PROFILE (NVMK_BFGS_PROFILE=1, DG and MMFF only): thread 0 accumulates wall-clock ticks (100 MHz) per phase into
-// prof[sys * 8 + k]: 0 line-search energy evaluations, 1 gradient, 2 H dGrad product, 3 update + direction,
+// prof[sys * 8 + k]: 0 line-search energy evaluations, 1 gradient, 2 pass over H (pending update + H g), 3 update scalars + direction,
 // 4 whole kernel, 5 iterations, 6 energy evaluations.
 template <int KIND, bool PROFILE = false>
-__global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
+__global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
                                                   const int maxIters, const double gradTol, const int scaleGrads,
                                                   const uint8_t* __restrict__ active, const int64_t* __restrict__ hessStarts,
                                                   double* __restrict__ hessians, double* __restrict__ energies,
@@ -637,11 +650,17 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
 
   double* pos   = reinterpret_cast<double*>(smem);
   double* grad  = pos + n;
-  double* dir   = grad + n;   // xi
-  double* trial = dir + n;    // line-search positions, later H * dGrad
+  double* dir   = grad + n;   // search direction, then the step actually taken (xi)
+  double* trial = dir + n;    // line-search positions
   double* dGrad = trial + n;
   double* oldp  = dGrad + n;
-  double* red   = oldp + n;   // NT/64 + 1
+  double* hg    = oldp + n;   // H g of the current iterate (= -direction before any rescaling)
+  double* tvec  = hg + n;     // H g_new from the pass
+  double* pxi   = tvec + n;   // pending rank-2 update: xi, H dGrad, u
+  double* phdg  = pxi + n;
+  double* pu    = phdg + n;
+  double* part  = pu + n;     // (1 + HTY) n partial sums of the pass
+  double* red   = part + (1 + HTY) * n;  // NT/64 + 1
 
   if (n == 0) {
     if (tid == 0) {
@@ -652,15 +671,13 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
     return;
   }
 
-  const int ld = (n + 1) & ~1;
   for (int i = tid; i < n; i += NT) pos[i] = gpos[i];
   {
-    double2* H2 = reinterpret_cast<double2*>(H);
-    for (int64_t i = tid; i < static_cast<int64_t>(n) * ld / 2; i += NT) {
-      const int64_t e = 2 * i;
-      const int     r = static_cast<int>(e / ld), c = static_cast<int>(e - static_cast<int64_t>(r) * ld);
-      H2[i]           = make_double2(r == c ? 1.0 : 0.0, r == c + 1 ? 1.0 : 0.0);
-    }
+    const int64_t total = hess_row_offset(n);
+    double2*      H2    = reinterpret_cast<double2*>(H);
+    for (int64_t i = tid; i < total / 2; i += NT) H2[i] = make_double2(0.0, 0.0);
+    __syncthreads();
+    for (int r = tid; r < n; r += NT) H[hess_row_offset(r) + r] = 1.0;  // H = identity
   }
 
   auto energy_at = [&](const double* p) -> double {
@@ -689,7 +706,12 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
 
   double prevE = energy_at(pos);
   grad_at(pos);
-  for (int i = tid; i < n; i += NT) dir[i] = -grad[i];
+  for (int i = tid; i < n; i += NT) {
+    hg[i]  = grad[i];  // H = I
+    dir[i] = -grad[i];
+  }
+  bool   pending = false;
+  double pRfac = 0.0, pFad = 0.0, pFae = 0.0;
   double sumsq = 0.0;
   for (int i = tid; i < n; i += NT) sumsq += pos[i] * pos[i];
   sumsq                 = block_reduce<Op::kSum>(sumsq, red);
@@ -782,34 +804,54 @@ __global__ __launch_bounds__(NT) void bfgs_kernel(const Batch b, double* __restr
       converged = true;
       break;
     }
-    // ---- BFGS update of the inverse Hessian, new direction (:304-407)
+    // ---- BFGS update of the inverse Hessian, new direction (:304-407) — one pass over H, see hess_pass
     const int64_t tH = now();
-    hess_matvec(H, n, ld, dGrad, trial, 1.0);  // hessDGrad
+    for (int i = tid; i < (1 + HTY) * n; i += NT) part[i] = 0.0;
+    __syncthreads();
+    hess_pass(H, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, tvec, part);  // H is now H_k; tvec = H_k g_new
     __syncthreads();
     tk[2] += now() - tH;
+    const int64_t tU = now();
     double fac = 0.0, fae = 0.0, sumDG = 0.0, sumXi = 0.0;
     for (int i = tid; i < n; i += NT) {
+      const double hd = tvec[i] - hg[i];  // H dGrad
+      phdg[i]         = hd;
+      pxi[i]          = dir[i];
       fac += dGrad[i] * dir[i];
-      fae += dGrad[i] * trial[i];
+      fae += dGrad[i] * hd;
       sumDG += dGrad[i] * dGrad[i];
       sumXi += dir[i] * dir[i];
     }
-    fac   = block_reduce<Op::kSum>(fac, red);
-    fae   = block_reduce<Op::kSum>(fae, red);
-    sumDG = block_reduce<Op::kSum>(sumDG, red);
-    sumXi = block_reduce<Op::kSum>(sumXi, red);
-    const bool   update = fac > 0.0 && fac * fac > EPS_HESS * sumDG * sumXi;
-    const double rfac = update ? 1.0 / fac : 0.0, fad = update ? 1.0 / fae : 0.0;
-    if (update) {
-      for (int i = tid; i < n; i += NT) dGrad[i] = rfac * dir[i] - fad * trial[i];
+    fac     = block_reduce<Op::kSum>(fac, red);
+    fae     = block_reduce<Op::kSum>(fae, red);
+    sumDG   = block_reduce<Op::kSum>(sumDG, red);
+    sumXi   = block_reduce<Op::kSum>(sumXi, red);
+    pending = fac > 0.0 && fac * fac > EPS_HESS * sumDG * sumXi;
+    if (pending) {
+      pRfac = 1.0 / fac;
+      pFad  = 1.0 / fae;
+      pFae  = fae;
+      // u = rfac xi - fad hdg, and the three dot products with the new gradient for H_new g_new
+      double dx = 0.0, dh = 0.0, du = 0.0;
+      for (int i = tid; i < n; i += NT) {
+        const double ui = pRfac * pxi[i] - pFad * phdg[i];
+        pu[i]           = ui;
+        dx += pxi[i] * grad[i];
+        dh += phdg[i] * grad[i];
+        du += ui * grad[i];
+      }
+      dx = block_reduce<Op::kSum>(dx, red);
+      dh = block_reduce<Op::kSum>(dh, red);
+      du = block_reduce<Op::kSum>(du, red);
+      for (int i = tid; i < n; i += NT) {
+        hg[i] = tvec[i] + pRfac * dx * pxi[i] - pFad * dh * phdg[i] + pFae * du * pu[i];
+      }
+    } else {
+      for (int i = tid; i < n; i += NT) hg[i] = tvec[i];
     }
-    __syncthreads();
-    const int64_t tU = now();
-    hess_update_matvec(H, n, ld, update, rfac, fad, fae, dir, trial, dGrad, grad, oldp);
+    for (int i = tid; i < n; i += NT) dir[i] = -hg[i];
     __syncthreads();
     tk[3] += now() - tU;
-    for (int i = tid; i < n; i += NT) dir[i] = oldp[i];
-    __syncthreads();
     ++iter;
   }
   for (int i = tid; i < n; i += NT) gpos[i] = pos[i];
@@ -905,16 +947,16 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   NVMK_REQUIRE(max_iters >= 0, "bfgs: negative iteration count");
   hipStream_t stream = as_stream(stream_);
   const int   dim    = (b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_UFF) ? 3 : 4;
-  // inverse-Hessian offsets (n x ld doubles per system) and the LDS need of the largest system
+  // inverse-Hessian offsets (packed lower triangle per system) and the LDS need of the largest system
   std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
   int                  maxN = 0;
   for (int s = 0; s < b.nSystems; ++s) {
     const int64_t n = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
     NVMK_REQUIRE(n >= 0, "bfgs: atom_starts must be non-decreasing");
-    hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + n * ((n + 1) & ~int64_t{1});  // rows padded to even length
+    hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + hess_row_offset(n);  // packed lower triangle
     maxN                           = std::max<int>(maxN, static_cast<int>(n));
   }
-  const size_t shmem = (6 * static_cast<size_t>(maxN) + NT / 64 + 1) * sizeof(double);
+  const size_t shmem = ((12 + HTY) * static_cast<size_t>(maxN) + NT / 64 + 1) * sizeof(double);
   NVMK_REQUIRE(shmem <= 160 * 1024, "bfgs: a system with %d coordinates needs %zu bytes of LDS (max 160 KiB)", maxN, shmem);
   StreamScratch hessMem, startsMem;
   NVMK_HIP_CHECK(hessMem.alloc(static_cast<size_t>(hs.back()) * sizeof(double), stream));

@@ -22,7 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--mols", type=int, default=1000)
 ap.add_argument("--confs", type=int, default=10)
 ap.add_argument("--mean-atoms", type=int, default=48)
-ap.add_argument("--batch-size", type=int, default=500)
+ap.add_argument("--batch-size", type=int, default=4096)
 ap.add_argument("--mmff-iters", type=int, default=200)
 args = ap.parse_args()
 rng = np.random.default_rng(20260926)
