@@ -116,15 +116,6 @@ __device__ __forceinline__ void chunk_mma(v16f (&acc)[2][2], const char* sA, con
   }
 }
 
-// Register-staged pieces (neighbour-count kernel): NAMED scalars, because arrays indexed in helper loops were
-// kept in scratch memory by this compiler (272 B/lane and a store/reload of the whole prefetch per chunk).
-#define NVMK_PIECE_ROW(t) ((tid + (t)*NT) >> C::LOG)
-#define NVMK_PIECE_SLOT(t) ((tid + (t)*NT) & (KCW - 1))
-#define NVMK_COMMIT_ONE(P, lds, t)                                                         \
-  if ((t) < C::T)                                                                          \
-    *reinterpret_cast<uint4*>((lds) + NVMK_PIECE_ROW(t) * C::ROWBYTES +                      \
-                              ((NVMK_PIECE_SLOT(t) ^ C::swz(NVMK_PIECE_ROW(t))) << 4)) = P##t;
-
 // ---- dense cross-similarity ----------------------------------------------------------------------
 // Operand chunks go global -> LDS directly (global_load_lds_dwordx4: 1 KB per wave instruction, no staging
 // VGPRs, no ds_write pass).  The DMA destination is wave-uniform base + lane * 16, so the LDS image is linear in
@@ -283,10 +274,11 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
 }
 
 // ---- neighbour counting on the matrix cores ------------------------------------------------------
-// Same main loop as the dense kernel (8-word chunks), but the epilogue thresholds the exact counts with
-// the Tanimoto table tmin[pa + pb] (see butina.hip) and reduces them to per-row (and, in symmetric mode,
-// per-column) neighbour counts: registers -> 32-lane shuffle reduction -> LDS -> one global atomic per row.
-// Rows are gathered through optional index lists so the Butina loop never compacts the fingerprint matrix.
+// Same main loop as the dense kernel (LDS-DMA operand chunks; the per-lane source row goes through the optional
+// gather lists, so the Butina loop never compacts the fingerprint matrix), but the epilogue thresholds the exact
+// counts with the Tanimoto table tmin[pa + pb] (see butina.hip; read through L1, it is 16 KB) and reduces them to
+// per-row (and, in symmetric mode, per-column) neighbour counts: ballot + scalar popcount -> LDS -> one global atomic
+// per row.  34 KB of LDS -> 4 workgroups per CU.
 
 __device__ __forceinline__ bool cosine_neighbor(const int c, const int pa, const int pb, const float thr) {
   const float denom = sqrtf(static_cast<float>(pa) * static_cast<float>(pb));
@@ -294,46 +286,37 @@ __device__ __forceinline__ bool cosine_neighbor(const int c, const int pa, const
   return static_cast<float>(c) / denom >= thr;
 }
 
-#define NVMK_FETCH4(P, base, o, k)  \
-  P##0 = (base)[o##0 + (k)];        \
-  P##1 = (base)[o##1 + (k)];        \
-  P##2 = (base)[o##2 + (k)];        \
-  P##3 = (base)[o##3 + (k)];
-#define NVMK_COMMIT4(P, lds) NVMK_COMMIT_ONE(P, lds, 0) NVMK_COMMIT_ONE(P, lds, 1) NVMK_COMMIT_ONE(P, lds, 2) NVMK_COMMIT_ONE(P, lds, 3)
-
 template <int METRIC>
-__global__ __launch_bounds__(NT, 2) void neighbor_count_mfma_kernel(
+__global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   const uint4* __restrict__ X, const int32_t* __restrict__ popX, const int32_t* __restrict__ xRows,
   const int32_t* __restrict__ xIds, int64_t nX,
   const int32_t* __restrict__ nXdev, const uint4* __restrict__ Y, const int32_t* __restrict__ popY,
   const int32_t* __restrict__ yRows, const int32_t* __restrict__ yIds, int64_t nY, const int32_t* __restrict__ nYdev, const int Wp, const int F,
   const uint16_t* __restrict__ table, const float thr, const int sign, const int symmetric, int32_t* __restrict__ counts, const unsigned superN,
-  const unsigned superW) {
+  const unsigned superW, const unsigned superH) {
   constexpr int KCW = 8;
+  constexpr int PPW = KCW / 2;
+  constexpr int RPP = 64 / KCW;
   using C           = Chunk<KCW>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char*     sA     = smem;
-  char*     sB     = smem + TM * C::ROWBYTES;
-  int*      pcA    = reinterpret_cast<int*>(smem + (TM + TN) * C::ROWBYTES);
-  int*      pcB    = pcA + TM;
-  int*      idA    = pcB + TN;
-  int*      idB    = idA + TM;
-  int*      cidA   = idB + TN;   // counts index of each row
-  int*      cidB   = cidA + TM;
-  int*      rowsum = cidB + TN;
-  int*      colsum = rowsum + TM;
-  uint16_t* sTab   = reinterpret_cast<uint16_t*>(colsum + TN);
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* sA     = smem;
+  char* sB     = smem + TM * C::ROWBYTES;
+  int*  pcA    = reinterpret_cast<int*>(smem + (TM + TN) * C::ROWBYTES);
+  int*  pcB    = pcA + TM;
+  int*  rowsum = pcB + TN;
+  int*  colsum = rowsum + TM;
 
   if (nXdev) nX = *nXdev;
   if (nYdev) nY = *nYdev;
   const unsigned tilesM = static_cast<unsigned>((nX + TM - 1) / TM);
   const unsigned tilesN = static_cast<unsigned>((nY + TN - 1) / TN);
   // supertile map over the HOST-side upper bounds (gridDim), exits against the device-side sizes.  A
-  // supertile is SUPER x superW tiles; superW < SUPER for skinny problems (a Butina subtract pass has one
+  // supertile is superH x superW tiles; superW < superH for skinny problems (a Butina subtract pass has one
   // column tile: a square 64 x 64 map would launch 63 empty workgroups per working one).
-  const unsigned sm     = blockIdx.y / superN;
-  const unsigned sn     = blockIdx.y - sm * superN;
-  const unsigned tile_m = sm * SUPER + blockIdx.x / superW;
+  const unsigned sidx   = blockIdx.z * gridDim.y + blockIdx.y;  // supertile index (grid y and z are 16-bit each)
+  const unsigned sm     = sidx / superN;
+  const unsigned sn     = sidx - sm * superN;
+  const unsigned tile_m = sm * superH + blockIdx.x / superW;
   const unsigned tile_n = sn * superW + (blockIdx.x - (blockIdx.x / superW) * superW);
   if (tile_m >= tilesM || tile_n >= tilesN) return;
   if (symmetric && tile_n < tile_m) return;
@@ -341,37 +324,32 @@ __global__ __launch_bounds__(NT, 2) void neighbor_count_mfma_kernel(
 
   const int     tid   = threadIdx.x;
   const int     lane  = tid & 63;
-  const int     wave  = tid >> 6;
+  const int     wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int     wm    = wave >> 1;
   const int     wn    = wave & 1;
   const int64_t rowA0 = static_cast<int64_t>(tile_m) * TM;
   const int64_t rowB0 = static_cast<int64_t>(tile_n) * TN;
   const int     SENT  = (METRIC == NVMK_METRIC_TANIMOTO) ? 2 * F + 1 : 0;  // popcount of a padded row
 
+  // physical row of logical row r (rows past the end alias the last one; their popcount is the sentinel)
+  auto physX = [&](const int64_t r) -> int {
+    const int64_t rc = r < nX ? r : nX - 1;
+    return xRows ? xRows[rc] : static_cast<int>(rc);
+  };
+  auto physY = [&](const int64_t r) -> int {
+    const int64_t rc = r < nY ? r : nY - 1;
+    return yRows ? yRows[rc] : static_cast<int>(rc);
+  };
   if (tid < TM) {
-    const int64_t r     = rowA0 + tid;
-    const bool    valid = r < nX;
-    const int64_t rc    = valid ? r : nX - 1;
-    const int     phys  = xRows ? xRows[rc] : static_cast<int>(rc);
-    idA[tid]            = phys;
-    cidA[tid]           = xIds ? xIds[rc] : phys;
-    pcA[tid]            = valid ? popX[phys] : SENT;
-    rowsum[tid]         = 0;
+    const int64_t r = rowA0 + tid;
+    pcA[tid]        = r < nX ? popX[physX(r)] : SENT;
+    rowsum[tid]     = 0;
   } else {
-    const int     t     = tid - TM;
-    const int64_t r     = rowB0 + t;
-    const bool    valid = r < nY;
-    const int64_t rc    = valid ? r : nY - 1;
-    const int     phys  = yRows ? yRows[rc] : static_cast<int>(rc);
-    idB[t]              = phys;
-    cidB[t]             = yIds ? yIds[rc] : phys;
-    pcB[t]              = valid ? popY[phys] : SENT;
-    colsum[t]           = 0;
+    const int     t = tid - TM;
+    const int64_t r = rowB0 + t;
+    pcB[t]          = r < nY ? popY[physY(r)] : SENT;
+    colsum[t]       = 0;
   }
-  if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-    for (int k = tid; k <= 4 * F + 2; k += NT) sTab[k] = table[k];
-  }
-  __syncthreads();
 
   v16f acc[2][2];
 #pragma unroll
@@ -384,76 +362,67 @@ __global__ __launch_bounds__(NT, 2) void neighbor_count_mfma_kernel(
   }
 
   {
-    // gathered row offsets of this thread's 4 + 4 staging pieces
-    const int64_t oa0 = static_cast<int64_t>(idA[NVMK_PIECE_ROW(0)]) * Wp + NVMK_PIECE_SLOT(0);
-    const int64_t oa1 = static_cast<int64_t>(idA[NVMK_PIECE_ROW(1)]) * Wp + NVMK_PIECE_SLOT(1);
-    const int64_t oa2 = static_cast<int64_t>(idA[NVMK_PIECE_ROW(2)]) * Wp + NVMK_PIECE_SLOT(2);
-    const int64_t oa3 = static_cast<int64_t>(idA[NVMK_PIECE_ROW(3)]) * Wp + NVMK_PIECE_SLOT(3);
-    const int64_t ob0 = static_cast<int64_t>(idB[NVMK_PIECE_ROW(0)]) * Wp + NVMK_PIECE_SLOT(0);
-    const int64_t ob1 = static_cast<int64_t>(idB[NVMK_PIECE_ROW(1)]) * Wp + NVMK_PIECE_SLOT(1);
-    const int64_t ob2 = static_cast<int64_t>(idB[NVMK_PIECE_ROW(2)]) * Wp + NVMK_PIECE_SLOT(2);
-    const int64_t ob3 = static_cast<int64_t>(idB[NVMK_PIECE_ROW(3)]) * Wp + NVMK_PIECE_SLOT(3);
-    uint4         ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    const int     nChunks = Wp / KCW;
-    NVMK_FETCH4(ra, X, oa, 0)
-    NVMK_FETCH4(rb, Y, ob, 0)
+    // piece p = (wave * PPW + t) * 64 + lane lands at LDS byte 16 p: row p / KCW, physical slot p % KCW; its source
+    // is the (gathered) row's logical slot physical ^ swz(row)
+    const unsigned prow = static_cast<unsigned>(wave * 32 + (lane >> C::LOG));
+    unsigned       oa[PPW], ob[PPW];  // offsets in uint4 units: < 2^31 rows * Wp is checked by the launcher
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+      const unsigned row  = prow + RPP * t;
+      const unsigned slot = (static_cast<unsigned>(lane) & (KCW - 1u)) ^ C::swz(row);
+      oa[t]               = static_cast<unsigned>(physX(rowA0 + row)) * static_cast<unsigned>(Wp) + slot;
+      ob[t]               = static_cast<unsigned>(physY(rowB0 + row)) * static_cast<unsigned>(Wp) + slot;
+    }
+    const int nChunks = Wp / KCW;
     for (int ch = 0; ch < nChunks; ++ch) {
       if (ch > 0) __syncthreads();
-      NVMK_COMMIT4(ra, sA)
-      NVMK_COMMIT4(rb, sB)
-      __syncthreads();
-      if (ch + 1 < nChunks) {
-        NVMK_FETCH4(ra, X, oa, (ch + 1) * KCW)
-        NVMK_FETCH4(rb, Y, ob, (ch + 1) * KCW)
+#pragma unroll
+      for (int t = 0; t < PPW; ++t) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(X + oa[t] + ch * KCW), (lptr_t)(sA + (wave * PPW + t) * 1024), 16, 0, 0);
       }
+#pragma unroll
+      for (int t = 0; t < PPW; ++t) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(Y + ob[t] + ch * KCW), (lptr_t)(sB + (wave * PPW + t) * 1024), 16, 0, 0);
+      }
+      __syncthreads();
       chunk_mma<KCW>(acc, sA, sB, wm, wn, lane);
     }
   }
 
-  int rc[2][16];
-  int cc[2] = {0, 0};
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rc[mi][r] = 0;
-  }
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int jl  = wn * 64 + ni * 32 + (lane & 31);
-    const int pbv = pcB[jl];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int il  = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int c   = static_cast<int>(acc[mi][ni][r]);
-        const int pav = pcA[il];
-        bool      p;
-        if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-          p = c >= static_cast<int>(sTab[pav + pbv]);
-        } else {
-          p = cosine_neighbor(c, pav, pbv, thr);
-        }
-        rc[mi][r] += p ? 1 : 0;
-        cc[ni] += p ? 1 : 0;
-      }
-    }
-  }
+  // Row counts without LDS traffic: a ballot of the predicate holds one row per 32-lane half (lanes 0-31: row il,
+  // lanes 32-63: row il + 4), its two popcounts are scalar, and a select drops them into the lane that owns the row.
+  // (Shuffle reductions cost 160 ds_bpermute per lane and tile: the 1M x 1M pass ran at 13 us per tile and CU against
+  // 5 us for the dense kernel with the same main loop.)
+  int       cc[2] = {0, 0};
+  int       myRow = 0;  // lane L: neighbours of row wm * 64 + L found in this tile
+  const int pb0   = pcB[wn * 64 + (lane & 31)];
+  const int pb1   = pcB[wn * 64 + 32 + (lane & 31)];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int v = rc[mi][r];
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      v += __shfl_xor(v, 8);
-      v += __shfl_xor(v, 16);
-      if ((lane & 31) == 0 && v != 0) {
-        atomicAdd(&rowsum[wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)], v);
+      const int rowLo = mi * 32 + (r & 3) + 8 * (r >> 2);  // wave-local row of lanes 0-31; lanes 32-63 hold rowLo + 4
+      const int pav   = pcA[wm * 64 + rowLo + 4 * (lane >> 5)];
+      int       lo = 0, hi = 0;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int c   = static_cast<int>(acc[mi][ni][r]);
+        const int pbv = ni ? pb1 : pb0;
+        bool      p;
+        if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+          p = c >= static_cast<int>(table[pav + pbv]);
+        } else {
+          p = cosine_neighbor(c, pav, pbv, thr);
+        }
+        cc[ni] += p ? 1 : 0;
+        const uint64_t m = __ballot(p);
+        lo += __popc(static_cast<unsigned>(m));
+        hi += __popc(static_cast<unsigned>(m >> 32));
       }
+      myRow = (lane == rowLo) ? lo : ((lane == rowLo + 4) ? hi : myRow);  // rows are visited once per tile
     }
   }
+  if (myRow != 0) atomicAdd(&rowsum[wm * 64 + lane], myRow);
   if (creditCols) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -464,12 +433,14 @@ __global__ __launch_bounds__(NT, 2) void neighbor_count_mfma_kernel(
   }
   __syncthreads();
   if (tid < TM) {
-    const int v = rowsum[tid];
-    if (v != 0 && rowA0 + tid < nX) atomicAdd(&counts[cidA[tid]], sign * v);
+    const int     v = rowsum[tid];
+    const int64_t r = rowA0 + tid;
+    if (v != 0 && r < nX) atomicAdd(&counts[xIds ? xIds[r] : physX(r)], sign * v);
   } else if (creditCols) {
-    const int t = tid - TM;
-    const int v = colsum[t];
-    if (v != 0 && rowB0 + t < nY) atomicAdd(&counts[cidB[t]], sign * v);
+    const int     t = tid - TM;
+    const int     v = colsum[t];
+    const int64_t r = rowB0 + t;
+    if (v != 0 && r < nY) atomicAdd(&counts[yIds ? yIds[r] : physY(r)], sign * v);
   }
 }
 
@@ -526,14 +497,22 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   const int     F       = X.L.W * 32;
   const int64_t tilesM  = ceil_div<int64_t>(a.nX, TM);
   const int64_t tilesN  = ceil_div<int64_t>(a.nY, TN);
-  const int64_t superW  = std::min<int64_t>(tilesN, SUPER);
-  const int64_t superM  = ceil_div<int64_t>(tilesM, SUPER);
+  static const int64_t superE = [] {  // supertile edge for this kernel (NVMK_COUNT_SUPER overrides for experiments)
+    const char* e = std::getenv("NVMK_COUNT_SUPER");
+    const int   v = e ? std::atoi(e) : 0;
+    return static_cast<int64_t>(v > 0 ? v : SUPER);
+  }();
+  const int64_t superW  = std::min<int64_t>(tilesN, superE);
+  const int64_t superM  = ceil_div<int64_t>(tilesM, superE);
   const int64_t superN  = ceil_div<int64_t>(tilesN, superW);
-  NVMK_REQUIRE(superM * superN <= 65535 && superN <= 65535, "neighbor counts: problem too large for one launch");
-  const dim3   grid(static_cast<unsigned>(SUPER * superW), static_cast<unsigned>(superM * superN), 1);
-  const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + 8 * 128 * 4 +
-                       (a.metric == NVMK_METRIC_TANIMOTO ? (static_cast<size_t>(4 * F + 3) * 2 + 15) / 16 * 16 : 0);
-  NVMK_REQUIRE(shmem <= 160 * 1024, "neighbor counts: fp_bits %d needs %zu bytes of LDS", F, shmem);
+  const int64_t supers = superM * superN;
+  const int64_t gy     = std::min<int64_t>(supers, 65535);
+  const int64_t gz     = ceil_div<int64_t>(supers, gy);
+  NVMK_REQUIRE(gz <= 65535, "neighbor counts: problem too large for one launch");
+  const dim3   grid(static_cast<unsigned>(superE * superW), static_cast<unsigned>(gy), static_cast<unsigned>(gz));
+  const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + 4 * 128 * 4;
+  NVMK_REQUIRE(std::max(X.L.nPad, Y.L.nPad) * X.L.Wp < (int64_t{1} << 32),
+               "neighbor counts: prepared set too large for 32-bit piece offsets");
   auto kernT = neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO>;
   auto kernC = neighbor_count_mfma_kernel<NVMK_METRIC_COSINE>;
   auto kern  = (a.metric == NVMK_METRIC_TANIMOTO) ? kernT : kernC;
@@ -543,7 +522,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   }
   hipLaunchKernelGGL(kern, grid, dim3(NT), shmem, stream, X.rows, X.popc, a.xRows, a.xIds, a.nX, a.nXdev, Y.rows, Y.popc,
                      a.yRows, a.yIds, a.nY, a.nYdev, X.L.Wp, F, a.table, a.thr, a.sign, a.symmetric ? 1 : 0, counts,
-                     static_cast<unsigned>(superN), static_cast<unsigned>(superW));
+                     static_cast<unsigned>(superN), static_cast<unsigned>(superW), static_cast<unsigned>(superE));
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }
