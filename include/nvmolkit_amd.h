@@ -295,6 +295,9 @@ typedef struct nvmk_etkdg_params {
   double   box_size;           /* 5 * boxSizeMult, or -boxSizeMult if negative (etkdg_stage_coordgen.cu:101-106) */
   double   force_tol;          /* EmbedParameters::optimizerForceTol */
   uint64_t seed;
+  int32_t  batches_per_gpu;    /* concurrent batches (worker threads + streams), BatchHardwareOptions::batchesPerGpu
+                                  (src/hardware_options.h:26-35); <= 1: one batch at a time, bit-reproducible for a
+                                  seed; > 1: faster, but which attempt a molecule gets depends on batch timing */
 } nvmk_etkdg_params;
 
 int nvmk_etkdg_embed(const nvmk_etkdg_molset* mols, const nvmk_etkdg_params* params, double* d_coords,

@@ -97,7 +97,7 @@ class EtkdgParams(ctypes.Structure):
     _fields_ = [("confs_per_mol", ctypes.c_int32), ("max_iterations", ctypes.c_int32), ("batch_size", ctypes.c_int32),
                 ("use_exp_torsions", ctypes.c_int32), ("use_basic_knowledge", ctypes.c_int32),
                 ("enforce_chirality", ctypes.c_int32), ("box_size", ctypes.c_double), ("force_tol", ctypes.c_double),
-                ("seed", ctypes.c_uint64)]
+                ("seed", ctypes.c_uint64), ("batches_per_gpu", ctypes.c_int32)]
 
 
 CHECK_TETRAHEDRAL, CHECK_CHIRAL_VOLUME, CHECK_CHIRAL_DISTANCE = 0, 1, 2

@@ -19,6 +19,9 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <string>
+#include <atomic>
 #include <stdexcept>
 #include <vector>
 
@@ -34,9 +37,12 @@ class Scheduler {
       : confs_(confsPerMol), maxTries_(maxIterations * confsPerMol), completed_(static_cast<size_t>(nMols), 0),
         attempts_(static_cast<size_t>(nMols), 0) {}
 
-  std::vector<int> dispatch(int batchSize) {
+  // `attemptBase` (optional) receives the number of attempts handed out before this call: a unique, scheduler-ordered
+  // id range for the random-coordinate generator
+  std::vector<int> dispatch(int batchSize, uint64_t* attemptBase = nullptr) {
     std::vector<int>            ids;
     const std::lock_guard<std::mutex> lock(mutex_);
+    if (attemptBase) *attemptBase = dispatched_;
     size_t                      prev = 1;
     while (static_cast<int>(ids.size()) < batchSize && prev != ids.size()) {
       prev            = ids.size();
@@ -50,6 +56,7 @@ class Scheduler {
       }
       if (attempts_.back() == limit) ++round_;
     }
+    dispatched_ += ids.size();
     return ids;
   }
 
@@ -67,6 +74,7 @@ class Scheduler {
   int              confs_;
   int              maxTries_;
   int              round_ = 1;
+  uint64_t         dispatched_ = 0;
   std::vector<int> completed_;
   std::vector<int> attempts_;
 };
@@ -321,7 +329,14 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     h_conf_counts[m] = 0;
   }
 
-  Scheduler sched(nMols, prm->confs_per_mol, prm->max_iterations);
+  Scheduler        sched(nMols, prm->confs_per_mol, prm->max_iterations);
+  std::mutex       outMutex;    // h_conf_counts / output slots / h_stage_failures
+  std::atomic<int> firstError{NVMK_OK};
+
+  // One worker = one stream running whole batches (dispatch -> 11 stages -> record -> pack) until the scheduler is
+  // dry.  batches_per_gpu workers run concurrently (the reference's batchesPerGpu, src/etkdg.cpp:330-380): the long
+  // tail of one batch (a handful of systems still iterating, the GPU almost idle) overlaps with the bulk of another.
+  auto worker = [&](hipStream_t stream) -> int {
   DevBuf<int32_t>  dAtomStarts, dSysMol, dRef12Starts, dRef13Starts, dSrcSys;
   DevBuf<int64_t>  dDstOff;
   DevBuf<double>   dPos, dEnergies, dRef12, dRef13;
@@ -329,10 +344,11 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
   DevBuf<int16_t>  dFinished, dStatuses, dFailSum;
   DevBuf<int>      dCount;
   NVMK_HIP_CHECK(dCount.ensure(1));
-  uint64_t attemptBase = 0;
 
   for (;;) {
-    const std::vector<int> ids = sched.dispatch(prm->batch_size);
+    if (firstError.load() != NVMK_OK) return NVMK_OK;
+    uint64_t               attemptBase = 0;
+    const std::vector<int> ids         = sched.dispatch(prm->batch_size, &attemptBase);
     if (ids.empty()) break;
     const int nSys = static_cast<int>(ids.size());
     std::vector<int32_t> atomStarts(static_cast<size_t>(nSys) + 1, 0), r12(static_cast<size_t>(nSys) + 1, 0),
@@ -500,21 +516,24 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     NVMK_HIP_CHECK(hipMemcpyAsync(finished.data(), dFinished.p, finished.size() * 2, hipMemcpyDeviceToHost, stream));
     NVMK_HIP_CHECK(hipMemcpyAsync(failSum.data(), dFailSum.p, failSum.size() * 2, hipMemcpyDeviceToHost, stream));
     NVMK_HIP_CHECK(hipStreamSynchronize(stream));
-    if (h_stage_failures) {
-      for (int st = 0; st < NVMK_ETKDG_N_STAGES; ++st) {
-        for (int s = 0; s < nSys; ++s) h_stage_failures[st] += failSum[static_cast<size_t>(st) * nSys + s];
-      }
-    }
     sched.record(ids.data(), finished.data(), nSys);
     // copy accepted conformers into their output slots (extras beyond confs_per_mol are dropped)
     std::vector<int32_t> src;
     std::vector<int64_t> dst;
-    for (int s = 0; s < nSys; ++s) {
-      const int m = ids[static_cast<size_t>(s)];
-      if (finished[static_cast<size_t>(s)] >= 0 && h_conf_counts[m] < prm->confs_per_mol) {
-        src.push_back(s);
-        dst.push_back(slotStart[static_cast<size_t>(m)] + static_cast<int64_t>(h_conf_counts[m]) * ms->h_n_atoms[m] * 3);
-        ++h_conf_counts[m];
+    {
+      const std::lock_guard<std::mutex> lock(outMutex);
+      if (h_stage_failures) {
+        for (int st = 0; st < NVMK_ETKDG_N_STAGES; ++st) {
+          for (int s = 0; s < nSys; ++s) h_stage_failures[st] += failSum[static_cast<size_t>(st) * nSys + s];
+        }
+      }
+      for (int s = 0; s < nSys; ++s) {
+        const int m = ids[static_cast<size_t>(s)];
+        if (finished[static_cast<size_t>(s)] >= 0 && h_conf_counts[m] < prm->confs_per_mol) {
+          src.push_back(s);
+          dst.push_back(slotStart[static_cast<size_t>(m)] + static_cast<int64_t>(h_conf_counts[m]) * ms->h_n_atoms[m] * 3);
+          ++h_conf_counts[m];
+        }
       }
     }
     if (!src.empty()) {
@@ -527,7 +546,47 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
       NVMK_LAUNCH_CHECK();
       NVMK_HIP_CHECK(hipStreamSynchronize(stream));
     }
-    attemptBase += static_cast<uint64_t>(nSys);
+  }
+  return NVMK_OK;
+  };  // worker
+
+  const int64_t totalAttempts = static_cast<int64_t>(nMols) * prm->confs_per_mol;
+  int           nWorkers      = prm->batches_per_gpu > 1 ? prm->batches_per_gpu : 1;
+  if (totalAttempts <= prm->batch_size) nWorkers = 1;
+  if (nWorkers == 1) return worker(stream);
+
+  int device = 0;
+  NVMK_HIP_CHECK(hipGetDevice(&device));
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // inputs enqueued on the caller's stream are complete
+  std::vector<hipStream_t> streams(static_cast<size_t>(nWorkers), nullptr);
+  for (auto& st : streams) NVMK_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  std::vector<std::string> errors(static_cast<size_t>(nWorkers));
+  auto run = [&](const int w) {
+    if (hipSetDevice(device) != hipSuccess) {
+      firstError.store(NVMK_ERR_HIP);
+      errors[static_cast<size_t>(w)] = "hipSetDevice failed in an ETKDG worker";
+      return;
+    }
+    const int rc = worker(streams[static_cast<size_t>(w)]);
+    if (rc != NVMK_OK) {
+      int expected = NVMK_OK;
+      firstError.compare_exchange_strong(expected, rc);
+      errors[static_cast<size_t>(w)] = nvmk_last_error();  // thread-local message of this worker
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int w = 1; w < nWorkers; ++w) threads.emplace_back(run, w);
+  run(0);
+  for (auto& t : threads) t.join();
+  for (auto& st : streams) (void)hipStreamDestroy(st);  // every batch ended with a stream synchronisation
+  if (firstError.load() != NVMK_OK) {
+    for (const auto& e : errors) {
+      if (!e.empty()) {
+        ::nvmk::set_last_error("%s", e.c_str());
+        break;
+      }
+    }
+    return firstError.load();
   }
   return NVMK_OK;
 }

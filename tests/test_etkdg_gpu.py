@@ -110,3 +110,30 @@ def test_seed_reproducibility_and_validation():
     no_etk, *_ = build([5], seed=1, with_etk=False)
     with pytest.raises(ValueError):
         embed_flat(no_etk, 1)  # ETK stage requested, no ETK terms
+
+
+def test_concurrent_batches_reach_the_same_counts_and_satisfy_bounds():
+    """batches_per_gpu > 1 (reference: HardwareOptions.batchesPerGpu): several batches in flight on their own streams.
+    Which attempt produces a conformer may differ from the serial run, the outcome may not: every feasible molecule
+    gets its conformers and every conformer satisfies its bounds."""
+    sizes = [6, 9, 12, 7, 10, 8, 11, 9]
+    molset, mols, refs, bounds = build(sizes, seed=12, with_etk=True)
+    confs = 4
+    serial = embed_flat(molset, confs_per_molecule=confs, max_iterations=20, batch_size=8, enforce_chirality=False, seed=4)
+    par = embed_flat(molset, confs_per_molecule=confs, max_iterations=20, batch_size=8, enforce_chirality=False, seed=4,
+                     batches_per_gpu=3)
+    assert (serial.conf_counts == confs).all() and (par.conf_counts == confs).all()
+
+    def worst(res):
+        rel = 0.0
+        for m, (pairs, lb, ub) in enumerate(bounds):
+            xyz = res.conformers(m).cpu().numpy()
+            assert np.isfinite(xyz).all()
+            for k in range(confs):
+                d = np.sqrt(((xyz[k][pairs[:, 0]] - xyz[k][pairs[:, 1]]) ** 2).sum(1))
+                rel = max(rel, float((np.maximum(np.maximum(lb - d, d - ub), 0.0) / ub).max()))
+        return rel
+
+    # accepted conformers passed the same stage checks in both modes: the worst bound violation is of the same size
+    w_serial, w_par = worst(serial), worst(par)
+    assert w_par < max(0.1, 2.0 * w_serial), (w_serial, w_par)

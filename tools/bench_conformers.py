@@ -24,6 +24,7 @@ ap.add_argument("--confs", type=int, default=10)
 ap.add_argument("--mean-atoms", type=int, default=48)
 ap.add_argument("--batch-size", type=int, default=4096)
 ap.add_argument("--mmff-iters", type=int, default=200)
+ap.add_argument("--batches-per-gpu", type=int, default=1)
 args = ap.parse_args()
 rng = np.random.default_rng(20260926)
 sizes = np.clip(rng.normal(args.mean_atoms, 12, size=args.mols).round().astype(int), 12, 96)
@@ -33,7 +34,8 @@ molset = FlatMoleculeSet(mols)
 t_prep = time.perf_counter() - t0
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-res = embed_flat(molset, confs_per_molecule=args.confs, max_iterations=10, batch_size=args.batch_size, enforce_chirality=False, seed=1)
+res = embed_flat(molset, confs_per_molecule=args.confs, max_iterations=10, batch_size=args.batch_size, enforce_chirality=False, seed=1,
+                 batches_per_gpu=args.batches_per_gpu)
 torch.cuda.synchronize()
 t_embed = time.perf_counter() - t0
 n_conf = int(res.conf_counts.sum())
