@@ -39,3 +39,72 @@ def all_gather_rows(shard: torch.Tensor, n_total: int, group=None) -> torch.Tens
         lo, hi = shard_bounds(n_total, world, r)
         parts.append(gathered[r * rows: r * rows + (hi - lo)])
     return torch.cat(parts, dim=0)
+
+
+# ---- molecule batches (conformer generation / optimisation): shard, no data-path collective ----------------------
+
+def shard_molecules_by_cost(n_atoms, world_size: int, rank: int, exponent: float = 2.0):
+    """Indices of the molecules rank ``rank`` owns.  Molecules are independent, so the only multi-GPU question is
+    balance: cost per BFGS iteration grows like atoms^2 (inverse-Hessian traffic), so molecules are dealt out largest
+    first to the least loaded rank (LPT), deterministically — every rank computes the same assignment with no
+    communication.  The reference round-robins batches over GPUs (src/etkdg.cpp:330-380, bfgs_mmff.cpp:139-157)."""
+    import numpy as np
+
+    cost = np.asarray(n_atoms, dtype=np.float64) ** exponent
+    order = np.lexsort((np.arange(len(cost)), -cost))  # largest first, index as tie-break
+    load = np.zeros(world_size)
+    owner = np.empty(len(cost), dtype=np.int64)
+    for i in order:
+        r = int(np.argmin(load))  # first minimum: deterministic
+        owner[i] = r
+        load[r] += cost[i]
+    return np.nonzero(owner == rank)[0]
+
+
+def merge_device_results(local, global_mol_ids, n_mols_total: int, group=None):
+    """All-gather per-rank :class:`~nvmolkit_amd.types.Device3DResult` shards into one result ordered by (molecule,
+    conformer) on every rank — the multi-GPU counterpart of the reference's ``finalizeOnTarget``
+    (src/conformer/device_coord_collector.cpp) for ranks that are processes rather than threads.
+
+    ``global_mol_ids[m]`` is the input-batch index of the shard's molecule m.  Not on the hot path: bookkeeping after
+    the embarrassingly parallel work, a few padded all-gathers of the coordinates and per-conformer metadata."""
+    from nvmolkit_amd.types import Device3DResult
+
+    world = dist.get_world_size(group)
+    values = local.values.torch()
+    dev = values.device
+    starts = local.atom_starts.torch().to(torch.int64)
+    sizes = starts[1:] - starts[:-1]
+    gmol = torch.as_tensor(global_mol_ids, dtype=torch.int64, device=dev)[local.mol_indices.torch().to(torch.int64)]
+    conf = local.conf_indices.torch().to(torch.int64)
+    has_e = local.energies is not None
+    meta = torch.tensor([values.shape[0], sizes.numel()], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    max_atoms = max(int(m[0]) for m in metas)
+    max_confs = max(int(m[1]) for m in metas)
+
+    def gather(t: torch.Tensor, rows: int) -> list[torch.Tensor]:
+        buf = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        buf[: t.shape[0]] = t
+        out = torch.empty((rows * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(out, buf, group=group)
+        return [out[r * rows:(r + 1) * rows] for r in range(world)]
+
+    g_vals = gather(values, max_atoms)
+    g_size, g_mol, g_conf = gather(sizes, max_confs), gather(gmol, max_confs), gather(conf, max_confs)
+    g_e = gather(local.energies.torch(), max_confs) if has_e else None
+    g_c = gather(local.converged.torch(), max_confs) if has_e else None
+    vals = torch.cat([g_vals[r][: int(metas[r][0])] for r in range(world)])
+    take = lambda g: torch.cat([g[r][: int(metas[r][1])] for r in range(world)])  # noqa: E731
+    size, mol, cnf = take(g_size), take(g_mol), take(g_conf)
+    order = torch.argsort(mol * (int(cnf.max()) + 1 if cnf.numel() else 1) + cnf, stable=True)
+    old_starts = torch.cumsum(size, 0) - size
+    size_o = size[order]
+    new_starts = torch.zeros(size.numel() + 1, dtype=torch.int64, device=dev)
+    new_starts[1:] = torch.cumsum(size_o, 0)
+    rows = (torch.repeat_interleave(old_starts[order] - new_starts[:-1], size_o) +
+            torch.arange(int(new_starts[-1]), device=dev))
+    return Device3DResult(vals[rows], new_starts.to(torch.int32), mol[order].to(torch.int32), cnf[order].to(torch.int32),
+                          local.gpu_id, n_mols_total,
+                          energies=take(g_e)[order] if has_e else None, converged=take(g_c)[order] if has_e else None)

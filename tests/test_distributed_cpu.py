@@ -63,3 +63,71 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(hi - lo for lo, hi in spans) <= padded_shard_rows(n, world)
+
+
+def _merge_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nvmolkit_amd.distributed import merge_device_results, shard_molecules_by_cost
+    from nvmolkit_amd.types import Device3DResult
+
+    n_atoms = np.array([5, 9, 3, 7, 4, 8, 6])
+    confs = np.array([2, 1, 0, 3, 1, 2, 1])                     # molecule 2 produced nothing
+    mine = shard_molecules_by_cost(n_atoms, world, rank)
+    # synthetic shard: value of atom a of conformer k of global molecule g is (g, k, a)
+    vals, starts, mols, cnfs, energies = [], [0], [], [], []
+    for local_m, g in enumerate(mine):
+        for k in range(confs[g]):
+            for a in range(n_atoms[g]):
+                vals.append((float(g), float(k), float(a)))
+            starts.append(starts[-1] + int(n_atoms[g]))
+            mols.append(local_m)
+            cnfs.append(k)
+            energies.append(100.0 * g + k)
+    local = Device3DResult(torch.tensor(vals, dtype=torch.float64).reshape(-1, 3), torch.tensor(starts, dtype=torch.int32),
+                           torch.tensor(mols, dtype=torch.int32), torch.tensor(cnfs, dtype=torch.int32), 0, len(mine),
+                           energies=torch.tensor(energies, dtype=torch.float64),
+                           converged=torch.ones(len(mols), dtype=torch.int8))
+    merged = merge_device_results(local, mine, len(n_atoms))
+    torch.save({"values": merged.values.torch(), "starts": merged.atom_starts.torch(), "mols": merged.mol_indices.torch(),
+                "confs": merged.conf_indices.torch(), "energies": merged.energies.torch(), "mine": torch.from_numpy(mine)},
+               os.path.join(out_dir, f"merged{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_molecule_sharding_and_result_merge(tmp_path):
+    """Molecule batches shard with no data-path collective; the per-rank Device3DResult shards merge
+    into the single-process order on every rank."""
+    from nvmolkit_amd.distributed import shard_molecules_by_cost
+
+    world = 2
+    mp.spawn(_merge_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    out = [torch.load(tmp_path / f"merged{r}.pt") for r in range(world)]
+    n_atoms = np.array([5, 9, 3, 7, 4, 8, 6])
+    confs = np.array([2, 1, 0, 3, 1, 2, 1])
+    owned = np.sort(np.concatenate([o["mine"].numpy() for o in out]))
+    assert owned.tolist() == list(range(len(n_atoms)))                       # a partition
+    loads = [float((n_atoms[o["mine"].numpy()] ** 2).sum()) for o in out]
+    assert max(loads) / min(loads) < 1.3                                     # balanced by atoms^2
+    for key in ("values", "starts", "mols", "confs", "energies"):
+        assert torch.equal(out[0][key], out[1][key])                        # every rank holds the same merged result
+    m = out[0]
+    want_mols = np.repeat(np.arange(len(n_atoms)), confs)
+    assert m["mols"].tolist() == want_mols.tolist()
+    assert m["confs"].tolist() == [k for g in range(len(n_atoms)) for k in range(confs[g])]
+    assert m["energies"].tolist() == [100.0 * g + k for g in range(len(n_atoms)) for k in range(confs[g])]
+    starts = m["starts"].tolist()
+    for c, (g, k) in enumerate(zip(m["mols"].tolist(), m["confs"].tolist())):
+        block = m["values"][starts[c]:starts[c + 1]]
+        assert block.shape == (n_atoms[g], 3)
+        assert torch.equal(block[:, 0], torch.full((n_atoms[g],), float(g), dtype=torch.float64))
+        assert torch.equal(block[:, 1], torch.full((n_atoms[g],), float(k), dtype=torch.float64))
+        assert torch.equal(block[:, 2], torch.arange(n_atoms[g], dtype=torch.float64))
+    # determinism and edge cases of the assignment
+    assert shard_molecules_by_cost(n_atoms, 1, 0).tolist() == list(range(len(n_atoms)))
+    assert shard_molecules_by_cost([], 4, 2).tolist() == []
+    parts = [shard_molecules_by_cost(np.full(10, 20), 4, r) for r in range(4)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(10)) and max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

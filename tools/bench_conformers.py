@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""Throughput of the conformer path on synthetic flattened molecules (BASELINE.json configs[2] shape):
+"""Throughput of the conformer path on synthetic flattened molecules (BASELINE.json configs[2] / configs[3] shape):
 ETKDG with numConfs conformers per molecule, then MMFF94 optimisation of every conformer.
-Usage: python tools/bench_conformers.py [--mols 1000] [--confs 10] [--mean-atoms 48]"""
+Usage: python tools/bench_conformers.py [--mols 1000] [--confs 10] [--mean-atoms 48]
+Multi-GPU (configs[3]): python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+  tools/bench_conformers.py --mols M   -- `--mols` is the WHOLE batch; molecules are dealt to ranks by cost
+  (nvmolkit_amd.distributed.shard_molecules_by_cost), no data-path collective; times are the max over ranks."""
+import os
 import argparse
 import json
 import sys
@@ -26,8 +30,22 @@ ap.add_argument("--batch-size", type=int, default=4096)
 ap.add_argument("--mmff-iters", type=int, default=200)
 ap.add_argument("--batches-per-gpu", type=int, default=1)
 args = ap.parse_args()
+world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+if world > 1:
+    import torch.distributed as dist
+
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl")
 rng = np.random.default_rng(20260926)
-sizes = np.clip(rng.normal(args.mean_atoms, 12, size=args.mols).round().astype(int), 12, 96)
+all_sizes = np.clip(rng.normal(args.mean_atoms, 12, size=args.mols).round().astype(int), 12, 96)
+if world > 1:
+    from nvmolkit_amd.distributed import shard_molecules_by_cost
+
+    sizes = all_sizes[shard_molecules_by_cost(all_sizes, world, rank)]
+    rng = np.random.default_rng(20260926 + 1 + rank)
+else:
+    sizes = all_sizes
+args.mols = len(sizes)
 t0 = time.perf_counter()
 mols = [FlatMolecule(**util.synthetic_embed_molecule(rng, int(n), with_etk=True)[0]) for n in sizes]
 molset = FlatMoleculeSet(mols)
@@ -62,8 +80,19 @@ for lo in range(0, args.mols, max(1, args.batch_size // args.confs)):
     t_mmff += time.perf_counter() - t0
     total_iters += int(it.sum())
     done += len(sub)
+if world > 1:  # whole-job numbers: sums of work, max of time
+    t = torch.tensor([t_embed, t_mmff], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor([n_conf, done, total_iters, args.mols], dtype=torch.float64, device="cuda")
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    t_embed, t_mmff = float(t[0]), float(t[1])
+    n_conf, done, total_iters, args.mols = (int(x) for x in c.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank != 0:
+        sys.exit(0)
 print(json.dumps({
-    "mols": args.mols, "confs_per_mol": args.confs, "mean_atoms": float(sizes.mean()),
+    "n_gpus": world, "mols": args.mols, "confs_per_mol": args.confs, "mean_atoms": float(all_sizes.mean()),
     "etkdg_s": t_embed, "etkdg_conformers": n_conf, "etkdg_confs_per_s": n_conf / t_embed,
     "etkdg_stage_failures": dict(zip(STAGE_NAMES, res.stage_failures.tolist())),
     "mmff_s": t_mmff, "mmff_conformers": done, "mmff_confs_per_s": done / t_mmff, "mmff_bfgs_iterations": total_iters,
