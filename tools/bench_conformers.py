@@ -19,8 +19,7 @@ import torch  # noqa: E402
 
 from nvmolkit_amd.embedMolecules import STAGE_NAMES, FlatMolecule, FlatMoleculeSet, embed_flat  # noqa: E402
 from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch  # noqa: E402
-from oracle import ff as off  # noqa: E402  (layout constants only; nothing from the oracle is executed on the timed path)
-from tests import util  # noqa: E402
+from nvmolkit_amd import synthetic as util  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--mols", type=int, default=1000)
