@@ -24,6 +24,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <hipcub/hipcub.hpp>
+
 #include "common.h"
 #include "fp4.h"
 
@@ -324,6 +326,12 @@ inline bool force_mfma() {
   return e != nullptr && std::strcmp(e, "mfma") == 0;
 }
 
+// NVMK_BUTINA_ROUNDS=dense keeps the round loop that streams the fingerprint matrix (tests run both formulations)
+inline bool dense_rounds() {
+  const char* e = std::getenv("NVMK_BUTINA_ROUNDS");
+  return e != nullptr && std::strcmp(e, "dense") == 0;
+}
+
 struct CountPlan {
   int             metric;
   int             fpBits;
@@ -561,6 +569,188 @@ __global__ void reset_round_kernel(LoopState* __restrict__ st, int32_t* __restri
   *nAliveNextOfNextRound   = 0;
 }
 
+// ===================== fused Butina on the sparse neighbour graph =================================
+// At a useful threshold the neighbour graph is sparse (mean degree ~50 at N = 1M): the first all-pairs pass also
+// emits every neighbour pair once (matrix-core kernel, EMIT), the pairs become a CSR adjacency, and a round then
+// touches only the centroid's list and its members' lists instead of streaming the whole fingerprint matrix twice
+// (extract: packed rows, subtract: FP4 rows — 1.3 GB per round at N = 1M, 223 us per round measured).
+// Semantics are the oracle's (oracle_similarity.c orc_butina_fused): centroid = LAST row with the maximal degree;
+// rows whose degree is 1 in a round that picks another centroid are harvested as singletons — a row's degree drops
+// to 1 only in some round's subtract, so the harvest of round k + 1 is exactly the list L collected in round k
+// (L0 = rows that start at degree 1); when no row of degree >= 2 is left, the last (highest) row of L becomes a
+// greedy cluster of its own and the rest are singletons, as in the dense-round formulation.
+
+__global__ void edge_degree_kernel(const int2* __restrict__ edges, const unsigned long long nEdges,
+                                   unsigned long long* __restrict__ deg) {
+  for (unsigned long long e = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; e < nEdges;
+       e += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+    const int2 p = edges[e];
+    atomicAdd(&deg[p.x], 1ull);
+    atomicAdd(&deg[p.y], 1ull);
+  }
+}
+
+__global__ void csr_fill_kernel(const int2* __restrict__ edges, const unsigned long long nEdges,
+                                const unsigned long long* __restrict__ offsets, unsigned int* __restrict__ cursor,
+                                int32_t* __restrict__ nbr) {
+  for (unsigned long long e = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; e < nEdges;
+       e += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+    const int2 p                                 = edges[e];
+    nbr[offsets[p.x] + atomicAdd(&cursor[p.x], 1u)] = p.y;
+    nbr[offsets[p.y] + atomicAdd(&cursor[p.y], 1u)] = p.x;
+  }
+}
+
+// alive = 1 everywhere; L0 = rows whose degree (self included) is exactly 1
+__global__ void sparse_init_kernel(const int32_t n, const int32_t* __restrict__ counts, uint8_t* __restrict__ alive,
+                                   int32_t* __restrict__ L0, int32_t* __restrict__ nL0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  alive[i] = 1;
+  if (counts[i] == 1) L0[atomicAdd(nL0, 1)] = i;
+}
+
+// argmax of the degree over alive rows with degree >= 2, ties toward the HIGHEST row (clustering.py:159)
+__global__ __launch_bounds__(NT) void sparse_argmax_kernel(LoopState* __restrict__ st, const int32_t n,
+                                                           const uint8_t* __restrict__ alive,
+                                                           const int32_t* __restrict__ counts, const int parity) {
+  if (st->done) return;
+  unsigned long long best = 0ull;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NT + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * NT) {
+    const int32_t c = counts[i];
+    if (c >= 2 && alive[i]) {
+      const unsigned long long key = (static_cast<unsigned long long>(c) << 32) | static_cast<unsigned>(i);
+      best                         = key > best ? key : best;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(best, o);
+    best                           = other > best ? other : best;
+  }
+  __shared__ unsigned long long wbest[NT / 64];
+  if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < NT / 64; ++w) best = wbest[w] > best ? wbest[w] : best;
+    if (best != 0ull) atomicMax(&st->bestKey[parity], best);
+  }
+}
+
+// One round on ONE workgroup: harvest L, extract the centroid's cluster, subtract its members from their live
+// neighbours and collect the rows that drop to degree 1.
+__global__ __launch_bounds__(NT) void sparse_round_kernel(LoopState* __restrict__ st, const unsigned long long* __restrict__ offsets,
+                                                          const int32_t* __restrict__ nbr, uint8_t* __restrict__ alive,
+                                                          int32_t* __restrict__ counts, int32_t* __restrict__ clusterIdx,
+                                                          int32_t* __restrict__ clusterOffsets, int32_t* __restrict__ centroids,
+                                                          int32_t* __restrict__ L0, int32_t* __restrict__ L1,
+                                                          int32_t* __restrict__ nL, const int parity) {
+  if (st->done) return;
+  __shared__ int sCount;   // members found / rows added to the next L
+  __shared__ int sMaxRow;
+  const int                tid   = threadIdx.x;
+  const unsigned long long key   = st->bestKey[parity];
+  int32_t*                 Lcur  = parity ? L1 : L0;
+  int32_t*                 Lnext = parity ? L0 : L1;
+  const int                nLcur = nL[parity];
+  if (tid == 0) {
+    sCount  = 0;
+    sMaxRow = -1;
+  }
+  __syncthreads();
+  if (key == 0ull) {
+    // no row of degree >= 2 is left: the highest row of L is this round's centroid (a cluster of one), the others
+    // are harvested; nothing else can change afterwards
+    for (int i = tid; i < nLcur; i += NT) atomicMax(&sMaxRow, Lcur[i]);
+    __syncthreads();
+    const int last = sMaxRow;
+    const int back = st->back;
+    if (last >= 0) {
+      for (int i = tid; i < nLcur; i += NT) {
+        const int r = Lcur[i];
+        alive[r]    = 0;
+        if (r != last) clusterIdx[back - atomicAdd(&sCount, 1)] = r;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (last >= 0) {
+        const int k           = st->nClusters;
+        const int front       = st->front;
+        clusterIdx[front]     = last;
+        centroids[k]          = last;
+        clusterOffsets[k + 1] = front + 1;
+        st->front             = front + 1;
+        st->nClusters         = k + 1;
+        st->back              = back - sCount;
+      }
+      st->done = 1;
+    }
+    return;
+  }
+  const int centroid = static_cast<int>(key & 0xffffffffull);
+  const int front    = st->front;
+  const int back     = st->back;
+  // harvest: rows that reached degree 1 in the previous round (they have no live neighbour, nobody touches them)
+  for (int i = tid; i < nLcur; i += NT) {
+    const int r              = Lcur[i];
+    alive[r]                 = 0;
+    clusterIdx[back - i]     = r;
+  }
+  // members = live neighbours of the centroid; they and the centroid leave the live set
+  const unsigned long long o0 = offsets[centroid], o1 = offsets[centroid + 1];
+  if (tid == 0) {
+    clusterIdx[front] = centroid;
+    alive[centroid]   = 0;
+  }
+  for (unsigned long long k = o0 + tid; k < o1; k += NT) {
+    const int j = nbr[k];
+    if (alive[j]) {
+      clusterIdx[front + 1 + atomicAdd(&sCount, 1)] = j;
+      alive[j]                                      = 0;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int total = 1 + sCount;
+  __syncthreads();
+  if (tid == 0) sCount = 0;
+  __syncthreads();
+  // subtract: every live neighbour of a member loses one; 16 lanes per member
+  const int g = tid >> 4, l = tid & 15;
+  for (int q = g; q < total; q += NT / 16) {
+    const int                m  = clusterIdx[front + q];
+    const unsigned long long a0 = offsets[m], a1 = offsets[m + 1];
+    for (unsigned long long k = a0 + l; k < a1; k += 16) {
+      const int j = nbr[k];
+      if (alive[j]) {
+        const int old = atomicSub(&counts[j], 1);
+        if (old == 2) Lnext[atomicAdd(&sCount, 1)] = j;  // only itself left: next round's harvest
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int k           = st->nClusters;
+    centroids[k]          = centroid;
+    clusterOffsets[k + 1] = front + total;
+    st->nClusters         = k + 1;
+    st->front             = front + total;
+    st->back              = back - nLcur;
+    st->lastMax           = static_cast<int32_t>(key >> 32);
+    st->bestKey[parity]   = 0ull;  // consumed; the argmax of round + 2 accumulates into it again
+    nL[parity]            = 0;
+    nL[parity ^ 1]        = sCount;
+  }
+}
+
+// rows that never had a neighbour (degree 0: all-zero fingerprints) join the singleton tail
+__global__ void sparse_leftover_kernel(LoopState* __restrict__ st, const int32_t n, const uint8_t* __restrict__ alive,
+                                       const int32_t* __restrict__ counts, int32_t* __restrict__ clusterIdx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && alive[i] && counts[i] == 0) clusterIdx[atomicSub(&st->back, 1)] = i;
+}
+
 template <int METRIC>
 int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_t* h_idx, int64_t* h_offsets,
                int32_t* h_centroids, int64_t* n_clusters, hipStream_t stream) {
@@ -627,18 +817,107 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
     return launch_counts(plan, d_x, xRows, nX, nXdev, d_x, yRows, nY, nYdev, sign, counts, stream);
   };
 
-  // first pass: all-vs-all degrees (upper triangle of tiles only on the matrix-core path)
-  rc = count_pass(nullptr, N, nullptr, nullptr, N, nullptr, +1, true);
+  // first pass: all-vs-all degrees (upper triangle of tiles only on the matrix-core path); the matrix-core kernel
+  // also emits the neighbour pairs for the sparse-graph round loop
+  const unsigned long long edgeCap =
+    useMfma && !dense_rounds() ? std::min<unsigned long long>(static_cast<unsigned long long>(N) * 128ull, (1ull << 30) - 1ull) : 0ull;
+  StreamScratch edgeMem;
+  int2*               edges      = nullptr;
+  unsigned long long* edgeCursor = nullptr;
+  if (edgeCap > 0) {
+    NVMK_HIP_CHECK(edgeMem.alloc(256 + edgeCap * sizeof(int2), stream));
+    edgeCursor = edgeMem.as<unsigned long long>();
+    edges      = reinterpret_cast<int2*>(edgeMem.as<char>() + 256);
+    NVMK_HIP_CHECK(hipMemsetAsync(edgeCursor, 0, 256, stream));
+    fp4::CountArgs a{};
+    a.metric       = METRIC;
+    a.thr          = thr;
+    a.table        = plan.table;
+    a.sign         = +1;
+    a.nX           = N;
+    a.nY           = N;
+    a.symmetric    = true;
+    a.edges        = edges;
+    a.edgeCursor   = edgeCursor;
+    a.edgeCapacity = edgeCap;
+    rc             = fp4::launch_counts(a, PX, PX, counts, stream);
+  } else {
+    rc = count_pass(nullptr, N, nullptr, nullptr, N, nullptr, +1, true);
+  }
   if (rc != NVMK_OK) return rc;
 
-  // round loop, enqueued in batches; the host only reads the state word between batches
+  LoopState snap{};
+  bool      sparseDone = false;
+  if (edgeCap > 0) {
+    unsigned long long nEdges = 0;
+    NVMK_HIP_CHECK(hipMemcpyAsync(&nEdges, edgeCursor, sizeof(nEdges), hipMemcpyDeviceToHost, stream));
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    if (nEdges <= edgeCap) {  // otherwise: too dense for the edge buffer, the dense rounds below handle it
+      // CSR: degrees -> exclusive scan -> fill
+      StreamScratch csrMem, scanTmp;
+      const size_t  offBytes = (n + 1) * sizeof(unsigned long long);
+      const size_t  nbrBytes = std::max<size_t>(1, static_cast<size_t>(2 * nEdges)) * sizeof(int32_t);
+      // layout: deg[n+1] | offsets[n+1] | cursor[n] (u32) | L0[n] | L1[n] | alive[n] (u8) | nbr[2E]
+      const size_t bytes = 2 * offBytes + n * 4 * 3 + (n + 15) / 16 * 16 + nbrBytes + 64;
+      NVMK_HIP_CHECK(csrMem.alloc(bytes, stream));
+      auto* deg     = csrMem.as<unsigned long long>();
+      auto* offs64  = deg + (n + 1);
+      auto* cursor  = reinterpret_cast<unsigned int*>(offs64 + (n + 1));
+      auto* L0      = reinterpret_cast<int32_t*>(cursor + n);
+      auto* L1      = L0 + n;
+      auto* aliveF  = reinterpret_cast<uint8_t*>(L1 + n);
+      auto* nbr     = reinterpret_cast<int32_t*>(aliveF + (n + 15) / 16 * 16);
+      NVMK_HIP_CHECK(hipMemsetAsync(deg, 0, 2 * offBytes + n * 4, stream));  // deg, offsets, cursor
+      const unsigned eBlocks = static_cast<unsigned>(std::min<unsigned long long>(ceil_div<unsigned long long>(std::max<unsigned long long>(nEdges, 1), 256), 65535));
+      if (nEdges > 0) {
+        hipLaunchKernelGGL(edge_degree_kernel, dim3(eBlocks), dim3(256), 0, stream, edges, nEdges, deg);
+        NVMK_LAUNCH_CHECK();
+      }
+      size_t tmpBytes = 0;
+      NVMK_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, deg, offs64, static_cast<int>(n + 1), stream));
+      NVMK_HIP_CHECK(scanTmp.alloc(tmpBytes, stream));
+      NVMK_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp.ptr, tmpBytes, deg, offs64, static_cast<int>(n + 1), stream));
+      if (nEdges > 0) {
+        hipLaunchKernelGGL(csr_fill_kernel, dim3(eBlocks), dim3(256), 0, stream, edges, nEdges, offs64, cursor, nbr);
+        NVMK_LAUNCH_CHECK();
+      }
+      int32_t* nL = nAliveNext;  // [2], zeroed above with the state block
+      hipLaunchKernelGGL(sparse_init_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
+                         static_cast<int32_t>(N), counts, aliveF, L0, &nL[0]);
+      NVMK_LAUNCH_CHECK();
+      const unsigned argBlocks = static_cast<unsigned>(std::min<int64_t>(ceil_div<int64_t>(N, NT * 4), 1024));
+      int64_t        round     = 0;
+      for (;;) {
+        for (int b = 0; b < 64; ++b, ++round) {
+          const int parity = static_cast<int>(round & 1);
+          hipLaunchKernelGGL(sparse_argmax_kernel, dim3(argBlocks), dim3(NT), 0, stream, st, static_cast<int32_t>(N), aliveF,
+                             counts, parity);
+          hipLaunchKernelGGL(sparse_round_kernel, dim3(1), dim3(NT), 0, stream, st, offs64, nbr, aliveF, counts, clusterIdx,
+                             offsets, centroids, L0, L1, nL, parity);
+        }
+        NVMK_LAUNCH_CHECK();
+        NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
+        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+        if (snap.done) break;
+      }
+      hipLaunchKernelGGL(sparse_leftover_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
+                         st, static_cast<int32_t>(N), aliveF, counts, clusterIdx);
+      NVMK_LAUNCH_CHECK();
+      NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
+      NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // csrMem / scanTmp are released in stream order after this
+      snap.nAlive = 0;                               // leftovers already sit in the singleton tail
+      sparseDone  = true;
+    }
+  }
+
+  // dense round loop (small N, VALU path, or a graph too dense for the edge buffer), enqueued in batches; the host only
+  // reads the state word between batches
   const auto* x4        = reinterpret_cast<const uint4*>(d_x);
   int64_t     aliveHost = N;  // upper bound on the device-side nAlive
   int64_t     maxDegree = N;  // upper bound on any later cluster size (degrees only decrease)
   int64_t     round     = 0;
-  LoopState   snap{};
   int         batch = 1;      // first sync after one round: learns the real max degree
-  for (;;) {
+  for (; !sparseDone;) {
     for (int b = 0; b < batch; ++b, ++round) {
       const int      parity   = static_cast<int>(round & 1);
       const int32_t* aliveIn  = parity ? alive1 : alive0;

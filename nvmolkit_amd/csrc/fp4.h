@@ -81,6 +81,11 @@ struct CountArgs {
   int64_t         nY;
   const int32_t*  nYdev;
   bool            symmetric;
+  // optional (symmetric mode only): also emit every neighbour pair i < j once as (i, j) into `edges`; `edgeCursor`
+  // counts ALL pairs found (it may pass `edgeCapacity`: the caller checks and falls back), device pointers
+  int2*               edges        = nullptr;
+  unsigned long long* edgeCursor   = nullptr;
+  unsigned long long  edgeCapacity = 0;
 };
 int launch_counts(const CountArgs& args, const Prepared& X, const Prepared& Y, int32_t* counts, hipStream_t stream);
 

@@ -286,14 +286,15 @@ __device__ __forceinline__ bool cosine_neighbor(const int c, const int pa, const
   return static_cast<float>(c) / denom >= thr;
 }
 
-template <int METRIC>
+template <int METRIC, bool EMIT>
 __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   const uint4* __restrict__ X, const int32_t* __restrict__ popX, const int32_t* __restrict__ xRows,
   const int32_t* __restrict__ xIds, int64_t nX,
   const int32_t* __restrict__ nXdev, const uint4* __restrict__ Y, const int32_t* __restrict__ popY,
   const int32_t* __restrict__ yRows, const int32_t* __restrict__ yIds, int64_t nY, const int32_t* __restrict__ nYdev, const int Wp, const int F,
   const uint16_t* __restrict__ table, const float thr, const int sign, const int symmetric, int32_t* __restrict__ counts, const unsigned superN,
-  const unsigned superW, const unsigned superH) {
+  const unsigned superW, const unsigned superH, int2* __restrict__ edges, unsigned long long* __restrict__ edgeCursor,
+  const unsigned long long edgeCapacity) {
   constexpr int KCW = 8;
   constexpr int PPW = KCW / 2;
   constexpr int RPP = 64 / KCW;
@@ -418,6 +419,25 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
         const uint64_t m = __ballot(p);
         lo += __popc(static_cast<unsigned>(m));
         hi += __popc(static_cast<unsigned>(m >> 32));
+        if constexpr (EMIT) {
+          // neighbour pairs are rare (mean degree / N of all pairs): almost every ballot is empty and skips this.
+          // Symmetric un-gathered mode only: logical row == physical row.  Pairs i < j once; the diagonal tile
+          // holds both orientations and the self pairs, which are dropped here.
+          const int64_t gi = rowA0 + wm * 64 + rowLo + 4 * (lane >> 5);
+          const int64_t gj = rowB0 + wn * 64 + ni * 32 + (lane & 31);
+          const bool    e  = p && gi < gj && gi < nX && gj < nY;
+          const uint64_t me = __ballot(e);
+          if (me != 0) {
+            unsigned long long base = 0;
+            const int          first = __ffsll(static_cast<long long>(me)) - 1;
+            if (lane == first) base = atomicAdd(edgeCursor, static_cast<unsigned long long>(__popcll(me)));
+            base = __shfl(base, first);
+            if (e) {
+              const unsigned long long slot = base + __popcll(me & ((1ull << lane) - 1ull));
+              if (slot < edgeCapacity) edges[slot] = make_int2(static_cast<int>(gi), static_cast<int>(gj));
+            }
+          }
+        }
       }
       myRow = (lane == rowLo) ? lo : ((lane == rowLo + 4) ? hi : myRow);  // rows are visited once per tile
     }
@@ -513,16 +533,23 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + 4 * 128 * 4;
   NVMK_REQUIRE(std::max(X.L.nPad, Y.L.nPad) * X.L.Wp < (int64_t{1} << 32),
                "neighbor counts: prepared set too large for 32-bit piece offsets");
-  auto kernT = neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO>;
-  auto kernC = neighbor_count_mfma_kernel<NVMK_METRIC_COSINE>;
-  auto kern  = (a.metric == NVMK_METRIC_TANIMOTO) ? kernT : kernC;
-  if (shmem > 64 * 1024) {
-    NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(shmem)));
+  const bool emit = a.edges != nullptr;
+  NVMK_REQUIRE(!emit || (a.symmetric && a.xRows == nullptr && a.yRows == nullptr && a.edgeCursor != nullptr),
+               "neighbor counts: edge emission needs the symmetric, un-gathered mode and a cursor");
+  using Kern = void (*)(const uint4*, const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, const uint4*,
+                        const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, int, int, const uint16_t*,
+                        float, int, int, int32_t*, unsigned, unsigned, unsigned, int2*, unsigned long long*,
+                        unsigned long long);
+  Kern kern;
+  if (a.metric == NVMK_METRIC_TANIMOTO) {
+    kern = emit ? neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, true> : neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, false>;
+  } else {
+    kern = emit ? neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, true> : neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, false>;
   }
   hipLaunchKernelGGL(kern, grid, dim3(NT), shmem, stream, X.rows, X.popc, a.xRows, a.xIds, a.nX, a.nXdev, Y.rows, Y.popc,
                      a.yRows, a.yIds, a.nY, a.nYdev, X.L.Wp, F, a.table, a.thr, a.sign, a.symmetric ? 1 : 0, counts,
-                     static_cast<unsigned>(superN), static_cast<unsigned>(superW), static_cast<unsigned>(superE));
+                     static_cast<unsigned>(superN), static_cast<unsigned>(superW), static_cast<unsigned>(superE), a.edges,
+                     a.edgeCursor, a.edgeCapacity);
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }

@@ -12,11 +12,17 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["valu", "mfma", "auto"], autouse=True)
+@pytest.fixture(params=["valu", "mfma", "mfma:dense", "auto"], autouse=True)
 def sim_path(request, monkeypatch):
-    """Neighbour counting / fused Butina run on the v_bcnt kernels, on the FP4 matrix-core kernels and on
-    the library's automatic choice (NVMK_SIM_PATH is read per call by butina.hip)."""
-    monkeypatch.setenv("NVMK_SIM_PATH", request.param)
+    """Neighbour counting / fused Butina run on the v_bcnt kernels, on the FP4 matrix-core kernels (round loop on the
+    sparse neighbour graph, and the dense round loop that streams the fingerprint matrix) and on the library's automatic
+    choice (NVMK_SIM_PATH / NVMK_BUTINA_ROUNDS are read per call by butina.hip)."""
+    path, _, rounds = request.param.partition(":")
+    monkeypatch.setenv("NVMK_SIM_PATH", path)
+    if rounds:
+        monkeypatch.setenv("NVMK_BUTINA_ROUNDS", rounds)
+    else:
+        monkeypatch.delenv("NVMK_BUTINA_ROUNDS", raising=False)
     return request.param
 
 METRICS = {"tanimoto": oracle.TANIMOTO, "cosine": oracle.COSINE}
@@ -89,6 +95,35 @@ def test_fused_butina_edge_cases():
     assert sorted(c[0] for c in cl) == list(range(5)) and sizes[-1] == 5
     empty = torch.zeros((0, 4), dtype=torch.int32, device="cuda")
     assert fused_butina(empty, 0.5) == ([], [0])
+
+
+@pytest.mark.parametrize("cutoff", [0.02, 0.1, 0.3])
+def test_fused_butina_prefix_chain(cutoff):
+    """Row i = the first i bits set (row 0 is empty): similarity min(i, j) / max(i, j) makes a banded neighbour graph
+    full of equal degrees, rows that drop to degree 1 round after round, and one degree-0 row — the tie-break
+    (last row wins), the singleton harvest and the end-game of the round loop all show up in the output."""
+    n = 300
+    idx = np.arange(n)
+    words = 16
+    full = idx[:, None] // 32 > np.arange(words)[None, :]
+    part = idx[:, None] // 32 == np.arange(words)[None, :]
+    rem = ((np.uint64(1) << (idx % 32).astype(np.uint64)) - np.uint64(1)).astype(np.uint32)
+    x = np.where(full, np.uint32(0xFFFFFFFF), np.where(part, rem[:, None], np.uint32(0))).astype(np.uint32)
+    got = fused_butina(dev(x), cutoff, return_centroids=True)
+    want = oracle.butina_fused(x, cutoff)
+    assert got[1] == want[1] and got[2] == want[2] and got[0] == want[0]
+
+
+def test_fused_butina_dense_graph_falls_back():
+    """More neighbour pairs than the edge buffer holds (128 per row): the sparse-graph loop hands over to the round
+    loop that streams the fingerprint matrix, same result."""
+    base = util.random_fingerprints(1, 64, density=0.3)
+    x = np.repeat(base, 700, axis=0)
+    x[np.arange(700), np.arange(700) % 64] ^= np.uint32(1) << (np.arange(700) % 32).astype(np.uint32)  # near-duplicates
+    got = fused_butina(dev(x), 0.5, return_centroids=True)
+    want = oracle.butina_fused(x, 0.5)
+    assert got[1] == want[1] and got[2] == want[2] and got[0] == want[0]
+    assert len(got[0]) == 1 and len(got[0][0]) == 700
 
 
 def test_fused_butina_argument_validation():
