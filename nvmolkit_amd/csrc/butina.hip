@@ -66,7 +66,10 @@ template <int METRIC> __device__ __forceinline__ bool is_neighbor(const int c, c
 
 // tmin[s], s = pa + pb in [0, 2*F]: smallest c with float(c)/float(s-c) >= thr (NEVER if none);
 // entries (2F, 4F+2] are NEVER so that a sentinel popcount of 2F+1 disables a padded row or column.
-__global__ void build_tanimoto_table_kernel(uint16_t* __restrict__ table, const int F, const float thr) {
+// tableF holds the same thresholds as floats (+inf for NEVER): the matrix-core kernel compares its f32 accumulators
+// (exact integers) against it without a conversion.
+__global__ void build_tanimoto_table_kernel(uint16_t* __restrict__ table, float* __restrict__ tableF, const int F,
+                                            const float thr) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > 4 * F + 2) return;
   uint16_t v = NEVER;
@@ -84,7 +87,8 @@ __global__ void build_tanimoto_table_kernel(uint16_t* __restrict__ table, const 
     }
     if (lo < s) v = static_cast<uint16_t>(lo);
   }
-  table[s] = v;
+  table[s]  = v;
+  tableF[s] = (v == NEVER) ? __builtin_inff() : static_cast<float>(v);
 }
 
 // ---- staging helpers -------------------------------------------------------------------------
@@ -337,6 +341,7 @@ struct CountPlan {
   int             fpBits;
   float           thr;
   const uint16_t* table;  // device, Tanimoto only
+  const float*    tableF; // the same thresholds as floats (+inf = never)
 };
 
 template <int METRIC>
@@ -397,13 +402,17 @@ int make_plan(CountPlan& plan, StreamScratch& tableMem, int metric, int fpBits, 
   plan.fpBits = fpBits;
   plan.thr    = thr;
   plan.table  = nullptr;
+  plan.tableF = nullptr;
   if (metric == NVMK_METRIC_TANIMOTO) {
-    const int entries = 4 * fpBits + 3;
-    NVMK_HIP_CHECK(tableMem.alloc(static_cast<size_t>(entries) * sizeof(uint16_t), stream));
+    const int    entries = 4 * fpBits + 3;
+    const size_t u16Bytes = (static_cast<size_t>(entries) * sizeof(uint16_t) + 255) / 256 * 256;
+    NVMK_HIP_CHECK(tableMem.alloc(u16Bytes + static_cast<size_t>(entries) * sizeof(float), stream));
+    auto* tf = reinterpret_cast<float*>(tableMem.as<char>() + u16Bytes);
     hipLaunchKernelGGL(build_tanimoto_table_kernel, dim3(ceil_div(entries, 256)), dim3(256), 0, stream,
-                       tableMem.as<uint16_t>(), fpBits, thr);
+                       tableMem.as<uint16_t>(), tf, fpBits, thr);
     NVMK_LAUNCH_CHECK();
-    plan.table = tableMem.as<uint16_t>();
+    plan.table  = tableMem.as<uint16_t>();
+    plan.tableF = tf;
   }
   return NVMK_OK;
 }
@@ -804,6 +813,7 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
       a.metric    = METRIC;
       a.thr       = thr;
       a.table     = plan.table;
+      a.tableF    = plan.tableF;
       a.sign      = sign;
       a.xRows     = xRows;
       a.nX        = nX;
@@ -833,6 +843,7 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
     a.metric       = METRIC;
     a.thr          = thr;
     a.table        = plan.table;
+    a.tableF       = plan.tableF;
     a.sign         = +1;
     a.nX           = N;
     a.nY           = N;
@@ -1157,6 +1168,7 @@ int nvmk_neighbor_counts(int metric, const uint32_t* d_x, const int32_t* d_x_row
   a.metric = metric;
   a.thr    = threshold;
   a.table  = plan.table;
+  a.tableF = plan.tableF;
   a.sign   = sign;
   a.xIds   = d_x_rows;
   a.nX     = nX;

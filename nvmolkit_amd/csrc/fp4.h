@@ -71,6 +71,7 @@ struct CountArgs {
   int             metric;
   float           thr;
   const uint16_t* table;    // Tanimoto threshold table with 4F + 3 entries (butina.hip), device
+  const float*    tableF;   // the same thresholds as floats, +inf = never (what the kernel reads)
   int             sign;
   const int32_t*  xRows;    // logical -> physical row of X (NULL: identity)
   const int32_t*  xIds;     // logical row -> index into counts (NULL: the physical row)

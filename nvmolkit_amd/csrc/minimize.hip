@@ -638,7 +638,7 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ H, const int n, c
   }
 }
 
-// PROFILE (NVMK_BFGS_PROFILE=1, DG and MMFF only): thread 0 accumulates wall-clock ticks (100 MHz) per phase into
+// PROFILE (NVMK_BFGS_PROFILE=1; DG, ETK and MMFF): thread 0 accumulates wall-clock ticks (100 MHz) per phase into
 // prof[sys * 8 + k]: 0 line-search energy evaluations, 1 gradient, 2 pass over H (pending update + H g), 3 update scalars + direction,
 // 4 whole kernel, 5 iterations, 6 energy evaluations.
 template <int KIND, bool PROFILE = false>
@@ -981,7 +981,7 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
     const char* e = std::getenv("NVMK_BFGS_PROFILE");
     return e != nullptr && e[0] == '1';
   }();
-  if (profile && (b.kind == NVMK_FF_DG || b.kind == NVMK_FF_MMFF)) {
+  if (profile && (b.kind == NVMK_FF_DG || b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_ETK)) {
     StreamScratch profMem;
     const size_t  words = static_cast<size_t>(b.nSystems) * 8;
     NVMK_HIP_CHECK(profMem.alloc(words * sizeof(int64_t), stream));
@@ -990,6 +990,10 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
       hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_DG, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters,
                          grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies, d_statuses,
                          d_iters, profMem.as<int64_t>());
+    } else if (b.kind == NVMK_FF_ETK) {
+      hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_ETK, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1,
+                         max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies,
+                         d_statuses, d_iters, profMem.as<int64_t>());
     } else {
       hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_MMFF, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1,
                          max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies,

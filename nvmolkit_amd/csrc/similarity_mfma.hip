@@ -15,6 +15,7 @@
 // 256-byte bank row.
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "fp4.h"
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   const int32_t* __restrict__ xIds, int64_t nX,
   const int32_t* __restrict__ nXdev, const uint4* __restrict__ Y, const int32_t* __restrict__ popY,
   const int32_t* __restrict__ yRows, const int32_t* __restrict__ yIds, int64_t nY, const int32_t* __restrict__ nYdev, const int Wp, const int F,
-  const uint16_t* __restrict__ table, const float thr, const int sign, const int symmetric, int32_t* __restrict__ counts, const unsigned superN,
+  const float* __restrict__ table, const float thr, const int sign, const int symmetric, int32_t* __restrict__ counts, const unsigned superN,
   const unsigned superW, const unsigned superH, int2* __restrict__ edges, unsigned long long* __restrict__ edgeCursor,
   const unsigned long long edgeCapacity) {
   constexpr int KCW = 8;
@@ -314,6 +315,9 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   // supertile map over the HOST-side upper bounds (gridDim), exits against the device-side sizes.  A
   // supertile is superH x superW tiles; superW < superH for skinny problems (a Butina subtract pass has one
   // column tile: a square 64 x 64 map would launch 63 empty workgroups per working one).
+  // One workgroup per tile.  (A persistent variant — 4 workgroups per CU striding over the tile list — was measured
+  // 40 % SLOWER: statically strided workgroups run phase-locked, so the four on a CU load together and then compute
+  // together instead of covering each other.)
   const unsigned sidx   = blockIdx.z * gridDim.y + blockIdx.y;  // supertile index (grid y and z are 16-bit each)
   const unsigned sm     = sidx / superN;
   const unsigned sn     = sidx - sm * superN;
@@ -398,22 +402,26 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   int       myRow = 0;  // lane L: neighbours of row wm * 64 + L found in this tile
   const int pb0   = pcB[wn * 64 + (lane & 31)];
   const int pb1   = pcB[wn * 64 + 32 + (lane & 31)];
+  // The epilogue is VALU-issue bound (4 waves per SIMD run it back to back: 40 VALU cycles per pair cost 3.4 us per
+  // tile and CU).  Kept lean: thresholds are floats compared against the f32 accumulators (exact integers, no
+  // conversion), the table offset is one add per pair (byte offsets of row and column popcounts prepared once).
+  const unsigned pbOff0 = static_cast<unsigned>(pb0) * 4u, pbOff1 = static_cast<unsigned>(pb1) * 4u;
+  const char*    tabB   = reinterpret_cast<const char*>(table);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int rowLo = mi * 32 + (r & 3) + 8 * (r >> 2);  // wave-local row of lanes 0-31; lanes 32-63 hold rowLo + 4
-      const int pav   = pcA[wm * 64 + rowLo + 4 * (lane >> 5)];
-      int       lo = 0, hi = 0;
+      const int      rowLo = mi * 32 + (r & 3) + 8 * (r >> 2);  // wave-local row of lanes 0-31; lanes 32-63 hold rowLo + 4
+      const int      pav   = pcA[wm * 64 + rowLo + 4 * (lane >> 5)];
+      const unsigned paOff = static_cast<unsigned>(pav) * 4u;
+      int            lo = 0, hi = 0;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int c   = static_cast<int>(acc[mi][ni][r]);
-        const int pbv = ni ? pb1 : pb0;
-        bool      p;
+        bool p;
         if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-          p = c >= static_cast<int>(table[pav + pbv]);
+          p = acc[mi][ni][r] >= *reinterpret_cast<const float*>(tabB + (paOff + (ni ? pbOff1 : pbOff0)));
         } else {
-          p = cosine_neighbor(c, pav, pbv, thr);
+          p = cosine_neighbor(static_cast<int>(acc[mi][ni][r]), pav, ni ? pb1 : pb0, thr);
         }
         cc[ni] += p ? 1 : 0;
         const uint64_t m = __ballot(p);
@@ -423,23 +431,27 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
           // neighbour pairs are rare (mean degree / N of all pairs): almost every ballot is empty and skips this.
           // Symmetric un-gathered mode only: logical row == physical row.  Pairs i < j once; the diagonal tile
           // holds both orientations and the self pairs, which are dropped here.
-          const int64_t gi = rowA0 + wm * 64 + rowLo + 4 * (lane >> 5);
-          const int64_t gj = rowB0 + wn * 64 + ni * 32 + (lane & 31);
-          const bool    e  = p && gi < gj && gi < nX && gj < nY;
-          const uint64_t me = __ballot(e);
-          if (me != 0) {
-            unsigned long long base = 0;
-            const int          first = __ffsll(static_cast<long long>(me)) - 1;
-            if (lane == first) base = atomicAdd(edgeCursor, static_cast<unsigned long long>(__popcll(me)));
-            base = __shfl(base, first);
-            if (e) {
-              const unsigned long long slot = base + __popcll(me & ((1ull << lane) - 1ull));
-              if (slot < edgeCapacity) edges[slot] = make_int2(static_cast<int>(gi), static_cast<int>(gj));
+          if (m != 0) {
+            const int64_t  gi = rowA0 + wm * 64 + rowLo + 4 * (lane >> 5);
+            const int64_t  gj = rowB0 + wn * 64 + ni * 32 + (lane & 31);
+            const bool     e  = p && gi < gj && gi < nX && gj < nY;
+            const uint64_t me = __ballot(e);
+            if (me != 0) {
+              unsigned long long base  = 0;
+              const int          first = __ffsll(static_cast<long long>(me)) - 1;
+              if (lane == first) base = atomicAdd(edgeCursor, static_cast<unsigned long long>(__popcll(me)));
+              base = __shfl(base, first);
+              if (e) {
+                const unsigned long long slot = base + __popcll(me & ((1ull << lane) - 1ull));
+                if (slot < edgeCapacity) edges[slot] = make_int2(static_cast<int>(gi), static_cast<int>(gj));
+              }
             }
           }
         }
       }
-      myRow = (lane == rowLo) ? lo : ((lane == rowLo + 4) ? hi : myRow);  // rows are visited once per tile
+      // drop the two scalar row counts into the lanes that own rows rowLo and rowLo + 4 (v_writelane: lane select in M0)
+      asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myRow) : "s"(lo), "s"(rowLo));
+      asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myRow) : "s"(hi), "s"(rowLo + 4));
     }
   }
   if (myRow != 0) atomicAdd(&rowsum[wm * 64 + lane], myRow);
@@ -514,6 +526,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   if (a.nX <= 0 || a.nY <= 0) return NVMK_OK;
   NVMK_REQUIRE(X.L.Wp == Y.L.Wp && X.L.W == Y.L.W, "prepared sets have different fingerprint widths");
   NVMK_REQUIRE(counts != nullptr, "neighbor counts: NULL counts");
+  NVMK_REQUIRE(a.metric != NVMK_METRIC_TANIMOTO || a.tableF != nullptr, "neighbor counts: missing threshold table");
   const int     F       = X.L.W * 32;
   const int64_t tilesM  = ceil_div<int64_t>(a.nX, TM);
   const int64_t tilesN  = ceil_div<int64_t>(a.nY, TN);
@@ -537,7 +550,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   NVMK_REQUIRE(!emit || (a.symmetric && a.xRows == nullptr && a.yRows == nullptr && a.edgeCursor != nullptr),
                "neighbor counts: edge emission needs the symmetric, un-gathered mode and a cursor");
   using Kern = void (*)(const uint4*, const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, const uint4*,
-                        const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, int, int, const uint16_t*,
+                        const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, int, int, const float*,
                         float, int, int, int32_t*, unsigned, unsigned, unsigned, int2*, unsigned long long*,
                         unsigned long long);
   Kern kern;
@@ -547,7 +560,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
     kern = emit ? neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, true> : neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, false>;
   }
   hipLaunchKernelGGL(kern, grid, dim3(NT), shmem, stream, X.rows, X.popc, a.xRows, a.xIds, a.nX, a.nXdev, Y.rows, Y.popc,
-                     a.yRows, a.yIds, a.nY, a.nYdev, X.L.Wp, F, a.table, a.thr, a.sign, a.symmetric ? 1 : 0, counts,
+                     a.yRows, a.yIds, a.nY, a.nYdev, X.L.Wp, F, a.tableF, a.thr, a.sign, a.symmetric ? 1 : 0, counts,
                      static_cast<unsigned>(superN), static_cast<unsigned>(superW), static_cast<unsigned>(superE), a.edges,
                      a.edgeCursor, a.edgeCapacity);
   NVMK_LAUNCH_CHECK();
