@@ -303,6 +303,24 @@ typedef struct nvmk_etkdg_params {
 int nvmk_etkdg_embed(const nvmk_etkdg_molset* mols, const nvmk_etkdg_params* params, double* d_coords,
                      int32_t* h_conf_counts, int32_t* h_stage_failures, void* stream);
 
+/* ---- conformer RMSD matrices and RMS pruning (the step right after the embedding) ---------
+ * Replaces conformerRmsdBatchMatrixGpu (src/conformer_rmsd.h:58-85, src/conformer_rmsd.cu:262-392) and the CPU pruning loop
+ * of addConformersToMoleculeWithPruning (rdkit_extensions/conformer_pruning.cpp:88-137).
+ * Molecule m has n_confs[m] conformers of n_atoms[m] atoms at d_coords[coord_offsets[m] + (conf * n_atoms[m] + atom) * 3 + xyz];
+ * its n (n - 1) / 2 pair values start at d_out[pair_offsets[m]] in condensed lower-triangle order: pair (i, j), i > j, at
+ * i (i - 1) / 2 + j (the order of RDKit's GetConformerRMSMatrix).  prealigned != 0: plain RMSD of the raw coordinates;
+ * otherwise each pair is optimally superimposed first (Kabsch, proper rotations only).  All pointers are device pointers;
+ * pair_offsets has n_mols + 1 entries with pair_offsets[n_mols] == total_pairs.
+ */
+int nvmk_conformer_rmsd_batch(const double* d_coords, const int64_t* d_coord_offsets, const int32_t* d_n_atoms,
+                              const int64_t* d_pair_offsets, int n_mols, int64_t total_pairs, int prealigned, double* d_out,
+                              void* stream);
+
+/* Greedy pruning on the matrices above: conformer i of a molecule is kept (d_keep[conf_starts[m] + i] = 1) iff its RMSD
+ * to every conformer kept before it is >= threshold.  conf_starts has n_mols + 1 entries. */
+int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, const int32_t* d_conf_starts, int n_mols,
+                         double threshold, uint8_t* d_keep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

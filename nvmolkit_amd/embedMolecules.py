@@ -141,11 +141,16 @@ class FlatEmbedResult:
 def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterations: int = -1, batch_size: int = -1,
                use_exp_torsions: bool = True, use_basic_knowledge: bool = True, enforce_chirality: bool = True,
                box_size_mult: float = 2.0, force_tol: float = 1e-3, seed: int = 42, stream=None,
-               output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, batches_per_gpu: int = 1):
+               output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, batches_per_gpu: int = 1,
+               prune_rms_thresh: float = -1.0, prune_atom_subsets=None):
     """ETKDG on flattened molecules (reference pipeline: src/etkdg.cpp:90-484 downstream of RDKit).
 
     Returns a :class:`FlatEmbedResult`, or with ``output=CoordinateOutput.DEVICE`` a :class:`Device3DResult` that the
     MMFF / UFF ``optimize_device`` entry points consume without a host round trip.
+
+    ``prune_rms_thresh`` > 0 (EmbedParameters.pruneRmsThresh) prunes the conformers of every molecule on the GPU after the
+    embedding (``conformerRmsd.prune_conformers``; ``prune_atom_subsets[m]`` = atom indices for onlyHeavyAtomsForRMS) and
+    needs ``output=DEVICE`` here — the reference prunes on the CPU and therefore only with RDKit conformer output.
 
     ``batches_per_gpu`` > 1 runs that many batches concurrently on their own streams (HardwareOptions.batchesPerGpu):
     kept for parity with the reference's option, default 1.  Measured on MI355X with the default 4096-attempt batches it
@@ -161,6 +166,8 @@ def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterati
         max_iterations = 10 * int(n_atoms.max()) if len(n_atoms) else 1
     if max_iterations <= 0:
         raise ValueError("maxIterations must be greater than 0 (or -1 for automatic)")
+    if prune_rms_thresh > 0.0 and output != CoordinateOutput.DEVICE:
+        raise ValueError("prune_rms_thresh needs output=CoordinateOutput.DEVICE in embed_flat")
     etk_on = (use_exp_torsions or use_basic_knowledge)
     if etk_on and not molset.has_etk:
         raise ValueError("the ETK stage needs ETK term groups on every molecule")
@@ -185,7 +192,14 @@ def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterati
                                             fails.ctypes.data, sptr)
     _native.check(rc, "nvmk_etkdg_embed")
     res = FlatEmbedResult(coords, counts, slot_starts[:-1], fails, n_atoms)
-    return res.to_device_result() if output == CoordinateOutput.DEVICE else res
+    if output != CoordinateOutput.DEVICE:
+        return res
+    dev = res.to_device_result()
+    if prune_rms_thresh > 0.0:
+        from nvmolkit_amd.conformerRmsd import prune_conformers
+
+        dev = prune_conformers(dev, float(prune_rms_thresh), prune_atom_subsets)
+    return dev
 
 
 def EmbedMolecules(molecules, params, confsPerMolecule: int = 1, maxIterations: int = -1,

@@ -1,0 +1,41 @@
+"""CPU oracle for conformer RMSD matrices and RMS pruning — TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+numpy restatement of the reference's math (src/conformer_rmsd.cu:133-258: centre, cross-covariance H, singular values,
+RMSD^2 = (Sp + Sq - 2 (s0 + s1 + sgn(det H) s2)) / N; prealigned = plain RMSD of the raw coordinates) with LAPACK's SVD in
+place of the closed-form eigenvalues, and of the greedy pruning loop (rdkit_extensions/conformer_pruning.cpp:88-137).
+Pinned by closed forms in tests/test_oracle_rmsd.py: rigid motions give 0, a mirror image does not, known displacements."""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def pair_rmsd(a: np.ndarray, b: np.ndarray, prealigned: bool = False) -> float:
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    n = len(a)
+    if prealigned:
+        return float(np.sqrt(((a - b) ** 2).sum() / n))
+    p, q = a - a.mean(0), b - b.mean(0)
+    h = p.T @ q
+    s = np.linalg.svd(h, compute_uv=False)
+    if np.linalg.det(h) < 0.0:
+        s[2] = -s[2]
+    return float(np.sqrt(max(((p * p).sum() + (q * q).sum() - 2.0 * s.sum()) / n, 0.0)))
+
+
+def rms_matrix(confs: np.ndarray, prealigned: bool = False) -> np.ndarray:
+    """Condensed lower triangle: pair (i, j), i > j, at i (i - 1) / 2 + j (RDKit GetConformerRMSMatrix order)."""
+    n = len(confs)
+    out = np.zeros(n * (n - 1) // 2)
+    for i in range(1, n):
+        for j in range(i):
+            out[i * (i - 1) // 2 + j] = pair_rmsd(confs[i], confs[j], prealigned)
+    return out
+
+
+def prune(confs: np.ndarray, threshold: float) -> np.ndarray:
+    """Boolean keep mask of the greedy pruning."""
+    keep = np.zeros(len(confs), dtype=bool)
+    for i in range(len(confs)):
+        keep[i] = all(pair_rmsd(confs[i], confs[k]) >= threshold for k in range(i) if keep[k])
+    return keep
