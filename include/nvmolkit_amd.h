@@ -187,6 +187,12 @@ int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uint32_t* d_bo
  *     g0 bond idx(i, j) par(restLen, k)             g1 angle idx(1,2,3) par(theta0, k, order, C0, C1, C2)
  *     g2 torsion idx(1..4) par(k, order, cosTerm)   g3 inversion idx(1..4) par(k, C0, C1, C2)
  *     g4 vdW idx(i, j) par(x_ij, wellDepth, threshold)
+ *   Constraint groups (optional, MMFF: g7..g10, UFF: g5..g8; NULL starts = none; reference terms
+ *   src/forcefields/mmff_kernels_device.cuh:663-1036, SoA mmff.h:101-145):
+ *     distance idx(i, j) par(minLen, maxLen, k)         E = k/2 d^2 outside [minLen, maxLen]
+ *     position idx(i) par(x, y, z, maxDispl, k)          E = k/2 max(|p - ref| - maxDispl, 0)^2
+ *     angle idx(1, 2, 3) par(minDeg, maxDeg, k)          E = k dTheta^2 [deg^2]
+ *     torsion idx(1..4) par(minDeg, maxDeg, k)           E = k dPhi^2 [deg^2], signed dihedral, periodic window
  *   NVMK_FF_QUARTIC: the synthetic field of the reference's BFGS tests (tests/test_bfgs_minimizer.cu:823-860),
  *     E = sum (x_p - p)^4 over global coordinate index p; w0 != 0 includes every atom's 4th coordinate.
  * All pointers inside the struct are DEVICE pointers; the struct itself is passed by host pointer.
@@ -207,7 +213,7 @@ typedef struct nvmk_ff_batch {
   int32_t        kind;
   int32_t        n_systems;
   const int32_t* atom_starts; /* device, [n_systems + 1] */
-  nvmk_ff_group  groups[8];
+  nvmk_ff_group  groups[12];
   /* Optional (NULL / 0 = unused).  system_mol: the term tables are per MOLECULE and system s reads row
    * system_mol[s] of every `starts` array — conformers of one molecule share one copy of the tables (the
    * reference replicates them per conformer, src/forcefields/mmff.h:327-344).  group_mask: bit g enables group g

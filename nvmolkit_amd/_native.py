@@ -76,7 +76,7 @@ class FFBatch(ctypes.Structure):
     """Mirror of ``nvmk_ff_batch`` (include/nvmolkit_amd.h)."""
 
     _fields_ = [("kind", ctypes.c_int32), ("n_systems", ctypes.c_int32), ("atom_starts", ctypes.c_void_p),
-                ("groups", FFGroup * 8), ("system_mol", ctypes.c_void_p), ("group_mask", ctypes.c_uint32),
+                ("groups", FFGroup * 12), ("system_mol", ctypes.c_void_p), ("group_mask", ctypes.c_uint32),
                 ("etk_ref12_starts", ctypes.c_void_p), ("etk_ref12", ctypes.c_void_p),
                 ("etk_ref13_starts", ctypes.c_void_p), ("etk_ref13", ctypes.c_void_p)]
 

@@ -1,0 +1,386 @@
+"""Object API for batched MMFF / UFF force fields with constraints (reference: nvmolkit/batchedForcefield.py:95-714 over
+src/forcefields/forcefield_constraints.cpp:128-232 and the constraint terms of mmff_kernels_device.cuh:663-1036).
+
+``MMFFBatchedForcefield(molecules, ...)`` / ``UFFBatchedForcefield(molecules, ...)`` keep the reference's constructors,
+``ff[i].add_*_constraint(...)`` element API, ``compute_energy()`` / ``compute_gradients()`` nested-list results and
+``minimize(maxIters, forceTol, output)``.  They need RDKit for typing (the flatteners of mmffOptimization /
+uffOptimization).  ``FlatBatchedForcefield(kind, tables, conformers)`` is the same object on flattened term tables and
+coordinate arrays — the seam the tests exercise.
+
+Constraints are resolved per conformer when the batch is built, as in the reference: ``relative`` bounds are offsets from
+the conformer's current distance / angle / dihedral and position restraints anchor at its current coordinates.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from nvmolkit_amd.forcefield import CONSTRAINT_LAYOUT, GROUP_LAYOUT, MMFF, UFF, FlatForcefieldBatch
+from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
+
+__all__ = ["FlatBatchedForcefield", "MMFFBatchedForcefield", "UFFBatchedForcefield"]
+
+
+@dataclass
+class _DistanceConstraint:
+    idx1: int
+    idx2: int
+    relative: bool
+    min_len: float
+    max_len: float
+    force_constant: float
+
+
+@dataclass
+class _PositionConstraint:
+    idx: int
+    max_displ: float
+    force_constant: float
+
+
+@dataclass
+class _AngleConstraint:
+    idx1: int
+    idx2: int
+    idx3: int
+    relative: bool
+    min_angle_deg: float
+    max_angle_deg: float
+    force_constant: float
+
+
+@dataclass
+class _TorsionConstraint:
+    idx1: int
+    idx2: int
+    idx3: int
+    idx4: int
+    relative: bool
+    min_dihedral_deg: float
+    max_dihedral_deg: float
+    force_constant: float
+
+
+def _normalize_deg(a: float) -> float:
+    a = float(np.fmod(a, 360.0))
+    if a < -180.0:
+        a += 360.0
+    elif a > 180.0:
+        a -= 360.0
+    return a
+
+
+def _angle_deg(xyz, i, j, k) -> float:
+    r1, r2 = xyz[i] - xyz[j], xyz[k] - xyz[j]
+    l1, l2 = max(float(r1 @ r1), 1e-5), max(float(r2 @ r2), 1e-5)
+    return float(np.degrees(np.arccos(np.clip(float(r1 @ r2) / np.sqrt(l1 * l2), -1.0, 1.0))))
+
+
+def _dihedral_deg(xyz, i, j, k, l) -> float:  # noqa: E741
+    r0, r1, r3 = xyz[i] - xyz[j], xyz[k] - xyz[j], xyz[l] - xyz[k]
+    t0, t1 = np.cross(r0, r1), np.cross(-r1, r3)
+    t0 = t0 / max(float(np.linalg.norm(t0)), 1e-5)
+    t1 = t1 / max(float(np.linalg.norm(t1)), 1e-5)
+    cos_phi = float(np.clip(t0 @ t1, -1.0, 1.0))
+    m = np.cross(t0, r1)
+    return float(np.degrees(-np.arctan2(float(m @ t1) / max(float(np.linalg.norm(m)), 1e-5), cos_phi)))
+
+
+def _resolve_constraints(xyz: np.ndarray, dist, posn, ang, tors):
+    """Constraint specs of one molecule + the coordinates of ONE conformer -> the four (idx, par) groups
+    (forcefield_constraints.cpp:128-232: relative bounds, anchors, validation)."""
+    rows = [[], [], [], []]
+    for c in dist:
+        lo, hi = c.min_len, c.max_len
+        if hi < lo:
+            raise ValueError("Distance constraint maxLen must be >= minLen")
+        if c.relative:
+            d = float(np.linalg.norm(xyz[c.idx1] - xyz[c.idx2]))
+            lo, hi = max(lo + d, 0.0), max(hi + d, 0.0)
+        rows[0].append((c.idx1, c.idx2, lo, hi, c.force_constant))
+    for c in posn:
+        rows[1].append((c.idx, *xyz[c.idx], c.max_displ, c.force_constant))
+    for c in ang:
+        lo, hi = c.min_angle_deg, c.max_angle_deg
+        if hi < lo:
+            raise ValueError("Angle constraint maxAngleDeg must be >= minAngleDeg")
+        if c.relative:
+            a = _angle_deg(xyz, c.idx1, c.idx2, c.idx3)
+            lo, hi = lo + a, hi + a
+        if lo < 0.0 or lo > 180.0 or hi < 0.0 or hi > 180.0:
+            raise ValueError("Angle constraint bounds must be within [0, 180]")
+        rows[2].append((c.idx1, c.idx2, c.idx3, lo, hi, c.force_constant))
+    for c in tors:
+        lo, hi = c.min_dihedral_deg, c.max_dihedral_deg
+        if hi < lo:
+            raise ValueError("Torsion constraint maxDihedralDeg must be >= minDihedralDeg")
+        if c.relative:
+            d = _dihedral_deg(xyz, c.idx1, c.idx2, c.idx3, c.idx4)
+            lo, hi = lo + d, hi + d
+        rows[3].append((c.idx1, c.idx2, c.idx3, c.idx4, _normalize_deg(lo), _normalize_deg(hi), c.force_constant))
+    out = []
+    for r, (n_idx, n_par) in zip(rows, CONSTRAINT_LAYOUT):
+        a = np.array(r, dtype=np.float64).reshape(-1, n_idx + n_par)
+        out.append((a[:, :n_idx].astype(np.int32), a[:, n_idx:]))
+    return out
+
+
+class _BatchElement:
+    """``ff[i]``: one molecule of the batch; constraints added here apply to all of its conformers."""
+
+    def __init__(self, parent, idx: int):
+        self._parent = parent
+        self._idx = idx
+
+    @property
+    def num_atoms(self) -> int:
+        return self._parent._n_atoms[self._idx]
+
+    def add_distance_constraint(self, idx1: int, idx2: int, relative: bool, min_len: float, max_len: float,
+                                force_constant: float) -> None:
+        self._parent._validate_atom_indices(self._idx, idx1, idx2)
+        self._parent._distance_constraints[self._idx].append(
+            _DistanceConstraint(int(idx1), int(idx2), bool(relative), float(min_len), float(max_len), float(force_constant)))
+        self._parent._dirty = True
+
+    def add_position_constraint(self, idx: int, max_displ: float, force_constant: float) -> None:
+        self._parent._validate_atom_indices(self._idx, idx)
+        self._parent._position_constraints[self._idx].append(_PositionConstraint(int(idx), float(max_displ), float(force_constant)))
+        self._parent._dirty = True
+
+    def add_angle_constraint(self, idx1: int, idx2: int, idx3: int, relative: bool, min_angle_deg: float, max_angle_deg: float,
+                             force_constant: float) -> None:
+        self._parent._validate_atom_indices(self._idx, idx1, idx2, idx3)
+        self._parent._angle_constraints[self._idx].append(
+            _AngleConstraint(int(idx1), int(idx2), int(idx3), bool(relative), float(min_angle_deg), float(max_angle_deg),
+                             float(force_constant)))
+        self._parent._dirty = True
+
+    def add_torsion_constraint(self, idx1: int, idx2: int, idx3: int, idx4: int, relative: bool, min_dihedral_deg: float,
+                               max_dihedral_deg: float, force_constant: float) -> None:
+        self._parent._validate_atom_indices(self._idx, idx1, idx2, idx3, idx4)
+        self._parent._torsion_constraints[self._idx].append(
+            _TorsionConstraint(int(idx1), int(idx2), int(idx3), int(idx4), bool(relative), float(min_dihedral_deg),
+                               float(max_dihedral_deg), float(force_constant)))
+        self._parent._dirty = True
+
+
+class FlatBatchedForcefield:
+    """A batch of molecules, each with its term tables and conformer coordinates, as ONE force-field object.
+
+    Args:
+        kind: ``forcefield.MMFF`` or ``forcefield.UFF``.
+        tables: ``tables[m]`` = the molecule's base term groups ``[(idx, par), ...]`` (include/nvmolkit_amd.h).
+        conformers: ``conformers[m]`` = array (n_confs_m, n_atoms_m, 3); updated in place by :meth:`minimize`.
+    """
+
+    def __init__(self, kind: int, tables: Sequence, conformers: Sequence[np.ndarray], device="cuda"):
+        if kind not in (MMFF, UFF):
+            raise ValueError("kind must be forcefield.MMFF or forcefield.UFF")
+        if len(tables) != len(conformers):
+            raise ValueError("one term table and one conformer array per molecule")
+        self.kind = kind
+        self.device = torch.device(device)
+        self._tables = list(tables)
+        self._conformers = [np.ascontiguousarray(c, dtype=np.float64).reshape(len(c), -1, 3) for c in conformers]
+        self._n_atoms = [int(c.shape[1]) for c in self._conformers]
+        n = len(self._tables)
+        self._distance_constraints = [[] for _ in range(n)]
+        self._position_constraints = [[] for _ in range(n)]
+        self._angle_constraints = [[] for _ in range(n)]
+        self._torsion_constraints = [[] for _ in range(n)]
+        self._batch = None
+        self._dirty = True
+        self.num_molecules = n
+        self.data_dim = 3
+
+    # ---- container protocol ----
+    def __len__(self) -> int:
+        return self.num_molecules
+
+    def __getitem__(self, idx: int) -> _BatchElement:
+        if idx < 0 or idx >= self.num_molecules:
+            raise IndexError(f"Batch element index {idx} out of range")
+        return _BatchElement(self, idx)
+
+    def _validate_atom_indices(self, batch_idx: int, *indices: int) -> None:
+        num_atoms = self._n_atoms[batch_idx]
+        for idx in indices:
+            if idx < 0 or idx >= num_atoms:
+                raise IndexError(f"Atom index {idx} out of range for molecule {batch_idx} with {num_atoms} atoms")
+
+    # ---- build ----
+    def _has_constraints(self) -> bool:
+        return any(any(lst) for group in (self._distance_constraints, self._position_constraints, self._angle_constraints,
+                                          self._torsion_constraints) for lst in group)
+
+    def _build(self) -> None:
+        self._systems = [(m, k) for m, c in enumerate(self._conformers) for k in range(len(c))]
+        atom_starts = np.zeros(len(self._systems) + 1, dtype=np.int32)
+        for s, (m, _) in enumerate(self._systems):
+            atom_starts[s + 1] = atom_starts[s] + self._n_atoms[m]
+        self._atom_starts = atom_starts
+        layout = list(GROUP_LAYOUT[self.kind])
+        constrained = self._has_constraints()
+        if constrained:
+            layout += CONSTRAINT_LAYOUT
+        per_system = []
+        for m, k in self._systems:
+            groups = list(self._tables[m])
+            if constrained:  # resolved against THIS conformer's coordinates
+                groups += _resolve_constraints(self._conformers[m][k], self._distance_constraints[m],
+                                               self._position_constraints[m], self._angle_constraints[m],
+                                               self._torsion_constraints[m])
+            per_system.append(groups)
+        stacked = []
+        for g, (n_idx, n_par) in enumerate(layout):
+            starts = np.zeros(len(per_system) + 1, dtype=np.int32)
+            for s, groups in enumerate(per_system):
+                starts[s + 1] = starts[s] + len(groups[g][0])
+            idx = (np.concatenate([np.asarray(groups[g][0], dtype=np.int32).reshape(-1, n_idx) for groups in per_system])
+                   if per_system else np.zeros((0, n_idx), dtype=np.int32))
+            par = (np.concatenate([np.asarray(groups[g][1], dtype=np.float64).reshape(-1, n_par) for groups in per_system])
+                   if per_system else np.zeros((0, n_par)))
+            stacked.append((starts, idx, par))
+        self._batch = FlatForcefieldBatch(self.kind, atom_starts, stacked, device=self.device)
+        self._dirty = False
+
+    def rebuild(self) -> None:
+        """Re-resolve the constraints against the current coordinates and rebuild the device batch."""
+        self._build()
+
+    def _ensure_built(self) -> None:
+        if self._dirty or self._batch is None:
+            self._build()
+
+    def _positions(self) -> torch.Tensor:
+        flat = (np.concatenate([self._conformers[m][k].reshape(-1) for m, k in self._systems]) if self._systems
+                else np.zeros(0))
+        return torch.from_numpy(flat).to(self.device)
+
+    def _nest(self, values):
+        out = [[] for _ in range(self.num_molecules)]
+        for (m, _), v in zip(self._systems, values):
+            out[m].append(v)
+        return out
+
+    # ---- evaluation ----
+    def compute_energy(self) -> list[list[float]]:
+        """``result[mol][conf]``: one energy per conformer."""
+        if self.num_molecules == 0:
+            return []
+        self._ensure_built()
+        return self._nest([float(e) for e in self._batch.compute_energy(self._positions()).cpu().numpy()])
+
+    def compute_gradients(self) -> list[list[list[float]]]:
+        """``result[mol][conf]``: the flattened ``[x0, y0, z0, ...]`` gradient of every conformer."""
+        if self.num_molecules == 0:
+            return []
+        self._ensure_built()
+        g = self._batch.compute_gradient(self._positions()).cpu().numpy()
+        return self._nest([g[3 * self._atom_starts[s]:3 * self._atom_starts[s + 1]].tolist() for s in range(len(self._systems))])
+
+    def minimize(self, maxIters: int = 200, forceTol: float = 1e-4,
+                 output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, targetGpu: int | None = None):
+        """BFGS-minimise every conformer.  ``RDKIT_CONFORMERS``: coordinates are written back (into the stored arrays, and
+        into RDKit conformers when the batch was built from molecules) and ``(energies, converged)`` nested lists are
+        returned; ``DEVICE``: a :class:`Device3DResult` and nothing is written back."""
+        if self.num_molecules == 0:
+            if output == CoordinateOutput.DEVICE:
+                raise ValueError("minimize(output=DEVICE) requires at least one molecule")
+            return [], []
+        self._ensure_built()
+        pos = self._positions()
+        energies, statuses, _ = self._batch.minimize(pos, max_iters=int(maxIters), grad_tol=float(forceTol), scale_grads=True)
+        if output == CoordinateOutput.DEVICE:
+            gpu = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            if targetGpu is not None and int(targetGpu) >= 0 and int(targetGpu) != gpu:
+                raise ValueError(f"targetGpu {targetGpu} is not in the configured set of execution GPUs")
+            i32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(self.device)  # noqa: E731
+            return Device3DResult(pos.view(-1, 3), i32(self._atom_starts), i32([m for m, _ in self._systems]),
+                                  i32([k for _, k in self._systems]), gpu, self.num_molecules, energies=energies,
+                                  converged=(statuses == 0).to(torch.int8))
+        out = pos.cpu().numpy()
+        for s, (m, k) in enumerate(self._systems):
+            self._conformers[m][k] = out[3 * self._atom_starts[s]:3 * self._atom_starts[s + 1]].reshape(-1, 3)
+        self._write_back()
+        return (self._nest([float(e) for e in energies.cpu().numpy()]),
+                self._nest([bool(c) for c in (statuses == 0).cpu().numpy()]))
+
+    def _write_back(self) -> None:  # overridden by the RDKit-backed classes
+        pass
+
+
+class _RdkitBacked(FlatBatchedForcefield):
+    def _init_from_molecules(self, kind, molecules, flatten, hardwareOptions):
+        none_idx = [i for i, m in enumerate(molecules) if m is None]
+        if none_idx:
+            raise ValueError(f"None at indices {none_idx}", {"none": none_idx, "no_params": []})
+        self._molecules = list(molecules)
+        self._hardware_options = hardwareOptions if hardwareOptions is not None else HardwareOptions()
+        self._conf_ids = [[c.GetId() for c in m.GetConformers()] for m in molecules]
+        conformers = [np.stack([np.asarray(m.GetConformer(cid).GetPositions(), dtype=np.float64) for cid in ids])
+                      if ids else np.zeros((0, m.GetNumAtoms(), 3)) for m, ids in zip(molecules, self._conf_ids)]
+        tables = [flatten(i, ids[0] if ids else -1) for i, ids in enumerate(self._conf_ids)]
+        gpu_ids = self._hardware_options.gpuIds
+        super().__init__(kind, tables, conformers, device=torch.device("cuda", gpu_ids[0] if gpu_ids else torch.cuda.current_device()))
+
+    def _write_back(self) -> None:
+        for m, ids, confs in zip(self._molecules, self._conf_ids, self._conformers):
+            for cid, xyz in zip(ids, confs):
+                conf = m.GetConformer(cid)
+                if hasattr(conf, "SetPositions"):
+                    conf.SetPositions(np.ascontiguousarray(xyz))
+                else:
+                    from rdkit.Geometry import Point3D
+
+                    for a, (x, y, z) in enumerate(xyz):
+                        conf.SetAtomPosition(a, Point3D(float(x), float(y), float(z)))
+
+
+def _per_mol(value, n: int, name: str):
+    if isinstance(value, Sequence) and not isinstance(value, (str, bytes)):
+        if len(value) != n:
+            raise ValueError(f"Expected {n} values for {name}, got {len(value)}")
+        return list(value)
+    return [value] * n
+
+
+class MMFFBatchedForcefield(_RdkitBacked):
+    """MMFF94 batch over RDKit molecules (reference: nvmolkit/batchedForcefield.py:443-598).  Needs RDKit."""
+
+    def __init__(self, molecules, properties=None, nonBondedThreshold=100.0, ignoreInterfragInteractions=True,
+                 hardwareOptions: HardwareOptions | None = None):
+        from nvmolkit_amd.mmffOptimization import flatten_mmff_from_rdkit
+
+        n = len(molecules)
+        thr, frag = _per_mol(nonBondedThreshold, n, "nonBondedThreshold"), _per_mol(ignoreInterfragInteractions, n, "ignoreInterfragInteractions")
+        props = _per_mol(properties, n, "properties") if isinstance(properties, (list, tuple)) else [properties] * n
+
+        def flatten(i, cid):
+            from rdkit.Chem import rdForceFieldHelpers as ffh
+
+            p = props[i] if props[i] is not None else ffh.MMFFGetMoleculeProperties(molecules[i])
+            if p is None:
+                raise ValueError(f"lacking MMFF atom types at indices [{i}]", {"none": [], "no_params": [i]})
+            return flatten_mmff_from_rdkit(molecules[i], p, cid, float(thr[i]), bool(frag[i]))
+
+        self._init_from_molecules(MMFF, molecules, flatten, hardwareOptions)
+
+
+class UFFBatchedForcefield(_RdkitBacked):
+    """UFF batch over RDKit molecules (reference: nvmolkit/batchedForcefield.py:601-714).  Needs RDKit."""
+
+    def __init__(self, molecules, vdwThreshold=10.0, ignoreInterfragInteractions=True,
+                 hardwareOptions: HardwareOptions | None = None):
+        from nvmolkit_amd.uffOptimization import flatten_uff_from_rdkit
+
+        n = len(molecules)
+        thr, frag = _per_mol(vdwThreshold, n, "vdwThreshold"), _per_mol(ignoreInterfragInteractions, n, "ignoreInterfragInteractions")
+        self._init_from_molecules(UFF, molecules,
+                                  lambda i, cid: flatten_uff_from_rdkit(molecules[i], cid, float(thr[i]), bool(frag[i])),
+                                  hardwareOptions)

@@ -445,5 +445,87 @@ __device__ __forceinline__ void uff_vdw(const double r, const double xij, const 
   dE_dr           = 12.0 * wellDepth / xij * (q6 * q - q12 * q);
 }
 
+// ---- constraint terms shared by MMFF and UFF (mmff_kernels_device.cuh:663-1036) --------------------
+
+__device__ __forceinline__ double atan2_(const double y, const double x) { return atan2(y, x); }
+template <int NP> __device__ __forceinline__ Dual<NP> atan2_(const Dual<NP>& y, const Dual<NP>& x) {
+  const double den = x.v * x.v + y.v * y.v;
+  Dual<NP>     r;
+  r.v = atan2(y.v, x.v);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) r.d[k] = den > 0.0 ? (x.v * y.d[k] - y.v * x.d[k]) / den : 0.0;
+  return r;
+}
+
+__device__ __forceinline__ double normalize_angle_deg(double a) {  // into (-180, 180]
+  a = fmod(a, 360.0);
+  if (a < -180.0) {
+    a += 360.0;
+  } else if (a > 180.0) {
+    a -= 360.0;
+  }
+  return a;
+}
+
+// signed dihedral 1-2-3-4 in radians with the reference's sign and floors (computeSignedDihedral, :899-960)
+template <typename T>
+__device__ __forceinline__ T signed_dihedral(const Vec3<T>& p1, const Vec3<T>& p2, const Vec3<T>& p3, const Vec3<T>& p4) {
+  const Vec3<T> r0 = p1 - p2, r1 = p3 - p2, r3 = p4 - p3;
+  const Vec3<T> r2 = {-r1.x, -r1.y, -r1.z};
+  Vec3<T>       t0 = cross(r0, r1), t1 = cross(r2, r3);
+  T             d0 = sqrt_(dot(t0, t0)), d1 = sqrt_(dot(t1, t1));
+  if (value(d0) < 1.0e-5) d0 = d0 * 0.0 + 1.0e-5;
+  if (value(d1) < 1.0e-5) d1 = d1 * 0.0 + 1.0e-5;
+  t0 = {t0.x / d0, t0.y / d0, t0.z / d0};
+  t1 = {t1.x / d1, t1.y / d1, t1.z / d1};
+  const T       cosPhi = clamp_unit(dot(t0, t1));
+  const Vec3<T> m      = cross(t0, r1);
+  T             ml     = sqrt_(dot(m, m));
+  if (value(ml) < 1.0e-5) ml = ml * 0.0 + 1.0e-5;
+  return -1.0 * atan2_(dot(m, t1) / ml, cosPhi);
+}
+
+// offset of a dihedral (degrees) from the window [minDeg, maxDeg] on the circle (computeDihedralConstraintTerm, :879-897)
+__device__ __forceinline__ double dihedral_window_offset(const double dihedral, const double minDeg, const double maxDeg) {
+  double target = dihedral;
+  if (!(dihedral > minDeg && dihedral < maxDeg) && !(dihedral > minDeg && minDeg > maxDeg) &&
+      !(dihedral < maxDeg && minDeg > maxDeg)) {
+    const double toMin = normalize_angle_deg(dihedral - minDeg);
+    const double toMax = normalize_angle_deg(dihedral - maxDeg);
+    target             = fabs(toMin) < fabs(toMax) ? minDeg : maxDeg;
+  }
+  return normalize_angle_deg(dihedral - target);
+}
+
+template <typename T>
+__device__ __forceinline__ T torsion_constraint(const Vec3<T>& p1, const Vec3<T>& p2, const Vec3<T>& p3, const Vec3<T>& p4,
+                                                const double minDeg, const double maxDeg, const double k) {
+  const T      phi = kRad2Deg * signed_dihedral(p1, p2, p3, p4);
+  const double off = dihedral_window_offset(value(phi), minDeg, maxDeg);
+  const T      d   = phi - (value(phi) - off);  // same derivative as phi, value = offset from the window
+  return k * d * d;
+}
+
+// position restraint: E(dist) and dE/ddist for dist = |p - ref|
+__device__ __forceinline__ void position_constraint(const double dist, const double maxDispl, const double k, double& e, double& dE) {
+  const double t = dist > maxDispl ? dist - maxDispl : 0.0;
+  e              = 0.5 * k * t * t;
+  dE             = k * t;
+}
+
+// angle restraint with the reference's arm-length floor (1e-5 on the squared lengths, :806-812)
+template <typename T>
+__device__ __forceinline__ T angle_constraint_ff(const Vec3<T>& p1, const Vec3<T>& p2, const Vec3<T>& p3, const double minDeg,
+                                                 const double maxDeg, const double k) {
+  const Vec3<T> r1 = p1 - p2, r2 = p3 - p2;
+  T             l1 = dot(r1, r1), l2 = dot(r2, r2);
+  if (value(l1) < 1.0e-5) l1 = l1 * 0.0 + 1.0e-5;
+  if (value(l2) < 1.0e-5) l2 = l2 * 0.0 + 1.0e-5;
+  const T theta = kRad2Deg * acos_(clamp_unit(dot(r1, r2) / sqrt_(l1 * l2)));
+  if (value(theta) < minDeg) return k * (theta - minDeg) * (theta - minDeg);
+  if (value(theta) > maxDeg) return k * (theta - maxDeg) * (theta - maxDeg);
+  return theta * 0.0;
+}
+
 }  // namespace ff
 }  // namespace nvmk

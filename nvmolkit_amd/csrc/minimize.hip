@@ -39,7 +39,7 @@ struct Batch {
   int            kind;
   int            nSystems;
   const int32_t* atomStarts;
-  Group          g[8];
+  Group          g[12];
   const int32_t* sysMol;      // optional: term tables are per MOLECULE and system s uses row sysMol[s] of every `starts`
   unsigned       groupMask;   // bit g set = evaluate term group g
   // ETK only, optional: per-system reference distances for the 1-2 / 1-3 restraints (the reference re-centres
@@ -48,8 +48,12 @@ struct Batch {
   const double*  ref[2];
 };
 
+// Internal kinds: MMFF / UFF batches that carry constraint groups run separate kernel instantiations, so the common
+// unconstrained kernels keep their register budget (the reference templates its kernels on HasConstraints).
+constexpr int KIND_MMFF_C = 5;
+constexpr int KIND_UFF_C  = 6;
 template <int KIND> struct Dim {
-  static constexpr int value = (KIND == NVMK_FF_MMFF || KIND == NVMK_FF_UFF) ? 3 : 4;
+  static constexpr int value = (KIND == NVMK_FF_MMFF || KIND == NVMK_FF_UFF || KIND == KIND_MMFF_C || KIND == KIND_UFF_C) ? 3 : 4;
 };
 
 // ---- block reductions -----------------------------------------------------------------------------
@@ -135,6 +139,82 @@ __device__ __forceinline__ void pair_terms(const Group& g, const int ms, Body&& 
       if (t < t1) body(t, ij[k].x, ij[k].y, par[k]);
     }
   }
+}
+
+// Constraint groups of the 3-D fields (MMFF: first = 7, UFF: first = 5): distance, position, angle, torsion.
+template <int DIM, bool GRAD>
+__device__ __forceinline__ double constraint_terms(const Batch& b, const int first, const int ms, const double* pos, double* grad) {
+  const int tid = threadIdx.x;
+  double    e   = 0.0;
+  auto      has = [&](const int gi) { return ((b.groupMask >> gi) & 1u) && b.g[gi].starts != nullptr; };
+  if (has(first)) {
+    pair_terms<3>(b.g[first], ms, [&](const int, const int i, const int j, const double* p) {
+      double       d[4];
+      const double dist = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
+      double       et, dE;
+      dist_constraint(dist, p[0], p[1], p[2], et, dE);
+      if constexpr (GRAD) {
+        if (dE != 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / (dist > 1.0e-8 ? dist : 1.0e-8));
+      } else {
+        e += et;
+      }
+    });
+  }
+  if (has(first + 1)) {
+    const Group& g = b.g[first + 1];
+    for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
+      const int     i = g.idx[t];
+      const double* p = g.par + 5 * t;
+      const double  dx = pos[i * DIM] - p[0], dy = pos[i * DIM + 1] - p[1], dz = pos[i * DIM + 2] - p[2];
+      const double  dist = sqrt(dx * dx + dy * dy + dz * dz);
+      double        et, dE;
+      position_constraint(dist, p[3], p[4], et, dE);
+      if constexpr (GRAD) {
+        if (dE != 0.0) {
+          const double f = dE / (dist > 1.0e-8 ? dist : 1.0e-8);
+          atomicAdd(&grad[i * DIM], f * dx);
+          atomicAdd(&grad[i * DIM + 1], f * dy);
+          atomicAdd(&grad[i * DIM + 2], f * dz);
+        }
+      } else {
+        e += et;
+      }
+    }
+  }
+  if (has(first + 2)) {
+    const Group& g = b.g[first + 2];
+    for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
+      const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
+      const double* p    = g.par + 3 * t;
+      if constexpr (GRAD) {
+        using D = Dual<9>;
+        scatter<9, DIM, 3>(angle_constraint_ff(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                               Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], p[2]),
+                           a, grad, 1.0);
+      } else {
+        e += angle_constraint_ff(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                                 Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], p[2]);
+      }
+    }
+  }
+  if (has(first + 3)) {
+    const Group& g = b.g[first + 3];
+    for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
+      const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
+      const double* p    = g.par + 3 * t;
+      if constexpr (GRAD) {
+        using D = Dual<12>;
+        scatter<12, DIM, 4>(torsion_constraint(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                               Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0], p[1],
+                                               p[2]),
+                            a, grad, 1.0);
+      } else {
+        e += torsion_constraint(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
+                                Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), p[0], p[1], p[2]);
+      }
+    }
+  }
+  return e;
 }
 
 // GRAD = false: returns the energy partial.  GRAD = true: accumulates the gradient, returns 0.
@@ -295,7 +375,7 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
     return e;
   }
 
-  if constexpr (KIND == NVMK_FF_MMFF) {
+  if constexpr (KIND == NVMK_FF_MMFF || KIND == KIND_MMFF_C) {
     if (on(0)) {  // bond stretch: r0, kb
       pair_terms<2>(b.g[0], ms, [&](const int, const int i, const int j, const double* p) {
         double       d[4];
@@ -400,10 +480,11 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         }
       });
     }
+    if constexpr (KIND == KIND_MMFF_C) e += constraint_terms<DIM, GRAD>(b, 7, ms, pos, grad);
     return e;
   }
 
-  if constexpr (KIND == NVMK_FF_UFF) {
+  if constexpr (KIND == NVMK_FF_UFF || KIND == KIND_UFF_C) {
     if (on(0)) {  // bond stretch: r0, k
       pair_terms<2>(b.g[0], ms, [&](const int, const int i, const int j, const double* p) {
         double       d[4];
@@ -494,6 +575,7 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         }
       });
     }
+    if constexpr (KIND == KIND_UFF_C) e += constraint_terms<DIM, GRAD>(b, 5, ms, pos, grad);
     return e;
   }
   return e;
@@ -894,12 +976,18 @@ int to_batch(const nvmk_ff_batch* in, Batch& out) {
   out.nSystems     = in->n_systems;
   out.atomStarts   = in->atom_starts;
   out.sysMol       = in->system_mol;
-  out.groupMask    = in->group_mask ? in->group_mask : 0xffu;
+  out.groupMask    = in->group_mask ? in->group_mask : 0xfffu;
   out.refStarts[0] = in->etk_ref12_starts;
   out.refStarts[1] = in->etk_ref13_starts;
   out.ref[0]       = in->etk_ref12;
   out.ref[1]       = in->etk_ref13;
-  for (int g = 0; g < 8; ++g) {
+  if (in->kind == NVMK_FF_MMFF || in->kind == NVMK_FF_UFF) {
+    const int first = (in->kind == NVMK_FF_MMFF) ? 7 : 5;
+    for (int g = first; g < first + 4; ++g) {
+      if (in->groups[g].starts != nullptr) out.kind = (in->kind == NVMK_FF_MMFF) ? KIND_MMFF_C : KIND_UFF_C;
+    }
+  }
+  for (int g = 0; g < 12; ++g) {
     out.g[g] = {in->groups[g].starts, in->groups[g].idx, in->groups[g].par};
     if (g < nGroups[in->kind] && in->n_systems > 0) {
       NVMK_REQUIRE(in->groups[g].starts != nullptr, "ff: term group %d of kind %d has NULL starts", g, in->kind);
@@ -914,6 +1002,8 @@ int to_batch(const nvmk_ff_batch* in, Batch& out) {
     case NVMK_FF_ETK: { constexpr int K = NVMK_FF_ETK; CALL; break; }         \
     case NVMK_FF_MMFF: { constexpr int K = NVMK_FF_MMFF; CALL; break; }       \
     case NVMK_FF_UFF: { constexpr int K = NVMK_FF_UFF; CALL; break; }         \
+    case KIND_MMFF_C: { constexpr int K = KIND_MMFF_C; CALL; break; }         \
+    case KIND_UFF_C: { constexpr int K = KIND_UFF_C; CALL; break; }           \
     default: { constexpr int K = NVMK_FF_QUARTIC; CALL; break; }              \
   }
 
@@ -961,7 +1051,7 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   NVMK_REQUIRE(h_atom_starts && d_pos && d_energies, "bfgs: NULL buffer");
   NVMK_REQUIRE(max_iters >= 0, "bfgs: negative iteration count");
   hipStream_t stream = as_stream(stream_);
-  const int   dim    = (b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_UFF) ? 3 : 4;
+  const int   dim    = (b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_UFF || b.kind == KIND_MMFF_C || b.kind == KIND_UFF_C) ? 3 : 4;
   // inverse-Hessian offsets (packed lower triangle per system) and the LDS need of the largest system
   std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
   int                  maxN = 0;

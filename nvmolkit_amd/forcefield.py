@@ -28,6 +28,8 @@ GROUP_LAYOUT = {
     UFF: [(2, 2), (3, 6), (4, 3), (4, 4), (2, 3)],
 }
 DIM = {DG: 4, ETK: 4, MMFF: 3, QUARTIC: 4, UFF: 3}
+# MMFF / UFF batches may append up to four constraint groups (distance, position, angle, torsion; include/nvmolkit_amd.h)
+CONSTRAINT_LAYOUT = [(2, 3), (1, 5), (3, 3), (4, 3)]
 
 
 class FlatForcefieldBatch:
@@ -47,9 +49,12 @@ class FlatForcefieldBatch:
     def __init__(self, kind: int, atom_starts, groups: Sequence[tuple], device="cuda", system_mol=None):
         if kind not in GROUP_LAYOUT:
             raise ValueError(f"unknown force-field kind {kind}")
-        layout = GROUP_LAYOUT[kind]
-        if len(groups) != len(layout):
-            raise ValueError(f"kind {kind} needs {len(layout)} term groups, got {len(groups)}")
+        layout = list(GROUP_LAYOUT[kind])
+        n_extra = len(groups) - len(layout)
+        if n_extra < 0 or (n_extra > 0 and (kind not in (MMFF, UFF) or n_extra > len(CONSTRAINT_LAYOUT))):
+            raise ValueError(f"kind {kind} needs {len(layout)} term groups"
+                             f"{' (+ up to 4 constraint groups)' if kind in (MMFF, UFF) else ''}, got {len(groups)}")
+        layout += CONSTRAINT_LAYOUT[:n_extra]
         self.kind = kind
         self.dim = DIM[kind]
         self.device = torch.device(device)

@@ -33,6 +33,8 @@ LAYOUT = {
     UFF: [(2, 2), (3, 6), (4, 3), (4, 4), (2, 3)],
 }
 DIM = {DG: 4, ETK: 4, MMFF: 3, QUARTIC: 4, UFF: 3}
+# optional constraint groups appended to the MMFF / UFF groups: distance, position, angle, torsion
+CONSTRAINT_LAYOUT = [(2, 3), (1, 5), (3, 3), (4, 3)]
 
 
 def _xyz(pos, idx):
@@ -236,6 +238,57 @@ def uff_inversion_gradient_reference(pos, idx, par):
     return np.array([de_dw * tg1, -de_dw * (tg1 + tg3 + tg4), de_dw * tg3, de_dw * tg4])
 
 
+# ---- constraints shared by MMFF and UFF (src/forcefields/mmff_kernels_device.cuh:663-1036) -------------
+
+def _normalize_deg(a):
+    a = np.fmod(a, 360.0)
+    return np.where(a < -180.0, a + 360.0, np.where(a > 180.0, a - 360.0, a))
+
+
+def signed_dihedral_deg(p1, p2, p3, p4):
+    """computeSignedDihedral (:899-960), vectorised over terms."""
+    r0, r1, r3 = p1 - p2, p3 - p2, p4 - p3
+    r2 = -r1
+    t0, t1 = np.cross(r0, r1), np.cross(r2, r3)
+    t0 = t0 / np.maximum(np.linalg.norm(t0, axis=1), 1e-5)[:, None]
+    t1 = t1 / np.maximum(np.linalg.norm(t1, axis=1), 1e-5)[:, None]
+    cos_phi = np.clip((t0 * t1).sum(1), -1.0, 1.0)
+    m = np.cross(t0, r1)
+    ml = np.maximum(np.linalg.norm(m, axis=1), 1e-5)
+    return -np.arctan2((m * t1).sum(1) / ml, cos_phi) * RAD2DEG
+
+
+def dihedral_window_offset(dihedral, lo, hi):
+    """computeDihedralConstraintTerm (:879-897)."""
+    inside = ((dihedral > lo) & (dihedral < hi)) | ((dihedral > lo) & (lo > hi)) | ((dihedral < hi) & (lo > hi))
+    to_lo, to_hi = _normalize_deg(dihedral - lo), _normalize_deg(dihedral - hi)
+    target = np.where(inside, dihedral, np.where(np.abs(to_lo) < np.abs(to_hi), lo, hi))
+    return _normalize_deg(dihedral - target)
+
+
+def constraint_terms(pos, groups):
+    """Per-group energies of the four optional constraint groups (any may be missing / empty)."""
+    out = []
+    groups = list(groups) + [(np.zeros((0, n), dtype=np.int64), np.zeros((0, m))) for n, m in CONSTRAINT_LAYOUT[len(groups):]]
+    idx, par = groups[0]
+    d = np.sqrt(((pos[idx[:, 0]] - pos[idx[:, 1]]) ** 2).sum(1))
+    diff = np.where(d < par[:, 0], par[:, 0] - d, np.where(d > par[:, 1], d - par[:, 1], 0.0))
+    out.append(0.5 * par[:, 2] * diff**2)                                                         # :674-690
+    idx, par = groups[1]
+    dist = np.sqrt(((pos[idx[:, 0]] - par[:, :3]) ** 2).sum(1))
+    out.append(0.5 * par[:, 4] * np.maximum(dist - par[:, 3], 0.0) ** 2)                          # :720-733
+    idx, par = groups[2]
+    r1, r2 = pos[idx[:, 0]] - pos[idx[:, 1]], pos[idx[:, 2]] - pos[idx[:, 1]]
+    l1, l2 = np.maximum((r1 * r1).sum(1), 1e-5), np.maximum((r2 * r2).sum(1), 1e-5)
+    theta = RAD2DEG * np.arccos(np.clip((r1 * r2).sum(1) / np.sqrt(l1 * l2), -1.0, 1.0))
+    term = np.where(theta < par[:, 0], theta - par[:, 0], np.where(theta > par[:, 1], theta - par[:, 1], 0.0))
+    out.append(par[:, 2] * term**2)                                                               # :770-815
+    idx, par = groups[3]
+    phi = signed_dihedral_deg(*(pos[idx[:, k]] for k in range(4)))
+    out.append(par[:, 2] * dihedral_window_offset(phi, par[:, 0], par[:, 1]) ** 2)                # :962-976
+    return out
+
+
 def system_energy(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: float = 1.0, coord_start: int = 0,
                   per_group: bool = False):
     """Energy of one system.  pos: (n_atoms, DIM[kind]); groups: list of (idx (n, n_idx) int, par (n, n_par))."""
@@ -245,8 +298,11 @@ def system_energy(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: float
         if w0 == 0.0:
             diff = diff[:, :3]
         return float((diff**4).sum())
+    n_base = len(LAYOUT[kind])
     parts = {DG: lambda: dg_terms(pos, groups, w0, w1), ETK: lambda: etk_terms(pos, groups),
-             MMFF: lambda: mmff_terms(pos, groups), UFF: lambda: uff_terms(pos, groups)}[kind]()
+             MMFF: lambda: mmff_terms(pos, groups[:n_base]), UFF: lambda: uff_terms(pos, groups[:n_base])}[kind]()
+    if kind in (MMFF, UFF) and len(groups) > n_base:
+        parts = list(parts) + constraint_terms(pos[:, :3], groups[n_base:])
     if per_group:
         return [float(p.sum()) for p in parts]
     return float(sum(p.sum() for p in parts))
@@ -269,7 +325,9 @@ def system_gradient(kind: int, pos: np.ndarray, groups, w0: float = 1.0, w1: flo
         return g
 
     if kind == UFF:  # the inversion gradient follows the reference's sign convention for its C2 part (see uff_terms)
-        return fd(lambda p: float(sum(t.sum() for t in uff_terms(p, groups, gradient_convention=True))))
+        nb = len(LAYOUT[UFF])
+        return fd(lambda p: float(sum(t.sum() for t in uff_terms(p, groups[:nb], gradient_convention=True)) +
+                                  sum(t.sum() for t in constraint_terms(p, groups[nb:]))))
     if kind != DG:
         return fd(lambda p: system_energy(kind, p, groups, w0, w1, coord_start))
     empty = [(np.zeros((0, n), dtype=np.int64), np.zeros((0, m))) for n, m in LAYOUT[DG]]

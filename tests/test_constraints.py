@@ -1,0 +1,177 @@
+"""Force-field constraints and the batched force-field object API (reference: nvmolkit/batchedForcefield.py,
+src/forcefields/forcefield_constraints.cpp:128-232, mmff_kernels_device.cuh:663-1036; tests modelled on
+nvmolkit/tests/test_batched_forcefield.py and tests/test_mmff.cu / test_uff.cu constraint cases)."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ff as off
+from nvmolkit_amd.batchedForcefield import FlatBatchedForcefield, _resolve_constraints
+from nvmolkit_amd.forcefield import MMFF, UFF
+from nvmolkit_amd.types import CoordinateOutput, Device3DResult
+from tests import util
+
+EMPTY = lambda kind: [(np.zeros((0, n), dtype=np.int64), np.zeros((0, m))) for n, m in off.LAYOUT[kind]]  # noqa: E731
+
+
+# ---------------- oracle pins (CPU) ----------------
+
+def test_constraint_energies_closed_form():
+    pos = np.array([[0.0, 0, 0], [2.0, 0, 0], [2.0, 1.0, 0], [2.0, 1.0, 1.0]])   # angle 0-1-2 = 90, dihedral 0-1-2-3 = 90
+    base = EMPTY(off.MMFF)
+    e = lambda cons: off.system_energy(off.MMFF, pos, base + cons, per_group=True)[len(base):]  # noqa: E731
+    none = [(np.zeros((0, n), dtype=np.int64), np.zeros((0, m))) for n, m in off.CONSTRAINT_LAYOUT]
+    c = list(none)
+    c[0] = (np.array([[0, 1]]), np.array([[0.5, 1.5, 10.0]]))                    # d = 2, 0.5 above the window
+    assert e(c)[0] == pytest.approx(0.5 * 10.0 * 0.25)
+    c[0] = (np.array([[0, 1]]), np.array([[2.5, 3.0, 10.0]]))                    # 0.5 below
+    assert e(c)[0] == pytest.approx(0.5 * 10.0 * 0.25)
+    c[0] = (np.array([[0, 1]]), np.array([[1.0, 3.0, 10.0]]))
+    assert e(c)[0] == 0.0
+    c = list(none)
+    c[1] = (np.array([[3]]), np.array([[2.0, 1.0, 4.0, 1.0, 6.0]]))              # 3 away from the anchor, 1 allowed
+    assert e(c)[1] == pytest.approx(0.5 * 6.0 * 4.0)
+    c = list(none)
+    c[2] = (np.array([[0, 1, 2]]), np.array([[100.0, 120.0, 0.3]]))              # 10 degrees below
+    assert e(c)[2] == pytest.approx(0.3 * 100.0)
+    c = list(none)
+    phi = off.signed_dihedral_deg(*(pos[[k]] for k in range(4)))[0]
+    assert abs(phi) == pytest.approx(90.0)
+    c[3] = (np.array([[0, 1, 2, 3]]), np.array([[phi + 10.0, phi + 40.0, 0.2]])) # 10 degrees outside the window
+    assert e(c)[3] == pytest.approx(0.2 * 100.0)
+    c[3] = (np.array([[0, 1, 2, 3]]), np.array([[170.0, -170.0, 0.2]]))          # window across +-180
+    off_deg = min(abs(off._normalize_deg(phi - 170.0)), abs(off._normalize_deg(phi + 170.0)))
+    assert e(c)[3] == pytest.approx(0.2 * off_deg**2)
+    assert off.dihedral_window_offset(np.array([175.0]), np.array([170.0]), np.array([-170.0]))[0] == 0.0
+    assert off.dihedral_window_offset(np.array([-175.0]), np.array([170.0]), np.array([-170.0]))[0] == 0.0
+
+
+def test_constraint_resolution_relative_bounds_and_validation():
+    xyz = np.array([[0.0, 0, 0], [2.0, 0, 0], [2.0, 1.0, 0], [2.0, 1.0, 1.0]])
+    from nvmolkit_amd.batchedForcefield import (_AngleConstraint, _DistanceConstraint, _PositionConstraint,
+                                                _TorsionConstraint)
+
+    g = _resolve_constraints(xyz, [_DistanceConstraint(0, 1, True, -0.5, 0.25, 7.0), _DistanceConstraint(0, 1, True, -5.0, -4.0, 1.0)],
+                             [_PositionConstraint(3, 0.1, 9.0)], [_AngleConstraint(0, 1, 2, True, -5.0, 5.0, 2.0)],
+                             [_TorsionConstraint(0, 1, 2, 3, True, 100.0, 120.0, 3.0)])
+    assert g[0][0].tolist() == [[0, 1], [0, 1]] and g[0][1].tolist() == [[1.5, 2.25, 7.0], [0.0, 0.0, 1.0]]   # clamped at 0
+    assert g[1][1].tolist() == [[2.0, 1.0, 1.0, 0.1, 9.0]]                                                    # anchored here
+    assert g[2][1][0] == pytest.approx([85.0, 95.0, 2.0])
+    phi = off.signed_dihedral_deg(*(xyz[[k]] for k in range(4)))[0]
+    assert g[3][1][0] == pytest.approx([off._normalize_deg(phi + 100.0), off._normalize_deg(phi + 120.0), 3.0])
+    with pytest.raises(ValueError, match="maxLen"):
+        _resolve_constraints(xyz, [_DistanceConstraint(0, 1, False, 2.0, 1.0, 1.0)], [], [], [])
+    with pytest.raises(ValueError, match=r"\[0, 180\]"):
+        _resolve_constraints(xyz, [], [], [_AngleConstraint(0, 1, 2, True, 0.0, 100.0, 1.0)], [])
+    with pytest.raises(ValueError, match="maxDihedralDeg"):
+        _resolve_constraints(xyz, [], [], [], [_TorsionConstraint(0, 1, 2, 3, False, 10.0, 5.0, 1.0)])
+
+
+# ---------------- GPU parity ----------------
+
+def random_constraints(rng, pos):
+    n = len(pos)
+    pairs = np.array([rng.choice(n, 2, replace=False) for _ in range(4)])
+    d = np.linalg.norm(pos[pairs[:, 0], :3] - pos[pairs[:, 1], :3], axis=1)
+    lo = d * rng.uniform(0.6, 1.3, size=4)
+    cons = [(pairs, np.stack([lo, lo + rng.uniform(0.0, 0.5, 4), rng.uniform(5, 100, 4)], 1))]
+    who = rng.choice(n, 3, replace=False)
+    cons.append((who[:, None], np.concatenate([pos[who, :3] + rng.normal(scale=0.4, size=(3, 3)),
+                                               rng.uniform(0.0, 0.3, (3, 1)), rng.uniform(5, 100, (3, 1))], 1)))
+    tri = np.array([rng.choice(n, 3, replace=False) for _ in range(3)])
+    amin = rng.uniform(20, 140, 3)
+    cons.append((tri, np.stack([amin, amin + rng.uniform(0, 30, 3), rng.uniform(0.01, 1.0, 3)], 1)))
+    quad = np.array([rng.choice(n, 4, replace=False) for _ in range(4)])
+    tmin = rng.uniform(-180, 180, 4)
+    tmax = np.array([off._normalize_deg(t) for t in tmin + rng.uniform(0, 90, 4)])
+    cons.append((quad, np.stack([tmin, tmax, rng.uniform(0.01, 0.5, 4)], 1)))
+    return cons
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [MMFF, UFF])
+def test_constrained_energy_and_gradient_match_oracle(kind):
+    from nvmolkit_amd.forcefield import FlatForcefieldBatch
+
+    rng = np.random.default_rng(kind + 40)
+    systems = []
+    for n in (5, 8, 13, 21):
+        pos, groups = util.random_ff_system(kind, n, rng)
+        systems.append((pos, groups + random_constraints(rng, pos)))
+    layout = off.LAYOUT[kind] + off.CONSTRAINT_LAYOUT
+    atom_starts = np.concatenate([[0], np.cumsum([len(p) for p, _ in systems])]).astype(np.int32)
+    stacked = []
+    for g, (n_idx, n_par) in enumerate(layout):
+        starts = np.concatenate([[0], np.cumsum([len(gr[g][0]) for _, gr in systems])]).astype(np.int32)
+        stacked.append((starts, np.concatenate([np.asarray(gr[g][0]).reshape(-1, n_idx) for _, gr in systems]),
+                        np.concatenate([np.asarray(gr[g][1]).reshape(-1, n_par) for _, gr in systems])))
+    batch = FlatForcefieldBatch(kind, atom_starts, stacked)
+    pos = torch.from_numpy(np.concatenate([p.reshape(-1) for p, _ in systems])).cuda()
+    got_e = batch.compute_energy(pos).cpu().numpy()
+    want_e = np.array([off.system_energy(kind, p, g) for p, g in systems])
+    np.testing.assert_allclose(got_e, want_e, rtol=1e-10, atol=1e-9)
+    cons_e = np.array([sum(off.system_energy(kind, p, g, per_group=True)[len(off.LAYOUT[kind]):]) for p, g in systems])
+    assert (cons_e > 0).all()                                     # the constraints are active in every system
+    got_g = batch.compute_gradient(pos).cpu().numpy()
+    o = 0
+    for p, g in systems:
+        want = off.system_gradient(kind, p, g, h=1e-6).reshape(-1)
+        mine = got_g[o:o + want.size]
+        o += want.size
+        scale = max(1.0, np.abs(want).max())
+        assert np.abs(mine - want).max() <= 5e-6 * scale
+    e1, st, _ = batch.minimize(pos, max_iters=200)
+    assert (e1.cpu().numpy() <= got_e + 1e-9).all()
+    np.testing.assert_allclose(batch.compute_energy(pos).cpu().numpy(), e1.cpu().numpy(), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [MMFF, UFF])
+def test_object_api(kind):
+    rng = np.random.default_rng(kind + 60)
+    mols = [util.random_ff_system(kind, n, rng) for n in (6, 9)]
+    if kind == UFF:  # conservative field for the minimisation checks (see test_forcefield_gpu.py on group-15 inversions)
+        for _, g in mols:
+            g[3][1][:, 1:] = (1.0, -1.0, 0.0)
+            g[1][1][:, 2] = np.where(g[1][1][:, 2] == 0, 0.0, 3.0)
+    confs = [np.stack([p[:, :3] + 0.05 * rng.normal(size=(len(p), 3)) for _ in range(k)]) for (p, _), k in zip(mols, (2, 3))]
+    ff = FlatBatchedForcefield(kind, [g for _, g in mols], [c.copy() for c in confs])
+    assert len(ff) == 2 and ff[1].num_atoms == 9 and ff.num_molecules == 2 and ff.data_dim == 3
+    e0 = ff.compute_energy()
+    assert [len(x) for x in e0] == [2, 3]
+    for m in range(2):
+        for k in range(len(confs[m])):
+            assert e0[m][k] == pytest.approx(off.system_energy(kind, confs[m][k], mols[m][1]), rel=1e-10, abs=1e-9)
+    # constraints: per molecule, resolved per conformer
+    ff[0].add_distance_constraint(0, 5, False, 0.5, 1.0, 50.0)
+    ff[1].add_position_constraint(2, 0.0, 30.0)                   # anchored at each conformer's own position: no energy yet
+    ff[1].add_angle_constraint(0, 1, 2, True, 10.0, 20.0, 0.1)   # 10 degrees away from wherever each conformer is
+    ff[1].add_torsion_constraint(0, 1, 2, 3, True, -5.0, 5.0, 0.2)
+    e1 = ff.compute_energy()
+    for k in range(2):
+        d = np.linalg.norm(confs[0][k][0] - confs[0][k][5])
+        extra = 0.5 * 50.0 * (max(d - 1.0, 0.0) + max(0.5 - d, 0.0)) ** 2
+        assert e1[0][k] == pytest.approx(e0[0][k] + extra, rel=1e-9)
+    for k in range(3):
+        assert e1[1][k] == pytest.approx(e0[1][k] + 0.1 * 100.0, rel=1e-9)
+    g = ff.compute_gradients()
+    assert [len(x) for x in g] == [2, 3] and len(g[1][0]) == 27
+    with pytest.raises(IndexError):
+        ff[0].add_distance_constraint(0, 6, False, 0, 1, 1.0)
+    with pytest.raises(IndexError):
+        ff[2]
+    # minimise: energies drop, coordinates are written back, DEVICE mode leaves them alone
+    dev = ff.minimize(50, output=CoordinateOutput.DEVICE)
+    assert isinstance(dev, Device3DResult) and dev.num_conformers == 5 and dev.mol_indices.torch().tolist() == [0, 0, 1, 1, 1]
+    assert np.array_equal(ff._conformers[0], confs[0])
+    energies, converged = ff.minimize(200, 1e-4)
+    assert [len(x) for x in energies] == [2, 3] and [len(x) for x in converged] == [2, 3]
+    for m in range(2):
+        for k in range(len(confs[m])):
+            assert energies[m][k] <= e1[m][k] + 1e-9
+    assert not np.array_equal(ff._conformers[0], confs[0])
+    # the position restraint held atom 2 of molecule 1 near its anchor
+    for k in range(3):
+        assert np.linalg.norm(ff._conformers[1][k][2] - confs[1][k][2]) < 0.5
+    assert FlatBatchedForcefield(kind, [], []).compute_energy() == []
