@@ -166,7 +166,8 @@ int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uint32_t* d_bo
  * (src/minimizer/bfgs_minimize_permol_kernels.cu:426-745; BfgsBatchMinimizer::minimize, bfgs_minimize.cu:978-1084).
  *
  * A batch is `n_systems` independent systems (conformers); system s owns atoms [atom_starts[s], atom_starts[s+1])
- * of the position array, `dim` doubles per atom (dim = 3 for MMFF / UFF, 4 for DG / ETK / QUARTIC).  Term tables are the
+ * of the position array, `dim` doubles per atom (dim = 3 for ETK / MMFF / UFF, 4 for DG / QUARTIC; the reference keeps ETK 4-D, but its
+ * terms never touch the 4th coordinate).  Term tables are the
  * flattened arrays the reference builds in rdkit_extensions/ (SoA + CSR): group g holds the terms of one type for
  * all systems, terms of system s are [starts[s], starts[s+1]); `idx` has n_idx LOCAL atom indices per term and
  * `par` n_par doubles per term, both interleaved per term:

@@ -257,6 +257,24 @@ __global__ void pack_kernel(const int nCopies, const int32_t* __restrict__ srcSy
   }
 }
 
+// The ETK terms only see x, y, z: the stage runs on a 3-D copy (a 4-D BFGS would carry 7/16 of its inverse Hessian as
+// dead weight — the 4th coordinates have zero gradient and never couple) and the result is written back into the 4-D
+// coordinates, 4th component untouched.
+__global__ void copy_4d_to_3d_kernel(const int64_t nAtoms, const double* __restrict__ p4, double* __restrict__ p3) {
+  const int64_t a = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a >= nAtoms) return;
+  p3[3 * a]     = p4[4 * a];
+  p3[3 * a + 1] = p4[4 * a + 1];
+  p3[3 * a + 2] = p4[4 * a + 2];
+}
+__global__ void copy_3d_to_4d_kernel(const int64_t nAtoms, const double* __restrict__ p3, double* __restrict__ p4) {
+  const int64_t a = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a >= nAtoms) return;
+  p4[4 * a]     = p3[3 * a];
+  p4[4 * a + 1] = p3[3 * a + 1];
+  p4[4 * a + 2] = p3[3 * a + 2];
+}
+
 template <typename T> struct DevBuf {
   T*          p = nullptr;
   size_t      n = 0;
@@ -339,7 +357,7 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
   auto worker = [&](hipStream_t stream) -> int {
   DevBuf<int32_t>  dAtomStarts, dSysMol, dRef12Starts, dRef13Starts, dSrcSys;
   DevBuf<int64_t>  dDstOff;
-  DevBuf<double>   dPos, dEnergies, dRef12, dRef13;
+  DevBuf<double>   dPos, dPos3, dEnergies, dRef12, dRef13;
   DevBuf<uint8_t>  dActive, dFailed, dSub;
   DevBuf<int16_t>  dFinished, dStatuses, dFailSum;
   DevBuf<int>      dCount;
@@ -365,6 +383,7 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     NVMK_HIP_CHECK(dAtomStarts.ensure(atomStarts.size()));
     NVMK_HIP_CHECK(dSysMol.ensure(static_cast<size_t>(nSys)));
     NVMK_HIP_CHECK(dPos.ensure(static_cast<size_t>(nAtoms) * 4));
+    if (useEtk) NVMK_HIP_CHECK(dPos3.ensure(static_cast<size_t>(nAtoms) * 3));
     NVMK_HIP_CHECK(dEnergies.ensure(static_cast<size_t>(nSys)));
     NVMK_HIP_CHECK(dActive.ensure(static_cast<size_t>(nSys)));
     NVMK_HIP_CHECK(dFailed.ensure(static_cast<size_t>(nSys)));
@@ -485,14 +504,21 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
       etk.etk_ref13_starts = dRef13Starts.p;
       etk.etk_ref13        = dRef13.p;
       etk.group_mask       = prm->use_basic_knowledge ? 0x3fu : 0x3du;  // plain mode drops the improper terms (ETKTerm::PLAIN)
-      NVMK_TRY(minimize(etk, 1.0, 1.0, 300, false));
+      const unsigned aBlocks = static_cast<unsigned>(blocks(nAtoms));
+      hipLaunchKernelGGL(copy_4d_to_3d_kernel, dim3(aBlocks), dim3(256), 0, stream, static_cast<int64_t>(nAtoms), dPos.p, dPos3.p);
+      {  // minimise the ACTIVE systems on the 3-D copy (one call, no repeat: etkdg_stage_etk_minimization.cu:204-266)
+        NVMK_HIP_CHECK(hipMemcpyAsync(dSub.p, dActive.p, static_cast<size_t>(nSys), hipMemcpyDeviceToDevice, stream));
+        NVMK_TRY(nvmk_bfgs_minimize(&etk, atomStarts.data(), 1.0, 1.0, 300, prm->force_tol, 1, dPos3.p, dSub.p, dEnergies.p,
+                                    dStatuses.p, nullptr, stream));
+      }
       if (prm->use_basic_knowledge) {
         nvmk_ff_batch planar = etk;
         planar.group_mask    = 0x2u;
-        NVMK_TRY(nvmk_ff_energy(&planar, 1.0, 1.0, dPos.p, nullptr, dEnergies.p, stream));
+        NVMK_TRY(nvmk_ff_energy(&planar, 1.0, 1.0, dPos3.p, nullptr, dEnergies.p, stream));
         hipLaunchKernelGGL(planar_check_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, dEnergies.p, dSysMol.p,
                            ms->num_impropers, dActive.p, dFailed.p);
       }
+      hipLaunchKernelGGL(copy_3d_to_4d_kernel, dim3(aBlocks), dim3(256), 0, stream, static_cast<int64_t>(nAtoms), dPos3.p, dPos.p);
     }
     NVMK_TRY(end_stage());
     // stages 6-10: final geometry / chirality checks

@@ -53,7 +53,7 @@ struct Batch {
 constexpr int KIND_MMFF_C = 5;
 constexpr int KIND_UFF_C  = 6;
 template <int KIND> struct Dim {
-  static constexpr int value = (KIND == NVMK_FF_MMFF || KIND == NVMK_FF_UFF || KIND == KIND_MMFF_C || KIND == KIND_UFF_C) ? 3 : 4;
+  static constexpr int value = (KIND == NVMK_FF_DG || KIND == NVMK_FF_QUARTIC) ? 4 : 3;
 };
 
 // ---- block reductions -----------------------------------------------------------------------------
@@ -1072,7 +1072,7 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   NVMK_REQUIRE(h_atom_starts && d_pos && d_energies, "bfgs: NULL buffer");
   NVMK_REQUIRE(max_iters >= 0, "bfgs: negative iteration count");
   hipStream_t stream = as_stream(stream_);
-  const int   dim    = (b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_UFF || b.kind == KIND_MMFF_C || b.kind == KIND_UFF_C) ? 3 : 4;
+  const int   dim    = (b.kind == NVMK_FF_DG || b.kind == NVMK_FF_QUARTIC) ? 4 : 3;
   // inverse-Hessian offsets (packed lower triangle per system) and the LDS need of the largest system
   std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
   int                  maxN = 0;

@@ -27,7 +27,7 @@ GROUP_LAYOUT = {
     QUARTIC: [],
     UFF: [(2, 2), (3, 6), (4, 3), (4, 4), (2, 3)],
 }
-DIM = {DG: 4, ETK: 4, MMFF: 3, QUARTIC: 4, UFF: 3}
+DIM = {DG: 4, ETK: 3, MMFF: 3, QUARTIC: 4, UFF: 3}
 # MMFF / UFF batches may append up to four constraint groups (distance, position, angle, torsion; include/nvmolkit_amd.h)
 CONSTRAINT_LAYOUT = [(2, 3), (1, 5), (3, 3), (4, 3)]
 

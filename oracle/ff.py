@@ -32,7 +32,7 @@ LAYOUT = {
     QUARTIC: [],
     UFF: [(2, 2), (3, 6), (4, 3), (4, 4), (2, 3)],
 }
-DIM = {DG: 4, ETK: 4, MMFF: 3, QUARTIC: 4, UFF: 3}
+DIM = {DG: 4, ETK: 3, MMFF: 3, QUARTIC: 4, UFF: 3}
 # optional constraint groups appended to the MMFF / UFF groups: distance, position, angle, torsion
 CONSTRAINT_LAYOUT = [(2, 3), (1, 5), (3, 3), (4, 3)]
 

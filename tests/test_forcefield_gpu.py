@@ -121,13 +121,21 @@ def test_bfgs_lowers_energy_and_matches_oracle_minimiser(kind):
     np.testing.assert_allclose(batch.compute_energy(pos, w0, w1).cpu().numpy(), e1, rtol=1e-9, atol=1e-9)
     # the same algorithm in plain numpy from the same start reaches the same minimum (trajectories are
     # chaotic in the last digits, so compare energies, as the reference does: 1e-3 after minimisation)
+    compared = 0
     for s, (p, g) in enumerate(systems[:3]):
         shape = p.shape
         e_fn = lambda x: off.system_energy(kind, x.reshape(shape), g, w0, w1)  # noqa: E731
         g_fn = lambda x: off.system_gradient(kind, x.reshape(shape), g, w0, w1, h=1e-6).reshape(-1)  # noqa: E731
         _, e_ref, conv, _ = off.bfgs_minimize(e_fn, g_fn, p.reshape(-1), max_iters=300, grad_tol=1e-4, scale_grads=True)
-        if conv and statuses[s].item() == 0:
+        # a start from which the oracle itself lands in different basins for different finite-difference steps says
+        # nothing about the product: compare only where the oracle is stable
+        g_fn2 = lambda x: off.system_gradient(kind, x.reshape(shape), g, w0, w1, h=1e-7).reshape(-1)  # noqa: E731
+        _, e_ref2, conv2, _ = off.bfgs_minimize(e_fn, g_fn2, p.reshape(-1), max_iters=300, grad_tol=1e-4, scale_grads=True)
+        stable = conv and conv2 and abs(e_ref - e_ref2) <= 1e-4 * max(1.0, abs(e_ref))
+        if stable and statuses[s].item() == 0:
+            compared += 1
             assert abs(e1[s] - e_ref) <= 1e-3 * max(1.0, abs(e_ref)), (s, e1[s], e_ref)
+    assert compared >= 1
 
 
 def test_split_call_equivalence():
