@@ -319,8 +319,22 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   // 40 % SLOWER: statically strided workgroups run phase-locked, so the four on a CU load together and then compute
   // together instead of covering each other.)
   const unsigned sidx   = blockIdx.z * gridDim.y + blockIdx.y;  // supertile index (grid y and z are 16-bit each)
-  const unsigned sm     = sidx / superN;
-  const unsigned sn     = sidx - sm * superN;
+  unsigned       sm, sn;
+  if (symmetric) {
+    // only the supertiles on or above the diagonal are launched (the strictly lower ones would be 2 M workgroups that
+    // exit at once at N = 1M): sidx enumerates row sm = 0.., columns sn = sm..superN-1
+    const double S = static_cast<double>(superN);
+    unsigned     r = static_cast<unsigned>((2.0 * S + 1.0 - sqrt((2.0 * S + 1.0) * (2.0 * S + 1.0) - 8.0 * static_cast<double>(sidx))) * 0.5);
+    auto rowStart  = [&](const unsigned q) { return static_cast<unsigned long long>(q) * (2ull * superN - q + 1ull) / 2ull; };
+    while (r > 0 && rowStart(r) > sidx) --r;
+    while (rowStart(r + 1) <= sidx) ++r;
+    sm = r;
+    sn = r + static_cast<unsigned>(sidx - rowStart(r));
+    if (sm >= superN) return;  // padding of the 2-D supertile grid
+  } else {
+    sm = sidx / superN;
+    sn = sidx - sm * superN;
+  }
   const unsigned tile_m = sm * superH + blockIdx.x / superW;
   const unsigned tile_n = sn * superW + (blockIdx.x - (blockIdx.x / superW) * superW);
   if (tile_m >= tilesM || tile_n >= tilesN) return;
@@ -538,7 +552,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   const int64_t superW  = std::min<int64_t>(tilesN, superE);
   const int64_t superM  = ceil_div<int64_t>(tilesM, superE);
   const int64_t superN  = ceil_div<int64_t>(tilesN, superW);
-  const int64_t supers = superM * superN;
+  const int64_t supers = a.symmetric ? superN * (superN + 1) / 2 : superM * superN;  // symmetric: upper triangle only
   const int64_t gy     = std::min<int64_t>(supers, 65535);
   const int64_t gz     = ceil_div<int64_t>(supers, gy);
   NVMK_REQUIRE(gz <= 65535, "neighbor counts: problem too large for one launch");
