@@ -6,6 +6,7 @@
 //   P3  16-B nontemporal stores, one full 1-KB tile row per wave instruction (LDS-transposed layout)
 //   P4  as P3 with plain stores
 //   P5  as P3, 512 B segments (2 rows x 512 B)
+//   P6 / P7 / P8  as P0 with cache-policy bits sc0 sc1 / sc0 sc1 nt / sc1 nt
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -62,6 +63,22 @@ template <int P> __global__ __launch_bounds__(256) void store_kernel(double* out
       d2 x; x.x = v + r; x.y = v - r;
       if (P == 3) __builtin_nontemporal_store(x, reinterpret_cast<d2*>(p)); else *reinterpret_cast<d2*>(p) = x;
     }
+  } else if (P == 6 || P == 7 || P == 8) {
+    // cache-policy variants of P0 (8-B stores in the MFMA C layout) via the instruction's sc0 / sc1 / nt bits
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wr + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          double*   p   = base + (long)row * ld + wc + j * 32 + (lane & 31);
+          const double x = v + r;
+          if (P == 6) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+          if (P == 7) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(x) : "memory");
+          if (P == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(p), "v"(x) : "memory");
+        }
   } else if (P == 5) {
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
@@ -94,6 +111,7 @@ int main() {
   double* out; CK(hipMalloc(&out, (size_t)tilesR * 128 * ld * 8));
   run<0>(out, ld, tilesR, tilesC); run<1>(out, ld, tilesR, tilesC); run<2>(out, ld, tilesR, tilesC);
   run<3>(out, ld, tilesR, tilesC); run<4>(out, ld, tilesR, tilesC); run<5>(out, ld, tilesR, tilesC);
+  run<6>(out, ld, tilesR, tilesC); run<7>(out, ld, tilesR, tilesC); run<8>(out, ld, tilesR, tilesC);
   CK(hipMemset(out, 0, (size_t)tilesR * 128 * ld * 8)); CK(hipDeviceSynchronize());
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   CK(hipEventRecord(a)); CK(hipMemsetAsync(out, 1, (size_t)tilesR * 128 * ld * 8)); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
