@@ -10,7 +10,7 @@
 //
 // Workspace layout of a prepared set of n fingerprints of W words (fp_bits = 32 W):
 //   [ int32 popc[nPad] ][ pad to 256 B ][ uint4 rows[nPad][Wp] ]
-//   nPad = round_up(n, 128) (zero rows), Wp = round_up(W, 16) (zero words): word w of a row becomes the
+//   nPad = round_up(n, 384) (zero rows), Wp = round_up(W, 16) (zero words): word w of a row becomes the
 //   16 bytes rows[row][w] = 32 nibbles, nibble k = 0x2 if bit k of the word is set.
 #pragma once
 
@@ -19,12 +19,14 @@
 namespace nvmk {
 namespace fp4 {
 
-constexpr int ROW_PAD  = 128;  // rows per workgroup tile
+constexpr int ROW_PAD   = 128;  // rows per workgroup tile of the 128 x 128 kernels; alignment of row chunks
+constexpr int ROW_ALLOC = 384;  // prepared sets are zero-padded to a multiple of this (lcm of every kernel's tile edges:
+                                // 128, and 128 x 192 for the producer / consumer dense kernel)
 constexpr int WORD_PAD = 16;   // words per LDS K-chunk
 
 struct Layout {
   int64_t n;       // valid rows
-  int64_t nPad;    // rows allocated (multiple of ROW_PAD)
+  int64_t nPad;    // rows allocated (multiple of ROW_ALLOC)
   int     W;       // packed words per fingerprint
   int     Wp;      // expanded words per row (multiple of WORD_PAD)
   size_t  rowsOffset;
@@ -34,7 +36,7 @@ struct Layout {
 inline Layout layout(int64_t n, int fpBits) {
   Layout L;
   L.n                   = n;
-  L.nPad                = (n + ROW_PAD - 1) / ROW_PAD * ROW_PAD;
+  L.nPad                = (n + ROW_ALLOC - 1) / ROW_ALLOC * ROW_ALLOC;
   L.W                   = fpBits / 32;
   L.Wp                  = (L.W + WORD_PAD - 1) / WORD_PAD * WORD_PAD;
   const size_t popBytes = static_cast<size_t>(L.nPad) * sizeof(int32_t);

@@ -189,6 +189,9 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
   } else {
     pcB[tid - TM] = popB[rowB0 + tid - TM];
   }
+  // Wave priority by phase: a workgroup in its main loop (DMA issue, ds_read, MFMA) goes before co-resident workgroups
+  // that are converting and storing, which have plenty of independent work to hide behind (+0.8 % measured).
+  __builtin_amdgcn_s_setprio(2);
 
   v16f acc[2][2];
 #pragma unroll
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
   // Epilogue: D[i][j], i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), j = lane & 31 inside each 32 x 32 block.
   // Addresses are a wave-uniform 64-bit row base plus one 32-bit per-lane byte offset; interior tiles take the
   // branch-free path so the 64 divisions and stores of a lane interleave.
+  __builtin_amdgcn_s_setprio(0);
   const bool     full    = (rowA0 + TM <= nA) && (rowB0 + TN <= nB);
   const unsigned hi      = static_cast<unsigned>(lane >> 5);
   const unsigned laneOff = (hi * 4u * static_cast<unsigned>(ld) + static_cast<unsigned>(lane & 31)) * 8u;
@@ -271,6 +275,263 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
     emit(std::true_type{});
   } else {
     emit(std::false_type{});
+  }
+}
+
+// ---- helpers of the producer / consumer kernel below ----------------------------------------------
+constexpr int BN = 192;  // tile columns
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {  // n <= 32: whatever the ring geometry can produce
+#define NVMK_W(k) case k: wait_vmcnt<k>(); break;
+  switch (n) {
+    NVMK_W(0) NVMK_W(1) NVMK_W(2) NVMK_W(3) NVMK_W(4) NVMK_W(5) NVMK_W(6) NVMK_W(7) NVMK_W(8) NVMK_W(9) NVMK_W(10)
+    NVMK_W(11) NVMK_W(12) NVMK_W(13) NVMK_W(14) NVMK_W(15) NVMK_W(16) NVMK_W(17) NVMK_W(18) NVMK_W(19) NVMK_W(20)
+    NVMK_W(21) NVMK_W(22) NVMK_W(23) NVMK_W(24) NVMK_W(25) NVMK_W(26) NVMK_W(27) NVMK_W(28) NVMK_W(29) NVMK_W(30)
+    NVMK_W(31) NVMK_W(32)
+    default: wait_vmcnt<0>(); break;
+  }
+#undef NVMK_W
+}
+
+// ---- dense cross-similarity, producer / consumer kernel --------------------------------------------
+// One persistent 1024-thread workgroup per CU, no workgroup barrier after start-up:
+//   * 4 loader waves stream the operand stages (KW words of 128 + 192 rows, LDS-DMA) of a SEQUENCE of 128 x 192 tiles
+//     into a ring of LDS slots, always D = STAGES - 2 stages in flight, and publish "slot s holds its k-th stage" by
+//     bumping readyCnt[s] after a counted s_waitcnt vmcnt;
+//   * two groups of 6 compute waves (2 x 3, 64 x 64 each) take the tiles alternately: poll readyCnt, ds_read + MFMA,
+//     bump freeCnt[s] (the loaders poll it before they overwrite a slot), and after the last stage of their tile run
+//     the whole 64-element epilogue as one straight-line block.  While one group converts and stores tile T the other
+//     multiplies tile T + 1, whose stages the loaders had already started fetching, so loads, matrix work and stores
+//     of ONE workgroup overlap (in the 128 x 128 kernel they only overlap across co-resident workgroups, by luck).
+// LDS operations of a wave execute in order, so a wave's freeCnt bump cannot pass its ds_reads of that slot, and a
+// loader's readyCnt bump cannot pass the DMA writes it waited for.  Loaders never store and compute waves never load
+// from global memory, so nobody's vmcnt mixes loads and stores.
+constexpr int PM = 128;  // tile rows
+
+__device__ __forceinline__ int lds_peek(const int* p) {  // ds_read the compiler may neither cache nor reorder
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p))) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void lds_bump(int* p, const int lane) {
+  if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p))), "v"(1) : "memory");
+}
+
+template <int METRIC, int STAGES, int KW, bool PROF = false>
+__global__ __launch_bounds__(1024, 1) void cross_sim_pp_kernel(const uint4* __restrict__ A, const int32_t* __restrict__ popA,
+                                                            const int64_t nA, const uint4* __restrict__ B,
+                                                            const int32_t* __restrict__ popB, const int64_t nB, const int Wp,
+                                                            double* __restrict__ out, const int64_t ld, const unsigned tilesM,
+                                                            const unsigned tilesN, long long* __restrict__ prof) {
+  using C = Chunk<KW>;
+  long long nPollFail = 0, tEpi = 0, tAll = PROF ? static_cast<long long>(wall_clock64()) : 0;
+  constexpr int STAGE_A = PM * KW * 16;                // 8 KB at KW = 4
+  constexpr int STAGE   = STAGE_A + BN * KW * 16;      // 20 KB at KW = 4
+  constexpr int RP      = 64 / KW;                     // rows one DMA instruction covers
+  constexpr int APL = PM / RP / 4, BPL = BN / RP / 4;  // DMA instructions per loader wave and stage, A and B
+  constexpr int LOADS   = APL + BPL;
+  constexpr int D       = STAGES - 2;                  // stages in flight
+  constexpr int PCBUF   = PM + BN;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  int* pcBase   = reinterpret_cast<int*>(smem + STAGES * STAGE);  // [4][PM + BN], by tile index & 3
+  int* readyCnt = pcBase + 4 * PCBUF;                             // [STAGES]
+  int* freeCnt  = readyCnt + STAGES;                              // [STAGES]
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nst  = Wp / KW;
+  // Tile order: 16 x 16-tile supertiles, row-major inside (tile column fastest).  The workgroups of one step work
+  // through the same supertile, so the chip writes a 24 KB wide stripe of the output at any moment and XCD x
+  // (workgroups = x mod 8) keeps tile columns x and x + 8 of the supertile in its L2.  Slots past the matrix edge
+  // are computed on clamped operands and stored nowhere.
+  constexpr unsigned SUP = 16;
+  const unsigned superM = (tilesM + SUP - 1) / SUP, superN = (tilesN + SUP - 1) / SUP;
+  const unsigned long long nSlots = static_cast<unsigned long long>(superM) * superN * (SUP * SUP);
+  const unsigned long long first = blockIdx.x, stride = gridDim.x;
+  if (first >= nSlots) return;
+  const int myTiles     = static_cast<int>((nSlots - first + stride - 1) / stride);
+  const int totalStages = myTiles * nst;
+  auto tile_of = [&](const int k, unsigned& tm, unsigned& tn) {
+    const unsigned long long t = first + static_cast<unsigned long long>(k) * stride;
+    const unsigned sidx = static_cast<unsigned>(t / (SUP * SUP)), within = static_cast<unsigned>(t % (SUP * SUP));
+    const unsigned sm = sidx / superN, sn = sidx - sm * superN;
+    tm = sm * SUP + within / SUP;
+    tn = sn * SUP + within % SUP;
+  };
+  if (tid < 2 * STAGES) readyCnt[tid] = 0;
+  __syncthreads();
+
+  if (wave >= 12) {
+    // ---------------- loader waves ----------------
+    const int q = wave - 12;
+    // Loaders outrank the compute waves they share a SIMD with: their few address instructions must not queue behind
+    // the epilogue's f64 stream, or the DMA pipe runs dry.
+    __builtin_amdgcn_s_setprio(3);
+    unsigned offA[APL], offB[BPL];  // this lane's 16-byte piece inside the tile, in uint4 units (without the stage's word offset)
+#pragma unroll
+    for (int k = 0; k < APL; ++k) {
+      const unsigned row = static_cast<unsigned>((q * APL + k) * RP + lane / KW);
+      offA[k]            = row * static_cast<unsigned>(Wp) + ((static_cast<unsigned>(lane) & (KW - 1)) ^ C::swz(row));
+    }
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+      const unsigned row = static_cast<unsigned>((q * BPL + k) * RP + lane / KW);
+      offB[k]            = row * static_cast<unsigned>(Wp) + ((static_cast<unsigned>(lane) & (KW - 1)) ^ C::swz(row));
+    }
+    // issue cursor: stage gi = tile ti, word chunk ci, ring slot si, its use count ui
+    int          gi = 0, ti = 0, ci = 0, si = 0, ui = 0;
+    const uint4 *gA = nullptr, *gB = nullptr;
+    const int32_t *pA = nullptr, *pB = nullptr;
+    auto issue = [&]() {
+      if (ci == 0) {
+        unsigned tm, tn;
+        tile_of(ti, tm, tn);
+        tm = tm < tilesM ? tm : tilesM - 1;
+        tn = tn < tilesN ? tn : tilesN - 1;
+        gA = A + static_cast<int64_t>(tm) * PM * Wp;
+        gB = B + static_cast<int64_t>(tn) * BN * Wp;
+        pA = popA + static_cast<int64_t>(tm) * PM;
+        pB = popB + static_cast<int64_t>(tn) * BN;
+      }
+      if (ui > 0) {  // the slot's previous stage must have been read by its six consumers
+        while (lds_peek(freeCnt + si) < 6 * ui) { __builtin_amdgcn_s_sleep(1); if constexpr (PROF) ++nPollFail; }
+      }
+      char*        st = smem + si * STAGE;
+      const uint4* sa = gA + ci * KW;  // wave-uniform bases; the per-lane part is a 32-bit offset
+      const uint4* sb = gB + ci * KW;
+#pragma unroll
+      for (int k = 0; k < APL; ++k) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(sa + offA[k]), (lptr_t)(st + (q * APL + k) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < BPL; ++k) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(sb + offB[k]), (lptr_t)(st + STAGE_A + (q * BPL + k) * 1024), 16, 0, 0);
+      }
+      if (ci == 0) {  // popcounts: two dword DMA loads per loader wave (repeats keep the count equal on every wave)
+        int*      pc = pcBase + (ti & 3) * PCBUF;
+        const int pa = q & 1, pb = q < 3 ? q : 0;
+        __builtin_amdgcn_global_load_lds((gptr_t)(pA + pa * 64 + lane), (lptr_t)(pc + pa * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pB + pb * 64 + lane), (lptr_t)(pc + PM + pb * 64), 4, 0, 0);
+      }
+      ++gi;
+      if (++ci == nst) { ci = 0; ++ti; }
+      if (++si == STAGES) { si = 0; ++ui; }
+    };
+    int ce = 0, se = 0;  // oldest unpublished stage: chunk index and slot
+    for (int g = 0; g < totalStages + D; ++g) {
+      if (g >= D) {  // publish stage e = g - D: everything this wave issued for it has landed
+        const int e = g - D;
+        int younger = 0, cc = ce;
+#pragma unroll
+        for (int k = 1; k < D; ++k) {
+          if (++cc == nst) cc = 0;
+          if (e + k < gi) younger += (cc == 0) ? LOADS + 2 : LOADS;
+        }
+        wait_vmcnt_dyn(younger);
+        lds_bump(readyCnt + se, lane);
+        if (++ce == nst) ce = 0;
+        if (++se == STAGES) se = 0;
+      }
+      if (g < totalStages) issue();
+    }
+    if constexpr (PROF) {
+      if (blockIdx.x == 0 && lane == 0) { prof[wave * 4] = nPollFail; prof[wave * 4 + 1] = 0; prof[wave * 4 + 2] = static_cast<long long>(wall_clock64()) - tAll; prof[wave * 4 + 3] = totalStages; }
+    }
+    return;
+  }
+
+  // ---------------- compute waves ----------------
+  const int      group = wave / 6, w6 = wave % 6;
+  const int      wm = w6 / 3, wn = w6 % 3;
+  const int      l31  = lane & 31;
+  const unsigned half = static_cast<unsigned>(lane >> 5);
+  const unsigned rA   = static_cast<unsigned>(wm * 64 + l31), rB = static_cast<unsigned>(wn * 64 + l31);
+  const unsigned baseA = rA * C::ROWBYTES, baseB = STAGE_A + rB * C::ROWBYTES;
+  const unsigned swA = C::swz(rA), swB = C::swz(rB);
+  for (int T = group; T < myTiles; T += 2) {
+    v16f acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+      }
+    }
+    int g    = T * nst;
+    int slot = g % STAGES, need = 4 * (g / STAGES + 1);
+    __builtin_amdgcn_s_setprio(2);  // the group feeding the matrix cores goes before the group converting and storing
+    for (int c = 0; c < nst; ++c) {
+      while (lds_peek(readyCnt + slot) < need) { __builtin_amdgcn_s_sleep(1); if constexpr (PROF) ++nPollFail; }
+      const char* st = smem + slot * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < KW / 2; ++ks) {
+        const unsigned sl   = static_cast<unsigned>(ks * 2) + half;
+        const unsigned offA = baseA + ((sl ^ swA) << 4), offB = baseB + ((sl ^ swB) << 4);
+        const uint4    a0 = *reinterpret_cast<const uint4*>(st + offA);
+        const uint4    a1 = *reinterpret_cast<const uint4*>(st + offA + 32 * C::ROWBYTES);
+        const uint4    b0 = *reinterpret_cast<const uint4*>(st + offB);
+        const uint4    b1 = *reinterpret_cast<const uint4*>(st + offB + 32 * C::ROWBYTES);
+        acc[0][0]         = mfma_fp4(a0, b0, acc[0][0]);
+        acc[0][1]         = mfma_fp4(a0, b1, acc[0][1]);
+        acc[1][0]         = mfma_fp4(a1, b0, acc[1][0]);
+        acc[1][1]         = mfma_fp4(a1, b1, acc[1][1]);
+      }
+      asm volatile("" ::: "memory");
+      lds_bump(freeCnt + slot, lane);  // queued behind this wave's ds_reads of the slot
+      if (++slot == STAGES) { slot = 0; need += 4; }
+    }
+    // epilogue (same element order as the 128 x 128 kernel), one straight-line block
+    __builtin_amdgcn_s_setprio(0);
+    const long long te0 = PROF ? static_cast<long long>(wall_clock64()) : 0;
+    unsigned tm, tn;
+    tile_of(T, tm, tn);
+    const int*     pc      = pcBase + (T & 3) * PCBUF;
+    const int64_t  rowA0   = static_cast<int64_t>(tm) * PM, rowB0 = static_cast<int64_t>(tn) * BN;
+    const bool     full    = (rowA0 + PM <= nA) && (rowB0 + BN <= nB);
+    const unsigned laneOff = (half * 4u * static_cast<unsigned>(ld) + static_cast<unsigned>(l31)) * 8u;
+    char*          waveOut = reinterpret_cast<char*>(out + (rowA0 + wm * 64) * ld + rowB0 + wn * 64);
+    const int      pb0 = pc[PM + wn * 64 + l31], pb1 = pc[PM + wn * 64 + 32 + l31];
+    auto value = [&](const int cnt, const int pav, const int pbv) -> double {
+      if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
+        const int u = pav + pbv - cnt;
+        return ratio_by_newton(cnt, u > 1 ? u : 1);
+      } else {
+        const double denom = sqrt(static_cast<double>(pav) * static_cast<double>(pbv));
+        return (cnt == 0 || denom == 0.0) ? 0.0 : static_cast<double>(cnt) / denom;
+      }
+    };
+    auto emit = [&](auto fullTag) {
+      constexpr bool FULL = decltype(fullTag)::value;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int il0    = mi * 32 + (r & 3) + 8 * (r >> 2);
+          const int pav    = pc[wm * 64 + il0 + 4 * static_cast<int>(half)];
+          char*     rowOut = waveOut + static_cast<int64_t>(il0) * ld * 8;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const double v   = value(static_cast<int>(acc[mi][ni][r]), pav, ni ? pb1 : pb0);
+            double*      dst = reinterpret_cast<double*>(rowOut + ni * 256 + laneOff);
+            if (FULL || (rowA0 + wm * 64 + il0 + 4 * static_cast<int>(half) < nA && rowB0 + wn * 64 + ni * 32 + l31 < nB)) {
+              __builtin_nontemporal_store(v, dst);
+            }
+          }
+        }
+      }
+    };
+    if (full) {
+      emit(std::true_type{});
+    } else {
+      emit(std::false_type{});
+    }
+    if constexpr (PROF) tEpi += static_cast<long long>(wall_clock64()) - te0;
+  }
+  if constexpr (PROF) {
+    if (blockIdx.x == 0 && lane == 0) { prof[wave * 4] = nPollFail; prof[wave * 4 + 1] = tEpi; prof[wave * 4 + 2] = static_cast<long long>(wall_clock64()) - tAll; prof[wave * 4 + 3] = totalStages; }
   }
 }
 
@@ -525,13 +786,51 @@ int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, 
   // the epilogue keeps 4 rows * ld * 8 bytes in a 32-bit lane offset; popcounts must stay exact in f32
   NVMK_REQUIRE(ld < (int64_t{1} << 26), "cross similarity: ld_out %lld too large (max 2^26 - 1)", (long long)ld);
   NVMK_REQUIRE(A.L.W * 32 < (1 << 24), "cross similarity: fingerprints too wide for the matrix-core path");
-  const int64_t tilesM = A.L.nPad / TM;
-  const int64_t tilesN = B.L.nPad / TN;
+  const int64_t tilesM = ceil_div<int64_t>(A.L.n, TM);
+  const int64_t tilesN = ceil_div<int64_t>(B.L.n, TN);
   const int64_t supers = ceil_div<int64_t>(tilesM, SUPER) * ceil_div<int64_t>(tilesN, SUPER);
   NVMK_REQUIRE(supers <= 65535, "cross similarity: problem too large for one launch (%lld x %lld tiles)",
                (long long)tilesM, (long long)tilesN);
   const dim3     grid(static_cast<unsigned>(SUPER * SUPER), static_cast<unsigned>(supers));
   const unsigned tm = static_cast<unsigned>(tilesM), tn = static_cast<unsigned>(tilesN);
+  // NVMK_DENSE_KERNEL=pp selects the experimental producer / consumer kernel (slower than the tile kernel as measured,
+  // DESIGN.md §4.1; kept selectable because the parity tests run it and the next optimisation round starts from it).
+  // It needs whole 4-word stages and operands zero-padded to 128- / 192-row tiles, which fp4::ROW_ALLOC guarantees.
+  const char*       dk = std::getenv("NVMK_DENSE_KERNEL");
+  const std::string dks(dk ? dk : "");
+  if (dks == "pp" && A.L.Wp % 4 == 0) {
+    static const int cus = [] {
+      int dev = 0, n = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return n > 0 ? n : 256;
+    }();
+    {
+      const unsigned btm = static_cast<unsigned>(ceil_div<int64_t>(A.L.n, PM)), btn = static_cast<unsigned>(ceil_div<int64_t>(B.L.n, BN));
+      constexpr int PPS = 7, PKW = 4;  // 7 ring slots of 20 KB, 5 in flight
+      const size_t  shmem = static_cast<size_t>(PPS) * (PM + BN) * PKW * 16 + 4 * (PM + BN) * 4 + 2 * PPS * 4;
+      auto kern = (metric == NVMK_METRIC_TANIMOTO) ? cross_sim_pp_kernel<NVMK_METRIC_TANIMOTO, PPS, PKW> : cross_sim_pp_kernel<NVMK_METRIC_COSINE, PPS, PKW>;
+      const bool profile = std::getenv("NVMK_PP_PROFILE") != nullptr && metric == NVMK_METRIC_TANIMOTO;
+      if (profile) kern = cross_sim_pp_kernel<NVMK_METRIC_TANIMOTO, PPS, PKW, true>;
+      long long* dProf = nullptr;
+      if (profile) NVMK_HIP_CHECK(hipMalloc(&dProf, 64 * sizeof(long long)));
+      NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(shmem)));
+      hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(cus)), dim3(1024), shmem, stream, A.rows, A.popc, A.L.n, B.rows, B.popc,
+                         B.L.n, A.L.Wp, out, ld, btm, btn, dProf);
+      NVMK_LAUNCH_CHECK();
+      if (profile) {  // debugging aid: workgroup 0, per wave
+        long long h[64];
+        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+        NVMK_HIP_CHECK(hipMemcpy(h, dProf, sizeof(h), hipMemcpyDeviceToHost));
+        NVMK_HIP_CHECK(hipFree(dProf));
+        for (int w = 0; w < 16; ++w)
+          std::fprintf(stderr, "[pp] wave %2d %s: %lld stages, %.2f failed polls/stage, epilogue %.3f us/stage, total %.3f us/stage\n", w,
+                       w < 12 ? "compute" : "loader ", h[w * 4 + 3], double(h[w * 4]) / h[w * 4 + 3], h[w * 4 + 1] * 0.01 / h[w * 4 + 3],
+                       h[w * 4 + 2] * 0.01 / h[w * 4 + 3]);
+      }
+      return NVMK_OK;
+    }
+  }
   if (metric == NVMK_METRIC_TANIMOTO) return launch_dense_t<NVMK_METRIC_TANIMOTO>(A, B, out, ld, grid, tm, tn, stream);
   return launch_dense_t<NVMK_METRIC_COSINE>(A, B, out, ld, grid, tm, tn, stream);
 }
