@@ -430,7 +430,13 @@ struct LoopState {
   int32_t            done;        // set when the max degree reaches 0 or nothing is alive
   int32_t            lastMax;     // degree of the most recent centroid (upper bound for later rounds)
   int32_t            finalParity; // which alive list holds the degree-0 leftovers when done
+  // sparse round loop: the bucket of rows that hold the current maximal degree
+  int32_t            bucketMax;   // scratch of bucket_max_kernel (reset by the loop kernel)
+  int32_t            curDegree;   // degree of the bucket in `cand`
+  int32_t            nCand;       // rows in `cand` (descending row order)
+  int32_t            parity;      // which of L0 / L1 is the harvest list of the next round
 };
+static_assert(sizeof(LoopState) <= 32 * sizeof(int32_t), "LoopState must fit the 32-word state block");
 
 __global__ void init_state_kernel(LoopState* __restrict__ st, const int32_t n) {
   st->bestKey[0]  = 0ull;
@@ -443,6 +449,10 @@ __global__ void init_state_kernel(LoopState* __restrict__ st, const int32_t n) {
   st->done        = 0;
   st->lastMax     = n;
   st->finalParity = 0;
+  st->bucketMax   = 0;
+  st->curDegree   = 0;
+  st->nCand       = 0;
+  st->parity      = 0;
 }
 
 __global__ void iota_kernel(int32_t* __restrict__ rows, const int64_t n) {
@@ -610,154 +620,295 @@ __global__ void csr_fill_kernel(const int2* __restrict__ edges, const unsigned l
   }
 }
 
-// alive = 1 everywhere; L0 = rows whose degree (self included) is exactly 1
-__global__ void sparse_init_kernel(const int32_t n, const int32_t* __restrict__ counts, uint8_t* __restrict__ alive,
-                                   int32_t* __restrict__ L0, int32_t* __restrict__ nL0) {
+// L0 = rows whose degree (self included) is exactly 1
+__global__ void sparse_init_kernel(const int32_t n, const int32_t* __restrict__ counts, int32_t* __restrict__ L0,
+                                   int32_t* __restrict__ nL0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  alive[i] = 1;
   if (counts[i] == 1) L0[atomicAdd(nL0, 1)] = i;
 }
 
-// argmax of the degree over alive rows with degree >= 2, ties toward the HIGHEST row (clustering.py:159)
-__global__ __launch_bounds__(NT) void sparse_argmax_kernel(LoopState* __restrict__ st, const int32_t n,
-                                                           const uint8_t* __restrict__ alive,
-                                                           const int32_t* __restrict__ counts, const int parity) {
+// ---- the round loop on the device ------------------------------------------------------------------
+// A round needs the LAST row with the maximal degree (clustering.py:159).  Degrees only ever decrease, so the rows that
+// hold the current maximum D form a bucket that can only shrink: it is compacted once, in DESCENDING row order, and a
+// persistent one-workgroup kernel then runs round after round off it — centroid = first bucket entry that is still
+// alive with degree D — with no launch, no 1M-row argmax and no host sync per round (those cost 24.5 us x 20 032
+// rounds = 0.49 of the 1.0 s at N = 1M).  When the bucket runs dry the kernel returns and the next epoch (four small
+// multi-workgroup kernels: max, count, scan, fill) builds the bucket of the next lower degree present; the number of
+// epochs is bounded by the number of distinct degrees (80 at N = 1M).
+// Inside the persistent kernel, data written by the workgroup itself (atomics execute in L2, stores write through)
+// is re-read with agent-scope loads, which bypass the CU's L1: a plain load could hit a stale line.
+
+constexpr int BUCKET_ROWS = 1024;  // rows per workgroup of the bucket kernels
+
+template <typename T> __device__ __forceinline__ T ldc(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(NT) void bucket_max_kernel(LoopState* __restrict__ st, const int32_t n, const int32_t* __restrict__ counts) {
   if (st->done) return;
-  unsigned long long best = 0ull;
+  int best = 0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * NT + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * NT) {
     const int32_t c = counts[i];
-    if (c >= 2 && alive[i]) {
-      const unsigned long long key = (static_cast<unsigned long long>(c) << 32) | static_cast<unsigned>(i);
-      best                         = key > best ? key : best;
-    }
+    if (c >= 2) best = c > best ? c : best;  // rows that left the live set carry the degree DEAD
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long other = __shfl_xor(best, o);
-    best                           = other > best ? other : best;
+    const int other = __shfl_xor(best, o);
+    best            = other > best ? other : best;
   }
-  __shared__ unsigned long long wbest[NT / 64];
-  if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+  if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(&st->bucketMax, best);
+}
+
+// reversed row index ri = 0 is row n - 1: ascending ri = descending row
+__device__ __forceinline__ bool in_bucket(const int64_t ri, const int32_t n, const int D, const int32_t* __restrict__ counts) {
+  return ri < n && counts[n - 1 - ri] == D;
+}
+
+__global__ __launch_bounds__(NT) void bucket_count_kernel(const LoopState* __restrict__ st, const int32_t n,
+                                                          const int32_t* __restrict__ counts, int32_t* __restrict__ blockCounts) {
+  if (st->done) return;
+  const int D = st->bucketMax;
+  int       c = 0;
+  if (D >= 2) {
+    for (int k = 0; k < BUCKET_ROWS / NT; ++k) {
+      c += in_bucket(static_cast<int64_t>(blockIdx.x) * BUCKET_ROWS + k * NT + threadIdx.x, n, D, counts) ? 1 : 0;
+    }
+  }
+  __shared__ int total;
+  if (threadIdx.x == 0) total = 0;
   __syncthreads();
+  if (c) atomicAdd(&total, c);
+  __syncthreads();
+  if (threadIdx.x == 0) blockCounts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(NT) void bucket_scan_kernel(LoopState* __restrict__ st, int32_t* __restrict__ blockCounts, const int nBlocks) {
+  if (st->done) return;
+  // exclusive scan in place, one workgroup (nBlocks <= a few thousand)
+  __shared__ int carry;
+  __shared__ int wsum[NT / 64];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nBlocks; base += NT) {
+    const int i = base + threadIdx.x;
+    const int v = i < nBlocks ? blockCounts[i] : 0;
+    int       x = v;  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if ((threadIdx.x & 63) >= o) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+    if (i < nBlocks) blockCounts[i] = before + x - v;
+    __syncthreads();
+    if (threadIdx.x == NT - 1) carry = before + x;
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    for (int w = 1; w < NT / 64; ++w) best = wbest[w] > best ? wbest[w] : best;
-    if (best != 0ull) atomicMax(&st->bestKey[parity], best);
+    st->nCand     = carry;
+    st->curDegree = st->bucketMax;
   }
 }
 
-// One round on ONE workgroup: harvest L, extract the centroid's cluster, subtract its members from their live
-// neighbours and collect the rows that drop to degree 1.
-__global__ __launch_bounds__(NT) void sparse_round_kernel(LoopState* __restrict__ st, const unsigned long long* __restrict__ offsets,
-                                                          const int32_t* __restrict__ nbr, uint8_t* __restrict__ alive,
-                                                          int32_t* __restrict__ counts, int32_t* __restrict__ clusterIdx,
-                                                          int32_t* __restrict__ clusterOffsets, int32_t* __restrict__ centroids,
-                                                          int32_t* __restrict__ L0, int32_t* __restrict__ L1,
-                                                          int32_t* __restrict__ nL, const int parity) {
+__global__ __launch_bounds__(NT) void bucket_fill_kernel(const LoopState* __restrict__ st, const int32_t n,
+                                                         const int32_t* __restrict__ counts, const int32_t* __restrict__ blockOffsets,
+                                                         int32_t* __restrict__ cand) {
   if (st->done) return;
-  __shared__ int sCount;   // members found / rows added to the next L
-  __shared__ int sMaxRow;
-  const int                tid   = threadIdx.x;
-  const unsigned long long key   = st->bestKey[parity];
-  int32_t*                 Lcur  = parity ? L1 : L0;
-  int32_t*                 Lnext = parity ? L0 : L1;
-  const int                nLcur = nL[parity];
+  const int D = st->bucketMax;
+  if (D < 2) return;
+  __shared__ int wbase[NT / 64];
+  __shared__ int running;
+  if (threadIdx.x == 0) running = blockOffsets[blockIdx.x];
+  __syncthreads();
+  for (int k = 0; k < BUCKET_ROWS / NT; ++k) {
+    const int64_t  ri = static_cast<int64_t>(blockIdx.x) * BUCKET_ROWS + k * NT + threadIdx.x;
+    const bool     f  = in_bucket(ri, n, D, counts);
+    const uint64_t m  = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wbase[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    int before = running;
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) before += wbase[w];
+    if (f) cand[before + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = static_cast<int32_t>(n - 1 - ri);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < NT / 64; ++w) t += wbase[w];
+      running += t;
+    }
+    __syncthreads();
+  }
+}
+
+// Rounds off the current bucket, on ONE workgroup: harvest L, extract the centroid's cluster, subtract its members
+// from their live neighbours and collect the rows that drop to degree 1; repeat until the bucket is exhausted.
+// A row that leaves the live set gets the degree DEAD (hugely negative), so "alive" needs no array of its own:
+// extraction is one atomicExch per neighbour (old > 0: a new member), subtraction one atomicSub (old == 2: the row is
+// down to itself -> next round's harvest; dead rows just get a little more negative), the bucket test is degree == D.
+// A round is then a chain of ~8 dependent L2 round trips: members and their CSR ranges are handed from the extraction
+// to the subtraction through LDS.
+constexpr int32_t DEAD        = -(1 << 30);
+constexpr int     LOOP_MEMBERS = 2048;  // members staged in LDS; larger clusters take the list back from clusterIdx
+
+__global__ __launch_bounds__(NT) void sparse_loop_kernel(LoopState* __restrict__ st, const unsigned long long* __restrict__ offsets,
+                                                         const int32_t* __restrict__ nbr, int32_t* __restrict__ counts,
+                                                         int32_t* __restrict__ clusterIdx, int32_t* __restrict__ clusterOffsets,
+                                                         int32_t* __restrict__ centroids, int32_t* __restrict__ L0,
+                                                         int32_t* __restrict__ L1, int32_t* __restrict__ nL,
+                                                         const int32_t* __restrict__ cand) {
+  if (st->done) return;
+  __shared__ int                sCount;   // members found / rows added to the next L
+  __shared__ int                sMaxRow;
+  __shared__ int                sPick;    // index into cand of this round's centroid
+  __shared__ unsigned long long sBeg[LOOP_MEMBERS];
+  __shared__ int                sLen[LOOP_MEMBERS];
+  const int tid    = threadIdx.x;
+  const int D      = st->curDegree;
+  const int nCand  = st->nCand;
+  int       parity = st->parity;
+  int       nLcur  = nL[parity];
+  int       front = st->front, back = st->back, nClusters = st->nClusters;
   if (tid == 0) {
     sCount  = 0;
     sMaxRow = -1;
   }
   __syncthreads();
-  if (key == 0ull) {
+  if (D < 2) {
     // no row of degree >= 2 is left: the highest row of L is this round's centroid (a cluster of one), the others
     // are harvested; nothing else can change afterwards
+    const int32_t* Lcur = parity ? L1 : L0;
     for (int i = tid; i < nLcur; i += NT) atomicMax(&sMaxRow, Lcur[i]);
     __syncthreads();
     const int last = sMaxRow;
-    const int back = st->back;
     if (last >= 0) {
       for (int i = tid; i < nLcur; i += NT) {
         const int r = Lcur[i];
-        alive[r]    = 0;
+        counts[r]   = DEAD;
         if (r != last) clusterIdx[back - atomicAdd(&sCount, 1)] = r;
       }
     }
     __syncthreads();
     if (tid == 0) {
       if (last >= 0) {
-        const int k           = st->nClusters;
-        const int front       = st->front;
-        clusterIdx[front]     = last;
-        centroids[k]          = last;
-        clusterOffsets[k + 1] = front + 1;
-        st->front             = front + 1;
-        st->nClusters         = k + 1;
-        st->back              = back - sCount;
+        clusterIdx[front]             = last;
+        centroids[nClusters]          = last;
+        clusterOffsets[nClusters + 1] = front + 1;
+        st->front                     = front + 1;
+        st->nClusters                 = nClusters + 1;
+        st->back                      = back - sCount;
       }
       st->done = 1;
     }
     return;
   }
-  const int centroid = static_cast<int>(key & 0xffffffffull);
-  const int front    = st->front;
-  const int back     = st->back;
-  // harvest: rows that reached degree 1 in the previous round (they have no live neighbour, nobody touches them)
-  for (int i = tid; i < nLcur; i += NT) {
-    const int r              = Lcur[i];
-    alive[r]                 = 0;
-    clusterIdx[back - i]     = r;
-  }
-  // members = live neighbours of the centroid; they and the centroid leave the live set
-  const unsigned long long o0 = offsets[centroid], o1 = offsets[centroid + 1];
-  if (tid == 0) {
-    clusterIdx[front] = centroid;
-    alive[centroid]   = 0;
-  }
-  for (unsigned long long k = o0 + tid; k < o1; k += NT) {
-    const int j = nbr[k];
-    if (alive[j]) {
-      clusterIdx[front + 1 + atomicAdd(&sCount, 1)] = j;
-      alive[j]                                      = 0;
+  int cursor = 0;
+  for (;;) {
+    // ---- centroid: first bucket entry at or after the cursor that still has degree D ----
+    int centroid = -1;
+    while (cursor < nCand) {
+      if (tid == 0) sPick = 0x7fffffff;
+      __syncthreads();
+      const int idx = cursor + tid;
+      if (idx < nCand && ldc(&counts[cand[idx]]) == D) atomicMin(&sPick, idx);
+      __syncthreads();
+      const int pick = sPick;
+      __syncthreads();
+      if (pick != 0x7fffffff) {
+        centroid = cand[pick];
+        cursor   = pick + 1;
+        break;
+      }
+      cursor += NT;
     }
-  }
-  __threadfence_block();
-  __syncthreads();
-  const int total = 1 + sCount;
-  __syncthreads();
-  if (tid == 0) sCount = 0;
-  __syncthreads();
-  // subtract: every live neighbour of a member loses one; 16 lanes per member
-  const int g = tid >> 4, l = tid & 15;
-  for (int q = g; q < total; q += NT / 16) {
-    const int                m  = clusterIdx[front + q];
-    const unsigned long long a0 = offsets[m], a1 = offsets[m + 1];
-    for (unsigned long long k = a0 + l; k < a1; k += 16) {
+    if (centroid < 0) break;  // bucket exhausted: the next epoch builds the next one
+
+    int32_t* Lcur  = parity ? L1 : L0;
+    int32_t* Lnext = parity ? L0 : L1;
+    // harvest: rows that reached degree 1 in the previous round (they have no live neighbour, nobody touches them)
+    for (int i = tid; i < nLcur; i += NT) {
+      const int r          = ldc(&Lcur[i]);
+      counts[r]            = DEAD;
+      clusterIdx[back - i] = r;
+    }
+    // members = live neighbours of the centroid; they and the centroid leave the live set
+    const unsigned long long o0 = offsets[centroid], o1 = offsets[centroid + 1];
+    if (tid == 0) {
+      clusterIdx[front] = centroid;
+      counts[centroid]  = DEAD;  // its own list does not contain it, nobody else reads it this round
+      sBeg[0]           = o0;
+      sLen[0]           = static_cast<int>(o1 - o0);
+    }
+    for (unsigned long long k = o0 + tid; k < o1; k += NT) {
       const int j = nbr[k];
-      if (alive[j]) {
-        const int old = atomicSub(&counts[j], 1);
-        if (old == 2) Lnext[atomicAdd(&sCount, 1)] = j;  // only itself left: next round's harvest
+      if (atomicExch(&counts[j], DEAD) > 0) {  // was alive: a new member (a neighbour appears once in the list)
+        const int slot             = 1 + atomicAdd(&sCount, 1);
+        clusterIdx[front + slot]   = j;
+        if (slot < LOOP_MEMBERS) {
+          const unsigned long long a0 = offsets[j];
+          sBeg[slot]                  = a0;
+          sLen[slot]                  = static_cast<int>(offsets[j + 1] - a0);
+        }
       }
     }
+    __syncthreads();
+    const int total = 1 + sCount;
+    __syncthreads();
+    if (tid == 0) sCount = 0;
+    if (total > LOOP_MEMBERS) __threadfence();  // the overflow members are re-read from clusterIdx below
+    __syncthreads();
+    // subtract: every neighbour of a member loses one; 16 lanes per member
+    const int g = tid >> 4, l = tid & 15;
+    for (int q = g; q < total; q += NT / 16) {
+      unsigned long long a0;
+      int                len;
+      if (q < LOOP_MEMBERS) {
+        a0  = sBeg[q];
+        len = sLen[q];
+      } else {
+        const int m = ldc(&clusterIdx[front + q]);
+        a0          = offsets[m];
+        len         = static_cast<int>(offsets[m + 1] - a0);
+      }
+      for (int k = l; k < len; k += 16) {
+        const int j = nbr[a0 + k];
+        if (atomicSub(&counts[j], 1) == 2) Lnext[atomicAdd(&sCount, 1)] = j;  // only itself left: next round's harvest
+      }
+    }
+    __threadfence();  // Lnext is read back (from L2) in the next round
+    __syncthreads();
+    if (tid == 0) {
+      centroids[nClusters]          = centroid;
+      clusterOffsets[nClusters + 1] = front + total;
+    }
+    front += total;
+    back -= nLcur;
+    ++nClusters;
+    nLcur = sCount;
+    parity ^= 1;
+    __syncthreads();
+    if (tid == 0) sCount = 0;
+    __syncthreads();
   }
-  __syncthreads();
   if (tid == 0) {
-    const int k           = st->nClusters;
-    centroids[k]          = centroid;
-    clusterOffsets[k + 1] = front + total;
-    st->nClusters         = k + 1;
-    st->front             = front + total;
-    st->back              = back - nLcur;
-    st->lastMax           = static_cast<int32_t>(key >> 32);
-    st->bestKey[parity]   = 0ull;  // consumed; the argmax of round + 2 accumulates into it again
-    nL[parity]            = 0;
-    nL[parity ^ 1]        = sCount;
+    st->front      = front;
+    st->back       = back;
+    st->nClusters  = nClusters;
+    st->lastMax    = D;
+    st->parity     = parity;
+    st->bucketMax  = 0;
+    nL[parity]     = nLcur;
+    nL[parity ^ 1] = 0;
   }
 }
 
 // rows that never had a neighbour (degree 0: all-zero fingerprints) join the singleton tail
-__global__ void sparse_leftover_kernel(LoopState* __restrict__ st, const int32_t n, const uint8_t* __restrict__ alive,
-                                       const int32_t* __restrict__ counts, int32_t* __restrict__ clusterIdx) {
+__global__ void sparse_leftover_kernel(LoopState* __restrict__ st, const int32_t n, const int32_t* __restrict__ counts,
+                                       int32_t* __restrict__ clusterIdx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && alive[i] && counts[i] == 0) clusterIdx[atomicSub(&st->back, 1)] = i;
+  if (i < n && counts[i] == 0) clusterIdx[atomicSub(&st->back, 1)] = i;
 }
 
 template <int METRIC>
@@ -868,16 +1019,15 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
       StreamScratch csrMem, scanTmp;
       const size_t  offBytes = (n + 1) * sizeof(unsigned long long);
       const size_t  nbrBytes = std::max<size_t>(1, static_cast<size_t>(2 * nEdges)) * sizeof(int32_t);
-      // layout: deg[n+1] | offsets[n+1] | cursor[n] (u32) | L0[n] | L1[n] | alive[n] (u8) | nbr[2E]
-      const size_t bytes = 2 * offBytes + n * 4 * 3 + (n + 15) / 16 * 16 + nbrBytes + 64;
+      // layout: deg[n+1] | offsets[n+1] | cursor[n] (u32) | L0[n] | L1[n] | nbr[2E]
+      const size_t bytes = 2 * offBytes + n * 4 * 3 + nbrBytes + 64;
       NVMK_HIP_CHECK(csrMem.alloc(bytes, stream));
       auto* deg     = csrMem.as<unsigned long long>();
       auto* offs64  = deg + (n + 1);
       auto* cursor  = reinterpret_cast<unsigned int*>(offs64 + (n + 1));
       auto* L0      = reinterpret_cast<int32_t*>(cursor + n);
       auto* L1      = L0 + n;
-      auto* aliveF  = reinterpret_cast<uint8_t*>(L1 + n);
-      auto* nbr     = reinterpret_cast<int32_t*>(aliveF + (n + 15) / 16 * 16);
+      auto* nbr     = L1 + n;
       NVMK_HIP_CHECK(hipMemsetAsync(deg, 0, 2 * offBytes + n * 4, stream));  // deg, offsets, cursor
       const unsigned eBlocks = static_cast<unsigned>(std::min<unsigned long long>(ceil_div<unsigned long long>(std::max<unsigned long long>(nEdges, 1), 256), 65535));
       if (nEdges > 0) {
@@ -894,17 +1044,23 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
       }
       int32_t* nL = nAliveNext;  // [2], zeroed above with the state block
       hipLaunchKernelGGL(sparse_init_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
-                         static_cast<int32_t>(N), counts, aliveF, L0, &nL[0]);
+                         static_cast<int32_t>(N), counts, L0, &nL[0]);
       NVMK_LAUNCH_CHECK();
-      const unsigned argBlocks = static_cast<unsigned>(std::min<int64_t>(ceil_div<int64_t>(N, NT * 4), 1024));
-      int64_t        round     = 0;
+      // epochs: build the bucket of the current maximal degree (4 small kernels), run rounds off it (1 persistent kernel)
+      StreamScratch bucketMem;
+      const int     nBuckets = static_cast<int>(ceil_div<int64_t>(N, BUCKET_ROWS));
+      NVMK_HIP_CHECK(bucketMem.alloc((n + nBuckets + 16) * sizeof(int32_t), stream));
+      int32_t*       cand        = bucketMem.as<int32_t>();
+      int32_t*       blockCounts = cand + n;
+      const unsigned maxBlocks   = static_cast<unsigned>(std::min<int64_t>(ceil_div<int64_t>(N, NT * 4), 1024));
       for (;;) {
-        for (int b = 0; b < 64; ++b, ++round) {
-          const int parity = static_cast<int>(round & 1);
-          hipLaunchKernelGGL(sparse_argmax_kernel, dim3(argBlocks), dim3(NT), 0, stream, st, static_cast<int32_t>(N), aliveF,
-                             counts, parity);
-          hipLaunchKernelGGL(sparse_round_kernel, dim3(1), dim3(NT), 0, stream, st, offs64, nbr, aliveF, counts, clusterIdx,
-                             offsets, centroids, L0, L1, nL, parity);
+        for (int e = 0; e < 4; ++e) {
+          hipLaunchKernelGGL(bucket_max_kernel, dim3(maxBlocks), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts);
+          hipLaunchKernelGGL(bucket_count_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts);
+          hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(NT), 0, stream, st, blockCounts, nBuckets);
+          hipLaunchKernelGGL(bucket_fill_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts, cand);
+          hipLaunchKernelGGL(sparse_loop_kernel, dim3(1), dim3(NT), 0, stream, st, offs64, nbr, counts, clusterIdx, offsets, centroids,
+                             L0, L1, nL, cand);
         }
         NVMK_LAUNCH_CHECK();
         NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
@@ -912,7 +1068,7 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
         if (snap.done) break;
       }
       hipLaunchKernelGGL(sparse_leftover_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
-                         st, static_cast<int32_t>(N), aliveF, counts, clusterIdx);
+                         st, static_cast<int32_t>(N), counts, clusterIdx);
       NVMK_LAUNCH_CHECK();
       NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
       NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // csrMem / scanTmp are released in stream order after this

@@ -10,7 +10,7 @@
 //
 // Workspace layout of a prepared set of n fingerprints of W words (fp_bits = 32 W):
 //   [ int32 popc[nPad] ][ pad to 256 B ][ uint4 rows[nPad][Wp] ]
-//   nPad = round_up(n, 384) (zero rows), Wp = round_up(W, 16) (zero words): word w of a row becomes the
+//   nPad = round_up(n, 768) (zero rows), Wp = round_up(W, 16) (zero words): word w of a row becomes the
 //   16 bytes rows[row][w] = 32 nibbles, nibble k = 0x2 if bit k of the word is set.
 #pragma once
 
@@ -20,8 +20,8 @@ namespace nvmk {
 namespace fp4 {
 
 constexpr int ROW_PAD   = 128;  // rows per workgroup tile of the 128 x 128 kernels; alignment of row chunks
-constexpr int ROW_ALLOC = 384;  // prepared sets are zero-padded to a multiple of this (lcm of every kernel's tile edges:
-                                // 128, and 128 x 192 for the producer / consumer dense kernel)
+constexpr int ROW_ALLOC = 768;  // prepared sets are zero-padded to a multiple of this (lcm of every kernel's tile edges:
+                                // 128; 128 x 192 for the producer / consumer dense kernel; 256 for the ring count kernel)
 constexpr int WORD_PAD = 16;   // words per LDS K-chunk
 
 struct Layout {

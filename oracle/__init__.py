@@ -91,6 +91,8 @@ def _declare(L: ctypes.CDLL) -> None:
     L.orc_morgan_fingerprints.restype = None
     L.orc_check_newton_division.argtypes = [ctypes.c_int]
     L.orc_check_newton_division.restype = ctypes.c_int64
+    L.orc_check_threshold_arith.argtypes = [ctypes.c_float, ctypes.c_int]
+    L.orc_check_threshold_arith.restype = ctypes.c_int64
 
 
 def _as_u32(x) -> np.ndarray:
@@ -139,6 +141,12 @@ def neighbor_counts(x, y, threshold: float, sign: int = 1, metric: int = TANIMOT
 def check_newton_division(umax: int) -> int:
     """Number of (c, u) pairs where the rcp_f32 + Newton division shortcut differs from IEEE c / u (must be 0)."""
     return int(lib().orc_check_newton_division(int(umax)))
+
+
+def check_threshold_arith(thr: float, smax: int) -> int:
+    """Number of (s, c) pairs where the exact-arithmetic Tanimoto threshold predicate of the ring count kernel differs
+    from the float-division predicate `float(c)/float(s-c) >= thr` (must be 0)."""
+    return int(lib().orc_check_threshold_arith(float(thr), int(smax)))
 
 
 def butina_fused(x, cutoff: float, metric: int = TANIMOTO):

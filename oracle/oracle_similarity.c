@@ -354,3 +354,32 @@ int64_t orc_check_newton_division(int umax) {
   }
   return bad;
 }
+
+/* Table-free form of the fused-Butina neighbour predicate used by the matrix-core count kernels
+ * (nvmolkit_amd/csrc/similarity_mfma.hip, arith_threshold / ARITH epilogues):
+ *   (float)c / (float)(s - c) >= thr   <=>   c (1 + m) - pb m  >  pa m - adj,      s = pa + pb,
+ * m = midpoint of thr and its float predecessor, adj = half a grid unit when the tie at m rounds up to thr (even
+ * significand) and 0 otherwise, all in exact double arithmetic.
+ * Returns the number of (s, c) pairs, 1 <= s <= smax, 0 <= c < s, on which the two predicates differ (must be 0).
+ */
+int64_t orc_check_threshold_arith(float thr, int smax) {
+  const float  pred = nextafterf(thr, -INFINITY);
+  const double m    = 0.5 * ((double)thr + (double)pred);
+  const double grid = 0.5 * ((double)thr - (double)pred);
+  uint32_t     bits;
+  memcpy(&bits, &thr, sizeof(bits));
+  const double adj = (bits & 1u) ? 0.0 : 0.5 * grid;
+  const double k1 = 1.0 + m, k2 = m;
+  int64_t      bad = 0;
+  for (int s = 1; s <= smax; ++s) {
+    for (int c = 0; c < s; ++c) {
+      const int ref = (float)c / (float)(s - c) >= thr;
+      /* the kernel keeps the row and column parts of s apart: any split must decide the same */
+      const int    pa  = s / 3, pb = s - pa;
+      const double paK = fma((double)pa, k2, -adj);
+      const double d   = fma((double)c, k1, -((double)pb * k2));
+      if (ref != (d > paK)) ++bad;
+    }
+  }
+  return bad;
+}

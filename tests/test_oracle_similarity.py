@@ -144,3 +144,17 @@ def test_division_shortcut_of_hip_epilogue_is_exact():
     quotient for every 0 <= c <= u <= 16384 (the device side is covered by
     tests/test_similarity_gpu.py::test_prefix_fingerprints_exhaust_all_ratios)."""
     assert oracle.check_newton_division(16384) == 0
+
+
+def test_table_free_threshold_predicate_of_ring_kernel_is_exact():
+    """c (1 + m) - s m >= 0 (> 0 for odd-significand thresholds), m = rounding boundary below thr, decides exactly like
+    float(c) / float(s - c) >= thr for every 0 <= c < s <= 4096 — at round thresholds, at thresholds sitting exactly on
+    a ratio and one ulp either side of it, at powers of two and at random floats in [2^-10, 1]."""
+    rng = np.random.default_rng(7)
+    thrs = [0.7, 0.3, 0.65, 0.5, 0.25, 1.0, 2.0 ** -10, 0.999, 1.0 / 3.0, 2.0 / 3.0]
+    for c, u in [(1, 3), (2, 3), (7, 10), (13, 17), (100, 143), (511, 730), (1, 1024), (1023, 1024)]:
+        t = np.float32(c) / np.float32(u)
+        thrs += [float(t), float(np.nextafter(t, np.float32(0))), float(np.nextafter(t, np.float32(2)))]
+    thrs += [float(np.float32(v)) for v in rng.uniform(2.0 ** -10, 1.0, size=12)]
+    for thr in thrs:
+        assert oracle.check_threshold_arith(thr, 4096 if thr in (0.7, 0.3) else 1500) == 0, thr

@@ -15,7 +15,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["valu", "mfma", "mfma:pp", "auto"], autouse=True)
+@pytest.fixture(params=["valu", "mfma", "mfma:pp", "mfma:pipe", "mfma:wide", "auto"], autouse=True)
 def sim_path(request, monkeypatch):
     """Every parity case runs on the VALU popcount kernel, on the FP4 matrix-core kernels (the 128 x 128 tile kernel and
     the experimental producer / consumer kernel) and on the library's automatic choice (NVMK_SIM_PATH / NVMK_DENSE_KERNEL are read per
