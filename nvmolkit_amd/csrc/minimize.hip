@@ -633,7 +633,8 @@ constexpr int    MAX_LS_ITERS  = 1000;
 // HU rows of a batch share their column and are combined in registers before they touch LDS.
 constexpr int HTX = 32;
 constexpr int HTY = NT / HTX;
-constexpr int HU  = 4;
+constexpr int HCS = 4;   // column steps (of 2 * HTX columns) loaded together in hess_pass
+// rows per lane in hess_pass: HU * HCS 16-byte loads in flight per lane; 8 where the registers allow it (DG, the largest H)
 
 __device__ __forceinline__ double half_wave_sum(double v) {
 #pragma unroll
@@ -648,6 +649,7 @@ __host__ __device__ __forceinline__ int64_t hess_row_offset(const int64_t r) {  
 // `part` is (1 + HTY) n doubles of LDS scratch: row sums, then one slab of mirrored-entry sums per row group; it must be
 // zero on entry (and visible to the workgroup).  On exit (after a barrier) t = H g.  No atomics: every partial sum
 // has a single writer and the final sum runs in a fixed order, so the minimiser is reproducible run to run.
+template <int HU>
 __device__ __forceinline__ void hess_pass(double* __restrict__ H, const int n, const bool pending, const double rfac,
                                           const double fad, const double fae, const double* xi, const double* hdg,
                                           const double* uu, const double* g, double* t, double* part) {
@@ -669,41 +671,59 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ H, const int n, c
       dr[u]        = pending ? fae * uu[rc] : 0.0;
     }
     const int rmax = min(n - 1, r0 + ty + HTY * (HU - 1));
-    for (int c = 2 * tx; c <= rmax; c += 2 * HTX) {
-      const bool   two = c + 1 < n;
-      const double g0 = g[c], g1 = two ? g[c + 1] : 0.0;
-      double       x0 = 0.0, x1 = 0.0, h0 = 0.0, h1 = 0.0, u0 = 0.0, u1 = 0.0;
-      if (pending) {
-        x0 = xi[c];
-        h0 = hdg[c];
-        u0 = uu[c];
-        if (two) {
-          x1 = xi[c + 1];
-          h1 = hdg[c + 1];
-          u1 = uu[c + 1];
-        }
-      }
-      double col0 = 0.0, col1 = 0.0;
+    // Columns go in blocks of HCS steps: every 16-byte load of the block is issued before the first use, so a lane has
+    // up to HU * HCS loads in flight.  (Load, update, store, next load — the first version — waited for the previous
+    // step's STORE before every load could be consumed, because vmcnt retires loads and stores in order: 41 us per
+    // pass at n = 192 even for a lone system, i.e. pure latency.)  Accumulation order is unchanged.
+    for (int cb = 2 * tx; cb <= rmax; cb += 2 * HTX * HCS) {
+      double2 hv[HCS][HU];
 #pragma unroll
-      for (int u = 0; u < HU; ++u) {
-        if (c <= row[u]) {
-          double2*   p    = reinterpret_cast<double2*>(H + off[u] + c);
-          double2    h    = *p;
-          const bool has1 = c + 1 <= row[u];
-          if (pending) {
-            h.x += ar[u] * x0 - br[u] * h0 + dr[u] * u0;
-            if (has1) h.y += ar[u] * x1 - br[u] * h1 + dr[u] * u1;  // the pad entry stays 0
-            *p = h;
-          }
-          racc[u] += h.x * g0 + (has1 ? h.y * g1 : 0.0);
-          if (c < row[u]) col0 += h.x * gr[u];      // mirrored entries (strictly below the diagonal)
-          if (c + 1 < row[u]) col1 += h.y * gr[u];
+      for (int sx = 0; sx < HCS; ++sx) {
+        const int c = cb + sx * 2 * HTX;
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+          hv[sx][u] = make_double2(0.0, 0.0);
+          if (c <= row[u]) hv[sx][u] = *reinterpret_cast<const double2*>(H + off[u] + c);
         }
       }
-      // (row group ty, column c) has exactly one writer: plain read-modify-write, summation order fixed
-      double* mine = part + (1 + ty) * n;
-      mine[c] += col0;
-      if (two) mine[c + 1] += col1;
+#pragma unroll
+      for (int sx = 0; sx < HCS; ++sx) {
+        const int c = cb + sx * 2 * HTX;
+        if (c > rmax) break;
+        const bool   two = c + 1 < n;
+        const double g0 = g[c], g1 = two ? g[c + 1] : 0.0;
+        double       x0 = 0.0, x1 = 0.0, h0 = 0.0, h1 = 0.0, u0 = 0.0, u1 = 0.0;
+        if (pending) {
+          x0 = xi[c];
+          h0 = hdg[c];
+          u0 = uu[c];
+          if (two) {
+            x1 = xi[c + 1];
+            h1 = hdg[c + 1];
+            u1 = uu[c + 1];
+          }
+        }
+        double col0 = 0.0, col1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+          if (c <= row[u]) {
+            double2    h    = hv[sx][u];
+            const bool has1 = c + 1 <= row[u];
+            if (pending) {
+              h.x += ar[u] * x0 - br[u] * h0 + dr[u] * u0;
+              if (has1) h.y += ar[u] * x1 - br[u] * h1 + dr[u] * u1;  // the pad entry stays 0
+              *reinterpret_cast<double2*>(H + off[u] + c) = h;
+            }
+            racc[u] += h.x * g0 + (has1 ? h.y * g1 : 0.0);
+            if (c < row[u]) col0 += h.x * gr[u];      // mirrored entries (strictly below the diagonal)
+            if (c + 1 < row[u]) col1 += h.y * gr[u];
+          }
+        }
+        // (row group ty, column c) has exactly one writer: plain read-modify-write, summation order fixed
+        double* mine = part + (1 + ty) * n;
+        mine[c] += col0;
+        if (two) mine[c + 1] += col1;
+      }
     }
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
@@ -926,7 +946,7 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
     const int64_t tH = now();
     for (int i = tid; i < (1 + HTY) * n; i += NT) part[i] = 0.0;
     __syncthreads();
-    hess_pass(H, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, tvec, part);  // H is now H_k; tvec = H_k g_new
+    hess_pass<(KIND == NVMK_FF_DG ? 6 : 4)>(H, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, tvec, part);  // H is now H_k; tvec = H_k g_new
     __syncthreads();
     tk[2] += now() - tH;
     const int64_t tU = now();

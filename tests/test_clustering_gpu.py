@@ -134,6 +134,27 @@ def test_fused_butina_dense_graph_falls_back():
     assert len(got[0]) == 1 and len(got[0][0]) == 700
 
 
+def test_fused_butina_cluster_larger_than_the_staged_member_list(sim_path):
+    """A 2600-member clique inside a sparse background: the graph (3.4 M pairs) still fits the edge buffer (128 per
+    row), so the device-side round loop runs, and the first cluster overflows the 2048 members it hands from the
+    extraction to the subtraction through LDS (the rest are re-read from the cluster list)."""
+    if sim_path in ("valu", "mfma:dense"):
+        pytest.skip("sparse round loop only")
+    rng = np.random.default_rng(11)
+    n, clique = 30000, 2600
+    x = util.random_fingerprints(n, 16, density=0.25, seed=5)
+    base = x[0].copy()
+    x[:clique] = base
+    flip = rng.integers(0, 16 * 32, size=clique)  # one bit flipped per clique member: all mutual neighbours at 0.5
+    x[np.arange(clique), flip // 32] ^= (np.uint32(1) << (flip % 32).astype(np.uint32))
+    perm = rng.permutation(n)
+    x = np.ascontiguousarray(x[perm])
+    got = fused_butina(dev(x), 0.5, return_centroids=True)
+    want = oracle.butina_fused(x, 0.5)
+    assert got[1] == want[1] and got[2] == want[2] and got[0] == want[0]
+    assert len(got[0][0]) >= clique
+
+
 def test_fused_butina_argument_validation():
     x = dev(util.random_fingerprints(10, 4))
     with pytest.raises(ValueError):
