@@ -1053,7 +1053,10 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
       int32_t*       cand        = bucketMem.as<int32_t>();
       int32_t*       blockCounts = cand + n;
       const unsigned maxBlocks   = static_cast<unsigned>(std::min<int64_t>(ceil_div<int64_t>(N, NT * 4), 1024));
-      for (;;) {
+      for (int64_t guard = 0;; ++guard) {
+        // every epoch with a non-empty bucket forms at least one cluster and the empty one ends the loop, so N epochs
+        // are an upper bound; anything beyond is a bug and must not spin on the GPU box
+        NVMK_REQUIRE(guard * 4 <= N + 8, "fused butina: the round loop did not terminate (internal error)");
         for (int e = 0; e < 4; ++e) {
           hipLaunchKernelGGL(bucket_max_kernel, dim3(maxBlocks), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts);
           hipLaunchKernelGGL(bucket_count_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts);

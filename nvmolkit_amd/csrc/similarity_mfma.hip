@@ -356,8 +356,45 @@ __global__ __launch_bounds__(NT * (TMV / TM), PIPE ? 3 : (TMV == TM ? 4 : 2)) vo
       }
     }
   };
+  // Interior tiles: neighbouring lanes swap one value (DPP quad_perm, no LDS) so that every lane owns two ADJACENT
+  // columns of one row and the tile goes out as 32 sixteen-byte stores per lane instead of 64 eight-byte ones —
+  // half the vector-memory instructions queued in front of the other workgroups' operand loads.  Accumulator rows
+  // r = 4 q + s are tile rows s + 8 q: rows s and s + 1 pair up; even lanes keep row s, odd lanes row s + 1.
+  auto emit_wide = [&]() {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const unsigned odd     = static_cast<unsigned>(lane) & 1u;
+    const unsigned laneOf2 = (hi * 4u * static_cast<unsigned>(ld) + odd * static_cast<unsigned>(ld) + (static_cast<unsigned>(lane & 31) & ~1u)) * 8u;
+    auto swap1 = [&](const double x) -> double {  // value of lane ^ 1
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xF, 0xF, false);
+      const int hh = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xF, 0xF, false);
+      return __hiloint2double(hh, lo);
+    };
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int sp = 0; sp < 4; sp += 2) {
+          const int   il0  = mi * 32 + sp + 8 * q;  // row of the even lanes (+ 4 hi); odd lanes: il0 + 1
+          const float pav0 = static_cast<float>(pcA[wm * 64 + il0 + 4 * static_cast<int>(hi)]);
+          const float pav1 = static_cast<float>(pcA[wm * 64 + il0 + 1 + 4 * static_cast<int>(hi)]);
+          char*       rowOut = waveOut + static_cast<int64_t>(il0) * ld * 8;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const double v0   = value(acc[mi][ni][4 * q + sp], pav0, ni ? pb1 : pb0);      // (row s,     my column)
+            const double v1   = value(acc[mi][ni][4 * q + sp + 1], pav1, ni ? pb1 : pb0);  // (row s + 1, my column)
+            const double got  = swap1(odd ? v0 : v1);                                      // partner's value for MY row
+            d2_t         out2;
+            out2.x = odd ? got : v0;
+            out2.y = odd ? v1 : got;
+            __builtin_nontemporal_store(out2, reinterpret_cast<d2_t*>(rowOut + ni * 256 + laneOf2));
+          }
+        }
+      }
+    }
+  };
   if (full) {
-    emit(std::true_type{});
+    emit_wide();
   } else {
     emit(std::false_type{});
   }
