@@ -914,11 +914,10 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
 constexpr int RT  = 256;  // tile edge
 constexpr int RKW = 4;    // words per stage
 constexpr int RST = 4;    // ring slots
-constexpr int RNT = 512;  // threads
 constexpr int REDGE_CAP = 1024, REDGE_FLUSH = 512;
 
-template <int METRIC, bool EMIT, bool PROF = false>
-__global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
+template <int METRIC, bool EMIT, bool PROF = false, int WT = 128>
+__global__ __launch_bounds__(64 * 4 * (RT / WT), 1) void neighbor_count_ring_kernel(
   const uint4* __restrict__ X, const int32_t* __restrict__ popX, const int64_t nX, const uint4* __restrict__ Y,
   const int32_t* __restrict__ popY, const int64_t nY, const int Wp, const double K1, const double K2, const double adj, const float thr,
   const int sign, const int symmetric, int32_t* __restrict__ counts, int2* __restrict__ edges,
@@ -938,7 +937,10 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 x 128
+  // 4 x RWN waves of 64 x WT: WT = 128 -> 8 waves (6 ds_read_b128 per 8 MFMAs, 2 waves per SIMD), WT = 64 -> 16 waves
+  // (4 per 4, 4 waves per SIMD)
+  constexpr int RWN = RT / WT, NWV = 4 * RWN, NI = WT / 32, RNTV = 64 * NWV, PPV = 16 / NWV;
+  const int wm = wave / RWN, wn = wave % RWN;
   const int nst  = Wp / RKW;
   constexpr int INVALID = (METRIC == NVMK_METRIC_TANIMOTO) ? -1 : 0;  // popcount stand-in of rows that can have no neighbour
   const unsigned tilesM = static_cast<unsigned>((nX + RT - 1) / RT), tilesN = static_cast<unsigned>((nY + RT - 1) / RT);
@@ -990,10 +992,10 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
   int       ici = 0, islot = 0, itile = 0;  // chunk inside the tile, ring slot, ordinal of the tile in the sequence
   int       issuedTotal = 0;                // vector-memory operations this wave has issued so far
   int       issuedAt[RST] = {0, 0, 0, 0};   // ... right after the loads of the stage in each slot
-  const unsigned prow0 = static_cast<unsigned>(wave * 2 * 16 + (lane >> 2));  // rows of this wave's two 16-row pieces
-  unsigned       offP[2];
+  const unsigned prow0 = static_cast<unsigned>(wave * PPV * 16 + (lane >> 2));  // rows of this wave's PPV 16-row pieces
+  unsigned       offP[PPV];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < PPV; ++t) {
     const unsigned row = prow0 + 16u * t;
     offP[t]            = row * static_cast<unsigned>(Wp) + ((static_cast<unsigned>(lane) & 3u) ^ C::swz(row));
   }
@@ -1003,15 +1005,15 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
       const uint4* gx = X + static_cast<int64_t>(itm) * RT * Wp + ici * RKW;
       const uint4* gy = Y + static_cast<int64_t>(itn) * RT * Wp + ici * RKW;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        dma_b128(gx + offP[t], lds_addr(st + (wave * 2 + t) * 1024));
+      for (int t = 0; t < PPV; ++t) {
+        dma_b128(gx + offP[t], lds_addr(st + (wave * PPV + t) * 1024));
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        dma_b128(gy + offP[t], lds_addr(st + STAGE_X + (wave * 2 + t) * 1024));
+      for (int t = 0; t < PPV; ++t) {
+        dma_b128(gy + offP[t], lds_addr(st + STAGE_X + (wave * PPV + t) * 1024));
       }
-      issuedTotal += 4;
-      if (ici == 0) {  // row popcounts of the tile: 512 dwords, one DMA instruction per wave (waves 0-3: X rows, 4-7: Y rows)
+      issuedTotal += 2 * PPV;
+      if (ici == 0 && wave < 8) {  // row popcounts of the tile: 512 dwords, one DMA instruction on waves 0-3 (X rows) and 4-7 (Y rows)
         int*           pc  = pcBase + (itile & 1) * 2 * RT;
         const int32_t* src = wave < 4 ? popX + static_cast<int64_t>(itm) * RT + wave * 64 : popY + static_cast<int64_t>(itn) * RT + (wave - 4) * 64;
         dma_b32(src + lane, lds_addr(pc + wave * 64));
@@ -1033,18 +1035,18 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
   // ---- compute side ----
   const int      l31  = lane & 31;
   const unsigned half = static_cast<unsigned>(lane >> 5);
-  const unsigned rA   = static_cast<unsigned>(wm * 64 + l31), rB = static_cast<unsigned>(wn * 128 + l31);
+  const unsigned rA   = static_cast<unsigned>(wm * 64 + l31), rB = static_cast<unsigned>(wn * WT + l31);
   const unsigned baseA = rA * C::ROWBYTES, baseB = STAGE_X + rB * C::ROWBYTES;
   const unsigned swA = C::swz(rA), swB = C::swz(rB);
   long long kCmp = -1;
   unsigned  tm = 0, tn = 0;
   int       cslot = 0, ctile = 0;
   while (next_tile(kCmp, tm, tn)) {
-    v16f acc[2][4];
+    v16f acc[2][NI];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
       }
@@ -1057,8 +1059,10 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
       if (ch == 0 && METRIC == NVMK_METRIC_TANIMOTO) {
         // rows past the end and empty fingerprints (union 0 -> similarity 0 -> never >= a positive threshold) never
         // match: flag them (this thread DMA'd the entry it patches, and its wait has just completed)
-        const int64_t r = tid < RT ? rowA0 + tid : rowB0 + (tid - RT);
-        if (r >= (tid < RT ? nX : nY) || pc[tid] == 0) pc[tid] = INVALID;
+        if (tid < 2 * RT) {
+          const int64_t r = tid < RT ? rowA0 + tid : rowB0 + (tid - RT);
+          if (r >= (tid < RT ? nX : nY) || pc[tid] == 0) pc[tid] = INVALID;
+        }
       }
       __builtin_amdgcn_s_barrier();  // ... and everyone else's; everyone is also done reading the slot refilled next
       asm volatile("" ::: "memory");
@@ -1069,20 +1073,20 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
       for (int ks = 0; ks < RKW / 2; ++ks) {
         const unsigned sl   = static_cast<unsigned>(ks * 2) + half;
         const unsigned offA = baseA + ((sl ^ swA) << 4), offB = baseB + ((sl ^ swB) << 4);
-        uint4 a[2], b[4];
+        uint4 a[2], b[NI];
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const uint4*>(st + offA + i * 32 * C::ROWBYTES);
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn) b[jn] = *reinterpret_cast<const uint4*>(st + offB + jn * 32 * C::ROWBYTES);
+        for (int jn = 0; jn < NI; ++jn) b[jn] = *reinterpret_cast<const uint4*>(st + offB + jn * 32 * C::ROWBYTES);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
-          for (int jn = 0; jn < 4; ++jn) acc[i][jn] = mfma_fp4(a[i], b[jn], acc[i][jn]);
+          for (int jn = 0; jn < NI; ++jn) acc[i][jn] = mfma_fp4(a[i], b[jn], acc[i][jn]);
         }
       }
       asm volatile("" ::: "memory");
       if constexpr (PROF) {
-        asm volatile("s_nop 0" : "+v"(acc[0][0]), "+v"(acc[1][3]));
+        asm volatile("s_nop 0" : "+v"(acc[0][0]), "+v"(acc[1][NI - 1]));
         tWait += t1 - t0;
         tMma += now() - t1;
       }
@@ -1092,14 +1096,16 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
 
     // ---- epilogue: threshold, row / column counts, staged neighbour pairs ----
     const bool creditCols = symmetric && tn > tm;
-    int        cc[4] = {0, 0, 0, 0};
+    int        cc[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) cc[ni] = 0;
     int        myRow = 0;
     // Tanimoto: the table-free exact predicate with the row-slot fast reject (see ArithThreshold above)
-    int    pbv[4];
-    double pbK[4];
+    int    pbv[NI];
+    double pbK[NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      pbv[ni] = pc[RT + wn * 128 + ni * 32 + l31];
+    for (int ni = 0; ni < NI; ++ni) {
+      pbv[ni] = pc[RT + wn * WT + ni * 32 + l31];
       pbK[ni] = pbv[ni] < 0 ? __builtin_inf() : static_cast<double>(pbv[ni]) * K2;
     }
 #pragma unroll
@@ -1108,16 +1114,22 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
       for (int r = 0; r < 16; ++r) {
         const int rowLo = mi * 32 + (r & 3) + 8 * (r >> 2);
         const int pav   = pc[wm * 64 + rowLo + 4 * static_cast<int>(half)];
-        double    d[4]  = {0.0, 0.0, 0.0, 0.0}, paK = 0.0;
+        double    d[NI], paK = 0.0;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) d[ni] = 0.0;
         if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
           paK = pav < 0 ? __builtin_inf() : __builtin_fma(static_cast<double>(pav), K2, -adj);
+          double best = -__builtin_inf();
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) d[ni] = __builtin_fma(static_cast<double>(acc[mi][ni][r]), K1, -pbK[ni]);
-          if (__ballot(fmax(fmax(d[0], d[1]), fmax(d[2], d[3])) > paK) == 0) continue;  // no neighbour in this row slot
+          for (int ni = 0; ni < NI; ++ni) {
+            d[ni] = __builtin_fma(static_cast<double>(acc[mi][ni][r]), K1, -pbK[ni]);
+            best  = fmax(best, d[ni]);
+          }
+          if (__ballot(best > paK) == 0) continue;  // no neighbour in this row slot
         }
         int lo = 0, hi = 0;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
           bool p;
           if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
             p = d[ni] > paK;
@@ -1131,7 +1143,7 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
           if constexpr (EMIT) {
             if (m != 0) {  // rare: pairs i < j once; the diagonal tile holds both orientations and the self pairs
               const int64_t  gi = rowA0 + wm * 64 + rowLo + 4 * static_cast<int>(half);
-              const int64_t  gj = rowB0 + wn * 128 + ni * 32 + l31;
+              const int64_t  gj = rowB0 + wn * WT + ni * 32 + l31;
               const bool     e  = p && gi < gj && gi < nX && gj < nY;
               const uint64_t me = __ballot(e);
               if (me != 0) {
@@ -1159,14 +1171,14 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
     if (myRow != 0) atomicAdd(&rowsum[wm * 64 + lane], myRow);
     if (creditCols) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
         int v = cc[ni];
         v += __shfl_xor(v, 32);
-        if (lane < 32 && v != 0) atomicAdd(&colsum[wn * 128 + ni * 32 + lane], v);
+        if (lane < 32 && v != 0) atomicAdd(&colsum[wn * WT + ni * 32 + lane], v);
       }
     }
     lds_barrier();
-    {  // exactly one global atomic instruction per wave and tile (adds of 0 included), so the vmcnt bookkeeping stays exact
+    if (tid < 2 * RT) {  // exactly one global atomic instruction per wave 0-7 and tile (adds of 0 included): exact vmcnt bookkeeping
       const bool    isRow = tid < RT;
       const int     t     = isRow ? tid : tid - RT;
       const int64_t r     = (isRow ? rowA0 : rowB0) + t;
@@ -1175,8 +1187,8 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
       if (isRow) rowsum[t] = 0; else colsum[t] = 0;
       if (r >= n || (!isRow && !creditCols)) v = 0;
       atomicAdd(&counts[r < n ? r : n - 1], sign * v);
-      issuedTotal += 1;
     }
+    if (wave < 8) issuedTotal += 1;
     if constexpr (EMIT) {
       const int staged = edgeMeta[0];  // same value in every thread: last written before the barrier above
       if (staged > REDGE_FLUSH) {
@@ -1188,7 +1200,7 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
         }
         lds_barrier();
         const unsigned long long base = (static_cast<unsigned long long>(static_cast<unsigned>(edgeMeta[3])) << 32) | static_cast<unsigned>(edgeMeta[2]);
-        for (int i = tid; i < nStaged; i += RNT) {
+        for (int i = tid; i < nStaged; i += RNTV) {
           if (base + i < edgeCapacity) edges[base + i] = edgeBuf[i];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // data-dependent number of stores: resynchronise the bookkeeping
@@ -1217,7 +1229,7 @@ __global__ __launch_bounds__(RNT, 1) void neighbor_count_ring_kernel(
       }
       lds_barrier();
       const unsigned long long base = (static_cast<unsigned long long>(static_cast<unsigned>(edgeMeta[3])) << 32) | static_cast<unsigned>(edgeMeta[2]);
-      for (int i = tid; i < nStaged; i += RNT) {
+      for (int i = tid; i < nStaged; i += RNTV) {
         if (base + i < edgeCapacity) edges[base + i] = edgeBuf[i];
       }
     }
@@ -1357,11 +1369,14 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
       using RKern = void (*)(const uint4*, const int32_t*, int64_t, const uint4*, const int32_t*, int64_t, int, double, double, double, float, int,
                              int, int32_t*, int2*, unsigned long long*, unsigned long long, long long*);
       const ArithThreshold at = arith_threshold(a.thr, F);
+      static const int wt = [] { const char* e = std::getenv("NVMK_RING_WT"); return (e && std::atoi(e) == 64) ? 64 : 128; }();
       RKern kern;
       if (a.metric == NVMK_METRIC_TANIMOTO) {
-        kern = emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false>;
+        kern = wt == 64 ? (emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true, false, 64> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false, false, 64>)
+                        : (emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false>);
       } else {
-        kern = emit ? neighbor_count_ring_kernel<NVMK_METRIC_COSINE, true> : neighbor_count_ring_kernel<NVMK_METRIC_COSINE, false>;
+        kern = wt == 64 ? (emit ? neighbor_count_ring_kernel<NVMK_METRIC_COSINE, true, false, 64> : neighbor_count_ring_kernel<NVMK_METRIC_COSINE, false, false, 64>)
+                        : (emit ? neighbor_count_ring_kernel<NVMK_METRIC_COSINE, true> : neighbor_count_ring_kernel<NVMK_METRIC_COSINE, false>);
       }
       const size_t shmem = static_cast<size_t>(RST) * 2 * RT * RKW * 16 + 2 * 2 * RT * 4 + 2 * RT * 4 + REDGE_CAP * 8 + 16;
       NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1369,11 +1384,12 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
       const bool profile = std::getenv("NVMK_RING_PROFILE") != nullptr && a.metric == NVMK_METRIC_TANIMOTO;
       long long* dProf   = nullptr;
       if (profile) {
-        kern = emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true, true> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false, true>;
+        kern = wt == 64 ? (emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true, true, 64> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false, true, 64>)
+                        : (emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true, true> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false, true>);
         NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem)));
         NVMK_HIP_CHECK(hipMalloc(&dProf, 64 * sizeof(long long)));
       }
-      hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(cus)), dim3(RNT), shmem, stream, X.rows, X.popc, a.nX, Y.rows, Y.popc, a.nY, X.L.Wp,
+      hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(cus)), dim3(wt == 64 ? 1024 : 512), shmem, stream, X.rows, X.popc, a.nX, Y.rows, Y.popc, a.nY, X.L.Wp,
                          at.k1, at.k2, at.adj, a.thr, a.sign, a.symmetric ? 1 : 0, counts, a.edges, a.edgeCursor, a.edgeCapacity, dProf);
       NVMK_LAUNCH_CHECK();
       if (profile) {  // debugging aid: workgroup 0, per wave, 100 MHz ticks
@@ -1381,7 +1397,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
         NVMK_HIP_CHECK(hipStreamSynchronize(stream));
         NVMK_HIP_CHECK(hipMemcpy(h, dProf, sizeof(h), hipMemcpyDeviceToHost));
         NVMK_HIP_CHECK(hipFree(dProf));
-        for (int w = 0; w < 8; ++w)
+        for (int w = 0; w < (wt == 64 ? 16 : 8); ++w)
           std::fprintf(stderr, "[ring] wave %d: %lld tiles; per tile: wait+barrier %.2f us, issue+mma %.2f us, epilogue %.2f us\n", w, h[w * 4 + 3],
                        h[w * 4] * 0.01 / h[w * 4 + 3], h[w * 4 + 1] * 0.01 / h[w * 4 + 3], h[w * 4 + 2] * 0.01 / h[w * 4 + 3]);
       }
