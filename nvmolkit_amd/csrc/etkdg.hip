@@ -366,8 +366,11 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
   for (;;) {
     if (firstError.load() != NVMK_OK) return NVMK_OK;
     uint64_t               attemptBase = 0;
-    const std::vector<int> ids         = sched.dispatch(prm->batch_size, &attemptBase);
+    std::vector<int> ids = sched.dispatch(prm->batch_size, &attemptBase);
     if (ids.empty()) break;
+    // Largest systems first (stable): one workgroup minimises one system and the launch ends with the slowest one, so
+    // the long jobs must not be the last to get a slot (cost per BFGS iteration grows with atoms^2).
+    std::stable_sort(ids.begin(), ids.end(), [&](const int a, const int b) { return ms->h_n_atoms[a] > ms->h_n_atoms[b]; });
     const int nSys = static_cast<int>(ids.size());
     std::vector<int32_t> atomStarts(static_cast<size_t>(nSys) + 1, 0), r12(static_cast<size_t>(nSys) + 1, 0),
       r13(static_cast<size_t>(nSys) + 1, 0);

@@ -747,6 +747,7 @@ template <int KIND, bool PROFILE = false>
 __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
                                                   const int maxIters, const double gradTol, const int scaleGrads,
                                                   const uint8_t* __restrict__ active, const int64_t* __restrict__ hessStarts,
+                                                  const int32_t* __restrict__ order,
                                                   double* __restrict__ hessians, double* __restrict__ energies,
                                                   int16_t* __restrict__ statuses, int32_t* __restrict__ itersOut,
                                                   int64_t* __restrict__ prof) {
@@ -757,7 +758,8 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   (void)tStart;
   constexpr int DIM = Dim<KIND>::value;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int sys = blockIdx.x;
+  // workgroups are handed out in launch order: the largest systems go first so that the launch does not end on a long job
+  const int sys = order[blockIdx.x];
   if (active && !active[sys]) return;
   const int tid = threadIdx.x;
   const int a0  = b.atomStarts[sys];
@@ -1104,10 +1106,18 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   }
   const size_t shmem = ((12 + HTY) * static_cast<size_t>(maxN) + NT / 64 + 1) * sizeof(double);
   NVMK_REQUIRE(shmem <= 160 * 1024, "bfgs: a system with %d coordinates needs %zu bytes of LDS (max 160 KiB)", maxN, shmem);
-  StreamScratch hessMem, startsMem;
+  StreamScratch hessMem, startsMem, orderMem;
   NVMK_HIP_CHECK(hessMem.alloc(static_cast<size_t>(hs.back()) * sizeof(double), stream));
   NVMK_HIP_CHECK(startsMem.alloc(hs.size() * sizeof(int64_t), stream));
   NVMK_HIP_CHECK(hipMemcpyAsync(startsMem.ptr, hs.data(), hs.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+  // launch order: largest system first (stable), see bfgs_kernel
+  std::vector<int32_t> order(static_cast<size_t>(b.nSystems));
+  for (int s = 0; s < b.nSystems; ++s) order[static_cast<size_t>(s)] = s;
+  std::stable_sort(order.begin(), order.end(), [&](const int32_t x, const int32_t y) {
+    return h_atom_starts[x + 1] - h_atom_starts[x] > h_atom_starts[y + 1] - h_atom_starts[y];
+  });
+  NVMK_HIP_CHECK(orderMem.alloc(order.size() * sizeof(int32_t), stream));
+  NVMK_HIP_CHECK(hipMemcpyAsync(orderMem.ptr, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   static const bool profile = [] {
     const char* e = std::getenv("NVMK_BFGS_PROFILE");
     return e != nullptr && e[0] == '1';
@@ -1119,15 +1129,15 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
     NVMK_HIP_CHECK(hipMemsetAsync(profMem.ptr, 0, words * sizeof(int64_t), stream));
     if (b.kind == NVMK_FF_DG) {
       hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_DG, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters,
-                         grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies, d_statuses,
+                         grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies, d_statuses,
                          d_iters, profMem.as<int64_t>());
     } else if (b.kind == NVMK_FF_ETK) {
       hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_ETK, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1,
-                         max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies,
+                         max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies,
                          d_statuses, d_iters, profMem.as<int64_t>());
     } else {
       hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_MMFF, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1,
-                         max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies,
+                         max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies,
                          d_statuses, d_iters, profMem.as<int64_t>());
     }
     NVMK_LAUNCH_CHECK();
@@ -1160,7 +1170,7 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
                                          static_cast<int>(shmem)));
     }
     hipLaunchKernelGGL(kern, dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters, grad_tol, scale_grads,
-                       d_active, startsMem.as<int64_t>(), hessMem.as<double>(), d_energies, d_statuses, d_iters,
+                       d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies, d_statuses, d_iters,
                        static_cast<int64_t*>(nullptr));
   });
   NVMK_LAUNCH_CHECK();
