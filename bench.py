@@ -288,11 +288,11 @@ def main() -> None:
         # prescribes).  Counters cannot be read inside this process, so the figure is reported only for the exact
         # workload it was collected on, else null.
         traffic, traffic_src = None, None
-        pmc = Path(__file__).resolve().parent / "profiles" / "r01_mfma_dense_dma" / "pmc_hbm_traffic_bench_launch.json"
+        pmc = Path(__file__).resolve().parent / "profiles" / "r01_final" / "pmc_hbm_traffic_bench_launch.json"
         if use_mfma and chunk == 8192 and n_ref == 1_000_000 and args.fp_bits == 2048 and pmc.exists():
             c = json.loads(pmc.read_text())
             traffic = (2.0 * c["FETCH_SIZE"]["mean_KiB_per_full_launch"] + c["WRITE_SIZE"]["mean_KiB_per_full_launch"]) * 1024.0
-            traffic_src = "profiles/r01_mfma_dense_dma/pmc_hbm_traffic_bench_launch.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per full launch"
+            traffic_src = "profiles/r01_final/pmc_hbm_traffic_bench_launch.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per full launch"
         result["roofline"] = {
             "bound": "hbm",
             "achieved": achieved,
