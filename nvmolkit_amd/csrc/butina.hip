@@ -874,7 +874,7 @@ __global__ __launch_bounds__(NT) void sparse_loop_kernel(LoopState* __restrict__
       }
       for (int k = l; k < len; k += 16) {
         const int j = nbr[a0 + k];
-        if (atomicSub(&counts[j], 1) == 2) Lnext[atomicAdd(&sCount, 1)] = j;  // only itself left: next round's harvest
+        if (ldc(&counts[j]) > 0 && atomicSub(&counts[j], 1) == 2) Lnext[atomicAdd(&sCount, 1)] = j;  // only itself left: next round's harvest
       }
     }
     __threadfence();  // Lnext is read back (from L2) in the next round
