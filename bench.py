@@ -318,13 +318,13 @@ def main() -> None:
             from nvmolkit_amd.clustering import fused_butina
 
             xb = synth_fingerprints(args.butina_n, words, device, SEED)  # own set: n / 50 planted clusters
-            fused_butina(xb[:4096].contiguous(), 0.3)  # warm-up
+            fused_butina(xb, 0.3)  # warm-up at full size: first-use allocations (scratch pools, hipcub) are not the algorithm
             torch.cuda.synchronize()
             tb = time.perf_counter()
             clusters, sizes = fused_butina(xb, 0.3)
             tb = time.perf_counter() - tb
             secondary["fused_butina"] = {"n": args.butina_n, "cutoff": 0.3, "seconds": tb, "n_clusters": len(clusters),
-                                         "fingerprints_per_s": args.butina_n / tb}
+                                         "fingerprints_per_s": args.butina_n / tb, "timing": "second call on the same set"}
         if world == 1 and args.conformer_mols > 0:
             secondary["conformers"] = conformer_secondary(args.conformer_mols)
         if secondary:

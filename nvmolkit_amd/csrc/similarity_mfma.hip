@@ -683,6 +683,8 @@ inline ArithThreshold arith_threshold(const float thr, const int F) {
   return t;
 }
 
+constexpr int EDGE_STAGE = 256;  // neighbour pairs a workgroup of the tile count kernel stages in LDS
+
 template <int METRIC, bool EMIT, bool ARITH = false>
 __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   const uint4* __restrict__ X, const int32_t* __restrict__ popX, const int32_t* __restrict__ xRows,
@@ -703,6 +705,10 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   int*  pcB    = pcA + TM;
   int*  rowsum = pcB + TN;
   int*  colsum = rowsum + TM;
+  // EMIT: neighbour pairs of the tile are staged here and leave with ONE atomic on the global cursor per workgroup
+  // (one per non-empty ballot serialised 2.3 M returning atomics on a single address at N = 100k: 27 ms for a 5 ms pass)
+  int2* edgeBuf  = reinterpret_cast<int2*>(colsum + TN);  // [EDGE_STAGE]
+  int*  edgeMeta = reinterpret_cast<int*>(edgeBuf + EDGE_STAGE);  // [0] staged, [1..2] global base
 
   if (nXdev) nX = *nXdev;
   if (nYdev) nY = *nYdev;
@@ -765,6 +771,7 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
     pcB[t]          = r < nY ? popY[physY(r)] : SENT;
     colsum[t]       = 0;
   }
+  if (EMIT && tid == 0) edgeMeta[0] = 0;
 
   v16f acc[2][2];
 #pragma unroll
@@ -859,13 +866,18 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
             const bool     e  = p && gi < gj && gi < nX && gj < nY;
             const uint64_t me = __ballot(e);
             if (me != 0) {
-              unsigned long long base  = 0;
-              const int          first = __ffsll(static_cast<long long>(me)) - 1;
-              if (lane == first) base = atomicAdd(edgeCursor, static_cast<unsigned long long>(__popcll(me)));
+              const int first = __ffsll(static_cast<long long>(me)) - 1;
+              int       base  = 0;
+              if (lane == first) base = atomicAdd(&edgeMeta[0], __popcll(me));  // LDS
               base = __shfl(base, first);
               if (e) {
-                const unsigned long long slot = base + __popcll(me & ((1ull << lane) - 1ull));
-                if (slot < edgeCapacity) edges[slot] = make_int2(static_cast<int>(gi), static_cast<int>(gj));
+                const int slot = base + __popcll(me & ((1ull << lane) - 1ull));
+                if (slot < EDGE_STAGE) {
+                  edgeBuf[slot] = make_int2(static_cast<int>(gi), static_cast<int>(gj));
+                } else {  // a tile with more pairs than the staging area: straight to memory
+                  const unsigned long long gs = atomicAdd(edgeCursor, 1ull);
+                  if (gs < edgeCapacity) edges[gs] = make_int2(static_cast<int>(gi), static_cast<int>(gj));
+                }
               }
             }
           }
@@ -886,6 +898,21 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
     }
   }
   __syncthreads();
+  if constexpr (EMIT) {
+    const int staged = edgeMeta[0] < EDGE_STAGE ? edgeMeta[0] : EDGE_STAGE;
+    if (staged > 0) {  // workgroup-uniform
+      if (tid == 0) {
+        const unsigned long long gb = atomicAdd(edgeCursor, static_cast<unsigned long long>(staged));
+        edgeMeta[1] = static_cast<int>(gb & 0xffffffffull);
+        edgeMeta[2] = static_cast<int>(gb >> 32);
+      }
+      __syncthreads();
+      const unsigned long long gb = (static_cast<unsigned long long>(static_cast<unsigned>(edgeMeta[2])) << 32) | static_cast<unsigned>(edgeMeta[1]);
+      for (int i = tid; i < staged; i += NT) {
+        if (gb + i < edgeCapacity) edges[gb + i] = edgeBuf[i];
+      }
+    }
+  }
   if (tid < TM) {
     const int     v = rowsum[tid];
     const int64_t r = rowA0 + tid;
@@ -1419,7 +1446,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   const int64_t gz     = ceil_div<int64_t>(supers, gy);
   NVMK_REQUIRE(gz <= 65535, "neighbor counts: problem too large for one launch");
   const dim3   grid(static_cast<unsigned>(superE * superW), static_cast<unsigned>(gy), static_cast<unsigned>(gz));
-  const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + 4 * 128 * 4;
+  const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + 4 * 128 * 4 + (emit ? EDGE_STAGE * 8 + 16 : 0);
   NVMK_REQUIRE(std::max(X.L.nPad, Y.L.nPad) * X.L.Wp < (int64_t{1} << 32),
                "neighbor counts: prepared set too large for 32-bit piece offsets");
   using Kern = void (*)(const uint4*, const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, const uint4*,
