@@ -751,9 +751,10 @@ __global__ __launch_bounds__(NT) void bucket_fill_kernel(const LoopState* __rest
 // A round is then a chain of ~8 dependent L2 round trips: members and their CSR ranges are handed from the extraction
 // to the subtraction through LDS.
 constexpr int32_t DEAD        = -(1 << 30);
+constexpr int     LNT          = 1024;  // threads of the round-loop workgroup: 64 members' lists are walked at a time
 constexpr int     LOOP_MEMBERS = 2048;  // members staged in LDS; larger clusters take the list back from clusterIdx
 
-__global__ __launch_bounds__(NT) void sparse_loop_kernel(LoopState* __restrict__ st, const unsigned long long* __restrict__ offsets,
+__global__ __launch_bounds__(LNT) void sparse_loop_kernel(LoopState* __restrict__ st, const unsigned long long* __restrict__ offsets,
                                                          const int32_t* __restrict__ nbr, int32_t* __restrict__ counts,
                                                          int32_t* __restrict__ clusterIdx, int32_t* __restrict__ clusterOffsets,
                                                          int32_t* __restrict__ centroids, int32_t* __restrict__ L0,
@@ -780,11 +781,11 @@ __global__ __launch_bounds__(NT) void sparse_loop_kernel(LoopState* __restrict__
     // no row of degree >= 2 is left: the highest row of L is this round's centroid (a cluster of one), the others
     // are harvested; nothing else can change afterwards
     const int32_t* Lcur = parity ? L1 : L0;
-    for (int i = tid; i < nLcur; i += NT) atomicMax(&sMaxRow, Lcur[i]);
+    for (int i = tid; i < nLcur; i += LNT) atomicMax(&sMaxRow, Lcur[i]);
     __syncthreads();
     const int last = sMaxRow;
     if (last >= 0) {
-      for (int i = tid; i < nLcur; i += NT) {
+      for (int i = tid; i < nLcur; i += LNT) {
         const int r = Lcur[i];
         counts[r]   = DEAD;
         if (r != last) clusterIdx[back - atomicAdd(&sCount, 1)] = r;
@@ -821,14 +822,14 @@ __global__ __launch_bounds__(NT) void sparse_loop_kernel(LoopState* __restrict__
         cursor   = pick + 1;
         break;
       }
-      cursor += NT;
+      cursor += LNT;
     }
     if (centroid < 0) break;  // bucket exhausted: the next epoch builds the next one
 
     int32_t* Lcur  = parity ? L1 : L0;
     int32_t* Lnext = parity ? L0 : L1;
     // harvest: rows that reached degree 1 in the previous round (they have no live neighbour, nobody touches them)
-    for (int i = tid; i < nLcur; i += NT) {
+    for (int i = tid; i < nLcur; i += LNT) {
       const int r          = ldc(&Lcur[i]);
       counts[r]            = DEAD;
       clusterIdx[back - i] = r;
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(NT) void sparse_loop_kernel(LoopState* __restrict__
       sBeg[0]           = o0;
       sLen[0]           = static_cast<int>(o1 - o0);
     }
-    for (unsigned long long k = o0 + tid; k < o1; k += NT) {
+    for (unsigned long long k = o0 + tid; k < o1; k += LNT) {
       const int j = nbr[k];
       if (atomicExch(&counts[j], DEAD) > 0) {  // was alive: a new member (a neighbour appears once in the list)
         const int slot             = 1 + atomicAdd(&sCount, 1);
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(NT) void sparse_loop_kernel(LoopState* __restrict__
     __syncthreads();
     // subtract: every neighbour of a member loses one; 16 lanes per member
     const int g = tid >> 4, l = tid & 15;
-    for (int q = g; q < total; q += NT / 16) {
+    for (int q = g; q < total; q += LNT / 16) {
       unsigned long long a0;
       int                len;
       if (q < LOOP_MEMBERS) {
@@ -1062,7 +1063,7 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
           hipLaunchKernelGGL(bucket_count_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts);
           hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(NT), 0, stream, st, blockCounts, nBuckets);
           hipLaunchKernelGGL(bucket_fill_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts, cand);
-          hipLaunchKernelGGL(sparse_loop_kernel, dim3(1), dim3(NT), 0, stream, st, offs64, nbr, counts, clusterIdx, offsets, centroids,
+          hipLaunchKernelGGL(sparse_loop_kernel, dim3(1), dim3(LNT), 0, stream, st, offs64, nbr, counts, clusterIdx, offsets, centroids,
                              L0, L1, nL, cand);
         }
         NVMK_LAUNCH_CHECK();

@@ -30,7 +30,22 @@ struct StreamScratch {
   StreamScratch& operator=(const StreamScratch&) = delete;
   hipError_t     alloc(size_t bytes, hipStream_t s) {
     stream = s;
+    keep_pool_warm();
     return hipMallocAsync(&ptr, bytes > 0 ? bytes : 1, s);
+  }
+  // By default the stream-ordered pool hands freed memory back to the driver at every synchronisation, so each call of a
+  // blocking entry point re-acquired its scratch from the OS (measured: 40 ms of a 70 ms fused-Butina call at N = 100k).
+  // Keep up to 8 GiB cached per device; anything beyond is still released.
+  static void keep_pool_warm() {
+    static bool done[64] = {};
+    int         dev     = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) return;
+    done[dev] = true;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool != nullptr) {
+      uint64_t threshold = 8ull << 30;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+    }
   }
   ~StreamScratch() {
     if (ptr != nullptr) {
