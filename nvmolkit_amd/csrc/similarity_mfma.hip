@@ -827,6 +827,12 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   // ARITH: popcounts that can have no neighbour (padding sentinel, empty fingerprint) become +inf
   const double pbK0 = (pb0 == 0 || pb0 >= SENT) ? __builtin_inf() : static_cast<double>(pb0) * K2;
   const double pbK1 = (pb1 == 0 || pb1 >= SENT) ? __builtin_inf() : static_cast<double>(pb1) * K2;
+  // ... and a single-precision screen in front of the exact test: the accumulators are floats already, and with
+  // |c (1 + m)|, |s m| < 2^13 the f32 evaluation of c (1 + m) - pb m - pa m is within 0.01 of the exact value, so a
+  // slot whose best lane is below -0.02 holds no neighbour (2 FMAs + max + compare per slot instead of the f64 chain)
+  const float K1f = static_cast<float>(K1), K2f = static_cast<float>(K2);
+  const float pbF0 = (pb0 == 0 || pb0 >= SENT) ? __builtin_inff() : static_cast<float>(pb0) * K2f;
+  const float pbF1 = (pb1 == 0 || pb1 >= SENT) ? __builtin_inff() : static_cast<float>(pb1) * K2f;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -836,6 +842,9 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
       const unsigned paOff = static_cast<unsigned>(pav) * 4u;
       double         d0 = 0.0, d1 = 0.0, paK = 0.0;
       if constexpr (ARITH) {
+        const float paF = (pav == 0 || pav >= SENT) ? __builtin_inff() : static_cast<float>(pav) * K2f;
+        const float s0 = fmaf(acc[mi][0][r], K1f, -pbF0), s1 = fmaf(acc[mi][1][r], K1f, -pbF1);
+        if (__ballot(fmaxf(s0, s1) - paF > -0.02f) == 0) continue;  // screened out (the common case)
         paK = (pav == 0 || pav >= SENT) ? __builtin_inf() : __builtin_fma(static_cast<double>(pav), K2, -adj);
         d0  = __builtin_fma(static_cast<double>(acc[mi][0][r]), K1, -pbK0);
         d1  = __builtin_fma(static_cast<double>(acc[mi][1][r]), K1, -pbK1);
