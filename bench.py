@@ -147,7 +147,7 @@ def main() -> None:
                     help="mfma: FP4 matrix-core kernel on prepared sets (default); valu: v_bcnt popcount kernel")
     ap.add_argument("--butina-n", type=int, default=100_000,
                     help="also time fused Butina (cutoff 0.3) on this many rows, reported under 'secondary' (0 = skip)")
-    ap.add_argument("--conformer-mols", type=int, default=300,
+    ap.add_argument("--conformer-mols", type=int, default=1000,
                     help="also time ETKDG (10 conformers) + MMFF optimise on this many synthetic ~48-atom molecules, reported "
                          "under 'secondary' (0 = skip)")
     args = ap.parse_args()
