@@ -310,6 +310,19 @@ typedef struct nvmk_etkdg_params {
 int nvmk_etkdg_embed(const nvmk_etkdg_molset* mols, const nvmk_etkdg_params* params, double* d_coords,
                      int32_t* h_conf_counts, int32_t* h_stage_failures, void* stream);
 
+/* One stereochemistry check stage on given coordinates: d_failed[s] is set to 1 for every active system s on which a
+ * term of `kind` fails (never cleared).  Replaces the execute() of the reference's check stages
+ * (ETKDGTetrahedralCheckStage, ETKDGFirstChiralCenterCheckStage, ETKDGChiralCenterVolumeCheckStage,
+ * ETKDGChiralDistMatrixCheckStage, ETKDGDoubleBondStereoCheckStage, ETKDGDoubleBondGeometryCheckStage:
+ * src/etkdg_stage_stereochem_checks.cu:25-442, .h:69,122) as a unit of its own, so that E6 can be tested directly; the
+ * embedding pipeline above runs the same kernel.  d_pos holds 4 doubles per atom (x, y, z, w; w ignored), atom_starts has
+ * n_systems + 1 entries, sys_mol[s] selects the molecule whose check terms (nvmk_etkdg_molset layout) apply to system s,
+ * d_active may be NULL (all active). */
+int nvmk_etkdg_stereo_check(int kind, int n_systems, const int32_t* d_atom_starts, const int32_t* d_sys_mol,
+                            const int32_t* d_check_starts, const int32_t* d_check_kind, const int32_t* d_check_idx,
+                            const double* d_check_par, const double* d_pos, const uint8_t* d_active, uint8_t* d_failed,
+                            void* stream);
+
 /* ---- conformer RMSD matrices and RMS pruning (the step right after the embedding) ---------
  * Replaces conformerRmsdBatchMatrixGpu (src/conformer_rmsd.h:58-85, src/conformer_rmsd.cu:262-392) and the CPU pruning loop
  * of addConformersToMoleculeWithPruning (rdkit_extensions/conformer_pruning.cpp:88-137).

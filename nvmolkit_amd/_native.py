@@ -62,6 +62,7 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_scheduler_dispatch": (_int, [_vp, _int, _vp, ctypes.POINTER(_int)]),
     "nvmk_scheduler_record": (_int, [_vp, _vp, _vp, _int]),
     "nvmk_etkdg_embed": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "nvmk_etkdg_stereo_check": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nvmk_conformer_rmsd_batch": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
     "nvmk_conformer_prune": (_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
     "nvmk_butina_dense": (_int, [_vp, _vp, _i64, ctypes.c_double, _int, _vp, _vp, ctypes.POINTER(_i64), _vp]),

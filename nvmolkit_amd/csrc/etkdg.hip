@@ -162,9 +162,13 @@ struct P3 {
 __device__ __forceinline__ P3 sub(const P3 a, const P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ P3 crs(const P3 a, const P3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 __device__ __forceinline__ double dt(const P3 a, const P3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// No guard for a zero vector, exactly like the reference's normalizeVector (src/forcefields/kernel_utils.cuh:140-145)
+// and RDKit's Point3D::normalize: a three-coordinate centre repeats itself as its fourth neighbour, the fourth
+// direction becomes NaN, every comparison with it is false and the volume test passes — returning the zero vector
+// instead made all such centres FAIL (found by tests/test_stereo_checks_gpu.py against oracle/stereo.py).
 __device__ __forceinline__ P3 unit(const P3 a) {
   const double l = sqrt(dt(a, a));
-  return l > 0.0 ? P3{a.x / l, a.y / l, a.z / l} : a;
+  return P3{a.x / l, a.y / l, a.z / l};
 }
 __device__ __forceinline__ P3 atom(const double* p, const int a) { return {p[4 * a], p[4 * a + 1], p[4 * a + 2]}; }
 
@@ -321,6 +325,29 @@ int  nvmk_scheduler_dispatch(void* s, int batch_size, int32_t* h_mol_ids_out, in
 int nvmk_scheduler_record(void* s, const int32_t* h_mol_ids, const int16_t* h_finished_on_iteration, int n) {
   NVMK_REQUIRE(s && (n == 0 || (h_mol_ids && h_finished_on_iteration)), "scheduler record: NULL argument");
   NVMK_REQUIRE(static_cast<Scheduler*>(s)->record(h_mol_ids, h_finished_on_iteration, n) == 0, "molId is out of range");
+  return NVMK_OK;
+}
+
+int nvmk_etkdg_stereo_check(int kind, int n_systems, const int32_t* d_atom_starts, const int32_t* d_sys_mol,
+                            const int32_t* d_check_starts, const int32_t* d_check_kind, const int32_t* d_check_idx,
+                            const double* d_check_par, const double* d_pos, const uint8_t* d_active, uint8_t* d_failed,
+                            void* stream_) {
+  NVMK_REQUIRE(kind >= NVMK_CHECK_TETRAHEDRAL && kind <= NVMK_CHECK_DOUBLE_BOND_GEOMETRY, "stereo check: unknown kind %d", kind);
+  NVMK_REQUIRE(n_systems >= 0, "stereo check: negative system count");
+  if (n_systems == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_atom_starts && d_sys_mol && d_check_starts && d_check_kind && d_check_idx && d_check_par && d_pos && d_failed,
+               "stereo check: NULL buffer");
+  hipStream_t   stream = as_stream(stream_);
+  StreamScratch allActive;
+  const uint8_t* active = d_active;
+  if (active == nullptr) {
+    NVMK_HIP_CHECK(allActive.alloc(static_cast<size_t>(n_systems), stream));
+    NVMK_HIP_CHECK(hipMemsetAsync(allActive.ptr, 1, static_cast<size_t>(n_systems), stream));
+    active = allActive.as<uint8_t>();
+  }
+  hipLaunchKernelGGL(stereo_check_kernel, dim3(n_systems), dim3(64), 0, stream, n_systems, d_atom_starts, d_sys_mol, d_check_starts,
+                     d_check_kind, d_check_idx, d_check_par, kind, d_pos, active, d_failed);
+  NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }
 

@@ -24,7 +24,7 @@ extern "C" {
 
 const char* nvmk_last_error(void) { return nvmk::g_last_error; }
 
-int nvmk_abi_version(void) { return (0 << 16) | 2; }
+int nvmk_abi_version(void) { return (0 << 16) | 3; }
 
 int nvmk_device_count(int* count) {
   NVMK_REQUIRE(count != nullptr, "nvmk_device_count: count is NULL");

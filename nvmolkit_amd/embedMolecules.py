@@ -202,6 +202,41 @@ def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterati
     return dev
 
 
+# stereo-check kinds (NVMK_CHECK_* of include/nvmolkit_amd.h)
+CHECK_TETRAHEDRAL, CHECK_CHIRAL_VOLUME, CHECK_CHIRAL_DISTANCE, CHECK_CHIRAL_CENTER_VOLUME, CHECK_DOUBLE_BOND_STEREO, \
+    CHECK_DOUBLE_BOND_GEOMETRY = range(6)
+
+
+def stereo_check_flat(kind: int, positions: torch.Tensor, atom_starts, sys_mol, check_starts, check_kind, check_idx, check_par,
+                      active=None, stream=None) -> torch.Tensor:
+    """One stereochemistry check stage (``CHECK_*`` kind) on given coordinates — the unit the embedding pipeline runs
+    between its minimisations (reference: src/etkdg_stage_stereochem_checks.cu).  ``positions`` is a float64 CUDA tensor
+    (total_atoms, 4) (x, y, z, w), ``atom_starts`` has n_systems + 1 entries, ``sys_mol[s]`` selects the molecule whose
+    check terms (``check_starts`` per molecule; ``check_kind``, ``check_idx`` (n, 5), ``check_par`` (n, 2)) apply to
+    system s.  Returns a uint8 CUDA tensor (n_systems,): 1 where a term of that kind failed."""
+    if not (isinstance(positions, torch.Tensor) and positions.is_cuda and positions.dtype == torch.float64 and positions.dim() == 2
+            and positions.shape[1] == 4):
+        raise ValueError("positions must be a float64 CUDA tensor of shape (total_atoms, 4)")
+    dev = positions.device
+    to = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
+    d_as, d_sm = to(atom_starts, np.int32), to(sys_mol, np.int32)
+    d_cs, d_ck = to(check_starts, np.int32), to(check_kind, np.int32)
+    d_ci, d_cp = to(np.asarray(check_idx).reshape(-1, 5), np.int32), to(np.asarray(check_par).reshape(-1, 2), np.float64)
+    n_sys = int(d_sm.numel())
+    if int(d_as.numel()) != n_sys + 1:
+        raise ValueError("atom_starts must have n_systems + 1 entries")
+    failed = torch.zeros(n_sys, dtype=torch.uint8, device=dev)
+    d_act = None if active is None else torch.as_tensor(active).to(device=dev, dtype=torch.uint8).contiguous()
+    pos = positions.contiguous()
+    with torch.cuda.device(dev):
+        rc = _native.lib().nvmk_etkdg_stereo_check(int(kind), n_sys, d_as.data_ptr(), d_sm.data_ptr(), d_cs.data_ptr(), d_ck.data_ptr(),
+                                                   d_ci.data_ptr(), d_cp.data_ptr(), pos.data_ptr(),
+                                                   0 if d_act is None else d_act.data_ptr(), failed.data_ptr(),
+                                                   _native.stream_ptr(stream))
+    _native.check(rc, "nvmk_etkdg_stereo_check")
+    return failed
+
+
 def EmbedMolecules(molecules, params, confsPerMolecule: int = 1, maxIterations: int = -1,
                    hardwareOptions: HardwareOptions | None = None, output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS,
                    targetGpu: int | None = None):
