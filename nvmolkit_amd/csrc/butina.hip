@@ -912,6 +912,39 @@ __global__ void sparse_leftover_kernel(LoopState* __restrict__ st, const int32_t
   if (i < n && counts[i] == 0) clusterIdx[atomicSub(&st->back, 1)] = i;
 }
 
+// ---- popcount-sorted first pass (opt-in: NVMK_BUTINA_SORT=1) ------------------------------------------
+// Tanimoto(a, b) <= min(|a|, |b|) / max(|a|, |b|): with the rows sorted by popcount, whole tiles whose popcount bands
+// are further apart than the threshold hold no neighbour pair and the count kernel skips them (fp4::CountArgs::bandSkip).
+// Only the all-pairs pass runs on the sorted copy; pairs and degrees are mapped back to the original row numbers, so
+// everything downstream (ties toward the highest ORIGINAL row, output order) is unchanged.
+__global__ void row_popcount_kernel(const uint32_t* __restrict__ x, const int64_t n, const int W, int32_t* __restrict__ pop) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* r = reinterpret_cast<const uint4*>(x + i * W);
+  int          c = 0;
+  for (int w = 0; w < W / 4; ++w) {
+    const uint4 v = r[w];
+    c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+  pop[i] = c;
+}
+__global__ void remap_edges_kernel(int2* __restrict__ edges, const unsigned long long nEdges, const int32_t* __restrict__ perm) {
+  for (unsigned long long e = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; e < nEdges;
+       e += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+    const int2 p = edges[e];
+    edges[e]     = make_int2(perm[p.x], perm[p.y]);
+  }
+}
+__global__ void scatter_counts_kernel(const int32_t* __restrict__ sorted, const int32_t* __restrict__ perm, const int64_t n,
+                                      int32_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[perm[i]] = sorted[i];
+}
+inline bool sorted_first_pass() {
+  const char* e = std::getenv("NVMK_BUTINA_SORT");
+  return e != nullptr && e[0] == '1';
+}
+
 template <int METRIC>
 int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_t* h_idx, int64_t* h_offsets,
                int32_t* h_centroids, int64_t* n_clusters, hipStream_t stream) {
@@ -952,9 +985,25 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
   const bool    useMfma = !force_valu() && (force_mfma() || N >= 2048);
   StreamScratch fp4Mem;
   fp4::Prepared PX{};
+  // popcount-sorted first pass: only with the sparse-graph loop (it consumes the emitted pairs) and Tanimoto
+  const bool    sortPass = useMfma && sorted_first_pass() && !dense_rounds() && METRIC == NVMK_METRIC_TANIMOTO && thr > 0.0f;
+  StreamScratch sortMem, sortTmp;
+  int32_t*      perm = nullptr;  // sorted position -> original row
   if (useMfma) {
     NVMK_HIP_CHECK(fp4Mem.alloc(fp4::layout(N, fpBits).bytes, stream));
-    rc = fp4::prepare(d_x, nullptr, N, fpBits, fp4Mem.ptr, stream);
+    if (sortPass) {
+      NVMK_HIP_CHECK(sortMem.alloc(3 * n * sizeof(int32_t), stream));
+      int32_t* pop = sortMem.as<int32_t>();
+      int32_t* popSorted = pop + n;
+      perm               = popSorted + n;
+      hipLaunchKernelGGL(row_popcount_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream, d_x, N, W, pop);
+      NVMK_LAUNCH_CHECK();
+      size_t tmpBytes = 0;
+      NVMK_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, pop, popSorted, alive0, perm, static_cast<int>(N), 0, 32, stream));
+      NVMK_HIP_CHECK(sortTmp.alloc(tmpBytes, stream));
+      NVMK_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(sortTmp.ptr, tmpBytes, pop, popSorted, alive0, perm, static_cast<int>(N), 0, 32, stream));
+    }
+    rc = fp4::prepare(d_x, perm, N, fpBits, fp4Mem.ptr, stream);
     if (rc != NVMK_OK) return rc;
     PX = fp4::view(fp4Mem.ptr, N, fpBits);
   }
@@ -1003,11 +1052,20 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
     a.edges        = edges;
     a.edgeCursor   = edgeCursor;
     a.edgeCapacity = edgeCap;
+    a.bandSkip     = sortPass;
     rc             = fp4::launch_counts(a, PX, PX, counts, stream);
   } else {
     rc = count_pass(nullptr, N, nullptr, nullptr, N, nullptr, +1, true);
   }
   if (rc != NVMK_OK) return rc;
+  if (sortPass && edgeCap > 0) {
+    // back to original row numbers: degrees now, pairs once their number is known; the FP4 copy goes back to the
+    // original order too (only the dense-round fallback reads it again)
+    hipLaunchKernelGGL(scatter_counts_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream, counts, perm, N,
+                       removed);
+    NVMK_LAUNCH_CHECK();
+    NVMK_HIP_CHECK(hipMemcpyAsync(counts, removed, n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  }
 
   LoopState snap{};
   bool      sparseDone = false;
@@ -1015,7 +1073,16 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
     unsigned long long nEdges = 0;
     NVMK_HIP_CHECK(hipMemcpyAsync(&nEdges, edgeCursor, sizeof(nEdges), hipMemcpyDeviceToHost, stream));
     NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    if (sortPass && nEdges > edgeCap) {  // dense-round fallback: it gathers rows of the FP4 copy by ORIGINAL row number
+      rc = fp4::prepare(d_x, nullptr, N, fpBits, fp4Mem.ptr, stream);
+      if (rc != NVMK_OK) return rc;
+    }
     if (nEdges <= edgeCap) {  // otherwise: too dense for the edge buffer, the dense rounds below handle it
+      if (sortPass && nEdges > 0) {
+        const unsigned rb = static_cast<unsigned>(std::min<unsigned long long>(ceil_div<unsigned long long>(nEdges, 256), 65535));
+        hipLaunchKernelGGL(remap_edges_kernel, dim3(rb), dim3(256), 0, stream, edges, nEdges, perm);
+        NVMK_LAUNCH_CHECK();
+      }
       // CSR: degrees -> exclusive scan -> fill
       StreamScratch csrMem, scanTmp;
       const size_t  offBytes = (n + 1) * sizeof(unsigned long long);

@@ -89,6 +89,9 @@ struct CountArgs {
   int2*               edges        = nullptr;
   unsigned long long* edgeCursor   = nullptr;
   unsigned long long  edgeCapacity = 0;
+  // rows of X and Y are sorted by popcount (ascending): tiles whose popcount bands cannot reach the Tanimoto threshold
+  // (T <= min(pa, pb) / max(pa, pb)) are skipped.  Tile count kernel, Tanimoto only.
+  bool                bandSkip     = false;
 };
 int launch_counts(const CountArgs& args, const Prepared& X, const Prepared& Y, int32_t* counts, hipStream_t stream);
 

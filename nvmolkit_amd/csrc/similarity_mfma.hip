@@ -693,7 +693,7 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   const int32_t* __restrict__ yRows, const int32_t* __restrict__ yIds, int64_t nY, const int32_t* __restrict__ nYdev, const int Wp, const int F,
   const float* __restrict__ table, const float thr, const int sign, const int symmetric, int32_t* __restrict__ counts, const unsigned superN,
   const unsigned superW, const unsigned superH, int2* __restrict__ edges, unsigned long long* __restrict__ edgeCursor,
-  const unsigned long long edgeCapacity, const double K1, const double K2, const double adj) {
+  const unsigned long long edgeCapacity, const double K1, const double K2, const double adj, const float bandThr) {
   constexpr int KCW = 8;
   constexpr int PPW = KCW / 2;
   constexpr int RPP = 64 / KCW;
@@ -772,6 +772,15 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
     colsum[t]       = 0;
   }
   if (EMIT && tid == 0) edgeMeta[0] = 0;
+  if (bandThr > 0.0f) {
+    // Rows sorted by popcount: a tile's popcounts span [pc[0], pc[last valid]].  Tanimoto <= min(pa, pb) / max(pa, pb),
+    // so when the bands are further apart than the threshold (taken 1e-6 low: the f32 predicate cannot round across
+    // that) no pair of the tile is a neighbour and the workgroup leaves before touching the operands.
+    __syncthreads();
+    const int    lastA = static_cast<int>(nX - rowA0 < TM ? nX - rowA0 : TM) - 1, lastB = static_cast<int>(nY - rowB0 < TN ? nY - rowB0 : TN) - 1;
+    const double minA = pcA[0], maxA = pcA[lastA], minB = pcB[0], maxB = pcB[lastB], t = static_cast<double>(bandThr) * (1.0 - 1.0e-6);
+    if (maxB < t * minA || maxA < t * minB) return;
+  }
 
   v16f acc[2][2];
 #pragma unroll
@@ -1461,7 +1470,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   using Kern = void (*)(const uint4*, const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, const uint4*,
                         const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, int, int, const float*,
                         float, int, int, int32_t*, unsigned, unsigned, unsigned, int2*, unsigned long long*,
-                        unsigned long long, double, double, double);
+                        unsigned long long, double, double, double, float);
   Kern kern;
   ArithThreshold at = arith_threshold(a.thr, F);
   if (const char* te = std::getenv("NVMK_COUNT_THRESHOLD"); te != nullptr && std::string(te) == "table") at.ok = false;  // tests: force the table form
@@ -1475,7 +1484,8 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   hipLaunchKernelGGL(kern, grid, dim3(NT), shmem, stream, X.rows, X.popc, a.xRows, a.xIds, a.nX, a.nXdev, Y.rows, Y.popc,
                      a.yRows, a.yIds, a.nY, a.nYdev, X.L.Wp, F, a.tableF, a.thr, a.sign, a.symmetric ? 1 : 0, counts,
                      static_cast<unsigned>(superN), static_cast<unsigned>(superW), static_cast<unsigned>(superE), a.edges,
-                     a.edgeCursor, a.edgeCapacity, at.k1, at.k2, at.adj);
+                     a.edgeCursor, a.edgeCapacity, at.k1, at.k2, at.adj,
+                     (a.bandSkip && a.metric == NVMK_METRIC_TANIMOTO && a.thr > 0.0f && a.xRows == nullptr && a.yRows == nullptr) ? a.thr : 0.0f);
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }
