@@ -36,13 +36,20 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 SEED = 20260926
 
 
-def synth_fingerprints(n: int, words: int, device, seed: int, n_centres: int | None = None) -> torch.Tensor:
-    """BASELINE.md cfg2 generator on the GPU: planted clusters, ~2.3 % density, <= 12 bit flips per row."""
+def synth_fingerprints(n: int, words: int, device, seed: int, n_centres: int | None = None,
+                       density_range: tuple[float, float] | None = None) -> torch.Tensor:
+    """BASELINE.md cfg2 generator on the GPU: planted clusters, ~2.3 % density, <= 12 bit flips per row.
+    ``density_range=(lo, hi)`` gives every cluster centre its own bit density instead (popcounts spread like real
+    Morgan fingerprints of small to large molecules; used by tools/bench_butina.py --spread)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     nbits = words * 32
     n_centres = n_centres or max(1, n // 50)
-    centres = torch.rand((n_centres, nbits), generator=g, device=device) < 0.023
+    if density_range is None:
+        centres = torch.rand((n_centres, nbits), generator=g, device=device) < 0.023
+    else:
+        dens = density_range[0] + (density_range[1] - density_range[0]) * torch.rand((n_centres, 1), generator=g, device=device)
+        centres = torch.rand((n_centres, nbits), generator=g, device=device) < dens
     weights = (torch.ones(32, dtype=torch.int32, device=device) << torch.arange(32, dtype=torch.int32, device=device))
     centres_packed = (centres.reshape(n_centres, words, 32).to(torch.int32) * weights).sum(dim=2, dtype=torch.int32)
     out = torch.empty((n, words), dtype=torch.int32, device=device)

@@ -912,7 +912,7 @@ __global__ void sparse_leftover_kernel(LoopState* __restrict__ st, const int32_t
   if (i < n && counts[i] == 0) clusterIdx[atomicSub(&st->back, 1)] = i;
 }
 
-// ---- popcount-sorted first pass (opt-in: NVMK_BUTINA_SORT=1) ------------------------------------------
+// ---- popcount-sorted first pass (NVMK_BUTINA_SORT=0 turns it off) ---------------------------------------
 // Tanimoto(a, b) <= min(|a|, |b|) / max(|a|, |b|): with the rows sorted by popcount, whole tiles whose popcount bands
 // are further apart than the threshold hold no neighbour pair and the count kernel skips them (fp4::CountArgs::bandSkip).
 // Only the all-pairs pass runs on the sorted copy; pairs and degrees are mapped back to the original row numbers, so
@@ -940,9 +940,9 @@ __global__ void scatter_counts_kernel(const int32_t* __restrict__ sorted, const 
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) out[perm[i]] = sorted[i];
 }
-inline bool sorted_first_pass() {
+inline bool sorted_first_pass() {  // default on; NVMK_BUTINA_SORT=0 keeps the input order
   const char* e = std::getenv("NVMK_BUTINA_SORT");
-  return e != nullptr && e[0] == '1';
+  return e == nullptr || e[0] != '0';
 }
 
 template <int METRIC>

@@ -12,7 +12,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["valu", "mfma", "mfma:dense", "mfma:ring", "mfma:table", "mfma:sort", "auto"], autouse=True)
+@pytest.fixture(params=["valu", "mfma", "mfma:dense", "mfma:ring", "mfma:table", "mfma:nosort", "auto"], autouse=True)
 def sim_path(request, monkeypatch):
     """Neighbour counting / fused Butina run on the v_bcnt kernels, on the FP4 matrix-core kernels (round loop on the
     sparse neighbour graph; the dense round loop that streams the fingerprint matrix; the sparse loop with every
@@ -26,8 +26,8 @@ def sim_path(request, monkeypatch):
     monkeypatch.delenv("NVMK_COUNT_KERNEL", raising=False)
     monkeypatch.delenv("NVMK_COUNT_THRESHOLD", raising=False)
     monkeypatch.delenv("NVMK_BUTINA_SORT", raising=False)
-    if variant == "sort":  # fused Butina: all-pairs pass on the popcount-sorted copy with tile skipping
-        monkeypatch.setenv("NVMK_BUTINA_SORT", "1")
+    if variant == "nosort":  # fused Butina: all-pairs pass in input order (default: popcount-sorted copy with tile skipping)
+        monkeypatch.setenv("NVMK_BUTINA_SORT", "0")
     if variant == "table":
         monkeypatch.setenv("NVMK_COUNT_THRESHOLD", "table")
     if variant == "dense":

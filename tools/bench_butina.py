@@ -18,10 +18,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("sizes", nargs="*", type=int, default=[100_000, 1_000_000])
 ap.add_argument("--cutoff", type=float, default=0.3)
 ap.add_argument("--skip-butina", action="store_true")
+ap.add_argument("--spread", action="store_true", help="cluster centres with bit densities from 1 % to 6 % (wide popcount spread)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 for n in args.sizes:
-    x = synth_fingerprints(n, 64, dev, SEED)
+    x = synth_fingerprints(n, 64, dev, SEED, density_range=(0.01, 0.06) if args.spread else None)
     counts = torch.zeros(n, dtype=torch.int32, device=dev)
     update_neighbor_counts(x[:4096], x[:4096], counts[:4096], 1.0 - args.cutoff)  # warm-up
     counts.zero_()
