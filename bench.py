@@ -106,38 +106,153 @@ def cpu_baseline(ref_words: np.ndarray, target_seconds: float) -> dict:
     }
 
 
-def conformer_secondary(n_mols: int, confs: int = 10, mean_atoms: int = 48) -> dict:
-    """ETKDG (`confs` conformers per molecule) then MMFF optimise of every conformer, DEVICE-chained, on synthetic
-    flattened molecules (nvmolkit_amd/synthetic.py; BASELINE.json configs[2] shape — real SMILES need RDKit)."""
-    from nvmolkit_amd import mmffOptimization
+def kernel_source_digest(names=("similarity_mfma.hip", "fp4.h", "similarity.hip")) -> str:
+    """sha256 over the dense-similarity kernel sources: a PMC traffic file is only quoted for the code it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in names:
+        h.update((ROOT / "nvmolkit_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()
+
+
+def butina_block(n: int, words: int, device, cpu_seconds: float) -> dict:
+    """Fused Butina (cutoff 0.3 = similarity threshold 0.7, BASELINE.json configs[1]) on n planted-cluster fingerprints,
+    with the roofline of its dominant kernel (the FP4 matrix-core neighbour-count pass) and the C oracle timed on a sample."""
+    from nvmolkit_amd.clustering import fused_butina
+
+    xb = synth_fingerprints(n, words, device, SEED)
+    fused_butina(xb, 0.3)  # warm-up at full size: scratch pools, hipcub temp storage
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tb = time.perf_counter()
+    ev0.record()
+    clusters, sizes = fused_butina(xb, 0.3)
+    ev1.record()
+    torch.cuda.synchronize()
+    tb = time.perf_counter() - tb
+    pairs = n * (n + 1) / 2.0                       # the symmetric all-pairs pass evaluates every unordered pair once
+    flops = pairs * 2.0 * words * 32                # one multiply-add per bit of the fingerprint
+    out = {"n": n, "cutoff": 0.3, "seconds": tb, "n_clusters": len(clusters), "fingerprints_per_s": n / tb,
+           "timing": "second call on the same set (whole call: all-pairs pass + CSR + device round loop + host lists)",
+           "roofline": {"bound": "mfma", "achieved": flops / tb / 1e12, "peak": 10000.0, "unit": "TFLOP/s",
+                        "frac": flops / tb / 1e12 / 10000.0, "traffic": None,
+                        "kernel": "nvmk::fp4::neighbor_count_mfma_kernel (FP4 e2m1 x e2m1 -> f32, exact 0/1 products)",
+                        "note": "algorithmic flops = n (n + 1) / 2 pairs x 2 x fp_bits, divided by the WHOLE call's wall time "
+                                "(conservative: the pass is ~60 % of the call); peak = ~10 PF dense FP4 MFMA "
+                                "(MI355X_MICROARCH.md; 9.1 PF measured there)"}}
+    if cpu_seconds > 0:
+        import oracle
+
+        m = min(n, 40_000)
+        sub = xb[:m].cpu().numpy().view(np.uint32)
+        t0 = time.perf_counter()
+        cl, _, _ = oracle.butina_fused(sub, 0.3)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": m / dt, "unit": "fingerprints/s", "cores": oracle.num_threads(), "kind": "port",
+                               "pairs_per_s": m * (m + 1) / 2.0 / dt,
+                               "sample": f"first {m} rows of the same set, oracle/oracle_similarity.c orc_butina_fused "
+                                         f"(OpenMP popcount passes), {dt:.1f} s, {len(cl)} clusters; cost grows with n^2, "
+                                         "so fingerprints/s at 1M rows is about n_sample / 1M of this"}
+    return out
+
+
+BFGS_KIND_NAMES = {0: "dg", 1: "etk", 2: "mmff"}
+
+
+def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int, rank: int, cpu_seconds: float) -> dict:
+    """BASELINE.json configs[2] (and [3] when world > 1: every rank embeds and optimises its own n_mols molecules, no
+    data-path collective): ETKDG (`confs` conformers per molecule) DEVICE-chained into MMFF94 on the synthetic drug-like
+    set of nvmolkit_amd/synthetic.py.  Roofline = the fused BFGS kernels' inverse-Hessian traffic."""
+    from nvmolkit_amd import _native, mmffOptimization, synthetic
     from nvmolkit_amd.embedMolecules import FlatMolecule, FlatMoleculeSet, embed_flat
-    from nvmolkit_amd.forcefield import MMFF
-    from nvmolkit_amd.synthetic import random_ff_system, synthetic_embed_molecule
     from nvmolkit_amd.types import CoordinateOutput
 
-    rng = np.random.default_rng(SEED)
-    sizes = np.clip(rng.normal(mean_atoms, 12, size=n_mols).round().astype(int), 12, 96)
-    molset = FlatMoleculeSet([FlatMolecule(**synthetic_embed_molecule(rng, int(n), with_etk=True)[0]) for n in sizes])
-    tables = [random_ff_system(MMFF, int(n), rng)[1] for n in sizes]
-    embed_flat(FlatMoleculeSet([FlatMolecule(**synthetic_embed_molecule(rng, 12, with_etk=True)[0])]), 1, 5,
-               enforce_chirality=False)  # warm-up (module load, allocator)
+    t0 = time.perf_counter()
+    procs = max(1, (os.cpu_count() or 2) // (2 * world))
+    library = synthetic.druglike_library(n_mols, seed=SEED + 17 * rank, processes=min(procs, 64))
+    molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library], device=device)
+    tables = [m["mmff"] for m in library]
+    t_prep = time.perf_counter() - t0
+    lib = _native.lib()
+    embed_flat(FlatMoleculeSet([FlatMolecule(**library[0]["embed"])], device=device), 1, 5)  # warm-up: module load, pools
+    stats = torch.zeros(64, dtype=torch.int64, device=device)
+    _native.check(lib.nvmk_bfgs_set_stats(stats.data_ptr()))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    dev = embed_flat(molset, confs_per_molecule=confs, max_iterations=10, enforce_chirality=False, seed=1,
-                     output=CoordinateOutput.DEVICE)
+    dev = embed_flat(molset, confs_per_molecule=confs, max_iterations=10, seed=1 + rank, output=CoordinateOutput.DEVICE)
     torch.cuda.synchronize()
     t_embed = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    opt = mmffOptimization.optimize_device(tables, dev, max_iters=200)
+    t1 = time.perf_counter()
+    opt = mmffOptimization.optimize_device(tables, dev, max_iters=mmff_iters)
     torch.cuda.synchronize()
-    t_mmff = time.perf_counter() - t0
+    t_mmff = time.perf_counter() - t1
+    wall = time.perf_counter() - t0
+    _native.check(lib.nvmk_bfgs_set_stats(None))
     n_conf = dev.num_conformers
-    return {"metric": "mols/s ETKDG(10 confs) + MMFF optimise, synthetic molecules", "value": n_mols / (t_embed + t_mmff),
-            "molecules": n_mols, "mean_atoms": float(sizes.mean()), "conformers": n_conf,
-            "etkdg_seconds": t_embed, "etkdg_conformers_per_s": n_conf / t_embed,
-            "mmff_seconds": t_mmff, "mmff_conformers_per_s": n_conf / t_mmff,
-            "mmff_converged": int(opt.converged.torch().sum().item()),
-            "note": "tables are random (parameter ranges of real tables), so MMFF mostly runs to the 200-iteration cap"}
+    converged = int(opt.converged.torch().sum().item())
+    if world > 1:
+        t = torch.tensor([wall, t_embed, t_mmff], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c = torch.tensor([n_conf, converged, n_mols], dtype=torch.int64, device=device)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        wall, t_embed, t_mmff = (float(x) for x in t.tolist())
+        n_conf, converged, total_mols = (int(x) for x in c.tolist())
+    else:
+        total_mols = n_mols
+    st = stats.cpu().numpy().reshape(8, 8)
+    per_kind = {BFGS_KIND_NAMES[k]: {"systems": int(st[k, 0]), "iterations": int(st[k, 1]), "algorithmic_bytes": int(st[k, 2]),
+                                     "energy_evaluations": int(st[k, 3]), "hbm_resident_bytes": int(st[k, 4]),
+                                     "mean_iterations": float(st[k, 1]) / max(int(st[k, 0]), 1)} for k in BFGS_KIND_NAMES}
+    algo = float(sum(v["algorithmic_bytes"] for v in per_kind.values()))
+    out = {"metric": f"mols/s ETKDG({confs} confs) + MMFF94 optimise (maxIters {mmff_iters})", "value": total_mols / wall,
+           "unit": "mols/s", "n_gpus": world, "molecules": total_mols, "confs_per_molecule": confs,
+           "mean_atoms": float(np.mean([m["embed"]["n_atoms"] for m in library])), "conformers": n_conf,
+           "etkdg_seconds": t_embed, "etkdg_conformers_per_s": n_conf / t_embed, "mmff_seconds": t_mmff,
+           "mmff_conformers_per_s": n_conf / t_mmff, "mmff_converged_fraction": converged / max(n_conf, 1),
+           "host_preparation_seconds": t_prep, "scaling": "weak", "bfgs": per_kind,
+           "data": "synthetic drug-like molecules (rings + chains + hydrogens, bounds / ETK / MMFF tables derived from one "
+                   "generated 3-D geometry; nvmolkit_amd/synthetic.py) — real SMILES need RDKit",
+           "roofline": {"bound": "hbm", "achieved": algo / wall / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": algo / wall / 1e9 / HBM_PEAK_GBPS / world, "traffic": None,
+                        "hbm_bytes_requested_by_the_hessian_pass": float(sum(v["hbm_resident_bytes"] for v in per_kind.values())),
+                        "kernel": "nvmk::minim::bfgs_kernel<DG|ETK|MMFF> (> 99 % of the GPU time of this block)",
+                        "note": "algorithmic bytes = sum over systems of BFGS iterations x 8 n (n + 2) (read + write of the "
+                                "packed inverse Hessian, counted by the kernels themselves: nvmk_bfgs_set_stats), divided by "
+                                "the block's wall time; rows of the inverse Hessian that stay in LDS never reach HBM, so "
+                                "the bytes requested from HBM are the smaller figure beside it"}}
+    if rank == 0 and world == 1 and cpu_seconds > 0:
+        from nvmolkit_amd.forcefield import MMFF as KIND_MMFF, stack_molecule_tables
+        from oracle import ffc
+        import oracle
+
+        threads = oracle.num_threads()
+        m = int(min(n_mols, max(16, 2 * threads)))
+        sub = library[:m]
+        mols = [FlatMolecule(**x["embed"]) for x in sub]
+        c0 = time.perf_counter()
+        coords, counts, slots, fails, iters = ffc.etkdg_embed(mols, confs_per_molecule=confs, max_iterations=10, seed=1)
+        c_embed = time.perf_counter() - c0
+        n_at = np.array([x["embed"]["n_atoms"] for x in sub])
+        sys_mol = np.repeat(np.arange(m), counts).astype(np.int32)
+        a_s = np.concatenate([[0], np.cumsum(n_at[sys_mol])])
+        pos = np.concatenate([coords[slots[i]:slots[i] + 3 * n_at[i] * counts[i]] for i in range(m)])
+        batch = ffc.Batch(KIND_MMFF, a_s, stack_molecule_tables(KIND_MMFF, [x["mmff"] for x in sub]), system_mol=sys_mol)
+        c1 = time.perf_counter()
+        _, _, st_c, it_c = batch.minimize(pos, max_iters=mmff_iters)
+        c_mmff = time.perf_counter() - c1
+        out["cpu_baseline"] = {"value": m / (c_embed + c_mmff), "unit": "mols/s", "cores": threads, "kind": "port",
+                               "etkdg_seconds": c_embed, "mmff_seconds": c_mmff, "conformers": int(counts.sum()),
+                               "mmff_converged_fraction": float((st_c == 0).mean()),
+                               "sample": f"first {m} molecules of the same set x {confs} conformers, oracle/oracle_ff.c "
+                                         f"(same stage pipeline, scheduler, BFGS and term tables; OpenMP over attempts / "
+                                         f"conformers on {threads} threads), {c_embed + c_mmff:.1f} s"}
+    return out
 
 
 def main() -> None:
@@ -152,11 +267,14 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--path", choices=["mfma", "valu"], default="mfma",
                     help="mfma: FP4 matrix-core kernel on prepared sets (default); valu: v_bcnt popcount kernel")
-    ap.add_argument("--butina-n", type=int, default=100_000,
-                    help="also time fused Butina (cutoff 0.3) on this many rows, reported under 'secondary' (0 = skip)")
-    ap.add_argument("--conformer-mols", type=int, default=1000,
-                    help="also time ETKDG (10 conformers) + MMFF optimise on this many synthetic ~48-atom molecules, reported "
+    ap.add_argument("--butina-n", type=int, default=1_000_000,
+                    help="also time fused Butina (cutoff 0.3) on this many rows (BASELINE.json configs[1]: 1M), reported "
                          "under 'secondary' (0 = skip)")
+    ap.add_argument("--conformer-mols", type=int, default=10_000,
+                    help="also time ETKDG (10 conformers) + MMFF94 optimise on this many synthetic drug-like molecules PER "
+                         "GPU (BASELINE.json configs[2]: 10k; configs[3] when --gpus > 1), reported under 'secondary' (0 = skip)")
+    ap.add_argument("--conformer-confs", type=int, default=10)
+    ap.add_argument("--mmff-iters", type=int, default=200, help="MMFF maxIters (the reference benchmark's default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,6 +317,7 @@ def main() -> None:
     sptr = int(stream.cuda_stream)
     n_launch = (n_q + chunk - 1) // chunk
     use_mfma = args.path == "mfma"
+    ws_q = ws_r = None
     if use_mfma:
         assert chunk % 128 == 0 or chunk == n_q, "--chunk-rows must be a multiple of 128 on the mfma path"
         ws_q = torch.empty(lib.nvmk_fp4_workspace_bytes(n_q, args.fp_bits), dtype=torch.uint8, device=device)
@@ -295,11 +414,14 @@ def main() -> None:
         # prescribes).  Counters cannot be read inside this process, so the figure is reported only for the exact
         # workload it was collected on, else null.
         traffic, traffic_src = None, None
-        pmc = Path(__file__).resolve().parent / "profiles" / "r01_final" / "pmc_hbm_traffic_bench_launch.json"
-        if use_mfma and chunk == 8192 and n_ref == 1_000_000 and args.fp_bits == 2048 and pmc.exists():
+        for pmc in sorted((ROOT / "profiles").glob("r*/pmc_hbm_traffic_bench_launch.json"), reverse=True):
             c = json.loads(pmc.read_text())
-            traffic = (2.0 * c["FETCH_SIZE"]["mean_KiB_per_full_launch"] + c["WRITE_SIZE"]["mean_KiB_per_full_launch"]) * 1024.0
-            traffic_src = "profiles/r01_final/pmc_hbm_traffic_bench_launch.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per full launch"
+            # quoted only for the exact workload AND kernel source it was collected on: a stale file is ignored
+            if (use_mfma and chunk == 8192 and n_ref == 1_000_000 and args.fp_bits == 2048
+                    and c.get("kernel_source_sha256") == kernel_source_digest()):
+                traffic = (2.0 * c["FETCH_SIZE"]["mean_KiB_per_full_launch"] + c["WRITE_SIZE"]["mean_KiB_per_full_launch"]) * 1024.0
+                traffic_src = f"{pmc.relative_to(ROOT)}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per full launch, kernel source hash matches"
+                break
         result["roofline"] = {
             "bound": "hbm",
             "achieved": achieved,
@@ -322,18 +444,16 @@ def main() -> None:
         # measured after and outside the timed region of the headline number, bounded to a few seconds.
         secondary = {}
         if world == 1 and args.butina_n > 0:
-            from nvmolkit_amd.clustering import fused_butina
-
-            xb = synth_fingerprints(args.butina_n, words, device, SEED)  # own set: n / 50 planted clusters
-            fused_butina(xb, 0.3)  # warm-up at full size: first-use allocations (scratch pools, hipcub) are not the algorithm
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            clusters, sizes = fused_butina(xb, 0.3)
-            tb = time.perf_counter() - tb
-            secondary["fused_butina"] = {"n": args.butina_n, "cutoff": 0.3, "seconds": tb, "n_clusters": len(clusters),
-                                         "fingerprints_per_s": args.butina_n / tb, "timing": "second call on the same set"}
-        if world == 1 and args.conformer_mols > 0:
-            secondary["conformers"] = conformer_secondary(args.conformer_mols)
+            secondary["fused_butina"] = butina_block(args.butina_n, words, device, args.cpu_seconds)
+    else:
+        secondary = {}
+    if args.conformer_mols > 0:  # every rank takes part (configs[3]: molecules sharded, no collective on the data path)
+        out = queries = ref_gathered = ref_shard = ws_q = ws_r = None  # noqa: F841  (release ~70 GB before the next block)
+        torch.cuda.empty_cache()
+        block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds)
+        if rank == 0:
+            secondary["conformers"] = block
+    if rank == 0:
         if secondary:
             result["secondary"] = secondary
         print(json.dumps(result))

@@ -241,6 +241,15 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
                        double grad_tol, int scale_grads, double* d_pos, const uint8_t* d_active, double* d_energies,
                        int16_t* d_statuses, int32_t* d_iters, void* stream);
 
+/* Measurement hook (bench.py's roofline, tests): when d_counters != NULL every BFGS launch of this process — the ones
+ * nvmk_etkdg_embed issues included — adds to d_counters[8 * kind + k] (device memory, 64 uint64, caller zeroes it):
+ * k = 0 systems minimised, 1 BFGS iterations, 2 inverse-Hessian bytes those iterations stand for (read + write of the
+ * packed triangle, 8 n (n + 2) per iteration: SURVEY.md 8(d)'s algorithmic bytes), 3 energy evaluations, 4 the part of
+ * (2) whose rows were not resident in LDS, i.e. the bytes actually requested from HBM.  kind as nvmk_ff_batch.kind
+ * (constraint variants of MMFF / UFF count as 5 / 6).  NULL switches the counters off (default).  The reference has no
+ * counterpart; its benchmarks time whole calls (benchmarks/bench_utils/timing.py:53-91). */
+int nvmk_bfgs_set_stats(uint64_t* d_counters);
+
 /* ---- E1: ETKDG attempt scheduler -------------------------------------------------------------------------
  * Replaces nvMolKit::detail::Scheduler (src/etkdg_impl.h:223-280, src/etkdg_impl.cpp:272-326): round-robin dispatch
  * of molecule ids, at most confs_per_mol * max_iterations attempts per molecule, oversubscription once every
@@ -309,6 +318,22 @@ typedef struct nvmk_etkdg_params {
 
 int nvmk_etkdg_embed(const nvmk_etkdg_molset* mols, const nvmk_etkdg_params* params, double* d_coords,
                      int32_t* h_conf_counts, int32_t* h_stage_failures, void* stream);
+
+/* Units of the pipeline above exposed on their own so that E2 / E3 can be tested the way the reference tests them.
+ *
+ * nvmk_etkdg_random_coords: stage 0 (reference: ETKDGCoordGenStage, src/etkdg_stage_coordgen.cu:83-127): every active
+ * system s gets 4 * n_atoms uniform coordinates in [-box_size / 2, box_size / 2), drawn from the counter-based generator
+ * keyed by (seed, attempt_base + s, coordinate index) — the reference draws them from RDKit's RNG on the host.
+ *
+ * nvmk_etkdg_driver_run: the driver's bookkeeping (reference: ETKDGDriver::run / iterate, src/etkdg_impl.cpp:111-149,
+ * kernels src/etkdg_kernels.cu:20-70) with programmed stages: h_failed[(stage * max_iterations + iteration) * n_systems
+ * + s] != 0 fails system s there.  Outputs (host): h_fail_counts[stage * n_systems + s], h_finished_on[s] (-1 = never),
+ * the number of finished systems and the iterations run.  Errors like the reference's constructor: no systems, no
+ * stages. */
+int nvmk_etkdg_random_coords(uint64_t seed, uint64_t attempt_base, int n_systems, const int32_t* d_atom_starts,
+                             const uint8_t* d_active, double box_size, double* d_pos, void* stream);
+int nvmk_etkdg_driver_run(int n_systems, int n_stages, int max_iterations, const uint8_t* h_failed, int16_t* h_fail_counts,
+                          int16_t* h_finished_on, int32_t* h_n_finished, int32_t* h_iterations, void* stream);
 
 /* One stereochemistry check stage on given coordinates: d_failed[s] is set to 1 for every active system s on which a
  * term of `kind` fails (never cleared).  Replaces the execute() of the reference's check stages

@@ -57,11 +57,15 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_ff_gradient": (_int, [_vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "nvmk_bfgs_minimize": (_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _int, ctypes.c_double, _int, _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
+    "nvmk_bfgs_set_stats": (_int, [_vp]),
     "nvmk_scheduler_create": (_vp, [_int, _int, _int]),
     "nvmk_scheduler_destroy": (None, [_vp]),
     "nvmk_scheduler_dispatch": (_int, [_vp, _int, _vp, ctypes.POINTER(_int)]),
     "nvmk_scheduler_record": (_int, [_vp, _vp, _vp, _int]),
     "nvmk_etkdg_embed": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "nvmk_etkdg_random_coords": (_int, [ctypes.c_uint64, ctypes.c_uint64, _int, _vp, _vp, ctypes.c_double, _vp, _vp]),
+    "nvmk_etkdg_driver_run": (_int, [_int, _int, _int, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32),
+                                     ctypes.POINTER(ctypes.c_int32), _vp]),
     "nvmk_etkdg_stereo_check": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nvmk_conformer_rmsd_batch": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
     "nvmk_conformer_prune": (_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),

@@ -351,6 +351,75 @@ int nvmk_etkdg_stereo_check(int kind, int n_systems, const int32_t* d_atom_start
   return NVMK_OK;
 }
 
+// Start coordinates of stage 0 as a unit of its own (E3): system s of the batch is attempt attempt_base + s.
+int nvmk_etkdg_random_coords(uint64_t seed, uint64_t attempt_base, int n_systems, const int32_t* d_atom_starts,
+                             const uint8_t* d_active, double box_size, double* d_pos, void* stream_) {
+  NVMK_REQUIRE(n_systems >= 0, "random coords: negative system count");
+  if (n_systems == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_atom_starts && d_pos, "random coords: NULL buffer");
+  hipStream_t    stream = as_stream(stream_);
+  StreamScratch  allActive;
+  const uint8_t* active = d_active;
+  if (active == nullptr) {
+    NVMK_HIP_CHECK(allActive.alloc(static_cast<size_t>(n_systems), stream));
+    NVMK_HIP_CHECK(hipMemsetAsync(allActive.ptr, 1, static_cast<size_t>(n_systems), stream));
+    active = allActive.as<uint8_t>();
+  }
+  hipLaunchKernelGGL(random_coords_kernel, dim3(n_systems), dim3(64), 0, stream, n_systems, d_atom_starts, active, seed, attempt_base,
+                     box_size, d_pos);
+  NVMK_LAUNCH_CHECK();
+  return NVMK_OK;
+}
+
+// The driver's bookkeeping (run filter -> per-stage failure collection -> finished marking) with PROGRAMMED stages: stage
+// k of iteration i fails exactly the systems flagged in h_failed[(k * max_iterations + i) * n_systems + s].  The same three
+// kernels nvmk_etkdg_embed runs between its real stages; this is how the reference's ProgrammableStep matrices
+// (tests/test_etkdg.cu:41-341) are reproduced.
+int nvmk_etkdg_driver_run(int n_systems, int n_stages, int max_iterations, const uint8_t* h_failed, int16_t* h_fail_counts,
+                          int16_t* h_finished_on, int32_t* h_n_finished, int32_t* h_iterations, void* stream_) {
+  NVMK_REQUIRE(n_systems > 0, "driver: no conformers");    // ETKDGDriver throws on an empty context (test NoConformers)
+  NVMK_REQUIRE(n_stages > 0, "driver: no stages");         // ... and on an empty stage list (test NoStages)
+  NVMK_REQUIRE(max_iterations >= 0 && h_failed && h_fail_counts && h_finished_on && h_n_finished && h_iterations,
+               "driver: NULL argument");
+  hipStream_t      stream = as_stream(stream_);
+  const size_t     n      = static_cast<size_t>(n_systems);
+  DevBuf<uint8_t>  dActive, dFailed;
+  DevBuf<int16_t>  dFinished, dFailSum;
+  DevBuf<int>      dCount;
+  NVMK_HIP_CHECK(dActive.ensure(n));
+  NVMK_HIP_CHECK(dFailed.ensure(n));
+  NVMK_HIP_CHECK(dFinished.ensure(n));
+  NVMK_HIP_CHECK(dFailSum.ensure(n * static_cast<size_t>(n_stages)));
+  NVMK_HIP_CHECK(dCount.ensure(1));
+  NVMK_HIP_CHECK(hipMemsetAsync(dFinished.p, 0xff, n * 2, stream));
+  NVMK_HIP_CHECK(hipMemsetAsync(dFailSum.p, 0, n * static_cast<size_t>(n_stages) * 2, stream));
+  int finished = 0, iteration = 0;
+  while (finished < n_systems && iteration < max_iterations) {  // ETKDGDriver::run (src/etkdg_impl.cpp:144-149)
+    hipLaunchKernelGGL(set_run_filter_kernel, dim3(blocks(n_systems)), dim3(256), 0, stream, n_systems, dActive.p, dFinished.p);
+    for (int k = 0; k < n_stages; ++k) {
+      const uint8_t* prog = h_failed + (static_cast<size_t>(k) * max_iterations + iteration) * n;
+      NVMK_HIP_CHECK(hipMemcpyAsync(dFailed.p, prog, n, hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(collect_failures_kernel, dim3(blocks(n_systems)), dim3(256), 0, stream, n_systems, dFailed.p, dActive.p,
+                         dFailSum.p + static_cast<size_t>(k) * n);
+    }
+    NVMK_HIP_CHECK(hipMemsetAsync(dCount.p, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(mark_finished_kernel, dim3(blocks(n_systems)), dim3(256), 0, stream, n_systems, iteration, dActive.p, dFinished.p,
+                       dCount.p);
+    NVMK_LAUNCH_CHECK();
+    int now = 0;
+    NVMK_HIP_CHECK(hipMemcpyAsync(&now, dCount.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    finished += now;
+    ++iteration;
+  }
+  NVMK_HIP_CHECK(hipMemcpyAsync(h_fail_counts, dFailSum.p, n * static_cast<size_t>(n_stages) * 2, hipMemcpyDeviceToHost, stream));
+  NVMK_HIP_CHECK(hipMemcpyAsync(h_finished_on, dFinished.p, n * 2, hipMemcpyDeviceToHost, stream));
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+  *h_n_finished = finished;
+  *h_iterations = iteration;
+  return NVMK_OK;
+}
+
 int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, double* d_coords, int32_t* h_conf_counts,
                      int32_t* h_stage_failures, void* stream_) {
   NVMK_REQUIRE(ms && prm && h_conf_counts, "etkdg: NULL argument");

@@ -17,8 +17,10 @@
 #include <algorithm>
 #include <vector>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "ff_terms.h"
@@ -646,31 +648,50 @@ __host__ __device__ __forceinline__ int64_t hess_row_offset(const int64_t r) {  
   return (r & 1) ? (r + 1) * (r + 1) / 2 : r * (r + 2) / 2;
 }
 
+// Rows [0, Rl) of the packed triangle may live in LDS, the rest in HBM (see bfgs_kernel): the pass is written over a row
+// range and a base pointer, and called once per residence.  Rl is either n (everything resident) or a multiple of the
+// row block HTY * HU, so a block never straddles the two.
+__host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t hldsDoubles, const int block) {
+  if (hess_row_offset(n) <= hldsDoubles) return n;
+  int r = 0;
+  while (r + block <= n && hess_row_offset(r + block) <= hldsDoubles) r += block;
+  return r;
+}
+__host__ __device__ constexpr int hess_rows_per_lane(const int kind) { return kind == NVMK_FF_DG ? 6 : 4; }
+// LDS layout of bfgs_kernel: 11 vectors + (1 + HTY) partial-sum slabs of n doubles, 8 doubles of reduction scratch, then
+// the resident rows of the inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
+__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (12 + HTY) * n + 8; }
+__host__ __device__ constexpr int64_t lds_hessian_doubles(const int64_t ldsDoubles, const int64_t n) {
+  return ldsDoubles > lds_vector_doubles(n) ? ldsDoubles - lds_vector_doubles(n) : 0;
+}
+
 // `part` is (1 + HTY) n doubles of LDS scratch: row sums, then one slab of mirrored-entry sums per row group; it must be
-// zero on entry (and visible to the workgroup).  On exit (after a barrier) t = H g.  No atomics: every partial sum
-// has a single writer and the final sum runs in a fixed order, so the minimiser is reproducible run to run.
+// zero on entry (and visible to the workgroup).  No atomics: every partial sum has a single writer and the final sum
+// (hess_finish) runs in a fixed order, so the minimiser is reproducible run to run.
+// H points at row rBegin's first element; rows [rBegin, rEnd) are processed.
 template <int HU>
-__device__ __forceinline__ void hess_pass(double* __restrict__ H, const int n, const bool pending, const double rfac,
-                                          const double fad, const double fae, const double* xi, const double* hdg,
-                                          const double* uu, const double* g, double* t, double* part) {
-  const int tx = threadIdx.x & (HTX - 1), ty = threadIdx.x / HTX;
-  for (int r0 = 0; r0 < n; r0 += HTY * HU) {
+__device__ __forceinline__ void hess_rows(double* __restrict__ H, const int rBegin, const int rEnd, const int n, const bool pending,
+                                          const double rfac, const double fad, const double fae, const double* xi, const double* hdg,
+                                          const double* uu, const double* g, double* part) {
+  const int     tx = threadIdx.x & (HTX - 1), ty = threadIdx.x / HTX;
+  const int64_t base = hess_row_offset(rBegin);
+  for (int r0 = rBegin; r0 < rEnd; r0 += HTY * HU) {
     double  racc[HU], ar[HU], br[HU], dr[HU], gr[HU];
     int     row[HU];
     int64_t off[HU];
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
       const int r  = r0 + ty + HTY * u;
-      row[u]       = r < n ? r : -1;
-      const int rc = r < n ? r : 0;
-      off[u]       = hess_row_offset(rc);
+      row[u]       = r < rEnd ? r : -1;
+      const int rc = r < rEnd ? r : rBegin;
+      off[u]       = hess_row_offset(rc) - base;
       racc[u]      = 0.0;
       gr[u]        = g[rc];
       ar[u]        = pending ? rfac * xi[rc] : 0.0;
       br[u]        = pending ? fad * hdg[rc] : 0.0;
       dr[u]        = pending ? fae * uu[rc] : 0.0;
     }
-    const int rmax = min(n - 1, r0 + ty + HTY * (HU - 1));
+    const int rmax = min(rEnd - 1, r0 + ty + HTY * (HU - 1));
     // Columns go in blocks of HCS steps: every 16-byte load of the block is issued before the first use, so a lane has
     // up to HU * HCS loads in flight.  (Load, update, store, next load — the first version — waited for the previous
     // step's STORE before every load could be consumed, because vmcnt retires loads and stores in order: 41 us per
@@ -731,6 +752,10 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ H, const int n, c
       if (tx == 0 && row[u] >= 0) part[row[u]] = v;  // row sums: one writer per row
     }
   }
+}
+
+// t = H g from the partial sums of hess_rows (fixed summation order).
+__device__ __forceinline__ void hess_finish(const int n, const double* part, double* t) {
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += NT) {
     double v = part[i];
@@ -750,7 +775,8 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
                                                   const int32_t* __restrict__ order,
                                                   double* __restrict__ hessians, double* __restrict__ energies,
                                                   int16_t* __restrict__ statuses, int32_t* __restrict__ itersOut,
-                                                  int64_t* __restrict__ prof) {
+                                                  int64_t* __restrict__ prof, const int ldsDoubles,
+                                                  unsigned long long* __restrict__ stats) {
   int64_t tk[7] = {0, 0, 0, 0, 0, 0, 0};
   auto    now   = [&]() -> int64_t { return PROFILE ? static_cast<int64_t>(wall_clock64()) : 0; };
   const int64_t tStart = now();
@@ -778,8 +804,13 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   double* pxi   = tvec + n;   // pending rank-2 update: xi, H dGrad, u
   double* phdg  = pxi + n;
   double* pu    = phdg + n;
-  double* part  = pu + n;     // (1 + HTY) n partial sums of the pass
-  double* red   = part + (1 + HTY) * n;  // NT/64 + 1
+  double* part  = pu + n;     // (1 + HTY) n partial sums of the pass; its first NT/64 slabs double as the per-wave gradients
+  double* red   = part + (1 + HTY) * n;  // NT/64 + 1 (padded to 8)
+  // Inverse Hessian: the first Rl rows of the packed triangle live in LDS behind the vectors (as many as the launch's LDS
+  // budget holds: all of them for small systems), rows Rl.. stream from HBM as before.
+  constexpr int HU = hess_rows_per_lane(KIND);
+  double*       Hl = red + 8;
+  const int     Rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n), HTY * HU);
 
   if (n == 0) {
     if (tid == 0) {
@@ -792,11 +823,19 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
 
   for (int i = tid; i < n; i += NT) pos[i] = gpos[i];
   {
-    const int64_t total = hess_row_offset(n);
-    double2*      H2    = reinterpret_cast<double2*>(H);
-    for (int64_t i = tid; i < total / 2; i += NT) H2[i] = make_double2(0.0, 0.0);
+    const int64_t nl = hess_row_offset(Rl), total = hess_row_offset(n);
+    double2*      L2 = reinterpret_cast<double2*>(Hl);
+    for (int64_t i = tid; i < nl / 2; i += NT) L2[i] = make_double2(0.0, 0.0);
+    double2* H2 = reinterpret_cast<double2*>(H);
+    for (int64_t i = tid; i < (total - nl) / 2; i += NT) H2[i] = make_double2(0.0, 0.0);
     __syncthreads();
-    for (int r = tid; r < n; r += NT) H[hess_row_offset(r) + r] = 1.0;  // H = identity
+    for (int r = tid; r < n; r += NT) {  // H = identity
+      if (r < Rl) {
+        Hl[hess_row_offset(r) + r] = 1.0;
+      } else {
+        H[hess_row_offset(r) - nl + r] = 1.0;
+      }
+    }
   }
 
   // The term-range offsets of this system (two per group, constant for the whole minimisation) are cached in LDS and the
@@ -824,17 +863,26 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
     return block_reduce<Op::kSum>(system_eval<KIND, false>(lb, lsys, p, nullptr, w0, w1, a0 * DIM), red);
   };
   double gradScale = 1.0;
+  // Gradient contributions are accumulated per WAVE (LDS atomics into the wave's own slab: within a wave the order of
+  // the additions is the program's, so it does not depend on how the waves happen to be scheduled) and the slabs are
+  // summed in a fixed order: a minimisation — and with it a seeded ETKDG run — is reproducible bit for bit.
+  constexpr int NW = NT / 64;
+  static_assert(NW <= 1 + HTY, "per-wave gradient slabs alias the pass's partial sums");
   auto   grad_at   = [&](const double* p) {
-    for (int i = tid; i < n; i += NT) grad[i] = 0.0;
+    for (int i = tid; i < NW * n; i += NT) part[i] = 0.0;
     __syncthreads();
-    system_eval<KIND, true>(lb, lsys, p, grad, w0, w1, a0 * DIM);
+    system_eval<KIND, true>(lb, lsys, p, part + (tid >> 6) * n, w0, w1, a0 * DIM);
     __syncthreads();
     // gradient scaling (bfgs_minimize_permol_kernels.cu:239-275; |g| rule of RDKit >= 2025.09)
     gradScale = scaleGrads ? 0.1 : 1.0;
     double mx = 0.0;
     for (int i = tid; i < n; i += NT) {
-      if (scaleGrads) grad[i] *= gradScale;
-      mx = fmax(mx, fabs(grad[i]));
+      double gi = part[i];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) gi += part[w * n + i];
+      if (scaleGrads) gi *= gradScale;
+      grad[i] = gi;
+      mx      = fmax(mx, fabs(gi));
     }
     mx = block_reduce<Op::kMax>(mx, red);
     if (scaleGrads && mx > 10.0) {
@@ -859,6 +907,7 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
 
   bool converged = false;
   int  iter      = 0;
+  int  nEvals    = 1;
   while (!converged && iter < maxIters) {
     for (int i = tid; i < n; i += NT) oldp[i] = pos[i];
     // ---- line search set-up (:54-136)
@@ -887,6 +936,7 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
       newE             = energy_at(trial);
       tk[0] += now() - tE;
       tk[6] += 1;
+      ++nEvals;
       const double eDiff = newE - prevE;
       if (lambda < lambdaMin || eDiff <= FUNCTOL * lambda * slope) break;
       double tmp;
@@ -948,7 +998,9 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
     const int64_t tH = now();
     for (int i = tid; i < (1 + HTY) * n; i += NT) part[i] = 0.0;
     __syncthreads();
-    hess_pass<(KIND == NVMK_FF_DG ? 6 : 4)>(H, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, tvec, part);  // H is now H_k; tvec = H_k g_new
+    if (Rl > 0) hess_rows<HU>(Hl, 0, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
+    if (Rl < n) hess_rows<HU>(H, Rl, n, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
+    hess_finish(n, part, tvec);  // H is now H_k; tvec = H_k g_new
     __syncthreads();
     tk[2] += now() - tH;
     const int64_t tU = now();
@@ -999,6 +1051,14 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
     energies[sys] = prevE;
     if (statuses) statuses[sys] = converged ? 0 : 1;
     if (itersOut) itersOut[sys] = iter;
+    if (stats) {  // nvmk_bfgs_set_stats: systems, BFGS iterations, inverse-Hessian bytes the iterations stand for, energy evaluations
+      unsigned long long* st = stats + 8 * (KIND < 8 ? KIND : 7);
+      atomicAdd(st + 0, 1ull);
+      atomicAdd(st + 1, static_cast<unsigned long long>(iter));
+      atomicAdd(st + 2, static_cast<unsigned long long>(iter) * 8ull * static_cast<unsigned long long>(hess_row_offset(n)) * 2ull);
+      atomicAdd(st + 3, static_cast<unsigned long long>(nEvals));
+      atomicAdd(st + 4, static_cast<unsigned long long>(iter) * 16ull * static_cast<unsigned long long>(hess_row_offset(n) - hess_row_offset(Rl)));
+    }
     if constexpr (PROFILE) {
       tk[4] = now() - tStart;
       tk[5] = iter;
@@ -1056,7 +1116,17 @@ int to_batch(const nvmk_ff_batch* in, Batch& out) {
 using namespace nvmk;
 using namespace nvmk::minim;
 
+namespace {
+// device counters the BFGS kernels add to when set (nvmk_bfgs_set_stats); process-wide, off by default
+std::atomic<unsigned long long*> g_stats{nullptr};
+}  // namespace
+
 extern "C" {
+
+int nvmk_bfgs_set_stats(uint64_t* d_counters) {
+  g_stats.store(reinterpret_cast<unsigned long long*>(d_counters));
+  return NVMK_OK;
+}
 
 int nvmk_ff_energy(const nvmk_ff_batch* batch, double w0, double w1, const double* d_pos, const uint8_t* d_active,
                    double* d_energies, void* stream) {
@@ -1095,17 +1165,38 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   NVMK_REQUIRE(max_iters >= 0, "bfgs: negative iteration count");
   hipStream_t stream = as_stream(stream_);
   const int   dim    = (b.kind == NVMK_FF_DG || b.kind == NVMK_FF_QUARTIC) ? 4 : 3;
-  // inverse-Hessian offsets (packed lower triangle per system) and the LDS need of the largest system
-  std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
-  int                  maxN = 0;
+  // LDS need of the largest system, then the launch's LDS budget.  NVMK_BFGS_LDS: "auto" (default) = what lets two
+  // workgroups share a CU; "full" = the whole 160 KiB (one workgroup per CU); "0" = vectors only (inverse Hessians
+  // entirely in HBM, the round-1 layout); a number = KiB per workgroup.
+  int maxN = 0;
   for (int s = 0; s < b.nSystems; ++s) {
     const int64_t n = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
     NVMK_REQUIRE(n >= 0, "bfgs: atom_starts must be non-decreasing");
-    hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + hess_row_offset(n);  // packed lower triangle
-    maxN                           = std::max<int>(maxN, static_cast<int>(n));
+    maxN = std::max<int>(maxN, static_cast<int>(n));
   }
-  const size_t shmem = ((12 + HTY) * static_cast<size_t>(maxN) + NT / 64 + 1) * sizeof(double);
-  NVMK_REQUIRE(shmem <= 160 * 1024, "bfgs: a system with %d coordinates needs %zu bytes of LDS (max 160 KiB)", maxN, shmem);
+  const size_t vecBytes = static_cast<size_t>(lds_vector_doubles(maxN)) * sizeof(double);
+  constexpr size_t kLdsPerCu = 160 * 1024, kLdsReserve = 1024;  // static LDS of the kernel + allocation granularity
+  NVMK_REQUIRE(vecBytes <= kLdsPerCu - kLdsReserve, "bfgs: a system with %d coordinates needs %zu bytes of LDS (max 160 KiB)", maxN,
+               vecBytes);
+  size_t budget = kLdsPerCu / 2 - kLdsReserve;
+  if (const char* e = std::getenv("NVMK_BFGS_LDS")) {
+    if (std::strcmp(e, "full") == 0) {
+      budget = kLdsPerCu - kLdsReserve;
+    } else if (std::strcmp(e, "auto") != 0) {
+      budget = static_cast<size_t>(std::max(0L, std::atol(e))) * 1024;
+    }
+  }
+  budget = std::min(std::max(budget, vecBytes), kLdsPerCu - kLdsReserve);
+  const size_t shmem = std::min(budget, vecBytes + static_cast<size_t>(hess_row_offset(maxN)) * sizeof(double));
+  const int    ldsDoubles = static_cast<int>(shmem / sizeof(double));
+  // offsets of the HBM part of every inverse Hessian (rows Rl.. of the packed lower triangle)
+  const int            block = HTY * hess_rows_per_lane(b.kind);
+  std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
+  for (int s = 0; s < b.nSystems; ++s) {
+    const int n  = (h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
+    const int rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n), block);
+    hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + hess_row_offset(n) - hess_row_offset(rl);
+  }
   StreamScratch hessMem, startsMem, orderMem;
   NVMK_HIP_CHECK(hessMem.alloc(static_cast<size_t>(hs.back()) * sizeof(double), stream));
   NVMK_HIP_CHECK(startsMem.alloc(hs.size() * sizeof(int64_t), stream));
@@ -1127,18 +1218,24 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
     const size_t  words = static_cast<size_t>(b.nSystems) * 8;
     NVMK_HIP_CHECK(profMem.alloc(words * sizeof(int64_t), stream));
     NVMK_HIP_CHECK(hipMemsetAsync(profMem.ptr, 0, words * sizeof(int64_t), stream));
+    if (shmem > 64 * 1024) {
+      const void* fn = b.kind == NVMK_FF_DG ? reinterpret_cast<const void*>(bfgs_kernel<NVMK_FF_DG, true>)
+                       : b.kind == NVMK_FF_ETK ? reinterpret_cast<const void*>(bfgs_kernel<NVMK_FF_ETK, true>)
+                                               : reinterpret_cast<const void*>(bfgs_kernel<NVMK_FF_MMFF, true>);
+      NVMK_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem)));
+    }
     if (b.kind == NVMK_FF_DG) {
       hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_DG, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters,
                          grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies, d_statuses,
-                         d_iters, profMem.as<int64_t>());
+                         d_iters, profMem.as<int64_t>(), ldsDoubles, g_stats.load());
     } else if (b.kind == NVMK_FF_ETK) {
       hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_ETK, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1,
                          max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies,
-                         d_statuses, d_iters, profMem.as<int64_t>());
+                         d_statuses, d_iters, profMem.as<int64_t>(), ldsDoubles, g_stats.load());
     } else {
       hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_MMFF, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1,
                          max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies,
-                         d_statuses, d_iters, profMem.as<int64_t>());
+                         d_statuses, d_iters, profMem.as<int64_t>(), ldsDoubles, g_stats.load());
     }
     NVMK_LAUNCH_CHECK();
     std::vector<int64_t> h(words);
@@ -1171,7 +1268,7 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
     }
     hipLaunchKernelGGL(kern, dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters, grad_tol, scale_grads,
                        d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies, d_statuses, d_iters,
-                       static_cast<int64_t*>(nullptr));
+                       static_cast<int64_t*>(nullptr), ldsDoubles, g_stats.load());
   });
   NVMK_LAUNCH_CHECK();
   NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // `hs` (pageable) must outlive its async copy; scratch is freed in stream order

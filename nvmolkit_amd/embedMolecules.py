@@ -262,3 +262,40 @@ def EmbedMolecules(molecules, params, confsPerMolecule: int = 1, maxIterations: 
                           "term tables, or build the RDKit adapter described in INTEGRATION.md") from exc
     raise NotImplementedError("the RDKit EmbedArgs -> flattened-term adapter is not built in this environment "
                               "(see INTEGRATION.md); embed_flat() is the supported entry point")
+
+
+def random_coords_flat(seed: int, attempt_base: int, atom_starts, box_size: float, active=None, device="cuda", stream=None):
+    """Stage 0 of the pipeline on its own: uniform 4-D start coordinates in [-box_size / 2, box_size / 2) for every active
+    system; system s is attempt ``attempt_base + s`` of the seeded run (reference: ETKDGCoordGenStage,
+    src/etkdg_stage_coordgen.cu:83-127).  Returns a float64 CUDA tensor (total_atoms, 4); inactive systems stay zero."""
+    dev = torch.device(device)
+    d_as = torch.as_tensor(np.ascontiguousarray(atom_starts, dtype=np.int32)).to(dev)
+    n_sys = int(d_as.numel()) - 1
+    pos = torch.zeros((int(np.asarray(atom_starts)[-1]), 4), dtype=torch.float64, device=dev)
+    d_act = None if active is None else torch.as_tensor(active).to(device=dev, dtype=torch.uint8).contiguous()
+    with torch.cuda.device(dev):
+        rc = _native.lib().nvmk_etkdg_random_coords(int(seed) & 0xFFFFFFFFFFFFFFFF, int(attempt_base), n_sys, d_as.data_ptr(),
+                                                    0 if d_act is None else d_act.data_ptr(), float(box_size), pos.data_ptr(),
+                                                    _native.stream_ptr(stream))
+    _native.check(rc, "nvmk_etkdg_random_coords")
+    return pos
+
+
+def driver_run_programmed(failed, max_iterations: int, stream=None):
+    """The ETKDG driver's bookkeeping with programmed stages (reference: ETKDGDriver with ProgrammableStep stages,
+    tests/test_etkdg.cu:41-341).  ``failed[stage][iteration][system]`` (0 / 1); returns ``(fail_counts (n_stages,
+    n_systems), finished_on (n_systems,), n_finished, iterations_complete)``."""
+    f = np.ascontiguousarray(failed, dtype=np.uint8)
+    if f.ndim != 3:
+        raise ValueError("failed must be (n_stages, n_iterations, n_systems)")
+    n_stages, n_it, n_sys = f.shape
+    if n_it < max_iterations:
+        f = np.concatenate([f, np.zeros((n_stages, max_iterations - n_it, n_sys), dtype=np.uint8)], axis=1)
+    f = np.ascontiguousarray(f[:, :max_iterations])
+    counts = np.zeros((max(n_stages, 1), max(n_sys, 1)), dtype=np.int16)
+    fin = np.full(max(n_sys, 1), -1, dtype=np.int16)
+    nf, it = ctypes.c_int32(0), ctypes.c_int32(0)
+    rc = _native.lib().nvmk_etkdg_driver_run(n_sys, n_stages, int(max_iterations), f.ctypes.data, counts.ctypes.data, fin.ctypes.data,
+                                             ctypes.byref(nf), ctypes.byref(it), _native.stream_ptr(stream))
+    _native.check(rc, "nvmk_etkdg_driver_run")
+    return counts[:n_stages, :n_sys], fin[:n_sys], nf.value, it.value

@@ -173,3 +173,390 @@ def synthetic_embed_molecule(rng, n_atoms: int, with_etk: bool = True):
                (chain3, np.stack([ang - 5.0, ang + 5.0], 1) if len(ang) else np.zeros((0, 2))), fb(sep >= 3, 10.0)]
     checks = [(5, (i, i + 1, i + 2), ()) for i in range(n - 2)]  # NVMK_CHECK_DOUBLE_BOND_GEOMETRY: never linear here
     return dict(n_atoms=n, dg=dg, etk=etk, checks=checks, num_impropers=0), ref, (pairs, lb, ub)
+
+
+# ---- drug-like synthetic molecules: graph + consistent 3-D geometry + every table derived from it -------------------
+#
+# The benchmark workload of BASELINE.json configs[2] / [3] is "10k drug-like SMILES": RDKit would perceive the chemistry
+# and derive the ETKDG bounds / MMFF94 tables.  Without RDKit the tables come from a generated molecule instead: a
+# skeleton of rings and chains with hydrogens on the free valences is grown atom by atom with ideal bond lengths and
+# angles (so a clash-free 3-D geometry EXISTS), and the distance bounds (1-2, 1-3, 1-4 cis/trans windows, van der Waals
+# floors, triangle smoothing), chiral sets, experimental-torsion / improper / restraint terms, stereo checks and the
+# MMFF94-shaped tables (rest lengths and angles = the geometry's, force constants from the ranges of the real tables) are
+# all derived from that one geometry.  Minima therefore exist and the minimisers converge the way they do on real input,
+# instead of running to their iteration caps on contradictory random tables.
+
+_BOND_HEAVY, _BOND_RING, _BOND_H = 1.50, 1.39, 1.09
+
+
+def _perp(rng, u):
+    v = rng.normal(size=3)
+    v -= v.dot(u) * u
+    n = np.linalg.norm(v)
+    return v / n if n > 1e-8 else _perp(rng, u)
+
+
+def _unit(v):
+    return v / np.linalg.norm(v)
+
+
+class _Grower:
+    def __init__(self, rng, n_atoms):
+        self.rng = rng
+        self.n_max = n_atoms
+        self.pos = np.zeros((n_atoms, 3))
+        self.n = 0
+        self.heavy = np.zeros(n_atoms, dtype=bool)
+        self.cap = np.zeros(n_atoms, dtype=np.int64)      # valence cap: 4 sp3, 3 sp2 / ring, 2, 1
+        self.ring = np.full(n_atoms, -1, dtype=np.int64)  # ring id or -1
+        self.nbr = [[] for _ in range(n_atoms)]
+        self.bonds = []
+        self.n_rings = 0
+
+    def clash(self, p, exclude, lim):
+        if self.n == 0:
+            return False
+        d = np.linalg.norm(self.pos[:self.n] - p, axis=1)
+        d[exclude] = 10.0
+        return bool(d.min() < lim)
+
+    def add(self, p, heavy, cap, ring=-1):
+        i = self.n
+        self.pos[i], self.heavy[i], self.cap[i], self.ring[i] = p, heavy, cap, ring
+        self.n += 1
+        return i
+
+    def bond(self, a, b):
+        self.nbr[a].append(b)
+        self.nbr[b].append(a)
+        self.bonds.append((min(a, b), max(a, b)))
+
+    def direction(self, a):
+        """Ideal direction of the next substituent of atom a (None = saturated geometry)."""
+        rng, us = self.rng, [_unit(self.pos[b] - self.pos[a]) for b in self.nbr[a]]
+        cap = self.cap[a]
+        if not us:
+            return _unit(rng.normal(size=3))
+        if len(us) == 1:
+            theta = np.deg2rad({4: 109.5, 3: 120.0, 2: 106.0}.get(int(cap), 109.5))
+            return np.cos(theta) * us[0] + np.sin(theta) * _perp(rng, us[0])
+        if len(us) == 2:
+            if np.linalg.norm(us[0] + us[1]) < 1e-6:  # collinear neighbours: any perpendicular direction
+                return _perp(rng, us[0])
+            mid = -_unit(us[0] + us[1])
+            if cap == 3:
+                return mid
+            side = _unit(np.cross(us[0], us[1])) * (1.0 if rng.random() < 0.5 else -1.0)
+            return _unit(np.cos(np.deg2rad(54.75)) * mid + np.sin(np.deg2rad(54.75)) * side)
+        tot = us[0] + us[1] + us[2]
+        if np.linalg.norm(tot) < 0.2:  # planar centre whose cap was raised: go out of the plane
+            return _unit(np.cross(us[0], us[1])) * (1.0 if rng.random() < 0.5 else -1.0)
+        return -_unit(tot)
+
+    def free(self, a):
+        return self.cap[a] - len(self.nbr[a])
+
+
+def _grow_heavy(g, rng, n_heavy, n_atoms):
+    """Add rings / chain atoms until the skeleton has n_heavy heavy atoms (or no room is left)."""
+    stall = 0
+    fails: dict = {}
+
+    def blocked(a):  # a valence that keeps clashing is closed, so that growth moves elsewhere
+        fails[a] = fails.get(a, 0) + 1
+        if fails[a] >= (2 if len(g.nbr[a]) >= 2 else 6):  # with two or more neighbours the direction has <= 2 choices
+            g.cap[a] = len(g.nbr[a])
+
+    while int(g.heavy[:g.n].sum()) < n_heavy and stall < 400 and g.n < n_atoms:
+        open_atoms = [a for a in range(g.n) if g.heavy[a] and g.free(a) > 0]
+        if not open_atoms:
+            # every valence is used: open one more on a terminal / divalent atom so the chain can go on
+            low = [a for a in range(g.n) if g.heavy[a] and g.cap[a] < 4 and g.ring[a] < 0]
+            if not low:
+                return
+            g.cap[low[int(rng.integers(0, len(low)))]] += 1
+            continue
+        a = open_atoms[-1 - int(rng.integers(0, min(4, len(open_atoms))))]  # recent atoms first: chain-like growth
+        d = g.direction(a)
+        left = n_heavy - int(g.heavy[:g.n].sum())
+        size = 6 if rng.random() < 0.8 else 5
+        if left >= size and rng.random() < 0.3 and g.n + size <= n_atoms:
+            rad = _BOND_RING / (2.0 * np.sin(np.pi / size))
+            p0 = g.pos[a] + _BOND_HEAVY * d
+            centre = p0 + rad * d
+            w = _perp(rng, d)
+            pts = [centre + rad * (np.cos(2 * np.pi * k / size) * (-d) + np.sin(2 * np.pi * k / size) * w) for k in range(size)]
+            if any(g.clash(p, [a], 2.1) for p in pts):
+                stall += 1
+                blocked(a)
+                continue
+            ids = [g.add(p, True, 3, g.n_rings) for p in pts]
+            g.n_rings += 1
+            g.bond(a, ids[0])
+            for k in range(size):
+                g.bond(ids[k], ids[(k + 1) % size])
+        else:
+            p = g.pos[a] + _BOND_HEAVY * d
+            if g.clash(p, [a], 2.1):
+                stall += 1
+                blocked(a)
+                continue
+            cap = int(rng.choice([4, 3, 2, 1], p=[0.5, 0.25, 0.15, 0.10]))
+            g.bond(a, g.add(p, True, cap))
+
+
+def _grow_hydrogens(g, n_atoms):
+    """Hydrogens on the free valences, round-robin, until the atom budget is used or nothing fits."""
+    progress = True
+    while g.n < n_atoms and progress:
+        progress = False
+        for a in range(g.n):
+            if g.n >= n_atoms:
+                break
+            if not g.heavy[a] or g.free(a) <= 0:
+                continue
+            placed = False
+            for _try in range(6):
+                p = g.pos[a] + _BOND_H * g.direction(a)
+                if not g.clash(p, [a], 1.55):
+                    g.bond(a, g.add(p, False, 1))
+                    progress = placed = True
+                    break
+            if not placed:
+                g.cap[a] = len(g.nbr[a])  # no room for a hydrogen here: close the valence
+
+
+def _grow_skeleton(rng, n_atoms):
+    """Heavy-atom skeleton (rings + chains), then hydrogens on the free valences: exactly n_atoms atoms."""
+    for _ in range(50):  # a growth that paints itself into a corner is restarted
+        g = _Grower(rng, n_atoms)
+        n_heavy = max(2, int(round(n_atoms * rng.uniform(0.42, 0.5)))) if n_atoms >= 4 else max(1, n_atoms // 2)
+        g.add(np.zeros(3), True, 4 if rng.random() < 0.6 else 3)
+        for _round in range(8):  # valences ran out before the budget: extend the skeleton and fill again
+            _grow_heavy(g, rng, n_heavy, n_atoms)
+            if _round == 0:
+                # enough free valences for the hydrogens still to come?  If not, lengthen the skeleton first (placing heavy
+                # atoms among hydrogens later is what clashes)
+                for _ext in range(4 * n_atoms):
+                    n_h = int(g.heavy[:g.n].sum())
+                    free = sum(int(g.free(a)) for a in range(g.n) if g.heavy[a])
+                    if free >= n_atoms - n_h or g.n >= n_atoms:
+                        break
+                    _grow_heavy(g, rng, n_h + 1, n_atoms)
+                    if int(g.heavy[:g.n].sum()) == n_h:
+                        break
+            _grow_hydrogens(g, n_atoms)
+            if g.n >= n_atoms:
+                return g
+            n_heavy = int(g.heavy[:g.n].sum()) + max(1, (n_atoms - g.n) // 3)
+    raise RuntimeError(f"could not grow a {n_atoms}-atom molecule")
+
+
+def _topological_distances(n, bonds):
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import shortest_path
+
+    b = np.asarray(bonds, dtype=np.int64).reshape(-1, 2)
+    adj = coo_matrix((np.ones(len(b)), (b[:, 0], b[:, 1])), shape=(n, n)).tocsr()
+    return shortest_path(adj, directed=False, unweighted=True).astype(np.int64)
+
+
+def _d14(r12, r23, r34, a123, a234, phi):
+    """1-4 distance for bond lengths, angles (rad) and dihedral phi."""
+    x1 = np.array([-r12 * np.cos(a123), r12 * np.sin(a123), 0.0]) * np.array([-1.0, 1.0, 1.0])  # atom 1, atom 2 at origin, 3 on +x
+    p1 = np.array([r12 * np.cos(a123), r12 * np.sin(a123), 0.0])
+    p4 = np.array([r23 - r34 * np.cos(a234), r34 * np.sin(a234) * np.cos(phi), r34 * np.sin(a234) * np.sin(phi)])
+    del x1
+    return float(np.linalg.norm(p1 - p4))
+
+
+def druglike_molecule(rng, n_atoms: int, with_etk: bool = True, with_mmff: bool = True):
+    """One synthetic drug-like molecule.  Returns a dict: ``embed`` (FlatMolecule fields), ``mmff`` (the 7 MMFF term groups),
+    ``ref`` (the hidden geometry, (n, 3)), ``bounds`` (pairs, lb, ub), ``bonds``, ``heavy``."""
+    g = _grow_skeleton(rng, n_atoms)
+    n, ref, nbr = n_atoms, g.pos.copy(), g.nbr
+    bonds = np.array(sorted(set(g.bonds)), dtype=np.int64).reshape(-1, 2)
+    topo = _topological_distances(n, bonds) if len(bonds) else np.zeros((n, n), dtype=np.int64)
+    iu = np.triu_indices(n, 1)
+    pairs = np.stack(iu, 1).astype(np.int64)
+    dist = np.linalg.norm(ref[:, None, :] - ref[None, :, :], axis=2)
+    same_ring = (g.ring[:, None] >= 0) & (g.ring[:, None] == g.ring[None, :])
+    angles = np.array([(i, j, k) for j in range(n) for x, i in enumerate(nbr[j]) for k in nbr[j][x + 1:]], dtype=np.int64).reshape(-1, 3)
+    torsions = np.array([(i, j, k, l) for j, k in bonds for i in nbr[j] if i != k for l in nbr[k] if l != j and l != i],
+                        dtype=np.int64).reshape(-1, 4)
+
+    def angle_of(t):
+        a, b = ref[t[:, 0]] - ref[t[:, 1]], ref[t[:, 2]] - ref[t[:, 1]]
+        return np.arccos(np.clip((a * b).sum(1) / np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1), -1, 1))
+
+    ang = angle_of(angles) if len(angles) else np.zeros(0)
+
+    # ---- distance bounds (the shape of RDKit's setTopolBounds + triangle smoothing) ------------------------------
+    lb = np.zeros((n, n))
+    ub = np.full((n, n), 1000.0)
+    np.fill_diagonal(ub, 0.0)
+    hv = g.heavy[:n]
+    floor = np.where(hv[:, None] & hv[None, :], 3.0, np.where(hv[:, None] | hv[None, :], 2.5, 2.0))
+    floor = np.where(topo == 4, floor * 0.8, floor)
+    lb[:] = np.minimum(floor, dist - 0.1)
+    for i, j in bonds:
+        lb[i, j] = lb[j, i] = dist[i, j] - 0.01
+        ub[i, j] = ub[j, i] = dist[i, j] + 0.01
+    for (i, j, k) in angles:
+        lb[i, k] = lb[k, i] = dist[i, k] - 0.04
+        ub[i, k] = ub[k, i] = dist[i, k] + 0.04
+    amap = {(int(i), int(j), int(k)): a for (i, j, k), a in zip(angles, ang)}
+    amap.update({(k, j, i): a for (i, j, k), a in list(amap.items())})
+    for (i, j, k, l) in torsions:
+        if topo[i, l] != 3:
+            continue
+        if same_ring[j, k] or same_ring[i, l]:
+            lo, hi = dist[i, l] - 0.06, dist[i, l] + 0.06
+        else:
+            a1, a2 = amap[(int(i), int(j), int(k))], amap[(int(j), int(k), int(l))]
+            lo = _d14(dist[i, j], dist[j, k], dist[k, l], a1, a2, 0.0) - 0.06
+            hi = _d14(dist[i, j], dist[j, k], dist[k, l], a1, a2, np.pi) + 0.06
+        lb[i, l] = lb[l, i] = max(min(lo, dist[i, l] - 0.02), 0.5)
+        ub[i, l] = ub[l, i] = max(hi, dist[i, l] + 0.02)
+    rr = same_ring & (topo >= 3)
+    lb[rr] = np.maximum(dist[rr] - 0.06, 0.5)
+    ub[rr] = dist[rr] + 0.06
+    for k in range(n):  # triangle smoothing: upper bounds (shortest paths), then lower bounds
+        ub = np.minimum(ub, ub[:, k, None] + ub[None, k, :])
+    for k in range(n):
+        lb = np.maximum(lb, np.maximum(lb[:, k, None] - ub[None, k, :], lb[None, k, :] - ub[:, k, None]))
+    lbp, ubp = lb[iu], ub[iu]
+    tp = topo[iu]
+
+    # ---- chiral centres and stereo checks --------------------------------------------------------------------------
+    checks, chiral_idx, chiral_par = [], [], []
+    for a in range(n):
+        if hv[a] and len(nbr[a]) == 4:
+            nb = nbr[a]
+            checks.append((0, (a, nb[0], nb[1], nb[2], nb[3]), (0.0,)))                    # tetrahedral centre
+            p4 = ref[nb[3]]
+            vol = float(np.dot(ref[nb[0]] - p4, np.cross(ref[nb[1]] - p4, ref[nb[2]] - p4)))
+            if abs(vol) > 6.0 and rng.random() < 0.5:                                     # a specified stereo centre
+                lo, hi = (5.0, 100.0) if vol > 0 else (-100.0, -5.0)
+                chiral_idx.append(nb[:4])
+                chiral_par.append((lo, hi))
+                checks.append((1, (0, nb[0], nb[1], nb[2], nb[3]), (lo, hi)))
+                checks.append((3, (a, nb[0], nb[1], nb[2], nb[3]), ()))
+                for x in range(4):
+                    for y in range(x + 1, 4):
+                        checks.append((2, (nb[x], nb[y]), (lb[nb[x], nb[y]], ub[nb[x], nb[y]])))
+        if hv[a] and g.cap[a] == 3 and len(nbr[a]) == 3:
+            checks.append((5, (nbr[a][0], a, nbr[a][1]), ()))                              # not linear
+    dg = [(pairs, np.stack([lbp**2, ubp**2, np.ones(len(pairs))], 1)),
+          (np.array(chiral_idx, dtype=np.int64).reshape(-1, 4), np.array(chiral_par, dtype=np.float64).reshape(-1, 2)),
+          (np.arange(n, dtype=np.int64).reshape(-1, 1), np.zeros((n, 0)))]
+
+    # ---- ETK terms -------------------------------------------------------------------------------------------------
+    etk, n_imp = None, 0
+    if with_etk:
+        t_idx, t_par = [], []
+        seen = set()
+        for (i, j, k, l) in torsions:
+            if (j, k) in seen or same_ring[j, k] or not (hv[i] and hv[l]):
+                continue
+            seen.add((j, k))
+            cj, ck = g.cap[j], g.cap[k]
+            fc = np.zeros(6)
+            sg = np.ones(6)
+            if cj == 4 and ck == 4:
+                fc[2] = rng.uniform(2.0, 6.0)
+            elif cj == 3 and ck == 3:
+                fc[1], sg[1] = rng.uniform(3.0, 8.0), -1.0
+            else:
+                fc[int(rng.integers(0, 6))] = rng.uniform(0.5, 3.0)
+                fc[2] += rng.uniform(0.0, 2.0)
+                sg = rng.choice([-1.0, 1.0], size=6)
+            t_idx.append((i, j, k, l))
+            t_par.append(np.concatenate([fc, sg]))
+        imp_idx, imp_par = [], []
+        for a in range(n):
+            if hv[a] and g.cap[a] == 3 and len(nbr[a]) == 3:
+                n_imp += 1
+                x, y, z = nbr[a]
+                for (p, q, r) in ((x, y, z), (x, z, y), (y, z, x)):
+                    imp_idx.append((p, a, q, r))
+                    imp_par.append((1.0, -1.0, 0.0, 10.0))
+
+        def fb(mask, tol, k, pinned):
+            sel = pairs[mask]
+            d = dist[iu][mask]
+            if tol is None:
+                lo, hi = lbp[mask], ubp[mask]
+            else:
+                lo, hi = d - tol, d + tol
+            return sel, np.stack([lo, hi, np.full(len(sel), k), np.full(len(sel), pinned)], 1)
+
+        lin = ang > np.deg2rad(175.0) if len(ang) else np.zeros(0, dtype=bool)
+        etk = [(np.array(t_idx, dtype=np.int64).reshape(-1, 4), np.array(t_par).reshape(-1, 12)),
+               (np.array(imp_idx, dtype=np.int64).reshape(-1, 4), np.array(imp_par).reshape(-1, 4)),
+               fb(tp == 1, 0.01, 100.0, 0.0), fb(tp == 2, 0.01, 100.0, 0.0),
+               (angles[lin], np.tile([179.0, 180.0], (int(lin.sum()), 1))),
+               fb(tp >= 3, None, 10.0, 0.0)]
+    embed = dict(n_atoms=n, dg=dg, etk=etk, checks=checks, num_impropers=n_imp)
+    out = dict(embed=embed, ref=ref, bounds=(pairs, lbp, ubp), bonds=bonds, heavy=hv.copy())
+
+    # ---- MMFF94-shaped tables: rest values from the geometry, force constants from the ranges of the real tables --
+    if with_mmff:
+        b_h = ~(hv[bonds[:, 0]] & hv[bonds[:, 1]]) if len(bonds) else np.zeros(0, dtype=bool)
+        bond_par = np.stack([dist[bonds[:, 0], bonds[:, 1]] * (1.0 + rng.normal(scale=0.004, size=len(bonds))),
+                             np.where(b_h, rng.uniform(4.5, 5.5, len(bonds)), rng.uniform(4.0, 9.0, len(bonds)))], 1) \
+            if len(bonds) else np.zeros((0, 2))
+        th0 = np.degrees(ang) + rng.normal(scale=1.5, size=len(ang))
+        ang_par = np.stack([th0, rng.uniform(0.4, 1.1, len(ang)), np.zeros(len(ang))], 1) if len(ang) else np.zeros((0, 3))
+        sb_par = np.stack([th0, dist[angles[:, 0], angles[:, 1]], dist[angles[:, 2], angles[:, 1]],
+                           rng.uniform(0.0, 0.5, len(ang)), rng.uniform(0.0, 0.5, len(ang))], 1) if len(ang) else np.zeros((0, 5))
+        oop_idx = [(nbr[a][0], a, nbr[a][1], nbr[a][2]) for a in range(n) if hv[a] and g.cap[a] == 3 and len(nbr[a]) == 3]
+        oop_idx = np.array([perm for (x, a, y, z) in oop_idx for perm in ((x, a, y, z), (x, a, z, y), (y, a, z, x))],
+                           dtype=np.int64).reshape(-1, 4)
+        oop_par = rng.uniform(0.01, 0.15, size=(len(oop_idx), 1))
+        ring_bond = same_ring[torsions[:, 1], torsions[:, 2]] if len(torsions) else np.zeros(0, dtype=bool)
+        tor_par = np.stack([rng.normal(scale=0.3, size=len(torsions)),
+                            np.where(ring_bond, rng.uniform(3.0, 7.0, len(torsions)), rng.normal(scale=0.5, size=len(torsions))),
+                            rng.uniform(0.0, 0.6, len(torsions))], 1) if len(torsions) else np.zeros((0, 3))
+        far = pairs[tp >= 3]
+        rstar = np.where(hv, rng.uniform(3.4, 4.0, n), rng.uniform(2.6, 3.0, n))
+        epsv = np.where(hv, rng.uniform(0.04, 0.12, n), rng.uniform(0.015, 0.03, n))
+        vdw_par = np.stack([0.5 * (rstar[far[:, 0]] + rstar[far[:, 1]]), np.sqrt(epsv[far[:, 0]] * epsv[far[:, 1]])], 1) \
+            if len(far) else np.zeros((0, 2))
+        q = rng.normal(scale=0.08, size=n)
+        q -= q.mean()
+        ele_par = np.stack([q[far[:, 0]] * q[far[:, 1]], np.ones(len(far)), (topo[far[:, 0], far[:, 1]] == 3).astype(float)], 1) \
+            if len(far) else np.zeros((0, 3))
+        out["mmff"] = [(bonds, bond_par), (angles, ang_par), (angles, sb_par), (oop_idx, oop_par), (torsions, tor_par),
+                       (far, vdw_par), (far, ele_par)]
+    return out
+
+
+def druglike_sizes(rng, n_mols: int, mean_atoms: float = 48.0, sd: float = 12.0, lo: int = 12, hi: int = 96) -> np.ndarray:
+    """Atom counts (hydrogens included) of the synthetic benchmark set: clipped Normal(48, 12) in [12, 96]."""
+    return np.clip(rng.normal(mean_atoms, sd, size=n_mols).round().astype(int), lo, hi)
+
+
+def _druglike_worker(args):
+    seed, sizes = args
+    rng = np.random.default_rng(seed)
+    return [druglike_molecule(rng, int(s)) for s in sizes]
+
+
+def druglike_library(n_mols: int, seed: int = 20260926, mean_atoms: float = 48.0, processes: int | None = None):
+    """`n_mols` drug-like molecules, generated in parallel worker processes (the generator is per-atom Python: about 10 ms
+    per molecule on one core).  Deterministic for (n_mols, seed): molecules are made in fixed chunks of 64 with per-chunk
+    seeds, whatever the process count."""
+    import os
+
+    sizes = druglike_sizes(np.random.default_rng(seed), n_mols, mean_atoms)
+    chunks = [(seed + 1 + c, sizes[lo:lo + 64]) for c, lo in enumerate(range(0, n_mols, 64))]
+    procs = processes if processes is not None else min(len(chunks), max(1, (os.cpu_count() or 1) // 2), 64)
+    if procs <= 1 or len(chunks) == 1:
+        parts = [_druglike_worker(c) for c in chunks]
+    else:
+        import multiprocessing as mp
+
+        with mp.get_context("fork").Pool(procs) as pool:
+            parts = pool.map(_druglike_worker, chunks)
+    return [m for p in parts for m in p]

@@ -1,0 +1,137 @@
+"""The HIP path at BASELINE.json's configuration sizes (configs[0] and configs[2] had no -m gpu test).
+
+configs[0]: 10 000 molecules -> Morgan r = 2 / 2048 bit -> 10k x 10k Tanimoto, bit-exact against oracle-Morgan ->
+oracle-similarity (the shape of the reference's tests/integration/test_fp_sim_workflow.cpp, RDKit replaced by seeded
+graphs).  configs[2]: 10 000 drug-like molecules x 10 conformers, ETKDG chained on the device into MMFF94: size-
+independent properties on all of it, the C oracle's pipeline on a slice of it."""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from nvmolkit_amd import mmffOptimization, synthetic
+from nvmolkit_amd.embedMolecules import FlatMolecule, FlatMoleculeSet, embed_flat
+from nvmolkit_amd.fingerprints import MorganFingerprintGenerator
+from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch, stack_molecule_tables
+from nvmolkit_amd.similarity import crossTanimotoSimilarity
+from nvmolkit_amd.types import CoordinateOutput
+from oracle import ffc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg1_morgan_to_similarity_chain_10k():
+    n = 10_000
+    mols = util.random_molecule_batch(n, 64, seed=20260926, min_atoms=8)
+    flat = util.flatten_molecules(mols, 64)
+    fps = MorganFingerprintGenerator(2, 2048).GetFingerprintsFromInvariants(*flat, max_atoms=64).torch()
+    want_fp = oracle.morgan_fingerprints(*flat, 64, 2, 2048)
+    assert np.array_equal(fps.cpu().numpy().view(np.uint32), want_fp)
+    sim = crossTanimotoSimilarity(fps).torch()                      # 10k x 10k float64 on the device (800 MB)
+    assert sim.shape == (n, n)
+    rows = np.r_[0:64, 4968:5032, n - 64:n]                          # 192 full rows against the CPU oracle, bit for bit
+    assert np.array_equal(sim[rows].cpu().numpy(), oracle.cross_similarity(want_fp[rows], want_fp))
+    # every entry: symmetric, in [0, 1], unit diagonal wherever the fingerprint is not empty
+    assert torch.equal(sim, sim.T)
+    assert float(sim.min()) >= 0.0 and float(sim.max()) <= 1.0
+    nonempty = torch.from_numpy((want_fp != 0).any(1)).cuda()
+    assert torch.equal(sim.diagonal() == 1.0, nonempty)
+    # a checksum of row checksums against the oracle on a strided sample of columns
+    cols = np.arange(0, n, 37)
+    want = oracle.cross_similarity(want_fp, want_fp[cols])
+    assert np.array_equal(sim[:, torch.from_numpy(cols).cuda()].cpu().numpy(), want)
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    lib = synthetic.druglike_library(10_000, seed=20260926)
+    molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in lib])
+    dev = embed_flat(molset, confs_per_molecule=10, max_iterations=10, seed=1, output=CoordinateOutput.DEVICE)
+    opt = mmffOptimization.optimize_device([m["mmff"] for m in lib], dev, max_iters=200)
+    torch.cuda.synchronize()
+    return lib, dev, opt
+
+
+def test_cfg3_etkdg_counts_and_bounds(cfg3):
+    lib, dev, _ = cfg3
+    n_conf = dev.num_conformers
+    assert n_conf >= 0.97 * 10 * len(lib)                            # nearly every molecule gets its 10 conformers
+    per_mol = np.bincount(dev.mol_indices.torch().cpu().numpy(), minlength=len(lib))
+    assert per_mol.max() <= 10 and (per_mol == 10).mean() > 0.95
+    # distance bounds of the embedded conformers (what the DG stage minimises): sampled molecules, every pair
+    xyz = dev.values.torch().cpu().numpy()
+    a_s = dev.atom_starts.torch().cpu().numpy()
+    mol_of = dev.mol_indices.torch().cpu().numpy()
+    rng = np.random.default_rng(0)
+    worst = []
+    for c in rng.choice(n_conf, size=400, replace=False):
+        m = lib[mol_of[c]]
+        pairs, lb, ub = m["bounds"]
+        p = xyz[a_s[c]:a_s[c + 1]]
+        d = np.linalg.norm(p[pairs[:, 0]] - p[pairs[:, 1]], axis=1)
+        worst.append(float(np.max(np.maximum(np.maximum(lb - d, d - ub), 0.0) / ub)))
+    assert np.percentile(worst, 95) < 0.05 and max(worst) < 0.25     # E/atom < 0.05 passed, so violations are small
+
+
+def test_cfg3_mmff_energies_decrease_and_match_oracle_energy(cfg3):
+    lib, dev, opt = cfg3
+    tables = [m["mmff"] for m in lib]
+    a_s = dev.atom_starts.torch().cpu().numpy()
+    mol_of = dev.mol_indices.torch().to(torch.int32)
+    batch = FlatForcefieldBatch(MMFF, a_s, stack_molecule_tables(MMFF, tables), system_mol=mol_of)
+    e0 = batch.compute_energy(dev.values.torch().reshape(-1).contiguous())
+    e1 = opt.energies.torch()
+    assert bool((e1 <= e0 + 1e-9).all())
+    assert torch.allclose(batch.compute_energy(opt.values.torch().reshape(-1).contiguous()), e1, rtol=1e-9, atol=1e-9)
+    assert float((e1 / torch.from_numpy(np.diff(a_s)).cuda()).median()) < 5.0      # kcal/mol per atom: relaxed structures
+    # reported energies against the C oracle on a sample of the optimised conformers
+    sel = np.random.default_rng(1).choice(dev.num_conformers, size=256, replace=False)
+    sel.sort()
+    xyz = opt.values.torch().cpu().numpy()
+    sizes = np.diff(a_s)[sel]
+    sub_as = np.concatenate([[0], np.cumsum(sizes)])
+    sub_pos = np.concatenate([xyz[a_s[c]:a_s[c + 1]].reshape(-1) for c in sel])
+    cpu = ffc.Batch(MMFF, sub_as, stack_molecule_tables(MMFF, tables), system_mol=mol_of.cpu().numpy()[sel])
+    np.testing.assert_allclose(e1.cpu().numpy()[sel], cpu.energy(sub_pos), rtol=1e-9, atol=1e-8)
+    conv = opt.converged.torch().float().mean().item()
+    assert 0.0 <= conv <= 1.0                                        # reported by bench.py; BFGS from H = I needs ~2.4 n iterations
+
+
+def test_etkdg_is_bitwise_reproducible_for_a_seed():
+    lib = synthetic.druglike_library(64, seed=5, processes=1)
+    molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in lib])
+    a = embed_flat(molset, confs_per_molecule=4, max_iterations=10, seed=7)
+    b = embed_flat(molset, confs_per_molecule=4, max_iterations=10, seed=7)
+    assert np.array_equal(a.conf_counts, b.conf_counts) and np.array_equal(a.stage_failures, b.stage_failures)
+    assert torch.equal(a.coords, b.coords)
+    c = embed_flat(molset, confs_per_molecule=4, max_iterations=10, seed=8)
+    assert not torch.equal(a.coords, c.coords)
+
+
+def test_etkdg_pipeline_matches_oracle_pipeline_statistically():
+    """Same molecules, same seed, same scheduler and start coordinates on both sides (the C oracle restates the whole
+    stage pipeline): conformer counts, per-stage failure totals and the geometry of the conformers agree.  Individual
+    trajectories of 400-iteration minimisations are chaotic in the last digits, so agreement is per population."""
+    lib = synthetic.druglike_library(96, seed=9, processes=1)
+    mols = [FlatMolecule(**m["embed"]) for m in lib]
+    gpu = embed_flat(FlatMoleculeSet(mols), confs_per_molecule=4, max_iterations=10, seed=3)
+    coords, counts, slots, fails, _ = ffc.etkdg_embed(mols, confs_per_molecule=4, max_iterations=10, seed=3, batch_size=4096)
+    assert abs(int(gpu.conf_counts.sum()) - int(counts.sum())) <= 0.03 * counts.sum()
+    assert np.all(np.abs(gpu.stage_failures - fails) <= np.maximum(4, 0.35 * np.maximum(gpu.stage_failures, fails)))
+    # first conformer of every molecule: attempt 0..n of the first batch has identical start coordinates on both sides;
+    # where both accepted it, the embedded geometries coincide for most molecules
+    same = 0
+    both = 0
+    for m, mol in enumerate(lib):
+        if gpu.conf_counts[m] == 0 or counts[m] == 0:
+            continue
+        n = mol["embed"]["n_atoms"]
+        g = gpu.conformers(m)[0].cpu().numpy()
+        c = coords[slots[m]:slots[m] + 3 * n].reshape(n, 3)
+        both += 1
+        dg = np.linalg.norm(g[:, None] - g[None], axis=2)
+        dc = np.linalg.norm(c[:, None] - c[None], axis=2)
+        same += np.abs(dg - dc).max() < 1e-2
+    assert both >= 80 and same >= 0.5 * both, (same, both)

@@ -1,0 +1,83 @@
+"""E2 / E3: the ETKDG driver's bookkeeping against the reference's programmed-stage matrices (tests/test_etkdg.cu:41-341:
+same failure programmes, same expected failure counts / finished counts / iterations) and the start-coordinate stage
+(range, moments, and bit-exact agreement with the C oracle's restatement of the counter-based generator)."""
+
+import numpy as np
+import pytest
+import torch
+
+from nvmolkit_amd.embedMolecules import driver_run_programmed, random_coords_flat
+from oracle import ffc
+
+pytestmark = pytest.mark.gpu
+
+
+def run(stages, max_iterations=5):
+    return driver_run_programmed(np.array(stages, dtype=np.uint8), max_iterations)
+
+
+def test_no_conformers_and_no_stages_raise():
+    with pytest.raises(ValueError):
+        driver_run_programmed(np.zeros((1, 1, 0), dtype=np.uint8), 5)      # ETKDGDriverFailTest.NoConformers
+    with pytest.raises(ValueError):
+        driver_run_programmed(np.zeros((0, 1, 4), dtype=np.uint8), 5)      # ETKDGDriverFailTest.NoStages
+
+
+def test_single_conformer():
+    counts, fin, n_fin, its = run([[[1], [0], [0]], [[0], [1], [0]]])
+    assert (n_fin, its) == (1, 3)
+    assert counts.tolist() == [[1], [1]]
+
+
+def test_single_stage_all_pass_first_iteration():
+    counts, fin, n_fin, its = run([[[0, 0, 0, 0]]])
+    assert (n_fin, its) == (4, 1) and counts.tolist() == [[0, 0, 0, 0]] and fin.tolist() == [0, 0, 0, 0]
+
+
+def test_single_stage_all_pass_second_iteration():
+    counts, fin, n_fin, its = run([[[1, 1, 1, 1], [0, 0, 0, 0]]])
+    assert (n_fin, its) == (4, 2) and counts.tolist() == [[1, 1, 1, 1]] and fin.tolist() == [1, 1, 1, 1]
+
+
+def test_single_stage_variable_pass():
+    counts, fin, n_fin, its = run([[[0, 1, 1, 1], [0, 0, 1, 1], [0, 0, 0, 1], [0, 0, 0, 0]]])
+    assert (n_fin, its) == (4, 4) and counts.tolist() == [[0, 1, 2, 3]] and fin.tolist() == [0, 1, 2, 3]
+
+
+def test_single_stage_some_not_passed():
+    counts, fin, n_fin, its = run([[[0, 1, 1, 1], [0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 1, 1]]])
+    assert (n_fin, its) == (2, 5) and counts.tolist() == [[0, 1, 5, 5]] and fin.tolist() == [0, 1, -1, -1]
+
+
+def test_multi_stage_all_fail():
+    z, o = [[0, 0, 0, 0]] * 5, [[1, 1, 1, 1]] * 5
+    counts, fin, n_fin, its = run([z, o, z])
+    assert (n_fin, its) == (0, 5)
+    assert counts.tolist() == [[0, 0, 0, 0], [5, 5, 5, 5], [0, 0, 0, 0]]
+
+
+def test_multi_stage_mixed():
+    s1 = [[0, 0, 0, 1], [0, 0, 0, 0], [0, 0, 1, 0], [0, 0, 1, 0], [0, 0, 0, 0]]
+    s2 = [[1, 0, 1, 0], [1, 0, 1, 1], [1, 0, 0, 0], [1, 0, 0, 1], [1, 0, 0, 0]]
+    s3 = [[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, 0], [0, 0, 0, 1]]
+    counts, fin, n_fin, its = run([s1, s2, s3])
+    assert (n_fin, its) == (2, 5)
+    assert counts.tolist() == [[0, 0, 2, 1], [5, 0, 2, 2], [0, 0, 0, 2]]
+    assert (fin >= 0).astype(int).tolist() == [0, 1, 1, 0]                  # completedConformers
+
+
+def test_random_coordinates_range_moments_and_oracle():
+    sizes = [1, 7, 64, 3000, 12]
+    atom_starts = np.concatenate([[0], np.cumsum(sizes)])
+    box = 10.0
+    pos = random_coords_flat(99, 1000, atom_starts, box).cpu().numpy()
+    assert pos.min() >= -box / 2 and pos.max() < box / 2
+    big = pos[atom_starts[3]:atom_starts[4]]
+    assert abs(big.mean()) < 0.08 and abs(big.var() - box * box / 12.0) < 0.3     # uniform on [-5, 5)
+    for s, n in enumerate(sizes):                                                 # same generator as the C oracle, bit for bit
+        assert np.array_equal(pos[atom_starts[s]:atom_starts[s + 1]], ffc.random_coords(99, 1000 + s, n, box))
+    other = random_coords_flat(100, 1000, atom_starts, box).cpu().numpy()
+    assert not np.array_equal(other, pos)
+    masked = random_coords_flat(99, 1000, atom_starts, box, active=[1, 0, 1, 0, 1]).cpu().numpy()
+    assert not masked[atom_starts[1]:atom_starts[2]].any() and np.array_equal(masked[:1], pos[:1])
+    assert torch.cuda.is_available()

@@ -7,11 +7,16 @@ OUT=$ROOT/gpurun_out/pmc_traffic
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --butina-n 0 --conformer-mols 0"
+export NVMK_ROOT=$ROOT
 timeout 600 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1
 python - "$OUT" <<'PY'
-import csv, glob, json, sys
+import csv, glob, hashlib, json, os, sys
 out = {}
+h = hashlib.sha256()
+for name in ("similarity_mfma.hip", "fp4.h", "similarity.hip"):   # same digest as bench.py kernel_source_digest()
+    h.update(open(os.path.join(os.environ["NVMK_ROOT"], "nvmolkit_amd", "csrc", name), "rb").read())
+out["kernel_source_sha256"] = h.hexdigest()
 for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     vals = []
     for f in glob.glob(f"{sys.argv[1]}/{sub}/**/*_counter_collection.csv", recursive=True):
