@@ -90,41 +90,6 @@ template <int KCW> struct Chunk {
   }
 };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {  // n <= 32: whatever the ring geometry can produce
-#define NVMK_W(k) case k: wait_vmcnt<k>(); break;
-  switch (n) {
-    NVMK_W(0) NVMK_W(1) NVMK_W(2) NVMK_W(3) NVMK_W(4) NVMK_W(5) NVMK_W(6) NVMK_W(7) NVMK_W(8) NVMK_W(9) NVMK_W(10)
-    NVMK_W(11) NVMK_W(12) NVMK_W(13) NVMK_W(14) NVMK_W(15) NVMK_W(16) NVMK_W(17) NVMK_W(18) NVMK_W(19) NVMK_W(20)
-    NVMK_W(21) NVMK_W(22) NVMK_W(23) NVMK_W(24) NVMK_W(25) NVMK_W(26) NVMK_W(27) NVMK_W(28) NVMK_W(29) NVMK_W(30)
-    NVMK_W(31) NVMK_W(32)
-    default: wait_vmcnt<0>(); break;
-  }
-#undef NVMK_W
-}
-
-// LDS-DMA issued through inline assembly.  With the builtin, the compiler's waitcnt pass tracks the DMA as a pending
-// LDS write and puts s_waitcnt vmcnt(..) in front of every later ds_read of the same wave that it cannot prove
-// disjoint — i.e. it drains the loads just issued for a LATER stage before the MFMAs of the current one, which
-// serialises exactly what a ring is there to overlap.  The asm form is opaque to that pass; completion is handled by
-// the counted waits below.  ldsByte = wave-uniform LDS byte address of the 1 KB (64 lanes x 16 B) destination.
-__device__ __forceinline__ void dma_b128(const void* g, const unsigned ldsByte) {
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(ldsByte) : "memory");
-}
-__device__ __forceinline__ void dma_b32(const void* g, const unsigned ldsByte) {
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(ldsByte) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)));
-}
-
-// workgroup barrier that orders LDS traffic only: __syncthreads() would also drain vmcnt, i.e. the DMA loads in flight
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 // One K chunk of MFMAs for this wave's 64 x 64 tile.
 template <int KCW>
 __device__ __forceinline__ void chunk_mma(v16f (&acc)[2][2], const char* sA, const char* sB, const int wm, const int wn,
@@ -198,26 +163,26 @@ __device__ __forceinline__ double ratio_by_newton_f(const float c, const float u
   return __fma_rn(e, r, q0);
 }
 
-template <int METRIC, int PIPE = 0, int TMV = TM>
-__global__ __launch_bounds__(NT * (TMV / TM), PIPE ? 3 : (TMV == TM ? 4 : 2)) void cross_sim_mfma_kernel(const uint4* __restrict__ A, const int32_t* __restrict__ popA,
+template <int METRIC>
+__global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __restrict__ A, const int32_t* __restrict__ popA,
                                                                const int64_t nA, const uint4* __restrict__ B,
                                                                const int32_t* __restrict__ popB, const int64_t nB,
                                                                const int Wp, double* __restrict__ out, const int64_t ld,
                                                                const unsigned tilesM, const unsigned tilesN) {
-  // PIPE = 0: one 8-word chunk buffer, load -> barrier -> multiply (overlap only across the 4 co-resident workgroups).
-  // PIPE = 3: ring of three 4-word chunks, two in flight while the third is multiplied (3 workgroups per CU).
-  constexpr int KCW = PIPE ? 4 : 8;
-  constexpr int PPW = KCW / 2;   // DMA pieces (1 KB wave instructions) per wave of the A operand (32 rows per wave)
-  constexpr int NWV = 4 * (TMV / TM);  // waves: (TMV / 64) x 2 of 64 x 64
-  constexpr int BPW = PPW * 4 / NWV;   // ... of the B operand (TN / NWV rows per wave)
+  // One 8-word chunk buffer: load -> barrier -> multiply; the phases of the 4 co-resident workgroups overlap each other
+  // (in-workgroup rings, wider tiles and a producer / consumer split were measured slower: tools/experiments/).
+  constexpr int KCW = 8;
+  constexpr int PPW = KCW / 2;   // DMA pieces (1 KB wave instructions) per wave and operand (32 rows per wave)
+  constexpr int NWV = 4;         // waves: 2 x 2 of 64 x 64
+  constexpr int BPW = PPW;
   constexpr int RPP = 64 / KCW;  // rows per piece
   using C           = Chunk<KCW>;
-  constexpr int STAGE = (TMV + TN) * C::ROWBYTES;
+  constexpr int STAGE = (TM + TN) * C::ROWBYTES;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* sA  = smem;
-  char* sB  = smem + TMV * C::ROWBYTES;
-  int*  pcA = reinterpret_cast<int*>(smem + (PIPE ? PIPE : 1) * STAGE);
-  int*  pcB = pcA + TMV;
+  char* sB  = smem + TM * C::ROWBYTES;
+  int*  pcA = reinterpret_cast<int*>(smem + STAGE);
+  int*  pcB = pcA + TM;
 
   // Workgroup -> tile map: blockIdx.y walks 64 x 64-tile supertiles, blockIdx.x walks a supertile with
   // tile_n fastest.  Inside a supertile both operand blocks (8 MB each) stay in L2 / Infinity Cache, so only
@@ -236,14 +201,13 @@ __global__ __launch_bounds__(NT * (TMV / TM), PIPE ? 3 : (TMV == TM ? 4 : 2)) vo
   const int     wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int     wm    = wave >> 1;
   const int     wn    = wave & 1;
-  const int64_t rowA0 = static_cast<int64_t>(tile_m) * TMV;
+  const int64_t rowA0 = static_cast<int64_t>(tile_m) * TM;
   const int64_t rowB0 = static_cast<int64_t>(tile_n) * TN;
 
-  static_assert(PIPE == 0 || TMV == TM, "the ring variant is written for the 128 x 128 tile");
-  if (tid < TMV) {
+  if (tid < TM) {
     pcA[tid] = popA[rowA0 + tid];
-  } else if (tid - TMV < TN) {
-    pcB[tid - TMV] = popB[rowB0 + tid - TMV];
+  } else if (tid - TM < TN) {
+    pcB[tid - TM] = popB[rowB0 + tid - TM];
   }
   // Wave priority by phase: a workgroup in its main loop (DMA issue, ds_read, MFMA) goes before co-resident workgroups
   // that are converting and storing, which have plenty of independent work to hide behind (+0.8 % measured).
@@ -268,33 +232,6 @@ __global__ __launch_bounds__(NT * (TMV / TM), PIPE ? 3 : (TMV == TM ? 4 : 2)) vo
     const unsigned prowB   = static_cast<unsigned>(wave * (TN / NWV) + (lane >> C::LOG));
     const uint4*   gB      = B + (rowB0 + prowB) * Wp;
     const int      nChunks = Wp / KCW;
-    if constexpr (PIPE != 0) {
-      // DMA through inline asm (invisible to the compiler's waitcnt pass, see dma_b128) + counted waits: chunk ch + 1
-      // and ch + 2 are in flight while chunk ch is multiplied; one barrier per chunk.
-      unsigned offA[PPW], offB[PPW];
-#pragma unroll
-      for (int t = 0; t < PPW; ++t) {
-        const unsigned slot = (static_cast<unsigned>(lane) & (KCW - 1u)) ^ C::swz(prow + RPP * t);
-        offA[t] = offB[t]   = static_cast<unsigned>(t * rowStep) + slot;
-      }
-      auto issue = [&](const int ch) {
-        char* st = smem + (ch % PIPE) * STAGE;
-#pragma unroll
-        for (int t = 0; t < PPW; ++t) dma_b128(gA + ch * KCW + offA[t], lds_addr(st + (wave * PPW + t) * 1024));
-#pragma unroll
-        for (int t = 0; t < PPW; ++t) dma_b128(gB + ch * KCW + offB[t], lds_addr(st + TMV * C::ROWBYTES + (wave * PPW + t) * 1024));
-      };
-      lds_barrier();  // popcounts are in LDS (their loads are the compiler's own and already waited for)
-      for (int ch = 0; ch < PIPE - 1 && ch < nChunks; ++ch) issue(ch);
-      for (int ch = 0; ch < nChunks; ++ch) {
-        const int ahead = nChunks - 1 - ch < PIPE - 2 ? nChunks - 1 - ch : PIPE - 2;  // chunks issued after ch and still flying
-        if (ahead >= 1) wait_vmcnt<2 * PPW>(); else wait_vmcnt<0>();
-        lds_barrier();
-        if (ch + PIPE - 1 < nChunks) issue(ch + PIPE - 1);
-        char* st = smem + (ch % PIPE) * STAGE;
-        chunk_mma<KCW>(acc, st, st + TMV * C::ROWBYTES, wm, wn, lane);
-      }
-    } else
     for (int ch = 0; ch < nChunks; ++ch) {
       if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk
 #pragma unroll
@@ -318,7 +255,7 @@ __global__ __launch_bounds__(NT * (TMV / TM), PIPE ? 3 : (TMV == TM ? 4 : 2)) vo
   // Addresses are a wave-uniform 64-bit row base plus one 32-bit per-lane byte offset; interior tiles take the
   // branch-free path so the 64 divisions and stores of a lane interleave.
   __builtin_amdgcn_s_setprio(0);
-  const bool     full    = (rowA0 + TMV <= nA) && (rowB0 + TN <= nB);
+  const bool     full    = (rowA0 + TM <= nA) && (rowB0 + TN <= nB);
   const unsigned hi      = static_cast<unsigned>(lane >> 5);
   const unsigned laneOff = (hi * 4u * static_cast<unsigned>(ld) + static_cast<unsigned>(lane & 31)) * 8u;
   char*          waveOut = reinterpret_cast<char*>(out + (rowA0 + wm * 64) * ld + rowB0 + wn * 64);
@@ -397,250 +334,6 @@ __global__ __launch_bounds__(NT * (TMV / TM), PIPE ? 3 : (TMV == TM ? 4 : 2)) vo
     emit_wide();
   } else {
     emit(std::false_type{});
-  }
-}
-
-// ---- helpers of the producer / consumer kernel below ----------------------------------------------
-constexpr int BN = 192;  // tile columns
-
-// ---- dense cross-similarity, producer / consumer kernel --------------------------------------------
-// One persistent 1024-thread workgroup per CU, no workgroup barrier after start-up:
-//   * 4 loader waves stream the operand stages (KW words of 128 + 192 rows, LDS-DMA) of a SEQUENCE of 128 x 192 tiles
-//     into a ring of LDS slots, always D = STAGES - 2 stages in flight, and publish "slot s holds its k-th stage" by
-//     bumping readyCnt[s] after a counted s_waitcnt vmcnt;
-//   * two groups of 6 compute waves (2 x 3, 64 x 64 each) take the tiles alternately: poll readyCnt, ds_read + MFMA,
-//     bump freeCnt[s] (the loaders poll it before they overwrite a slot), and after the last stage of their tile run
-//     the whole 64-element epilogue as one straight-line block.  While one group converts and stores tile T the other
-//     multiplies tile T + 1, whose stages the loaders had already started fetching, so loads, matrix work and stores
-//     of ONE workgroup overlap (in the 128 x 128 kernel they only overlap across co-resident workgroups, by luck).
-// LDS operations of a wave execute in order, so a wave's freeCnt bump cannot pass its ds_reads of that slot, and a
-// loader's readyCnt bump cannot pass the DMA writes it waited for.  Loaders never store and compute waves never load
-// from global memory, so nobody's vmcnt mixes loads and stores.
-constexpr int PM = 128;  // tile rows
-
-__device__ __forceinline__ int lds_peek(const int* p) {  // ds_read the compiler may neither cache nor reorder
-  int v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p))) : "memory");
-  return __builtin_amdgcn_readfirstlane(v);
-}
-__device__ __forceinline__ void lds_bump(int* p, const int lane) {
-  if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p))), "v"(1) : "memory");
-}
-
-template <int METRIC, int STAGES, int KW, bool PROF = false>
-__global__ __launch_bounds__(1024, 1) void cross_sim_pp_kernel(const uint4* __restrict__ A, const int32_t* __restrict__ popA,
-                                                            const int64_t nA, const uint4* __restrict__ B,
-                                                            const int32_t* __restrict__ popB, const int64_t nB, const int Wp,
-                                                            double* __restrict__ out, const int64_t ld, const unsigned tilesM,
-                                                            const unsigned tilesN, long long* __restrict__ prof) {
-  using C = Chunk<KW>;
-  long long nPollFail = 0, tEpi = 0, tAll = PROF ? static_cast<long long>(wall_clock64()) : 0;
-  constexpr int STAGE_A = PM * KW * 16;                // 8 KB at KW = 4
-  constexpr int STAGE   = STAGE_A + BN * KW * 16;      // 20 KB at KW = 4
-  constexpr int RP      = 64 / KW;                     // rows one DMA instruction covers
-  constexpr int APL = PM / RP / 4, BPL = BN / RP / 4;  // DMA instructions per loader wave and stage, A and B
-  constexpr int LOADS   = APL + BPL;
-  constexpr int D       = STAGES - 2;                  // stages in flight
-  constexpr int PCBUF   = PM + BN;
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  int* pcBase   = reinterpret_cast<int*>(smem + STAGES * STAGE);  // [4][PM + BN], by tile index & 3
-  int* readyCnt = pcBase + 4 * PCBUF;                             // [STAGES]
-  int* freeCnt  = readyCnt + STAGES;                              // [STAGES]
-
-  const int tid  = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nst  = Wp / KW;
-  // Tile order: 16 x 16-tile supertiles, row-major inside (tile column fastest).  The workgroups of one step work
-  // through the same supertile, so the chip writes a 24 KB wide stripe of the output at any moment and XCD x
-  // (workgroups = x mod 8) keeps tile columns x and x + 8 of the supertile in its L2.  Slots past the matrix edge
-  // are computed on clamped operands and stored nowhere.
-  constexpr unsigned SUP = 16;
-  const unsigned superM = (tilesM + SUP - 1) / SUP, superN = (tilesN + SUP - 1) / SUP;
-  const unsigned long long nSlots = static_cast<unsigned long long>(superM) * superN * (SUP * SUP);
-  const unsigned long long first = blockIdx.x, stride = gridDim.x;
-  if (first >= nSlots) return;
-  const int myTiles     = static_cast<int>((nSlots - first + stride - 1) / stride);
-  const int totalStages = myTiles * nst;
-  auto tile_of = [&](const int k, unsigned& tm, unsigned& tn) {
-    const unsigned long long t = first + static_cast<unsigned long long>(k) * stride;
-    const unsigned sidx = static_cast<unsigned>(t / (SUP * SUP)), within = static_cast<unsigned>(t % (SUP * SUP));
-    const unsigned sm = sidx / superN, sn = sidx - sm * superN;
-    tm = sm * SUP + within / SUP;
-    tn = sn * SUP + within % SUP;
-  };
-  if (tid < 2 * STAGES) readyCnt[tid] = 0;
-  __syncthreads();
-
-  if (wave >= 12) {
-    // ---------------- loader waves ----------------
-    const int q = wave - 12;
-    // Loaders outrank the compute waves they share a SIMD with: their few address instructions must not queue behind
-    // the epilogue's f64 stream, or the DMA pipe runs dry.
-    __builtin_amdgcn_s_setprio(3);
-    unsigned offA[APL], offB[BPL];  // this lane's 16-byte piece inside the tile, in uint4 units (without the stage's word offset)
-#pragma unroll
-    for (int k = 0; k < APL; ++k) {
-      const unsigned row = static_cast<unsigned>((q * APL + k) * RP + lane / KW);
-      offA[k]            = row * static_cast<unsigned>(Wp) + ((static_cast<unsigned>(lane) & (KW - 1)) ^ C::swz(row));
-    }
-#pragma unroll
-    for (int k = 0; k < BPL; ++k) {
-      const unsigned row = static_cast<unsigned>((q * BPL + k) * RP + lane / KW);
-      offB[k]            = row * static_cast<unsigned>(Wp) + ((static_cast<unsigned>(lane) & (KW - 1)) ^ C::swz(row));
-    }
-    // issue cursor: stage gi = tile ti, word chunk ci, ring slot si, its use count ui
-    int          gi = 0, ti = 0, ci = 0, si = 0, ui = 0;
-    const uint4 *gA = nullptr, *gB = nullptr;
-    const int32_t *pA = nullptr, *pB = nullptr;
-    auto issue = [&]() {
-      if (ci == 0) {
-        unsigned tm, tn;
-        tile_of(ti, tm, tn);
-        tm = tm < tilesM ? tm : tilesM - 1;
-        tn = tn < tilesN ? tn : tilesN - 1;
-        gA = A + static_cast<int64_t>(tm) * PM * Wp;
-        gB = B + static_cast<int64_t>(tn) * BN * Wp;
-        pA = popA + static_cast<int64_t>(tm) * PM;
-        pB = popB + static_cast<int64_t>(tn) * BN;
-      }
-      if (ui > 0) {  // the slot's previous stage must have been read by its six consumers
-        while (lds_peek(freeCnt + si) < 6 * ui) { __builtin_amdgcn_s_sleep(1); if constexpr (PROF) ++nPollFail; }
-      }
-      char*        st = smem + si * STAGE;
-      const uint4* sa = gA + ci * KW;  // wave-uniform bases; the per-lane part is a 32-bit offset
-      const uint4* sb = gB + ci * KW;
-#pragma unroll
-      for (int k = 0; k < APL; ++k) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(sa + offA[k]), (lptr_t)(st + (q * APL + k) * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int k = 0; k < BPL; ++k) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(sb + offB[k]), (lptr_t)(st + STAGE_A + (q * BPL + k) * 1024), 16, 0, 0);
-      }
-      if (ci == 0) {  // popcounts: two dword DMA loads per loader wave (repeats keep the count equal on every wave)
-        int*      pc = pcBase + (ti & 3) * PCBUF;
-        const int pa = q & 1, pb = q < 3 ? q : 0;
-        __builtin_amdgcn_global_load_lds((gptr_t)(pA + pa * 64 + lane), (lptr_t)(pc + pa * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(pB + pb * 64 + lane), (lptr_t)(pc + PM + pb * 64), 4, 0, 0);
-      }
-      ++gi;
-      if (++ci == nst) { ci = 0; ++ti; }
-      if (++si == STAGES) { si = 0; ++ui; }
-    };
-    int ce = 0, se = 0;  // oldest unpublished stage: chunk index and slot
-    for (int g = 0; g < totalStages + D; ++g) {
-      if (g >= D) {  // publish stage e = g - D: everything this wave issued for it has landed
-        const int e = g - D;
-        int younger = 0, cc = ce;
-#pragma unroll
-        for (int k = 1; k < D; ++k) {
-          if (++cc == nst) cc = 0;
-          if (e + k < gi) younger += (cc == 0) ? LOADS + 2 : LOADS;
-        }
-        wait_vmcnt_dyn(younger);
-        lds_bump(readyCnt + se, lane);
-        if (++ce == nst) ce = 0;
-        if (++se == STAGES) se = 0;
-      }
-      if (g < totalStages) issue();
-    }
-    if constexpr (PROF) {
-      if (blockIdx.x == 0 && lane == 0) { prof[wave * 4] = nPollFail; prof[wave * 4 + 1] = 0; prof[wave * 4 + 2] = static_cast<long long>(wall_clock64()) - tAll; prof[wave * 4 + 3] = totalStages; }
-    }
-    return;
-  }
-
-  // ---------------- compute waves ----------------
-  const int      group = wave / 6, w6 = wave % 6;
-  const int      wm = w6 / 3, wn = w6 % 3;
-  const int      l31  = lane & 31;
-  const unsigned half = static_cast<unsigned>(lane >> 5);
-  const unsigned rA   = static_cast<unsigned>(wm * 64 + l31), rB = static_cast<unsigned>(wn * 64 + l31);
-  const unsigned baseA = rA * C::ROWBYTES, baseB = STAGE_A + rB * C::ROWBYTES;
-  const unsigned swA = C::swz(rA), swB = C::swz(rB);
-  for (int T = group; T < myTiles; T += 2) {
-    v16f acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-      }
-    }
-    int g    = T * nst;
-    int slot = g % STAGES, need = 4 * (g / STAGES + 1);
-    __builtin_amdgcn_s_setprio(2);  // the group feeding the matrix cores goes before the group converting and storing
-    for (int c = 0; c < nst; ++c) {
-      while (lds_peek(readyCnt + slot) < need) { __builtin_amdgcn_s_sleep(1); if constexpr (PROF) ++nPollFail; }
-      const char* st = smem + slot * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < KW / 2; ++ks) {
-        const unsigned sl   = static_cast<unsigned>(ks * 2) + half;
-        const unsigned offA = baseA + ((sl ^ swA) << 4), offB = baseB + ((sl ^ swB) << 4);
-        const uint4    a0 = *reinterpret_cast<const uint4*>(st + offA);
-        const uint4    a1 = *reinterpret_cast<const uint4*>(st + offA + 32 * C::ROWBYTES);
-        const uint4    b0 = *reinterpret_cast<const uint4*>(st + offB);
-        const uint4    b1 = *reinterpret_cast<const uint4*>(st + offB + 32 * C::ROWBYTES);
-        acc[0][0]         = mfma_fp4(a0, b0, acc[0][0]);
-        acc[0][1]         = mfma_fp4(a0, b1, acc[0][1]);
-        acc[1][0]         = mfma_fp4(a1, b0, acc[1][0]);
-        acc[1][1]         = mfma_fp4(a1, b1, acc[1][1]);
-      }
-      asm volatile("" ::: "memory");
-      lds_bump(freeCnt + slot, lane);  // queued behind this wave's ds_reads of the slot
-      if (++slot == STAGES) { slot = 0; need += 4; }
-    }
-    // epilogue (same element order as the 128 x 128 kernel), one straight-line block
-    __builtin_amdgcn_s_setprio(0);
-    const long long te0 = PROF ? static_cast<long long>(wall_clock64()) : 0;
-    unsigned tm, tn;
-    tile_of(T, tm, tn);
-    const int*     pc      = pcBase + (T & 3) * PCBUF;
-    const int64_t  rowA0   = static_cast<int64_t>(tm) * PM, rowB0 = static_cast<int64_t>(tn) * BN;
-    const bool     full    = (rowA0 + PM <= nA) && (rowB0 + BN <= nB);
-    const unsigned laneOff = (half * 4u * static_cast<unsigned>(ld) + static_cast<unsigned>(l31)) * 8u;
-    char*          waveOut = reinterpret_cast<char*>(out + (rowA0 + wm * 64) * ld + rowB0 + wn * 64);
-    const int      pb0 = pc[PM + wn * 64 + l31], pb1 = pc[PM + wn * 64 + 32 + l31];
-    auto value = [&](const int cnt, const int pav, const int pbv) -> double {
-      if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-        const int u = pav + pbv - cnt;
-        return ratio_by_newton(cnt, u > 1 ? u : 1);
-      } else {
-        const double denom = sqrt(static_cast<double>(pav) * static_cast<double>(pbv));
-        return (cnt == 0 || denom == 0.0) ? 0.0 : static_cast<double>(cnt) / denom;
-      }
-    };
-    auto emit = [&](auto fullTag) {
-      constexpr bool FULL = decltype(fullTag)::value;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int il0    = mi * 32 + (r & 3) + 8 * (r >> 2);
-          const int pav    = pc[wm * 64 + il0 + 4 * static_cast<int>(half)];
-          char*     rowOut = waveOut + static_cast<int64_t>(il0) * ld * 8;
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            const double v   = value(static_cast<int>(acc[mi][ni][r]), pav, ni ? pb1 : pb0);
-            double*      dst = reinterpret_cast<double*>(rowOut + ni * 256 + laneOff);
-            if (FULL || (rowA0 + wm * 64 + il0 + 4 * static_cast<int>(half) < nA && rowB0 + wn * 64 + ni * 32 + l31 < nB)) {
-              __builtin_nontemporal_store(v, dst);
-            }
-          }
-        }
-      }
-    };
-    if (full) {
-      emit(std::true_type{});
-    } else {
-      emit(std::false_type{});
-    }
-    if constexpr (PROF) tEpi += static_cast<long long>(wall_clock64()) - te0;
-  }
-  if constexpr (PROF) {
-    if (blockIdx.x == 0 && lane == 0) { prof[wave * 4] = nPollFail; prof[wave * 4 + 1] = tEpi; prof[wave * 4 + 2] = static_cast<long long>(wall_clock64()) - tAll; prof[wave * 4 + 3] = totalStages; }
   }
 }
 
@@ -943,344 +636,6 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   }
 }
 
-// ---- neighbour counting, ring kernel (un-gathered all-pairs passes) ------------------------------
-// The tile kernel above spends its time in phases that do not overlap inside a workgroup and pulls 16 B of operand
-// bytes per pair through L2.  For the big passes (fused Butina's all-pairs pass, nvmk_neighbor_counts) this kernel
-// is a conventional pipelined GEMM instead — possible here because there is no output stream to drain:
-//   * ONE persistent 512-thread workgroup per CU, tile 256 x 256 (8 B/pair), 8 waves of 64 x 128 (6 ds_read_b128 per
-//     8 MFMAs instead of 4 per 4);
-//   * a ring of four 4-word stages (32 KB each): every wave issues its share of LDS-DMA loads three stages ahead and
-//     waits with a COUNTED s_waitcnt vmcnt (wave-uniform bookkeeping of everything it has issued, so the two count
-//     atomics per tile are accounted for), one s_barrier per stage; the stage stream runs on across tile boundaries,
-//     so the next tile's operands arrive under the epilogue;
-//   * tiles are walked in 16 x 16-tile superblocks, each XCD (workgroups = x mod 8) owning a 4 x 8 sub-block so its
-//     L2 holds 4 + 8 operand tiles; symmetric passes enumerate only the superblocks on or above the diagonal;
-//   * neighbour pairs are staged in LDS and flushed in bulk (one returning atomic per ~512 pairs, not per ballot).
-constexpr int RT  = 256;  // tile edge
-constexpr int RKW = 4;    // words per stage
-constexpr int RST = 4;    // ring slots
-constexpr int REDGE_CAP = 1024, REDGE_FLUSH = 512;
-
-template <int METRIC, bool EMIT, bool PROF = false, int WT = 128>
-__global__ __launch_bounds__(64 * 4 * (RT / WT), 1) void neighbor_count_ring_kernel(
-  const uint4* __restrict__ X, const int32_t* __restrict__ popX, const int64_t nX, const uint4* __restrict__ Y,
-  const int32_t* __restrict__ popY, const int64_t nY, const int Wp, const double K1, const double K2, const double adj, const float thr,
-  const int sign, const int symmetric, int32_t* __restrict__ counts, int2* __restrict__ edges,
-  unsigned long long* __restrict__ edgeCursor, const unsigned long long edgeCapacity, long long* __restrict__ prof) {
-  using C = Chunk<RKW>;
-  auto      now = [&]() -> long long { return PROF ? static_cast<long long>(wall_clock64()) : 0; };
-  long long tWait = 0, tMma = 0, tEpi = 0, nTiles = 0;
-  constexpr int STAGE_X = RT * RKW * 16;  // 16 KB
-  constexpr int STAGE   = 2 * STAGE_X;    // 32 KB
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  int*  pcBase   = reinterpret_cast<int*>(smem + RST * STAGE);  // [2][512]: tile parity, X rows then Y rows
-  int*  rowsum   = pcBase + 2 * 2 * RT;                          // [256]
-  int*  colsum   = rowsum + RT;                                  // [256]
-  int2* edgeBuf  = reinterpret_cast<int2*>(colsum + RT);         // [REDGE_CAP]
-  int*  edgeMeta = reinterpret_cast<int*>(edgeBuf + REDGE_CAP);  // [0] staged count, [2..3] flush base
-
-  const int tid  = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // 4 x RWN waves of 64 x WT: WT = 128 -> 8 waves (6 ds_read_b128 per 8 MFMAs, 2 waves per SIMD), WT = 64 -> 16 waves
-  // (4 per 4, 4 waves per SIMD)
-  constexpr int RWN = RT / WT, NWV = 4 * RWN, NI = WT / 32, RNTV = 64 * NWV, PPV = 16 / NWV;
-  const int wm = wave / RWN, wn = wave % RWN;
-  const int nst  = Wp / RKW;
-  constexpr int INVALID = (METRIC == NVMK_METRIC_TANIMOTO) ? -1 : 0;  // popcount stand-in of rows that can have no neighbour
-  const unsigned tilesM = static_cast<unsigned>((nX + RT - 1) / RT), tilesN = static_cast<unsigned>((nY + RT - 1) / RT);
-  constexpr unsigned SUP = 16;
-  const unsigned superM = (tilesM + SUP - 1) / SUP, superN = (tilesN + SUP - 1) / SUP;
-  const unsigned long long nSuper = symmetric ? static_cast<unsigned long long>(superN) * (superN + 1ull) / 2ull :
-                                                static_cast<unsigned long long>(superM) * superN;
-  // slot k of this workgroup -> tile; false when the slot holds no work (edge of the matrix, below the diagonal)
-  auto tile_at = [&](const long long k, unsigned& tm, unsigned& tn, bool& end) -> bool {
-    const unsigned long long t  = blockIdx.x + static_cast<unsigned long long>(k) * gridDim.x;
-    const unsigned long long sb = t / (SUP * SUP);
-    end                         = sb >= nSuper;
-    if (end) return false;
-    const unsigned within = static_cast<unsigned>(t % (SUP * SUP));
-    unsigned       sm, sn;
-    if (symmetric) {
-      const double S = static_cast<double>(superN);
-      unsigned     r = static_cast<unsigned>((2.0 * S + 1.0 - sqrt((2.0 * S + 1.0) * (2.0 * S + 1.0) - 8.0 * static_cast<double>(sb))) * 0.5);
-      auto rowStart  = [&](const unsigned q) { return static_cast<unsigned long long>(q) * (2ull * superN - q + 1ull) / 2ull; };
-      while (r > 0 && rowStart(r) > sb) --r;
-      while (rowStart(r + 1) <= sb) ++r;
-      sm = r;
-      sn = r + static_cast<unsigned>(sb - rowStart(r));
-    } else {
-      sm = static_cast<unsigned>(sb / superN);
-      sn = static_cast<unsigned>(sb - static_cast<unsigned long long>(sm) * superN);
-    }
-    const unsigned x = within & 7u, j = within >> 3;  // XCD x owns a 4 x 8 sub-block of the superblock
-    tm = sm * SUP + (x >> 1) * 4u + (j >> 3);
-    tn = sn * SUP + (x & 1u) * 8u + (j & 7u);
-    return tm < tilesM && tn < tilesN && (!symmetric || tn >= tm);
-  };
-  auto next_tile = [&](long long& k, unsigned& tm, unsigned& tn) -> bool {  // advance to the next slot with work
-    bool end = false;
-    for (++k;; ++k) {
-      if (tile_at(k, tm, tn, end)) return true;
-      if (end) return false;
-    }
-  };
-
-  if (tid < RT) { rowsum[tid] = 0; colsum[tid] = 0; }
-  if (tid == 0) edgeMeta[0] = 0;
-  lds_barrier();
-
-  // ---- load side: the stage stream of this workgroup's tile sequence ----
-  long long kIss = -1;
-  unsigned  itm = 0, itn = 0;
-  bool      issLive = next_tile(kIss, itm, itn);
-  int       ici = 0, islot = 0, itile = 0;  // chunk inside the tile, ring slot, ordinal of the tile in the sequence
-  int       issuedTotal = 0;                // vector-memory operations this wave has issued so far
-  int       issuedAt[RST] = {0, 0, 0, 0};   // ... right after the loads of the stage in each slot
-  const unsigned prow0 = static_cast<unsigned>(wave * PPV * 16 + (lane >> 2));  // rows of this wave's PPV 16-row pieces
-  unsigned       offP[PPV];
-#pragma unroll
-  for (int t = 0; t < PPV; ++t) {
-    const unsigned row = prow0 + 16u * t;
-    offP[t]            = row * static_cast<unsigned>(Wp) + ((static_cast<unsigned>(lane) & 3u) ^ C::swz(row));
-  }
-  auto issue_stage = [&]() {
-    if (issLive) {
-      char*        st = smem + islot * STAGE;
-      const uint4* gx = X + static_cast<int64_t>(itm) * RT * Wp + ici * RKW;
-      const uint4* gy = Y + static_cast<int64_t>(itn) * RT * Wp + ici * RKW;
-#pragma unroll
-      for (int t = 0; t < PPV; ++t) {
-        dma_b128(gx + offP[t], lds_addr(st + (wave * PPV + t) * 1024));
-      }
-#pragma unroll
-      for (int t = 0; t < PPV; ++t) {
-        dma_b128(gy + offP[t], lds_addr(st + STAGE_X + (wave * PPV + t) * 1024));
-      }
-      issuedTotal += 2 * PPV;
-      if (ici == 0 && wave < 8) {  // row popcounts of the tile: 512 dwords, one DMA instruction on waves 0-3 (X rows) and 4-7 (Y rows)
-        int*           pc  = pcBase + (itile & 1) * 2 * RT;
-        const int32_t* src = wave < 4 ? popX + static_cast<int64_t>(itm) * RT + wave * 64 : popY + static_cast<int64_t>(itn) * RT + (wave - 4) * 64;
-        dma_b32(src + lane, lds_addr(pc + wave * 64));
-        issuedTotal += 1;
-      }
-      issuedAt[islot] = issuedTotal;
-      if (++ici == nst) {
-        ici = 0;
-        ++itile;
-        issLive = next_tile(kIss, itm, itn);
-      }
-    } else {
-      issuedAt[islot] = issuedTotal;
-    }
-    if (++islot == RST) islot = 0;
-  };
-  for (int i = 0; i < RST - 1; ++i) issue_stage();
-
-  // ---- compute side ----
-  const int      l31  = lane & 31;
-  const unsigned half = static_cast<unsigned>(lane >> 5);
-  const unsigned rA   = static_cast<unsigned>(wm * 64 + l31), rB = static_cast<unsigned>(wn * WT + l31);
-  const unsigned baseA = rA * C::ROWBYTES, baseB = STAGE_X + rB * C::ROWBYTES;
-  const unsigned swA = C::swz(rA), swB = C::swz(rB);
-  long long kCmp = -1;
-  unsigned  tm = 0, tn = 0;
-  int       cslot = 0, ctile = 0;
-  while (next_tile(kCmp, tm, tn)) {
-    v16f acc[2][NI];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-      }
-    }
-    const int64_t rowA0 = static_cast<int64_t>(tm) * RT, rowB0 = static_cast<int64_t>(tn) * RT;
-    int*          pc    = pcBase + (ctile & 1) * 2 * RT;
-    for (int ch = 0; ch < nst; ++ch) {
-      const long long t0 = now();
-      wait_vmcnt_dyn(issuedTotal - issuedAt[cslot]);  // this wave's loads of the stage have landed
-      if (ch == 0 && METRIC == NVMK_METRIC_TANIMOTO) {
-        // rows past the end and empty fingerprints (union 0 -> similarity 0 -> never >= a positive threshold) never
-        // match: flag them (this thread DMA'd the entry it patches, and its wait has just completed)
-        if (tid < 2 * RT) {
-          const int64_t r = tid < RT ? rowA0 + tid : rowB0 + (tid - RT);
-          if (r >= (tid < RT ? nX : nY) || pc[tid] == 0) pc[tid] = INVALID;
-        }
-      }
-      __builtin_amdgcn_s_barrier();  // ... and everyone else's; everyone is also done reading the slot refilled next
-      asm volatile("" ::: "memory");
-      const long long t1 = now();
-      issue_stage();
-      const char* st = smem + cslot * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < RKW / 2; ++ks) {
-        const unsigned sl   = static_cast<unsigned>(ks * 2) + half;
-        const unsigned offA = baseA + ((sl ^ swA) << 4), offB = baseB + ((sl ^ swB) << 4);
-        uint4 a[2], b[NI];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const uint4*>(st + offA + i * 32 * C::ROWBYTES);
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn) b[jn] = *reinterpret_cast<const uint4*>(st + offB + jn * 32 * C::ROWBYTES);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-          for (int jn = 0; jn < NI; ++jn) acc[i][jn] = mfma_fp4(a[i], b[jn], acc[i][jn]);
-        }
-      }
-      asm volatile("" ::: "memory");
-      if constexpr (PROF) {
-        asm volatile("s_nop 0" : "+v"(acc[0][0]), "+v"(acc[1][NI - 1]));
-        tWait += t1 - t0;
-        tMma += now() - t1;
-      }
-      if (++cslot == RST) cslot = 0;
-    }
-    const long long te = now();
-
-    // ---- epilogue: threshold, row / column counts, staged neighbour pairs ----
-    const bool creditCols = symmetric && tn > tm;
-    int        cc[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) cc[ni] = 0;
-    int        myRow = 0;
-    // Tanimoto: the table-free exact predicate with the row-slot fast reject (see ArithThreshold above)
-    int    pbv[NI];
-    double pbK[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      pbv[ni] = pc[RT + wn * WT + ni * 32 + l31];
-      pbK[ni] = pbv[ni] < 0 ? __builtin_inf() : static_cast<double>(pbv[ni]) * K2;
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rowLo = mi * 32 + (r & 3) + 8 * (r >> 2);
-        const int pav   = pc[wm * 64 + rowLo + 4 * static_cast<int>(half)];
-        double    d[NI], paK = 0.0;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) d[ni] = 0.0;
-        if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-          paK = pav < 0 ? __builtin_inf() : __builtin_fma(static_cast<double>(pav), K2, -adj);
-          double best = -__builtin_inf();
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            d[ni] = __builtin_fma(static_cast<double>(acc[mi][ni][r]), K1, -pbK[ni]);
-            best  = fmax(best, d[ni]);
-          }
-          if (__ballot(best > paK) == 0) continue;  // no neighbour in this row slot
-        }
-        int lo = 0, hi = 0;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          bool p;
-          if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-            p = d[ni] > paK;
-          } else {
-            p = cosine_neighbor(static_cast<int>(acc[mi][ni][r]), pav, pbv[ni], thr);
-          }
-          cc[ni] += p ? 1 : 0;
-          const uint64_t m = __ballot(p);
-          lo += __popc(static_cast<unsigned>(m));
-          hi += __popc(static_cast<unsigned>(m >> 32));
-          if constexpr (EMIT) {
-            if (m != 0) {  // rare: pairs i < j once; the diagonal tile holds both orientations and the self pairs
-              const int64_t  gi = rowA0 + wm * 64 + rowLo + 4 * static_cast<int>(half);
-              const int64_t  gj = rowB0 + wn * WT + ni * 32 + l31;
-              const bool     e  = p && gi < gj && gi < nX && gj < nY;
-              const uint64_t me = __ballot(e);
-              if (me != 0) {
-                const int first = __ffsll(static_cast<long long>(me)) - 1;
-                int       base  = 0;
-                if (lane == first) base = atomicAdd(&edgeMeta[0], __popcll(me));  // LDS
-                base = __shfl(base, first);
-                if (e) {
-                  const int slot = base + __popcll(me & ((1ull << lane) - 1ull));
-                  if (slot < REDGE_CAP) {
-                    edgeBuf[slot] = make_int2(static_cast<int>(gi), static_cast<int>(gj));
-                  } else {  // staging overflow (a tile full of neighbours): straight to memory
-                    const unsigned long long gs = atomicAdd(edgeCursor, 1ull);
-                    if (gs < edgeCapacity) edges[gs] = make_int2(static_cast<int>(gi), static_cast<int>(gj));
-                  }
-                }
-              }
-            }
-          }
-        }
-        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myRow) : "s"(lo), "s"(rowLo));
-        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myRow) : "s"(hi), "s"(rowLo + 4));
-      }
-    }
-    if (myRow != 0) atomicAdd(&rowsum[wm * 64 + lane], myRow);
-    if (creditCols) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        int v = cc[ni];
-        v += __shfl_xor(v, 32);
-        if (lane < 32 && v != 0) atomicAdd(&colsum[wn * WT + ni * 32 + lane], v);
-      }
-    }
-    lds_barrier();
-    if (tid < 2 * RT) {  // exactly one global atomic instruction per wave 0-7 and tile (adds of 0 included): exact vmcnt bookkeeping
-      const bool    isRow = tid < RT;
-      const int     t     = isRow ? tid : tid - RT;
-      const int64_t r     = (isRow ? rowA0 : rowB0) + t;
-      const int64_t n     = isRow ? nX : nY;
-      int           v     = isRow ? rowsum[t] : colsum[t];
-      if (isRow) rowsum[t] = 0; else colsum[t] = 0;
-      if (r >= n || (!isRow && !creditCols)) v = 0;
-      atomicAdd(&counts[r < n ? r : n - 1], sign * v);
-    }
-    if (wave < 8) issuedTotal += 1;
-    if constexpr (EMIT) {
-      const int staged = edgeMeta[0];  // same value in every thread: last written before the barrier above
-      if (staged > REDGE_FLUSH) {
-        const int nStaged = staged < REDGE_CAP ? staged : REDGE_CAP;
-        if (tid == 0) {
-          const unsigned long long base = atomicAdd(edgeCursor, static_cast<unsigned long long>(nStaged));
-          edgeMeta[2] = static_cast<int>(base & 0xffffffffull);
-          edgeMeta[3] = static_cast<int>(base >> 32);
-        }
-        lds_barrier();
-        const unsigned long long base = (static_cast<unsigned long long>(static_cast<unsigned>(edgeMeta[3])) << 32) | static_cast<unsigned>(edgeMeta[2]);
-        for (int i = tid; i < nStaged; i += RNTV) {
-          if (base + i < edgeCapacity) edges[base + i] = edgeBuf[i];
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // data-dependent number of stores: resynchronise the bookkeeping
-#pragma unroll
-        for (int q = 0; q < RST; ++q) issuedAt[q] = issuedTotal;
-        lds_barrier();
-        if (tid == 0) edgeMeta[0] = 0;
-        lds_barrier();
-      }
-    }
-    ++ctile;
-    if constexpr (PROF) { tEpi += now() - te; ++nTiles; }
-  }
-  if constexpr (PROF) {
-    if (blockIdx.x == 0 && lane == 0) { prof[wave * 4] = tWait; prof[wave * 4 + 1] = tMma; prof[wave * 4 + 2] = tEpi; prof[wave * 4 + 3] = nTiles; }
-  }
-  if constexpr (EMIT) {  // final flush
-    lds_barrier();
-    const int staged  = edgeMeta[0];
-    const int nStaged = staged < REDGE_CAP ? staged : REDGE_CAP;
-    if (nStaged > 0) {
-      if (tid == 0) {
-        const unsigned long long base = atomicAdd(edgeCursor, static_cast<unsigned long long>(nStaged));
-        edgeMeta[2] = static_cast<int>(base & 0xffffffffull);
-        edgeMeta[3] = static_cast<int>(base >> 32);
-      }
-      lds_barrier();
-      const unsigned long long base = (static_cast<unsigned long long>(static_cast<unsigned>(edgeMeta[3])) << 32) | static_cast<unsigned>(edgeMeta[2]);
-      for (int i = tid; i < nStaged; i += RNTV) {
-        if (base + i < edgeCapacity) edges[base + i] = edgeBuf[i];
-      }
-    }
-  }
-}
-
 }  // namespace
 
 int prepare(const uint32_t* d_in, const int32_t* d_rows, int64_t n, int fpBits, void* ws, hipStream_t stream) {
@@ -1303,28 +658,6 @@ template <int METRIC>
 int launch_dense_t(const Prepared& A, const Prepared& B, double* out, int64_t ld, dim3 grid, unsigned tilesM,
                    unsigned tilesN, hipStream_t stream) {
   const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + (TM + TN) * 4;
-  if (const char* pe = std::getenv("NVMK_DENSE_KERNEL"); pe != nullptr && std::string(pe) == "wide" && A.L.nPad % (2 * TM) == 0) {
-    // experiment (0.58 vs 0.60 T pairs/s): 256 x 128 tiles, 8 waves, 2 workgroups per CU, 12 instead of 16 B/pair of
-    // operand traffic.  Only when the row block is padded to whole 256-row tiles.
-    constexpr int  TW  = 2 * TM;
-    const unsigned tmw = static_cast<unsigned>(ceil_div<int64_t>(A.L.n, TW));
-    const int64_t  sup = ceil_div<int64_t>(tmw, SUPER) * ceil_div<int64_t>(tilesN, SUPER);
-    const size_t   shw = static_cast<size_t>(TW + TN) * 8 * 16 + (TW + TN) * 4;
-    auto           kern = cross_sim_mfma_kernel<METRIC, 0, TW>;
-    NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shw)));
-    hipLaunchKernelGGL(kern, dim3(grid.x, static_cast<unsigned>(sup)), dim3(2 * NT), shw, stream, A.rows, A.popc, A.L.n, B.rows, B.popc, B.L.n,
-                       A.L.Wp, out, ld, tmw, tilesN);
-    NVMK_LAUNCH_CHECK();
-    return NVMK_OK;
-  }
-  if (const char* pe = std::getenv("NVMK_DENSE_KERNEL"); pe != nullptr && std::string(pe) == "pipe") {
-    // experiment (0.56 vs 0.60 T pairs/s): three-stage ring of 4-word chunks inside the workgroup, 3 workgroups per CU
-    const size_t shmem3 = static_cast<size_t>(3) * (TM + TN) * 4 * 16 + (TM + TN) * 4;
-    hipLaunchKernelGGL((cross_sim_mfma_kernel<METRIC, 3>), grid, dim3(NT), shmem3, stream, A.rows, A.popc, A.L.n, B.rows, B.popc,
-                       B.L.n, A.L.Wp, out, ld, tilesM, tilesN);
-    NVMK_LAUNCH_CHECK();
-    return NVMK_OK;
-  }
   hipLaunchKernelGGL(cross_sim_mfma_kernel<METRIC>, grid, dim3(NT), shmem, stream, A.rows, A.popc, A.L.n, B.rows, B.popc,
                      B.L.n, A.L.Wp, out, ld, tilesM, tilesN);
   NVMK_LAUNCH_CHECK();
@@ -1345,44 +678,6 @@ int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, 
                (long long)tilesM, (long long)tilesN);
   const dim3     grid(static_cast<unsigned>(SUPER * SUPER), static_cast<unsigned>(supers));
   const unsigned tm = static_cast<unsigned>(tilesM), tn = static_cast<unsigned>(tilesN);
-  // NVMK_DENSE_KERNEL=pp selects the experimental producer / consumer kernel (slower than the tile kernel as measured,
-  // DESIGN.md §4.1; kept selectable because the parity tests run it and the next optimisation round starts from it).
-  // It needs whole 4-word stages and operands zero-padded to 128- / 192-row tiles, which fp4::ROW_ALLOC guarantees.
-  const char*       dk = std::getenv("NVMK_DENSE_KERNEL");
-  const std::string dks(dk ? dk : "");
-  if (dks == "pp" && A.L.Wp % 4 == 0) {
-    static const int cus = [] {
-      int dev = 0, n = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      return n > 0 ? n : 256;
-    }();
-    {
-      const unsigned btm = static_cast<unsigned>(ceil_div<int64_t>(A.L.n, PM)), btn = static_cast<unsigned>(ceil_div<int64_t>(B.L.n, BN));
-      constexpr int PPS = 7, PKW = 4;  // 7 ring slots of 20 KB, 5 in flight
-      const size_t  shmem = static_cast<size_t>(PPS) * (PM + BN) * PKW * 16 + 4 * (PM + BN) * 4 + 2 * PPS * 4;
-      auto kern = (metric == NVMK_METRIC_TANIMOTO) ? cross_sim_pp_kernel<NVMK_METRIC_TANIMOTO, PPS, PKW> : cross_sim_pp_kernel<NVMK_METRIC_COSINE, PPS, PKW>;
-      const bool profile = std::getenv("NVMK_PP_PROFILE") != nullptr && metric == NVMK_METRIC_TANIMOTO;
-      if (profile) kern = cross_sim_pp_kernel<NVMK_METRIC_TANIMOTO, PPS, PKW, true>;
-      long long* dProf = nullptr;
-      if (profile) NVMK_HIP_CHECK(hipMalloc(&dProf, 64 * sizeof(long long)));
-      NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(shmem)));
-      hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(cus)), dim3(1024), shmem, stream, A.rows, A.popc, A.L.n, B.rows, B.popc,
-                         B.L.n, A.L.Wp, out, ld, btm, btn, dProf);
-      NVMK_LAUNCH_CHECK();
-      if (profile) {  // debugging aid: workgroup 0, per wave
-        long long h[64];
-        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
-        NVMK_HIP_CHECK(hipMemcpy(h, dProf, sizeof(h), hipMemcpyDeviceToHost));
-        NVMK_HIP_CHECK(hipFree(dProf));
-        for (int w = 0; w < 16; ++w)
-          std::fprintf(stderr, "[pp] wave %2d %s: %lld stages, %.2f failed polls/stage, epilogue %.3f us/stage, total %.3f us/stage\n", w,
-                       w < 12 ? "compute" : "loader ", h[w * 4 + 3], double(h[w * 4]) / h[w * 4 + 3], h[w * 4 + 1] * 0.01 / h[w * 4 + 3],
-                       h[w * 4 + 2] * 0.01 / h[w * 4 + 3]);
-      }
-      return NVMK_OK;
-    }
-  }
   if (metric == NVMK_METRIC_TANIMOTO) return launch_dense_t<NVMK_METRIC_TANIMOTO>(A, B, out, ld, grid, tm, tn, stream);
   return launch_dense_t<NVMK_METRIC_COSINE>(A, B, out, ld, grid, tm, tn, stream);
 }
@@ -1396,59 +691,6 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   const bool    emit    = a.edges != nullptr;
   NVMK_REQUIRE(!emit || (a.symmetric && a.xRows == nullptr && a.yRows == nullptr && a.edgeCursor != nullptr),
                "neighbor counts: edge emission needs the symmetric, un-gathered mode and a cursor");
-  {
-    // NVMK_COUNT_KERNEL=ring sends un-gathered passes to the pipelined ring kernel (256 x 256 tiles, one persistent
-    // workgroup per CU).  Opt-in: measured 0.93 T pairs/s against 1.15 for the tile kernel.
-    static const int cus = [] {
-      int dev = 0, n = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      return n > 0 ? n : 256;
-    }();
-    const char*       ck = std::getenv("NVMK_COUNT_KERNEL");
-    const std::string cks(ck ? ck : "");
-    const bool        plain = a.xRows == nullptr && a.yRows == nullptr && a.xIds == nullptr && a.yIds == nullptr && a.nXdev == nullptr &&
-                       a.nYdev == nullptr && X.L.Wp % RKW == 0 && X.L.Wp / RKW >= RST && X.L.nPad % RT == 0 && Y.L.nPad % RT == 0 &&
-                       std::max(X.L.nPad, Y.L.nPad) * X.L.Wp < (int64_t{1} << 32) &&
-                       (a.metric != NVMK_METRIC_TANIMOTO || arith_threshold(a.thr, F).ok);
-    if (plain && cks == "ring") {
-      using RKern = void (*)(const uint4*, const int32_t*, int64_t, const uint4*, const int32_t*, int64_t, int, double, double, double, float, int,
-                             int, int32_t*, int2*, unsigned long long*, unsigned long long, long long*);
-      const ArithThreshold at = arith_threshold(a.thr, F);
-      static const int wt = [] { const char* e = std::getenv("NVMK_RING_WT"); return (e && std::atoi(e) == 64) ? 64 : 128; }();
-      RKern kern;
-      if (a.metric == NVMK_METRIC_TANIMOTO) {
-        kern = wt == 64 ? (emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true, false, 64> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false, false, 64>)
-                        : (emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false>);
-      } else {
-        kern = wt == 64 ? (emit ? neighbor_count_ring_kernel<NVMK_METRIC_COSINE, true, false, 64> : neighbor_count_ring_kernel<NVMK_METRIC_COSINE, false, false, 64>)
-                        : (emit ? neighbor_count_ring_kernel<NVMK_METRIC_COSINE, true> : neighbor_count_ring_kernel<NVMK_METRIC_COSINE, false>);
-      }
-      const size_t shmem = static_cast<size_t>(RST) * 2 * RT * RKW * 16 + 2 * 2 * RT * 4 + 2 * RT * 4 + REDGE_CAP * 8 + 16;
-      NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(shmem)));
-      const bool profile = std::getenv("NVMK_RING_PROFILE") != nullptr && a.metric == NVMK_METRIC_TANIMOTO;
-      long long* dProf   = nullptr;
-      if (profile) {
-        kern = wt == 64 ? (emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true, true, 64> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false, true, 64>)
-                        : (emit ? neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, true, true> : neighbor_count_ring_kernel<NVMK_METRIC_TANIMOTO, false, true>);
-        NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem)));
-        NVMK_HIP_CHECK(hipMalloc(&dProf, 64 * sizeof(long long)));
-      }
-      hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(cus)), dim3(wt == 64 ? 1024 : 512), shmem, stream, X.rows, X.popc, a.nX, Y.rows, Y.popc, a.nY, X.L.Wp,
-                         at.k1, at.k2, at.adj, a.thr, a.sign, a.symmetric ? 1 : 0, counts, a.edges, a.edgeCursor, a.edgeCapacity, dProf);
-      NVMK_LAUNCH_CHECK();
-      if (profile) {  // debugging aid: workgroup 0, per wave, 100 MHz ticks
-        long long h[64];
-        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
-        NVMK_HIP_CHECK(hipMemcpy(h, dProf, sizeof(h), hipMemcpyDeviceToHost));
-        NVMK_HIP_CHECK(hipFree(dProf));
-        for (int w = 0; w < (wt == 64 ? 16 : 8); ++w)
-          std::fprintf(stderr, "[ring] wave %d: %lld tiles; per tile: wait+barrier %.2f us, issue+mma %.2f us, epilogue %.2f us\n", w, h[w * 4 + 3],
-                       h[w * 4] * 0.01 / h[w * 4 + 3], h[w * 4 + 1] * 0.01 / h[w * 4 + 3], h[w * 4 + 2] * 0.01 / h[w * 4 + 3]);
-      }
-      return NVMK_OK;
-    }
-  }
   const int64_t tilesM  = ceil_div<int64_t>(a.nX, TM);
   const int64_t tilesN  = ceil_div<int64_t>(a.nY, TN);
   static const int64_t superE = [] {  // supertile edge for this kernel (NVMK_COUNT_SUPER overrides for experiments)

@@ -12,18 +12,15 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["valu", "mfma", "mfma:dense", "mfma:ring", "mfma:table", "mfma:nosort", "auto"], autouse=True)
+@pytest.fixture(params=["valu", "mfma", "mfma:dense", "mfma:table", "mfma:nosort", "auto"], autouse=True)
 def sim_path(request, monkeypatch):
     """Neighbour counting / fused Butina run on the v_bcnt kernels, on the FP4 matrix-core kernels (round loop on the
-    sparse neighbour graph; the dense round loop that streams the fingerprint matrix; the sparse loop with every
-    un-gathered pass forced onto the pipelined ring kernel, which otherwise only takes the big passes; the tile kernel
+    sparse neighbour graph; the dense round loop that streams the fingerprint matrix; the tile kernel
     with the threshold TABLE instead of the exact-arithmetic predicate it uses for thresholds in [2^-10, 1]) and on the
-    library's automatic choice (NVMK_SIM_PATH / NVMK_BUTINA_ROUNDS / NVMK_COUNT_KERNEL / NVMK_COUNT_THRESHOLD are read
-    per call)."""
+    library's automatic choice (NVMK_SIM_PATH / NVMK_BUTINA_ROUNDS / NVMK_COUNT_THRESHOLD are read per call)."""
     path, _, variant = request.param.partition(":")
     monkeypatch.setenv("NVMK_SIM_PATH", path)
     monkeypatch.delenv("NVMK_BUTINA_ROUNDS", raising=False)
-    monkeypatch.delenv("NVMK_COUNT_KERNEL", raising=False)
     monkeypatch.delenv("NVMK_COUNT_THRESHOLD", raising=False)
     monkeypatch.delenv("NVMK_BUTINA_SORT", raising=False)
     if variant == "nosort":  # fused Butina: all-pairs pass in input order (default: popcount-sorted copy with tile skipping)
@@ -32,8 +29,6 @@ def sim_path(request, monkeypatch):
         monkeypatch.setenv("NVMK_COUNT_THRESHOLD", "table")
     if variant == "dense":
         monkeypatch.setenv("NVMK_BUTINA_ROUNDS", "dense")
-    elif variant == "ring":
-        monkeypatch.setenv("NVMK_COUNT_KERNEL", "ring")
     return request.param
 
 METRICS = {"tanimoto": oracle.TANIMOTO, "cosine": oracle.COSINE}

@@ -15,17 +15,11 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["valu", "mfma", "mfma:pp", "mfma:pipe", "mfma:wide", "auto"], autouse=True)
+@pytest.fixture(params=["valu", "mfma", "auto"], autouse=True)
 def sim_path(request, monkeypatch):
-    """Every parity case runs on the VALU popcount kernel, on the FP4 matrix-core kernels (the 128 x 128 tile kernel and
-    the experimental producer / consumer kernel) and on the library's automatic choice (NVMK_SIM_PATH / NVMK_DENSE_KERNEL are read per
-    call by nvmolkit_amd/csrc/similarity.hip / similarity_mfma.hip)."""
-    path, _, kern = request.param.partition(":")
-    monkeypatch.setenv("NVMK_SIM_PATH", path)
-    if kern:
-        monkeypatch.setenv("NVMK_DENSE_KERNEL", kern)
-    else:
-        monkeypatch.delenv("NVMK_DENSE_KERNEL", raising=False)
+    """Every parity case runs on the VALU popcount kernel, on the FP4 matrix-core kernel and on the library's automatic
+    choice (NVMK_SIM_PATH is read per call by nvmolkit_amd/csrc/similarity.hip)."""
+    monkeypatch.setenv("NVMK_SIM_PATH", request.param)
     return request.param
 
 FUNCS = {"tanimoto": (crossTanimotoSimilarity, oracle.TANIMOTO), "cosine": (crossCosineSimilarity, oracle.COSINE)}
