@@ -8,6 +8,7 @@ created by torch are then directly usable by the kernels.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from pathlib import Path
@@ -151,6 +152,23 @@ def check(rc: int, what: str = "") -> None:
     if rc == ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
     raise RuntimeError(msg)
+
+
+@contextlib.contextmanager
+def on_stream(stream, device):
+    """Run the staging of a call (allocations, ``.contiguous()`` / host-to-device copies) on the SAME stream as its kernel.
+
+    With ``stream=None`` everything is on torch's current stream already.  With a side stream, staging done on the current
+    stream would race with the kernel (no dependency between the streams) and its temporaries would return to the caching
+    allocator tied to the wrong stream while the kernel may still read them: so the side stream first waits for the work
+    already queued on the current stream (the inputs), then becomes current for the block."""
+    if stream is None:
+        yield
+        return
+    with torch.cuda.device(device):
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            yield
 
 
 def stream_ptr(stream) -> int:

@@ -43,16 +43,17 @@ def conformer_rms_matrix_flat(coords: list[torch.Tensor], prealigned: bool = Fal
     coord_off = np.zeros(len(coords) + 1, dtype=np.int64)
     coord_off[1:] = np.cumsum(n_confs * n_atoms * 3)
     total = int(pair_off[-1])
-    out = torch.empty(total, dtype=torch.float64, device=device)
-    if total > 0:
-        flat = torch.cat([c.reshape(-1) for c in coords]) if len(coords) > 1 else coords[0].reshape(-1).contiguous()
-        to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)  # noqa: E731
-        d_coff, d_na, d_poff = to_dev(coord_off, np.int64), to_dev(n_atoms, np.int32), to_dev(pair_off, np.int64)
-        with torch.cuda.device(device):
-            rc = _native.lib().nvmk_conformer_rmsd_batch(flat.data_ptr(), d_coff.data_ptr(), d_na.data_ptr(), d_poff.data_ptr(),
-                                                         len(coords), total, int(bool(prealigned)), out.data_ptr(),
-                                                         _native.stream_ptr(stream))
-        _native.check(rc, "nvmk_conformer_rmsd_batch")
+    with _native.on_stream(stream, device):  # staging tensors and the kernel share one stream
+        out = torch.empty(total, dtype=torch.float64, device=device)
+        if total > 0:
+            flat = torch.cat([c.reshape(-1) for c in coords]) if len(coords) > 1 else coords[0].reshape(-1).contiguous()
+            to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)  # noqa: E731
+            d_coff, d_na, d_poff = to_dev(coord_off, np.int64), to_dev(n_atoms, np.int32), to_dev(pair_off, np.int64)
+            with torch.cuda.device(device):
+                rc = _native.lib().nvmk_conformer_rmsd_batch(flat.data_ptr(), d_coff.data_ptr(), d_na.data_ptr(),
+                                                             d_poff.data_ptr(), len(coords), total, int(bool(prealigned)),
+                                                             out.data_ptr(), _native.stream_ptr(stream))
+            _native.check(rc, "nvmk_conformer_rmsd_batch")
     return [out[pair_off[m]:pair_off[m + 1]] for m in range(len(coords))]
 
 

@@ -105,7 +105,11 @@ extern "C" int nvmk_cross_similarity_host_f64(int metric, const uint32_t* d_a, i
   const int    W        = fp_bits / 32;
   size_t       chunkRows;
   int          nWorkers;
-  if (allowed >= total * sizeof(double)) {
+  // The single-chunk path needs the whole result AND the FP4-expanded operand sets the launch allocates (fp4.h: 16 bytes
+  // per fingerprint word) on the device, with the same 10 % headroom the chunked path keeps: a matrix that only just fits
+  // the free memory goes through the chunked path instead of failing with out-of-memory.
+  const size_t operandBytes = nvmk_fp4_workspace_bytes(nA, fp_bits) + nvmk_fp4_workspace_bytes(nB, fp_bits);
+  if (allowed / 10 * 9 >= total * sizeof(double) + operandBytes) {
     chunkRows = static_cast<size_t>(nA);
     nWorkers  = 1;
   } else {

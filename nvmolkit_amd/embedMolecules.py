@@ -237,31 +237,149 @@ def stereo_check_flat(kind: int, positions: torch.Tensor, atom_starts, sys_mol, 
     return failed
 
 
+def embed_flat_molecules(flat_mols: Sequence[FlatMolecule], confs_per_molecule: int, max_iterations: int,
+                         hardware_options: HardwareOptions | None, output: CoordinateOutput, target_gpu: int | None, **kw):
+    """ETKDG on flattened molecules over the GPUs of ``hardware_options.gpuIds``: molecules are dealt to the GPUs largest
+    first (cost ~ atoms^2, like the reference's sort in src/etkdg.cpp:151-154) and every GPU embeds its share on a host
+    thread and stream of its own (src/etkdg.cpp:211-240); no data moves between GPUs until the results are gathered.
+    Returns a list of (k_m, n_atoms_m, 3) host arrays in input order, or with ``output=DEVICE`` one
+    :class:`Device3DResult` on ``target_gpu`` whose ``mol_indices`` are input positions."""
+    from nvmolkit_amd._rdkit_confs import run_per_gpu
+
+    opts = hardware_options or HardwareOptions()
+    gpu_ids = list(opts.gpuIds) if opts.gpuIds else [torch.cuda.current_device()]
+    if output == CoordinateOutput.DEVICE:
+        if target_gpu is None or target_gpu < 0:
+            target_gpu = gpu_ids[0]
+        if target_gpu not in gpu_ids:
+            raise ValueError(f"targetGpu {target_gpu} is not in the configured set of execution GPUs; pass it via "
+                             "hardwareOptions.gpuIds first.")
+    n_atoms = np.array([m.n_atoms for m in flat_mols], dtype=np.int64)
+    order = np.argsort(-n_atoms, kind="stable")
+    shares = [order[slot::len(gpu_ids)] for slot in range(len(gpu_ids))]
+    results: list = [None] * len(gpu_ids)
+
+    def gpu_worker(slot: int) -> None:
+        mine = shares[slot]
+        if len(mine) == 0:
+            return
+        device = torch.device("cuda", gpu_ids[slot])
+        with torch.cuda.device(device):
+            stream = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(stream):
+                molset = FlatMoleculeSet([flat_mols[i] for i in mine], device=device)
+                stream.synchronize()  # the tables were staged on this stream
+                results[slot] = embed_flat(molset, confs_per_molecule, max_iterations,
+                                           batch_size=opts.batchSize if opts.batchSize > 0 else -1,
+                                           batches_per_gpu=max(1, opts.batchesPerGpu), stream=stream, output=output, **kw)
+            stream.synchronize()
+
+    run_per_gpu(gpu_worker, len(gpu_ids))
+    if output != CoordinateOutput.DEVICE:
+        per_mol: list = [np.zeros((0, int(n), 3)) for n in n_atoms]
+        for slot, res in enumerate(results):
+            if res is None:
+                continue
+            for local, m in enumerate(shares[slot]):
+                per_mol[int(m)] = res.conformers(local).cpu().numpy()
+        return per_mol
+    # consolidate on the target GPU, conformers ordered by input molecule (detail::finalizeOnTarget)
+    tgt = torch.device("cuda", target_gpu)
+    parts = []
+    for slot, res in enumerate(results):
+        if res is None:
+            continue
+        g = torch.from_numpy(np.asarray(shares[slot], dtype=np.int64)).to(tgt)
+        parts.append((res.values.torch().to(tgt), res.atom_starts.torch().to(tgt).to(torch.int64),
+                      g[res.mol_indices.torch().to(tgt).to(torch.int64)], res.conf_indices.torch().to(tgt).to(torch.int64)))
+    if not parts:
+        z = lambda dt: torch.zeros(0, dtype=dt, device=tgt)  # noqa: E731
+        return Device3DResult(torch.zeros((0, 3), dtype=torch.float64, device=tgt), torch.zeros(1, dtype=torch.int32, device=tgt),
+                              z(torch.int32), z(torch.int32), target_gpu, len(flat_mols))
+    sizes = torch.cat([p[1][1:] - p[1][:-1] for p in parts])
+    mols = torch.cat([p[2] for p in parts])
+    confs = torch.cat([p[3] for p in parts])
+    row0 = torch.cat([p[1][:-1] + off for p, off in zip(parts, np.cumsum([0] + [int(p[0].shape[0]) for p in parts[:-1]]))])
+    values = torch.cat([p[0] for p in parts])
+    key = torch.argsort(mols * (int(confs.max().item()) + 1 if confs.numel() else 1) + confs, stable=True)
+    sizes, mols, confs, row0 = sizes[key], mols[key], confs[key], row0[key]
+    starts = torch.zeros(sizes.numel() + 1, dtype=torch.int64, device=tgt)
+    starts[1:] = torch.cumsum(sizes, 0)
+    rows = torch.repeat_interleave(row0 - starts[:-1], sizes) + torch.arange(int(starts[-1].item()), device=tgt)
+    return Device3DResult(values[rows], starts.to(torch.int32), mols.to(torch.int32), confs.to(torch.int32), target_gpu,
+                          len(flat_mols))
+
+
 def EmbedMolecules(molecules, params, confsPerMolecule: int = 1, maxIterations: int = -1,
                    hardwareOptions: HardwareOptions | None = None, output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS,
-                   targetGpu: int | None = None):
-    """Embed multiple molecules with multiple conformers on the GPU (reference: nvmolkit/embedMolecules.py:55-158).
+                   targetGpu: int = -1):
+    """Embed multiple molecules with multiple conformers on the GPU(s) (reference: nvmolkit/embedMolecules.py:55-158).
 
-    The RDKit -> flattened-term adapter (bounds matrix with triangle smoothing, chiral sets, experimental torsions:
-    src/embedder_utils.cpp:229-347, rdkit_extensions/dist_geom_flattened_builder.cpp) depends on RDKit internals
-    (``EmbedArgs``) that have no Python API; it belongs in a C++ extension built where RDKit is installed
-    (INTEGRATION.md).  Without it this entry point validates its arguments like the reference and then raises.
-    """
+    Chemistry perception is RDKit's through its public Python API (``nvmolkit_amd._rdkit_embed``: smoothed bounds matrix,
+    experimental torsions, chiral sets, double-bond lists -> flattened term tables; the reference does the same in C++,
+    src/embedder_utils.cpp:662-712).  ``RDKIT_CONFORMERS`` writes the conformers into the molecules (existing conformers
+    are cleared, ids 0..k-1) and returns ``None``; ``DEVICE`` leaves the molecules untouched and returns a
+    :class:`Device3DResult` on ``targetGpu`` (default: the first execution GPU).  Restrictions as the reference:
+    ``useRandomCoords`` must be True; bounds matrices, coordinate maps and custom CPCI are not supported; all fragments are
+    embedded together.  ``params.pruneRmsThresh > 0`` prunes the conformers on the GPU (RDKIT_CONFORMERS only, like the
+    reference)."""
     if confsPerMolecule <= 0:
         raise ValueError("confsPerMolecule must be greater than 0")
     if maxIterations < -1 or maxIterations == 0:
         raise ValueError("maxIterations must be -1 (automatic) or greater than 0")
+    if not molecules:
+        if output == CoordinateOutput.DEVICE:
+            raise ValueError("EmbedMolecules(output=DEVICE) requires at least one molecule")
+        return None
+    for i, mol in enumerate(molecules):
+        if mol is None:
+            raise ValueError(f"Molecule at index {i} is None")
     if not getattr(params, "useRandomCoords", False):
-        raise ValueError("ETKDG requires useRandomCoords=True")  # nvmolkit/embedMolecules.py:146-147
-    if output is CoordinateOutput.DEVICE and getattr(params, "pruneRmsThresh", -1.0) > 0:
+        raise ValueError("ETKDG requires useRandomCoords=True in EmbedParameters")  # nvmolkit/embedMolecules.py:146-147
+    prune = float(getattr(params, "pruneRmsThresh", -1.0))
+    if output is CoordinateOutput.DEVICE and prune > 0:
         raise ValueError("RMS pruning is not supported with DEVICE output")
-    try:
-        import rdkit  # noqa: F401
-    except ImportError as exc:
-        raise ImportError("EmbedMolecules needs RDKit for chemistry perception; use embed_flat() with flattened "
-                          "term tables, or build the RDKit adapter described in INTEGRATION.md") from exc
-    raise NotImplementedError("the RDKit EmbedArgs -> flattened-term adapter is not built in this environment "
-                              "(see INTEGRATION.md); embed_flat() is the supported entry point")
+    for name in ("boundsMat", "coordMap", "CPCI"):
+        if getattr(params, name, None):
+            raise NotImplementedError(f"EmbedParameters.{name} is not supported (as in the reference)")
+    from nvmolkit_amd import _rdkit_embed
+
+    flat = [FlatMolecule(**_rdkit_embed.flatten_etkdg_from_rdkit(m, params)) for m in molecules]
+    seed = int(getattr(params, "randomSeed", -1))
+    if seed < 0:
+        seed = int(np.random.SeedSequence().entropy & 0x7FFFFFFFFFFFFFFF)
+    kw = dict(use_exp_torsions=bool(getattr(params, "useExpTorsionAnglePrefs", False)),
+              use_basic_knowledge=bool(getattr(params, "useBasicKnowledge", False)),
+              enforce_chirality=bool(getattr(params, "enforceChirality", True)),
+              box_size_mult=float(getattr(params, "boxSizeMult", 2.0)),
+              force_tol=float(getattr(params, "optimizerForceTol", 1e-3)), seed=seed)
+    if output is CoordinateOutput.DEVICE:
+        return embed_flat_molecules(flat, confsPerMolecule, maxIterations, hardwareOptions, output, targetGpu, **kw)
+    coords = embed_flat_molecules(flat, confsPerMolecule, maxIterations, hardwareOptions, output, None, **kw)
+    if prune > 0:
+        coords = [_prune_host(c, prune, m, bool(getattr(params, "onlyHeavyAtomsForRMS", False))) for c, m in zip(coords, molecules)]
+    for mol, xyz in zip(molecules, coords):
+        _rdkit_embed.write_conformers(mol, xyz)
+    return None
+
+
+def _prune_host(xyz: np.ndarray, threshold: float, mol, heavy_only: bool) -> np.ndarray:
+    """RMS pruning of one molecule's conformers with the GPU pruning kernels (conformerRmsd.prune_conformers)."""
+    if len(xyz) < 2:
+        return xyz
+    from nvmolkit_amd.conformerRmsd import prune_conformers
+
+    n = xyz.shape[1]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    starts = torch.arange(0, (len(xyz) + 1) * n, n, dtype=torch.int32, device=dev)
+    res = Device3DResult(torch.from_numpy(np.ascontiguousarray(xyz.reshape(-1, 3))).to(dev), starts,
+                         torch.zeros(len(xyz), dtype=torch.int32, device=dev),
+                         torch.arange(len(xyz), dtype=torch.int32, device=dev), dev.index, 1)
+    subset = None
+    if heavy_only:
+        subset = [[a.GetIdx() for a in mol.GetAtoms() if a.GetAtomicNum() > 1]]
+    kept = prune_conformers(res, threshold, subset)
+    return kept.values.torch().cpu().numpy().reshape(-1, n, 3)
 
 
 def random_coords_flat(seed: int, attempt_base: int, atom_starts, box_size: float, active=None, device="cuda", stream=None):

@@ -58,6 +58,8 @@ class FlatForcefieldBatch:
         self.kind = kind
         self.dim = DIM[kind]
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.atom_starts_host = np.ascontiguousarray(atom_starts, dtype=np.int32)
         self.n_systems = len(self.atom_starts_host) - 1
         if self.n_systems < 0 or np.any(np.diff(self.atom_starts_host) < 0):
@@ -98,6 +100,8 @@ class FlatForcefieldBatch:
     def _check_pos(self, pos: torch.Tensor) -> torch.Tensor:
         if not isinstance(pos, torch.Tensor) or not pos.is_cuda or pos.dtype != torch.float64:
             raise ValueError("positions must be a float64 CUDA tensor")
+        if pos.device != self.device:
+            raise ValueError(f"positions live on {pos.device} but the batch's tables are on {self.device}")
         if pos.numel() != self.n_atoms_total * self.dim:
             raise ValueError(f"positions must hold {self.n_atoms_total} atoms x {self.dim} coordinates")
         if not pos.is_contiguous():
@@ -113,9 +117,10 @@ class FlatForcefieldBatch:
         self._check_pos(pos)
         out = torch.zeros(max(self.n_systems, 0), dtype=torch.float64, device=self.device)
         m = self._mask(active)
-        rc = _native.lib().nvmk_ff_energy(ctypes.byref(self._c), float(w0), float(w1), pos.data_ptr(),
-                                          m.data_ptr() if m is not None else None, out.data_ptr(),
-                                          _native.stream_ptr(stream))
+        with torch.cuda.device(self.device):  # kernels, scratch and the default stream belong to THIS batch's GPU
+            rc = _native.lib().nvmk_ff_energy(ctypes.byref(self._c), float(w0), float(w1), pos.data_ptr(),
+                                              m.data_ptr() if m is not None else None, out.data_ptr(),
+                                              _native.stream_ptr(stream))
         _native.check(rc, "nvmk_ff_energy")
         return out
 
@@ -124,9 +129,10 @@ class FlatForcefieldBatch:
         self._check_pos(pos)
         grad = torch.zeros_like(pos)
         m = self._mask(active)
-        rc = _native.lib().nvmk_ff_gradient(ctypes.byref(self._c), float(w0), float(w1), pos.data_ptr(),
-                                            m.data_ptr() if m is not None else None, grad.data_ptr(),
-                                            _native.stream_ptr(stream))
+        with torch.cuda.device(self.device):
+            rc = _native.lib().nvmk_ff_gradient(ctypes.byref(self._c), float(w0), float(w1), pos.data_ptr(),
+                                                m.data_ptr() if m is not None else None, grad.data_ptr(),
+                                                _native.stream_ptr(stream))
         _native.check(rc, "nvmk_ff_gradient")
         return grad
 
@@ -142,10 +148,11 @@ class FlatForcefieldBatch:
         statuses = torch.full((n,), -1, dtype=torch.int16, device=self.device)
         iters = torch.zeros(n, dtype=torch.int32, device=self.device)
         m = self._mask(active)
-        rc = _native.lib().nvmk_bfgs_minimize(ctypes.byref(self._c), self.atom_starts_host.ctypes.data, float(w0), float(w1),
-                                              int(max_iters), float(grad_tol), int(bool(scale_grads)), pos.data_ptr(),
-                                              m.data_ptr() if m is not None else None, energies.data_ptr(),
-                                              statuses.data_ptr(), iters.data_ptr(), _native.stream_ptr(stream))
+        with torch.cuda.device(self.device):
+            rc = _native.lib().nvmk_bfgs_minimize(ctypes.byref(self._c), self.atom_starts_host.ctypes.data, float(w0), float(w1),
+                                                  int(max_iters), float(grad_tol), int(bool(scale_grads)), pos.data_ptr(),
+                                                  m.data_ptr() if m is not None else None, energies.data_ptr(),
+                                                  statuses.data_ptr(), iters.data_ptr(), _native.stream_ptr(stream))
         _native.check(rc, "nvmk_bfgs_minimize")
         return energies, statuses, iters
 

@@ -40,10 +40,38 @@ def optimize_device(tables, conformers: Device3DResult, max_iters: int = 200, gr
     return minimize_device_conformers(MMFF, tables, conformers, max_iters, grad_tol)
 
 
+def mmff_dielectric(props, dielectric_model=None, dielectric_constant=None):
+    """(model code, constant) of the electrostatic term: 1 = constant dielectric, 2 = distance dependent (the codes
+    ``mmff_ele`` takes; reference: addEle, rdkit_extensions/mmff_flattened_builder.cpp, divides the charge product by
+    getMMFFDielectricConstant() and passes getMMFFDielectricModel()).  RDKit's Python ``MMFFMolProperties`` has SETTERS for
+    these two but no getters, so non-default settings made with ``SetMMFFDielectricModel`` / ``SetMMFFDielectricConstant``
+    cannot be read back: pass them explicitly (``dielectricModel`` / ``dielectricConstant`` of
+    ``MMFFOptimizeMoleculesConfs``).  Getters are used when an RDKit build provides them."""
+    model, const = dielectric_model, dielectric_constant
+    if model is None:
+        get = getattr(props, "GetMMFFDielectricModel", None)
+        model = get() if callable(get) else 1
+    if const is None:
+        get = getattr(props, "GetMMFFDielectricConstant", None)
+        const = get() if callable(get) else 1.0
+    if isinstance(model, str):
+        model = {"constant": 1, "distance": 2}[model.lower()]
+    if isinstance(model, bool):  # RDKit's own flag: SetMMFFDielectricModel(distDepDielectric)
+        model = 2 if model else 1
+    if model not in (1, 2):
+        raise ValueError("dielectricModel must be 'constant' / 1 or 'distance' / 2")
+    const = float(const)
+    if not const > 0.0:
+        raise ValueError("the dielectric constant must be positive")
+    return int(model), const
+
+
 def flatten_mmff_from_rdkit(mol, props, conf_id: int = -1, non_bonded_threshold: float = 100.0,
-                            ignore_interfrag_interactions: bool = True):
+                            ignore_interfrag_interactions: bool = True, dielectric_model=None, dielectric_constant=None):
     """RDKit molecule -> the 7 MMFF term groups (local atom indices).  UNTESTED without RDKit (see module docstring)."""
     from rdkit import Chem
+
+    diel_model, diel_const = mmff_dielectric(props, dielectric_model, dielectric_constant)
 
     n = mol.GetNumAtoms()
     bonds, angles, strbend, oops, tors, vdw, ele = ([] for _ in range(7))
@@ -115,7 +143,7 @@ def flatten_mmff_from_rdkit(mol, props, conf_id: int = -1, non_bonded_threshold:
             if pv:
                 vdw.append((i, j, pv[2], pv[3]))
             if abs(charges[i]) > 1e-10 and abs(charges[j]) > 1e-10:
-                ele.append((i, j, charges[i] * charges[j], 1.0, 1.0 if dm[i, j] == 3 else 0.0))  # constant dielectric, D = 1
+                ele.append((i, j, charges[i] * charges[j] / diel_const, float(diel_model), 1.0 if dm[i, j] == 3 else 0.0))
 
     def split(rows, n_idx, n_par):
         a = np.array(rows, dtype=np.float64).reshape(-1, n_idx + n_par)
@@ -127,13 +155,16 @@ def flatten_mmff_from_rdkit(mol, props, conf_id: int = -1, non_bonded_threshold:
 
 def MMFFOptimizeMoleculesConfs(molecules, maxIters: int = 200, properties=None, nonBondedThreshold=100.0,
                                ignoreInterfragInteractions=True, hardwareOptions: HardwareOptions | None = None,
-                               output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, targetGpu: int = -1):
+                               output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, targetGpu: int = -1,
+                               dielectricModel=None, dielectricConstant=None):
     """Optimise every conformer of every molecule with MMFF94 + BFGS on the GPU.
 
     Same contract as the reference (nvmolkit/mmffOptimization.py:60-201): ``RDKIT_CONFORMERS`` updates the conformers
     in place and returns a list of per-conformer energies per molecule, ``DEVICE`` returns a :class:`Device3DResult`;
     ``ValueError(message, {"none": [...], "no_params": [...]})`` for ``None`` entries or molecules without MMFF
-    parameters."""
+    parameters.  ``dielectricModel`` ("constant" / "distance") and ``dielectricConstant`` carry the two
+    ``MMFFMolProperties`` settings that RDKit's Python API can set but not read back (see :func:`mmff_dielectric`);
+    default: constant dielectric, D = 1, RDKit's defaults."""
     if not molecules:
         if output == CoordinateOutput.DEVICE:
             raise ValueError("MMFFOptimizeMoleculesConfs(output=DEVICE) requires at least one molecule")
@@ -167,5 +198,6 @@ def MMFFOptimizeMoleculesConfs(molecules, maxIters: int = 200, properties=None, 
 
     return optimize_rdkit_conformers(
         MMFF, molecules,
-        lambda mi, cid: flatten_mmff_from_rdkit(molecules[mi], props[mi], cid, float(thresholds[mi]), bool(interfrag[mi])),
+        lambda mi, cid: flatten_mmff_from_rdkit(molecules[mi], props[mi], cid, float(thresholds[mi]), bool(interfrag[mi]),
+                                                dielectricModel, dielectricConstant),
         int(maxIters), 1e-4, hardwareOptions, output, targetGpu)

@@ -40,16 +40,11 @@ def _pair(one, two):
 
 def _cross_device(fn_name: str, one, two, stream) -> AsyncGpuResult:
     sptr = _native.stream_ptr(stream)
-    a, b = _pair(one, two)
-    with torch.cuda.device(a.device):
-        ctx = torch.cuda.stream(stream) if stream is not None else None
-        if ctx is not None:
-            ctx.__enter__()
-        try:
-            out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=a.device)
-        finally:
-            if ctx is not None:
-                ctx.__exit__(None, None, None)
+    first = one if isinstance(one, torch.Tensor) else getattr(one, "torch", lambda: None)()
+    device = first.device if isinstance(first, torch.Tensor) and first.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    with torch.cuda.device(device), _native.on_stream(stream, device):
+        a, b = _pair(one, two)  # any .contiguous() copy is made on the stream the kernel runs on
+        out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=a.device)
         rc = getattr(_native.lib(), fn_name)(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], a.shape[1] * 32,
                                              out.data_ptr(), b.shape[0], sptr)
     _native.check(rc, fn_name)
