@@ -8,8 +8,9 @@
 //
 // Design for wave64 (the reference uses a cooperative-group tile of maxAtoms threads and a CUB merge sort
 // of (neighbourhood, invariant, atom) tuples every round):
-//   * one workgroup per molecule, lane = atom: ONE wave64 for the 32- and 64-atom buckets (the barrier is
-//     free), two waves for the 128-atom bucket;
+//   * lane = atom: ONE wave64 per molecule in the 64-atom bucket and TWO molecules per wave64 in the 32-atom bucket
+//     (lanes 0-31 / 32-63, each half with its own LDS state: no idle half wave; the barrier is free in both),
+//     two waves per molecule for the 128-atom bucket;
 //   * no sort.  The reference's sorted sweep only decides, among atoms whose bond-neighbourhood bitsets are
 //     EQUAL, which one comes first — the primary sort key is the bitset itself, so atoms with different
 //     bitsets never interact.  An atom therefore survives a round iff its bitset was not accepted in an
@@ -41,8 +42,9 @@ template <int NW> __device__ __forceinline__ bool bits_equal(const Bits<NW>& a, 
   return eq;
 }
 
-// NW = bitset words = stride / 32; BLOCK = threads per molecule (>= stride).
-template <int NW, int BLOCK>
+// NW = bitset words = stride / 32; BLOCK = threads per workgroup; MPB = molecules per workgroup (BLOCK / MPB >= stride
+// lanes each).
+template <int NW, int BLOCK, int MPB = 1>
 __global__ __launch_bounds__(BLOCK) void morgan_kernel(const uint32_t* __restrict__ atomInv,
                                                        const uint32_t* __restrict__ bondInv,
                                                        const int16_t* __restrict__ bondIdx,
@@ -51,7 +53,12 @@ __global__ __launch_bounds__(BLOCK) void morgan_kernel(const uint32_t* __restric
                                                        const int32_t* __restrict__ outIdx, const int64_t nMols,
                                                        const int radius, const int fpBits, uint32_t* __restrict__ out) {
   constexpr int STRIDE = NW * 32;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LPM    = BLOCK / MPB;  // lanes per molecule
+  static_assert(LPM >= STRIDE, "one lane per atom slot");
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  const int    sub      = threadIdx.x / LPM;
+  const size_t molWords = 3 * STRIDE + 2 * STRIDE * NW + static_cast<size_t>(radius) * STRIDE * NW + fpBits / 32 + 4;
+  char*        smem     = smem_all + sub * molWords * 4;
   uint32_t* cur      = reinterpret_cast<uint32_t*>(smem);        // [STRIDE] invariants entering this round
   uint32_t* rinv     = cur + STRIDE;                             // [STRIDE] invariants computed this round
   uint32_t* liveNow  = rinv + STRIDE;                            // [STRIDE] atom produced an environment this round
@@ -61,14 +68,15 @@ __global__ __launch_bounds__(BLOCK) void morgan_kernel(const uint32_t* __restric
   uint32_t* fp       = seen + static_cast<size_t>(radius) * STRIDE * NW;  // [fpBits / 32]
   int*      seenCnt  = reinterpret_cast<int*>(fp + fpBits / 32);
 
-  const int64_t mol = blockIdx.x;
-  if (mol >= nMols) return;
-  const int a      = threadIdx.x;
-  const int n      = nAtomsPerMol[mol];
+  const int64_t molRaw = static_cast<int64_t>(blockIdx.x) * MPB + sub;
+  const bool    valid  = molRaw < nMols;  // an odd tail leaves one half idle: it still takes part in the barriers
+  const int64_t mol    = valid ? molRaw : 0;
+  const int a      = threadIdx.x % LPM;
+  const int n      = valid ? nAtomsPerMol[mol] : 0;
   const int words  = fpBits / 32;
   uint32_t* outRow = out + static_cast<int64_t>(outIdx ? outIdx[mol] : mol) * words;
 
-  for (int k = a; k < words; k += BLOCK) fp[k] = 0u;
+  for (int k = a; k < words; k += LPM) fp[k] = 0u;
   if (a == 0) *seenCnt = 0;
   const bool     atom = a < n;
   const uint32_t inv0 = (atom && a < STRIDE) ? atomInv[mol * STRIDE + a] : 0u;
@@ -207,21 +215,23 @@ __global__ __launch_bounds__(BLOCK) void morgan_kernel(const uint32_t* __restric
     __syncthreads();
   }
   __syncthreads();
-  for (int k = a; k < words; k += BLOCK) outRow[k] = fp[k];
+  if (valid) {
+    for (int k = a; k < words; k += LPM) outRow[k] = fp[k];
+  }
 }
 
-template <int NW, int BLOCK>
+template <int NW, int BLOCK, int MPB = 1>
 int launch_t(const uint32_t* atomInv, const uint32_t* bondInv, const int16_t* bondIdx, const int16_t* bondOther,
              const int16_t* nAtoms, const int32_t* outIdx, int64_t nMols, int radius, int fpBits, uint32_t* out,
              hipStream_t stream) {
   constexpr int STRIDE = NW * 32;
-  const size_t  shmem  = (3 * STRIDE + 2 * STRIDE * NW + static_cast<size_t>(radius) * STRIDE * NW + fpBits / 32 + 4) * 4;
-  auto          kern   = morgan_kernel<NW, BLOCK>;
+  const size_t  shmem  = MPB * (3 * STRIDE + 2 * STRIDE * NW + static_cast<size_t>(radius) * STRIDE * NW + fpBits / 32 + 4) * 4;
+  auto          kern   = morgan_kernel<NW, BLOCK, MPB>;
   if (shmem > 64 * 1024) {
     NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(shmem)));
   }
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nMols)), dim3(BLOCK), shmem, stream, atomInv, bondInv, bondIdx,
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>((nMols + MPB - 1) / MPB)), dim3(BLOCK), shmem, stream, atomInv, bondInv, bondIdx,
                      bondOther, nAtoms, outIdx, nMols, radius, fpBits, out);
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
@@ -248,7 +258,7 @@ extern "C" int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uin
   hipStream_t s = as_stream(stream);
   switch (max_atoms) {
     case 32:
-      return morgan::launch_t<1, 64>(d_atom_inv, d_bond_inv, d_bond_idx, d_bond_other, d_n_atoms, d_out_idx, n_mols, radius,
+      return morgan::launch_t<1, 64, 2>(d_atom_inv, d_bond_inv, d_bond_idx, d_bond_other, d_n_atoms, d_out_idx, n_mols, radius,
                                      fp_bits, d_out, s);
     case 64:
       return morgan::launch_t<2, 64>(d_atom_inv, d_bond_inv, d_bond_idx, d_bond_other, d_n_atoms, d_out_idx, n_mols, radius,

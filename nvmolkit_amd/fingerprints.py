@@ -44,15 +44,22 @@ _MAX_BONDS_PER_ATOM = 8  # kMaxBondsPerAtom in the reference
 _VALID_FP_SIZES = (128, 256, 512, 1024, 2048, 4096)
 
 
-def _hash_combine(seed: int, value: int) -> int:
-    return (seed ^ ((value + 0x9E3779B9 + ((seed << 6) & 0xFFFFFFFF) + (seed >> 2)) & 0xFFFFFFFF)) & 0xFFFFFFFF
+def _hash_combine_np(seed: np.ndarray, value: np.ndarray) -> np.ndarray:
+    """boost::hash_combine on uint32, vectorised (reference hash: src/morgan_fingerprint_kernels.cu:53-55)."""
+    with np.errstate(over="ignore"):
+        return seed ^ (value + np.uint32(0x9E3779B9) + (seed << np.uint32(6)) + (seed >> np.uint32(2)))
 
 
-def _hash_vector(components) -> int:
-    seed = 0
-    for c in components:
-        seed = _hash_combine(seed, int(c) & 0xFFFFFFFF)
-    return seed
+def hash_invariant_components(components: np.ndarray, in_ring: np.ndarray) -> np.ndarray:
+    """Atom invariants from (n_atoms, 5) integer components [Z, degree + Hs, Hs incl. H neighbours, formal charge,
+    int(mass - average mass)] and the ring flags: hash_range over the uint32 components, + [1] for ring atoms
+    (src/morgan_fingerprint_common.cpp:96-121).  One numpy pass for all atoms of a batch."""
+    comps = np.asarray(components, dtype=np.int64).astype(np.uint32)  # negative charges wrap like the C++ cast
+    seed = np.zeros(len(comps), dtype=np.uint32)
+    for k in range(comps.shape[1]):
+        seed = _hash_combine_np(seed, comps[:, k])
+    ring = np.asarray(in_ring, dtype=bool)
+    return np.where(ring, _hash_combine_np(seed, np.full(len(comps), 1, dtype=np.uint32)), seed)
 
 
 def morgan_invariants_from_rdkit(mols, max_atoms: int):
@@ -61,42 +68,66 @@ def morgan_invariants_from_rdkit(mols, max_atoms: int):
     Host-side counterpart of ``MorganInvariantsGenerator::ComputeInvariantsInto``
     (reference: src/morgan_fingerprint_common.cpp:43-124): atom invariant = hash of
     [Z, degree + Hs, Hs incl. H neighbours, formal charge, int(mass - average mass)] (+ [1] if in a ring),
-    bond invariant = bond type.  Needs RDKit; all chemistry perception stays RDKit's.
+    bond invariant = bond type.  Needs RDKit objects (or duck-typed stand-ins); all chemistry perception stays RDKit's
+    (SURVEY.md F7).  Per-atom / per-bond RDKit getters are collected with list comprehensions; hashing and the array
+    fill are numpy over the whole batch (the first version hashed atom by atom in Python).
     """
-    from rdkit import Chem  # noqa: F401  (gated: RDKit is the ingestion surface, not a dependency of the kernels)
-
     n = len(mols)
     atom_inv = np.zeros((n, max_atoms), dtype=np.uint32)
     bond_inv = np.zeros((n, max_atoms), dtype=np.uint32)
     bond_idx = np.full((n, max_atoms, _MAX_BONDS_PER_ATOM), -1, dtype=np.int16)
     bond_other = np.full((n, max_atoms, _MAX_BONDS_PER_ATOM), -1, dtype=np.int16)
     n_atoms = np.zeros(n, dtype=np.int16)
-    table = Chem.GetPeriodicTable()
+    table = None
+    comps, rings, owner = [], [], []
     for m, mol in enumerate(mols):
-        if mol.GetNumAtoms() >= max_atoms or mol.GetNumBonds() >= max_atoms:
+        na, nb = mol.GetNumAtoms(), mol.GetNumBonds()
+        if na >= max_atoms or nb >= max_atoms:
             raise ValueError("molecule does not fit this bucket")
-        n_atoms[m] = mol.GetNumAtoms()
+        n_atoms[m] = na
+        if na == 0:
+            continue
+        if table is None:
+            from rdkit import Chem
+
+            table = Chem.GetPeriodicTable()
+        atoms = list(mol.GetAtoms())
+        z = np.fromiter((a.GetAtomicNum() for a in atoms), dtype=np.int64, count=na)
+        hs = np.fromiter((a.GetNumExplicitHs() + a.GetNumImplicitHs() for a in atoms), dtype=np.int64, count=na)
+        charge = np.fromiter((a.GetFormalCharge() for a in atoms), dtype=np.int64, count=na)
+        dmass = np.fromiter((int(a.GetMass() - table.GetAtomicWeight(a.GetAtomicNum())) for a in atoms), dtype=np.int64, count=na)
         ring = mol.GetRingInfo()
-        for atom in mol.GetAtoms():
-            a = atom.GetIdx()
-            degree = 0
-            neighbor_hs = 0
-            for bond in atom.GetBonds():
-                if degree >= _MAX_BONDS_PER_ATOM:
-                    raise ValueError("more than 8 bonds on one atom is not supported")
-                b = bond.GetIdx()
-                bond_idx[m, a, degree] = b
-                bond_other[m, a, degree] = bond.GetOtherAtomIdx(a)
-                bond_inv[m, b] = int(bond.GetBondType())
-                if bond.GetOtherAtom(atom).GetAtomicNum() == 1:
-                    neighbor_hs += 1
-                degree += 1
-            hs = atom.GetNumExplicitHs() + atom.GetNumImplicitHs()
-            comps = [atom.GetAtomicNum(), hs + degree, hs + neighbor_hs, atom.GetFormalCharge(),
-                     int(atom.GetMass() - table.GetAtomicWeight(atom.GetAtomicNum()))]
-            if ring.NumAtomRings(a) > 0:
-                comps.append(1)
-            atom_inv[m, a] = _hash_vector(comps)
+        in_ring = np.fromiter((ring.NumAtomRings(i) > 0 for i in range(na)), dtype=bool, count=na)
+        degree = np.zeros(na, dtype=np.int64)
+        nbr_h = np.zeros(na, dtype=np.int64)
+        if nb:
+            bonds = list(mol.GetBonds())
+            bi = np.fromiter((b.GetBeginAtomIdx() for b in bonds), dtype=np.int64, count=nb)
+            bj = np.fromiter((b.GetEndAtomIdx() for b in bonds), dtype=np.int64, count=nb)
+            bond_inv[m, :nb] = np.fromiter((int(b.GetBondType()) for b in bonds), dtype=np.int64, count=nb).astype(np.uint32)
+            # slot of every (atom, bond) incidence = rank of the bond among the atom's bonds in bond-index order
+            ends = np.concatenate([bi, bj])
+            others = np.concatenate([bj, bi])
+            bidx = np.concatenate([np.arange(nb), np.arange(nb)])
+            order = np.lexsort((bidx, ends))
+            ends, others, bidx = ends[order], others[order], bidx[order]
+            first = np.searchsorted(ends, ends, side="left")
+            slot = np.arange(2 * nb) - first
+            if slot.max(initial=0) >= _MAX_BONDS_PER_ATOM:
+                raise ValueError("more than 8 bonds on one atom is not supported")
+            bond_idx[m, ends, slot] = bidx
+            bond_other[m, ends, slot] = others
+            degree = np.bincount(ends, minlength=na)
+            nbr_h = np.bincount(ends, weights=(z[others] == 1), minlength=na).astype(np.int64)
+        comps.append(np.stack([z, hs + degree, hs + nbr_h, charge, dmass], 1))
+        rings.append(in_ring)
+        owner.append((m, na))
+    if comps:
+        inv = hash_invariant_components(np.concatenate(comps), np.concatenate(rings))
+        off = 0
+        for m, na in owner:
+            atom_inv[m, :na] = inv[off:off + na]
+            off += na
     return atom_inv, bond_inv, bond_idx, bond_other, n_atoms
 
 
@@ -112,19 +143,33 @@ class MorganFingerprintGenerator:
         self._fp_size = int(fpSize)
 
     def _launch(self, flat, max_atoms: int, out: torch.Tensor, out_idx, stream) -> None:
+        """Stage one bucket and launch its kernel on ``stream`` WITHOUT synchronising (the reference's API is asynchronous:
+        per-thread pinned staging buffers + stream + event, src/morgan_fingerprint_gpu.cpp:245-250,296-310,449-454).
+        The staging runs with ``stream`` current, so the caching allocator ties the device buffers to that stream and
+        they can be released as soon as Python drops them; the pinned host buffers are parked on the output tensor until
+        the caller synchronises."""
         atom_inv, bond_inv, bond_idx, bond_other, n_atoms = flat
         dev = out.device
-        to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev, non_blocking=False)  # noqa: E731
-        d = [to_dev(atom_inv.view(np.int32)), to_dev(bond_inv.view(np.int32)), to_dev(bond_idx), to_dev(bond_other),
-             to_dev(n_atoms)]
-        d_idx = to_dev(np.asarray(out_idx, dtype=np.int32)) if out_idx is not None else None
-        rc = _native.lib().nvmk_morgan_from_invariants(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
-                                                       d[4].data_ptr(), d_idx.data_ptr() if d_idx is not None else None,
-                                                       len(n_atoms), max_atoms, self._radius, self._fp_size,
-                                                       out.data_ptr(), _native.stream_ptr(stream))
-        _native.check(rc, "nvmk_morgan_from_invariants")
-        # the staging tensors must outlive the asynchronous kernel: make the stream wait before they are freed
-        (stream if stream is not None else torch.cuda.current_stream()).synchronize()
+        keep = getattr(out, "_nvmk_staging", None)
+        if keep is None:
+            keep = []
+            out._nvmk_staging = keep
+
+        def to_dev(x):
+            h = torch.from_numpy(np.ascontiguousarray(x)).pin_memory()
+            keep.append(h)
+            return h.to(dev, non_blocking=True)
+
+        with _native.on_stream(stream, dev):
+            d = [to_dev(atom_inv.view(np.int32)), to_dev(bond_inv.view(np.int32)), to_dev(bond_idx), to_dev(bond_other),
+                 to_dev(n_atoms)]
+            d_idx = to_dev(np.asarray(out_idx, dtype=np.int32)) if out_idx is not None else None
+            with torch.cuda.device(dev):
+                rc = _native.lib().nvmk_morgan_from_invariants(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                                               d[4].data_ptr(), d_idx.data_ptr() if d_idx is not None else None,
+                                                               len(n_atoms), max_atoms, self._radius, self._fp_size,
+                                                               out.data_ptr(), _native.stream_ptr(stream))
+            _native.check(rc, "nvmk_morgan_from_invariants")
 
     def GetFingerprintsFromInvariants(self, atom_invariants, bond_invariants, bond_indices, bond_other_atoms,
                                       n_atoms, max_atoms: int, stream=None) -> AsyncGpuResult:
@@ -147,7 +192,9 @@ class MorganFingerprintGenerator:
         Molecules are bucketed by size (atoms and bonds < 32 / 64 / 128 / 256) exactly like the reference
         (src/morgan_fingerprint_gpu.cpp:253-268).  The reference computes molecules of 128 atoms or more on
         the CPU; here they run in the 256 bucket and anything larger raises (no CPU fallback in this build).
-        ``num_threads`` is accepted for API compatibility (the Python adapter is single-threaded).
+        Buckets are staged and launched back to back on ``stream`` with no host synchronisation in between; the result is
+        an ``AsyncGpuResult`` like the reference's.  ``num_threads`` is accepted for API compatibility (invariants are
+        gathered on the calling thread: RDKit's Python getters hold the GIL).
         """
         _native.stream_ptr(stream)
         if self._fp_size not in _VALID_FP_SIZES:

@@ -21,9 +21,33 @@ class _Enum:
         return self.name
 
 
+class _IntEnum(_Enum):
+    def __init__(self, name, value):
+        super().__init__(name)
+        self.value = value
+
+    def __int__(self):
+        return self.value
+
+
+BOND_TYPE_VALUES = {"SINGLE": 1, "DOUBLE": 2, "TRIPLE": 3, "AROMATIC": 12}  # RDKit::Bond::BondType
+
+
 class FakeAtom:
-    def __init__(self, mol, idx, z, tag="CHI_UNSPECIFIED", hyb="SP3"):
-        self.mol, self.idx, self.z, self.tag, self.hyb = mol, idx, z, tag, hyb
+    def __init__(self, mol, idx, z, tag="CHI_UNSPECIFIED", hyb="SP3", n_h=0, charge=0):
+        self.mol, self.idx, self.z, self.tag, self.hyb, self.n_h, self.charge = mol, idx, z, tag, hyb, n_h, charge
+
+    def GetNumExplicitHs(self):
+        return 0
+
+    def GetNumImplicitHs(self):
+        return self.n_h
+
+    def GetFormalCharge(self):
+        return self.charge
+
+    def GetMass(self):
+        return 2.0 * self.z
 
     def GetIdx(self):
         return self.idx
@@ -52,7 +76,10 @@ class FakeBond:
         return self.j
 
     def GetBondType(self):
-        return _Enum(self.btype)
+        if isinstance(self.btype, int):
+            name = {v: k for k, v in BOND_TYPE_VALUES.items()}.get(self.btype, f"BT{self.btype}")
+            return _IntEnum(name, self.btype)
+        return _IntEnum(self.btype, BOND_TYPE_VALUES.get(self.btype, 0))
 
     def GetStereo(self):
         return _Enum(self.stereo)
@@ -127,6 +154,9 @@ class FakeMol:
     def GetNumAtoms(self):
         return len(self.atoms)
 
+    def GetNumBonds(self):
+        return len(self.bonds)
+
     def GetAtoms(self):
         return self.atoms
 
@@ -197,6 +227,12 @@ def install():
 
     dg.GetMoleculeBoundsMatrix = bounds
     dg.GetExperimentalTorsions = lambda mol, params=None: tuple(mol.torsions)
+    class _Table:
+        @staticmethod
+        def GetAtomicWeight(z):
+            return 2.0 * z
+
+    chem.GetPeriodicTable = lambda: _Table()
     chem.Conformer = FakeConformer
     chem.rdDistGeom = dg
     geom.Point3D = Point3D

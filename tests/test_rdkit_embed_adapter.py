@@ -151,3 +151,26 @@ def test_embed_molecules_end_to_end_on_duck_typed_molecules():
         pruned = fr.FakeEmbedParameters(randomSeed=7, pruneRmsThresh=50.0)         # absurd threshold: one survivor each
         EmbedMolecules(mols, pruned, confsPerMolecule=3, maxIterations=10)
         assert [m.GetNumConformers() for m in mols] == [1, 1, 1, 1]
+
+
+def test_morgan_invariants_adapter_matches_the_scalar_restatement():
+    """fingerprints.morgan_invariants_from_rdkit (vectorised: M1, src/morgan_fingerprint_common.cpp:43-124) on duck-typed
+    molecules == tests/util.flatten_molecules (atom-by-atom hashing through the C oracle's hash_range)."""
+    from nvmolkit_amd.fingerprints import morgan_invariants_from_rdkit
+    from tests import util
+
+    graphs = util.random_molecule_batch(40, 64, seed=3, min_atoms=1) + [([], []), ([(6, 4, 0, False)], [])]
+    mols = []
+    for atoms, bonds in graphs:
+        m = fr.FakeMol([a[0] for a in atoms], [fr.FakeBond(i, j, int(t)) for i, j, t in bonds],
+                       rings=[{i for i, a in enumerate(atoms) if a[3]}] if any(a[3] for a in atoms) else ())
+        for fa, (z, nh, q, ring) in zip(m.atoms, atoms):
+            fa.n_h, fa.charge = nh, q
+        mols.append(m)
+    with fr.install():
+        got = morgan_invariants_from_rdkit(mols, 64)
+    want = util.flatten_molecules(graphs, 64)
+    for g, w in zip(got, want):
+        assert g.dtype == w.dtype and np.array_equal(g, w)
+    with fr.install(), pytest.raises(ValueError, match="bucket"):
+        morgan_invariants_from_rdkit(mols[:3], 4)
