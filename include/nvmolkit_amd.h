@@ -134,6 +134,12 @@ int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, d
  *   d_hit       : N x N uint8 adjacency (used when d_dist is NULL)
  *   d_clusters  : N int32 out; cluster ids, id 0 = largest cluster, ties by ascending original id
  *   d_centroids : N int32 capacity out or NULL; centroid row of each cluster id
+ *   neighborlist_max_size : must be one of 8 / 16 / 24 / 32 / 64 / 128 like the reference (nvmolkit/clustering.py:79-82) and
+ *                 is otherwise IGNORED: it sizes the neighbour lists of the reference's small-cluster phase
+ *                 (src/butina.cu:975-1004); this implementation has one phase (byte hit matrix + its transpose, contiguous
+ *                 row / column reads every round), so there is nothing for it to tune.  Results do not depend on it in the
+ *                 reference either.
+ * Singleton ids and the renumbering by size (src/butina.cu:281-307, :369-448) run on the device.
  */
 int nvmk_butina_dense(const double* d_dist, const uint8_t* d_hit, int64_t N, double cutoff, int neighborlist_max_size,
                       int32_t* d_clusters, int32_t* d_centroids, int64_t* h_n_clusters, void* stream);

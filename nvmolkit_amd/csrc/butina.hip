@@ -1358,6 +1358,47 @@ __global__ void dense_finish_kernel(DenseState* __restrict__ st, const int parit
   st->nMembers = 0;
 }
 
+// ---- singleton ids and renumbering by size, on the device (src/butina.cu:281-307, :369-448) -----------------------
+// flags[i] = 1 for points no cluster took; their exclusive prefix sum ranks them in ascending index order.
+__global__ void dense_unassigned_flags_kernel(const int32_t* __restrict__ clusters, const int64_t N, int32_t* __restrict__ flags) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < N) flags[i] = clusters[i] < 0 ? 1 : 0;
+}
+// singleton cluster ids follow the greedy clusters in ascending point order; sizes are histogrammed on the way
+__global__ void dense_singletons_kernel(const DenseState* __restrict__ st, int32_t* __restrict__ clusters, const int32_t* __restrict__ rank,
+                                        const int64_t N, int32_t* __restrict__ centroids, int32_t* __restrict__ sizes) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int c = clusters[i];
+  if (c < 0) {
+    c            = st->nClusters + rank[i];
+    clusters[i]  = c;
+    centroids[c] = static_cast<int32_t>(i);
+  }
+  atomicAdd(&sizes[c], 1);
+}
+__global__ void dense_total_kernel(const DenseState* __restrict__ st, const int32_t* __restrict__ rank, const int32_t* __restrict__ flags,
+                                   const int64_t N, int32_t* __restrict__ nTotal) {
+  *nTotal = st->nClusters + rank[N - 1] + flags[N - 1];
+}
+// order[newId] = old id (ids sorted by size, descending, stable) -> remap[old] = newId, newCent[newId] = cent[old]
+__global__ void dense_remap_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ nTotal, const int32_t* __restrict__ cent,
+                                   int32_t* __restrict__ remap, int32_t* __restrict__ newCent) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= *nTotal) return;
+  const int old = order[k];
+  remap[old]    = k;
+  if (newCent) newCent[k] = cent[old];
+}
+__global__ void dense_apply_remap_kernel(int32_t* __restrict__ clusters, const int32_t* __restrict__ remap, const int64_t N) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < N) clusters[i] = remap[clusters[i]];
+}
+__global__ void iota32_kernel(int32_t* __restrict__ v, const int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = static_cast<int32_t>(i);
+}
+
 }  // namespace butina
 }  // namespace nvmk
 
@@ -1424,8 +1465,11 @@ int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, d
 
 int nvmk_butina_dense(const double* d_dist, const uint8_t* d_hit, int64_t N, double cutoff, int neighborlist_max_size,
                       int32_t* d_clusters, int32_t* d_centroids, int64_t* h_n_clusters, void* stream_) {
-  // neighborlist_max_size only tunes the reference's small-cluster phase (src/butina.cu:975-1004); it is
-  // validated for API compatibility (nvmolkit/clustering.py:79-82) and otherwise unused here.
+  // neighborlist_max_size only tunes the reference's small-cluster phase (src/butina.cu:975-1004: clusters below that
+  // size are resolved from per-point neighbour lists instead of matrix rows).  This implementation has a single phase —
+  // the hit matrix is thresholded to bytes once and every round reads contiguous rows / columns of it — so the parameter
+  // changes nothing here: it is validated for API compatibility (nvmolkit/clustering.py:79-82) and IGNORED
+  // (include/nvmolkit_amd.h says so).
   const int nl = neighborlist_max_size;
   NVMK_REQUIRE(nl == 8 || nl == 16 || nl == 24 || nl == 32 || nl == 64 || nl == 128,
                "neighborlistMaxSize must be 8, 16, 24, 32, 64, or 128. Got: %d", nl);
@@ -1476,37 +1520,46 @@ int nvmk_butina_dense(const double* d_dist, const uint8_t* d_hit, int64_t N, dou
     if (snap.done) break;
   }
 
-  // singletons (ascending index) + renumber by descending size, stable by original id
-  // (assignSingletonIdsKernel src/butina.cu:281-307, renumberClustersBySize :369-448) — O(N) on the host.
-  std::vector<int32_t> cl(n), cent(n);
-  NVMK_HIP_CHECK(hipMemcpyAsync(cl.data(), d_clusters, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  NVMK_HIP_CHECK(hipMemcpyAsync(cent.data(), centroids, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  // singletons (ascending index) + renumber by descending size, stable by original id (assignSingletonIdsKernel
+  // src/butina.cu:281-307, renumberClustersBySize :369-448) — on the device: prefix sum of the unassigned flags, size
+  // histogram, one stable radix sort of the cluster ids by size, two remap kernels.  Only the cluster count comes back.
+  StreamScratch rn, tmp;
+  NVMK_HIP_CHECK(rn.alloc((8 * n + 16) * sizeof(int32_t), stream));
+  int32_t* flags   = rn.as<int32_t>();
+  int32_t* rank    = flags + n;
+  int32_t* sizes   = rank + n;
+  int32_t* sizesS  = sizes + n;
+  int32_t* ids     = sizesS + n;
+  int32_t* order   = ids + n;
+  int32_t* remap   = order + n;
+  int32_t* newCent = remap + n;
+  int32_t* nTotal  = newCent + n;
+  const unsigned nb256 = static_cast<unsigned>(ceil_div<int64_t>(N, 256));
+  NVMK_HIP_CHECK(hipMemsetAsync(sizes, 0, n * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(dense_unassigned_flags_kernel, dim3(nb256), dim3(256), 0, stream, d_clusters, N, flags);
+  size_t tmpBytes = 0, sortBytes = 0;
+  NVMK_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, flags, rank, static_cast<int>(N), stream));
+  NVMK_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sortBytes, sizes, sizesS, ids, order, static_cast<int>(N), 0, 32, stream));
+  NVMK_HIP_CHECK(tmp.alloc(std::max(tmpBytes, sortBytes), stream));
+  NVMK_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.ptr, tmpBytes, flags, rank, static_cast<int>(N), stream));
+  hipLaunchKernelGGL(dense_total_kernel, dim3(1), dim3(1), 0, stream, st, rank, flags, N, nTotal);
+  hipLaunchKernelGGL(dense_singletons_kernel, dim3(nb256), dim3(256), 0, stream, st, d_clusters, rank, N, centroids, sizes);
+  hipLaunchKernelGGL(iota32_kernel, dim3(nb256), dim3(256), 0, stream, ids, N);
+  NVMK_LAUNCH_CHECK();
+  int32_t nTot = 0;
+  NVMK_HIP_CHECK(hipMemcpyAsync(&nTot, nTotal, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   NVMK_HIP_CHECK(hipStreamSynchronize(stream));
-  int64_t nC = snap.nClusters;
-  for (size_t i = 0; i < n; ++i) {
-    if (cl[i] < 0) {
-      cl[i]                          = static_cast<int32_t>(nC);
-      cent[static_cast<size_t>(nC++)] = static_cast<int32_t>(i);
-    }
-  }
-  std::vector<int64_t> sizes(static_cast<size_t>(nC), 0);
-  for (size_t i = 0; i < n; ++i) sizes[static_cast<size_t>(cl[i])]++;
-  std::vector<int32_t> order(static_cast<size_t>(nC));
-  for (int64_t c = 0; c < nC; ++c) order[static_cast<size_t>(c)] = static_cast<int32_t>(c);
-  std::stable_sort(order.begin(), order.end(),
-                   [&](int32_t a, int32_t b) { return sizes[static_cast<size_t>(a)] > sizes[static_cast<size_t>(b)]; });
-  std::vector<int32_t> remap(static_cast<size_t>(nC)), newCent(static_cast<size_t>(nC));
-  for (int64_t newId = 0; newId < nC; ++newId) {
-    remap[static_cast<size_t>(order[static_cast<size_t>(newId)])] = static_cast<int32_t>(newId);
-    newCent[static_cast<size_t>(newId)]                           = cent[static_cast<size_t>(order[static_cast<size_t>(newId)])];
-  }
-  for (size_t i = 0; i < n; ++i) cl[i] = remap[static_cast<size_t>(cl[i])];
-  NVMK_HIP_CHECK(hipMemcpyAsync(d_clusters, cl.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  const int64_t nC = nTot;
+  // ids beyond nC have size 0 and sort behind every real cluster (stable), so sorting all N slots is harmless
+  NVMK_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(tmp.ptr, sortBytes, sizes, sizesS, ids, order, static_cast<int>(nC), 0, 32, stream));
+  const unsigned cb = static_cast<unsigned>(ceil_div<int64_t>(std::max<int64_t>(nC, 1), 256));
+  hipLaunchKernelGGL(dense_remap_kernel, dim3(cb), dim3(256), 0, stream, order, nTotal, centroids, remap, d_centroids ? newCent : nullptr);
+  hipLaunchKernelGGL(dense_apply_remap_kernel, dim3(nb256), dim3(256), 0, stream, d_clusters, remap, N);
+  NVMK_LAUNCH_CHECK();
   if (d_centroids) {
-    NVMK_HIP_CHECK(hipMemcpyAsync(d_centroids, newCent.data(), static_cast<size_t>(nC) * sizeof(int32_t),
-                                  hipMemcpyHostToDevice, stream));
+    NVMK_HIP_CHECK(hipMemcpyAsync(d_centroids, newCent, static_cast<size_t>(nC) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
   }
-  NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors die at return
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // scratch is released in stream order; the caller reads d_clusters next
   if (h_n_clusters) *h_n_clusters = nC;
   return NVMK_OK;
 }
