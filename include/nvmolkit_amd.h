@@ -126,6 +126,22 @@ int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, d
                       int32_t* h_cluster_indices, int64_t* h_offsets, int32_t* h_centroids, int64_t* n_clusters,
                       void* stream);
 
+/* Fused Butina in two steps, for row-sharding the all-pairs pass over several GPUs (the reference is
+ * single-GPU here: nvmolkit/clustering.py:99-189).
+ *   nvmk_butina_pairs      : shard `shard` of `n_shards` evaluates its band of 128-row tile rows of the symmetric pass
+ *                            (bands of equal area).  d_counts (N int32, overwritten) receives the PARTIAL neighbour counts of
+ *                            all rows from those tiles; d_pairs (2 * pair_capacity int32) the neighbour pairs (i, j) found,
+ *                            each once, original row numbers; *h_n_pairs their number.  NVMK_ERR_OUT_OF_MEMORY when they do
+ *                            not fit (*h_n_pairs still says how many there were).
+ *   nvmk_butina_from_pairs : the clustering from the full degrees (sum of the shards' counts) and the concatenated pairs
+ *                            — the same device-side round loop nvmk_butina_fused runs; outputs as nvmk_butina_fused.
+ * One shard (shard 0 of 1) followed by from_pairs gives exactly nvmk_butina_fused's clusters; every rank that runs
+ * from_pairs on the assembled graph gets the same answer, so no per-round collective is needed. */
+int nvmk_butina_pairs(int metric, const uint32_t* d_x, int64_t N, int fp_bits, double cutoff, int shard, int n_shards,
+                      int32_t* d_counts, int32_t* d_pairs, uint64_t pair_capacity, uint64_t* h_n_pairs, void* stream);
+int nvmk_butina_from_pairs(int64_t N, const int32_t* d_counts, const int32_t* d_pairs, uint64_t n_pairs, int32_t* h_cluster_indices,
+                           int64_t* h_offsets, int32_t* h_centroids, int64_t* n_clusters, void* stream);
+
 /* ---- B1: Taylor-Butina on a dense matrix ----------------------------------------------------------
  * Replaces butinaGpu(span<const double>, ...) and butinaGpu(span<const uint8_t>, ...)
  * (src/butina.cu:1017-1071).  Blocking (the reference also synchronises the stream before returning,

@@ -53,6 +53,9 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_cross_similarity_host_f64": (_int, [_int, _vp, _i64, _vp, _i64, _int, _vp, _i64]),
     "nvmk_neighbor_counts": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _i64, _int, ctypes.c_float, _int, _vp, _vp]),
     "nvmk_butina_fused": (_int, [_int, _vp, _i64, _int, ctypes.c_double, _vp, _vp, _vp, ctypes.POINTER(_i64), _vp]),
+    "nvmk_butina_pairs": (_int, [_int, _vp, _i64, _int, ctypes.c_double, _int, _int, _vp, _vp, ctypes.c_uint64,
+                                 ctypes.POINTER(ctypes.c_uint64), _vp]),
+    "nvmk_butina_from_pairs": (_int, [_i64, _vp, _vp, ctypes.c_uint64, _vp, _vp, _vp, ctypes.POINTER(_i64), _vp]),
     "nvmk_morgan_from_invariants": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "nvmk_ff_energy": (_int, [_vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "nvmk_ff_gradient": (_int, [_vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),

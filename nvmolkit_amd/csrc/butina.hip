@@ -945,6 +945,161 @@ inline bool sorted_first_pass() {  // default on; NVMK_BUTINA_SORT=0 keeps the i
   return e == nullptr || e[0] != '0';
 }
 
+// Buffers of a fused-Butina run: one scratch block | state | nAliveNext[2] | counts | alive[2] | removed | clusterIndices |
+// offsets | centroids.
+struct RoundBuffers {
+  LoopState* st;
+  int32_t *  nAliveNext, *counts, *alive0, *alive1, *removed, *clusterIdx, *offsets, *centroids;
+};
+
+inline int alloc_round_buffers(StreamScratch& mem, const int64_t N, hipStream_t stream, RoundBuffers& b) {
+  const size_t n    = static_cast<size_t>(N);
+  const size_t ints = 64 + n * 7 + 8;
+  NVMK_HIP_CHECK(mem.alloc(ints * sizeof(int32_t), stream));
+  auto* base   = mem.as<int32_t>();
+  b.st         = reinterpret_cast<LoopState*>(base);
+  b.nAliveNext = base + 32;  // [2]
+  b.counts     = base + 64;
+  b.alive0     = b.counts + n;
+  b.alive1     = b.alive0 + n;
+  b.removed    = b.alive1 + n;
+  b.clusterIdx = b.removed + n;
+  b.offsets    = b.clusterIdx + n;  // n + 1 entries
+  b.centroids  = b.offsets + n + 1;
+  NVMK_HIP_CHECK(hipMemsetAsync(base, 0, (64 + n) * sizeof(int32_t), stream));  // state + nAliveNext + counts
+  NVMK_HIP_CHECK(hipMemsetAsync(b.offsets, 0, sizeof(int32_t), stream));
+  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, b.st, static_cast<int32_t>(N));
+  hipLaunchKernelGGL(iota_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream, b.alive0, N);
+  NVMK_LAUNCH_CHECK();
+  return NVMK_OK;
+}
+
+// The round loop on the sparse neighbour graph: `edges` holds every neighbour pair once (original row numbers), b.counts
+// the degrees.  CSR (degrees -> exclusive scan -> fill), then epochs of the device-side loop.  On return `snap` is the
+// final loop state with nAlive = 0 (leftovers already sit in the singleton tail).
+inline int graph_rounds(const RoundBuffers& b, const int64_t N, const int2* edges, const unsigned long long nEdges, hipStream_t stream,
+                        LoopState& snap) {
+  const size_t n = static_cast<size_t>(N);
+  LoopState*   st = b.st;
+  int32_t *    counts = b.counts, *clusterIdx = b.clusterIdx, *offsets = b.offsets, *centroids = b.centroids, *nAliveNext = b.nAliveNext;
+  // CSR: degrees -> exclusive scan -> fill
+  StreamScratch csrMem, scanTmp;
+  const size_t  offBytes = (n + 1) * sizeof(unsigned long long);
+  const size_t  nbrBytes = std::max<size_t>(1, static_cast<size_t>(2 * nEdges)) * sizeof(int32_t);
+  // layout: deg[n+1] | offsets[n+1] | cursor[n] (u32) | L0[n] | L1[n] | nbr[2E]
+  const size_t bytes = 2 * offBytes + n * 4 * 3 + nbrBytes + 64;
+  NVMK_HIP_CHECK(csrMem.alloc(bytes, stream));
+  auto* deg     = csrMem.as<unsigned long long>();
+  auto* offs64  = deg + (n + 1);
+  auto* cursor  = reinterpret_cast<unsigned int*>(offs64 + (n + 1));
+  auto* L0      = reinterpret_cast<int32_t*>(cursor + n);
+  auto* L1      = L0 + n;
+  auto* nbr     = L1 + n;
+  NVMK_HIP_CHECK(hipMemsetAsync(deg, 0, 2 * offBytes + n * 4, stream));  // deg, offsets, cursor
+  const unsigned eBlocks = static_cast<unsigned>(std::min<unsigned long long>(ceil_div<unsigned long long>(std::max<unsigned long long>(nEdges, 1), 256), 65535));
+  if (nEdges > 0) {
+    hipLaunchKernelGGL(edge_degree_kernel, dim3(eBlocks), dim3(256), 0, stream, edges, nEdges, deg);
+    NVMK_LAUNCH_CHECK();
+  }
+  size_t tmpBytes = 0;
+  NVMK_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, deg, offs64, static_cast<int>(n + 1), stream));
+  NVMK_HIP_CHECK(scanTmp.alloc(tmpBytes, stream));
+  NVMK_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp.ptr, tmpBytes, deg, offs64, static_cast<int>(n + 1), stream));
+  if (nEdges > 0) {
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(eBlocks), dim3(256), 0, stream, edges, nEdges, offs64, cursor, nbr);
+    NVMK_LAUNCH_CHECK();
+  }
+  int32_t* nL = nAliveNext;  // [2], zeroed above with the state block
+  hipLaunchKernelGGL(sparse_init_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
+                     static_cast<int32_t>(N), counts, L0, &nL[0]);
+  NVMK_LAUNCH_CHECK();
+  // epochs: build the bucket of the current maximal degree (4 small kernels), run rounds off it (1 persistent kernel)
+  StreamScratch bucketMem;
+  const int     nBuckets = static_cast<int>(ceil_div<int64_t>(N, BUCKET_ROWS));
+  NVMK_HIP_CHECK(bucketMem.alloc((n + nBuckets + 16) * sizeof(int32_t), stream));
+  int32_t*       cand        = bucketMem.as<int32_t>();
+  int32_t*       blockCounts = cand + n;
+  const unsigned maxBlocks   = static_cast<unsigned>(std::min<int64_t>(ceil_div<int64_t>(N, NT * 4), 1024));
+  for (int64_t guard = 0;; ++guard) {
+    // every epoch with a non-empty bucket forms at least one cluster and the empty one ends the loop, so N epochs
+    // are an upper bound; anything beyond is a bug and must not spin on the GPU box
+    NVMK_REQUIRE(guard * 4 <= N + 8, "fused butina: the round loop did not terminate (internal error)");
+    for (int e = 0; e < 4; ++e) {
+      hipLaunchKernelGGL(bucket_max_kernel, dim3(maxBlocks), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts);
+      hipLaunchKernelGGL(bucket_count_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts);
+      hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(NT), 0, stream, st, blockCounts, nBuckets);
+      hipLaunchKernelGGL(bucket_fill_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts, cand);
+      hipLaunchKernelGGL(sparse_loop_kernel, dim3(1), dim3(LNT), 0, stream, st, offs64, nbr, counts, clusterIdx, offsets, centroids,
+                         L0, L1, nL, cand);
+    }
+    NVMK_LAUNCH_CHECK();
+    NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    if (snap.done) break;
+  }
+  hipLaunchKernelGGL(sparse_leftover_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
+                     st, static_cast<int32_t>(N), counts, clusterIdx);
+  NVMK_LAUNCH_CHECK();
+  NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // csrMem / scanTmp are released in stream order after this
+  snap.nAlive = 0;                               // leftovers already sit in the singleton tail
+  return NVMK_OK;
+}
+
+// Read the clusters back and canonicalise on the host (member order from atomics is unspecified).
+inline int read_back(const RoundBuffers& b, const int64_t N, const LoopState& snap, int32_t* h_idx, int64_t* h_offsets,
+                     int32_t* h_centroids, int64_t* n_clusters, hipStream_t stream) {
+  const size_t   n = static_cast<size_t>(N);
+  const int32_t *clusterIdx = b.clusterIdx, *offsets = b.offsets, *centroids = b.centroids, *alive0 = b.alive0, *alive1 = b.alive1;
+  // ---- read back and canonicalise on the host (member order from atomics is unspecified) ----
+  const int64_t nGreedy = snap.nClusters;
+  std::vector<int32_t> idx(n), offs(static_cast<size_t>(nGreedy) + 1), cent(static_cast<size_t>(nGreedy));
+  NVMK_HIP_CHECK(hipMemcpyAsync(idx.data(), clusterIdx, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  NVMK_HIP_CHECK(hipMemcpyAsync(offs.data(), offsets, offs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  if (nGreedy > 0) {
+    NVMK_HIP_CHECK(hipMemcpyAsync(cent.data(), centroids, cent.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  }
+  // rows still alive when the loop stopped have degree 0 (all-zero fingerprints)
+  const int32_t* aliveFinal = snap.finalParity ? alive1 : alive0;
+  std::vector<int32_t> leftovers(static_cast<size_t>(snap.nAlive));
+  if (snap.nAlive > 0) {
+    NVMK_HIP_CHECK(hipMemcpyAsync(leftovers.data(), aliveFinal, leftovers.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                  stream));
+  }
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+
+  int64_t pos = 0;
+  h_offsets[0] = 0;
+  for (int64_t k = 0; k < nGreedy; ++k) {
+    const int32_t c    = cent[static_cast<size_t>(k)];
+    int32_t*      dst  = h_idx + pos;
+    int64_t       m    = 0;
+    dst[m++]           = c;
+    for (int32_t q = offs[static_cast<size_t>(k)]; q < offs[static_cast<size_t>(k) + 1]; ++q) {
+      if (idx[static_cast<size_t>(q)] != c) dst[m++] = idx[static_cast<size_t>(q)];
+    }
+    std::sort(dst + 1, dst + m);
+    h_centroids[k] = c;
+    pos += m;
+    h_offsets[k + 1] = pos;
+  }
+  std::vector<int32_t> singles(idx.begin() + (snap.back + 1), idx.end());
+  singles.insert(singles.end(), leftovers.begin(), leftovers.end());
+  std::sort(singles.begin(), singles.end());
+  int64_t k = nGreedy;
+  for (const int32_t s : singles) {
+    h_idx[pos++]   = s;
+    h_centroids[k] = s;
+    h_offsets[++k] = pos;
+  }
+  if (pos != N) {
+    set_last_error("fused butina: internal accounting error (%lld of %lld rows assigned)", (long long)pos, (long long)N);
+    return NVMK_ERR_INTERNAL;
+  }
+  *n_clusters = k;
+  return NVMK_OK;
+}
+
 template <int METRIC>
 int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_t* h_idx, int64_t* h_offsets,
                int32_t* h_centroids, int64_t* n_clusters, hipStream_t stream) {
@@ -959,26 +1114,13 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
   int           rc = make_plan(plan, tableMem, METRIC, fpBits, thr, stream);
   if (rc != NVMK_OK) return rc;
 
-  // one scratch block: state | nAliveNext[2] | counts | alive[2] | removed | clusterIndices | offsets | centroids
-  const size_t n      = static_cast<size_t>(N);
-  const size_t ints   = 64 + n * 7 + 8;
-  NVMK_HIP_CHECK(mem.alloc(ints * sizeof(int32_t), stream));
-  auto*    base       = mem.as<int32_t>();
-  auto*    st         = reinterpret_cast<LoopState*>(base);
-  int32_t* nAliveNext = base + 32;  // [2]
-  int32_t* counts     = base + 64;
-  int32_t* alive0     = counts + n;
-  int32_t* alive1     = alive0 + n;
-  int32_t* removed    = alive1 + n;
-  int32_t* clusterIdx = removed + n;
-  int32_t* offsets    = clusterIdx + n;  // n + 1 entries
-  int32_t* centroids  = offsets + n + 1;
-  NVMK_HIP_CHECK(hipMemsetAsync(base, 0, (64 + n) * sizeof(int32_t), stream));  // state + nAliveNext + counts
-  NVMK_HIP_CHECK(hipMemsetAsync(offsets, 0, sizeof(int32_t), stream));
-  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, st, static_cast<int32_t>(N));
-  hipLaunchKernelGGL(iota_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream, alive0,
-                     N);
-  NVMK_LAUNCH_CHECK();
+  const size_t n = static_cast<size_t>(N);
+  RoundBuffers rb{};
+  rc = alloc_round_buffers(mem, N, stream, rb);
+  if (rc != NVMK_OK) return rc;
+  LoopState* st         = rb.st;
+  int32_t *  nAliveNext = rb.nAliveNext, *counts = rb.counts, *alive0 = rb.alive0, *alive1 = rb.alive1, *removed = rb.removed,
+          *clusterIdx = rb.clusterIdx, *offsets = rb.offsets, *centroids = rb.centroids;
 
   // Matrix-core path: expand the whole set to FP4 once (4x the packed bytes); every counting pass then
   // gathers rows of it through the alive / removed index lists.  NVMK_SIM_PATH=valu keeps the v_bcnt kernels.
@@ -1079,71 +1221,12 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
     }
     if (nEdges <= edgeCap) {  // otherwise: too dense for the edge buffer, the dense rounds below handle it
       if (sortPass && nEdges > 0) {
-        const unsigned rb = static_cast<unsigned>(std::min<unsigned long long>(ceil_div<unsigned long long>(nEdges, 256), 65535));
-        hipLaunchKernelGGL(remap_edges_kernel, dim3(rb), dim3(256), 0, stream, edges, nEdges, perm);
+        const unsigned eb = static_cast<unsigned>(std::min<unsigned long long>(ceil_div<unsigned long long>(nEdges, 256), 65535));
+        hipLaunchKernelGGL(remap_edges_kernel, dim3(eb), dim3(256), 0, stream, edges, nEdges, perm);
         NVMK_LAUNCH_CHECK();
       }
-      // CSR: degrees -> exclusive scan -> fill
-      StreamScratch csrMem, scanTmp;
-      const size_t  offBytes = (n + 1) * sizeof(unsigned long long);
-      const size_t  nbrBytes = std::max<size_t>(1, static_cast<size_t>(2 * nEdges)) * sizeof(int32_t);
-      // layout: deg[n+1] | offsets[n+1] | cursor[n] (u32) | L0[n] | L1[n] | nbr[2E]
-      const size_t bytes = 2 * offBytes + n * 4 * 3 + nbrBytes + 64;
-      NVMK_HIP_CHECK(csrMem.alloc(bytes, stream));
-      auto* deg     = csrMem.as<unsigned long long>();
-      auto* offs64  = deg + (n + 1);
-      auto* cursor  = reinterpret_cast<unsigned int*>(offs64 + (n + 1));
-      auto* L0      = reinterpret_cast<int32_t*>(cursor + n);
-      auto* L1      = L0 + n;
-      auto* nbr     = L1 + n;
-      NVMK_HIP_CHECK(hipMemsetAsync(deg, 0, 2 * offBytes + n * 4, stream));  // deg, offsets, cursor
-      const unsigned eBlocks = static_cast<unsigned>(std::min<unsigned long long>(ceil_div<unsigned long long>(std::max<unsigned long long>(nEdges, 1), 256), 65535));
-      if (nEdges > 0) {
-        hipLaunchKernelGGL(edge_degree_kernel, dim3(eBlocks), dim3(256), 0, stream, edges, nEdges, deg);
-        NVMK_LAUNCH_CHECK();
-      }
-      size_t tmpBytes = 0;
-      NVMK_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, deg, offs64, static_cast<int>(n + 1), stream));
-      NVMK_HIP_CHECK(scanTmp.alloc(tmpBytes, stream));
-      NVMK_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp.ptr, tmpBytes, deg, offs64, static_cast<int>(n + 1), stream));
-      if (nEdges > 0) {
-        hipLaunchKernelGGL(csr_fill_kernel, dim3(eBlocks), dim3(256), 0, stream, edges, nEdges, offs64, cursor, nbr);
-        NVMK_LAUNCH_CHECK();
-      }
-      int32_t* nL = nAliveNext;  // [2], zeroed above with the state block
-      hipLaunchKernelGGL(sparse_init_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
-                         static_cast<int32_t>(N), counts, L0, &nL[0]);
-      NVMK_LAUNCH_CHECK();
-      // epochs: build the bucket of the current maximal degree (4 small kernels), run rounds off it (1 persistent kernel)
-      StreamScratch bucketMem;
-      const int     nBuckets = static_cast<int>(ceil_div<int64_t>(N, BUCKET_ROWS));
-      NVMK_HIP_CHECK(bucketMem.alloc((n + nBuckets + 16) * sizeof(int32_t), stream));
-      int32_t*       cand        = bucketMem.as<int32_t>();
-      int32_t*       blockCounts = cand + n;
-      const unsigned maxBlocks   = static_cast<unsigned>(std::min<int64_t>(ceil_div<int64_t>(N, NT * 4), 1024));
-      for (int64_t guard = 0;; ++guard) {
-        // every epoch with a non-empty bucket forms at least one cluster and the empty one ends the loop, so N epochs
-        // are an upper bound; anything beyond is a bug and must not spin on the GPU box
-        NVMK_REQUIRE(guard * 4 <= N + 8, "fused butina: the round loop did not terminate (internal error)");
-        for (int e = 0; e < 4; ++e) {
-          hipLaunchKernelGGL(bucket_max_kernel, dim3(maxBlocks), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts);
-          hipLaunchKernelGGL(bucket_count_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts);
-          hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(NT), 0, stream, st, blockCounts, nBuckets);
-          hipLaunchKernelGGL(bucket_fill_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts, cand);
-          hipLaunchKernelGGL(sparse_loop_kernel, dim3(1), dim3(LNT), 0, stream, st, offs64, nbr, counts, clusterIdx, offsets, centroids,
-                             L0, L1, nL, cand);
-        }
-        NVMK_LAUNCH_CHECK();
-        NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
-        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
-        if (snap.done) break;
-      }
-      hipLaunchKernelGGL(sparse_leftover_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
-                         st, static_cast<int32_t>(N), counts, clusterIdx);
-      NVMK_LAUNCH_CHECK();
-      NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
-      NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // csrMem / scanTmp are released in stream order after this
-      snap.nAlive = 0;                               // leftovers already sit in the singleton tail
+      rc = graph_rounds(rb, N, edges, nEdges, stream, snap);
+      if (rc != NVMK_OK) return rc;
       sparseDone  = true;
     }
   }
@@ -1182,52 +1265,100 @@ int fused_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int32_
     batch     = 32;
   }
 
-  // ---- read back and canonicalise on the host (member order from atomics is unspecified) ----
-  const int64_t nGreedy = snap.nClusters;
-  std::vector<int32_t> idx(n), offs(static_cast<size_t>(nGreedy) + 1), cent(static_cast<size_t>(nGreedy));
-  NVMK_HIP_CHECK(hipMemcpyAsync(idx.data(), clusterIdx, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  NVMK_HIP_CHECK(hipMemcpyAsync(offs.data(), offsets, offs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  if (nGreedy > 0) {
-    NVMK_HIP_CHECK(hipMemcpyAsync(cent.data(), centroids, cent.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  }
-  // rows still alive when the loop stopped have degree 0 (all-zero fingerprints)
-  const int32_t* aliveFinal = snap.finalParity ? alive1 : alive0;
-  std::vector<int32_t> leftovers(static_cast<size_t>(snap.nAlive));
-  if (snap.nAlive > 0) {
-    NVMK_HIP_CHECK(hipMemcpyAsync(leftovers.data(), aliveFinal, leftovers.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                  stream));
-  }
-  NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+  return read_back(rb, N, snap, h_idx, h_offsets, h_centroids, n_clusters, stream);
+}
 
-  int64_t pos = 0;
-  h_offsets[0] = 0;
-  for (int64_t k = 0; k < nGreedy; ++k) {
-    const int32_t c    = cent[static_cast<size_t>(k)];
-    int32_t*      dst  = h_idx + pos;
-    int64_t       m    = 0;
-    dst[m++]           = c;
-    for (int32_t q = offs[static_cast<size_t>(k)]; q < offs[static_cast<size_t>(k) + 1]; ++q) {
-      if (idx[static_cast<size_t>(q)] != c) dst[m++] = idx[static_cast<size_t>(q)];
-    }
-    std::sort(dst + 1, dst + m);
-    h_centroids[k] = c;
-    pos += m;
-    h_offsets[k + 1] = pos;
+// ---- row-sharded first pass ---------------------------------------------------------------
+// Shard `shard` of `nShards` evaluates its band of tile rows of the symmetric all-pairs pass (bands of equal AREA of the
+// upper triangle, so the shards do equal work): partial degrees of ALL rows (row and column credits of its tiles) and the
+// neighbour pairs found there, in original row numbers.  Summing the degrees and concatenating the pairs of all shards
+// gives exactly what the un-sharded pass produces; the round loop (graph_rounds) then runs on the assembled graph.
+inline void shard_tile_rows(const int64_t tiles, const int shard, const int nShards, unsigned& lo, unsigned& hi) {
+  auto bound = [&](const int k) -> unsigned {  // first tile row of shard k: area above it = k / nShards of the triangle
+    if (k <= 0) return 0u;
+    if (k >= nShards) return static_cast<unsigned>(tiles);
+    const double T = static_cast<double>(tiles), total = T * (T + 1.0) / 2.0, want = total * k / nShards;
+    // rows 0..m-1 hold m T - m (m - 1) / 2 tiles
+    double m = (2.0 * T + 1.0 - std::sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * want)) / 2.0;
+    return static_cast<unsigned>(std::min<double>(std::max(0.0, std::floor(m + 0.5)), T));
+  };
+  lo = bound(shard);
+  hi = bound(shard + 1);
+}
+
+template <int METRIC>
+int pairs_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int shard, int nShards, int32_t* d_counts, int2* d_edges,
+               unsigned long long capacity, unsigned long long* h_n_edges, hipStream_t stream) {
+  const int   W   = fpBits / 32;
+  const float thr = static_cast<float>(1.0 - cutoff);
+  const size_t n  = static_cast<size_t>(N);
+  StreamScratch tableMem, fp4Mem, sortMem, sortTmp, curMem, tmpCounts;
+  CountPlan     plan;
+  int           rc = make_plan(plan, tableMem, METRIC, fpBits, thr, stream);
+  if (rc != NVMK_OK) return rc;
+  const bool sortPass = sorted_first_pass() && METRIC == NVMK_METRIC_TANIMOTO && thr > 0.0f;
+  int32_t*   perm     = nullptr;
+  NVMK_HIP_CHECK(fp4Mem.alloc(fp4::layout(N, fpBits).bytes, stream));
+  if (sortPass) {  // same permutation on every shard: it depends on the fingerprints only
+    NVMK_HIP_CHECK(sortMem.alloc(4 * n * sizeof(int32_t), stream));
+    int32_t* pop       = sortMem.as<int32_t>();
+    int32_t* popSorted = pop + n;
+    int32_t* ident     = popSorted + n;
+    perm               = ident + n;
+    hipLaunchKernelGGL(iota_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream, ident, N);
+    hipLaunchKernelGGL(row_popcount_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream, d_x, N, W, pop);
+    NVMK_LAUNCH_CHECK();
+    size_t tmpBytes = 0;
+    NVMK_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, pop, popSorted, ident, perm, static_cast<int>(N), 0, 32, stream));
+    NVMK_HIP_CHECK(sortTmp.alloc(tmpBytes, stream));
+    NVMK_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(sortTmp.ptr, tmpBytes, pop, popSorted, ident, perm, static_cast<int>(N), 0, 32, stream));
   }
-  std::vector<int32_t> singles(idx.begin() + (snap.back + 1), idx.end());
-  singles.insert(singles.end(), leftovers.begin(), leftovers.end());
-  std::sort(singles.begin(), singles.end());
-  int64_t k = nGreedy;
-  for (const int32_t s : singles) {
-    h_idx[pos++]   = s;
-    h_centroids[k] = s;
-    h_offsets[++k] = pos;
+  rc = fp4::prepare(d_x, perm, N, fpBits, fp4Mem.ptr, stream);
+  if (rc != NVMK_OK) return rc;
+  const fp4::Prepared PX = fp4::view(fp4Mem.ptr, N, fpBits);
+  NVMK_HIP_CHECK(curMem.alloc(256, stream));
+  NVMK_HIP_CHECK(hipMemsetAsync(curMem.ptr, 0, 256, stream));
+  NVMK_HIP_CHECK(tmpCounts.alloc(n * sizeof(int32_t), stream));
+  int32_t* counts = sortPass ? tmpCounts.as<int32_t>() : d_counts;
+  NVMK_HIP_CHECK(hipMemsetAsync(counts, 0, n * sizeof(int32_t), stream));
+  fp4::CountArgs a{};
+  a.metric       = METRIC;
+  a.thr          = thr;
+  a.table        = plan.table;
+  a.tableF       = plan.tableF;
+  a.sign         = +1;
+  a.nX           = N;
+  a.nY           = N;
+  a.symmetric    = true;
+  a.edges        = d_edges;
+  a.edgeCursor   = curMem.as<unsigned long long>();
+  a.edgeCapacity = capacity;
+  a.bandSkip     = sortPass;
+  shard_tile_rows(ceil_div<int64_t>(N, fp4::ROW_PAD), shard, nShards, a.tileRowLo, a.tileRowHi);
+  if (a.tileRowHi > a.tileRowLo) {  // an empty band (more shards than tile rows) contributes nothing
+    rc = fp4::launch_counts(a, PX, PX, counts, stream);
+    if (rc != NVMK_OK) return rc;
   }
-  if (pos != N) {
-    set_last_error("fused butina: internal accounting error (%lld of %lld rows assigned)", (long long)pos, (long long)N);
-    return NVMK_ERR_INTERNAL;
+  if (sortPass) {
+    hipLaunchKernelGGL(scatter_counts_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream, counts, perm, N,
+                       d_counts);
+    NVMK_LAUNCH_CHECK();
   }
-  *n_clusters = k;
+  unsigned long long nEdges = 0;
+  NVMK_HIP_CHECK(hipMemcpyAsync(&nEdges, curMem.ptr, sizeof(nEdges), hipMemcpyDeviceToHost, stream));
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+  *h_n_edges = nEdges;
+  if (nEdges > capacity) {
+    set_last_error("butina pairs: %llu neighbour pairs do not fit the buffer of %llu (graph too dense for the sharded path)", nEdges,
+                   capacity);
+    return NVMK_ERR_OUT_OF_MEMORY;
+  }
+  if (sortPass && nEdges > 0) {
+    const unsigned eb = static_cast<unsigned>(std::min<unsigned long long>(ceil_div<unsigned long long>(nEdges, 256), 65535));
+    hipLaunchKernelGGL(remap_edges_kernel, dim3(eb), dim3(256), 0, stream, d_edges, nEdges, perm);
+    NVMK_LAUNCH_CHECK();
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // scratch (perm) is released at return
+  }
   return NVMK_OK;
 }
 
@@ -1461,6 +1592,48 @@ int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, d
                                             n_clusters, as_stream(stream)) :
            fused_impl<NVMK_METRIC_COSINE>(d_x, N, fp_bits, cutoff, h_cluster_indices, h_offsets, h_centroids,
                                           n_clusters, as_stream(stream));
+}
+
+int nvmk_butina_pairs(int metric, const uint32_t* d_x, int64_t N, int fp_bits, double cutoff, int shard, int n_shards,
+                      int32_t* d_counts, int32_t* d_pairs, uint64_t pair_capacity, uint64_t* h_n_pairs, void* stream) {
+  NVMK_REQUIRE(metric == NVMK_METRIC_TANIMOTO || metric == NVMK_METRIC_COSINE, "unknown metric %d", metric);
+  NVMK_REQUIRE(cutoff >= 0.0 && cutoff <= 1.0, "cutoff must be in [0, 1], got %g", cutoff);
+  NVMK_REQUIRE(fp_bits > 0 && fp_bits % 128 == 0, "fp_bits must be a positive multiple of 128, got %d", fp_bits);
+  NVMK_REQUIRE(n_shards >= 1 && shard >= 0 && shard < n_shards, "butina pairs: bad shard %d of %d", shard, n_shards);
+  NVMK_REQUIRE(N >= 0 && N <= 0x7fffffffLL, "butina pairs: bad N %lld", (long long)N);
+  NVMK_REQUIRE(h_n_pairs != nullptr, "butina pairs: NULL output");
+  *h_n_pairs = 0;
+  if (N == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_x && d_counts && (d_pairs || pair_capacity == 0), "butina pairs: NULL buffer");
+  NVMK_REQUIRE(reinterpret_cast<uintptr_t>(d_x) % 16 == 0, "butina pairs: the fingerprint matrix must be 16-byte aligned");
+  unsigned long long nE = 0;
+  const int rc = metric == NVMK_METRIC_TANIMOTO ?
+                   pairs_impl<NVMK_METRIC_TANIMOTO>(d_x, N, fp_bits, cutoff, shard, n_shards, d_counts, reinterpret_cast<int2*>(d_pairs),
+                                                    pair_capacity, &nE, as_stream(stream)) :
+                   pairs_impl<NVMK_METRIC_COSINE>(d_x, N, fp_bits, cutoff, shard, n_shards, d_counts, reinterpret_cast<int2*>(d_pairs),
+                                                  pair_capacity, &nE, as_stream(stream));
+  *h_n_pairs = nE;
+  return rc;
+}
+
+int nvmk_butina_from_pairs(int64_t N, const int32_t* d_counts, const int32_t* d_pairs, uint64_t n_pairs, int32_t* h_cluster_indices,
+                           int64_t* h_offsets, int32_t* h_centroids, int64_t* n_clusters, void* stream_) {
+  NVMK_REQUIRE(N >= 0 && N <= 0x7fffffffLL, "butina from pairs: bad N %lld", (long long)N);
+  NVMK_REQUIRE(h_offsets && n_clusters, "NULL output");
+  h_offsets[0] = 0;
+  *n_clusters  = 0;
+  if (N == 0) return NVMK_OK;
+  NVMK_REQUIRE(d_counts && h_cluster_indices && h_centroids && (d_pairs || n_pairs == 0), "butina from pairs: NULL buffer");
+  hipStream_t   stream = as_stream(stream_);
+  StreamScratch mem;
+  RoundBuffers  rb{};
+  int           rc = alloc_round_buffers(mem, N, stream, rb);
+  if (rc != NVMK_OK) return rc;
+  NVMK_HIP_CHECK(hipMemcpyAsync(rb.counts, d_counts, static_cast<size_t>(N) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  LoopState snap{};
+  rc = graph_rounds(rb, N, reinterpret_cast<const int2*>(d_pairs), n_pairs, stream, snap);
+  if (rc != NVMK_OK) return rc;
+  return read_back(rb, N, snap, h_cluster_indices, h_offsets, h_centroids, n_clusters, stream);
 }
 
 int nvmk_butina_dense(const double* d_dist, const uint8_t* d_hit, int64_t N, double cutoff, int neighborlist_max_size,

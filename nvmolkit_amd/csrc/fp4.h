@@ -20,8 +20,8 @@ namespace nvmk {
 namespace fp4 {
 
 constexpr int ROW_PAD   = 128;  // rows per workgroup tile of the 128 x 128 kernels; alignment of row chunks
-constexpr int ROW_ALLOC = 768;  // prepared sets are zero-padded to a multiple of this (lcm of every kernel's tile edges:
-                                // 128; 128 x 192 for the producer / consumer dense kernel; 256 for the ring count kernel)
+constexpr int ROW_ALLOC = 768;  // prepared sets are zero-padded to a multiple of this (a multiple of the 128-row tiles; 768 also
+                                // covers the 192- / 256-row tiles of the kernels under tools/experiments)
 constexpr int WORD_PAD = 16;   // words per LDS K-chunk
 
 struct Layout {
@@ -92,6 +92,11 @@ struct CountArgs {
   // rows of X and Y are sorted by popcount (ascending): tiles whose popcount bands cannot reach the Tanimoto threshold
   // (T <= min(pa, pb) / max(pa, pb)) are skipped.  Tile count kernel, Tanimoto only.
   bool                bandSkip     = false;
+  // symmetric mode only: evaluate just the tile rows [tileRowLo, tileRowHi) of the upper triangle (a row shard of the
+  // all-pairs pass; 0, 0 = everything).  Row AND column credits of those tiles are added, so the per-shard counts of all
+  // shards sum to the full degrees and their edge lists are disjoint.
+  unsigned            tileRowLo    = 0;
+  unsigned            tileRowHi    = 0;
 };
 int launch_counts(const CountArgs& args, const Prepared& X, const Prepared& Y, int32_t* counts, hipStream_t stream);
 

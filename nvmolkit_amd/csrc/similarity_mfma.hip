@@ -386,7 +386,8 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   const int32_t* __restrict__ yRows, const int32_t* __restrict__ yIds, int64_t nY, const int32_t* __restrict__ nYdev, const int Wp, const int F,
   const float* __restrict__ table, const float thr, const int sign, const int symmetric, int32_t* __restrict__ counts, const unsigned superN,
   const unsigned superW, const unsigned superH, int2* __restrict__ edges, unsigned long long* __restrict__ edgeCursor,
-  const unsigned long long edgeCapacity, const double K1, const double K2, const double adj, const float bandThr) {
+  const unsigned long long edgeCapacity, const double K1, const double K2, const double adj, const float bandThr,
+  const unsigned tileRowLo, const unsigned tileRowHi) {
   constexpr int KCW = 8;
   constexpr int PPW = KCW / 2;
   constexpr int RPP = 64 / KCW;
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   const unsigned tile_n = sn * superW + (blockIdx.x - (blockIdx.x / superW) * superW);
   if (tile_m >= tilesM || tile_n >= tilesN) return;
   if (symmetric && tile_n < tile_m) return;
+  if (tileRowHi != 0u && (tile_m < tileRowLo || tile_m >= tileRowHi)) return;  // another shard's tile rows
   const bool creditCols = symmetric && tile_n > tile_m;
 
   const int     tid   = threadIdx.x;
@@ -712,7 +714,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   using Kern = void (*)(const uint4*, const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, const uint4*,
                         const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, int, int, const float*,
                         float, int, int, int32_t*, unsigned, unsigned, unsigned, int2*, unsigned long long*,
-                        unsigned long long, double, double, double, float);
+                        unsigned long long, double, double, double, float, unsigned, unsigned);
   Kern kern;
   ArithThreshold at = arith_threshold(a.thr, F);
   if (const char* te = std::getenv("NVMK_COUNT_THRESHOLD"); te != nullptr && std::string(te) == "table") at.ok = false;  // tests: force the table form
@@ -727,7 +729,8 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
                      a.yRows, a.yIds, a.nY, a.nYdev, X.L.Wp, F, a.tableF, a.thr, a.sign, a.symmetric ? 1 : 0, counts,
                      static_cast<unsigned>(superN), static_cast<unsigned>(superW), static_cast<unsigned>(superE), a.edges,
                      a.edgeCursor, a.edgeCapacity, at.k1, at.k2, at.adj,
-                     (a.bandSkip && a.metric == NVMK_METRIC_TANIMOTO && a.thr > 0.0f && a.xRows == nullptr && a.yRows == nullptr) ? a.thr : 0.0f);
+                     (a.bandSkip && a.metric == NVMK_METRIC_TANIMOTO && a.thr > 0.0f && a.xRows == nullptr && a.yRows == nullptr) ? a.thr : 0.0f,
+                     a.symmetric ? a.tileRowLo : 0u, a.symmetric ? a.tileRowHi : 0u);
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }

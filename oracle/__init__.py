@@ -78,6 +78,8 @@ def _declare(L: ctypes.CDLL) -> None:
     L.orc_butina_fused.argtypes = [ctypes.c_int, _u32p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, _i32p, _i64p,
                                    _i32p]
     L.orc_butina_fused.restype = ctypes.c_int64
+    L.orc_butina_from_pairs.argtypes = [ctypes.c_int64, _i32p, _i32p, ctypes.c_int64, _i32p, _i64p, _i32p]
+    L.orc_butina_from_pairs.restype = ctypes.c_int64
     L.orc_butina_dense.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, _i32p,
                                    ctypes.c_void_p]
     L.orc_butina_dense.restype = ctypes.c_int64
@@ -159,6 +161,48 @@ def butina_fused(x, cutoff: float, metric: int = TANIMOTO):
     nc = lib().orc_butina_fused(metric, x, n, x.shape[1], float(cutoff), idx, offs, cent)
     clusters = [tuple(int(v) for v in idx[offs[k]:offs[k + 1]]) for k in range(nc)]
     return clusters, [int(v) for v in offs[:nc + 1]], [int(v) for v in cent[:nc]]
+
+
+def butina_from_pairs(n: int, counts, pairs):
+    """Fused-Butina rounds on a neighbour graph (degrees incl. self, unordered pairs once) -> like butina_fused."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    cent = np.zeros(max(n, 1), dtype=np.int32)
+    nc = lib().orc_butina_from_pairs(n, counts, pairs, len(pairs), idx, offs, cent)
+    clusters = [tuple(int(v) for v in idx[offs[k]:offs[k + 1]]) for k in range(nc)]
+    return clusters, [int(v) for v in offs[:nc + 1]], [int(v) for v in cent[:nc]]
+
+
+def neighbor_pairs(x, cutoff: float, row_lo: int = 0, row_hi: int | None = None, metric: int = TANIMOTO):
+    """(partial counts int32[N], pairs int32[E, 2]) of the unordered neighbour pairs (i, j), i < j, whose FIRST row lies in
+    [row_lo, row_hi), plus the self pairs of those rows — a row shard of the symmetric all-pairs pass; the predicate is the
+    f32 one of the fused kernel (float(c) / float(u) >= float32(1 - cutoff))."""
+    x = _as_u32(x)
+    n = x.shape[0]
+    row_hi = n if row_hi is None else row_hi
+    thr = np.float32(1.0 - cutoff)
+    inter = cross_intersection(x[row_lo:row_hi], x).astype(np.float32)
+    pc = np.array([int(np.unpackbits(r.view(np.uint8)).sum()) for r in x], dtype=np.float32)
+    if metric == TANIMOTO:
+        union = pc[row_lo:row_hi, None] + pc[None, :] - inter
+        with np.errstate(divide="ignore", invalid="ignore"):
+            hit = np.where(union > 0, inter / np.maximum(union, np.float32(1)) >= thr, False)
+    else:
+        denom = np.sqrt(pc[row_lo:row_hi, None] * pc[None, :]).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            hit = np.where(denom > 0, inter / np.maximum(denom, np.float32(1e-30)) >= thr, False)
+    counts = np.zeros(n, dtype=np.int32)
+    ii, jj = np.nonzero(hit)
+    ii = ii + row_lo
+    keep = ii < jj
+    pairs = np.stack([ii[keep], jj[keep]], 1).astype(np.int32)
+    np.add.at(counts, pairs[:, 0], 1)
+    np.add.at(counts, pairs[:, 1], 1)
+    self_hit = ii == jj
+    np.add.at(counts, ii[self_hit], 1)
+    return counts, pairs
 
 
 def butina_dense(dist=None, cutoff: float = 0.0, hit=None):

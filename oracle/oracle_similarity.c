@@ -166,6 +166,9 @@ void orc_neighbor_counts(int metric, const uint32_t* x, int64_t nX, const uint32
  * singleton tail (the reference leaves them unwritten — clustering.py:171-175 reads zeros there).
  * Returns the number of clusters; offsets has n_clusters+1 entries.
  */
+static int64_t butina_rounds_on_adjacency(const uint8_t* adj, int64_t N, int32_t* cluster_indices, int64_t* offsets,
+                                          int32_t* centroids);
+
 int64_t orc_butina_fused(int metric, const uint32_t* x, int64_t N, int W, double cutoff, int32_t* cluster_indices,
                          int64_t* offsets, int32_t* centroids) {
   const float thr = (float)(1.0 - cutoff); /* clustering.py:149, passed to the kernel as f32 */
@@ -180,6 +183,34 @@ int64_t orc_butina_fused(int metric, const uint32_t* x, int64_t N, int W, double
       adj[i * N + j] = (uint8_t)is_neighbor_f32(metric, popc_and(x + i * W, x + j * W, W), pc[i], pc[j], thr);
     }
   }
+  const int64_t nc = butina_rounds_on_adjacency(adj, N, cluster_indices, offsets, centroids);
+  free(adj);
+  free(pc);
+  return nc;
+}
+
+/* The same round loop on a neighbour GRAPH: `pairs` lists every unordered neighbour pair (i != j) once, `counts[i]` is
+ * row i's degree INCLUDING itself when it is its own neighbour (an all-zero fingerprint is not) — the inputs of the
+ * product's nvmk_butina_from_pairs (row-sharded fused Butina). */
+int64_t orc_butina_from_pairs(int64_t N, const int32_t* counts, const int32_t* pairs, int64_t n_pairs, int32_t* cluster_indices,
+                              int64_t* offsets, int32_t* centroids) {
+  uint8_t* adj = (uint8_t*)calloc((size_t)(N * N > 0 ? N * N : 1), 1);
+  int32_t* inc = (int32_t*)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));
+  for (int64_t e = 0; e < n_pairs; ++e) {
+    const int64_t i = pairs[2 * e], j = pairs[2 * e + 1];
+    adj[i * N + j] = adj[j * N + i] = 1;
+    ++inc[i];
+    ++inc[j];
+  }
+  for (int64_t i = 0; i < N; ++i) adj[i * N + i] = (uint8_t)(counts[i] - inc[i] > 0);
+  const int64_t nc = butina_rounds_on_adjacency(adj, N, cluster_indices, offsets, centroids);
+  free(adj);
+  free(inc);
+  return nc;
+}
+
+static int64_t butina_rounds_on_adjacency(const uint8_t* adj, int64_t N, int32_t* cluster_indices, int64_t* offsets,
+                                          int32_t* centroids) {
   uint8_t* is_free   = (uint8_t*)malloc((size_t)(N > 0 ? N : 1));
   int32_t* degree    = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
   int32_t* singles   = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
@@ -239,8 +270,6 @@ int64_t orc_butina_fused(int metric, const uint32_t* x, int64_t N, int W, double
     cluster_indices[pos++] = singles[s];
     offsets[++nClusters]   = pos;
   }
-  free(adj);
-  free(pc);
   free(is_free);
   free(degree);
   free(singles);

@@ -219,3 +219,25 @@ def test_fused_matches_dense_on_same_data():
     with np.errstate(divide="ignore", invalid="ignore"):
         hit = (inter.astype(np.float32) / den >= np.float32(1.0 - cutoff)) & (den > 0)
     util.check_greedy_butina(hit, clusters)
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 5])
+@pytest.mark.parametrize("n", [700, 4000])
+def test_sharded_pairs_assemble_to_the_fused_result(n, n_shards):
+    """nvmk_butina_pairs per shard (bands of tile rows of the symmetric pass) -> summed degrees + concatenated pairs ->
+    nvmk_butina_from_pairs == nvmk_butina_fused == the oracle (the single-GPU half of SURVEY.md 8(e) row 3; the exchange
+    itself is tests/test_distributed_cpu.py)."""
+    from nvmolkit_amd.distributed import butina_from_pairs_gpu, butina_pairs_gpu
+
+    x = util.clustered_fingerprints(n, 64, max(4, n // 60), seed=n)
+    d = dev(x)
+    parts = [butina_pairs_gpu(d, 0.35, s, n_shards) for s in range(n_shards)]
+    counts = sum(p[0] for p in parts)
+    pairs = torch.cat([p[1] for p in parts])
+    assert np.array_equal(counts.cpu().numpy(), oracle.neighbor_counts(x, x, np.float32(0.65)))
+    pp = pairs.cpu().numpy()
+    lo_, hi_ = pp.min(1).astype(np.int64), pp.max(1).astype(np.int64)
+    assert np.all(lo_ != hi_) and len(np.unique(lo_ * n + hi_)) == len(pp)          # every unordered pair once, no self pairs
+    got = butina_from_pairs_gpu(n, counts, pairs)
+    assert got == oracle.butina_fused(x, 0.35)
+    assert got == fused_butina(d, 0.35, return_centroids=True)

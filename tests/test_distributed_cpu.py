@@ -131,3 +131,50 @@ def test_molecule_sharding_and_result_merge(tmp_path):
     assert shard_molecules_by_cost([], 4, 2).tolist() == []
     parts = [shard_molecules_by_cost(np.full(10, 20), 4, r) for r in range(4)]
     assert sorted(np.concatenate(parts).tolist()) == list(range(10)) and max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _butina_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import json
+
+    import oracle
+    from nvmolkit_amd.distributed import fused_butina_sharded, shard_bounds
+    from tests import util
+
+    x = util.clustered_fingerprints(257, 8, 9, seed=4)        # replicated on every rank
+
+    def pairs_fn(xx, cutoff, shard, n_shards):                # CPU stand-in for nvmk_butina_pairs: a row band of the pass
+        lo, hi = shard_bounds(len(x), n_shards, shard)
+        c, p = oracle.neighbor_pairs(x, cutoff, lo, hi)
+        return torch.from_numpy(c), torch.from_numpy(p)
+
+    def rounds_fn(n, counts, pairs):                          # CPU stand-in for nvmk_butina_from_pairs
+        return oracle.butina_from_pairs(n, counts.numpy(), pairs.numpy())
+
+    got = fused_butina_sharded(torch.from_numpy(x.view(np.int32)), 0.35, return_centroids=True, pairs_fn=pairs_fn,
+                               rounds_fn=rounds_fn)
+    with open(os.path.join(out_dir, f"butina{rank}.json"), "w") as f:
+        json.dump([list(map(list, got[0])), got[1], got[2]], f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_fused_butina_equals_single_process(tmp_path):
+    """the all-pairs pass sharded over two ranks, degrees all-reduced, pair lists all-gathered, the
+    round loop replicated — both ranks end with the single-process clustering."""
+    import json
+
+    world = 2
+    mp.spawn(_butina_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, str(ROOT))
+    import oracle
+    from tests import util
+
+    x = util.clustered_fingerprints(257, 8, 9, seed=4)
+    want = oracle.butina_fused(x, 0.35)
+    for r in range(world):
+        clusters, cum, cent = json.load(open(tmp_path / f"butina{r}.json"))
+        assert [tuple(c) for c in clusters] == want[0] and cum == want[1] and cent == want[2]
