@@ -627,130 +627,128 @@ constexpr int    MAX_LS_ITERS  = 1000;
 // needs per iteration follow from t without touching the matrix again:
 //     H dGrad       = H g_new - H g_old = t - hg                       (hg = H g of the previous iterate, kept in LDS)
 //     H_new g_new   = t + rfac xi (xi.g) - fad hdg (hdg.g) + fae u (u.g)
-// so the traffic per iteration is one read + one write of n (n + 2) / 2 doubles instead of two reads + one write of
-// n^2 (measured before: 47 + 75 us of a 134 us iteration at n = 192, and the 512 resident workgroups together were
-// pulling 3-4 TB/s of Hessian traffic from HBM).
-// Work split: 32 lanes span 64 consecutive columns of a row, 8 row groups per workgroup, HU rows per lane in flight
-// as independent 16-byte loads.  Row sums finish with a 32-lane shuffle reduction; the mirrored (column) sums of the
-// HU rows of a batch share their column and are combined in registers before they touch LDS.
-constexpr int HTX = 32;
-constexpr int HTY = NT / HTX;
-constexpr int HCS = 4;   // column steps (of 2 * HTX columns) loaded together in hess_pass
-// rows per lane in hess_pass: HU * HCS 16-byte loads in flight per lane; 8 where the registers allow it (DG, the largest H)
-
-__device__ __forceinline__ double half_wave_sum(double v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+// so the traffic per iteration is one read + one write of n (n + 2) / 2 doubles instead of two reads + one write of n^2.
+//
+// Work split (round 2): ONE WAVE PER ROW.  Wave w owns rows w, w + NW, ...; its 64 lanes span 128 consecutive columns of
+// the row as 16-byte pairs, so every load / store of a row is one fully coalesced (global) or conflict-free (LDS) wave
+// instruction.  A lane keeps the vector entries of ITS two columns (xi, hdg, u, g) in registers for the whole column
+// chunk; the row's coefficients are wave-uniform.  Row sums finish with a DPP reduction inside the wave (no LDS), mirrored
+// (column) sums stay in the lane's registers over all the rows of the chunk and are written once per wave.  Every partial
+// sum has a single writer and the final sum runs in a fixed order: a minimisation is reproducible run to run.
+// (Round 1 split rows over 8 row groups x 32 lanes with per-group partial-sum slabs in LDS: measured 20-27 us per pass at
+// n = 144-192 whether the matrix came from HBM or from LDS — the pass was bound by its own chain of LDS read-modify-writes
+// and half-wave shuffles, not by bandwidth: profiles/r02_conformers/.)
+constexpr int NW = NT / 64;  // waves per workgroup
 
 __host__ __device__ __forceinline__ int64_t hess_row_offset(const int64_t r) {  // rows 0..r-1, each padded to even length
   return (r & 1) ? (r + 1) * (r + 1) / 2 : r * (r + 2) / 2;
 }
 
-// Rows [0, Rl) of the packed triangle may live in LDS, the rest in HBM (see bfgs_kernel): the pass is written over a row
-// range and a base pointer, and called once per residence.  Rl is either n (everything resident) or a multiple of the
-// row block HTY * HU, so a block never straddles the two.
-__host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t hldsDoubles, const int block) {
+// Rows [0, Rl) of the packed triangle live in LDS behind the vectors (as many as the launch's LDS budget holds), rows Rl..
+// stream from HBM.
+__host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t hldsDoubles) {
   if (hess_row_offset(n) <= hldsDoubles) return n;
   int r = 0;
-  while (r + block <= n && hess_row_offset(r + block) <= hldsDoubles) r += block;
+  while (r < n && hess_row_offset(r + 1) <= hldsDoubles) ++r;
   return r;
 }
-__host__ __device__ constexpr int hess_rows_per_lane(const int kind) { return kind == NVMK_FF_DG ? 6 : 4; }
-// LDS layout of bfgs_kernel: 11 vectors + (1 + HTY) partial-sum slabs of n doubles, 8 doubles of reduction scratch, then
-// the resident rows of the inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
-__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (12 + HTY) * n + 8; }
+// LDS layout of bfgs_kernel: 11 vectors + (1 + NW) partial-sum slabs of n doubles (row sums, then one slab of mirrored-entry
+// sums per wave; the per-wave gradient slabs alias them), 8 doubles of reduction scratch, then the resident rows of the
+// inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
+__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (12 + NW) * n + 8; }
 __host__ __device__ constexpr int64_t lds_hessian_doubles(const int64_t ldsDoubles, const int64_t n) {
   return ldsDoubles > lds_vector_doubles(n) ? ldsDoubles - lds_vector_doubles(n) : 0;
 }
 
-// `part` is (1 + HTY) n doubles of LDS scratch: row sums, then one slab of mirrored-entry sums per row group; it must be
-// zero on entry (and visible to the workgroup).  No atomics: every partial sum has a single writer and the final sum
-// (hess_finish) runs in a fixed order, so the minimiser is reproducible run to run.
-// H points at row rBegin's first element; rows [rBegin, rEnd) are processed.
-template <int HU>
+// Sum over the 64 lanes of a wave, result in every lane.  DPP moves only (no LDS traffic): butterflies inside a quad and
+// a row of 16, then the two row broadcasts of gfx9; the order of the additions is fixed.
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ double dpp_mov(const double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_mov<0xb1>(v);         // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4e>(v);         // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x124>(v);        // row_ror 4
+  v += dpp_mov<0x128>(v);        // row_ror 8: every lane of a row of 16 holds the row's sum
+  v += dpp_mov<0x142, 0xa>(v);   // row_bcast 15 into rows 1 and 3
+  v += dpp_mov<0x143, 0xc>(v);   // row_bcast 31 into rows 2 and 3: lane 63 holds the total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// Rows [rBegin, rEnd) of the matrix whose row rBegin starts at H (LDS or HBM: the address space is known at the call).
+// `part` = row sums [n] then NW slabs [n] of mirrored-entry sums, all zero on entry (and visible to the workgroup).  RU rows of a wave are in
+// flight together (their loads are issued before the first use).
+template <int RU>
 __device__ __forceinline__ void hess_rows(double* __restrict__ H, const int rBegin, const int rEnd, const int n, const bool pending,
-                                          const double rfac, const double fad, const double fae, const double* xi, const double* hdg,
-                                          const double* uu, const double* g, double* part) {
-  const int     tx = threadIdx.x & (HTX - 1), ty = threadIdx.x / HTX;
+                                          const double rfac, const double fad, const double fae, const double* __restrict__ xi,
+                                          const double* __restrict__ hdg, const double* __restrict__ uu,
+                                          const double* __restrict__ g, double* __restrict__ part) {
+  const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = hess_row_offset(rBegin);
-  for (int r0 = rBegin; r0 < rEnd; r0 += HTY * HU) {
-    double  racc[HU], ar[HU], br[HU], dr[HU], gr[HU];
-    int     row[HU];
-    int64_t off[HU];
-#pragma unroll
-    for (int u = 0; u < HU; ++u) {
-      const int r  = r0 + ty + HTY * u;
-      row[u]       = r < rEnd ? r : -1;
-      const int rc = r < rEnd ? r : rBegin;
-      off[u]       = hess_row_offset(rc) - base;
-      racc[u]      = 0.0;
-      gr[u]        = g[rc];
-      ar[u]        = pending ? rfac * xi[rc] : 0.0;
-      br[u]        = pending ? fad * hdg[rc] : 0.0;
-      dr[u]        = pending ? fae * uu[rc] : 0.0;
-    }
-    const int rmax = min(rEnd - 1, r0 + ty + HTY * (HU - 1));
-    // Columns go in blocks of HCS steps: every 16-byte load of the block is issued before the first use, so a lane has
-    // up to HU * HCS loads in flight.  (Load, update, store, next load — the first version — waited for the previous
-    // step's STORE before every load could be consumed, because vmcnt retires loads and stores in order: 41 us per
-    // pass at n = 192 even for a lone system, i.e. pure latency.)  Accumulation order is unchanged.
-    for (int cb = 2 * tx; cb <= rmax; cb += 2 * HTX * HCS) {
-      double2 hv[HCS][HU];
-#pragma unroll
-      for (int sx = 0; sx < HCS; ++sx) {
-        const int c = cb + sx * 2 * HTX;
-#pragma unroll
-        for (int u = 0; u < HU; ++u) {
-          hv[sx][u] = make_double2(0.0, 0.0);
-          if (c <= row[u]) hv[sx][u] = *reinterpret_cast<const double2*>(H + off[u] + c);
-        }
+  double*       rowsum = part;
+  double*       colsum = part + (1 + wave) * n;
+  for (int c0 = 2 * lane, cBase = 0; cBase < rEnd; c0 += 128, cBase += 128) {  // column chunk [cBase, cBase + 128)
+    const bool   in0 = c0 < n, in1 = c0 + 1 < n;
+    const double g0 = in0 ? g[c0] : 0.0, g1 = in1 ? g[c0 + 1] : 0.0;
+    double       x0 = 0.0, x1 = 0.0, h0 = 0.0, h1 = 0.0, u0 = 0.0, u1 = 0.0;
+    if (pending) {
+      if (in0) {
+        x0 = xi[c0];
+        h0 = hdg[c0];
+        u0 = uu[c0];
       }
-#pragma unroll
-      for (int sx = 0; sx < HCS; ++sx) {
-        const int c = cb + sx * 2 * HTX;
-        if (c > rmax) break;
-        const bool   two = c + 1 < n;
-        const double g0 = g[c], g1 = two ? g[c + 1] : 0.0;
-        double       x0 = 0.0, x1 = 0.0, h0 = 0.0, h1 = 0.0, u0 = 0.0, u1 = 0.0;
-        if (pending) {
-          x0 = xi[c];
-          h0 = hdg[c];
-          u0 = uu[c];
-          if (two) {
-            x1 = xi[c + 1];
-            h1 = hdg[c + 1];
-            u1 = uu[c + 1];
-          }
-        }
-        double col0 = 0.0, col1 = 0.0;
-#pragma unroll
-        for (int u = 0; u < HU; ++u) {
-          if (c <= row[u]) {
-            double2    h    = hv[sx][u];
-            const bool has1 = c + 1 <= row[u];
-            if (pending) {
-              h.x += ar[u] * x0 - br[u] * h0 + dr[u] * u0;
-              if (has1) h.y += ar[u] * x1 - br[u] * h1 + dr[u] * u1;  // the pad entry stays 0
-              *reinterpret_cast<double2*>(H + off[u] + c) = h;
-            }
-            racc[u] += h.x * g0 + (has1 ? h.y * g1 : 0.0);
-            if (c < row[u]) col0 += h.x * gr[u];      // mirrored entries (strictly below the diagonal)
-            if (c + 1 < row[u]) col1 += h.y * gr[u];
-          }
-        }
-        // (row group ty, column c) has exactly one writer: plain read-modify-write, summation order fixed
-        double* mine = part + (1 + ty) * n;
-        mine[c] += col0;
-        if (two) mine[c + 1] += col1;
+      if (in1) {
+        x1 = xi[c0 + 1];
+        h1 = hdg[c0 + 1];
+        u1 = uu[c0 + 1];
       }
     }
+    double col0 = 0.0, col1 = 0.0;
+    // first row of this wave at or after max(rBegin, cBase): rows before cBase have no column in this chunk
+    const int rStart = max(rBegin, cBase);
+    for (int r0 = rStart + ((wave - rStart) % NW + NW) % NW; r0 < rEnd; r0 += NW * RU) {
+      // stage 1: everything a batch of RU rows needs is requested before the first use (matrix pairs, the rows' running
+      // sums, the rows' coefficients): the latencies overlap instead of adding up row after row
+      double2 hv[RU];
+      double  rold[RU], gr[RU], ar[RU], br[RU], dr[RU];
 #pragma unroll
-    for (int u = 0; u < HU; ++u) {
-      const double v = half_wave_sum(racc[u]);
-      if (tx == 0 && row[u] >= 0) part[row[u]] = v;  // row sums: one writer per row
+      for (int u = 0; u < RU; ++u) {
+        const int r  = r0 + NW * u;
+        const int rc = r < rEnd ? r : rBegin;
+        hv[u]        = make_double2(0.0, 0.0);
+        if (r < rEnd && c0 <= r) hv[u] = *reinterpret_cast<const double2*>(H + (hess_row_offset(r) - base) + c0);
+        rold[u] = rowsum[rc];
+        gr[u]   = g[rc];
+        ar[u]   = pending ? rfac * xi[rc] : 0.0;
+        br[u]   = pending ? fad * hdg[rc] : 0.0;
+        dr[u]   = pending ? fae * uu[rc] : 0.0;
+      }
+      // stage 2: update, write back, partial sums
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int r = r0 + NW * u;
+        if (r < rEnd) {  // wave-uniform
+          double2 h = hv[u];
+          if (pending && c0 <= r) {
+            h.x += ar[u] * x0 - br[u] * h0 + dr[u] * u0;
+            if (c0 + 1 <= r) h.y += ar[u] * x1 - br[u] * h1 + dr[u] * u1;  // the pad entry stays 0
+            *reinterpret_cast<double2*>(H + (hess_row_offset(r) - base) + c0) = h;
+          }
+          if (c0 < r) col0 += h.x * gr[u];  // mirrored entries (strictly below the diagonal)
+          if (c0 + 1 < r) col1 += h.y * gr[u];
+          const double rs = wave_sum(h.x * g0 + h.y * g1);  // lanes past the row hold zeros
+          if (lane == 0) rowsum[r] = rold[u] + rs;          // one writer per row (this wave), chunks in order
+        }
+      }
     }
+    // this wave's mirrored-entry sums of the chunk's columns: single writer (the slab was zeroed before the pass; the HBM
+    // range adds to what the LDS range left)
+    if (in0) colsum[c0] += col0;
+    if (in1) colsum[c0 + 1] += col1;
   }
 }
 
@@ -760,7 +758,7 @@ __device__ __forceinline__ void hess_finish(const int n, const double* part, dou
   for (int i = threadIdx.x; i < n; i += NT) {
     double v = part[i];
 #pragma unroll
-    for (int k = 1; k <= HTY; ++k) v += part[k * n + i];
+    for (int k = 1; k <= NW; ++k) v += part[k * n + i];
     t[i] = v;
   }
 }
@@ -804,13 +802,12 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   double* pxi   = tvec + n;   // pending rank-2 update: xi, H dGrad, u
   double* phdg  = pxi + n;
   double* pu    = phdg + n;
-  double* part  = pu + n;     // (1 + HTY) n partial sums of the pass; its first NT/64 slabs double as the per-wave gradients
-  double* red   = part + (1 + HTY) * n;  // NT/64 + 1 (padded to 8)
+  double* part  = pu + n;     // (1 + NW) n partial sums of the pass; its first NW slabs double as the per-wave gradients
+  double* red   = part + (1 + NW) * n;  // NT/64 + 1 (padded to 8)
   // Inverse Hessian: the first Rl rows of the packed triangle live in LDS behind the vectors (as many as the launch's LDS
   // budget holds: all of them for small systems), rows Rl.. stream from HBM as before.
-  constexpr int HU = hess_rows_per_lane(KIND);
-  double*       Hl = red + 8;
-  const int     Rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n), HTY * HU);
+  double*   Hl = red + 8;
+  const int Rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n));
 
   if (n == 0) {
     if (tid == 0) {
@@ -866,8 +863,6 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   // Gradient contributions are accumulated per WAVE (LDS atomics into the wave's own slab: within a wave the order of
   // the additions is the program's, so it does not depend on how the waves happen to be scheduled) and the slabs are
   // summed in a fixed order: a minimisation — and with it a seeded ETKDG run — is reproducible bit for bit.
-  constexpr int NW = NT / 64;
-  static_assert(NW <= 1 + HTY, "per-wave gradient slabs alias the pass's partial sums");
   auto   grad_at   = [&](const double* p) {
     for (int i = tid; i < NW * n; i += NT) part[i] = 0.0;
     __syncthreads();
@@ -996,10 +991,11 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
     }
     // ---- BFGS update of the inverse Hessian, new direction (:304-407) — one pass over H, see hess_pass
     const int64_t tH = now();
-    for (int i = tid; i < (1 + HTY) * n; i += NT) part[i] = 0.0;
+    for (int i = tid; i < (1 + NW) * n; i += NT) part[i] = 0.0;
     __syncthreads();
-    if (Rl > 0) hess_rows<HU>(Hl, 0, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
-    if (Rl < n) hess_rows<HU>(H, Rl, n, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
+    // resident rows from LDS (4 rows of a wave in flight), the rest from HBM (8 in flight: ~1 us of latency to cover)
+    if (Rl > 0) hess_rows<4>(Hl, 0, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
+    if (Rl < n) hess_rows<8>(H, Rl, n, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
     hess_finish(n, part, tvec);  // H is now H_k; tvec = H_k g_new
     __syncthreads();
     tk[2] += now() - tH;
@@ -1190,11 +1186,10 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   const size_t shmem = std::min(budget, vecBytes + static_cast<size_t>(hess_row_offset(maxN)) * sizeof(double));
   const int    ldsDoubles = static_cast<int>(shmem / sizeof(double));
   // offsets of the HBM part of every inverse Hessian (rows Rl.. of the packed lower triangle)
-  const int            block = HTY * hess_rows_per_lane(b.kind);
   std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
   for (int s = 0; s < b.nSystems; ++s) {
     const int n  = (h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
-    const int rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n), block);
+    const int rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n));
     hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + hess_row_offset(n) - hess_row_offset(rl);
   }
   StreamScratch hessMem, startsMem, orderMem;
