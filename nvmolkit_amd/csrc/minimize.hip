@@ -78,6 +78,30 @@ template <Op OP> __device__ __forceinline__ double block_reduce(double v, double
   return r;
 }
 
+// N sums at once: one pair of barriers instead of N (the kernel is barrier-bound between its short vector loops:
+// SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.19, profiles/r02_conformers_round1_pass).  `red` holds (NT / 64) * N doubles.
+// The summation order of each value is the same as block_reduce<kSum>'s.
+template <int N> __device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+  }
+  __syncthreads();  // protect `red` from the previous use
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[(threadIdx.x >> 6) * N + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double r = red[k];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r += red[w * N + k];
+    v[k] = r;
+  }
+}
+
 // ---- per-system energy / gradient -----------------------------------------------------------------
 // pos / grad are the system's own arrays (LDS or global), DIM doubles per atom.  Every thread walks its
 // share of each term group; energy() returns the thread's partial sum, grad() accumulates with atomics.
@@ -653,9 +677,9 @@ __host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t
   return r;
 }
 // LDS layout of bfgs_kernel: 11 vectors + (1 + NW) partial-sum slabs of n doubles (row sums, then one slab of mirrored-entry
-// sums per wave; the per-wave gradient slabs alias them), 8 doubles of reduction scratch, then the resident rows of the
+// sums per wave; the per-wave gradient slabs alias them), 16 doubles of reduction scratch, then the resident rows of the
 // inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
-__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (12 + NW) * n + 8; }
+__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (12 + NW) * n + 16; }
 __host__ __device__ constexpr int64_t lds_hessian_doubles(const int64_t ldsDoubles, const int64_t n) {
   return ldsDoubles > lds_vector_doubles(n) ? ldsDoubles - lds_vector_doubles(n) : 0;
 }
@@ -806,7 +830,7 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   double* red   = part + (1 + NW) * n;  // NT/64 + 1 (padded to 8)
   // Inverse Hessian: the first Rl rows of the packed triangle live in LDS behind the vectors (as many as the launch's LDS
   // budget holds: all of them for small systems), rows Rl.. stream from HBM as before.
-  double*   Hl = red + 8;
+  double*   Hl = red + 16;
   const int Rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n));
 
   if (n == 0) {
@@ -1010,10 +1034,14 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
       sumDG += dGrad[i] * dGrad[i];
       sumXi += dir[i] * dir[i];
     }
-    fac     = block_reduce<Op::kSum>(fac, red);
-    fae     = block_reduce<Op::kSum>(fae, red);
-    sumDG   = block_reduce<Op::kSum>(sumDG, red);
-    sumXi   = block_reduce<Op::kSum>(sumXi, red);
+    {
+      double four[4] = {fac, fae, sumDG, sumXi};
+      block_sum_n<4>(four, red);
+      fac   = four[0];
+      fae   = four[1];
+      sumDG = four[2];
+      sumXi = four[3];
+    }
     pending = fac > 0.0 && fac * fac > EPS_HESS * sumDG * sumXi;
     if (pending) {
       pRfac = 1.0 / fac;
@@ -1028,9 +1056,13 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
         dh += phdg[i] * grad[i];
         du += ui * grad[i];
       }
-      dx = block_reduce<Op::kSum>(dx, red);
-      dh = block_reduce<Op::kSum>(dh, red);
-      du = block_reduce<Op::kSum>(du, red);
+      {
+        double three[3] = {dx, dh, du};
+        block_sum_n<3>(three, red);
+        dx = three[0];
+        dh = three[1];
+        du = three[2];
+      }
       for (int i = tid; i < n; i += NT) {
         hg[i] = tvec[i] + pRfac * dx * pxi[i] - pFad * dh * phdg[i] + pFae * du * pu[i];
       }
