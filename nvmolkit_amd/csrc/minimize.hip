@@ -23,6 +23,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "ff_grad.h"
 #include "ff_terms.h"
 
 namespace nvmk {
@@ -117,6 +118,17 @@ __device__ __forceinline__ void scatter(const Dual<NP>& e, const int (&atoms)[NA
     }
   }
 }
+
+// Accumulator of ff_grad.h's term gradients: atomic adds into the caller's gradient array (the wave's LDS slab inside
+// the fused BFGS kernel, global memory in the stand-alone gradient kernel).
+template <int DIM> struct AtomicAcc {
+  double* grad;
+  __device__ __forceinline__ void operator()(const int atom, const ffg::V3 f) const {
+    if (f.x != 0.0) atomicAdd(&grad[atom * DIM], f.x);
+    if (f.y != 0.0) atomicAdd(&grad[atom * DIM + 1], f.y);
+    if (f.z != 0.0) atomicAdd(&grad[atom * DIM + 2], f.z);
+  }
+};
 
 template <int DIM> __device__ __forceinline__ double pair_dist2(const double* pos, const int i, const int j, const int ndim, double (&d)[4]) {
   double s = 0.0;
@@ -293,11 +305,16 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
       for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D       = Dual<12>;
           const D   vol = chiral_volume(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                         Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3));
           const D   ev  = chiral_violation(vol, g.par[2 * t], g.par[2 * t + 1], w0);
           scatter<12, DIM, 4>(ev, a, grad, 0.5);
+#else
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_dg_chiral<DIM>(pos, a, g.par[2 * t], g.par[2 * t + 1], w0, acc);
+#endif
         } else {
           const double vol = chiral_volume(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                                            Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3));
@@ -328,10 +345,16 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         const double* fc   = g.par + 12 * t;
         bool          ok;
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D   = Dual<12>;
           const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                    Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
           if (ok) scatter<12, DIM, 4>(torsion_m6(c, fc, fc + 6), a, grad, 1.0);
+#else
+          (void)ok;
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_etk_torsion<DIM>(pos, a, fc, acc);
+#endif
         } else {
           const double c = cos_dihedral(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                                         Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), ok);
@@ -345,11 +368,16 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
         const double* p    = g.par + 4 * t;
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D = Dual<12>;
           scatter<12, DIM, 4>(inversion(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                         Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0], p[1], p[2],
                                         p[3]),
                               a, grad, 1.0);
+#else
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_inversion<DIM>(pos, a, p[1], p[2], p[3], false, acc);
+#endif
         } else {
           e += inversion(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                          Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), p[0], p[1], p[2], p[3]);
@@ -388,10 +416,15 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
       for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D = Dual<9>;
           scatter<9, DIM, 3>(angle_constraint(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                               Loader<D, DIM>::get(pos, a[2], 2), g.par[2 * t], g.par[2 * t + 1], 1.0),
                              a, grad, 1.0);
+#else
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_angle_window<DIM>(pos, a, g.par[2 * t], g.par[2 * t + 1], 1.0, acc);
+#endif
         } else {
           e += angle_constraint(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                                 Loader<double, DIM>::get(pos, a[2], 2), g.par[2 * t], g.par[2 * t + 1], 1.0);
@@ -421,10 +454,15 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
         const double* p    = g.par + 3 * t;
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D = Dual<9>;
           scatter<9, DIM, 3>(mmff_angle(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                         Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], p[2] != 0.0),
                              a, grad, 1.0);
+#else
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_mmff_angle<DIM>(pos, a, p[0], p[1], p[2] != 0.0, acc);
+#endif
         } else {
           e += mmff_angle(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                           Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], p[2] != 0.0);
@@ -437,10 +475,15 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
         const double* p    = g.par + 5 * t;
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D = Dual<9>;
           scatter<9, DIM, 3>(mmff_stretch_bend(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                                Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], p[2], p[3], p[4]),
                              a, grad, 1.0);
+#else
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_mmff_stretch_bend<DIM>(pos, a, p, acc);
+#endif
         } else {
           e += mmff_stretch_bend(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                                  Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], p[2], p[3], p[4]);
@@ -452,10 +495,15 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
       for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
         const int a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D = Dual<12>;
           scatter<12, DIM, 4>(mmff_oop(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                        Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), g.par[t]),
                               a, grad, 1.0);
+#else
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_mmff_oop<DIM>(pos, a, g.par[t], acc);
+#endif
         } else {
           e += mmff_oop(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                         Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), g.par[t]);
@@ -469,10 +517,16 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         const double* p    = g.par + 3 * t;
         bool          ok;
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D   = Dual<12>;
           const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                    Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
           if (ok) scatter<12, DIM, 4>(mmff_torsion(c, p[0], p[1], p[2]), a, grad, 1.0);
+#else
+          (void)ok;
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_mmff_torsion<DIM>(pos, a, p[0], p[1], p[2], acc);
+#endif
         } else {
           const double c = cos_dihedral(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                                         Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), ok);
@@ -536,10 +590,16 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         const double* p    = g.par + 6 * t;
         const int     ord  = static_cast<int>(p[2]);
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D = Dual<9>;
           scatter<9, DIM, 3>(uff_angle(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                        Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], ord, p[3], p[4], p[5]),
                              a, grad, 1.0);
+#else
+          (void)ord;
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_uff_angle<DIM>(pos, a, p, acc);
+#endif
         } else {
           e += uff_angle(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                          Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], ord, p[3], p[4], p[5]);
@@ -554,10 +614,16 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         const int     ord  = static_cast<int>(p[1]);
         bool          ok;
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D   = Dual<12>;
           const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                    Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
           if (ok) scatter<12, DIM, 4>(uff_torsion(c, p[0], ord, p[2]), a, grad, 1.0);
+#else
+          (void)ok;
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_uff_torsion<DIM>(pos, a, p[0], ord, p[2], acc);
+#endif
         } else {
           const double c = cos_dihedral(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                                         Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), ok);
@@ -571,11 +637,16 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
         const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
         const double* p    = g.par + 4 * t;
         if constexpr (GRAD) {
+#ifdef NVMK_FF_DUAL_GRAD
           using D = Dual<12>;
           scatter<12, DIM, 4>(uff_inversion(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
                                             Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0], p[1],
                                             p[2], p[3]),
                               a, grad, 1.0);
+#else
+          AtomicAcc<DIM> acc{grad};
+          ffg::grad_inversion<DIM>(pos, a, p[2], p[3], p[0], true, acc);
+#endif
         } else {
           e += uff_inversion(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
                              Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), p[0], p[1], p[2],
@@ -665,7 +736,7 @@ constexpr int    MAX_LS_ITERS  = 1000;
 constexpr int NW = NT / 64;  // waves per workgroup
 
 __host__ __device__ __forceinline__ int64_t hess_row_offset(const int64_t r) {  // rows 0..r-1, each padded to even length
-  return (r & 1) ? (r + 1) * (r + 1) / 2 : r * (r + 2) / 2;
+  return ((r + 1) >> 1) * ((r | 1) + 1);  // r even: r (r + 2) / 2, r odd: (r + 1)^2 / 2 — branch-free
 }
 
 // Rows [0, Rl) of the packed triangle live in LDS behind the vectors (as many as the launch's LDS budget holds), rows Rl..
@@ -687,92 +758,151 @@ __host__ __device__ constexpr int64_t lds_hessian_doubles(const int64_t ldsDoubl
 // Sum over the 64 lanes of a wave, result in every lane.  DPP moves only (no LDS traffic): butterflies inside a quad and
 // a row of 16, then the two row broadcasts of gfx9; the order of the additions is fixed.
 template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ double dpp_mov(const double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
-  return __hiloint2double(hi, lo);
+  if constexpr (ROW_MASK == 0xf) {  // every lane has a source (permutations inside a quad / a row): no "old" value needed
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  } else {  // row broadcasts: rows outside the mask add 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
 }
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_mov<0xb1>(v);         // quad_perm [1, 0, 3, 2]
-  v += dpp_mov<0x4e>(v);         // quad_perm [2, 3, 0, 1]
-  v += dpp_mov<0x124>(v);        // row_ror 4
-  v += dpp_mov<0x128>(v);        // row_ror 8: every lane of a row of 16 holds the row's sum
-  v += dpp_mov<0x142, 0xa>(v);   // row_bcast 15 into rows 1 and 3
-  v += dpp_mov<0x143, 0xc>(v);   // row_bcast 31 into rows 2 and 3: lane 63 holds the total
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-  return __hiloint2double(hi, lo);
+// N independent sums at once, step by step: the N dependency chains interleave instead of running one after the other.
+template <int N> __device__ __forceinline__ void wave_sum_n(double (&v)[N]) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0xb1>(v[u]);  // quad_perm [1, 0, 3, 2]
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x4e>(v[u]);  // quad_perm [2, 3, 0, 1]
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x124>(v[u]);  // row_ror 4
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x128>(v[u]);  // row_ror 8: every lane of a row of 16 holds the row's sum
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x142, 0xa>(v[u]);  // row_bcast 15 into rows 1 and 3
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x143, 0xc>(v[u]);  // row_bcast 31 into rows 2 and 3: lane 63 holds the total
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v[u]), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v[u]), 63);
+    v[u]         = __hiloint2double(hi, lo);
+  }
 }
 
-// Rows [rBegin, rEnd) of the matrix whose row rBegin starts at H (LDS or HBM: the address space is known at the call).
-// `part` = row sums [n] then NW slabs [n] of mirrored-entry sums, all zero on entry (and visible to the workgroup).  RU rows of a wave are in
-// flight together (their loads are issued before the first use).
-template <int RU>
-__device__ __forceinline__ void hess_rows(double* __restrict__ H, const int rBegin, const int rEnd, const int n, const bool pending,
+// State of one column chunk: this lane's two columns and the vector entries that belong to them.
+struct HessChunk {
+  int    c0;
+  double g0, g1, x0, x1, h0, h1, u0, u1;
+};
+
+// Rows [rFrom, rEnd) of one column chunk; the matrix row `rBase` starts at H (LDS or HBM: the address space is known at the
+// call).  RU rows of a wave form a batch: everything the batch needs is requested before the first use, its RU wave
+// reductions run interleaved, and with PREFETCH (HBM rows) the NEXT batch's matrix pairs are requested before the current
+// batch is worked on — ahead of the current batch's stores, so waiting for them does not wait for the stores (vmcnt is
+// in-order).  The wave index is scalar: row numbers, row offsets and the branches on them live on the scalar unit.
+// col0 / col1 (mirrored-entry sums of the lane's columns) are carried by the caller across the LDS and the HBM range, so
+// every sum is formed in the same order wherever the rows live: results do not depend on the residency split.
+template <int RU, bool PREFETCH>
+__device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBase, const int rFrom, const int rEnd, const int wave,
+                                           const int lane, const HessChunk& ck, const bool pending, const double rfac, const double fad,
+                                           const double fae, const double* __restrict__ xi, const double* __restrict__ hdg,
+                                           const double* __restrict__ uu, const double* __restrict__ g, double* __restrict__ rowsum,
+                                           double& col0, double& col1) {
+  const int base = static_cast<int>(hess_row_offset(rBase));
+  const int c0   = ck.c0;
+  auto row_ptr = [&](const int r) -> double* { return H + (static_cast<int>(hess_row_offset(r)) - base); };
+  auto load_batch = [&](const int r0, double2 (&dst)[RU]) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = r0 + NW * u;
+      dst[u]      = make_double2(0.0, 0.0);
+      if (r < rEnd && c0 <= r) dst[u] = *reinterpret_cast<const double2*>(row_ptr(r) + c0);
+    }
+  };
+  int     r0 = rFrom + ((wave - rFrom) % NW + NW) % NW;  // first row of this wave at or after rFrom
+  double2 next[RU];
+  if constexpr (PREFETCH) load_batch(r0, next);
+  for (; r0 < rEnd; r0 += NW * RU) {
+    double2 hv[RU];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int u = 0; u < RU; ++u) hv[u] = next[u];
+      load_batch(r0 + NW * RU, next);  // rows past rEnd load nothing
+    } else {
+      load_batch(r0, hv);
+    }
+    double rold[RU], gr[RU], ar[RU], br[RU], dr[RU], rs[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r  = r0 + NW * u;
+      const int rc = r < rEnd ? r : rFrom;
+      rold[u]      = rowsum[rc];
+      gr[u]        = g[rc];
+      ar[u]        = pending ? rfac * xi[rc] : 0.0;
+      br[u]        = pending ? fad * hdg[rc] : 0.0;
+      dr[u]        = pending ? fae * uu[rc] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = r0 + NW * u;
+      double2   h = hv[u];
+      if (r < rEnd && pending && c0 <= r) {
+        h.x += ar[u] * ck.x0 - br[u] * ck.h0 + dr[u] * ck.u0;
+        if (c0 + 1 <= r) h.y += ar[u] * ck.x1 - br[u] * ck.h1 + dr[u] * ck.u1;  // the pad entry stays 0
+        *reinterpret_cast<double2*>(row_ptr(r) + c0) = h;
+      }
+      if (r < rEnd && c0 < r) col0 += h.x * gr[u];  // mirrored entries (strictly below the diagonal)
+      if (r < rEnd && c0 + 1 < r) col1 += h.y * gr[u];
+      rs[u] = h.x * ck.g0 + h.y * ck.g1;  // lanes past the row (and rows past the range) hold zeros
+    }
+    wave_sum_n<RU>(rs);
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = r0 + NW * u;
+      if (r < rEnd && lane == 0) rowsum[r] = rold[u] + rs[u];  // one writer per row (this wave), chunks in order
+    }
+  }
+}
+
+// The pass: rows [0, Rl) from LDS (Hl), rows [Rl, n) from HBM (Hg, whose first element is row Rl's).  `part` = row sums
+// [n] (zero on entry, visible to the workgroup) then NW slabs [n] of mirrored-entry sums (written here).
+template <int RUG>
+__device__ __forceinline__ void hess_pass(double* __restrict__ Hl, double* __restrict__ Hg, const int Rl, const int n, const bool pending,
                                           const double rfac, const double fad, const double fae, const double* __restrict__ xi,
                                           const double* __restrict__ hdg, const double* __restrict__ uu,
                                           const double* __restrict__ g, double* __restrict__ part) {
-  const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t base = hess_row_offset(rBegin);
-  double*       rowsum = part;
-  double*       colsum = part + (1 + wave) * n;
-  for (int c0 = 2 * lane, cBase = 0; cBase < rEnd; c0 += 128, cBase += 128) {  // column chunk [cBase, cBase + 128)
-    const bool   in0 = c0 < n, in1 = c0 + 1 < n;
-    const double g0 = in0 ? g[c0] : 0.0, g1 = in1 ? g[c0 + 1] : 0.0;
-    double       x0 = 0.0, x1 = 0.0, h0 = 0.0, h1 = 0.0, u0 = 0.0, u1 = 0.0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  double*   rowsum = part;
+  double*   colsum = part + (1 + wave) * n;
+  for (int cBase = 0; cBase < n; cBase += 128) {  // column chunk [cBase, cBase + 128): rows before cBase have no column in it
+    HessChunk ck;
+    ck.c0          = cBase + 2 * lane;
+    const bool in0 = ck.c0 < n, in1 = ck.c0 + 1 < n;
+    ck.g0          = in0 ? g[ck.c0] : 0.0;
+    ck.g1          = in1 ? g[ck.c0 + 1] : 0.0;
+    ck.x0 = ck.x1 = ck.h0 = ck.h1 = ck.u0 = ck.u1 = 0.0;
     if (pending) {
       if (in0) {
-        x0 = xi[c0];
-        h0 = hdg[c0];
-        u0 = uu[c0];
+        ck.x0 = xi[ck.c0];
+        ck.h0 = hdg[ck.c0];
+        ck.u0 = uu[ck.c0];
       }
       if (in1) {
-        x1 = xi[c0 + 1];
-        h1 = hdg[c0 + 1];
-        u1 = uu[c0 + 1];
+        ck.x1 = xi[ck.c0 + 1];
+        ck.h1 = hdg[ck.c0 + 1];
+        ck.u1 = uu[ck.c0 + 1];
       }
     }
     double col0 = 0.0, col1 = 0.0;
-    // first row of this wave at or after max(rBegin, cBase): rows before cBase have no column in this chunk
-    const int rStart = max(rBegin, cBase);
-    for (int r0 = rStart + ((wave - rStart) % NW + NW) % NW; r0 < rEnd; r0 += NW * RU) {
-      // stage 1: everything a batch of RU rows needs is requested before the first use (matrix pairs, the rows' running
-      // sums, the rows' coefficients): the latencies overlap instead of adding up row after row
-      double2 hv[RU];
-      double  rold[RU], gr[RU], ar[RU], br[RU], dr[RU];
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const int r  = r0 + NW * u;
-        const int rc = r < rEnd ? r : rBegin;
-        hv[u]        = make_double2(0.0, 0.0);
-        if (r < rEnd && c0 <= r) hv[u] = *reinterpret_cast<const double2*>(H + (hess_row_offset(r) - base) + c0);
-        rold[u] = rowsum[rc];
-        gr[u]   = g[rc];
-        ar[u]   = pending ? rfac * xi[rc] : 0.0;
-        br[u]   = pending ? fad * hdg[rc] : 0.0;
-        dr[u]   = pending ? fae * uu[rc] : 0.0;
-      }
-      // stage 2: update, write back, partial sums
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const int r = r0 + NW * u;
-        if (r < rEnd) {  // wave-uniform
-          double2 h = hv[u];
-          if (pending && c0 <= r) {
-            h.x += ar[u] * x0 - br[u] * h0 + dr[u] * u0;
-            if (c0 + 1 <= r) h.y += ar[u] * x1 - br[u] * h1 + dr[u] * u1;  // the pad entry stays 0
-            *reinterpret_cast<double2*>(H + (hess_row_offset(r) - base) + c0) = h;
-          }
-          if (c0 < r) col0 += h.x * gr[u];  // mirrored entries (strictly below the diagonal)
-          if (c0 + 1 < r) col1 += h.y * gr[u];
-          const double rs = wave_sum(h.x * g0 + h.y * g1);  // lanes past the row hold zeros
-          if (lane == 0) rowsum[r] = rold[u] + rs;          // one writer per row (this wave), chunks in order
-        }
-      }
+    // resident rows from LDS (4 rows of a wave per batch), the rest from HBM (8 per batch, next batch prefetched)
+    if (cBase < Rl) hess_range<4, false>(Hl, 0, cBase, Rl, wave, lane, ck, pending, rfac, fad, fae, xi, hdg, uu, g, rowsum, col0, col1);
+    if (Rl < n) {
+      hess_range<RUG, true>(Hg, Rl, max(Rl, cBase), n, wave, lane, ck, pending, rfac, fad, fae, xi, hdg, uu, g, rowsum, col0, col1);
     }
-    // this wave's mirrored-entry sums of the chunk's columns: single writer (the slab was zeroed before the pass; the HBM
-    // range adds to what the LDS range left)
-    if (in0) colsum[c0] += col0;
-    if (in1) colsum[c0 + 1] += col1;
+    if (in0) colsum[ck.c0] = col0;  // this wave's mirrored-entry sums of its columns: single writer
+    if (in1) colsum[ck.c0 + 1] = col1;
   }
 }
 
@@ -790,8 +920,11 @@ __device__ __forceinline__ void hess_finish(const int n, const double* part, dou
 // PROFILE (NVMK_BFGS_PROFILE=1; DG, ETK and MMFF): thread 0 accumulates wall-clock ticks (100 MHz) per phase into
 // prof[sys * 8 + k]: 0 line-search energy evaluations, 1 gradient, 2 pass over H (pending update + H g), 3 update scalars + direction,
 // 4 whole kernel, 5 iterations, 6 energy evaluations.
-template <int KIND, bool PROFILE = false>
-__global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
+// OCC = workgroups the register budget leaves room for on a CU (2: up to 256 VGPRs, 3: up to 168).  The kernels are
+// latency / barrier bound (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES ~ 0.19), so a third resident workgroup can pay even though
+// it gets a smaller share of the LDS for resident inverse-Hessian rows.
+template <int KIND, bool PROFILE = false, int OCC = 2>
+__global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
                                                   const int maxIters, const double gradTol, const int scaleGrads,
                                                   const uint8_t* __restrict__ active, const int64_t* __restrict__ hessStarts,
                                                   const int32_t* __restrict__ order,
@@ -1015,11 +1148,9 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
     }
     // ---- BFGS update of the inverse Hessian, new direction (:304-407) — one pass over H, see hess_pass
     const int64_t tH = now();
-    for (int i = tid; i < (1 + NW) * n; i += NT) part[i] = 0.0;
+    for (int i = tid; i < n; i += NT) part[i] = 0.0;  // row sums accumulate over the column chunks
     __syncthreads();
-    // resident rows from LDS (4 rows of a wave in flight), the rest from HBM (8 in flight: ~1 us of latency to cover)
-    if (Rl > 0) hess_rows<4>(Hl, 0, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
-    if (Rl < n) hess_rows<8>(H, Rl, n, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
+    hess_pass<(OCC >= 3 ? 4 : 8)>(Hl, H, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
     hess_finish(n, part, tvec);  // H is now H_k; tvec = H_k g_new
     __syncthreads();
     tk[2] += now() - tH;
@@ -1206,7 +1337,11 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   constexpr size_t kLdsPerCu = 160 * 1024, kLdsReserve = 1024;  // static LDS of the kernel + allocation granularity
   NVMK_REQUIRE(vecBytes <= kLdsPerCu - kLdsReserve, "bfgs: a system with %d coordinates needs %zu bytes of LDS (max 160 KiB)", maxN,
                vecBytes);
-  size_t budget = kLdsPerCu / 2 - kLdsReserve;
+  // NVMK_BFGS_OCC = 2 | 3: workgroups per CU the kernel variant is compiled for (3 only for the DG / ETK / MMFF kinds)
+  int occ = 2;
+  if (const char* e = std::getenv("NVMK_BFGS_OCC")) occ = std::atoi(e) == 3 ? 3 : 2;
+  if (!(b.kind == NVMK_FF_DG || b.kind == NVMK_FF_ETK || b.kind == NVMK_FF_MMFF)) occ = 2;
+  size_t budget = kLdsPerCu / static_cast<size_t>(occ) - kLdsReserve;
   if (const char* e = std::getenv("NVMK_BFGS_LDS")) {
     if (std::strcmp(e, "full") == 0) {
       budget = kLdsPerCu - kLdsReserve;
@@ -1285,6 +1420,30 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
                    sum[0] / std::max(sum[5], 1.0) * us, sum[1] / std::max(sum[5], 1.0) * us, sum[2] / std::max(sum[5], 1.0) * us,
                    sum[3] / std::max(sum[5], 1.0) * us);
     }
+    return NVMK_OK;
+  }
+  if (occ == 3) {
+    auto launch3 = [&](auto kern) -> int {
+      if (shmem > 64 * 1024) {
+        NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(shmem)));
+      }
+      hipLaunchKernelGGL(kern, dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters, grad_tol, scale_grads, d_active,
+                         startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies, d_statuses, d_iters,
+                         static_cast<int64_t*>(nullptr), ldsDoubles, g_stats.load());
+      return NVMK_OK;
+    };
+    int rc3 = NVMK_OK;
+    if (b.kind == NVMK_FF_DG) {
+      rc3 = launch3(bfgs_kernel<NVMK_FF_DG, false, 3>);
+    } else if (b.kind == NVMK_FF_ETK) {
+      rc3 = launch3(bfgs_kernel<NVMK_FF_ETK, false, 3>);
+    } else {
+      rc3 = launch3(bfgs_kernel<NVMK_FF_MMFF, false, 3>);
+    }
+    if (rc3 != NVMK_OK) return rc3;
+    NVMK_LAUNCH_CHECK();
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
     return NVMK_OK;
   }
   NVMK_FF_DISPATCH(b.kind, {

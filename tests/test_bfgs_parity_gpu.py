@@ -25,15 +25,20 @@ def systems_of(kind, sizes, seed):
     return [synthetic.random_ff_system(kind, n, rng) for n in sizes]
 
 
-@pytest.fixture(params=["0", "auto", "full"])
+@pytest.fixture(params=["0", "auto", "full", "auto:occ3"])
 def lds_policy(request):
-    old = os.environ.get("NVMK_BFGS_LDS")
-    os.environ["NVMK_BFGS_LDS"] = request.param
+    """LDS residency policy of the inverse Hessian (all in HBM / shared by the workgroups of a CU / whole LDS) and the
+    three-workgroups-per-CU kernel variant (NVMK_BFGS_OCC=3)."""
+    pol, _, occ = request.param.partition(":")
+    old = {k: os.environ.get(k) for k in ("NVMK_BFGS_LDS", "NVMK_BFGS_OCC")}
+    os.environ["NVMK_BFGS_LDS"] = pol
+    os.environ["NVMK_BFGS_OCC"] = "3" if occ == "occ3" else "2"
     yield request.param
-    if old is None:
-        os.environ.pop("NVMK_BFGS_LDS", None)
-    else:
-        os.environ["NVMK_BFGS_LDS"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
@@ -84,7 +89,8 @@ def test_minimisation_is_bitwise_reproducible(kind, lds_policy):
 
 
 def test_lds_policies_give_identical_results():
-    """Where the rows of the inverse Hessian live changes no arithmetic: same accumulation order, same bits."""
+    """Where the rows of the inverse Hessian live changes no arithmetic: every sum of the pass is formed in the same order
+    (the mirrored-entry sums are carried across the LDS and the HBM range), same bits."""
     systems = systems_of(MMFF, [20, 48, 64, 90], 41)
     a_s, flat, groups = synthetic.build_ff_batch_arrays(MMFF, systems)
     gpu = FlatForcefieldBatch(MMFF, a_s, groups)
