@@ -24,14 +24,13 @@
 
 #include "common.h"
 #include "ff_grad.h"
+#include "hess_pass.h"
 #include "ff_terms.h"
 
 namespace nvmk {
 namespace minim {
 
 using namespace nvmk::ff;
-
-constexpr int NT = 256;
 
 struct Group {
   const int32_t* starts;
@@ -713,210 +712,6 @@ constexpr double TOLX          = 4.0 * 3.0e-8;
 constexpr double EPS_HESS      = 3.0e-8;
 constexpr int    MAX_LS_ITERS  = 1000;
 
-// ---- inverse-Hessian pass -------------------------------------------------------------------------
-// The inverse Hessian is symmetric: only its lower triangle is stored, row r holding columns 0..r padded to an even
-// length (rows stay 16-byte aligned, the pad entry stays 0).  ONE pass per BFGS iteration streams it once with the
-// whole workgroup: it applies the rank-2 update that the PREVIOUS iteration left pending
-//     H += rfac xi xi^T - fad hdg hdg^T + fae u u^T          (RDKit BFGSOpt.h; u = rfac xi - fad hdg)
-// writes the element back, and accumulates t = H g for the current gradient.  The two products the textbook loop
-// needs per iteration follow from t without touching the matrix again:
-//     H dGrad       = H g_new - H g_old = t - hg                       (hg = H g of the previous iterate, kept in LDS)
-//     H_new g_new   = t + rfac xi (xi.g) - fad hdg (hdg.g) + fae u (u.g)
-// so the traffic per iteration is one read + one write of n (n + 2) / 2 doubles instead of two reads + one write of n^2.
-//
-// Work split (round 2): ONE WAVE PER ROW.  Wave w owns rows w, w + NW, ...; its 64 lanes span 128 consecutive columns of
-// the row as 16-byte pairs, so every load / store of a row is one fully coalesced (global) or conflict-free (LDS) wave
-// instruction.  A lane keeps the vector entries of ITS two columns (xi, hdg, u, g) in registers for the whole column
-// chunk; the row's coefficients are wave-uniform.  Row sums finish with a DPP reduction inside the wave (no LDS), mirrored
-// (column) sums stay in the lane's registers over all the rows of the chunk and are written once per wave.  Every partial
-// sum has a single writer and the final sum runs in a fixed order: a minimisation is reproducible run to run.
-// (Round 1 split rows over 8 row groups x 32 lanes with per-group partial-sum slabs in LDS: measured 20-27 us per pass at
-// n = 144-192 whether the matrix came from HBM or from LDS — the pass was bound by its own chain of LDS read-modify-writes
-// and half-wave shuffles, not by bandwidth: profiles/r02_conformers/.)
-constexpr int NW = NT / 64;  // waves per workgroup
-
-__host__ __device__ __forceinline__ int64_t hess_row_offset(const int64_t r) {  // rows 0..r-1, each padded to even length
-  return ((r + 1) >> 1) * ((r | 1) + 1);  // r even: r (r + 2) / 2, r odd: (r + 1)^2 / 2 — branch-free
-}
-
-// Rows [0, Rl) of the packed triangle live in LDS behind the vectors (as many as the launch's LDS budget holds), rows Rl..
-// stream from HBM.
-__host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t hldsDoubles) {
-  if (hess_row_offset(n) <= hldsDoubles) return n;
-  int r = 0;
-  while (r < n && hess_row_offset(r + 1) <= hldsDoubles) ++r;
-  return r;
-}
-// LDS layout of bfgs_kernel: 11 vectors + (1 + NW) partial-sum slabs of n doubles (row sums, then one slab of mirrored-entry
-// sums per wave; the per-wave gradient slabs alias them), 16 doubles of reduction scratch, then the resident rows of the
-// inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
-__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (12 + NW) * n + 16; }
-__host__ __device__ constexpr int64_t lds_hessian_doubles(const int64_t ldsDoubles, const int64_t n) {
-  return ldsDoubles > lds_vector_doubles(n) ? ldsDoubles - lds_vector_doubles(n) : 0;
-}
-
-// Sum over the 64 lanes of a wave, result in every lane.  DPP moves only (no LDS traffic): butterflies inside a quad and
-// a row of 16, then the two row broadcasts of gfx9; the order of the additions is fixed.
-template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ double dpp_mov(const double x) {
-  if constexpr (ROW_MASK == 0xf) {  // every lane has a source (permutations inside a quad / a row): no "old" value needed
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-  } else {  // row broadcasts: rows outside the mask add 0
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-  }
-}
-// N independent sums at once, step by step: the N dependency chains interleave instead of running one after the other.
-template <int N> __device__ __forceinline__ void wave_sum_n(double (&v)[N]) {
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0xb1>(v[u]);  // quad_perm [1, 0, 3, 2]
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x4e>(v[u]);  // quad_perm [2, 3, 0, 1]
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x124>(v[u]);  // row_ror 4
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x128>(v[u]);  // row_ror 8: every lane of a row of 16 holds the row's sum
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x142, 0xa>(v[u]);  // row_bcast 15 into rows 1 and 3
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x143, 0xc>(v[u]);  // row_bcast 31 into rows 2 and 3: lane 63 holds the total
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v[u]), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v[u]), 63);
-    v[u]         = __hiloint2double(hi, lo);
-  }
-}
-
-// State of one column chunk: this lane's two columns and the vector entries that belong to them.
-struct HessChunk {
-  int    c0;
-  double g0, g1, x0, x1, h0, h1, u0, u1;
-};
-
-// Rows [rFrom, rEnd) of one column chunk; the matrix row `rBase` starts at H (LDS or HBM: the address space is known at the
-// call).  RU rows of a wave form a batch: everything the batch needs is requested before the first use, its RU wave
-// reductions run interleaved, and with PREFETCH (HBM rows) the NEXT batch's matrix pairs are requested before the current
-// batch is worked on — ahead of the current batch's stores, so waiting for them does not wait for the stores (vmcnt is
-// in-order).  The wave index is scalar: row numbers, row offsets and the branches on them live on the scalar unit.
-// col0 / col1 (mirrored-entry sums of the lane's columns) are carried by the caller across the LDS and the HBM range, so
-// every sum is formed in the same order wherever the rows live: results do not depend on the residency split.
-template <int RU, bool PREFETCH>
-__device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBase, const int rFrom, const int rEnd, const int wave,
-                                           const int lane, const HessChunk& ck, const bool pending, const double rfac, const double fad,
-                                           const double fae, const double* __restrict__ xi, const double* __restrict__ hdg,
-                                           const double* __restrict__ uu, const double* __restrict__ g, double* __restrict__ rowsum,
-                                           double& col0, double& col1) {
-  const int base = static_cast<int>(hess_row_offset(rBase));
-  const int c0   = ck.c0;
-  auto row_ptr = [&](const int r) -> double* { return H + (static_cast<int>(hess_row_offset(r)) - base); };
-  auto load_batch = [&](const int r0, double2 (&dst)[RU]) {
-#pragma unroll
-    for (int u = 0; u < RU; ++u) {
-      const int r = r0 + NW * u;
-      dst[u]      = make_double2(0.0, 0.0);
-      if (r < rEnd && c0 <= r) dst[u] = *reinterpret_cast<const double2*>(row_ptr(r) + c0);
-    }
-  };
-  int     r0 = rFrom + ((wave - rFrom) % NW + NW) % NW;  // first row of this wave at or after rFrom
-  double2 next[RU];
-  if constexpr (PREFETCH) load_batch(r0, next);
-  for (; r0 < rEnd; r0 += NW * RU) {
-    double2 hv[RU];
-    if constexpr (PREFETCH) {
-#pragma unroll
-      for (int u = 0; u < RU; ++u) hv[u] = next[u];
-      load_batch(r0 + NW * RU, next);  // rows past rEnd load nothing
-    } else {
-      load_batch(r0, hv);
-    }
-    double rold[RU], gr[RU], ar[RU], br[RU], dr[RU], rs[RU];
-#pragma unroll
-    for (int u = 0; u < RU; ++u) {
-      const int r  = r0 + NW * u;
-      const int rc = r < rEnd ? r : rFrom;
-      rold[u]      = rowsum[rc];
-      gr[u]        = g[rc];
-      ar[u]        = pending ? rfac * xi[rc] : 0.0;
-      br[u]        = pending ? fad * hdg[rc] : 0.0;
-      dr[u]        = pending ? fae * uu[rc] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < RU; ++u) {
-      const int r = r0 + NW * u;
-      double2   h = hv[u];
-      if (r < rEnd && pending && c0 <= r) {
-        h.x += ar[u] * ck.x0 - br[u] * ck.h0 + dr[u] * ck.u0;
-        if (c0 + 1 <= r) h.y += ar[u] * ck.x1 - br[u] * ck.h1 + dr[u] * ck.u1;  // the pad entry stays 0
-        *reinterpret_cast<double2*>(row_ptr(r) + c0) = h;
-      }
-      if (r < rEnd && c0 < r) col0 += h.x * gr[u];  // mirrored entries (strictly below the diagonal)
-      if (r < rEnd && c0 + 1 < r) col1 += h.y * gr[u];
-      rs[u] = h.x * ck.g0 + h.y * ck.g1;  // lanes past the row (and rows past the range) hold zeros
-    }
-    wave_sum_n<RU>(rs);
-#pragma unroll
-    for (int u = 0; u < RU; ++u) {
-      const int r = r0 + NW * u;
-      if (r < rEnd && lane == 0) rowsum[r] = rold[u] + rs[u];  // one writer per row (this wave), chunks in order
-    }
-  }
-}
-
-// The pass: rows [0, Rl) from LDS (Hl), rows [Rl, n) from HBM (Hg, whose first element is row Rl's).  `part` = row sums
-// [n] (zero on entry, visible to the workgroup) then NW slabs [n] of mirrored-entry sums (written here).
-template <int RUG>
-__device__ __forceinline__ void hess_pass(double* __restrict__ Hl, double* __restrict__ Hg, const int Rl, const int n, const bool pending,
-                                          const double rfac, const double fad, const double fae, const double* __restrict__ xi,
-                                          const double* __restrict__ hdg, const double* __restrict__ uu,
-                                          const double* __restrict__ g, double* __restrict__ part) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  double*   rowsum = part;
-  double*   colsum = part + (1 + wave) * n;
-  for (int cBase = 0; cBase < n; cBase += 128) {  // column chunk [cBase, cBase + 128): rows before cBase have no column in it
-    HessChunk ck;
-    ck.c0          = cBase + 2 * lane;
-    const bool in0 = ck.c0 < n, in1 = ck.c0 + 1 < n;
-    ck.g0          = in0 ? g[ck.c0] : 0.0;
-    ck.g1          = in1 ? g[ck.c0 + 1] : 0.0;
-    ck.x0 = ck.x1 = ck.h0 = ck.h1 = ck.u0 = ck.u1 = 0.0;
-    if (pending) {
-      if (in0) {
-        ck.x0 = xi[ck.c0];
-        ck.h0 = hdg[ck.c0];
-        ck.u0 = uu[ck.c0];
-      }
-      if (in1) {
-        ck.x1 = xi[ck.c0 + 1];
-        ck.h1 = hdg[ck.c0 + 1];
-        ck.u1 = uu[ck.c0 + 1];
-      }
-    }
-    double col0 = 0.0, col1 = 0.0;
-    // resident rows from LDS (4 rows of a wave per batch), the rest from HBM (8 per batch, next batch prefetched)
-    if (cBase < Rl) hess_range<4, false>(Hl, 0, cBase, Rl, wave, lane, ck, pending, rfac, fad, fae, xi, hdg, uu, g, rowsum, col0, col1);
-    if (Rl < n) {
-      hess_range<RUG, true>(Hg, Rl, max(Rl, cBase), n, wave, lane, ck, pending, rfac, fad, fae, xi, hdg, uu, g, rowsum, col0, col1);
-    }
-    if (in0) colsum[ck.c0] = col0;  // this wave's mirrored-entry sums of its columns: single writer
-    if (in1) colsum[ck.c0 + 1] = col1;
-  }
-}
-
-// t = H g from the partial sums of hess_rows (fixed summation order).
-__device__ __forceinline__ void hess_finish(const int n, const double* part, double* t) {
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += NT) {
-    double v = part[i];
-#pragma unroll
-    for (int k = 1; k <= NW; ++k) v += part[k * n + i];
-    t[i] = v;
-  }
-}
-
 // PROFILE (NVMK_BFGS_PROFILE=1; DG, ETK and MMFF): thread 0 accumulates wall-clock ticks (100 MHz) per phase into
 // prof[sys * 8 + k]: 0 line-search energy evaluations, 1 gradient, 2 pass over H (pending update + H g), 3 update scalars + direction,
 // 4 whole kernel, 5 iterations, 6 energy evaluations.
@@ -1150,7 +945,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
     const int64_t tH = now();
     for (int i = tid; i < n; i += NT) part[i] = 0.0;  // row sums accumulate over the column chunks
     __syncthreads();
-    hess_pass<(OCC >= 3 ? 4 : 8)>(Hl, H, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
+    hess_pass<(OCC < 3)>(Hl, H, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
     hess_finish(n, part, tvec);  // H is now H_k; tvec = H_k g_new
     __syncthreads();
     tk[2] += now() - tH;
