@@ -12,29 +12,36 @@ namespace minim {
 constexpr int NT = 256;
 
 // ---- inverse-Hessian pass -------------------------------------------------------------------------
-// The inverse Hessian is symmetric: only its lower triangle is stored, row r holding columns 0..r padded to an even
-// length (rows stay 16-byte aligned, the pad entry stays 0).  ONE pass per BFGS iteration streams it once with the
-// whole workgroup: it applies the rank-2 update that the PREVIOUS iteration left pending
+// The inverse Hessian is symmetric.  Its DIAGONAL lives in an n-vector (in LDS for the whole minimisation); its strictly
+// lower triangle is stored by rows, row r holding columns 0..r-1 padded to an even length (rows stay 16-byte aligned, the
+// pad entry stays 0).  ONE pass per BFGS iteration streams the triangle once with the whole workgroup: it applies the
+// rank-2 update that the PREVIOUS iteration left pending
 //     H += rfac xi xi^T - fad hdg hdg^T + fae u u^T          (RDKit BFGSOpt.h; u = rfac xi - fad hdg)
 // writes the element back, and accumulates t = H g for the current gradient.  The two products the textbook loop
 // needs per iteration follow from t without touching the matrix again:
 //     H dGrad       = H g_new - H g_old = t - hg                       (hg = H g of the previous iterate, kept in LDS)
 //     H_new g_new   = t + rfac xi (xi.g) - fad hdg (hdg.g) + fae u (u.g)
-// so the traffic per iteration is one read + one write of n (n + 2) / 2 doubles instead of two reads + one write of n^2.
+// so the traffic per iteration is one read + one write of ~n^2 / 2 doubles instead of two reads + one write of n^2.
 //
-// Work split (round 2): ONE WAVE PER ROW.  Wave w owns rows w, w + NW, ...; its 64 lanes span 128 consecutive columns of
-// the row as 16-byte pairs, so every load / store of a row is one fully coalesced (global) or conflict-free (LDS) wave
-// instruction.  A lane keeps the vector entries of ITS two columns (xi, hdg, u, g) in registers for the whole column
-// chunk; the row's coefficients are wave-uniform.  Row sums finish with a DPP reduction inside the wave (no LDS), mirrored
-// (column) sums stay in the lane's registers over all the rows of the chunk and are written once per wave.  Every partial
-// sum has a single writer and the final sum runs in a fixed order: a minimisation is reproducible run to run.
-// (Round 1 split rows over 8 row groups x 32 lanes with per-group partial-sum slabs in LDS: measured 20-27 us per pass at
-// n = 144-192 whether the matrix came from HBM or from LDS — the pass was bound by its own chain of LDS read-modify-writes
-// and half-wave shuffles, not by bandwidth: profiles/r02_conformers/.)
+// Work split: ONE WAVE PER ROW.  Wave w owns rows w, w + NW, ...; its 64 lanes span 128 consecutive columns of the row as
+// 16-byte pairs, so every load / store of a row is one fully coalesced (global) or conflict-free (LDS) wave instruction.
+// A lane keeps the (pre-scaled) vector entries of ITS columns in registers; a row's coefficients are wave-uniform.  Four
+// rows of a wave form a group: their loads are requested together, their four row sums are reduced together (DPP only),
+// mirrored (column) sums stay in the lane's registers over all rows and are written once per wave.  Every partial sum has
+// a single writer and every sum is formed in a fixed order that does not depend on where the rows live (LDS or HBM): a
+// minimisation is reproducible bit for bit, whatever the launch's LDS budget.
+//
+// What bounds it (measured with tools/ubench_hess.hip, profiles/r02_conformers/): at these sizes (n = 36 .. 384) the pass is
+// bound by INSTRUCTION ISSUE when the rows are in LDS and by the CU's share of HBM bandwidth when they are not — so the code
+// below is written to minimise instructions per row: loads are unconditional (lanes past the end of a row read the next
+// row / zeros and are masked out by ONE predicated region per row), the diagonal is kept apart so that every stored element
+// is a mirrored one (no per-element special cases), rows shorter than 128 columns never touch the second column chunk.
+// (Round 1 split rows over 8 row groups x 32 lanes with per-group partial sums in LDS: 20-27 us per pass at n = 144-192
+// whether the matrix came from HBM or from LDS.)
 constexpr int NW = NT / 64;  // waves per workgroup
 
-__host__ __device__ __forceinline__ int64_t hess_row_offset(const int64_t r) {  // rows 0..r-1, each padded to even length
-  return ((r + 1) >> 1) * ((r | 1) + 1);  // r even: r (r + 2) / 2, r odd: (r + 1)^2 / 2 — branch-free
+__host__ __device__ __forceinline__ int64_t hess_row_offset(const int64_t r) {  // rows 0..r-1 (row k: k entries, padded to even)
+  return (r * r) >> 1;
 }
 
 // Rows [0, Rl) of the packed triangle live in LDS behind the vectors (as many as the launch's LDS budget holds), rows Rl..
@@ -45,16 +52,16 @@ __host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t
   while (r < n && hess_row_offset(r + 1) <= hldsDoubles) ++r;
   return r;
 }
-// LDS layout of bfgs_kernel: 11 vectors + (1 + NW) partial-sum slabs of n doubles (row sums, then one slab of mirrored-entry
-// sums per wave; the per-wave gradient slabs alias them), 16 doubles of reduction scratch, then the resident rows of the
-// inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
-__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (12 + NW) * n + 16; }
+// LDS layout of bfgs_kernel: 12 vectors (the 12th is the diagonal of the inverse Hessian) + (1 + NW) partial-sum slabs of n
+// doubles (row sums, then one slab of mirrored-entry sums per wave; the per-wave gradient slabs alias them), 16 doubles of
+// reduction scratch, then the resident rows of the inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
+__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (13 + NW) * n + 16; }
 __host__ __device__ constexpr int64_t lds_hessian_doubles(const int64_t ldsDoubles, const int64_t n) {
   return ldsDoubles > lds_vector_doubles(n) ? ldsDoubles - lds_vector_doubles(n) : 0;
 }
+// HBM bytes to allocate behind the last system: lanes past the end of the last rows read (and ignore) up to this much
+constexpr int64_t kHessTailPadDoubles = 512;
 
-// Sum over the 64 lanes of a wave, result in every lane.  DPP moves only (no LDS traffic): butterflies inside a quad and
-// a row of 16, then the two row broadcasts of gfx9; the order of the additions is fixed.
 template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ double dpp_mov(const double x) {
   if constexpr (ROW_MASK == 0xf) {  // every lane has a source (permutations inside a quad / a row): no "old" value needed
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
@@ -64,27 +71,6 @@ template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ double dpp_mo
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
-  }
-}
-// N independent sums at once, step by step: the N dependency chains interleave instead of running one after the other.
-template <int N> __device__ __forceinline__ void wave_sum_n(double (&v)[N]) {
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0xb1>(v[u]);  // quad_perm [1, 0, 3, 2]
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x4e>(v[u]);  // quad_perm [2, 3, 0, 1]
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x124>(v[u]);  // row_ror 4
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x128>(v[u]);  // row_ror 8: every lane of a row of 16 holds the row's sum
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x142, 0xa>(v[u]);  // row_bcast 15 into rows 1 and 3
-#pragma unroll
-  for (int u = 0; u < N; ++u) v[u] += dpp_mov<0x143, 0xc>(v[u]);  // row_bcast 31 into rows 2 and 3: lane 63 holds the total
-#pragma unroll
-  for (int u = 0; u < N; ++u) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v[u]), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v[u]), 63);
-    v[u]         = __hiloint2double(hi, lo);
   }
 }
 
@@ -103,44 +89,40 @@ __device__ __forceinline__ double wave_sum4_transposed(const double (&rs)[4], co
   return x;
 }
 
-// State of one column chunk of 128 columns: this lane's two columns and the vector entries that belong to them.
+// State of one column chunk of 128 columns: this lane's two columns, the gradient entries and the PRE-SCALED update
+// vectors that belong to them (xs = rfac xi, hs = fad hdg, us = fae u: a row then needs its raw xi, hdg, u only).
 struct HessChunk {
   int    c0;
-  double g0, g1, x0, x1, h0, h1, u0, u1;
+  double g0, g1, xs0, xs1, hs0, hs1, us0, us1;
 };
 
-// Rows [rFrom, rEnd) of NCH adjacent column chunks (128 NCH columns); the matrix row `rBase` starts at H (LDS or HBM: the
-// address space is known at the call).  A wave owns rows w, w + NW, ...; four of its rows form a group whose loads are all
-// requested before the first use and whose four row sums are reduced together (wave_sum4_transposed); with PREFETCH (HBM
-// rows) the NEXT group's matrix pairs are requested before the current group is worked on — ahead of the current group's
-// stores, so waiting for them does not wait for the stores (vmcnt is in-order).  Per-row overhead (coefficients, reduction,
-// row-sum update) is shared by the NCH chunks: the pass is bound by instruction issue, not by bandwidth, at these sizes.
+// Rows [rFrom, rEnd) of NCH adjacent column chunks; the matrix row `rBase` starts at H (LDS or HBM: the address space is
+// known at the call).  With PREFETCH (HBM rows) the NEXT group's matrix pairs are requested before the current group is
+// worked on — ahead of the current group's stores, so waiting for them does not wait for the stores (vmcnt is in-order).
 // The wave index is scalar: row numbers, row offsets and the branches on them live on the scalar unit.
-// col[k][0..1] (mirrored-entry sums of the lane's columns) are carried by the caller across the LDS and the HBM range, so
-// every sum is formed in the same order wherever the rows live: results do not depend on the residency split.
+// col[k][0..1] (mirrored-entry sums of the lane's columns) are carried by the caller across ranges.
 template <int NCH, bool PREFETCH>
 __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBase, const int rFrom, const int rEnd, const int wave,
-                                           const int lane, const HessChunk (&ck)[NCH], const bool pending, const double rfac,
-                                           const double fad, const double fae, const double* __restrict__ xi,
-                                           const double* __restrict__ hdg, const double* __restrict__ uu,
-                                           const double* __restrict__ g, double* __restrict__ rowsum, double (&col)[NCH][2]) {
+                                           const int lane, const HessChunk (&ck)[NCH], const bool pending,
+                                           const double* __restrict__ xi, const double* __restrict__ hdg,
+                                           const double* __restrict__ uu, const double* __restrict__ g, double* __restrict__ rowsum,
+                                           double (&col)[NCH][2]) {
   constexpr int RU   = 4;
   const int     base = static_cast<int>(hess_row_offset(rBase));
   auto row_ptr = [&](const int r) -> double* { return H + (static_cast<int>(hess_row_offset(r)) - base); };
   auto load_group = [&](const int r0, double2 (&dst)[RU][NCH]) {
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-      const int r = r0 + NW * u;
+      const int r = min(r0 + NW * u, rEnd - 1);  // rows past the range re-read the last one (never used)
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        dst[u][k] = make_double2(0.0, 0.0);
-        if (r < rEnd && ck[k].c0 <= r) dst[u][k] = *reinterpret_cast<const double2*>(row_ptr(r) + ck[k].c0);
-      }
+      for (int k = 0; k < NCH; ++k) dst[u][k] = *reinterpret_cast<const double2*>(row_ptr(r) + ck[k].c0);  // unconditional
     }
   };
   int     r0 = rFrom + ((wave - rFrom) % NW + NW) % NW;  // first row of this wave at or after rFrom
   double2 next[RU][NCH];
-  if constexpr (PREFETCH) load_group(r0, next);
+  if constexpr (PREFETCH) {
+    if (r0 < rEnd) load_group(r0, next);
+  }
   for (; r0 < rEnd; r0 += NW * RU) {
     double2 hv[RU][NCH];
     if constexpr (PREFETCH) {
@@ -149,39 +131,44 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
 #pragma unroll
         for (int k = 0; k < NCH; ++k) hv[u][k] = next[u][k];
       }
-      load_group(r0 + NW * RU, next);  // rows past rEnd load nothing
+      if (r0 + NW * RU < rEnd) load_group(r0 + NW * RU, next);
     } else {
       load_group(r0, hv);
     }
     // the row this LANE will write the sum of (lane & 3 selects it, see wave_sum4_transposed) and its running sum
     const int    myRow = r0 + NW * (lane & 3);
     const double rold  = (lane < 4 && myRow < rEnd) ? rowsum[myRow] : 0.0;
-    double       gr[RU], ar[RU], br[RU], dr[RU], rs[RU];
+    double       gr[RU], xr[RU], hr[RU], ur[RU], rs[RU];
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-      const int r  = r0 + NW * u;
-      const int rc = r < rEnd ? r : rFrom;
+      const int rc = min(r0 + NW * u, rEnd - 1);
       gr[u]        = g[rc];
-      ar[u]        = pending ? rfac * xi[rc] : 0.0;
-      br[u]        = pending ? fad * hdg[rc] : 0.0;
-      dr[u]        = pending ? fae * uu[rc] : 0.0;
+      xr[u]        = xi[rc];
+      hr[u]        = hdg[rc];
+      ur[u]        = uu[rc];
     }
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
       const int r = r0 + NW * u;
       rs[u]       = 0.0;
+      if (r < rEnd) {  // wave-uniform
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        const int c0 = ck[k].c0;
-        double2   h  = hv[u][k];
-        if (r < rEnd && pending && c0 <= r) {
-          h.x += ar[u] * ck[k].x0 - br[u] * ck[k].h0 + dr[u] * ck[k].u0;
-          if (c0 + 1 <= r) h.y += ar[u] * ck[k].x1 - br[u] * ck[k].h1 + dr[u] * ck[k].u1;  // the pad entry stays 0
-          *reinterpret_cast<double2*>(row_ptr(r) + c0) = h;
+        for (int k = 0; k < NCH; ++k) {
+          const int c0 = ck[k].c0;
+          if (c0 < r) {  // ONE predicated region per row and chunk: the lanes that hold entries of this row
+            double2    h   = hv[u][k];
+            const bool two = c0 + 1 < r;  // false only for the lane holding the pad of an odd-length row
+            if (pending) {
+              h.x += xr[u] * ck[k].xs0 - hr[u] * ck[k].hs0 + ur[u] * ck[k].us0;
+              const double y = h.y + (xr[u] * ck[k].xs1 - hr[u] * ck[k].hs1 + ur[u] * ck[k].us1);
+              h.y            = two ? y : 0.0;  // the pad entry stays 0
+              *reinterpret_cast<double2*>(row_ptr(r) + c0) = h;
+            }
+            col[k][0] += h.x * gr[u];  // every stored entry is strictly below the diagonal: it has a mirror image
+            col[k][1] += h.y * gr[u];
+            rs[u] += h.x * ck[k].g0 + h.y * ck[k].g1;
+          }
         }
-        if (r < rEnd && c0 < r) col[k][0] += h.x * gr[u];  // mirrored entries (strictly below the diagonal)
-        if (r < rEnd && c0 + 1 < r) col[k][1] += h.y * gr[u];
-        rs[u] += h.x * ck[k].g0 + h.y * ck[k].g1;  // lanes past the row (and rows past the range) hold zeros
       }
     }
     const double tot = wave_sum4_transposed(rs, lane);
@@ -189,68 +176,84 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
   }
 }
 
-// The pass: rows [0, Rl) from LDS (Hl), rows [Rl, n) from HBM (Hg, whose first element is row Rl's).  `part` = row sums
-// [n] (zero on entry, visible to the workgroup) then NW slabs [n] of mirrored-entry sums (written here).
-template <int NCH, bool PREFETCH>
-__device__ __forceinline__ void hess_pass_chunks(double* __restrict__ Hl, double* __restrict__ Hg, const int Rl, const int n,
-                                                 const bool pending, const double rfac, const double fad, const double fae,
-                                                 const double* __restrict__ xi, const double* __restrict__ hdg,
-                                                 const double* __restrict__ uu, const double* __restrict__ g,
-                                                 double* __restrict__ part) {
+template <int NCH> __device__ __forceinline__ void hess_chunk_state(HessChunk (&ck)[NCH], double (&col)[NCH][2], const int cBase,
+                                                                    const int lane, const int n, const bool pending, const double rfac,
+                                                                    const double fad, const double fae, const double* __restrict__ xi,
+                                                                    const double* __restrict__ hdg, const double* __restrict__ uu,
+                                                                    const double* __restrict__ g) {
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int  c0  = cBase + 128 * k + 2 * lane;
+    const bool in0 = c0 < n, in1 = c0 + 1 < n;
+    ck[k].c0       = c0;
+    ck[k].g0       = in0 ? g[c0] : 0.0;
+    ck[k].g1       = in1 ? g[c0 + 1] : 0.0;
+    ck[k].xs0 = ck[k].xs1 = ck[k].hs0 = ck[k].hs1 = ck[k].us0 = ck[k].us1 = 0.0;
+    if (pending) {
+      if (in0) {
+        ck[k].xs0 = rfac * xi[c0];
+        ck[k].hs0 = fad * hdg[c0];
+        ck[k].us0 = fae * uu[c0];
+      }
+      if (in1) {
+        ck[k].xs1 = rfac * xi[c0 + 1];
+        ck[k].hs1 = fad * hdg[c0 + 1];
+        ck[k].us1 = fae * uu[c0 + 1];
+      }
+    }
+    col[k][0] = col[k][1] = 0.0;
+  }
+}
+
+// The pass: diagonal in `diag` (LDS), rows [0, Rl) of the strict lower triangle from LDS (Hl), rows [Rl, n) from HBM (Hg,
+// whose first element is row Rl's).  `part` = row sums [n] then NW slabs [n] of mirrored-entry sums (all written here).
+// PREFETCH: the HBM rows' next group is requested one group ahead (more VGPRs; off in the three-workgroups-per-CU kernels).
+// Must be entered by the whole workgroup after a barrier (it starts by writing the row sums of the diagonal).
+template <bool PREFETCH = true>
+__device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __restrict__ Hl, double* __restrict__ Hg, const int Rl,
+                                          const int n, const bool pending, const double rfac, const double fad, const double fae,
+                                          const double* __restrict__ xi, const double* __restrict__ hdg, const double* __restrict__ uu,
+                                          const double* __restrict__ g, double* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   double*   rowsum = part;
   double*   colsum = part + (1 + wave) * n;
-  for (int cBase = 0; cBase < n; cBase += 128 * NCH) {  // column super-chunk: rows before cBase have no column in it
-    HessChunk ck[NCH];
-    double    col[NCH][2];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      const int  c0  = cBase + 128 * k + 2 * lane;
-      const bool in0 = c0 < n, in1 = c0 + 1 < n;
-      ck[k].c0       = c0;
-      ck[k].g0       = in0 ? g[c0] : 0.0;
-      ck[k].g1       = in1 ? g[c0 + 1] : 0.0;
-      ck[k].x0 = ck[k].x1 = ck[k].h0 = ck[k].h1 = ck[k].u0 = ck[k].u1 = 0.0;
-      if (pending) {
-        if (in0) {
-          ck[k].x0 = xi[c0];
-          ck[k].h0 = hdg[c0];
-          ck[k].u0 = uu[c0];
-        }
-        if (in1) {
-          ck[k].x1 = xi[c0 + 1];
-          ck[k].h1 = hdg[c0 + 1];
-          ck[k].u1 = uu[c0 + 1];
-        }
-      }
-      col[k][0] = col[k][1] = 0.0;
+  // the diagonal: update, and start every row sum with its term
+  for (int i = threadIdx.x; i < n; i += NT) {
+    double d = diag[i];
+    if (pending) {
+      d += rfac * xi[i] * xi[i] - fad * hdg[i] * hdg[i] + fae * uu[i] * uu[i];
+      diag[i] = d;
     }
-    if (cBase < Rl) hess_range<NCH, false>(Hl, 0, cBase, Rl, wave, lane, ck, pending, rfac, fad, fae, xi, hdg, uu, g, rowsum, col);
-    if (Rl < n) hess_range<NCH, PREFETCH>(Hg, Rl, max(Rl, cBase), n, wave, lane, ck, pending, rfac, fad, fae, xi, hdg, uu, g, rowsum, col);
+    rowsum[i] = d * g[i];
+  }
+  __syncthreads();
+  for (int cBase = 0; cBase < n; cBase += 256) {  // column super-chunk of 2 x 128 columns: rows before cBase have no column in it
+    HessChunk ck[2];
+    double    col[2][2];
+    hess_chunk_state<2>(ck, col, cBase, lane, n, pending, rfac, fad, fae, xi, hdg, uu, g);
+    // rows that reach into the first chunk only ([cBase, cBase + 128]) never touch the second one
+    const int mid = min(n, cBase + 129);  // row cBase + 128 is the first with an entry in the second chunk... (c0 < r)
+    {
+      HessChunk(&ck1)[1]    = reinterpret_cast<HessChunk(&)[1]>(ck[0]);
+      double(&col1)[1][2]   = reinterpret_cast<double(&)[1][2]>(col[0]);
+      const int lo = cBase, hi = mid;
+      if (lo < min(hi, Rl)) hess_range<1, false>(Hl, 0, lo, min(hi, Rl), wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
+      if (max(lo, Rl) < hi) hess_range<1, PREFETCH>(Hg, Rl, max(lo, Rl), hi, wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
+    }
+    if (mid < n) {
+      if (mid < Rl) hess_range<2, false>(Hl, 0, mid, Rl, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
+      if (max(mid, Rl) < n) hess_range<2, PREFETCH>(Hg, Rl, max(mid, Rl), n, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
+    }
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {  // this wave's mirrored-entry sums of its columns: single writer
+    for (int k = 0; k < 2; ++k) {  // this wave's mirrored-entry sums of its columns: single writer
       if (ck[k].c0 < n) colsum[ck[k].c0] = col[k][0];
       if (ck[k].c0 + 1 < n) colsum[ck[k].c0 + 1] = col[k][1];
     }
   }
 }
 
-// Rows of up to 128 columns take one chunk per lane, longer rows two at a time (the benchmark sizes: n = 3 x 48 .. 4 x 96).
-// PREFETCH: the HBM rows' next group is requested one group ahead (32 more VGPRs; off in the three-workgroups-per-CU kernels).
-template <bool PREFETCH = true>
-__device__ __forceinline__ void hess_pass(double* __restrict__ Hl, double* __restrict__ Hg, const int Rl, const int n, const bool pending,
-                                          const double rfac, const double fad, const double fae, const double* __restrict__ xi,
-                                          const double* __restrict__ hdg, const double* __restrict__ uu,
-                                          const double* __restrict__ g, double* __restrict__ part) {
-  if (n <= 128) {
-    hess_pass_chunks<1, PREFETCH>(Hl, Hg, Rl, n, pending, rfac, fad, fae, xi, hdg, uu, g, part);
-  } else {
-    hess_pass_chunks<2, PREFETCH>(Hl, Hg, Rl, n, pending, rfac, fad, fae, xi, hdg, uu, g, part);
-  }
-}
-
-// t = H g from the partial sums of hess_rows (fixed summation order).
+// t = H g from the partial sums of the pass (fixed summation order).
 __device__ __forceinline__ void hess_finish(const int n, const double* part, double* t) {
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += NT) {

@@ -754,7 +754,8 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
   double* pxi   = tvec + n;   // pending rank-2 update: xi, H dGrad, u
   double* phdg  = pxi + n;
   double* pu    = phdg + n;
-  double* part  = pu + n;     // (1 + NW) n partial sums of the pass; its first NW slabs double as the per-wave gradients
+  double* hdiag = pu + n;     // diagonal of the inverse Hessian (the strict lower triangle is in Hl / H)
+  double* part  = hdiag + n;  // (1 + NW) n partial sums of the pass; its first NW slabs double as the per-wave gradients
   double* red   = part + (1 + NW) * n;  // NT/64 + 1 (padded to 8)
   // Inverse Hessian: the first Rl rows of the packed triangle live in LDS behind the vectors (as many as the launch's LDS
   // budget holds: all of them for small systems), rows Rl.. stream from HBM as before.
@@ -777,14 +778,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
     for (int64_t i = tid; i < nl / 2; i += NT) L2[i] = make_double2(0.0, 0.0);
     double2* H2 = reinterpret_cast<double2*>(H);
     for (int64_t i = tid; i < (total - nl) / 2; i += NT) H2[i] = make_double2(0.0, 0.0);
-    __syncthreads();
-    for (int r = tid; r < n; r += NT) {  // H = identity
-      if (r < Rl) {
-        Hl[hess_row_offset(r) + r] = 1.0;
-      } else {
-        H[hess_row_offset(r) - nl + r] = 1.0;
-      }
-    }
+    for (int r = tid; r < n; r += NT) hdiag[r] = 1.0;  // H = identity
   }
 
   // The term-range offsets of this system (two per group, constant for the whole minimisation) are cached in LDS and the
@@ -943,9 +937,8 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
     }
     // ---- BFGS update of the inverse Hessian, new direction (:304-407) — one pass over H, see hess_pass
     const int64_t tH = now();
-    for (int i = tid; i < n; i += NT) part[i] = 0.0;  // row sums accumulate over the column chunks
     __syncthreads();
-    hess_pass<(OCC < 3)>(Hl, H, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
+    hess_pass<(OCC < 3)>(hdiag, Hl, H, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
     hess_finish(n, part, tvec);  // H is now H_k; tvec = H_k g_new
     __syncthreads();
     tk[2] += now() - tH;
@@ -1155,7 +1148,7 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
     hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + hess_row_offset(n) - hess_row_offset(rl);
   }
   StreamScratch hessMem, startsMem, orderMem;
-  NVMK_HIP_CHECK(hessMem.alloc(static_cast<size_t>(hs.back()) * sizeof(double), stream));
+  NVMK_HIP_CHECK(hessMem.alloc(static_cast<size_t>(hs.back() + kHessTailPadDoubles) * sizeof(double), stream));
   NVMK_HIP_CHECK(startsMem.alloc(hs.size() * sizeof(int64_t), stream));
   NVMK_HIP_CHECK(hipMemcpyAsync(startsMem.ptr, hs.data(), hs.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
   // launch order: largest system first (stable), see bfgs_kernel

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(NT, OCC) void pass_kernel(double* __restrict__ hess
   double*   uu   = hdg + n;
   double*   g    = uu + n;
   double*   tvec = g + n;
-  double*   part = xi + 11 * n;  // same offsets as bfgs_kernel: 11 vectors, then the partial sums
+  double*   diag = xi + 11 * n;  // same offsets as bfgs_kernel: 11 vectors, the diagonal, then the partial sums
+  double*   part = diag + n;
   double*   red  = part + (1 + NW) * n;
   double*   Hl   = red + 16;
   double*   H    = hessians + starts[blockIdx.x];
@@ -49,24 +50,15 @@ __global__ __launch_bounds__(NT, OCC) void pass_kernel(double* __restrict__ hess
     const int64_t nl = hess_row_offset(Rl), total = hess_row_offset(n);
     for (int64_t i = tid; i < nl; i += NT) Hl[i] = 0.0;
     for (int64_t i = tid; i < total - nl; i += NT) H[i] = 0.0;
-    __syncthreads();
-    for (int r = tid; r < n; r += NT) {
-      if (r < Rl) {
-        Hl[hess_row_offset(r) + r] = 1.0;
-      } else {
-        H[hess_row_offset(r) - nl + r] = 1.0;
-      }
-    }
+    for (int r = tid; r < n; r += NT) diag[r] = 1.0;
   }
   __syncthreads();
   const long long t0 = wall_clock64();
   for (int it = 0; it < iters; ++it) {
-    for (int i = tid; i < n; i += NT) part[i] = 0.0;
-    __syncthreads();
-    hess_pass<(OCC < 3)>(Hl, H, Rl, n, true, 1.0e-3, 2.0e-3, 0.5, xi, hdg, uu, g, part);
+    hess_pass<(OCC < 3)>(diag, Hl, H, Rl, n, true, 1.0e-6, 2.0e-6, 0.5e-3, xi, hdg, uu, g, part);
     hess_finish(n, part, tvec);
     __syncthreads();
-    for (int i = tid; i < n; i += NT) g[i] = 0.999 * g[i] + 1.0e-3 * tvec[i];  // the next pass depends on this one
+    for (int i = tid; i < n; i += NT) g[i] = 0.5 * g[i] + 1.0e-3 * tvec[i];  // the next pass depends on this one
     __syncthreads();
   }
   const long long t1 = wall_clock64();
@@ -95,7 +87,7 @@ int main(int argc, char** argv) {
   double *   dH = nullptr, *dSum = nullptr;
   int64_t*   dStarts = nullptr;
   long long* dTicks  = nullptr;
-  CHECK(hipMalloc(&dH, std::max<size_t>(static_cast<size_t>(perSys) * systems * 8, 8)));
+  CHECK(hipMalloc(&dH, (static_cast<size_t>(perSys) * systems + kHessTailPadDoubles) * 8));
   CHECK(hipMalloc(&dSum, systems * sizeof(double)));
   CHECK(hipMalloc(&dStarts, starts.size() * sizeof(int64_t)));
   CHECK(hipMalloc(&dTicks, systems * sizeof(long long)));
