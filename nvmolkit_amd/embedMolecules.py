@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from nvmolkit_amd import _native
-from nvmolkit_amd.forcefield import GROUP_LAYOUT, DG, ETK
+from nvmolkit_amd.forcefield import GROUP_LAYOUT, DG, ETK, PAIR_ORDER_GROUPS, diagonal_pair_order, pair_order_enabled
 from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
 N_STAGES = _native.ETKDG_N_STAGES
@@ -49,9 +49,9 @@ class FlatMoleculeSet:
         self.c.n_mols = len(self.mols)
         self.c.h_n_atoms = self.n_atoms.ctypes.data
         self.has_etk = bool(self.mols) and all(m.etk is not None for m in self.mols)
-        self._fill_groups(self.c.dg, GROUP_LAYOUT[DG], [m.dg for m in self.mols])
+        self._fill_groups(self.c.dg, GROUP_LAYOUT[DG], [m.dg for m in self.mols], PAIR_ORDER_GROUPS[DG])
         if self.has_etk:
-            counts = self._fill_groups(self.c.etk, GROUP_LAYOUT[ETK], [m.etk for m in self.mols])
+            counts = self._fill_groups(self.c.etk, GROUP_LAYOUT[ETK], [m.etk for m in self.mols], PAIR_ORDER_GROUPS[ETK])
             self.d12 = np.ascontiguousarray(counts[2], dtype=np.int32)
             self.d13 = np.ascontiguousarray(counts[3], dtype=np.int32)
             self.c.h_etk_d12_counts = self.d12.ctypes.data
@@ -75,7 +75,7 @@ class FlatMoleculeSet:
         self._keep.append(t)
         return t
 
-    def _fill_groups(self, c_groups, layout, per_mol_groups):
+    def _fill_groups(self, c_groups, layout, per_mol_groups, reorder=()):
         counts = []
         for g, (n_idx, n_par) in enumerate(layout):
             starts = np.zeros(len(per_mol_groups) + 1, dtype=np.int32)
@@ -90,9 +90,13 @@ class FlatMoleculeSet:
             counts.append(np.diff(starts))
             idx_cat = np.concatenate(idx_all) if idx_all else np.zeros((0, n_idx), np.int32)
             par_cat = np.concatenate(par_all) if par_all else np.zeros((0, n_par))
-            c_groups[g].starts = self._dev(starts).data_ptr()
-            c_groups[g].idx = self._dev(idx_cat).data_ptr() if idx_cat.size else None
-            c_groups[g].par = self._dev(par_cat).data_ptr() if par_cat.size else None
+            d_starts, d_idx, d_par = self._dev(starts), self._dev(idx_cat), self._dev(par_cat)
+            if g in reorder and pair_order_enabled():
+                d_idx, d_par = diagonal_pair_order(d_starts, d_idx, d_par)
+                self._keep += [d_idx, d_par]
+            c_groups[g].starts = d_starts.data_ptr()
+            c_groups[g].idx = d_idx.data_ptr() if idx_cat.size else None
+            c_groups[g].par = d_par.data_ptr() if par_cat.size else None
         return counts
 
 

@@ -10,6 +10,7 @@ interface (src/forcefields/batched_forcefield.h:74-149) and BfgsBatchMinimizer (
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Sequence
 
 import numpy as np
@@ -28,8 +29,37 @@ GROUP_LAYOUT = {
     UFF: [(2, 2), (3, 6), (4, 3), (4, 4), (2, 3)],
 }
 DIM = {DG: 4, ETK: 3, MMFF: 3, QUARTIC: 4, UFF: 3}
+#: pair-term groups whose rows are re-ordered on the device when a batch is built (see :func:`diagonal_pair_order`);
+#: the small 1-2 / 1-3 groups keep the caller's order (ETK groups 2 and 3 are tied to per-system reference distances)
+PAIR_ORDER_GROUPS = {DG: (0,), ETK: (5,), MMFF: (5, 6), UFF: (4,), QUARTIC: ()}
 # MMFF / UFF batches may append up to four constraint groups (distance, position, angle, torsion; include/nvmolkit_amd.h)
 CONSTRAINT_LAYOUT = [(2, 3), (1, 5), (3, 3), (4, 3)]
+
+
+def pair_order_enabled() -> bool:
+    """``NVMK_PAIR_ORDER=input`` keeps the caller's row order of the pair tables (A/B switch for measurements)."""
+    return os.environ.get("NVMK_PAIR_ORDER", "diagonal") != "input"
+
+
+def diagonal_pair_order(starts: torch.Tensor, idx: torch.Tensor, par: torch.Tensor):
+    """Re-order the rows of a pair-term group inside every system by (|j - i|, min(i, j)).
+
+    RDKit (and every natural builder) emits the O(N^2) pair lists i-major: 64 consecutive terms share atom i, so the 64
+    lanes of a wavefront accumulate their forces into the SAME three LDS words and the hardware serialises the atomic
+    adds lane by lane.  Along a diagonal of the pair matrix consecutive terms touch distinct atoms on both sides.  The
+    energy and gradient are sums over terms, so only the floating-point summation order changes.  Runs on the device
+    (one key computation + one sort per group and batch).
+    """
+    n_terms = idx.shape[0]
+    if n_terms == 0:
+        return idx, par
+    counts = (starts[1:] - starts[:-1]).to(torch.int64)
+    seg = torch.repeat_interleave(torch.arange(counts.numel(), device=idx.device, dtype=torch.int64), counts, output_size=n_terms)
+    a, b = idx[:, 0].to(torch.int64), idx[:, 1].to(torch.int64)
+    lo = torch.minimum(a, b)
+    key = (seg << 40) | ((torch.maximum(a, b) - lo) << 20) | lo
+    perm = torch.argsort(key, stable=True)
+    return idx[perm].contiguous(), par[perm].contiguous()
 
 
 class FlatForcefieldBatch:
@@ -88,6 +118,8 @@ class FlatForcefieldBatch:
                 raise ValueError(f"term group {g}: inconsistent starts / idx / par sizes")
             t = [torch.from_numpy(starts).to(self.device), torch.from_numpy(idx.copy()).to(self.device),
                  torch.from_numpy(np.ascontiguousarray(par)).to(self.device)]
+            if g in PAIR_ORDER_GROUPS[kind] and pair_order_enabled():
+                t[1], t[2] = diagonal_pair_order(t[0], t[1], t[2])
             self._keep.extend(t)
             self._c.groups[g].starts = t[0].data_ptr()
             self._c.groups[g].idx = t[1].data_ptr() if len(idx) else None
