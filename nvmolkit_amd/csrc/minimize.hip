@@ -254,14 +254,126 @@ __device__ __forceinline__ double constraint_terms(const Batch& b, const int fir
   return e;
 }
 
+// ---- term batches: every group's first terms are loaded before any of them is computed --------------------------------
+// One evaluation walks 3-7 term groups.  Written group after group, each group costs a full chain of dependent
+// latencies (table offsets -> indices and parameters -> positions in LDS -> arithmetic) before the next one starts:
+// 8.5 us per MMFF energy evaluation of a 48-atom molecule, of which < 3 us is arithmetic (profiles/r02_conformers).
+// system_eval therefore first ISSUES the loads of every group's leading batch (PUK terms per thread: 4 for the O(N^2)
+// pair groups, 1 for the bonded groups, which rarely have more than 256 terms) and only then computes them in issue
+// order; what a group holds beyond its leading batch is walked by a batched remainder loop.
+template <int NI, int NP, int PUK> struct TermBatch {
+  int    a[PUK][NI];
+  double p[PUK][NP > 0 ? NP : 1];
+  int    first;  // this thread's first term
+  int    begin;  // the group's first term of this system (for tables indexed relative to it)
+  int    end;
+};
+
+template <int NI, int NP> __device__ __forceinline__ void load_term(const Group& g, const int t, int (&a)[NI], double (&p)[NP > 0 ? NP : 1]) {
+  if constexpr (NI == 2) {
+    const int2 v = *reinterpret_cast<const int2*>(g.idx + 2 * t);
+    a[0] = v.x, a[1] = v.y;
+  } else if constexpr (NI == 4) {
+    const int4 v = *reinterpret_cast<const int4*>(g.idx + 4 * t);
+    a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < NI; ++q) a[q] = g.idx[NI * t + q];
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q) p[q] = g.par[NP * t + q];
+}
+
+template <int NI, int NP, int PUK> __device__ __forceinline__ void load_batch(const Group& g, const int first, TermBatch<NI, NP, PUK>& tb) {
+  tb.first = first;
+#pragma unroll
+  for (int k = 0; k < PUK; ++k) {
+    const int t = first + k * NT;
+    if (t < tb.end) load_term<NI, NP>(g, t, tb.a[k], tb.p[k]);
+  }
+}
+
+// What an evaluation needs to know about its system besides the positions: the table row, every group's term range
+// (empty when the group is masked off) and the ETK reference distances.  All of it is constant over a minimisation, so
+// the fused BFGS kernel builds it ONCE and keeps it in scalar registers; evaluations then start with the term loads
+// themselves instead of a chain of offset loads (two per group, 3-11 groups per evaluation).
+struct TermRange {
+  int begin, end;
+};
+struct EvalContext {
+  int           ms;  // row of the term tables
+  TermRange     r[12];
+  const double* ref[2];
+};
+// Thread rotation of a group: term t of the group is taken by thread (t - begin + rot) mod NT, with rot = the number of
+// terms in the groups before it.  The bonded groups have fewer terms than the workgroup has threads; unrotated, every
+// one of them starts at thread 0, so wave 0 walks ALL of them one after the other (each a chain of square roots,
+// divisions and an arc cosine at FP64 latency) while wave 3 has nothing but its pair terms: the evaluation takes as
+// long as wave 0.  Rotated, the groups lie end to end across the waves.
+__device__ __forceinline__ int group_rotation(const EvalContext& c, const int gi) {
+  int rot = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+    if (k < gi) rot += c.r[k].end - c.r[k].begin;
+  return rot & (NT - 1);
+}
+template <int KIND> struct GroupCount {
+  static constexpr int value = KIND == NVMK_FF_DG ? 3 : KIND == NVMK_FF_ETK ? 6 : KIND == NVMK_FF_MMFF ? 7 : KIND == KIND_MMFF_C ? 11
+                               : KIND == NVMK_FF_UFF ? 5 : KIND == KIND_UFF_C ? 9 : 0;
+};
+template <int KIND> __device__ __forceinline__ EvalContext eval_context(const Batch& b, const int sys) {
+  EvalContext c;
+  c.ms = b.sysMol ? b.sysMol[sys] : sys;
+#pragma unroll
+  for (int gi = 0; gi < 12; ++gi) {
+    if (gi < GroupCount<KIND>::value) {
+      // branch-free: a masked-off or absent group reads the always-valid atom offsets and gets an empty range
+      const bool     enabled = ((b.groupMask >> gi) & 1u) != 0u && b.g[gi].starts != nullptr;
+      const int32_t* st      = enabled ? b.g[gi].starts : b.atomStarts;
+      const int      lo = st[c.ms], hi = st[c.ms + 1];
+      c.r[gi] = {__builtin_amdgcn_readfirstlane(lo), __builtin_amdgcn_readfirstlane(enabled ? hi : lo)};
+    } else {
+      c.r[gi] = {0, 0};
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) c.ref[k] = (KIND == NVMK_FF_ETK && b.ref[k]) ? b.ref[k] + b.refStarts[k][sys] : nullptr;
+  return c;
+}
+
+template <int NI, int NP, int PUK>
+__device__ __forceinline__ TermBatch<NI, NP, PUK> term_batch(const Group& g, const TermRange r, const int rot) {
+  TermBatch<NI, NP, PUK> tb;
+  tb.begin = r.begin;
+  tb.end   = r.end;
+  load_batch<NI, NP, PUK>(g, tb.begin + ((static_cast<int>(threadIdx.x) + NT - rot) & (NT - 1)), tb);
+  return tb;
+}
+
+// body(t, a, p): term index, its atom indices, its parameters.
+template <int NI, int NP, int PUK, typename Body>
+__device__ __forceinline__ void run_terms(const Group& g, TermBatch<NI, NP, PUK>& tb, Body&& body) {
+  while (true) {
+#pragma unroll
+    for (int k = 0; k < PUK; ++k) {
+      const int t = tb.first + k * NT;
+      if (t < tb.end) body(t, tb.a[k], tb.p[k]);
+    }
+    const int next = tb.first + PUK * NT;
+    if (next >= tb.end) break;
+    load_batch<NI, NP, PUK>(g, next, tb);
+  }
+}
+
 // GRAD = false: returns the energy partial.  GRAD = true: accumulates the gradient, returns 0.
 template <int KIND, bool GRAD>
-__device__ __forceinline__ double system_eval(const Batch& b, const int sys, const double* pos, double* grad, const double w0, const double w1,
-                              const int globalCoordStart) {
+__device__ __forceinline__ double system_eval(const Batch& b, const EvalContext& ctx, const int nCoords, const double* pos, double* grad,
+                                               const double w0, const double w1, const int globalCoordStart) {
   constexpr int DIM = Dim<KIND>::value;
   const int     tid = threadIdx.x;
-  const int     ms  = b.sysMol ? b.sysMol[sys] : sys;  // row of the term tables
+  const int     ms  = ctx.ms;
   double        e   = 0.0;
+  (void)nCoords;
   (void)grad;
   (void)ms;
   (void)w0;
@@ -271,8 +383,7 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
   if constexpr (KIND == NVMK_FF_QUARTIC) {
     // test field of the reference's BFGS suite (tests/test_bfgs_minimizer.cu:823-860): sum (x_p - p)^4 over the
     // GLOBAL coordinate index p; w0 != 0 includes the 4th coordinate of every atom
-    const int n = (b.atomStarts[sys + 1] - b.atomStarts[sys]) * 4;
-    for (int p = tid; p < n; p += NT) {
+    for (int p = tid; p < nCoords; p += NT) {
       if ((p & 3) == 3 && w0 == 0.0) continue;
       const double diff = pos[p] - static_cast<double>(globalCoordStart + p);
       if constexpr (GRAD) {
@@ -284,393 +395,350 @@ __device__ __forceinline__ double system_eval(const Batch& b, const int sys, con
     return e;
   }
 
-  auto on = [&](const int gi) { return (b.groupMask >> gi) & 1u; };
+  [[maybe_unused]] AtomicAcc<DIM> acc{grad};
+  // positions of a term's atoms for the scalar (energy) form of the angular terms
+  auto at = [&](const int atom, const int slot) { return Loader<double, DIM>::get(pos, atom, slot); };
+  (void)at;
+
   if constexpr (KIND == NVMK_FF_DG) {
-    if (on(0)) {  // distance violations, all 4 dimensions (dist_geom_kernels_device.cuh:37-95)
-      pair_terms<3>(b.g[0], ms, [&](const int, const int i, const int j, const double* p) {
-        double       d[4];
-        const double d2 = pair_dist2<DIM>(pos, i, j, 4, d);
-        double       et, dE;
-        dist_violation(d2, p[0], p[1], p[2], et, dE);
-        if constexpr (GRAD) {
-          if (dE != 0.0) pair_push<DIM>(grad, i, j, 4, d, 2.0 * dE);
-        } else {
-          e += et;
-        }
-      });
-    }
-    if (on(1)) {  // chiral volumes, weight w0 (:97-207); RDKit's gradient is half the derivative
-      const Group& g = b.g[1];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
-        if constexpr (GRAD) {
+    auto t0 = term_batch<2, 3, PU>(b.g[0], ctx.r[0], group_rotation(ctx, 0));
+    auto t1 = term_batch<4, 2, 1>(b.g[1], ctx.r[1], group_rotation(ctx, 1));
+    auto t2 = term_batch<1, 0, 1>(b.g[2], ctx.r[2], group_rotation(ctx, 2));
+    // distance violations, all 4 dimensions (dist_geom_kernels_device.cuh:37-95)
+    run_terms(b.g[0], t0, [&](const int, const int* a, const double* p) {
+      double       d[4];
+      const double d2 = pair_dist2<DIM>(pos, a[0], a[1], 4, d);
+      double       et, dE;
+      dist_violation(d2, p[0], p[1], p[2], et, dE);
+      if constexpr (GRAD) {
+        if (dE != 0.0) pair_push<DIM>(grad, a[0], a[1], 4, d, 2.0 * dE);
+      } else {
+        e += et;
+      }
+    });
+    // chiral volumes, weight w0 (:97-207); RDKit's gradient is half the derivative
+    run_terms(b.g[1], t1, [&](const int, const int* a, const double* p) {
+      if constexpr (GRAD) {
+        const int aa[4] = {a[0], a[1], a[2], a[3]};
 #ifdef NVMK_FF_DUAL_GRAD
-          using D       = Dual<12>;
-          const D   vol = chiral_volume(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                        Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3));
-          const D   ev  = chiral_violation(vol, g.par[2 * t], g.par[2 * t + 1], w0);
-          scatter<12, DIM, 4>(ev, a, grad, 0.5);
+        using D     = Dual<12>;
+        const D vol = chiral_volume(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                    Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3));
+        scatter<12, DIM, 4>(chiral_violation(vol, p[0], p[1], w0), aa, grad, 0.5);
 #else
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_dg_chiral<DIM>(pos, a, g.par[2 * t], g.par[2 * t + 1], w0, acc);
+        ffg::grad_dg_chiral<DIM>(pos, aa, p[0], p[1], w0, acc);
 #endif
-        } else {
-          const double vol = chiral_volume(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                                           Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3));
-          e += chiral_violation(vol, g.par[2 * t], g.par[2 * t + 1], w0);
-        }
+      } else {
+        e += chiral_violation(chiral_volume(at(a[0], 0), at(a[1], 1), at(a[2], 2), at(a[3], 3)), p[0], p[1], w0);
       }
-    }
-    if (on(2)) {  // fourth dimension, weight w1 (:209-231): E = w x4^2, RDKit gradient w x4
-      const Group& g = b.g[2];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int    i = g.idx[t];
-        const double x = pos[i * DIM + 3];
-        if constexpr (GRAD) {
-          atomicAdd(&grad[i * DIM + 3], w1 * x);
-        } else {
-          e += w1 * x * x;
-        }
+    });
+    // fourth dimension, weight w1 (:209-231): E = w x4^2, RDKit gradient w x4
+    run_terms(b.g[2], t2, [&](const int, const int* a, const double*) {
+      const double x = pos[a[0] * DIM + 3];
+      if constexpr (GRAD) {
+        atomicAdd(&grad[a[0] * DIM + 3], w1 * x);
+      } else {
+        e += w1 * x * x;
       }
-    }
+    });
     return e;
   }
 
   if constexpr (KIND == NVMK_FF_ETK) {
-    if (on(0)) {  // experimental torsions: 6 force constants + 6 signs per term (:237-313, :447-575)
-      const Group& g = b.g[0];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
-        const double* fc   = g.par + 12 * t;
-        bool          ok;
-        if constexpr (GRAD) {
-#ifdef NVMK_FF_DUAL_GRAD
-          using D   = Dual<12>;
-          const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                   Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
-          if (ok) scatter<12, DIM, 4>(torsion_m6(c, fc, fc + 6), a, grad, 1.0);
-#else
-          (void)ok;
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_etk_torsion<DIM>(pos, a, fc, acc);
-#endif
-        } else {
-          const double c = cos_dihedral(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                                        Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), ok);
-          e += torsion_m6(ok ? c : 0.0, fc, fc + 6);  // degenerate: cosPhi = 0 (:286-288)
-        }
-      }
-    }
-    if (on(1)) {  // improper torsions / inversions: C0, C1, C2, k (:315-366, :577-694)
-      const Group& g = b.g[1];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
-        const double* p    = g.par + 4 * t;
-        if constexpr (GRAD) {
-#ifdef NVMK_FF_DUAL_GRAD
-          using D = Dual<12>;
-          scatter<12, DIM, 4>(inversion(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                        Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0], p[1], p[2],
-                                        p[3]),
-                              a, grad, 1.0);
-#else
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_inversion<DIM>(pos, a, p[1], p[2], p[3], false, acc);
-#endif
-        } else {
-          e += inversion(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                         Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), p[0], p[1], p[2], p[3]);
-        }
-      }
-    }
+    // 1-2 / 1-3 restraints may be re-centred per system: bounds = ref +- (max - min) / 2 unless the term's 4th
+    // parameter pins the table bounds (isImproperConstrained, dist_geom.h:103-110)
+    const double* ref2 = ctx.ref[0];
+    const double* ref3 = ctx.ref[1];
+    auto t0 = term_batch<4, 0, 1>(b.g[0], ctx.r[0], group_rotation(ctx, 0));  // indices only: the 12 parameters of the (few) torsions would pin 24 registers
+    auto t1 = term_batch<4, 4, 1>(b.g[1], ctx.r[1], group_rotation(ctx, 1));
+    auto t2 = term_batch<2, 4, 1>(b.g[2], ctx.r[2], group_rotation(ctx, 2));
+    auto t3 = term_batch<2, 4, 1>(b.g[3], ctx.r[3], group_rotation(ctx, 3));
+    auto t4 = term_batch<3, 2, 1>(b.g[4], ctx.r[4], group_rotation(ctx, 4));
+    auto t5 = term_batch<2, 4, PU>(b.g[5], ctx.r[5], group_rotation(ctx, 5));
+    const double r2first = (ref2 && t2.first < t2.end) ? ref2[t2.first - t2.begin] : 0.0;
+    const double r3first = (ref3 && t3.first < t3.end) ? ref3[t3.first - t3.begin] : 0.0;
     // flat-bottom distance restraints in 3-D: groups 2 (1-2), 3 (1-3), 5 (long range) (:368-392, :696-729)
-#pragma unroll
-    for (int gi = 2; gi <= 5; ++gi) {
-      if (gi == 4 || !on(gi)) continue;
-      const Group& g = b.g[gi];
-      // 1-2 / 1-3 restraints may be re-centred per system: bounds = ref +- (max - min) / 2 unless the term's 4th
-      // parameter pins the table bounds (isImproperConstrained, dist_geom.h:103-110)
-      const double* ref = (gi <= 3 && b.ref[gi - 2]) ? b.ref[gi - 2] + b.refStarts[gi - 2][sys] : nullptr;
-      const int     t0  = g.starts[ms];
-      pair_terms<4>(g, ms, [&](const int t, const int i, const int j, const double* p) {
-        double       d[4];
-        const double dist = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
-        double       lo = p[0], hi = p[1];
-        if (ref && p[3] == 0.0) {
-          const double half = 0.5 * (hi - lo);
-          lo                = ref[t - t0] - half;
-          hi                = ref[t - t0] + half;
-        }
-        double et, dE;
-        dist_constraint(dist, lo, hi, p[2], et, dE);
-        if constexpr (GRAD) {
-          if (dE != 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / (dist > 1.0e-8 ? dist : 1.0e-8));
-        } else {
-          e += et;
-        }
-      });
-    }
-    if (on(4)) {  // 1-3 angle restraints, force constant 1 (:394-445, :731-830)
-      const Group& g = b.g[4];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
-        if constexpr (GRAD) {
-#ifdef NVMK_FF_DUAL_GRAD
-          using D = Dual<9>;
-          scatter<9, DIM, 3>(angle_constraint(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                              Loader<D, DIM>::get(pos, a[2], 2), g.par[2 * t], g.par[2 * t + 1], 1.0),
-                             a, grad, 1.0);
-#else
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_angle_window<DIM>(pos, a, g.par[2 * t], g.par[2 * t + 1], 1.0, acc);
-#endif
-        } else {
-          e += angle_constraint(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                                Loader<double, DIM>::get(pos, a[2], 2), g.par[2 * t], g.par[2 * t + 1], 1.0);
-        }
+    auto restraint = [&](const int* a, const double lo, const double hi, const double k) {
+      double       d[4];
+      const double dist = sqrt(pair_dist2<DIM>(pos, a[0], a[1], 3, d));
+      double       et, dE;
+      dist_constraint(dist, lo, hi, k, et, dE);
+      if constexpr (GRAD) {
+        if (dE != 0.0) pair_push<DIM>(grad, a[0], a[1], 3, d, dE / (dist > 1.0e-8 ? dist : 1.0e-8));
+      } else {
+        e += et;
       }
+    };
+    // experimental torsions: 6 force constants + 6 signs per term (:237-313, :447-575)
+    run_terms(b.g[0], t0, [&](const int t, const int* a, const double*) {
+      const double* fc = b.g[0].par + 12 * t;
+      if constexpr (GRAD) {
+        const int aa[4] = {a[0], a[1], a[2], a[3]};
+#ifdef NVMK_FF_DUAL_GRAD
+        using D = Dual<12>;
+        bool    ok;
+        const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                 Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
+        if (ok) scatter<12, DIM, 4>(torsion_m6(c, fc, fc + 6), aa, grad, 1.0);
+#else
+        ffg::grad_etk_torsion<DIM>(pos, aa, fc, acc);
+#endif
+      } else {
+        bool         ok;
+        const double c = cos_dihedral(at(a[0], 0), at(a[1], 1), at(a[2], 2), at(a[3], 3), ok);
+        e += torsion_m6(ok ? c : 0.0, fc, fc + 6);  // degenerate: cosPhi = 0 (:286-288)
+      }
+    });
+    // improper torsions / inversions: C0, C1, C2, k (:315-366, :577-694)
+    run_terms(b.g[1], t1, [&](const int, const int* a, const double* p) {
+      if constexpr (GRAD) {
+        const int aa[4] = {a[0], a[1], a[2], a[3]};
+#ifdef NVMK_FF_DUAL_GRAD
+        using D = Dual<12>;
+        scatter<12, DIM, 4>(inversion(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                      Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0], p[1], p[2], p[3]),
+                            aa, grad, 1.0);
+#else
+        ffg::grad_inversion<DIM>(pos, aa, p[1], p[2], p[3], false, acc);
+#endif
+      } else {
+        e += inversion(at(a[0], 0), at(a[1], 1), at(a[2], 2), at(a[3], 3), p[0], p[1], p[2], p[3]);
+      }
+    });
+    auto recentred = [&](const double* ref, const double refFirst, const int first, const int begin) {
+      return [&, ref, refFirst, first, begin](const int t, const int* a, const double* p) {
+        double lo = p[0], hi = p[1];
+        if (ref && p[3] == 0.0) {
+          const double centre = (t == first) ? refFirst : ref[t - begin];
+          const double half   = 0.5 * (hi - lo);
+          lo                  = centre - half;
+          hi                  = centre + half;
+        }
+        restraint(a, lo, hi, p[2]);
+      };
+    };
+    {
+      const int first2 = t2.first, first3 = t3.first;  // run_terms advances .first through the remainder
+      run_terms(b.g[2], t2, recentred(ref2, r2first, first2, t2.begin));
+      run_terms(b.g[3], t3, recentred(ref3, r3first, first3, t3.begin));
     }
+    // 1-3 angle restraints, force constant 1 (:394-445, :731-830)
+    run_terms(b.g[4], t4, [&](const int, const int* a, const double* p) {
+      if constexpr (GRAD) {
+        const int aa[3] = {a[0], a[1], a[2]};
+#ifdef NVMK_FF_DUAL_GRAD
+        using D = Dual<9>;
+        scatter<9, DIM, 3>(angle_constraint(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                            Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], 1.0),
+                           aa, grad, 1.0);
+#else
+        ffg::grad_angle_window<DIM>(pos, aa, p[0], p[1], 1.0, acc);
+#endif
+      } else {
+        e += angle_constraint(at(a[0], 0), at(a[1], 1), at(a[2], 2), p[0], p[1], 1.0);
+      }
+    });
+    // long-range restraints last (their loads are the largest)
+    run_terms(b.g[5], t5, [&](const int, const int* a, const double* p) { restraint(a, p[0], p[1], p[2]); });
     return e;
   }
 
   if constexpr (KIND == NVMK_FF_MMFF || KIND == KIND_MMFF_C) {
-    if (on(0)) {  // bond stretch: r0, kb
-      pair_terms<2>(b.g[0], ms, [&](const int, const int i, const int j, const double* p) {
-        double       d[4];
-        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
-        double       et, dE;
-        mmff_bond(r, p[0], p[1], et, dE);
-        if constexpr (GRAD) {
-          if (r > 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / r);
-        } else {
-          e += et;
-        }
-      });
-    }
-    if (on(1)) {  // angle bend: theta0, ka, isLinear
-      const Group& g = b.g[1];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
-        const double* p    = g.par + 3 * t;
-        if constexpr (GRAD) {
+    // issue order = compute order: the bonded groups first; while they compute, the larger loads of the pair groups
+    // are still arriving
+    auto t1 = term_batch<3, 3, 1>(b.g[1], ctx.r[1], group_rotation(ctx, 1));
+    auto t2 = term_batch<3, 5, 1>(b.g[2], ctx.r[2], group_rotation(ctx, 2));
+    auto t3 = term_batch<4, 1, 1>(b.g[3], ctx.r[3], group_rotation(ctx, 3));
+    auto t4 = term_batch<4, 3, 1>(b.g[4], ctx.r[4], group_rotation(ctx, 4));
+    auto t0 = term_batch<2, 2, 1>(b.g[0], ctx.r[0], group_rotation(ctx, 0));
+    auto t5 = term_batch<2, 2, PU>(b.g[5], ctx.r[5], group_rotation(ctx, 5));
+    auto t6 = term_batch<2, 3, PU>(b.g[6], ctx.r[6], group_rotation(ctx, 6));
+    // angle bend: theta0, ka, isLinear
+    run_terms(b.g[1], t1, [&](const int, const int* a, const double* p) {
+      if constexpr (GRAD) {
+        const int aa[3] = {a[0], a[1], a[2]};
 #ifdef NVMK_FF_DUAL_GRAD
-          using D = Dual<9>;
-          scatter<9, DIM, 3>(mmff_angle(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                        Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], p[2] != 0.0),
-                             a, grad, 1.0);
+        using D = Dual<9>;
+        scatter<9, DIM, 3>(mmff_angle(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                      Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], p[2] != 0.0),
+                           aa, grad, 1.0);
 #else
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_mmff_angle<DIM>(pos, a, p[0], p[1], p[2] != 0.0, acc);
+        ffg::grad_mmff_angle<DIM>(pos, aa, p[0], p[1], p[2] != 0.0, acc);
 #endif
-        } else {
-          e += mmff_angle(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                          Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], p[2] != 0.0);
-        }
+      } else {
+        e += mmff_angle(at(a[0], 0), at(a[1], 1), at(a[2], 2), p[0], p[1], p[2] != 0.0);
       }
-    }
-    if (on(2)) {  // stretch-bend: theta0, r0ij, r0kj, kbaIJK, kbaKJI
-      const Group& g = b.g[2];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
-        const double* p    = g.par + 5 * t;
-        if constexpr (GRAD) {
+    });
+    // stretch-bend: theta0, r0ij, r0kj, kbaIJK, kbaKJI
+    run_terms(b.g[2], t2, [&](const int, const int* a, const double* p) {
+      if constexpr (GRAD) {
+        const int aa[3] = {a[0], a[1], a[2]};
 #ifdef NVMK_FF_DUAL_GRAD
-          using D = Dual<9>;
-          scatter<9, DIM, 3>(mmff_stretch_bend(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                               Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], p[2], p[3], p[4]),
-                             a, grad, 1.0);
+        using D = Dual<9>;
+        scatter<9, DIM, 3>(mmff_stretch_bend(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                             Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], p[2], p[3], p[4]),
+                           aa, grad, 1.0);
 #else
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_mmff_stretch_bend<DIM>(pos, a, p, acc);
+        ffg::grad_mmff_stretch_bend<DIM>(pos, aa, p, acc);
 #endif
-        } else {
-          e += mmff_stretch_bend(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                                 Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], p[2], p[3], p[4]);
-        }
+      } else {
+        e += mmff_stretch_bend(at(a[0], 0), at(a[1], 1), at(a[2], 2), p[0], p[1], p[2], p[3], p[4]);
       }
-    }
-    if (on(3)) {  // out-of-plane: koop
-      const Group& g = b.g[3];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
-        if constexpr (GRAD) {
+    });
+    // out-of-plane: koop
+    run_terms(b.g[3], t3, [&](const int, const int* a, const double* p) {
+      if constexpr (GRAD) {
+        const int aa[4] = {a[0], a[1], a[2], a[3]};
 #ifdef NVMK_FF_DUAL_GRAD
-          using D = Dual<12>;
-          scatter<12, DIM, 4>(mmff_oop(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                       Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), g.par[t]),
-                              a, grad, 1.0);
+        using D = Dual<12>;
+        scatter<12, DIM, 4>(mmff_oop(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                     Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0]),
+                            aa, grad, 1.0);
 #else
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_mmff_oop<DIM>(pos, a, g.par[t], acc);
+        ffg::grad_mmff_oop<DIM>(pos, aa, p[0], acc);
 #endif
-        } else {
-          e += mmff_oop(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                        Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), g.par[t]);
-        }
+      } else {
+        e += mmff_oop(at(a[0], 0), at(a[1], 1), at(a[2], 2), at(a[3], 3), p[0]);
       }
-    }
-    if (on(4)) {  // torsion: V1, V2, V3
-      const Group& g = b.g[4];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
-        const double* p    = g.par + 3 * t;
-        bool          ok;
-        if constexpr (GRAD) {
+    });
+    // torsion: V1, V2, V3
+    run_terms(b.g[4], t4, [&](const int, const int* a, const double* p) {
+      if constexpr (GRAD) {
+        const int aa[4] = {a[0], a[1], a[2], a[3]};
 #ifdef NVMK_FF_DUAL_GRAD
-          using D   = Dual<12>;
-          const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                   Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
-          if (ok) scatter<12, DIM, 4>(mmff_torsion(c, p[0], p[1], p[2]), a, grad, 1.0);
+        using D = Dual<12>;
+        bool    ok;
+        const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                 Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
+        if (ok) scatter<12, DIM, 4>(mmff_torsion(c, p[0], p[1], p[2]), aa, grad, 1.0);
 #else
-          (void)ok;
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_mmff_torsion<DIM>(pos, a, p[0], p[1], p[2], acc);
+        ffg::grad_mmff_torsion<DIM>(pos, aa, p[0], p[1], p[2], acc);
 #endif
-        } else {
-          const double c = cos_dihedral(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                                        Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), ok);
-          e += mmff_torsion(ok ? c : 0.0, p[0], p[1], p[2]);
-        }
+      } else {
+        bool         ok;
+        const double c = cos_dihedral(at(a[0], 0), at(a[1], 1), at(a[2], 2), at(a[3], 3), ok);
+        e += mmff_torsion(ok ? c : 0.0, p[0], p[1], p[2]);
       }
-    }
-    if (on(5)) {  // van der Waals: R*, eps
-      pair_terms<2>(b.g[5], ms, [&](const int, const int i, const int j, const double* p) {
-        double       d[4];
-        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
-        double       et, dE;
-        mmff_vdw(r, p[0], p[1], et, dE);
-        if constexpr (GRAD) {
-          if (r > 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / r);
-        } else {
-          e += et;
-        }
-      });
-    }
-    if (on(6)) {  // electrostatics: chargeTerm, dielModel, is1_4
-      pair_terms<3>(b.g[6], ms, [&](const int, const int i, const int j, const double* p) {
-        double       d[4];
-        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
-        double       et, dE;
-        mmff_ele(r, p[0], static_cast<int>(p[1]), p[2] != 0.0, et, dE);
-        if constexpr (GRAD) {
-          if (r > 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / r);
-        } else {
-          e += et;
-        }
-      });
-    }
+    });
+    // radial terms share their tail: distance, the term's (energy, dE/dr), force along the pair
+    auto radial = [&](const int* a, auto&& term) {
+      double       d[4];
+      const double r = sqrt(pair_dist2<DIM>(pos, a[0], a[1], 3, d));
+      double       et, dE;
+      term(r, et, dE);
+      if constexpr (GRAD) {
+        if (r > 0.0) pair_push<DIM>(grad, a[0], a[1], 3, d, dE / r);
+      } else {
+        e += et;
+      }
+    };
+    // bond stretch: r0, kb
+    run_terms(b.g[0], t0, [&](const int, const int* a, const double* p) {
+      radial(a, [&](const double r, double& et, double& dE) { mmff_bond(r, p[0], p[1], et, dE); });
+    });
+    // van der Waals: R*, eps
+    run_terms(b.g[5], t5, [&](const int, const int* a, const double* p) {
+      radial(a, [&](const double r, double& et, double& dE) { mmff_vdw(r, p[0], p[1], et, dE); });
+    });
+    // electrostatics: chargeTerm, dielModel, is1_4
+    run_terms(b.g[6], t6, [&](const int, const int* a, const double* p) {
+      radial(a, [&](const double r, double& et, double& dE) { mmff_ele(r, p[0], static_cast<int>(p[1]), p[2] != 0.0, et, dE); });
+    });
     if constexpr (KIND == KIND_MMFF_C) e += constraint_terms<DIM, GRAD>(b, 7, ms, pos, grad);
     return e;
   }
 
   if constexpr (KIND == NVMK_FF_UFF || KIND == KIND_UFF_C) {
-    if (on(0)) {  // bond stretch: r0, k
-      pair_terms<2>(b.g[0], ms, [&](const int, const int i, const int j, const double* p) {
-        double       d[4];
-        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
-        double       et, dE;
-        uff_bond(r, p[0], p[1], et, dE);
-        if constexpr (GRAD) {
-          if (r > 0.0) {
-            pair_push<DIM>(grad, i, j, 3, d, dE / r);
-          } else {  // coincident atoms: the reference pushes them apart along (1, 1, 1) with k / 100 (:56-58)
-            const double one[4] = {1.0, 1.0, 1.0, 0.0};
-            pair_push<DIM>(grad, i, j, 3, one, p[1] * 0.01);
-          }
-        } else {
-          e += et;
+    auto t4 = term_batch<2, 3, PU>(b.g[4], ctx.r[4], group_rotation(ctx, 4));
+    auto t0 = term_batch<2, 2, 1>(b.g[0], ctx.r[0], group_rotation(ctx, 0));
+    auto t1 = term_batch<3, 6, 1>(b.g[1], ctx.r[1], group_rotation(ctx, 1));
+    auto t2 = term_batch<4, 3, 1>(b.g[2], ctx.r[2], group_rotation(ctx, 2));
+    auto t3 = term_batch<4, 4, 1>(b.g[3], ctx.r[3], group_rotation(ctx, 3));
+    const double one[4] = {1.0, 1.0, 1.0, 0.0};
+    // van der Waals: x_ij, wellDepth, threshold
+    run_terms(b.g[4], t4, [&](const int, const int* a, const double* p) {
+      double       d[4];
+      const double r = sqrt(pair_dist2<DIM>(pos, a[0], a[1], 3, d));
+      double       et, dE;
+      uff_vdw(r, p[0], p[1], p[2], et, dE);
+      if constexpr (GRAD) {
+        if (r > 0.0) {
+          if (dE != 0.0) pair_push<DIM>(grad, a[0], a[1], 3, d, dE / r);
+        } else if (r <= p[2]) {  // coincident atoms inside the cutoff: +-100 per component (:552-560)
+          pair_push<DIM>(grad, a[0], a[1], 3, one, 100.0);
         }
-      });
-    }
-    if (on(1)) {  // angle bend: theta0, k, order, C0, C1, C2
-      const Group& g = b.g[1];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int     a[3] = {g.idx[3 * t], g.idx[3 * t + 1], g.idx[3 * t + 2]};
-        const double* p    = g.par + 6 * t;
-        const int     ord  = static_cast<int>(p[2]);
-        if constexpr (GRAD) {
-#ifdef NVMK_FF_DUAL_GRAD
-          using D = Dual<9>;
-          scatter<9, DIM, 3>(uff_angle(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                       Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], ord, p[3], p[4], p[5]),
-                             a, grad, 1.0);
-#else
-          (void)ord;
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_uff_angle<DIM>(pos, a, p, acc);
-#endif
-        } else {
-          e += uff_angle(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                         Loader<double, DIM>::get(pos, a[2], 2), p[0], p[1], ord, p[3], p[4], p[5]);
-        }
+      } else {
+        e += et;
       }
-    }
-    if (on(2)) {  // torsion: k, order, cosTerm
-      const Group& g = b.g[2];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
-        const double* p    = g.par + 3 * t;
-        const int     ord  = static_cast<int>(p[1]);
-        bool          ok;
-        if constexpr (GRAD) {
-#ifdef NVMK_FF_DUAL_GRAD
-          using D   = Dual<12>;
-          const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                   Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
-          if (ok) scatter<12, DIM, 4>(uff_torsion(c, p[0], ord, p[2]), a, grad, 1.0);
-#else
-          (void)ok;
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_uff_torsion<DIM>(pos, a, p[0], ord, p[2], acc);
-#endif
-        } else {
-          const double c = cos_dihedral(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                                        Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), ok);
-          e += uff_torsion(ok ? c : 0.0, p[0], ord, p[2]);  // collinear: cos(phi) := 0 (:271-273)
+    });
+    // bond stretch: r0, k
+    run_terms(b.g[0], t0, [&](const int, const int* a, const double* p) {
+      double       d[4];
+      const double r = sqrt(pair_dist2<DIM>(pos, a[0], a[1], 3, d));
+      double       et, dE;
+      uff_bond(r, p[0], p[1], et, dE);
+      if constexpr (GRAD) {
+        if (r > 0.0) {
+          pair_push<DIM>(grad, a[0], a[1], 3, d, dE / r);
+        } else {  // coincident atoms: the reference pushes them apart along (1, 1, 1) with k / 100 (:56-58)
+          pair_push<DIM>(grad, a[0], a[1], 3, one, p[1] * 0.01);
         }
+      } else {
+        e += et;
       }
-    }
-    if (on(3)) {  // inversion: k, C0, C1, C2
-      const Group& g = b.g[3];
-      for (int t = g.starts[ms] + tid; t < g.starts[ms + 1]; t += NT) {
-        const int     a[4] = {g.idx[4 * t], g.idx[4 * t + 1], g.idx[4 * t + 2], g.idx[4 * t + 3]};
-        const double* p    = g.par + 4 * t;
-        if constexpr (GRAD) {
+    });
+    // angle bend: theta0, k, order, C0, C1, C2
+    run_terms(b.g[1], t1, [&](const int, const int* a, const double* p) {
+      if constexpr (GRAD) {
+        const int aa[3] = {a[0], a[1], a[2]};
 #ifdef NVMK_FF_DUAL_GRAD
-          using D = Dual<12>;
-          scatter<12, DIM, 4>(uff_inversion(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
-                                            Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0], p[1],
-                                            p[2], p[3]),
-                              a, grad, 1.0);
+        using D = Dual<9>;
+        scatter<9, DIM, 3>(uff_angle(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                     Loader<D, DIM>::get(pos, a[2], 2), p[0], p[1], static_cast<int>(p[2]), p[3], p[4], p[5]),
+                           aa, grad, 1.0);
 #else
-          AtomicAcc<DIM> acc{grad};
-          ffg::grad_inversion<DIM>(pos, a, p[2], p[3], p[0], true, acc);
+        ffg::grad_uff_angle<DIM>(pos, aa, p, acc);
 #endif
-        } else {
-          e += uff_inversion(Loader<double, DIM>::get(pos, a[0], 0), Loader<double, DIM>::get(pos, a[1], 1),
-                             Loader<double, DIM>::get(pos, a[2], 2), Loader<double, DIM>::get(pos, a[3], 3), p[0], p[1], p[2],
-                             p[3]);
-        }
+      } else {
+        e += uff_angle(at(a[0], 0), at(a[1], 1), at(a[2], 2), p[0], p[1], static_cast<int>(p[2]), p[3], p[4], p[5]);
       }
-    }
-    if (on(4)) {  // van der Waals: x_ij, wellDepth, threshold
-      pair_terms<3>(b.g[4], ms, [&](const int, const int i, const int j, const double* p) {
-        double       d[4];
-        const double r = sqrt(pair_dist2<DIM>(pos, i, j, 3, d));
-        double       et, dE;
-        uff_vdw(r, p[0], p[1], p[2], et, dE);
-        if constexpr (GRAD) {
-          if (r > 0.0) {
-            if (dE != 0.0) pair_push<DIM>(grad, i, j, 3, d, dE / r);
-          } else if (r <= p[2]) {  // coincident atoms inside the cutoff: +-100 per component (:552-560)
-            const double one[4] = {1.0, 1.0, 1.0, 0.0};
-            pair_push<DIM>(grad, i, j, 3, one, 100.0);
-          }
-        } else {
-          e += et;
-        }
-      });
-    }
+    });
+    // torsion: k, order, cosTerm
+    run_terms(b.g[2], t2, [&](const int, const int* a, const double* p) {
+      const int ord = static_cast<int>(p[1]);
+      if constexpr (GRAD) {
+        const int aa[4] = {a[0], a[1], a[2], a[3]};
+#ifdef NVMK_FF_DUAL_GRAD
+        using D = Dual<12>;
+        bool    ok;
+        const D c = cos_dihedral(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                 Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), ok);
+        if (ok) scatter<12, DIM, 4>(uff_torsion(c, p[0], ord, p[2]), aa, grad, 1.0);
+#else
+        ffg::grad_uff_torsion<DIM>(pos, aa, p[0], ord, p[2], acc);
+#endif
+      } else {
+        bool         ok;
+        const double c = cos_dihedral(at(a[0], 0), at(a[1], 1), at(a[2], 2), at(a[3], 3), ok);
+        e += uff_torsion(ok ? c : 0.0, p[0], ord, p[2]);  // collinear: cos(phi) := 0 (:271-273)
+      }
+    });
+    // inversion: k, C0, C1, C2
+    run_terms(b.g[3], t3, [&](const int, const int* a, const double* p) {
+      if constexpr (GRAD) {
+        const int aa[4] = {a[0], a[1], a[2], a[3]};
+#ifdef NVMK_FF_DUAL_GRAD
+        using D = Dual<12>;
+        scatter<12, DIM, 4>(uff_inversion(Loader<D, DIM>::get(pos, a[0], 0), Loader<D, DIM>::get(pos, a[1], 1),
+                                          Loader<D, DIM>::get(pos, a[2], 2), Loader<D, DIM>::get(pos, a[3], 3), p[0], p[1], p[2], p[3]),
+                            aa, grad, 1.0);
+#else
+        ffg::grad_inversion<DIM>(pos, aa, p[2], p[3], p[0], true, acc);
+#endif
+      } else {
+        e += uff_inversion(at(a[0], 0), at(a[1], 1), at(a[2], 2), at(a[3], 3), p[0], p[1], p[2], p[3]);
+      }
+    });
     if constexpr (KIND == KIND_UFF_C) e += constraint_terms<DIM, GRAD>(b, 5, ms, pos, grad);
     return e;
   }
@@ -686,7 +754,8 @@ __global__ __launch_bounds__(NT) void energy_kernel(const Batch b, const double*
   const int         sys = blockIdx.x;
   if (active && !active[sys]) return;
   const int    a0 = b.atomStarts[sys];
-  const double e  = system_eval<KIND, false>(b, sys, pos + static_cast<int64_t>(a0) * DIM, nullptr, w0, w1, a0 * DIM);
+  const double e  = system_eval<KIND, false>(b, eval_context<KIND>(b, sys), (b.atomStarts[sys + 1] - a0) * DIM,
+                                             pos + static_cast<int64_t>(a0) * DIM, nullptr, w0, w1, a0 * DIM);
   const double s  = block_reduce<Op::kSum>(e, red);
   if (threadIdx.x == 0) energies[sys] = s;
 }
@@ -702,7 +771,8 @@ __global__ __launch_bounds__(NT) void grad_kernel(const Batch b, const double* _
   double*   g  = grad + static_cast<int64_t>(a0) * DIM;
   for (int p = threadIdx.x; p < n; p += NT) g[p] = 0.0;
   __syncthreads();
-  system_eval<KIND, true>(b, sys, pos + static_cast<int64_t>(a0) * DIM, g, w0, w1, a0 * DIM);
+  system_eval<KIND, true>(b, eval_context<KIND>(b, sys), (b.atomStarts[sys + 1] - a0) * DIM, pos + static_cast<int64_t>(a0) * DIM, g, w0, w1,
+                          a0 * DIM);
 }
 
 // ---- fused BFGS -----------------------------------------------------------------------------------
@@ -781,29 +851,12 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
     for (int r = tid; r < n; r += NT) hdiag[r] = 1.0;  // H = identity
   }
 
-  // The term-range offsets of this system (two per group, constant for the whole minimisation) are cached in LDS and the
-  // evaluations run on a system-local view of the batch: every group walk used to open with two dependent global loads
-  // (~1 us each under load), 7-11 groups per evaluation and 3-4 evaluations per iteration.
-  __shared__ int sRange[26];
-  Batch          lb   = b;
-  int            lsys = sys;
-  if constexpr (KIND != NVMK_FF_QUARTIC) {
-    const int ms = b.sysMol ? b.sysMol[sys] : sys;
-    if (tid < 24) sRange[tid] = b.g[tid >> 1].starts ? b.g[tid >> 1].starts[ms + (tid & 1)] : 0;
-    if (tid >= 24 && tid < 26) sRange[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < 12; ++g) lb.g[g].starts = b.g[g].starts ? &sRange[2 * g] : nullptr;
-    lb.sysMol = nullptr;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      lb.ref[k]       = b.ref[k] ? b.ref[k] + b.refStarts[k][sys] : nullptr;
-      lb.refStarts[k] = &sRange[24];
-    }
-    lsys = 0;
-  }
+  // table row, term ranges and reference-distance pointers of this system: loaded once, kept in LDS
+  __shared__ EvalContext ctx;
+  if (tid == 0) ctx = eval_context<KIND>(b, sys);
+  __syncthreads();
   auto energy_at = [&](const double* p) -> double {
-    return block_reduce<Op::kSum>(system_eval<KIND, false>(lb, lsys, p, nullptr, w0, w1, a0 * DIM), red);
+    return block_reduce<Op::kSum>(system_eval<KIND, false>(b, ctx, n, p, nullptr, w0, w1, a0 * DIM), red);
   };
   double gradScale = 1.0;
   // Gradient contributions are accumulated per WAVE (LDS atomics into the wave's own slab: within a wave the order of
@@ -812,7 +865,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
   auto   grad_at   = [&](const double* p) {
     for (int i = tid; i < NW * n; i += NT) part[i] = 0.0;
     __syncthreads();
-    system_eval<KIND, true>(lb, lsys, p, part + (tid >> 6) * n, w0, w1, a0 * DIM);
+    system_eval<KIND, true>(b, ctx, n, p, part + (tid >> 6) * n, w0, w1, a0 * DIM);
     __syncthreads();
     // gradient scaling (bfgs_minimize_permol_kernels.cu:239-275; |g| rule of RDKit >= 2025.09)
     gradScale = scaleGrads ? 0.1 : 1.0;
@@ -833,23 +886,24 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
     __syncthreads();
   };
 
-  double prevE = energy_at(pos);
-  grad_at(pos);
+  // The first energy / gradient evaluation runs through the loop body as a step of length zero (`init`), so that the
+  // kernel holds ONE copy of the evaluation code: inlined at two call sites each, the MMFF kernel was 108 KB of
+  // instructions against a 64 KB instruction cache shared by two CUs.
   for (int i = tid; i < n; i += NT) {
-    hg[i]  = grad[i];  // H = I
-    dir[i] = -grad[i];
+    dir[i]  = 0.0;
+    grad[i] = 0.0;
   }
+  __syncthreads();
+  double prevE   = 0.0;
   bool   pending = false;
   double pRfac = 0.0, pFad = 0.0, pFae = 0.0;
-  double sumsq = 0.0;
-  for (int i = tid; i < n; i += NT) sumsq += pos[i] * pos[i];
-  sumsq                 = block_reduce<Op::kSum>(sumsq, red);
-  const double maxStep2 = 1.0e4 * fmax(sumsq, static_cast<double>(n) * static_cast<double>(n));
+  double maxStep2 = 0.0;
 
+  bool init      = true;
   bool converged = false;
   int  iter      = 0;
-  int  nEvals    = 1;
-  while (!converged && iter < maxIters) {
+  int  nEvals    = 0;
+  while (init || (!converged && iter < maxIters)) {
     for (int i = tid; i < n; i += NT) oldp[i] = pos[i];
     // ---- line search set-up (:54-136)
     double s = 0.0;
@@ -917,7 +971,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
     stepTest = block_reduce<Op::kMax>(stepTest, red);
     prevE    = newE;  // energy of the coordinates that are returned (the reference reports the pre-step energy when
                       // TOLX fires, :680-687; the step is below 1.2e-7 relative there)
-    if (stepTest < TOLX) {
+    if (!init && stepTest < TOLX) {
       converged = true;
       break;
     }
@@ -931,6 +985,18 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
       gTest    = fmax(gTest, fabs(grad[i]) * fmax(fabs(pos[i]), 1.0));
     }
     gTest = block_reduce<Op::kMax>(gTest, red) / fmax(prevE * gradScale, 1.0);
+    if (init) {  // H = I: the first direction is steepest descent; the step bound of the line searches (:54-60)
+      double sumsq = 0.0;
+      for (int i = tid; i < n; i += NT) {
+        hg[i]  = grad[i];
+        dir[i] = -grad[i];
+        sumsq += pos[i] * pos[i];
+      }
+      sumsq    = block_reduce<Op::kSum>(sumsq, red);
+      maxStep2 = 1.0e4 * fmax(sumsq, static_cast<double>(n) * static_cast<double>(n));
+      init     = false;
+      continue;
+    }
     if (gTest < gradTol) {
       converged = true;
       break;
