@@ -388,6 +388,34 @@ int nvmk_conformer_rmsd_batch(const double* d_coords, const int64_t* d_coord_off
 int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, const int32_t* d_conf_starts, int n_mols,
                          double threshold, uint8_t* d_keep, void* stream);
 
+/* ---- SMILES ingestion for the fingerprint path (host code, no GPU involved) ----------------
+ * Replaces what the reference takes from RDKit before MorganInvariantsGenerator::ComputeInvariantsInto can run
+ * (RDKit::SmilesToMol + sanitisation: src/morgan_fingerprint_common.cpp:43-124 works on ROMol objects; the reference's
+ * benchmarks read benchmarks/data/chembl_10k.smi through RDKit).  Scope and rules: nvmolkit_amd/csrc/smiles.cpp — aromaticity is
+ * taken from the input (aromatic-form SMILES such as RDKit's canonical output); Kekule-form aromatic rings and valences
+ * RDKit's sanitisation rejects or rewrites are REFUSED per molecule, never fingerprinted differently from RDKit.
+ *   nvmk_smiles_parse        : n_mols NUL- or whitespace-terminated strings -> an opaque set of graphs (n_threads <= 0: all
+ *                              host threads).  Never fails on bad chemistry: the per-molecule status says what happened.
+ *   nvmk_smiles_counts       : atoms / bonds (after folding [H] atoms) and status of every molecule; any output may be NULL
+ *   nvmk_smiles_graph        : one molecule's graph, for tests and other consumers: atom_fields[6 * n_atoms] =
+ *                              (Z, formal charge, isotope, total H count, aromatic, in ring), bond_fields[4 * n_bonds] =
+ *                              (begin, end, RDKit bond type 1 / 2 / 3 / 4 / 12, in ring)
+ *   nvmk_smiles_morgan_inputs: the five HOST arrays nvmk_morgan_from_invariants consumes, for the selected molecules
+ *                              (mol_ids NULL = all, in order) in slots of max_atoms; every selected molecule must have
+ *                              status NVMK_SMILES_OK and atoms, bonds < max_atoms (the reference's bucketing rule).
+ */
+#define NVMK_SMILES_OK 0
+#define NVMK_SMILES_SYNTAX_ERROR 1
+#define NVMK_SMILES_VALENCE_ERROR 2      /* RDKit: "Explicit valence for atom ... is greater than permitted" */
+#define NVMK_SMILES_NEEDS_AROMATICITY 3  /* Kekule-form ring RDKit would perceive as aromatic */
+#define NVMK_SMILES_TOO_MANY_BONDS 4     /* more than 8 bonds on one atom (kMaxBondsPerAtom of the reference) */
+int nvmk_smiles_parse(const char* const* smiles, int64_t n_mols, int n_threads, void** handle);
+int nvmk_smiles_free(void* handle);
+int nvmk_smiles_counts(const void* handle, int32_t* n_atoms, int32_t* n_bonds, int8_t* status);
+int nvmk_smiles_graph(const void* handle, int64_t mol, int32_t* atom_fields, int32_t* bond_fields);
+int nvmk_smiles_morgan_inputs(const void* handle, const int64_t* mol_ids, int64_t n_sel, int max_atoms, uint32_t* atom_inv,
+                              uint32_t* bond_inv, int16_t* bond_idx, int16_t* bond_other, int16_t* n_atoms, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,8 @@ def pack_fingerprint(fp: torch.Tensor) -> torch.Tensor:
 
 # ---- Morgan fingerprints ------------------------------------------------------------------------
 
+import ctypes  # noqa: E402
+
 import numpy as np  # noqa: E402
 
 from nvmolkit_amd import _native  # noqa: E402
@@ -131,6 +133,66 @@ def morgan_invariants_from_rdkit(mols, max_atoms: int):
     return atom_inv, bond_inv, bond_idx, bond_other, n_atoms
 
 
+SMILES_STATUS = {0: "ok", 1: "syntax error", 2: "valence RDKit's sanitisation rejects or rewrites",
+                 3: "Kekule-form aromatic ring (write the SMILES in aromatic form)", 4: "more than 8 bonds on one atom"}
+
+
+class SmilesSet:
+    """Molecular graphs parsed from SMILES by the library itself — the RDKit-free ingestion of the fingerprint path
+    (rules and scope: nvmolkit_amd/csrc/smiles.cpp).  Replaces ``Chem.MolFromSmiles`` for the one
+    thing the Morgan path needs from a molecule: its graph with hydrogen counts, charges, ring flags and bond types.
+
+    ``status[i]`` is 0 for an ingested molecule; the other codes (``SMILES_STATUS``) mean the molecule was REFUSED — the
+    library never fingerprints a molecule whose bond types RDKit would perceive differently.
+    """
+
+    def __init__(self, smiles, num_threads: int = 0):
+        self._handle = ctypes.c_void_p()
+        items = [s.encode() if isinstance(s, str) else bytes(s) for s in smiles]
+        arr = (ctypes.c_char_p * max(len(items), 1))(*items)
+        _native.check(_native.lib().nvmk_smiles_parse(arr, len(items), int(num_threads), ctypes.byref(self._handle)), "nvmk_smiles_parse")
+        n = len(items)
+        self.n_atoms = np.zeros(n, dtype=np.int32)
+        self.n_bonds = np.zeros(n, dtype=np.int32)
+        self.status = np.zeros(n, dtype=np.int8)
+        if n:
+            _native.check(_native.lib().nvmk_smiles_counts(self._handle, self.n_atoms.ctypes.data, self.n_bonds.ctypes.data,
+                                                           self.status.ctypes.data), "nvmk_smiles_counts")
+
+    def __len__(self) -> int:
+        return len(self.status)
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            try:
+                _native.lib().nvmk_smiles_free(h)
+            except Exception:  # interpreter shutdown
+                pass
+
+    def graph(self, i: int):
+        """(atoms (n, 6) [Z, charge, isotope, total Hs, aromatic, in ring], bonds (m, 4) [begin, end, bond type, in ring])."""
+        atoms = np.zeros((int(self.n_atoms[i]), 6), dtype=np.int32)
+        bonds = np.zeros((int(self.n_bonds[i]), 4), dtype=np.int32)
+        _native.check(_native.lib().nvmk_smiles_graph(self._handle, int(i), atoms.ctypes.data, bonds.ctypes.data), "nvmk_smiles_graph")
+        return atoms, bonds
+
+    def morgan_inputs(self, mol_ids, max_atoms: int, num_threads: int = 0):
+        """The five host arrays of ``nvmk_morgan_from_invariants`` for the listed molecules, in ``max_atoms`` slots."""
+        ids = np.ascontiguousarray(mol_ids, dtype=np.int64)
+        n = len(ids)
+        atom_inv = np.empty((n, max_atoms), dtype=np.uint32)
+        bond_inv = np.empty((n, max_atoms), dtype=np.uint32)
+        bond_idx = np.empty((n, max_atoms, _MAX_BONDS_PER_ATOM), dtype=np.int16)
+        bond_other = np.empty((n, max_atoms, _MAX_BONDS_PER_ATOM), dtype=np.int16)
+        n_atoms = np.empty(n, dtype=np.int16)
+        if n:
+            _native.check(_native.lib().nvmk_smiles_morgan_inputs(self._handle, ids.ctypes.data, n, int(max_atoms), atom_inv.ctypes.data,
+                                                                  bond_inv.ctypes.data, bond_idx.ctypes.data, bond_other.ctypes.data,
+                                                                  n_atoms.ctypes.data, int(num_threads)), "nvmk_smiles_morgan_inputs")
+        return atom_inv, bond_inv, bond_idx, bond_other, n_atoms
+
+
 class MorganFingerprintGenerator:
     """Batched Morgan fingerprints on the GPU (reference: nvmolkit/fingerprints.py:75-108).
 
@@ -186,6 +248,39 @@ class MorganFingerprintGenerator:
             raise ValueError(f"Unsupported fpSize {self._fp_size}")
         return AsyncGpuResult(out)
 
+    def GetFingerprintsFromSmiles(self, smiles, num_threads: int = 0, stream=None, on_error: str = "raise") -> AsyncGpuResult:
+        """SMILES strings (or an already parsed :class:`SmilesSet`) -> packed fingerprints, one row per molecule in input
+        order, without RDKit: the library parses the strings, derives the invariants on ``num_threads`` host threads
+        (0 = all) and launches the same kernels as :meth:`GetFingerprints`.
+
+        ``on_error``: ``"raise"`` (default) — a ``ValueError`` listing the refused molecules by index and reason, like the
+        reference's ``None`` / parse failures; ``"zero"`` — their rows stay all-zero and ``result.smiles_status`` says why.
+        """
+        _native.stream_ptr(stream)
+        if self._fp_size not in _VALID_FP_SIZES:
+            raise ValueError(f"Unsupported fpSize {self._fp_size}: must be one of {_VALID_FP_SIZES}")
+        if on_error not in ("raise", "zero"):
+            raise ValueError("on_error must be 'raise' or 'zero'")
+        mols = smiles if isinstance(smiles, SmilesSet) else SmilesSet(smiles, num_threads)
+        bad = np.flatnonzero(mols.status != 0)
+        if len(bad) and on_error == "raise":
+            shown = ", ".join(f"{i}: {SMILES_STATUS.get(int(mols.status[i]), '?')}" for i in bad[:8])
+            raise ValueError(f"{len(bad)} of {len(mols)} SMILES were not ingested ({shown}{', ...' if len(bad) > 8 else ''})")
+        size = np.maximum(mols.n_atoms, mols.n_bonds)
+        if np.any((size >= _BUCKETS[-1]) & (mols.status == 0)):
+            i = int(np.flatnonzero((size >= _BUCKETS[-1]) & (mols.status == 0))[0])
+            raise NotImplementedError(f"molecule {i} has {int(size[i])} atoms/bonds; the GPU path handles < {_BUCKETS[-1]}")
+        out = torch.zeros((len(mols), self._fp_size // 32), dtype=torch.int32, device="cuda")
+        lo = 0
+        for b in _BUCKETS:
+            idx = np.flatnonzero((size >= lo) & (size < b) & (mols.status == 0))
+            lo = b
+            if len(idx):
+                self._launch(mols.morgan_inputs(idx, b, num_threads), b, out, idx, stream)
+        res = AsyncGpuResult(out)
+        res.smiles_status = mols.status
+        return res
+
     def GetFingerprints(self, mols: list, num_threads: int = 0, stream=None) -> AsyncGpuResult:
         """RDKit molecules -> packed fingerprints, one row per molecule in input order.
 
@@ -201,6 +296,8 @@ class MorganFingerprintGenerator:
             raise ValueError(f"Unsupported fpSize {self._fp_size}: must be one of {_VALID_FP_SIZES}")
         if any(m is None for m in mols):
             raise ValueError("molecule list contains None")
+        if mols and all(isinstance(m, (str, bytes)) for m in mols):
+            return self.GetFingerprintsFromSmiles(mols, num_threads=num_threads, stream=stream)
         n = len(mols)
         out = torch.zeros((n, self._fp_size // 32), dtype=torch.int32, device="cuda")
         buckets: dict[int, list[int]] = {b: [] for b in _BUCKETS}

@@ -1,0 +1,211 @@
+"""TEST INFRASTRUCTURE — an independent restatement of the SMILES ingestion of the fingerprint path.
+
+The product's ingestion is C++ (nvmolkit_amd/csrc/smiles.cpp: character-level parser, low-link bridge search).  This file
+derives the same quantities a second way (regular-expression tokens, ring bonds by removing each bond and asking whether its
+ends stay connected, valence rules written from RDKit's documented model) so that the two can only agree by being right
+about the rules, not by sharing code.  What is restated from the reference: the invariant components and their order
+(src/morgan_fingerprint_common.cpp:80-121: Z, degree + Hs, Hs incl. hydrogen neighbours, formal charge,
+int(mass - average mass), + [1] for ring atoms) and the bond invariant (RDKit bond type, :100).  RDKit itself is in
+neither image: parity with RDKit's SMILES parser is UNPINNED except for the element-count known answers of
+tests/test_morgan_fingerprint_ref.cpp:44-69, which go through this module in tests/test_smiles_ingestion.py.
+
+Only tests/ may import this module.
+"""
+
+from __future__ import annotations
+
+import re
+
+import numpy as np
+
+ELEMENTS = ("* H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn Ga Ge As Se Br Kr Rb Sr Y Zr Nb Mo "
+            "Tc Ru Rh Pd Ag Cd In Sn Sb Te I Xe Cs Ba La Ce Pr Nd Pm Sm Eu Gd Tb Dy Ho Er Tm Yb Lu Hf Ta W Re Os Ir Pt Au Hg Tl Pb "
+            "Bi Po At Rn Fr Ra Ac Th Pa U Np Pu Am Cm Bk Cf Es Fm Md No Lr Rf Db Sg Bh Hs Mt Ds Rg Cn Nh Fl Mc Lv Ts Og").split()
+Z_OF = {s: z for z, s in enumerate(ELEMENTS)}
+AROMATIC_SYMBOLS = {"b": 5, "c": 6, "n": 7, "o": 8, "p": 15, "s": 16, "se": 34, "as": 33, "te": 52, "si": 14}
+VALENCES = {5: (3,), 6: (4,), 7: (3,), 8: (2,), 9: (1,), 15: (3, 5, 7), 16: (2, 4, 6), 17: (1,), 35: (1,), 53: (1, 3, 5)}
+BOND_TYPE = {"-": 1, "/": 1, "\\": 1, "=": 2, "#": 3, "$": 4, ":": 12}
+# average weights and a few exact isotope masses: only what the hand-made test molecules use (H, C, N, O, F, I)
+WEIGHT = {1: 1.008, 6: 12.011, 7: 14.007, 8: 15.999, 9: 18.998, 53: 126.90}
+ISOTOPE = {(1, 2): 2.01410, (1, 3): 3.01605, (6, 13): 13.00335, (6, 14): 14.00324, (7, 15): 15.00011, (8, 18): 17.99916,
+           (9, 18): 18.00094, (53, 125): 124.90463, (53, 131): 130.90612}
+
+TOKEN = re.compile(r"""
+    (?P<bracket>\[[^\]]*\]) | (?P<organic>Cl|Br|[BCNOFPSI]|[bcnops]|\*) | (?P<bond>[-=#$:/\\]) |
+    (?P<ring>%\d\d|\d) | (?P<open>\() | (?P<close>\)) | (?P<dot>\.)""", re.X)
+BRACKET = re.compile(r"^\[(?P<iso>\d+)?(?P<sym>se|as|te|si|[bcnops]|[A-Z][a-z]?|\*)(?P<chiral>@(?:@|[A-Z]{2}\d+)?)?"
+                     r"(?P<h>H\d?)?(?P<charge>\++\d*|-+\d*)?(?::\d+)?\]$")
+
+
+class SmilesError(ValueError):
+    pass
+
+
+def parse(smiles: str):
+    """-> (atoms, bonds): atoms are dicts (z, charge, isotope, h_explicit, bracket, aromatic), bonds [a, b, type or None]."""
+    atoms, bonds = [], []
+    prev, pending, stack, open_rings = None, None, [], {}
+    pos = 0
+    while pos < len(smiles):
+        m = TOKEN.match(smiles, pos)
+        if m is None:
+            raise SmilesError(f"unexpected character {smiles[pos]!r} at {pos}")
+        pos = m.end()
+        kind, text = m.lastgroup, m.group()
+        if kind in ("bracket", "organic"):
+            if kind == "bracket":
+                b = BRACKET.match(text)
+                if b is None:
+                    raise SmilesError(f"bad bracket atom {text}")
+                sym = b["sym"]
+                aromatic = sym in AROMATIC_SYMBOLS
+                if not aromatic and sym not in Z_OF:
+                    raise SmilesError(f"unknown element {sym}")
+                h = 0 if b["h"] is None else (int(b["h"][1:]) if len(b["h"]) > 1 else 1)
+                q = 0
+                if b["charge"]:
+                    c = b["charge"]
+                    digits = c.lstrip("+-")
+                    q = int(digits) if digits else len(c)
+                    if c[0] == "-":
+                        q = -q
+                atoms.append(dict(z=AROMATIC_SYMBOLS[sym] if aromatic else Z_OF[sym], charge=q, isotope=int(b["iso"] or 0),
+                                  h_explicit=h, bracket=True, aromatic=aromatic))
+            else:
+                aromatic = text.islower()
+                atoms.append(dict(z=AROMATIC_SYMBOLS[text] if aromatic else Z_OF[text], charge=0, isotope=0, h_explicit=0,
+                                  bracket=False, aromatic=aromatic))
+            if prev is not None:
+                bonds.append([prev, len(atoms) - 1, BOND_TYPE.get(pending)])
+            prev, pending = len(atoms) - 1, None
+        elif kind == "bond":
+            if prev is None or pending is not None:
+                raise SmilesError("misplaced bond symbol")
+            pending = text
+        elif kind == "ring":
+            if prev is None:
+                raise SmilesError("ring closure before any atom")
+            label = int(text.lstrip("%"))
+            if label in open_rings:
+                other, sym = open_rings.pop(label)
+                if sym is not None and pending is not None and BOND_TYPE[sym] != BOND_TYPE[pending]:
+                    raise SmilesError("conflicting ring-closure bond symbols")
+                if other == prev or any({a, b} == {other, prev} for a, b, _ in bonds):
+                    raise SmilesError("ring closure duplicates a bond")
+                bonds.append([other, prev, BOND_TYPE.get(pending or sym)])
+            else:
+                open_rings[label] = (prev, pending)
+            pending = None
+        elif kind == "open":
+            if prev is None or pending is not None:
+                raise SmilesError("misplaced '('")
+            stack.append(prev)
+        elif kind == "close":
+            if not stack or pending is not None:
+                raise SmilesError("misplaced ')'")
+            prev = stack.pop()
+        else:  # dot
+            if pending is not None:
+                raise SmilesError("bond symbol before '.'")
+            prev = None
+    if pending is not None or stack or open_rings:
+        raise SmilesError("unterminated bond, branch or ring")
+    return atoms, bonds
+
+
+def _connected_without(n, bonds, skip, src, dst):
+    adj = [[] for _ in range(n)]
+    for k, (a, b, _) in enumerate(bonds):
+        if k != skip:
+            adj[a].append(b)
+            adj[b].append(a)
+    seen, todo = {src}, [src]
+    while todo:
+        u = todo.pop()
+        if u == dst:
+            return True
+        for v in adj[u]:
+            if v not in seen:
+                seen.add(v)
+                todo.append(v)
+    return False
+
+
+def molecule(smiles: str):
+    """SMILES -> (atom table (n, 6) int [Z, charge, isotope, total Hs, aromatic, in ring], bond table (m, 4) int
+    [begin, end, RDKit bond type, in ring]) with the rules listed in nvmolkit_amd/csrc/smiles.cpp's header."""
+    atoms, bonds = parse(smiles.split()[0] if smiles.split() else "")
+    # fold plain hydrogen atoms into their neighbour (RDKit's default removeHs)
+    degree = [0] * len(atoms)
+    for a, b, _ in bonds:
+        degree[a] += 1
+        degree[b] += 1
+    drop = set()
+    for i, at in enumerate(atoms):
+        if at["z"] == 1 and at["isotope"] == 0 and at["charge"] == 0 and at["h_explicit"] == 0 and degree[i] == 1:
+            (a, b, t), = [bd for bd in bonds if i in bd[:2]]
+            other = b if a == i else a
+            if atoms[other]["z"] != 1 and t in (None, 1):
+                drop.add(i)
+                if atoms[other]["bracket"]:
+                    atoms[other]["h_explicit"] += 1
+    keep = [i for i in range(len(atoms)) if i not in drop]
+    renum = {old: new for new, old in enumerate(keep)}
+    atoms = [atoms[i] for i in keep]
+    bonds = [[renum[a], renum[b], t] for a, b, t in bonds if a not in drop and b not in drop]
+    n = len(atoms)
+    in_ring_bond = [_connected_without(n, bonds, k, a, b) for k, (a, b, _) in enumerate(bonds)]
+    for k, bd in enumerate(bonds):
+        if bd[2] is None:
+            bd[2] = 12 if (atoms[bd[0]]["aromatic"] and atoms[bd[1]]["aromatic"] and in_ring_bond[k]) else 1
+    # implicit hydrogens of organic-subset atoms
+    order_sum = [0.0] * n
+    for a, b, t in bonds:
+        w = 1.5 if t == 12 else float(t)
+        order_sum[a] += w
+        order_sum[b] += w
+    total_h = []
+    for i, at in enumerate(atoms):
+        if at["bracket"] or at["z"] == 0:
+            total_h.append(at["h_explicit"])
+            continue
+        allowed = VALENCES[at["z"]]
+        acc = order_sum[i]
+        if at["aromatic"]:
+            default = allowed[0]
+            if acc > default:
+                acc = max([v for v in allowed if v <= acc] or [default])
+            ev = int(np.floor(acc + 0.1 + 0.5))
+            total_h.append(max(default - ev, 0))
+        else:
+            ev = int(np.floor(acc + 0.1 + 0.5))
+            fits = [v for v in allowed if v >= ev]
+            if not fits:
+                raise SmilesError(f"valence {ev} of atom {i} is not allowed")
+            total_h.append(fits[0] - ev)
+    ring_atom = [False] * n
+    for k, (a, b, _) in enumerate(bonds):
+        if in_ring_bond[k]:
+            ring_atom[a] = ring_atom[b] = True
+    atom_table = np.array([[at["z"], at["charge"], at["isotope"], total_h[i], int(at["aromatic"]), int(ring_atom[i])]
+                           for i, at in enumerate(atoms)], dtype=np.int64).reshape(n, 6)
+    bond_table = np.array([[a, b, t, int(in_ring_bond[k])] for k, (a, b, t) in enumerate(bonds)], dtype=np.int64).reshape(len(bonds), 4)
+    return atom_table, bond_table
+
+
+def invariant_components(atom_table, bond_table):
+    """(n, 5) components [Z, degree + Hs, Hs incl. hydrogen neighbours, charge, int(mass - average mass)] + ring flags."""
+    n = len(atom_table)
+    degree = np.zeros(n, dtype=np.int64)
+    nbr_h = np.zeros(n, dtype=np.int64)
+    for a, b, _, _ in bond_table:
+        degree[a] += 1
+        degree[b] += 1
+        nbr_h[a] += atom_table[b, 0] == 1
+        nbr_h[b] += atom_table[a, 0] == 1
+    dmass = np.zeros(n, dtype=np.int64)
+    for i, (z, _, iso, *_rest) in enumerate(atom_table):
+        if iso:
+            dmass[i] = int(ISOTOPE.get((int(z), int(iso)), float(iso)) - WEIGHT[int(z)])
+    comps = np.stack([atom_table[:, 0], atom_table[:, 3] + degree, atom_table[:, 3] + nbr_h, atom_table[:, 1], dmass], 1)
+    return comps, atom_table[:, 5].astype(bool)

@@ -44,6 +44,36 @@ def test_cfg1_morgan_to_similarity_chain_10k():
     assert np.array_equal(sim[:, torch.from_numpy(cols).cuda()].cpu().numpy(), want)
 
 
+def test_cfg1_on_the_reference_benchmark_smiles():
+    """BASELINE.json configs[0] on the molecules the reference benchmarks with: 10 000 ChEMBL SMILES -> the library's own
+    ingestion -> Morgan r = 2 / 2048 bit on the GPU -> 10k x 10k Tanimoto, against oracle Morgan -> oracle similarity."""
+    from pathlib import Path
+
+    from nvmolkit_amd.fingerprints import SmilesSet
+
+    smiles = [line.split()[0] for line in (Path(__file__).parent / "golden" / "chembl_10k.smi").read_text().splitlines() if line.strip()]
+    assert len(smiles) == 10_000
+    mols = SmilesSet(smiles)
+    assert np.all(mols.status == 0)
+    fps = MorganFingerprintGenerator(2, 2048).GetFingerprintsFromSmiles(mols).torch()
+    got = fps.cpu().numpy().view(np.uint32)
+    size = np.maximum(mols.n_atoms, mols.n_bonds)
+    want_fp = np.zeros_like(got)
+    lo = 0
+    for stride in (32, 64, 128, 256):
+        idx = np.flatnonzero((size >= lo) & (size < stride))
+        lo = stride
+        if len(idx):
+            want_fp[idx] = oracle.morgan_fingerprints(*mols.morgan_inputs(idx, stride), stride, 2, 2048)
+    assert np.array_equal(got, want_fp)
+    density = np.unpackbits(got.view(np.uint8), axis=1).sum(1)
+    assert 20 < np.median(density) < 80                              # the ~2.3 % density the synthetic sets assume
+    sim = crossTanimotoSimilarity(fps).torch()
+    rows = np.r_[0:64, 5000:5064, 9936:10_000]
+    assert np.array_equal(sim[rows].cpu().numpy(), oracle.cross_similarity(want_fp[rows], want_fp))
+    assert torch.equal(sim, sim.T) and bool((sim.diagonal() == 1.0).all())
+
+
 @pytest.fixture(scope="module")
 def cfg3():
     lib = synthetic.druglike_library(10_000, seed=20260926)

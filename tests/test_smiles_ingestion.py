@@ -1,0 +1,221 @@
+"""RDKit-free ingestion of the fingerprint path: the library's SMILES parser
+(nvmolkit_amd/csrc/smiles.cpp) against hand-computed graphs, against the independent restatement oracle/smiles.py on the
+1000 ChEMBL SMILES the reference's tests read, and — through the Morgan oracle — against the element-count known answers
+RDKit's test-suite holds for four SMILES (reference tests/test_morgan_fingerprint_ref.cpp:44-69)."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from nvmolkit_amd.fingerprints import SMILES_STATUS, MorganFingerprintGenerator, SmilesSet
+from oracle import smiles as osmi
+
+CHEMBL = [line.split()[0] for line in (Path(__file__).parent / "golden" / "chembl_1k.smi").read_text().splitlines()
+          if line.strip() and not line.startswith("#")]
+
+
+def graph(smi):
+    s = SmilesSet([smi])
+    assert s.status[0] == 0, SMILES_STATUS[int(s.status[0])]
+    return s.graph(0)
+
+
+def hash_components(comps, ring):
+    out = []
+    for c, r in zip(comps.tolist(), ring.tolist()):
+        v = [int(x) & 0xFFFFFFFF for x in c]
+        out.append(oracle.morgan_hash_vector(v + [1] if r else v))
+    return np.array(out, dtype=np.uint32)
+
+
+def oracle_inputs(smiles_list, stride):
+    """The five Morgan input arrays derived entirely on the oracle side."""
+    n = len(smiles_list)
+    atom_inv = np.zeros((n, stride), dtype=np.uint32)
+    bond_inv = np.zeros((n, stride), dtype=np.uint32)
+    bond_idx = np.full((n, stride, 8), -1, dtype=np.int16)
+    bond_other = np.full((n, stride, 8), -1, dtype=np.int16)
+    n_atoms = np.zeros(n, dtype=np.int16)
+    for m, smi in enumerate(smiles_list):
+        atoms, bonds = osmi.molecule(smi)
+        comps, ring = osmi.invariant_components(atoms, bonds)
+        n_atoms[m] = len(atoms)
+        atom_inv[m, :len(atoms)] = hash_components(comps, ring)
+        deg = np.zeros(len(atoms), dtype=int)
+        for k, (a, b, t, _) in enumerate(bonds):
+            bond_inv[m, k] = t
+            for x, y in ((a, b), (b, a)):
+                bond_idx[m, x, deg[x]] = k
+                bond_other[m, x, deg[x]] = y
+                deg[x] += 1
+    return atom_inv, bond_inv, bond_idx, bond_other, n_atoms
+
+
+# ---- hand-computed graphs ---------------------------------------------------------------------------
+def test_ethanol_by_hand():
+    atoms, bonds = graph("CCO")
+    #                       Z  q iso H arom ring
+    assert atoms.tolist() == [[6, 0, 0, 3, 0, 0], [6, 0, 0, 2, 0, 0], [8, 0, 0, 1, 0, 0]]
+    assert bonds.tolist() == [[0, 1, 1, 0], [1, 2, 1, 0]]
+
+
+def test_aromatic_rings_by_hand():
+    atoms, bonds = graph("c1ccccc1")
+    assert atoms.tolist() == [[6, 0, 0, 1, 1, 1]] * 6
+    assert sorted(b[2] for b in bonds.tolist()) == [12] * 6 and all(b[3] == 1 for b in bonds.tolist())
+    atoms, _ = graph("c1cc[nH]c1")                       # pyrrole: the hydrogen is written, aromatic n takes none by itself
+    assert atoms[:, 3].tolist() == [1, 1, 1, 1, 1] and atoms[3, 0] == 7
+    atoms, _ = graph("c1ccncc1")                          # pyridine: no hydrogen on n
+    assert atoms[3].tolist() == [7, 0, 0, 0, 1, 1]
+    atoms, bonds = graph("Cn1ccnc1")                      # N-methyl imidazole: substituted aromatic n, valence 4 > 3 -> no H
+    assert atoms[1].tolist() == [7, 0, 0, 0, 1, 1] and bonds[0].tolist() == [0, 1, 1, 0]
+    atoms, _ = graph("O=c1cc[nH]cc1")                     # pyridone: exocyclic C=O on an aromatic carbon
+    assert atoms[1].tolist() == [6, 0, 0, 0, 1, 1]
+    atoms, _ = graph("c1ccc2ccccc2c1")                    # naphthalene: fusion carbons (three aromatic bonds = 4.5) take no H
+    assert atoms[:, 3].tolist() == [1, 1, 1, 0, 1, 1, 1, 1, 0, 1]
+    atoms, _ = graph("c1ccsc1")                           # thiophene
+    assert atoms[3].tolist() == [16, 0, 0, 0, 1, 1]
+
+
+def test_biphenyl_link_is_single_with_or_without_the_dash():
+    for smi in ("c1ccccc1-c1ccccc1", "c1ccccc1c1ccccc1"):
+        _, bonds = graph(smi)
+        link = [b for b in bonds.tolist() if b[3] == 0]
+        assert len(link) == 1 and link[0][2] == 1
+        assert sum(1 for b in bonds.tolist() if b[2] == 12) == 12
+
+
+def test_hydrogens_charges_isotopes_and_fragments():
+    atoms, bonds = graph("[H]C([H])([H])O")               # written hydrogens fold into the carbon
+    assert atoms.tolist() == [[6, 0, 0, 3, 0, 0], [8, 0, 0, 1, 0, 0]] and len(bonds) == 1
+    atoms, bonds = graph("[2H]C")                         # a labelled hydrogen stays an atom
+    assert atoms.tolist() == [[1, 0, 2, 0, 0, 0], [6, 0, 0, 3, 0, 0]] and len(bonds) == 1
+    atoms, bonds = graph("CC(=O)[O-].[Na+]")
+    assert atoms.tolist() == [[6, 0, 0, 3, 0, 0], [6, 0, 0, 0, 0, 0], [8, 0, 0, 0, 0, 0], [8, -1, 0, 0, 0, 0], [11, 1, 0, 0, 0, 0]]
+    assert bonds[:, 2].tolist() == [1, 2, 1]
+    atoms, _ = graph("C[N+](=O)[O-]")
+    assert atoms[1].tolist() == [7, 1, 0, 0, 0, 0]
+    atoms, _ = graph("[NH4+]")
+    assert atoms.tolist() == [[7, 1, 0, 4, 0, 0]]
+    atoms, _ = graph("CS(=O)(=O)N")                       # sulfonamide: S valence 6
+    assert atoms[1].tolist() == [16, 0, 0, 0, 0, 0] and atoms[4, 3] == 2
+    atoms, _ = graph("OP(=O)(O)O")                        # phosphate: P valence 5
+    assert atoms[1, 3] == 0
+    atoms, _ = graph("C%10CC%10")                         # two-digit ring labels
+    assert atoms[:, 5].tolist() == [1, 1, 1]
+    atoms, _ = graph("C[C@@H](N)C(=O)O")                  # chirality marks are read and dropped
+    assert atoms[1].tolist() == [6, 0, 0, 1, 0, 0]
+    atoms, _ = graph("F/C=C/F")                           # directional bonds are single bonds
+    assert atoms[:, 3].tolist() == [0, 1, 1, 0]
+
+
+def test_ring_membership_is_cycle_membership():
+    atoms, bonds = graph("C1CC1CC1CCC1")                  # two rings joined by a CH2: the linker is on no cycle
+    assert atoms[:, 5].tolist() == [1, 1, 1, 0, 1, 1, 1, 1]
+    assert bonds[:, 3].tolist() == [1, 1, 1, 0, 0, 1, 1, 1, 1]
+    atoms, _ = graph("C1CC2CCC1C2")                       # bicyclic: every atom is on a cycle
+    assert atoms[:, 5].tolist() == [1] * 7
+
+
+@pytest.mark.parametrize("smi,code", [("C(", 1), ("C1CC", 1), ("C)", 1), ("[Xx]", 1), ("C=", 1), ("C1C1", 1), ("", 0),
+                                      ("CN(=O)=O", 2), ("C(C)(C)(C)(C)C", 2), ("OCl(=O)(=O)=O", 2),
+                                      ("C1=CC=CC=C1", 3), ("C1=CNC=C1", 3), ("C1=COC=C1", 3), ("C1=CC=C2C=CC=CC2=C1", 3),
+                                      ("C1=CCCCC1", 0), ("O=C1C=CC(=O)C=C1", 0), ("C1=CC=CC1", 0), ("C1=CC=CCC=C1", 0)])
+def test_refusals_and_their_neighbours(smi, code):
+    assert int(SmilesSet([smi]).status[0]) == code
+
+
+# ---- against the independent restatement --------------------------------------------------------------
+def test_graphs_equal_the_oracle_on_chembl_1k():
+    s = SmilesSet(CHEMBL)
+    assert len(CHEMBL) == 999 and np.all(s.status == 0)
+    for i, smi in enumerate(CHEMBL):
+        atoms, bonds = s.graph(i)
+        want_atoms, want_bonds = osmi.molecule(smi)
+        assert np.array_equal(atoms, want_atoms), smi
+        assert np.array_equal(bonds, want_bonds), smi
+
+
+def test_morgan_inputs_equal_the_oracle_on_chembl_1k():
+    s = SmilesSet(CHEMBL)
+    size = np.maximum(s.n_atoms, s.n_bonds)
+    idx = np.flatnonzero(size < 64)[:300]
+    got = s.morgan_inputs(idx, 64)
+    want = oracle_inputs([CHEMBL[i] for i in idx], 64)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_parallel_and_serial_parsing_agree():
+    a, b = SmilesSet(CHEMBL, 1), SmilesSet(CHEMBL, 8)
+    assert np.array_equal(a.n_atoms, b.n_atoms) and np.array_equal(a.n_bonds, b.n_bonds) and np.array_equal(a.status, b.status)
+    ids = np.flatnonzero(np.maximum(a.n_atoms, a.n_bonds) < 128)
+    for x, y in zip(a.morgan_inputs(ids, 128, 1), b.morgan_inputs(ids, 128, 8)):
+        assert np.array_equal(x, y)
+
+
+def test_morgan_inputs_refuse_what_was_not_ingested():
+    s = SmilesSet(["CCO", "C1=CC=CC=C1", "CCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCC"])
+    with pytest.raises(ValueError, match="not ingested"):
+        s.morgan_inputs([0, 1], 32)
+    with pytest.raises(ValueError, match="does not fit"):
+        s.morgan_inputs([2], 32)
+    assert s.morgan_inputs([0], 32)[4].tolist() == [3]
+
+
+# ---- RDKit's own known answers, through SMILES ---------------------------------------------------------
+@pytest.mark.parametrize("smi,want", [("CCCCC", [2, 5, 7, 7]), ("O=C(O)CC1CC1", [6, 12, 16, 17]), ("OC(=O)CC1CC1", [6, 12, 16, 17])])
+def test_environment_counts_known_answers_from_smiles(smi, want):
+    # tests/test_morgan_fingerprint_ref.cpp:53-58: number of distinct sparse Morgan ids per radius 0..3
+    ai, bi, bx, bo, na = SmilesSet([smi]).morgan_inputs([0], 32)
+    for radius, n_expected in enumerate(want):
+        codes, _ = oracle.morgan_environments(ai[0], bi[0], bx[0], bo[0], int(na[0]), radius)
+        assert len(set(codes.tolist())) == n_expected, f"radius {radius}"
+
+
+def test_symmetry_known_answer_from_smiles():
+    # :60-69: OCCCCO, radius 2 -> 7 distinct ids, each seen 2 or 4 times
+    ai, bi, bx, bo, na = SmilesSet(["OCCCCO"]).morgan_inputs([0], 32)
+    codes, _ = oracle.morgan_environments(ai[0], bi[0], bx[0], bo[0], int(na[0]), 2)
+    values, counts = np.unique(codes, return_counts=True)
+    assert len(values) == 7 and set(counts.tolist()) <= {2, 4}
+
+
+def test_atom_order_invariance_from_smiles():
+    fps = []
+    for smi in ("O=C(O)CC1CC1", "OC(=O)CC1CC1", "C1CC1CC(O)=O", "C(C1CC1)C(=O)O"):
+        ai, bi, bx, bo, na = SmilesSet([smi]).morgan_inputs([0], 32)
+        fps.append(oracle.morgan_fingerprints(ai, bi, bx, bo, na, 32, 2, 2048))
+    assert all(np.array_equal(fps[0], f) for f in fps[1:])
+
+
+# ---- on the GPU ----------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_fingerprints_from_smiles_equal_the_oracle_pipeline():
+    gen = MorganFingerprintGenerator(radius=2, fpSize=2048)
+    got = gen.GetFingerprints(CHEMBL).torch().cpu().numpy().view(np.uint32)   # strings dispatch to the SMILES path
+    sizes = []
+    for smi in CHEMBL:
+        a, b = osmi.molecule(smi)
+        sizes.append(max(len(a), len(b)))
+    sizes = np.array(sizes)
+    lo = 0
+    for stride in (32, 64, 128, 256):
+        idx = np.flatnonzero((sizes >= lo) & (sizes < stride))
+        lo = stride
+        if len(idx):
+            want = oracle.morgan_fingerprints(*oracle_inputs([CHEMBL[i] for i in idx], stride), stride, 2, 2048)
+            assert np.array_equal(got[idx], want)
+    assert (got != 0).any(axis=1).all()
+
+
+@pytest.mark.gpu
+def test_refused_smiles_raise_or_stay_zero():
+    gen = MorganFingerprintGenerator(radius=2, fpSize=1024)
+    with pytest.raises(ValueError, match="1 of 3 SMILES were not ingested"):
+        gen.GetFingerprintsFromSmiles(["CCO", "C1=CC=CC=C1", "c1ccccc1"])
+    res = gen.GetFingerprintsFromSmiles(["CCO", "C1=CC=CC=C1", "c1ccccc1"], on_error="zero")
+    fp = res.torch().cpu().numpy()
+    assert res.smiles_status.tolist() == [0, 3, 0] and not fp[1].any() and fp[0].any() and fp[2].any()
