@@ -172,8 +172,9 @@ int nvmk_butina_dense(const double* d_dist, const uint8_t* d_hit, int64_t N, dou
  *   d_n_atoms    [n_mols] i16
  *   d_out_idx    [n_mols] i32            output row of each molecule (NULL = identity)
  *   d_out        rows of fp_bits/32 u32  (rows are OVERWRITTEN for the listed molecules)
- * max_atoms in {32, 64, 128, 256} (the reference computes molecules of >= 128 atoms on the CPU,
- * src/morgan_fingerprint_gpu.cpp:181-188, :296-304; here the 256 bucket keeps them on the GPU);
+ * max_atoms in {32, 64, 128, 256, 512, 1024} (the reference computes molecules of >= 128 atoms on the CPU,
+ * src/morgan_fingerprint_gpu.cpp:181-188, :296-304; here they stay on the GPU: up to 256 with all state in LDS, the 512 and
+ * 1024 buckets with the neighbourhood bitsets in a stream-ordered global scratch);
  * fp_bits in {128, 256, 512, 1024, 2048, 4096}; radius in [0, 8].  Atoms and bonds of a molecule must both be
  * < max_atoms (the reference's bucketing rule, src/morgan_fingerprint_common.cpp:71-73).
  */

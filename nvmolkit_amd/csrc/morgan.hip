@@ -18,7 +18,10 @@
 //     That is an all-pairs compare of <= 128 bitsets out of LDS, O(n) per lane, and needs no ordering of
 //     bitsets at all (FlatBitVect::operator<, flat_bit_vect.h:219-237, is not needed);
 //   * per-molecule state (invariants, neighbourhood bitsets, the list of accepted neighbourhoods, the folded
-//     fingerprint) lives in LDS; the reference keeps the accepted list in a global scratch buffer.
+//     fingerprint) lives in LDS; the reference keeps the accepted list in a global scratch buffer;
+//   * molecules of 256 to 1023 atoms (0.8 % of the reference's ChEMBL benchmark set; the reference computes them on the
+//     CPU, src/morgan_fingerprint_gpu.cpp:181-188) run the same kernel with 512 / 1024 lanes and the three bitset arrays
+//     in a per-workgroup global scratch (GSETS): 1024 bitsets of 1024 bits do not fit the LDS.
 #include "common.h"
 
 namespace nvmk {
@@ -44,28 +47,31 @@ template <int NW> __device__ __forceinline__ bool bits_equal(const Bits<NW>& a, 
 
 // NW = bitset words = stride / 32; BLOCK = threads per workgroup; MPB = molecules per workgroup (BLOCK / MPB >= stride
 // lanes each).
-template <int NW, int BLOCK, int MPB = 1>
+template <int NW, int BLOCK, int MPB = 1, bool GSETS = false>
 __global__ __launch_bounds__(BLOCK) void morgan_kernel(const uint32_t* __restrict__ atomInv,
                                                        const uint32_t* __restrict__ bondInv,
                                                        const int16_t* __restrict__ bondIdx,
                                                        const int16_t* __restrict__ bondOther,
                                                        const int16_t* __restrict__ nAtomsPerMol,
                                                        const int32_t* __restrict__ outIdx, const int64_t nMols,
-                                                       const int radius, const int fpBits, uint32_t* __restrict__ out) {
+                                                       const int radius, const int fpBits, uint32_t* __restrict__ out,
+                                                       uint32_t* __restrict__ setScratch) {
   constexpr int STRIDE = NW * 32;
   constexpr int LPM    = BLOCK / MPB;  // lanes per molecule
   static_assert(LPM >= STRIDE, "one lane per atom slot");
+  static_assert(!GSETS || MPB == 1, "the global-scratch form runs one molecule per workgroup");
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
   const int    sub      = threadIdx.x / LPM;
-  const size_t molWords = 3 * STRIDE + 2 * STRIDE * NW + static_cast<size_t>(radius) * STRIDE * NW + fpBits / 32 + 4;
+  const size_t setWords = (2 + static_cast<size_t>(radius)) * STRIDE * NW;  // nbh, rnbh, seen
+  const size_t molWords = 3 * STRIDE + (GSETS ? 0 : setWords) + fpBits / 32 + 4;
   char*        smem     = smem_all + sub * molWords * 4;
   uint32_t* cur      = reinterpret_cast<uint32_t*>(smem);        // [STRIDE] invariants entering this round
   uint32_t* rinv     = cur + STRIDE;                             // [STRIDE] invariants computed this round
   uint32_t* liveNow  = rinv + STRIDE;                            // [STRIDE] atom produced an environment this round
-  uint32_t* nbh      = liveNow + STRIDE;                         // [STRIDE][NW] neighbourhoods of the previous round
+  uint32_t* nbh      = GSETS ? setScratch + static_cast<size_t>(blockIdx.x) * setWords : liveNow + STRIDE;  // [STRIDE][NW] previous round
   uint32_t* rnbh     = nbh + STRIDE * NW;                        // [STRIDE][NW] neighbourhoods of this round
   uint32_t* seen     = rnbh + STRIDE * NW;                       // [radius * STRIDE][NW] accepted neighbourhoods
-  uint32_t* fp       = seen + static_cast<size_t>(radius) * STRIDE * NW;  // [fpBits / 32]
+  uint32_t* fp       = GSETS ? liveNow + STRIDE : seen + static_cast<size_t>(radius) * STRIDE * NW;  // [fpBits / 32]
   int*      seenCnt  = reinterpret_cast<int*>(fp + fpBits / 32);
 
   const int64_t molRaw = static_cast<int64_t>(blockIdx.x) * MPB + sub;
@@ -220,19 +226,22 @@ __global__ __launch_bounds__(BLOCK) void morgan_kernel(const uint32_t* __restric
   }
 }
 
-template <int NW, int BLOCK, int MPB = 1>
+template <int NW, int BLOCK, int MPB = 1, bool GSETS = false>
 int launch_t(const uint32_t* atomInv, const uint32_t* bondInv, const int16_t* bondIdx, const int16_t* bondOther,
              const int16_t* nAtoms, const int32_t* outIdx, int64_t nMols, int radius, int fpBits, uint32_t* out,
              hipStream_t stream) {
-  constexpr int STRIDE = NW * 32;
-  const size_t  shmem  = MPB * (3 * STRIDE + 2 * STRIDE * NW + static_cast<size_t>(radius) * STRIDE * NW + fpBits / 32 + 4) * 4;
-  auto          kern   = morgan_kernel<NW, BLOCK, MPB>;
+  constexpr int STRIDE   = NW * 32;
+  const size_t  setWords = (2 + static_cast<size_t>(radius)) * STRIDE * NW;
+  const size_t  shmem    = MPB * (3 * STRIDE + (GSETS ? 0 : setWords) + fpBits / 32 + 4) * 4;
+  auto          kern     = morgan_kernel<NW, BLOCK, MPB, GSETS>;
   if (shmem > 64 * 1024) {
     NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(shmem)));
   }
+  StreamScratch scratch;  // freed stream-ordered after the kernel
+  if (GSETS) NVMK_HIP_CHECK(scratch.alloc(static_cast<size_t>(nMols) * setWords * 4, stream));
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>((nMols + MPB - 1) / MPB)), dim3(BLOCK), shmem, stream, atomInv, bondInv, bondIdx,
-                     bondOther, nAtoms, outIdx, nMols, radius, fpBits, out);
+                     bondOther, nAtoms, outIdx, nMols, radius, fpBits, out, scratch.as<uint32_t>());
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }
@@ -245,8 +254,8 @@ extern "C" int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uin
                                            const int16_t* d_n_atoms, const int32_t* d_out_idx, int64_t n_mols,
                                            int max_atoms, int radius, int fp_bits, uint32_t* d_out, void* stream) {
   using namespace nvmk;
-  NVMK_REQUIRE(max_atoms == 32 || max_atoms == 64 || max_atoms == 128 || max_atoms == 256,
-               "morgan: max_atoms must be 32, 64, 128 or 256, got %d", max_atoms);
+  NVMK_REQUIRE(max_atoms == 32 || max_atoms == 64 || max_atoms == 128 || max_atoms == 256 || max_atoms == 512 || max_atoms == 1024,
+               "morgan: max_atoms must be 32, 64, 128, 256, 512 or 1024, got %d", max_atoms);
   NVMK_REQUIRE(radius >= 0 && radius <= morgan::MAX_RADIUS, "morgan: radius must be in [0, %d], got %d",
                morgan::MAX_RADIUS, radius);
   // reference: fpSize in {128, ..., 4096} (nvmolkit/fingerprints.cpp:66-90 -> std::invalid_argument otherwise)
@@ -266,8 +275,14 @@ extern "C" int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uin
     case 128:
       return morgan::launch_t<4, 128>(d_atom_inv, d_bond_inv, d_bond_idx, d_bond_other, d_n_atoms, d_out_idx, n_mols, radius,
                                       fp_bits, d_out, s);
-    default:
+    case 256:
       return morgan::launch_t<8, 256>(d_atom_inv, d_bond_inv, d_bond_idx, d_bond_other, d_n_atoms, d_out_idx, n_mols, radius,
                                       fp_bits, d_out, s);
+    case 512:
+      return morgan::launch_t<16, 512, 1, true>(d_atom_inv, d_bond_inv, d_bond_idx, d_bond_other, d_n_atoms, d_out_idx, n_mols,
+                                                radius, fp_bits, d_out, s);
+    default:
+      return morgan::launch_t<32, 1024, 1, true>(d_atom_inv, d_bond_inv, d_bond_idx, d_bond_other, d_n_atoms, d_out_idx, n_mols,
+                                                 radius, fp_bits, d_out, s);
   }
 }

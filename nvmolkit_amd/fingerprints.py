@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 from nvmolkit_amd import _native  # noqa: E402
 from nvmolkit_amd.types import AsyncGpuResult  # noqa: E402
 
-_BUCKETS = (32, 64, 128, 256)
+_BUCKETS = (32, 64, 128, 256, 512, 1024)
 _MAX_BONDS_PER_ATOM = 8  # kMaxBondsPerAtom in the reference
 _VALID_FP_SIZES = (128, 256, 512, 1024, 2048, 4096)
 
@@ -284,9 +284,9 @@ class MorganFingerprintGenerator:
     def GetFingerprints(self, mols: list, num_threads: int = 0, stream=None) -> AsyncGpuResult:
         """RDKit molecules -> packed fingerprints, one row per molecule in input order.
 
-        Molecules are bucketed by size (atoms and bonds < 32 / 64 / 128 / 256) exactly like the reference
+        Molecules are bucketed by size (atoms and bonds < 32 / 64 / 128 / 256 / 512 / 1024) like the reference
         (src/morgan_fingerprint_gpu.cpp:253-268).  The reference computes molecules of 128 atoms or more on
-        the CPU; here they run in the 256 bucket and anything larger raises (no CPU fallback in this build).
+        the CPU; here they run in the larger buckets and anything beyond 1023 atoms raises (no CPU fallback in this build).
         Buckets are staged and launched back to back on ``stream`` with no host synchronisation in between; the result is
         an ``AsyncGpuResult`` like the reference's.  ``num_threads`` is accepted for API compatibility (invariants are
         gathered on the calling thread: RDKit's Python getters hold the GIL).
@@ -308,7 +308,7 @@ class MorganFingerprintGenerator:
                     buckets[b].append(i)
                     break
             else:
-                raise NotImplementedError(f"molecule {i} has {size} atoms/bonds; the GPU path handles < 256")
+                raise NotImplementedError(f"molecule {i} has {size} atoms/bonds; the GPU path handles < {_BUCKETS[-1]}")
         for b, idx in buckets.items():
             if idx:
                 flat = morgan_invariants_from_rdkit([mols[i] for i in idx], b)

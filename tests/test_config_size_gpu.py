@@ -60,7 +60,7 @@ def test_cfg1_on_the_reference_benchmark_smiles():
     size = np.maximum(mols.n_atoms, mols.n_bonds)
     want_fp = np.zeros_like(got)
     lo = 0
-    for stride in (32, 64, 128, 256):
+    for stride in (32, 64, 128, 256, 512, 1024):
         idx = np.flatnonzero((size >= lo) & (size < stride))
         lo = stride
         if len(idx):

@@ -35,6 +35,17 @@ def test_random_batches_bit_exact(stride, radius, fp_bits):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("stride", [512, 1024])
+@pytest.mark.parametrize("radius", [0, 2, 3])
+def test_large_molecule_buckets_bit_exact(stride, radius):
+    # 256-1023 atoms: the reference computes these on the CPU; here the bitsets move to a global scratch
+    mols = util.random_molecule_batch(6, stride, seed=stride + radius, symmetric=(radius == 2), min_atoms=stride // 2)
+    flat = util.flatten_molecules(mols, stride)
+    assert int(flat[4].max()) >= stride // 2
+    want = oracle.morgan_fingerprints(*flat, stride, radius, 2048)
+    assert np.array_equal(gpu_fps(flat, stride, radius, 2048), want)
+
+
 @pytest.mark.parametrize("batch", [1, 5, 2048])
 def test_batch_sizes(batch):
     mols = util.random_molecule_batch(batch, 64, seed=batch, symmetric=True)

@@ -202,7 +202,7 @@ def test_fingerprints_from_smiles_equal_the_oracle_pipeline():
         sizes.append(max(len(a), len(b)))
     sizes = np.array(sizes)
     lo = 0
-    for stride in (32, 64, 128, 256):
+    for stride in (32, 64, 128, 256, 512, 1024):
         idx = np.flatnonzero((sizes >= lo) & (sizes < stride))
         lo = stride
         if len(idx):
