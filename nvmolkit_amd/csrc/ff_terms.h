@@ -328,31 +328,57 @@ template <typename T> __device__ __forceinline__ T mmff_torsion(const T c, const
 }
 
 // buffered 14-7: E(r), dE/dr
+// ---- lean reciprocal / square root for the O(N^2) pair terms ------------------------------------------
+// The pair loops are VALU bound (tools/probe_mmff_groups.py: 0.34 us per MMFF pair term and thread, about 70 % of it in
+// two IEEE square roots and five IEEE divisions per van der Waals + electrostatic pair).  An IEEE f64 division is 11
+// instructions with scaling and fix-up for subnormal / infinite operands, a square root about 20; the operands here are
+// inter-atomic distances and sums of positive powers of them, so the hardware seed and two Newton steps (5 and 9
+// instructions, <= 2 ulp) do.  A van der Waals term also takes ONE reciprocal for its two denominators.
+__device__ __forceinline__ double rcp_lean(const double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y        = fma(y, e, y);
+  e        = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+struct Root {
+  double r, rinv;  // sqrt(x), 1 / sqrt(x)
+};
+__device__ __forceinline__ Root root_lean(const double x0) {
+  const double x = fmax(x0, 1.0e-300);  // coincident atoms: r -> 1e-150, forces stay finite (0 * rinv = 0)
+  const double y = __builtin_amdgcn_rsq(x);
+  double       g = x * y, h = 0.5 * y;
+  double       e = fma(-h, g, 0.5);
+  g              = fma(g, e, g);
+  h              = fma(h, e, h);
+  e              = fma(-h, g, 0.5);
+  g              = fma(g, e, g);
+  h              = fma(h, e, h);
+  return {g, 2.0 * h};
+}
+
 __device__ __forceinline__ void mmff_vdw(const double r, const double Rs, const double eps, double& e, double& dE_dr) {
   const double Rs2 = Rs * Rs, Rs7 = Rs2 * Rs2 * Rs2 * Rs;
   const double r2 = r * r, r6 = r2 * r2 * r2, r7 = r6 * r;
-  const double a   = 1.07 * Rs / (r + 0.07 * Rs);
+  const double t = r + 0.07 * Rs, den = r7 + 0.12 * Rs7;
+  const double ip = rcp_lean(t * den), it = ip * den, iden = ip * t;  // 1 / t, 1 / den
+  const double a   = 1.07 * Rs * it;
   const double a2  = a * a, a7 = a2 * a2 * a2 * a;
-  const double den = r7 + 0.12 * Rs7;
-  const double b   = 1.12 * Rs7 / den;
+  const double b   = 1.12 * Rs7 * iden;
   e                = eps * a7 * (b - 2.0);
-  const double da7 = -7.0 * a7 / (r + 0.07 * Rs);
-  const double db  = -b * 7.0 * r6 / den;
+  const double da7 = -7.0 * a7 * it;
+  const double db  = -b * 7.0 * r6 * iden;
   dE_dr            = eps * (da7 * (b - 2.0) + a7 * db);
 }
 
 // buffered Coulomb: chargeTerm = qi qj / D; dielModel 1 = constant (1/(r+b)), 2 = distance dependent (1/(r+b)^2)
 __device__ __forceinline__ void mmff_ele(const double r, const double chargeTerm, const int dielModel, const bool is14, double& e,
                                          double& dE_dr) {
-  const double rb = r + 0.05;
-  const double s  = is14 ? 0.75 : 1.0;
-  if (dielModel == 2) {
-    e     = s * 332.0716 * chargeTerm / (rb * rb);
-    dE_dr = -2.0 * e / rb;
-  } else {
-    e     = s * 332.0716 * chargeTerm / rb;
-    dE_dr = -e / rb;
-  }
+  const double inv = rcp_lean(r + 0.05);
+  const double s   = is14 ? 0.75 : 1.0;
+  const bool   sq  = dielModel == 2;
+  e                = s * 332.0716 * chargeTerm * (sq ? inv * inv : inv);
+  dE_dr            = (sq ? -2.0 : -1.0) * e * inv;
 }
 
 // ---- UFF terms (uff_kernels_device.cuh:37-580) --------------------------------------------------

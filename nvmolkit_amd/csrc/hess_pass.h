@@ -53,9 +53,10 @@ __host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t
   return r;
 }
 // LDS layout of bfgs_kernel: 12 vectors (the 12th is the diagonal of the inverse Hessian) + (1 + NW) partial-sum slabs of n
-// doubles (row sums, then one slab of mirrored-entry sums per wave; the per-wave gradient slabs alias them), 16 doubles of
+// doubles (row sums, then one slab of mirrored-entry sums per wave; the per-wave gradient slabs alias them), kRedDoubles of
 // reduction scratch, then the resident rows of the inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
-__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (13 + NW) * n + 16; }
+constexpr int kRedDoubles = 40;  // two alternating buffers of up to 4 values x NW waves (block reductions), padded
+__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (13 + NW) * n + kRedDoubles; }
 __host__ __device__ constexpr int64_t lds_hessian_doubles(const int64_t ldsDoubles, const int64_t n) {
   return ldsDoubles > lds_vector_doubles(n) ? ldsDoubles - lds_vector_doubles(n) : 0;
 }

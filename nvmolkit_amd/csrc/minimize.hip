@@ -102,6 +102,57 @@ template <int N> __device__ __forceinline__ void block_sum_n(double (&v)[N], dou
   }
 }
 
+// Block reductions of the fused BFGS kernel (about ten per iteration; the kernel is latency / barrier bound).  Two
+// things make them cheaper than block_reduce above: the wave stage runs on the DPP crossbar (quad, row of 16, then the
+// four rows through scalar registers: no LDS-crossbar permutes, which cost ~100 cycles each in a dependent chain of six)
+// and the LDS stage alternates between two buffers, so ONE barrier per reduction suffices — a thread can only reach the
+// write of reduction k + 2 after everyone has passed the barrier of reduction k + 1, i.e. after all reads of reduction k.
+template <Op OP> __device__ __forceinline__ double wave_reduce_dpp(double v) {
+  v = combine<OP>(v, dpp_mov<0xb1>(v));   // quad_perm [1, 0, 3, 2]
+  v = combine<OP>(v, dpp_mov<0x4e>(v));   // quad_perm [2, 3, 0, 1]
+  v = combine<OP>(v, dpp_mov<0x124>(v));  // row_ror 4
+  v = combine<OP>(v, dpp_mov<0x128>(v));  // row_ror 8: every lane holds its row's result
+  double r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * k), __builtin_amdgcn_readlane(__double2loint(v), 16 * k));
+  }
+  return combine<OP>(combine<OP>(r[0], r[1]), combine<OP>(r[2], r[3]));
+}
+struct BlockReducer {
+  double* red;    // kRedDoubles of LDS
+  int     phase;  // which half the next reduction uses (uniform)
+  template <Op OP> __device__ __forceinline__ double run(double v) {
+    v            = wave_reduce_dpp<OP>(v);
+    double* slot = red + phase * (kRedDoubles / 2);
+    phase ^= 1;
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = slot[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r = combine<OP>(r, slot[w]);
+    return r;
+  }
+  template <int N> __device__ __forceinline__ void sum_n(double (&v)[N]) {
+    static_assert(N * NW <= kRedDoubles / 2, "reduction scratch too small");
+    double* slot = red + phase * (kRedDoubles / 2);
+    phase ^= 1;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      v[k] = wave_reduce_dpp<Op::kSum>(v[k]);
+      if ((threadIdx.x & 63) == 0) slot[(threadIdx.x >> 6) * N + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      double r = slot[k];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) r += slot[w * N + k];
+      v[k] = r;
+    }
+  }
+};
+
 // ---- per-system energy / gradient -----------------------------------------------------------------
 // pos / grad are the system's own arrays (LDS or global), DIM doubles per atom.  Every thread walks its
 // share of each term group; energy() returns the thread's partial sum, grad() accumulates with atomics.
@@ -459,12 +510,12 @@ __device__ __forceinline__ double system_eval(const Batch& b, const EvalContext&
     const double r3first = (ref3 && t3.first < t3.end) ? ref3[t3.first - t3.begin] : 0.0;
     // flat-bottom distance restraints in 3-D: groups 2 (1-2), 3 (1-3), 5 (long range) (:368-392, :696-729)
     auto restraint = [&](const int* a, const double lo, const double hi, const double k) {
-      double       d[4];
-      const double dist = sqrt(pair_dist2<DIM>(pos, a[0], a[1], 3, d));
-      double       et, dE;
-      dist_constraint(dist, lo, hi, k, et, dE);
+      double     d[4];
+      const Root rt = root_lean(pair_dist2<DIM>(pos, a[0], a[1], 3, d));
+      double     et, dE;
+      dist_constraint(rt.r, lo, hi, k, et, dE);
       if constexpr (GRAD) {
-        if (dE != 0.0) pair_push<DIM>(grad, a[0], a[1], 3, d, dE / (dist > 1.0e-8 ? dist : 1.0e-8));
+        if (dE != 0.0) pair_push<DIM>(grad, a[0], a[1], 3, d, dE * fmin(rt.rinv, 1.0e8));  // dE / max(dist, 1e-8)
       } else {
         e += et;
       }
@@ -622,12 +673,12 @@ __device__ __forceinline__ double system_eval(const Batch& b, const EvalContext&
     });
     // radial terms share their tail: distance, the term's (energy, dE/dr), force along the pair
     auto radial = [&](const int* a, auto&& term) {
-      double       d[4];
-      const double r = sqrt(pair_dist2<DIM>(pos, a[0], a[1], 3, d));
-      double       et, dE;
-      term(r, et, dE);
+      double     d[4];
+      const Root rt = root_lean(pair_dist2<DIM>(pos, a[0], a[1], 3, d));
+      double     et, dE;
+      term(rt.r, et, dE);
       if constexpr (GRAD) {
-        if (r > 0.0) pair_push<DIM>(grad, a[0], a[1], 3, d, dE / r);
+        pair_push<DIM>(grad, a[0], a[1], 3, d, dE * rt.rinv);  // coincident atoms: d = 0, no force (as with the r > 0 test)
       } else {
         e += et;
       }
@@ -826,10 +877,10 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
   double* pu    = phdg + n;
   double* hdiag = pu + n;     // diagonal of the inverse Hessian (the strict lower triangle is in Hl / H)
   double* part  = hdiag + n;  // (1 + NW) n partial sums of the pass; its first NW slabs double as the per-wave gradients
-  double* red   = part + (1 + NW) * n;  // NT/64 + 1 (padded to 8)
+  BlockReducer br{part + (1 + NW) * n, 0};  // kRedDoubles of reduction scratch
   // Inverse Hessian: the first Rl rows of the packed triangle live in LDS behind the vectors (as many as the launch's LDS
   // budget holds: all of them for small systems), rows Rl.. stream from HBM as before.
-  double*   Hl = red + 16;
+  double*   Hl = br.red + kRedDoubles;
   const int Rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n));
 
   if (n == 0) {
@@ -856,7 +907,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
   if (tid == 0) ctx = eval_context<KIND>(b, sys);
   __syncthreads();
   auto energy_at = [&](const double* p) -> double {
-    return block_reduce<Op::kSum>(system_eval<KIND, false>(b, ctx, n, p, nullptr, w0, w1, a0 * DIM), red);
+    return br.run<Op::kSum>(system_eval<KIND, false>(b, ctx, n, p, nullptr, w0, w1, a0 * DIM));
   };
   double gradScale = 1.0;
   // Gradient contributions are accumulated per WAVE (LDS atomics into the wave's own slab: within a wave the order of
@@ -878,7 +929,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
       grad[i] = gi;
       mx      = fmax(mx, fabs(gi));
     }
-    mx = block_reduce<Op::kMax>(mx, red);
+    mx = br.run<Op::kMax>(mx);
     if (scaleGrads && mx > 10.0) {
       while (mx * gradScale > 10.0) gradScale *= 0.5;
       for (int i = tid; i < n; i += NT) grad[i] *= gradScale;
@@ -908,7 +959,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
     // ---- line search set-up (:54-136)
     double s = 0.0;
     for (int i = tid; i < n; i += NT) s += dir[i] * dir[i];
-    s = block_reduce<Op::kSum>(s, red);
+    s = br.run<Op::kSum>(s);
     if (s > maxStep2) {
       const double sc = sqrt(maxStep2 / s);
       for (int i = tid; i < n; i += NT) dir[i] *= sc;
@@ -919,8 +970,8 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
       slope += dir[i] * grad[i];
       test = fmax(test, fabs(dir[i]) / fmax(fabs(pos[i]), 1.0));
     }
-    slope                  = block_reduce<Op::kSum>(slope, red);
-    test                   = block_reduce<Op::kMax>(test, red);
+    slope                  = br.run<Op::kSum>(slope);
+    test                   = br.run<Op::kMax>(test);
     const double lambdaMin = MOVETOL / (test > 0.0 ? test : 1.0e-20);
     // ---- backtracking line search (:147-196)
     double lambda = 1.0, lambda2 = 0.0, e2 = 0.0, newE = prevE;
@@ -968,7 +1019,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
       dGrad[i] = grad[i];
       stepTest = fmax(stepTest, fabs(dir[i]) / fmax(fabs(trial[i]), 1.0));
     }
-    stepTest = block_reduce<Op::kMax>(stepTest, red);
+    stepTest = br.run<Op::kMax>(stepTest);
     prevE    = newE;  // energy of the coordinates that are returned (the reference reports the pre-step energy when
                       // TOLX fires, :680-687; the step is below 1.2e-7 relative there)
     if (!init && stepTest < TOLX) {
@@ -984,7 +1035,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
       dGrad[i] = grad[i] - dGrad[i];
       gTest    = fmax(gTest, fabs(grad[i]) * fmax(fabs(pos[i]), 1.0));
     }
-    gTest = block_reduce<Op::kMax>(gTest, red) / fmax(prevE * gradScale, 1.0);
+    gTest = br.run<Op::kMax>(gTest) / fmax(prevE * gradScale, 1.0);
     if (init) {  // H = I: the first direction is steepest descent; the step bound of the line searches (:54-60)
       double sumsq = 0.0;
       for (int i = tid; i < n; i += NT) {
@@ -992,7 +1043,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
         dir[i] = -grad[i];
         sumsq += pos[i] * pos[i];
       }
-      sumsq    = block_reduce<Op::kSum>(sumsq, red);
+      sumsq    = br.run<Op::kSum>(sumsq);
       maxStep2 = 1.0e4 * fmax(sumsq, static_cast<double>(n) * static_cast<double>(n));
       init     = false;
       continue;
@@ -1021,7 +1072,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
     }
     {
       double four[4] = {fac, fae, sumDG, sumXi};
-      block_sum_n<4>(four, red);
+      br.sum_n<4>(four);
       fac   = four[0];
       fae   = four[1];
       sumDG = four[2];
@@ -1043,7 +1094,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
       }
       {
         double three[3] = {dx, dh, du};
-        block_sum_n<3>(three, red);
+        br.sum_n<3>(three);
         dx = three[0];
         dh = three[1];
         du = three[2];

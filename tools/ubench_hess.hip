@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NT, OCC) void pass_kernel(double* __restrict__ hess
   double*   diag = xi + 11 * n;  // same offsets as bfgs_kernel: 11 vectors, the diagonal, then the partial sums
   double*   part = diag + n;
   double*   red  = part + (1 + NW) * n;
-  double*   Hl   = red + 16;
+  double*   Hl   = red + kRedDoubles;
   double*   H    = hessians + starts[blockIdx.x];
   const int Rl   = resident_rows(n, lds_hessian_doubles(ldsDoubles, n));
   for (int i = tid; i < n; i += NT) {
