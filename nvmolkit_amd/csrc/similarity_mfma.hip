@@ -230,7 +230,11 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
     const int64_t  rowStep = static_cast<int64_t>(RPP) * Wp;
     const uint4*   gA      = A + (rowA0 + prow) * Wp;
     const unsigned prowB   = static_cast<unsigned>(wave * (TN / NWV) + (lane >> C::LOG));
-    const uint4*   gB      = B + (rowB0 + prowB) * Wp;
+    // LDS row p of the B tile holds tile COLUMN (p & 64) + 2 (p & 31) + ((p >> 5) & 1): the two 32-column MFMA blocks of a
+    // wave then cover the even and the odd columns of its 64, so a lane's accumulators acc[.][0][r], acc[.][1][r] are
+    // ADJACENT columns of one row and leave as one 16-byte store — no lane exchange, no selects in the epilogue.
+    const unsigned colB    = (prowB & 64u) + 2u * (prowB & 31u) + ((prowB >> 5) & 1u);
+    const uint4*   gB      = B + (rowB0 + colB) * Wp;
     const int      nChunks = Wp / KCW;
     for (int ch = 0; ch < nChunks; ++ch) {
       if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
 #pragma unroll
       for (int t = 0; t < BPW; ++t) {
         const unsigned slot = (static_cast<unsigned>(lane) & (KCW - 1u)) ^ C::swz(prowB + RPP * t);
-        __builtin_amdgcn_global_load_lds((gptr_t)(gB + t * rowStep + ch * KCW + slot),
+        __builtin_amdgcn_global_load_lds((gptr_t)(gB + 2 * t * rowStep + ch * KCW + slot),  // RPP LDS rows = 2 RPP columns
                                          (lptr_t)(sB + (wave * BPW + t) * 1024), 16, 0, 0);
       }
       __syncthreads();  // hipcc drains vmcnt before the barrier: the chunk has landed for every wave
@@ -257,7 +261,8 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
   __builtin_amdgcn_s_setprio(0);
   const bool     full    = (rowA0 + TM <= nA) && (rowB0 + TN <= nB);
   const unsigned hi      = static_cast<unsigned>(lane >> 5);
-  const unsigned laneOff = (hi * 4u * static_cast<unsigned>(ld) + static_cast<unsigned>(lane & 31)) * 8u;
+  const int      col0    = 2 * (lane & 31);  // this lane's two columns inside the wave tile: col0 (block 0), col0 + 1 (block 1)
+  const unsigned laneOff = (hi * 4u * static_cast<unsigned>(ld) + static_cast<unsigned>(col0)) * 8u;
   char*          waveOut = reinterpret_cast<char*>(out + (rowA0 + wm * 64) * ld + rowB0 + wn * 64);
   // popcounts and the f32 accumulators are exact integers < 2^24, so the union is formed in f32 (no int round trip)
   auto value = [&](const float c, const float pav, const float pbv) -> double {
@@ -269,8 +274,12 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
       return (c == 0.0f || denom == 0.0) ? 0.0 : static_cast<double>(c) / denom;
     }
   };
-  const float pb0 = static_cast<float>(pcB[wn * 64 + (lane & 31)]);
-  const float pb1 = static_cast<float>(pcB[wn * 64 + 32 + (lane & 31)]);
+  const float pb0 = static_cast<float>(pcB[wn * 64 + col0]);
+  const float pb1 = static_cast<float>(pcB[wn * 64 + col0 + 1]);
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  // Interior tiles: 32 sixteen-byte stores per lane, each wave instruction writing two 512-byte row segments (rows i and
+  // i + 4), branch-free so that the divisions and stores of a lane interleave.  Nontemporal: the 8 B/pair output stream
+  // must not evict the operand blocks from L2.
   auto emit = [&](auto fullTag) {
     constexpr bool FULL = decltype(fullTag)::value;
 #pragma unroll
@@ -280,58 +289,21 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
         const int   il0    = mi * 32 + (r & 3) + 8 * (r >> 2);  // + 4 hi: this lane's row inside the wave tile
         const float pav    = static_cast<float>(pcA[wm * 64 + il0 + 4 * static_cast<int>(hi)]);
         char*       rowOut = waveOut + static_cast<int64_t>(il0) * ld * 8;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const double v   = value(acc[mi][ni][r], pav, ni ? pb1 : pb0);
-          double*      dst = reinterpret_cast<double*>(rowOut + ni * 256 + laneOff);
-          if (FULL || (rowA0 + wm * 64 + il0 + 4 * static_cast<int>(hi) < nA &&
-                       rowB0 + wn * 64 + ni * 32 + (lane & 31) < nB)) {
-            // nontemporal: the 8 B/pair output stream must not evict the operand blocks from L2
-            __builtin_nontemporal_store(v, dst);
-          }
-        }
-      }
-    }
-  };
-  // Interior tiles: neighbouring lanes swap one value (DPP quad_perm, no LDS) so that every lane owns two ADJACENT
-  // columns of one row and the tile goes out as 32 sixteen-byte stores per lane instead of 64 eight-byte ones —
-  // half the vector-memory instructions queued in front of the other workgroups' operand loads.  Accumulator rows
-  // r = 4 q + s are tile rows s + 8 q: rows s and s + 1 pair up; even lanes keep row s, odd lanes row s + 1.
-  auto emit_wide = [&]() {
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    const unsigned odd     = static_cast<unsigned>(lane) & 1u;
-    const unsigned laneOf2 = (hi * 4u * static_cast<unsigned>(ld) + odd * static_cast<unsigned>(ld) + (static_cast<unsigned>(lane & 31) & ~1u)) * 8u;
-    auto swap1 = [&](const double x) -> double {  // value of lane ^ 1
-      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xF, 0xF, false);
-      const int hh = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xF, 0xF, false);
-      return __hiloint2double(hh, lo);
-    };
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int sp = 0; sp < 4; sp += 2) {
-          const int   il0  = mi * 32 + sp + 8 * q;  // row of the even lanes (+ 4 hi); odd lanes: il0 + 1
-          const float pav0 = static_cast<float>(pcA[wm * 64 + il0 + 4 * static_cast<int>(hi)]);
-          const float pav1 = static_cast<float>(pcA[wm * 64 + il0 + 1 + 4 * static_cast<int>(hi)]);
-          char*       rowOut = waveOut + static_cast<int64_t>(il0) * ld * 8;
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            const double v0   = value(acc[mi][ni][4 * q + sp], pav0, ni ? pb1 : pb0);      // (row s,     my column)
-            const double v1   = value(acc[mi][ni][4 * q + sp + 1], pav1, ni ? pb1 : pb0);  // (row s + 1, my column)
-            const double got  = swap1(odd ? v0 : v1);                                      // partner's value for MY row
-            d2_t         out2;
-            out2.x = odd ? got : v0;
-            out2.y = odd ? v1 : got;
-            __builtin_nontemporal_store(out2, reinterpret_cast<d2_t*>(rowOut + ni * 256 + laneOf2));
-          }
+        d2_t        v;
+        v.x = value(acc[mi][0][r], pav, pb0);
+        v.y = value(acc[mi][1][r], pav, pb1);
+        if constexpr (FULL) {
+          __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(rowOut + laneOff));
+        } else if (rowA0 + wm * 64 + il0 + 4 * static_cast<int>(hi) < nA) {
+          double* dst = reinterpret_cast<double*>(rowOut + laneOff);
+          if (rowB0 + wn * 64 + col0 < nB) __builtin_nontemporal_store(v.x, dst);
+          if (rowB0 + wn * 64 + col0 + 1 < nB) __builtin_nontemporal_store(v.y, dst + 1);
         }
       }
     }
   };
   if (full) {
-    emit_wide();
+    emit(std::true_type{});
   } else {
     emit(std::false_type{});
   }

@@ -40,6 +40,47 @@ template <int MODE> __global__ __launch_bounds__(256) void k(uint32_t* out, uint
 #define X(i) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(d[i]));
         X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3)
 #undef X
+      } else if constexpr (MODE == 6) {  // v_cvt_f64_f32 (the dense epilogue converts c, u and the f32 reciprocal seed)
+        double* d = reinterpret_cast<double*>(a);
+        float*  f = reinterpret_cast<float*>(b);
+#define X(i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(f[i]));
+        X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3)
+#undef X
+      } else if constexpr (MODE == 7) {  // v_rcp_f32
+        float* f = reinterpret_cast<float*>(a);
+#define X(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[i]));
+        REP8(X)
+#undef X
+      } else if constexpr (MODE == 8) {  // v_rcp_f64
+        double* d = reinterpret_cast<double*>(a);
+#define X(i) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[i]));
+        X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3)
+#undef X
+      } else if constexpr (MODE == 9) {  // v_add_f64
+        double* d = reinterpret_cast<double*>(a);
+#define X(i) asm volatile("v_add_f64 %0, %0, %0" : "+v"(d[i]));
+        X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3)
+#undef X
+      } else if constexpr (MODE == 10) {  // v_add_f32
+        float* f = reinterpret_cast<float*>(a);
+#define X(i) asm volatile("v_add_f32 %0, %0, %0" : "+v"(f[i]));
+        REP8(X)
+#undef X
+      } else if constexpr (MODE == 11) {  // v_cvt_f64_i32
+        double* d = reinterpret_cast<double*>(a);
+#define X(i) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d[i]) : "v"(c[i]));
+        X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3)
+#undef X
+      } else if constexpr (MODE == 12) {  // v_rsq_f64
+        double* d = reinterpret_cast<double*>(a);
+#define X(i) asm volatile("v_rsq_f64 %0, %0" : "+v"(d[i]));
+        X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3)
+#undef X
+      } else if constexpr (MODE == 13) {  // v_mul_f64
+        double* d = reinterpret_cast<double*>(a);
+#define X(i) asm volatile("v_mul_f64 %0, %0, %0" : "+v"(d[i]));
+        X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3)
+#undef X
       } else if constexpr (MODE == 5) {  // v_and_or_b32 (VOP3 3-src) as a proxy for VOP3 rate
 #define X(i) asm volatile("v_and_or_b32 %0, %1, %0, %0" : "+v"(a[i]) : "v"(b[i]));
         REP8(X)
@@ -72,6 +113,17 @@ template <int MODE> int run(const char* name, int instrPerBody, int blocksPerCU)
 }
 
 int main() {
+  for (int bpc : {4}) {  // the f64 / conversion instructions of the dense-similarity epilogue and the BFGS pair terms
+    run<4>("v_fma_f64", 8, bpc);
+    run<9>("v_add_f64", 8, bpc);
+    run<13>("v_mul_f64", 8, bpc);
+    run<6>("v_cvt_f64_f32", 8, bpc);
+    run<11>("v_cvt_f64_i32", 8, bpc);
+    run<7>("v_rcp_f32", 8, bpc);
+    run<8>("v_rcp_f64", 8, bpc);
+    run<12>("v_rsq_f64", 8, bpc);
+    run<10>("v_add_f32", 8, bpc);
+  }
   for (int bpc : {1, 2, 4, 8}) {
     run<0>("v_and_b32", 8, bpc);
     run<1>("v_bcnt_u32_b32 acc", 8, bpc);
