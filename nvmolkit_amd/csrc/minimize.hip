@@ -836,11 +836,9 @@ constexpr int    MAX_LS_ITERS  = 1000;
 // PROFILE (NVMK_BFGS_PROFILE=1; DG, ETK and MMFF): thread 0 accumulates wall-clock ticks (100 MHz) per phase into
 // prof[sys * 8 + k]: 0 line-search energy evaluations, 1 gradient, 2 pass over H (pending update + H g), 3 update scalars + direction,
 // 4 whole kernel, 5 iterations, 6 energy evaluations.
-// OCC = workgroups the register budget leaves room for on a CU (2: up to 256 VGPRs, 3: up to 168).  The kernels are
-// latency / barrier bound (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES ~ 0.19), so a third resident workgroup can pay even though
-// it gets a smaller share of the LDS for resident inverse-Hessian rows.
-template <int KIND, bool PROFILE = false, int OCC = 2>
-__global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
+// Two workgroups per CU (up to 256 VGPRs each) share the LDS.
+template <int KIND, bool PROFILE = false>
+__global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
                                                   const int maxIters, const double gradTol, const int scaleGrads,
                                                   const uint8_t* __restrict__ active, const int64_t* __restrict__ hessStarts,
                                                   const int32_t* __restrict__ order,
@@ -1055,7 +1053,7 @@ __global__ __launch_bounds__(NT, OCC) void bfgs_kernel(const Batch b, double* __
     // ---- BFGS update of the inverse Hessian, new direction (:304-407) — one pass over H, see hess_pass
     const int64_t tH = now();
     __syncthreads();
-    hess_pass<(OCC < 3)>(hdiag, Hl, H, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
+    hess_pass<true>(hdiag, Hl, H, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
     hess_finish(n, part, tvec);  // H is now H_k; tvec = H_k g_new
     __syncthreads();
     tk[2] += now() - tH;
@@ -1242,11 +1240,9 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   constexpr size_t kLdsPerCu = 160 * 1024, kLdsReserve = 1024;  // static LDS of the kernel + allocation granularity
   NVMK_REQUIRE(vecBytes <= kLdsPerCu - kLdsReserve, "bfgs: a system with %d coordinates needs %zu bytes of LDS (max 160 KiB)", maxN,
                vecBytes);
-  // NVMK_BFGS_OCC = 2 | 3: workgroups per CU the kernel variant is compiled for (3 only for the DG / ETK / MMFF kinds)
-  int occ = 2;
-  if (const char* e = std::getenv("NVMK_BFGS_OCC")) occ = std::atoi(e) == 3 ? 3 : 2;
-  if (!(b.kind == NVMK_FF_DG || b.kind == NVMK_FF_ETK || b.kind == NVMK_FF_MMFF)) occ = 2;
-  size_t budget = kLdsPerCu / static_cast<size_t>(occ) - kLdsReserve;
+  // Two workgroups per CU share the LDS.  (A variant compiled for three — 168 VGPRs — was worth +3 % with the round-1
+  // evaluation code and -20 % with the current one, which keeps every group's leading terms in registers: removed.)
+  size_t budget = kLdsPerCu / 2 - kLdsReserve;
   if (const char* e = std::getenv("NVMK_BFGS_LDS")) {
     if (std::strcmp(e, "full") == 0) {
       budget = kLdsPerCu - kLdsReserve;
@@ -1325,30 +1321,6 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
                    sum[0] / std::max(sum[5], 1.0) * us, sum[1] / std::max(sum[5], 1.0) * us, sum[2] / std::max(sum[5], 1.0) * us,
                    sum[3] / std::max(sum[5], 1.0) * us);
     }
-    return NVMK_OK;
-  }
-  if (occ == 3) {
-    auto launch3 = [&](auto kern) -> int {
-      if (shmem > 64 * 1024) {
-        NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(shmem)));
-      }
-      hipLaunchKernelGGL(kern, dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters, grad_tol, scale_grads, d_active,
-                         startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies, d_statuses, d_iters,
-                         static_cast<int64_t*>(nullptr), ldsDoubles, g_stats.load());
-      return NVMK_OK;
-    };
-    int rc3 = NVMK_OK;
-    if (b.kind == NVMK_FF_DG) {
-      rc3 = launch3(bfgs_kernel<NVMK_FF_DG, false, 3>);
-    } else if (b.kind == NVMK_FF_ETK) {
-      rc3 = launch3(bfgs_kernel<NVMK_FF_ETK, false, 3>);
-    } else {
-      rc3 = launch3(bfgs_kernel<NVMK_FF_MMFF, false, 3>);
-    }
-    if (rc3 != NVMK_OK) return rc3;
-    NVMK_LAUNCH_CHECK();
-    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
     return NVMK_OK;
   }
   NVMK_FF_DISPATCH(b.kind, {

@@ -25,14 +25,12 @@ def systems_of(kind, sizes, seed):
     return [synthetic.random_ff_system(kind, n, rng) for n in sizes]
 
 
-@pytest.fixture(params=["0", "auto", "full", "auto:occ3"])
+@pytest.fixture(params=["0", "auto", "full", "40"])
 def lds_policy(request):
-    """LDS residency policy of the inverse Hessian (all in HBM / shared by the workgroups of a CU / whole LDS) and the
-    three-workgroups-per-CU kernel variant (NVMK_BFGS_OCC=3)."""
-    pol, _, occ = request.param.partition(":")
-    old = {k: os.environ.get(k) for k in ("NVMK_BFGS_LDS", "NVMK_BFGS_OCC")}
-    os.environ["NVMK_BFGS_LDS"] = pol
-    os.environ["NVMK_BFGS_OCC"] = "3" if occ == "occ3" else "2"
+    """LDS residency policy of the inverse Hessian: all in HBM / shared by the two workgroups of a CU / whole LDS for one
+    workgroup / an explicit budget in KB."""
+    old = {k: os.environ.get(k) for k in ("NVMK_BFGS_LDS",)}
+    os.environ["NVMK_BFGS_LDS"] = request.param
     yield request.param
     for k, v in old.items():
         if v is None:
