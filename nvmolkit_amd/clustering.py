@@ -37,11 +37,11 @@ def butina(distance_matrix, cutoff: float, neighborlist_max_size: int = 64, retu
         raise ValueError("distance_matrix must be a GPU tensor or AsyncGpuResult")
     if d.ndim != 2 or d.shape[0] != d.shape[1]:
         raise ValueError(f"distance_matrix must be square, got shape {tuple(d.shape)}")
-    if d.dtype != torch.float64:
-        d = d.to(torch.float64)
-    d = d.contiguous()
     n = d.shape[0]
-    with torch.cuda.device(d.device):
+    with torch.cuda.device(d.device), _native.on_stream(stream, d.device):  # conversions and outputs on the kernel's stream
+        if d.dtype != torch.float64:
+            d = d.to(torch.float64)
+        d = d.contiguous()
         clusters = torch.empty(n, dtype=torch.int32, device=d.device)
         centroids = torch.empty(n, dtype=torch.int32, device=d.device)
         n_clusters = ctypes.c_int64(0)
@@ -101,13 +101,13 @@ def fused_butina(x: torch.Tensor, cutoff: float, return_centroids: bool = False,
     sptr = _native.stream_ptr(stream)
     if cutoff < 0 or cutoff > 1:
         raise ValueError(f"cutoff must be in [0, 1], got {cutoff}")
-    x = x.contiguous()
     n = x.shape[0]
     idx = np.empty(max(n, 1), dtype=np.int32)
     offs = np.zeros(n + 1, dtype=np.int64)
     cent = np.empty(max(n, 1), dtype=np.int32)
     n_clusters = ctypes.c_int64(0)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _native.on_stream(stream, x.device):
+        x = x.contiguous()
         rc = _native.lib().nvmk_butina_fused(_METRICS[metric], x.data_ptr(), n, x.shape[1] * 32, float(cutoff),
                                              idx.ctypes.data, offs.ctypes.data, cent.ctypes.data,
                                              ctypes.byref(n_clusters), sptr)
