@@ -133,6 +133,26 @@ struct BlockReducer {
     for (int w = 1; w < NW; ++w) r = combine<OP>(r, slot[w]);
     return r;
   }
+  // NS sums followed by NM maxima in one barrier: v[0 .. NS) are summed, v[NS .. NS + NM) maximised
+  template <int NS, int NM> __device__ __forceinline__ void sums_and_maxima(double (&v)[NS + NM]) {
+    constexpr int N = NS + NM;
+    static_assert(N * NW <= kRedDoubles / 2, "reduction scratch too small");
+    double* slot = red + phase * (kRedDoubles / 2);
+    phase ^= 1;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      v[k] = k < NS ? wave_reduce_dpp<Op::kSum>(v[k]) : wave_reduce_dpp<Op::kMax>(v[k]);
+      if ((threadIdx.x & 63) == 0) slot[(threadIdx.x >> 6) * N + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      double r = slot[k];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) r = k < NS ? r + slot[w * N + k] : fmax(r, slot[w * N + k]);
+      v[k] = r;
+    }
+  }
   template <int N> __device__ __forceinline__ void sum_n(double (&v)[N]) {
     static_assert(N * NW <= kRedDoubles / 2, "reduction scratch too small");
     double* slot = red + phase * (kRedDoubles / 2);
@@ -911,7 +931,9 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   // Gradient contributions are accumulated per WAVE (LDS atomics into the wave's own slab: within a wave the order of
   // the additions is the program's, so it does not depend on how the waves happen to be scheduled) and the slabs are
   // summed in a fixed order: a minimisation — and with it a seeded ETKDG run — is reproducible bit for bit.
-  auto   grad_at   = [&](const double* p) {
+  // `alsoMax` rides along in the gradient's own max-reduction (one barrier for both).  No barrier at the end: what follows
+  // touches grad / dGrad at the thread's own indices only, up to the next reduction.
+  auto   grad_at   = [&](const double* p, double& alsoMax) {
     for (int i = tid; i < NW * n; i += NT) part[i] = 0.0;
     __syncthreads();
     system_eval<KIND, true>(b, ctx, n, p, part + (tid >> 6) * n, w0, w1, a0 * DIM);
@@ -927,12 +949,14 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
       grad[i] = gi;
       mx      = fmax(mx, fabs(gi));
     }
-    mx = br.run<Op::kMax>(mx);
+    double two[2] = {mx, alsoMax};
+    br.sums_and_maxima<0, 2>(two);
+    mx      = two[0];
+    alsoMax = two[1];
     if (scaleGrads && mx > 10.0) {
       while (mx * gradScale > 10.0) gradScale *= 0.5;
       for (int i = tid; i < n; i += NT) grad[i] *= gradScale;
     }
-    __syncthreads();
   };
 
   // The first energy / gradient evaluation runs through the loop body as a step of length zero (`init`), so that the
@@ -953,23 +977,33 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   int  iter      = 0;
   int  nEvals    = 0;
   while (init || (!converged && iter < maxIters)) {
-    for (int i = tid; i < n; i += NT) oldp[i] = pos[i];
-    // ---- line search set-up (:54-136)
-    double s = 0.0;
-    for (int i = tid; i < n; i += NT) s += dir[i] * dir[i];
-    s = br.run<Op::kSum>(s);
-    if (s > maxStep2) {
-      const double sc = sqrt(maxStep2 / s);
-      for (int i = tid; i < n; i += NT) dir[i] *= sc;
+    // ---- line search set-up (:54-136): |dir|^2, the slope and the step test in ONE reduction; the step bound almost
+    // never bites, and when it does the two quantities that depend on the rescaled direction are formed again
+    double slope, test;
+    {
+      double three[3] = {0.0, 0.0, 0.0};
+      for (int i = tid; i < n; i += NT) {
+        oldp[i] = pos[i];
+        three[0] += dir[i] * dir[i];
+        three[1] += dir[i] * grad[i];
+        three[2] = fmax(three[2], fabs(dir[i]) / fmax(fabs(pos[i]), 1.0));
+      }
+      br.sums_and_maxima<2, 1>(three);
+      slope = three[1];
+      test  = three[2];
+      if (three[0] > maxStep2) {
+        const double sc = sqrt(maxStep2 / three[0]);
+        double       two[2] = {0.0, 0.0};
+        for (int i = tid; i < n; i += NT) {
+          dir[i] *= sc;
+          two[0] += dir[i] * grad[i];
+          two[1] = fmax(two[1], fabs(dir[i]) / fmax(fabs(pos[i]), 1.0));
+        }
+        br.sums_and_maxima<1, 1>(two);
+        slope = two[0];
+        test  = two[1];
+      }
     }
-    __syncthreads();
-    double slope = 0.0, test = 0.0;
-    for (int i = tid; i < n; i += NT) {
-      slope += dir[i] * grad[i];
-      test = fmax(test, fabs(dir[i]) / fmax(fabs(pos[i]), 1.0));
-    }
-    slope                  = br.run<Op::kSum>(slope);
-    test                   = br.run<Op::kMax>(test);
     const double lambdaMin = MOVETOL / (test > 0.0 ? test : 1.0e-20);
     // ---- backtracking line search (:147-196)
     double lambda = 1.0, lambda2 = 0.0, e2 = 0.0, newE = prevE;
@@ -1009,7 +1043,8 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
       e2      = newE;
       lambda  = fmax(tmp, 0.1 * lambda);
     }
-    // ---- accept the step, TOLX test (:198-229)
+    // ---- accept the step (:198-229); its TOLX test is reduced together with the gradient's maximum below (one barrier
+    // less per iteration; the gradient of an iterate that turns out to be converged is computed and dropped)
     double stepTest = 0.0;
     for (int i = tid; i < n; i += NT) {
       pos[i]   = trial[i];
@@ -1017,17 +1052,16 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
       dGrad[i] = grad[i];
       stepTest = fmax(stepTest, fabs(dir[i]) / fmax(fabs(trial[i]), 1.0));
     }
-    stepTest = br.run<Op::kMax>(stepTest);
-    prevE    = newE;  // energy of the coordinates that are returned (the reference reports the pre-step energy when
-                      // TOLX fires, :680-687; the step is below 1.2e-7 relative there)
+    prevE = newE;  // energy of the coordinates that are returned (the reference reports the pre-step energy when
+                   // TOLX fires, :680-687; the step is below 1.2e-7 relative there)
+    // ---- new gradient, gradient test (:277-303)
+    const int64_t tG = now();
+    grad_at(pos, stepTest);
+    tk[1] += now() - tG;
     if (!init && stepTest < TOLX) {
       converged = true;
       break;
     }
-    // ---- new gradient, gradient test (:277-303)
-    const int64_t tG = now();
-    grad_at(pos);
-    tk[1] += now() - tG;
     double gTest = 0.0;
     for (int i = tid; i < n; i += NT) {
       dGrad[i] = grad[i] - dGrad[i];
@@ -1051,11 +1085,9 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
       break;
     }
     // ---- BFGS update of the inverse Hessian, new direction (:304-407) — one pass over H, see hess_pass
-    const int64_t tH = now();
-    __syncthreads();
+    const int64_t tH = now();  // (the reduction above was a barrier: every gradient entry is visible, nobody reads `part` any more)
     hess_pass<true>(hdiag, Hl, H, Rl, n, pending, pRfac, pFad, pFae, pxi, phdg, pu, grad, part);
-    hess_finish(n, part, tvec);  // H is now H_k; tvec = H_k g_new
-    __syncthreads();
+    hess_finish(n, part, tvec);  // H is now H_k; tvec = H_k g_new (entry i is used by thread i only: no barrier)
     tk[2] += now() - tH;
     const int64_t tU = now();
     double fac = 0.0, fae = 0.0, sumDG = 0.0, sumXi = 0.0;
@@ -1103,8 +1135,7 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
     } else {
       for (int i = tid; i < n; i += NT) hg[i] = tvec[i];
     }
-    for (int i = tid; i < n; i += NT) dir[i] = -hg[i];
-    __syncthreads();
+    for (int i = tid; i < n; i += NT) dir[i] = -hg[i];  // read back by this thread only until the next reduction's barrier
     tk[3] += now() - tU;
     ++iter;
   }
