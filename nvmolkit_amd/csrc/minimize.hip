@@ -437,7 +437,10 @@ __device__ __forceinline__ void run_terms(const Group& g, TermBatch<NI, NP, PUK>
 }
 
 // GRAD = false: returns the energy partial.  GRAD = true: accumulates the gradient, returns 0.
-template <int KIND, bool GRAD>
+// GRAD && WITH_E (distance-geometry field only): the gradient walk also returns the energy partial — the BFGS kernel
+// evaluates the first trial point of a DG line search this way, because 96 % of those trials are accepted and the
+// separate gradient evaluation of the new iterate then falls away.
+template <int KIND, bool GRAD, bool WITH_E = false>
 __device__ __forceinline__ double system_eval(const Batch& b, const EvalContext& ctx, const int nCoords, const double* pos, double* grad,
                                                const double w0, const double w1, const int globalCoordStart) {
   constexpr int DIM = Dim<KIND>::value;
@@ -471,7 +474,9 @@ __device__ __forceinline__ double system_eval(const Batch& b, const EvalContext&
   auto at = [&](const int atom, const int slot) { return Loader<double, DIM>::get(pos, atom, slot); };
   (void)at;
 
+  static_assert(!WITH_E || (GRAD && KIND == NVMK_FF_DG), "energy + gradient in one walk is built for the DG field");
   if constexpr (KIND == NVMK_FF_DG) {
+    constexpr bool ENERGY = !GRAD || WITH_E;
     auto t0 = term_batch<2, 3, PU>(b.g[0], ctx.r[0], group_rotation(ctx, 0));
     auto t1 = term_batch<4, 2, 1>(b.g[1], ctx.r[1], group_rotation(ctx, 1));
     auto t2 = term_batch<1, 0, 1>(b.g[2], ctx.r[2], group_rotation(ctx, 2));
@@ -483,9 +488,8 @@ __device__ __forceinline__ double system_eval(const Batch& b, const EvalContext&
       dist_violation(d2, p[0], p[1], p[2], et, dE);
       if constexpr (GRAD) {
         if (dE != 0.0) pair_push<DIM>(grad, a[0], a[1], 4, d, 2.0 * dE);
-      } else {
-        e += et;
       }
+      if constexpr (ENERGY) e += et;
     });
     // chiral volumes, weight w0 (:97-207); RDKit's gradient is half the derivative
     run_terms(b.g[1], t1, [&](const int, const int* a, const double* p) {
@@ -499,18 +503,14 @@ __device__ __forceinline__ double system_eval(const Batch& b, const EvalContext&
 #else
         ffg::grad_dg_chiral<DIM>(pos, aa, p[0], p[1], w0, acc);
 #endif
-      } else {
-        e += chiral_violation(chiral_volume(at(a[0], 0), at(a[1], 1), at(a[2], 2), at(a[3], 3)), p[0], p[1], w0);
       }
+      if constexpr (ENERGY) e += chiral_violation(chiral_volume(at(a[0], 0), at(a[1], 1), at(a[2], 2), at(a[3], 3)), p[0], p[1], w0);
     });
     // fourth dimension, weight w1 (:209-231): E = w x4^2, RDKit gradient w x4
     run_terms(b.g[2], t2, [&](const int, const int* a, const double*) {
       const double x = pos[a[0] * DIM + 3];
-      if constexpr (GRAD) {
-        atomicAdd(&grad[a[0] * DIM + 3], w1 * x);
-      } else {
-        e += w1 * x * x;
-      }
+      if constexpr (GRAD) atomicAdd(&grad[a[0] * DIM + 3], w1 * x);
+      if constexpr (ENERGY) e += w1 * x * x;
     });
     return e;
   }
@@ -933,11 +933,21 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   // summed in a fixed order: a minimisation — and with it a seeded ETKDG run — is reproducible bit for bit.
   // `alsoMax` rides along in the gradient's own max-reduction (one barrier for both).  No barrier at the end: what follows
   // touches grad / dGrad at the thread's own indices only, up to the next reduction.
-  auto   grad_at   = [&](const double* p, double& alsoMax) {
+  // DG only: energy AND per-wave gradient slabs of a trial point in one walk over the terms
+  auto energy_and_slabs_at = [&](const double* p) -> double {
     for (int i = tid; i < NW * n; i += NT) part[i] = 0.0;
     __syncthreads();
-    system_eval<KIND, true>(b, ctx, n, p, part + (tid >> 6) * n, w0, w1, a0 * DIM);
-    __syncthreads();
+    double e = 0.0;
+    if constexpr (KIND == NVMK_FF_DG) e = system_eval<KIND, true, true>(b, ctx, n, p, part + (tid >> 6) * n, w0, w1, a0 * DIM);
+    return br.run<Op::kSum>(e);  // its barrier also completes the slabs
+  };
+  auto   grad_at   = [&](const double* p, double& alsoMax, const bool slabsValid) {
+    if (!slabsValid) {
+      for (int i = tid; i < NW * n; i += NT) part[i] = 0.0;
+      __syncthreads();
+      system_eval<KIND, true>(b, ctx, n, p, part + (tid >> 6) * n, w0, w1, a0 * DIM);
+      __syncthreads();
+    }
     // gradient scaling (bfgs_minimize_permol_kernels.cu:239-275; |g| rule of RDKit >= 2025.09)
     gradScale = scaleGrads ? 0.1 : 1.0;
     double mx = 0.0;
@@ -1007,11 +1017,18 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
     const double lambdaMin = MOVETOL / (test > 0.0 ? test : 1.0e-20);
     // ---- backtracking line search (:147-196)
     double lambda = 1.0, lambda2 = 0.0, e2 = 0.0, newE = prevE;
+    bool   slabsValid = false;  // the gradient slabs in `part` belong to the trial point that gets accepted
     for (int ls = 0; ls < MAX_LS_ITERS; ++ls) {
       for (int i = tid; i < n; i += NT) trial[i] = oldp[i] + lambda * dir[i];
       __syncthreads();
       const int64_t tE = now();
-      newE             = energy_at(trial);
+      if (KIND == NVMK_FF_DG && ls == 0) {
+        newE       = energy_and_slabs_at(trial);
+        slabsValid = true;
+      } else {
+        newE       = energy_at(trial);
+        slabsValid = false;
+      }
       tk[0] += now() - tE;
       tk[6] += 1;
       ++nEvals;
@@ -1056,7 +1073,7 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
                    // TOLX fires, :680-687; the step is below 1.2e-7 relative there)
     // ---- new gradient, gradient test (:277-303)
     const int64_t tG = now();
-    grad_at(pos, stepTest);
+    grad_at(pos, stepTest, slabsValid);
     tk[1] += now() - tG;
     if (!init && stepTest < TOLX) {
       converged = true;
