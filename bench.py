@@ -160,6 +160,59 @@ def butina_block(n: int, words: int, device, cpu_seconds: float) -> dict:
     return out
 
 
+def cfg1_block(device, cpu_seconds: float) -> dict:
+    """BASELINE.json configs[0]: the reference's 10 000 benchmark SMILES (benchmarks/data/chembl_10k.smi, kept as input
+    data under tests/golden/) -> Morgan r = 2 / 2048 bit -> 10k x 10k Tanimoto, end to end without RDKit: the library's own
+    SMILES ingestion on the host, the Morgan kernels and the dense similarity kernel on the GPU."""
+    from nvmolkit_amd.fingerprints import MorganFingerprintGenerator, SmilesSet
+    from nvmolkit_amd.similarity import crossTanimotoSimilarity
+
+    path = ROOT / "tests" / "golden" / "chembl_10k.smi"
+    smiles = [line.split()[0] for line in path.read_text().splitlines() if line.strip()]
+    gen = MorganFingerprintGenerator(radius=2, fpSize=2048)
+    gen.GetFingerprintsFromSmiles(smiles[:512]).torch()                # warm-up: library, staging pools
+    crossTanimotoSimilarity(gen.GetFingerprintsFromSmiles(smiles[:512]).torch()).torch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mols = SmilesSet(smiles)
+    t_parse = time.perf_counter() - t0
+    fps = gen.GetFingerprintsFromSmiles(mols).torch()
+    torch.cuda.synchronize()
+    t_fp = time.perf_counter() - t0
+    sim = crossTanimotoSimilarity(fps).torch()
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    n = len(smiles)
+    out = {"molecules": n, "ingested": int((mols.status == 0).sum()), "seconds": t_all, "smiles_parse_seconds": t_parse,
+           "smiles_to_fingerprints_seconds": t_fp, "similarity_seconds": t_all - t_fp,
+           "fingerprints_per_s": n / t_fp, "similarity_pairs_per_s": float(n) * n / (t_all - t_fp),
+           "data": "tests/golden/chembl_10k.smi (the reference's benchmarks/data/chembl_10k.smi)",
+           "note": "one cold pass: SMILES strings on the host -> (10000, 10000) float64 Tanimoto matrix on the GPU"}
+    if cpu_seconds > 0:
+        import oracle
+
+        size = np.maximum(mols.n_atoms, mols.n_bonds)
+        t0 = time.perf_counter()
+        want = np.zeros((n, 64), dtype=np.uint32)
+        lo = 0
+        for stride in (32, 64, 128, 256, 512, 1024):
+            idx = np.flatnonzero((size >= lo) & (size < stride) & (mols.status == 0))
+            lo = stride
+            if len(idx):
+                want[idx] = oracle.morgan_fingerprints(*mols.morgan_inputs(idx, stride), stride, 2, 2048)
+        t_cpu_fp = time.perf_counter() - t0
+        ref = oracle.cross_similarity(want, want)
+        t_cpu = time.perf_counter() - t0
+        rows = np.r_[0:32, n - 32:n]
+        out["cpu_baseline"] = {"value": t_cpu, "unit": "s", "cores": oracle.num_threads(), "kind": "port",
+                               "fingerprint_seconds": t_cpu_fp, "similarity_seconds": t_cpu - t_cpu_fp,
+                               "sample": "the whole configuration: oracle/oracle_morgan.c on the same graphs + oracle/oracle_similarity.c "
+                                         "(OpenMP) for the 10k x 10k matrix"}
+        out["matches_cpu_port"] = bool(np.array_equal(fps.cpu().numpy().view(np.uint32), want)
+                                       and np.array_equal(sim[rows].cpu().numpy(), ref[rows]))
+    return out
+
+
 BFGS_KIND_NAMES = {0: "dg", 1: "etk", 2: "mmff"}
 
 
@@ -277,6 +330,7 @@ def main() -> None:
                     help="also time ETKDG (10 conformers) + MMFF94 optimise on this many synthetic drug-like molecules PER "
                          "GPU (BASELINE.json configs[2]: 10k; configs[3] when --gpus > 1), reported under 'secondary' (0 = skip)")
     ap.add_argument("--conformer-confs", type=int, default=10)
+    ap.add_argument("--cfg1", type=int, default=1, help="1: also run BASELINE configs[0] (10k SMILES -> Morgan -> 10k x 10k), 0: skip")
     ap.add_argument("--mmff-iters", type=int, default=200, help="MMFF maxIters (the reference benchmark's default)")
     args = ap.parse_args()
 
@@ -448,6 +502,10 @@ def main() -> None:
         secondary = {}
         if world == 1 and args.butina_n > 0:
             secondary["fused_butina"] = butina_block(args.butina_n, words, device, args.cpu_seconds)
+        if world == 1 and args.cfg1:
+            out = None  # release the 65 GB output block first
+            torch.cuda.empty_cache()
+            secondary["cfg1_smiles_to_similarity"] = cfg1_block(device, args.cpu_seconds)
     else:
         secondary = {}
     if args.conformer_mols > 0:  # every rank takes part (configs[3]: molecules sharded, no collective on the data path)

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_traffic
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --butina-n 0 --conformer-mols 0"
+BENCH="python $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --butina-n 0 --conformer-mols 0 --cfg1 0"
 export NVMK_ROOT=$ROOT
 timeout 600 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1
