@@ -641,7 +641,7 @@ struct Set {
 
 template <typename F> void parallel_for(const int64_t n, int threads, F&& body) {
   if (threads <= 0) threads = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
-  threads = static_cast<int>(std::min<int64_t>(threads, std::max<int64_t>(1, n / 64)));
+  threads = static_cast<int>(std::min<int64_t>(threads, std::max<int64_t>(1, n / 256)));  // a thread is worth starting for >= 256 molecules
   if (threads <= 1) {
     for (int64_t i = 0; i < n; ++i) body(i);
     return;
