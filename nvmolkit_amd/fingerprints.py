@@ -35,6 +35,7 @@ def pack_fingerprint(fp: torch.Tensor) -> torch.Tensor:
 # ---- Morgan fingerprints ------------------------------------------------------------------------
 
 import ctypes  # noqa: E402
+import threading  # noqa: E402
 
 import numpy as np  # noqa: E402
 
@@ -193,6 +194,30 @@ class SmilesSet:
         return atom_inv, bond_inv, bond_idx, bond_other, n_atoms
 
 
+# Pinned staging blocks, pooled per process: (tensor, event or None) pairs; a block is reused when the copy that last read it
+# has completed.  Sizes are rounded up to powers of two so that a few blocks serve every bucket.
+_PINNED_POOL: list = []
+_PINNED_LOCK = threading.Lock()
+
+
+def _pinned_block(n_bytes: int) -> torch.Tensor:
+    size = 1 << max(16, int(n_bytes - 1).bit_length())
+    with _PINNED_LOCK:
+        for k, (t, ev) in enumerate(_PINNED_POOL):
+            if t.numel() >= n_bytes and t.numel() <= 4 * size and ev.query():
+                _PINNED_POOL.pop(k)
+                return t
+    return torch.empty(size, dtype=torch.uint8, pin_memory=True)  # allocated pinned: no pageable copy on torch's CPU thread pool
+
+
+def _release_pinned_block(t: torch.Tensor, dev, stream) -> None:
+    ev = torch.cuda.Event()
+    ev.record(stream if stream is not None else torch.cuda.current_stream(dev))
+    with _PINNED_LOCK:
+        if len(_PINNED_POOL) < 16:
+            _PINNED_POOL.append((t, ev))
+
+
 class MorganFingerprintGenerator:
     """Batched Morgan fingerprints on the GPU (reference: nvmolkit/fingerprints.py:75-108).
 
@@ -207,28 +232,32 @@ class MorganFingerprintGenerator:
     def _launch(self, flat, max_atoms: int, out: torch.Tensor, out_idx, stream) -> None:
         """Stage one bucket and launch its kernel on ``stream`` WITHOUT synchronising (the reference's API is asynchronous:
         per-thread pinned staging buffers + stream + event, src/morgan_fingerprint_gpu.cpp:245-250,296-310,449-454).
-        The staging runs with ``stream`` current, so the caching allocator ties the device buffers to that stream and
-        they can be released as soon as Python drops them; the pinned host buffers are parked on the output tensor until
-        the caller synchronises."""
+        The six input arrays of a bucket travel as ONE pinned block and one host-to-device copy (pinning costs about a
+        millisecond per allocation, which dominated a 10 000-molecule call when every array was pinned by itself); the pinned
+        blocks are pooled per process and handed out again once the copy that read them has completed (event).  The staging
+        runs with ``stream`` current, so the caching allocator ties the device block to that stream."""
         atom_inv, bond_inv, bond_idx, bond_other, n_atoms = flat
         dev = out.device
-        keep = getattr(out, "_nvmk_staging", None)
-        if keep is None:
-            keep = []
-            out._nvmk_staging = keep
-
-        def to_dev(x):
-            h = torch.from_numpy(np.ascontiguousarray(x)).pin_memory()
-            keep.append(h)
-            return h.to(dev, non_blocking=True)
-
+        parts = [np.ascontiguousarray(atom_inv).view(np.uint8).reshape(-1), np.ascontiguousarray(bond_inv).view(np.uint8).reshape(-1),
+                 np.ascontiguousarray(bond_idx).view(np.uint8).reshape(-1), np.ascontiguousarray(bond_other).view(np.uint8).reshape(-1),
+                 np.ascontiguousarray(n_atoms).view(np.uint8).reshape(-1)]
+        if out_idx is not None:
+            parts.append(np.ascontiguousarray(out_idx, dtype=np.int32).view(np.uint8).reshape(-1))
+        offsets, total = [], 0
+        for p in parts:
+            offsets.append(total)
+            total += (p.size + 255) // 256 * 256  # every array starts 256-byte aligned inside the block
         with _native.on_stream(stream, dev):
-            d = [to_dev(atom_inv.view(np.int32)), to_dev(bond_inv.view(np.int32)), to_dev(bond_idx), to_dev(bond_other),
-                 to_dev(n_atoms)]
-            d_idx = to_dev(np.asarray(out_idx, dtype=np.int32)) if out_idx is not None else None
+            host = _pinned_block(total)
+            hview = host.numpy()
+            for p, o in zip(parts, offsets):
+                hview[o:o + p.size] = p
+            block = host[:total].to(dev, non_blocking=True)
+            _release_pinned_block(host, dev, stream)
+            ptr = [block.data_ptr() + o for o in offsets]
             with torch.cuda.device(dev):
-                rc = _native.lib().nvmk_morgan_from_invariants(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
-                                                               d[4].data_ptr(), d_idx.data_ptr() if d_idx is not None else None,
+                rc = _native.lib().nvmk_morgan_from_invariants(ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
+                                                               ptr[5] if out_idx is not None else None,
                                                                len(n_atoms), max_atoms, self._radius, self._fp_size,
                                                                out.data_ptr(), _native.stream_ptr(stream))
             _native.check(rc, "nvmk_morgan_from_invariants")
