@@ -109,21 +109,30 @@ class FlatForcefieldBatch:
             self._c.system_mol = sm.data_ptr()
             n_rows = None  # validated against the tables below
         for g, ((n_idx, n_par), (starts, idx, par)) in enumerate(zip(layout, groups)):
-            starts = np.ascontiguousarray(starts, dtype=np.int32)
-            idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, n_idx)
-            par = (np.ascontiguousarray(par, dtype=np.float64).reshape(-1, n_par) if n_par else np.zeros((len(idx), 0)))
-            if n_rows is None:
-                n_rows = len(starts) - 1
-            if len(starts) != n_rows + 1 or (len(starts) and starts[-1] != len(idx)) or len(par) != len(idx):
-                raise ValueError(f"term group {g}: inconsistent starts / idx / par sizes")
-            t = [torch.from_numpy(starts).to(self.device), torch.from_numpy(idx.copy()).to(self.device),
-                 torch.from_numpy(np.ascontiguousarray(par)).to(self.device)]
-            if g in PAIR_ORDER_GROUPS[kind] and pair_order_enabled():
-                t[1], t[2] = diagonal_pair_order(t[0], t[1], t[2])
+            if isinstance(starts, torch.Tensor):  # already resident (MoleculeTermTables): validated and ordered there
+                t = [starts, idx, par]
+                if any(x.device != self.device for x in t):
+                    raise ValueError(f"term group {g}: resident tables live on {starts.device}, the batch on {self.device}")
+                if n_rows is None:
+                    n_rows = starts.numel() - 1
+                if starts.numel() != n_rows + 1:
+                    raise ValueError(f"term group {g}: inconsistent starts / idx / par sizes")
+            else:
+                starts = np.ascontiguousarray(starts, dtype=np.int32)
+                idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, n_idx)
+                par = (np.ascontiguousarray(par, dtype=np.float64).reshape(-1, n_par) if n_par else np.zeros((len(idx), 0)))
+                if n_rows is None:
+                    n_rows = len(starts) - 1
+                if len(starts) != n_rows + 1 or (len(starts) and starts[-1] != len(idx)) or len(par) != len(idx):
+                    raise ValueError(f"term group {g}: inconsistent starts / idx / par sizes")
+                t = [torch.from_numpy(starts).to(self.device), torch.from_numpy(idx.copy()).to(self.device),
+                     torch.from_numpy(np.ascontiguousarray(par)).to(self.device)]
+                if g in PAIR_ORDER_GROUPS[kind] and pair_order_enabled():
+                    t[1], t[2] = diagonal_pair_order(t[0], t[1], t[2])
             self._keep.extend(t)
             self._c.groups[g].starts = t[0].data_ptr()
-            self._c.groups[g].idx = t[1].data_ptr() if len(idx) else None
-            self._c.groups[g].par = t[2].data_ptr() if par.size else None
+            self._c.groups[g].idx = t[1].data_ptr() if t[1].numel() else None
+            self._c.groups[g].par = t[2].data_ptr() if t[2].numel() else None
 
     @property
     def n_atoms_total(self) -> int:
@@ -189,6 +198,31 @@ class FlatForcefieldBatch:
         return energies, statuses, iters
 
 
+class MoleculeTermTables:
+    """Per-MOLECULE term tables of `kind`, stacked, uploaded and pair-ordered ONCE, for any number of conformer batches.
+
+    ``tables[m][g] = (idx, par)`` as for :func:`stack_molecule_tables`.  The reference flattens once per unique molecule
+    and copies into every batch (src/minimizer/bfgs_mmff.cpp:159,195-201); here the tables stay where they are and a
+    batch only adds its atom offsets and its system -> molecule map (``FlatForcefieldBatch(..., system_mol=...)``).
+    """
+
+    def __init__(self, kind: int, tables: Sequence[Sequence[tuple]], device="cuda"):
+        self.kind = kind
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_mols = len(tables)
+        self.groups = []
+        with torch.cuda.device(self.device):
+            for g, (starts, idx, par) in enumerate(stack_molecule_tables(kind, tables)):
+                t = [torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int32)).to(self.device),
+                     torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device),
+                     torch.from_numpy(np.ascontiguousarray(par, dtype=np.float64)).to(self.device)]
+                if g in PAIR_ORDER_GROUPS[kind] and pair_order_enabled():
+                    t[1], t[2] = diagonal_pair_order(t[0], t[1], t[2])
+                self.groups.append(tuple(t))
+
+
 def stack_molecule_tables(kind: int, tables: Sequence[Sequence[tuple]]):
     """Per-molecule term tables ``tables[m][g] = (idx, par)`` -> the ``(starts, idx, par)`` groups of a batch whose
     rows are MOLECULES (to be used with ``system_mol``)."""
@@ -218,14 +252,20 @@ def minimize_device_conformers(kind: int, tables, conformers: Device3DResult, ma
     new ``Device3DResult`` carrying ``energies`` and ``converged``.  The input result is left untouched."""
     if kind not in (MMFF, UFF):
         raise ValueError("minimize_device_conformers supports the MMFF and UFF kinds")
-    if len(tables) != conformers.n_mols:
-        raise ValueError(f"expected term tables for {conformers.n_mols} molecules, got {len(tables)}")
+    n_tables = tables.n_mols if isinstance(tables, MoleculeTermTables) else len(tables)
+    if n_tables != conformers.n_mols:
+        raise ValueError(f"expected term tables for {conformers.n_mols} molecules, got {n_tables}")
     values = conformers.values.torch()
     device = values.device
     atom_starts = conformers.atom_starts.torch()
     mols = conformers.mol_indices.torch().to(torch.int32)
-    batch = FlatForcefieldBatch(kind, atom_starts.cpu().numpy(), stack_molecule_tables(kind, tables), device=device,
-                                system_mol=mols)
+    if isinstance(tables, MoleculeTermTables):
+        if tables.kind != kind:
+            raise ValueError("the resident term tables belong to another force field")
+        groups = tables.groups
+    else:
+        groups = stack_molecule_tables(kind, tables)
+    batch = FlatForcefieldBatch(kind, atom_starts.cpu().numpy(), groups, device=device, system_mol=mols)
     pos = values.reshape(-1).clone()
     energies, statuses, _ = batch.minimize(pos, max_iters=max_iters, grad_tol=grad_tol, scale_grads=True, stream=stream)
     return Device3DResult(pos.view(-1, 3), atom_starts, conformers.mol_indices, conformers.conf_indices,

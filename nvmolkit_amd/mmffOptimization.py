@@ -14,7 +14,7 @@ from typing import Sequence
 import numpy as np
 import torch
 
-from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch, minimize_device_conformers
+from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch, MoleculeTermTables, minimize_device_conformers
 from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
 _LINEAR_MMFF_TYPES = frozenset({4, 53, 61})  # MMFFPROP.PAR rows with linh = 1 (CSP, =N=, NR%)
@@ -33,9 +33,17 @@ def optimize_flat(atom_starts, groups, positions: torch.Tensor, max_iters: int =
     return energies, statuses == 0
 
 
+def resident_tables(tables, device="cuda") -> MoleculeTermTables:
+    """Upload the per-molecule MMFF term tables once (see :class:`MoleculeTermTables`); pass the result to
+    :func:`optimize_device` instead of ``tables`` when the same molecules are optimised more than once, or to keep the
+    upload out of a timed region."""
+    return MoleculeTermTables(MMFF, tables, device)
+
+
 def optimize_device(tables, conformers: Device3DResult, max_iters: int = 200, grad_tol: float = 1e-4) -> Device3DResult:
     """MMFF-minimise the conformers of a :class:`Device3DResult` (e.g. ``embed_flat(..., output=DEVICE)``) on the GPU
-    they live on; ``tables[m]`` are the 7 MMFF term groups ``(idx, par)`` of input molecule m.  DEVICE in, DEVICE out
+    they live on; ``tables[m]`` are the 7 MMFF term groups ``(idx, par)`` of input molecule m, or the
+    :func:`resident_tables` of those molecules.  DEVICE in, DEVICE out
     (reference: MMFFOptimizeMoleculesConfs(..., output=DEVICE) fed by a ``deviceInput``)."""
     return minimize_device_conformers(MMFF, tables, conformers, max_iters, grad_tol)
 

@@ -15,7 +15,7 @@ from typing import Sequence
 import numpy as np
 import torch
 
-from nvmolkit_amd.forcefield import UFF, FlatForcefieldBatch, minimize_device_conformers
+from nvmolkit_amd.forcefield import UFF, FlatForcefieldBatch, MoleculeTermTables, minimize_device_conformers
 from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
 _TORSION_BOND_SMARTS = "[!$([D1]);!$([#1])]~[!$([D1]);!$([#1])]"  # RDKit DefaultTorsionBondSmarts
@@ -33,6 +33,11 @@ def optimize_flat(atom_starts, groups, positions: torch.Tensor, max_iters: int =
     batch = FlatForcefieldBatch(UFF, atom_starts, groups, device=positions.device, system_mol=system_mol)
     energies, statuses, _ = batch.minimize(positions, max_iters=max_iters, grad_tol=grad_tol, scale_grads=True)
     return energies, statuses == 0
+
+
+def resident_tables(tables, device="cuda") -> MoleculeTermTables:
+    """Upload the per-molecule UFF term tables once; pass the result to :func:`optimize_device` instead of ``tables``."""
+    return MoleculeTermTables(UFF, tables, device)
 
 
 def optimize_device(tables, conformers: Device3DResult, max_iters: int = 1000, grad_tol: float = 1e-4) -> Device3DResult:

@@ -158,3 +158,23 @@ def test_rdkit_conformer_driver_on_duck_typed_molecules(kind):
             assert e_oracle == pytest.approx(energies[mi][k], rel=1e-9, abs=1e-9)
     with pytest.raises(ValueError, match="targetGpu"):
         optimize_rdkit_conformers(kind, mols, flatten, 10, 1e-4, HardwareOptions(gpuIds=[0]), CoordinateOutput.DEVICE, 3)
+
+
+def test_resident_term_tables_give_the_same_minimisation():
+    """MoleculeTermTables (tables uploaded and pair-ordered once) against per-call upload: same bits."""
+    from nvmolkit_amd import mmffOptimization, synthetic
+    from nvmolkit_amd.embedMolecules import FlatMolecule, FlatMoleculeSet, embed_flat
+    from nvmolkit_amd.types import CoordinateOutput
+
+    lib = synthetic.druglike_library(12, seed=21, mean_atoms=30, processes=1)
+    tables = [m["mmff"] for m in lib]
+    dev = embed_flat(FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in lib]), confs_per_molecule=3, max_iterations=10, seed=2,
+                     output=CoordinateOutput.DEVICE)
+    a = mmffOptimization.optimize_device(tables, dev, max_iters=60)
+    resident = mmffOptimization.resident_tables(tables)
+    b = mmffOptimization.optimize_device(resident, dev, max_iters=60)
+    c = mmffOptimization.optimize_device(resident, dev, max_iters=60)      # and again from the same resident tables
+    assert torch.equal(a.values.torch(), b.values.torch()) and torch.equal(a.energies.torch(), b.energies.torch())
+    assert torch.equal(b.values.torch(), c.values.torch())
+    with pytest.raises(ValueError, match="expected term tables"):
+        mmffOptimization.optimize_device(mmffOptimization.resident_tables(tables[:5]), dev)
