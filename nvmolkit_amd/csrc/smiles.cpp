@@ -186,10 +186,14 @@ struct Parser {
     } else {
       return fail();
     }
-    while (s[pos] == '@') {  // chirality: @, @@, @TH1, @AL2, @SP1.. @TB.. @OH.. — read and dropped
+    if (s[pos] == '@') {  // chirality: @, @@, or a class @TH1 @AL2 @SP3 @TB20 @OH30 — read and dropped
       ++pos;
-      if (s[pos] == 'T' || s[pos] == 'A' || s[pos] == 'S' || s[pos] == 'O') {
-        while (s[pos] >= 'A' && s[pos] <= 'Z') ++pos;
+      if (s[pos] == '@') {
+        ++pos;
+      } else if ((s[pos] == 'T' && (s[pos + 1] == 'H' || s[pos + 1] == 'B')) || (s[pos] == 'A' && s[pos + 1] == 'L') ||
+                 (s[pos] == 'S' && s[pos + 1] == 'P') || (s[pos] == 'O' && s[pos + 1] == 'H')) {
+        if (!(s[pos + 2] >= '0' && s[pos + 2] <= '9')) return fail();
+        pos += 2;
         while (s[pos] >= '0' && s[pos] <= '9') ++pos;
       }
     }
@@ -302,6 +306,7 @@ struct Parser {
       bd.order = order;
       g.bonds.push_back(bd);
     };
+    while (s[pos] == ' ' || s[pos] == '\t') ++pos;  // leading blanks; the SMILES ends at the next blank (name columns follow)
     while (s[pos] != '\0' && s[pos] != ' ' && s[pos] != '\t' && s[pos] != '\n' && s[pos] != '\r') {
       const char c = s[pos];
       if (c == '(') {

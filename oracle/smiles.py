@@ -33,7 +33,7 @@ ISOTOPE = {(1, 2): 2.01410, (1, 3): 3.01605, (6, 13): 13.00335, (6, 14): 14.0032
 TOKEN = re.compile(r"""
     (?P<bracket>\[[^\]]*\]) | (?P<organic>Cl|Br|[BCNOFPSI]|[bcnops]|\*) | (?P<bond>[-=#$:/\\]) |
     (?P<ring>%\d\d|\d) | (?P<open>\() | (?P<close>\)) | (?P<dot>\.)""", re.X)
-BRACKET = re.compile(r"^\[(?P<iso>\d+)?(?P<sym>se|as|te|si|[bcnops]|[A-Z][a-z]?|\*)(?P<chiral>@(?:@|[A-Z]{2}\d+)?)?"
+BRACKET = re.compile(r"^\[(?P<iso>\d+)?(?P<sym>se|as|te|si|[bcnops]|[A-Z][a-z]?|\*)(?P<chiral>@(?:@|(?:TH|AL|SP|TB|OH)\d+)?)?"
                      r"(?P<h>H\d?)?(?P<charge>\++\d*|-+\d*)?(?::\d+)?\]$")
 
 
@@ -69,6 +69,8 @@ def parse(smiles: str):
                     q = int(digits) if digits else len(c)
                     if c[0] == "-":
                         q = -q
+                if int(b["iso"] or 0) > 999 or abs(q) > 15:
+                    raise SmilesError(f"isotope or charge out of range in {text}")
                 atoms.append(dict(z=AROMATIC_SYMBOLS[sym] if aromatic else Z_OF[sym], charge=q, isotope=int(b["iso"] or 0),
                                   h_explicit=h, bracket=True, aromatic=aromatic))
             else:

@@ -219,3 +219,41 @@ def test_refused_smiles_raise_or_stay_zero():
     res = gen.GetFingerprintsFromSmiles(["CCO", "C1=CC=CC=C1", "c1ccccc1"], on_error="zero")
     fp = res.torch().cpu().numpy()
     assert res.smiles_status.tolist() == [0, 3, 0] and not fp[1].any() and fp[0].any() and fp[2].any()
+
+
+def test_mutated_smiles_never_crash_and_agree_with_the_oracle():
+    """Random edits of real SMILES (mostly invalid afterwards): the parser refuses or ingests exactly what the oracle does,
+    with the same graph, and survives everything."""
+    import random
+
+    rng = random.Random(7)
+    alphabet = "CNOPSFIclBrnos()[]=#-+123456789%@H/\\.:*$ "
+    muts = []
+    for _ in range(4000):
+        s = list(rng.choice(CHEMBL)[:100])
+        for _ in range(rng.randint(1, 4)):
+            op, pos = rng.random(), rng.randrange(len(s) + 1)
+            if op < 0.4 and s:
+                s[min(pos, len(s) - 1)] = rng.choice(alphabet)
+            elif op < 0.7:
+                s.insert(pos, rng.choice(alphabet))
+            elif s:
+                del s[min(pos, len(s) - 1)]
+        muts.append("".join(s))
+    muts += ["", "[", "]", "[]", "[C", "C]", "%", "%1", "C%1", "((", "C((C))", "[12345C]", "[C" + "+" * 20 + "]", "[CH999]", "C" * 5000,
+             "C1CC1C1CC1" * 50, "[*]", "*", "[C@O]", "[C@TH]", "[C@TH1](F)(Cl)(Br)I", " CCO", "CCO name", "C=#C", "C..C", ".C", "C."]
+    got = SmilesSet(muts)
+    n_ok = 0
+    for i, m in enumerate(muts):
+        try:
+            atoms, bonds = osmi.molecule(m)
+            oracle_ok = True
+        except osmi.SmilesError:
+            oracle_ok = False
+        st = int(got.status[i])
+        assert oracle_ok == (st not in (1, 2)), (m, st)        # syntax and valence refusals coincide
+        if oracle_ok and st == 0:
+            ga, gb = got.graph(i)
+            assert np.array_equal(ga, atoms) and np.array_equal(gb, bonds), m
+            n_ok += 1
+    assert n_ok > 100
