@@ -181,8 +181,8 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* sA  = smem;
   char* sB  = smem + TM * C::ROWBYTES;
-  int*  pcA = reinterpret_cast<int*>(smem + STAGE);
-  int*  pcB = pcA + TM;
+  float* pcA = reinterpret_cast<float*>(smem + STAGE);  // popcounts as the f32 values the epilogue works with
+  float* pcB = pcA + TM;
 
   // Workgroup -> tile map: blockIdx.y walks 64 x 64-tile supertiles, blockIdx.x walks a supertile with
   // tile_n fastest.  Inside a supertile both operand blocks (8 MB each) stay in L2 / Infinity Cache, so only
@@ -205,9 +205,12 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
   const int64_t rowB0 = static_cast<int64_t>(tile_n) * TN;
 
   if (tid < TM) {
-    pcA[tid] = popA[rowA0 + tid];
+    // Tanimoto: an empty row gets 0.5 instead of 0, so that the union pa + pb - c is never 0 and the epilogue needs no
+    // per-element clamp: c is 0 whenever a popcount is 0, and 0 / u is exactly 0 for every u > 0
+    const float pa = static_cast<float>(popA[rowA0 + tid]);
+    pcA[tid]       = METRIC == NVMK_METRIC_TANIMOTO ? fmaxf(pa, 0.5f) : pa;
   } else if (tid - TM < TN) {
-    pcB[tid - TM] = popB[rowB0 + tid - TM];
+    pcB[tid - TM] = static_cast<float>(popB[rowB0 + tid - TM]);
   }
   // Wave priority by phase: a workgroup in its main loop (DMA issue, ds_read, MFMA) goes before co-resident workgroups
   // that are converting and storing, which have plenty of independent work to hide behind (+0.8 % measured).
@@ -267,15 +270,14 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
   // popcounts and the f32 accumulators are exact integers < 2^24, so the union is formed in f32 (no int round trip)
   auto value = [&](const float c, const float pav, const float pbv) -> double {
     if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-      const float u = pav + pbv - c;
-      return ratio_by_newton_f(c, fmaxf(u, 1.0f));
+      return ratio_by_newton_f(c, pav + pbv - c);  // u >= 0.5 (see pcA)
     } else {
       const double denom = sqrt(static_cast<double>(pav) * static_cast<double>(pbv));
       return (c == 0.0f || denom == 0.0) ? 0.0 : static_cast<double>(c) / denom;
     }
   };
-  const float pb0 = static_cast<float>(pcB[wn * 64 + col0]);
-  const float pb1 = static_cast<float>(pcB[wn * 64 + col0 + 1]);
+  const float pb0 = pcB[wn * 64 + col0];
+  const float pb1 = pcB[wn * 64 + col0 + 1];
   typedef double d2_t __attribute__((ext_vector_type(2)));
   // Interior tiles: 32 sixteen-byte stores per lane, each wave instruction writing two 512-byte row segments (rows i and
   // i + 4), branch-free so that the divisions and stores of a lane interleave.  Nontemporal: the 8 B/pair output stream
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int   il0    = mi * 32 + (r & 3) + 8 * (r >> 2);  // + 4 hi: this lane's row inside the wave tile
-        const float pav    = static_cast<float>(pcA[wm * 64 + il0 + 4 * static_cast<int>(hi)]);
+        const float pav    = pcA[wm * 64 + il0 + 4 * static_cast<int>(hi)];
         char*       rowOut = waveOut + static_cast<int64_t>(il0) * ld * 8;
         d2_t        v;
         v.x = value(acc[mi][0][r], pav, pb0);
