@@ -408,8 +408,17 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
     sm = sidx / superN;
     sn = sidx - sm * superN;
   }
-  const unsigned tile_m = sm * superH + blockIdx.x / superW;
-  const unsigned tile_n = sn * superW + (blockIdx.x - (blockIdx.x / superW) * superW);
+  unsigned tile_m, tile_n;
+  if (superH == 64u && superW == 64u) {
+    // XCD-aware walk of a full supertile, as in the dense kernel: workgroup b runs on XCD b % 8, which gets its own
+    // 32 x 16-tile sub-block, so that its L2 keeps 16 column tiles and one row tile instead of sharing all 64 row tiles
+    const unsigned xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+    tile_m = sm * 64u + (xcd >> 2) * 32u + (local >> 4);
+    tile_n = sn * 64u + (xcd & 3u) * 16u + (local & 15u);
+  } else {
+    tile_m = sm * superH + blockIdx.x / superW;
+    tile_n = sn * superW + (blockIdx.x - (blockIdx.x / superW) * superW);
+  }
   if (tile_m >= tilesM || tile_n >= tilesN) return;
   if (symmetric && tile_n < tile_m) return;
   if (tileRowHi != 0u && (tile_m < tileRowLo || tile_m >= tileRowHi)) return;  // another shard's tile rows
