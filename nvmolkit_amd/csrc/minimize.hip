@@ -1318,6 +1318,28 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   std::stable_sort(order.begin(), order.end(), [&](const int32_t x, const int32_t y) {
     return h_atom_starts[x + 1] - h_atom_starts[x] > h_atom_starts[y + 1] - h_atom_starts[y];
   });
+  // XCD-aware hand-out: workgroup p runs on XCD p % 8 and every XCD has its own L2.  Conformers of one molecule are
+  // neighbours in `order` (same size, stable sort) and share their term tables (system_mol), so a run of kXcdGroup
+  // consecutive systems goes to ONE XCD: its L2 then holds a handful of molecules' tables instead of one per resident
+  // workgroup.  Chunks of 8 * kXcdGroup systems keep the sizes balanced over the XCDs.  NVMK_BFGS_XCD_GROUP=1: plain order.
+  {
+    static const int kXcdGroup = [] {
+      const char* e = std::getenv("NVMK_BFGS_XCD_GROUP");
+      const int   v = e != nullptr ? std::atoi(e) : 16;
+      return v >= 1 ? v : 16;
+    }();
+    const int64_t n = b.nSystems, chunk = 8LL * kXcdGroup;
+    if (kXcdGroup > 1 && b.sysMol != nullptr && n >= 2 * chunk) {
+      std::vector<int32_t> grouped(order.size());
+      const int64_t        full = n / chunk * chunk;  // the ragged tail keeps the plain order
+      for (int64_t p = 0; p < full; ++p) {
+        const int64_t c = p / chunk, q = p % chunk;
+        grouped[static_cast<size_t>(p)] = order[static_cast<size_t>(c * chunk + (q % 8) * kXcdGroup + q / 8)];
+      }
+      for (int64_t p = full; p < n; ++p) grouped[static_cast<size_t>(p)] = order[static_cast<size_t>(p)];
+      order.swap(grouped);
+    }
+  }
   NVMK_HIP_CHECK(orderMem.alloc(order.size() * sizeof(int32_t), stream));
   NVMK_HIP_CHECK(hipMemcpyAsync(orderMem.ptr, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   static const bool profile = [] {
