@@ -208,7 +208,7 @@ template <int NCH> __device__ __forceinline__ void hess_chunk_state(HessChunk (&
 
 // The pass: diagonal in `diag` (LDS), rows [0, Rl) of the strict lower triangle from LDS (Hl), rows [Rl, n) from HBM (Hg,
 // whose first element is row Rl's).  `part` = row sums [n] then NW slabs [n] of mirrored-entry sums (all written here).
-// PREFETCH: the HBM rows' next group is requested one group ahead (more VGPRs; off in the three-workgroups-per-CU kernels).
+// PREFETCH: the HBM rows' next group is requested one group ahead (more VGPRs; the microbenchmark can switch it off).
 // Must be entered by the whole workgroup after a barrier (it starts by writing the row sums of the diagonal).
 template <bool PREFETCH = true>
 __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __restrict__ Hl, double* __restrict__ Hg, const int Rl,
