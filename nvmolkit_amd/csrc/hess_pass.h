@@ -43,6 +43,8 @@ constexpr int NW = NT / 64;  // waves per workgroup
 __host__ __device__ __forceinline__ int64_t hess_row_offset(const int64_t r) {  // rows 0..r-1 (row k: k entries, padded to even)
   return (r * r) >> 1;
 }
+// the same inside one system (n < 46341): 32-bit scalar arithmetic in the pass's inner loop
+__host__ __device__ __forceinline__ int hess_row_offset32(const int r) { return (r * r) >> 1; }
 
 // Rows [0, Rl) of the packed triangle live in LDS behind the vectors (as many as the launch's LDS budget holds), rows Rl..
 // stream from HBM.
@@ -85,8 +87,18 @@ __device__ __forceinline__ double wave_sum4_transposed(const double (&rs)[4], co
   double       x  = (up ? cd : ab) + dpp_mov<0x4e>(up ? ab : cd);                // lane & 3 = row: sum over the quad
   x += dpp_mov<0x124>(x);  // row_ror 4  (keeps lane & 3)
   x += dpp_mov<0x128>(x);  // row_ror 8: sum over the row of 16 lanes
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 32);
+  // the two cross-row steps on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap of a register with its own copy) — an
+  // LDS-crossbar shuffle here was two dependent ~100-cycle round trips per group of four rows
+  {
+    const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+    x            = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);  // x + (lane ^ 16)
+  }
+  {
+    const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+    x            = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);  // x + (lane ^ 32)
+  }
   return x;
 }
 
@@ -109,8 +121,8 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
                                            const double* __restrict__ uu, const double* __restrict__ g, double* __restrict__ rowsum,
                                            double (&col)[NCH][2]) {
   constexpr int RU   = 4;
-  const int     base = static_cast<int>(hess_row_offset(rBase));
-  auto row_ptr = [&](const int r) -> double* { return H + (static_cast<int>(hess_row_offset(r)) - base); };
+  const int     base = hess_row_offset32(rBase);
+  auto row_ptr = [&](const int r) -> double* { return H + (hess_row_offset32(r) - base); };
   auto load_group = [&](const int r0, double2 (&dst)[RU][NCH]) {
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
