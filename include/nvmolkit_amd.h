@@ -207,6 +207,11 @@ int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uint32_t* d_bo
  *     g2 stretch-bend idx(1,2,3) par(theta0, r0ij, r0kj, kbaIJK, kbaKJI)   g3 out-of-plane idx(1..4) par(koop)
  *     g4 torsion idx(1..4) par(V1, V2, V3)          g5 vdW idx(i, j) par(R*, eps)
  *     g6 electrostatic idx(i, j) par(qi*qj/D, dielModel, is1_4)
+ *     g11 (optional) merged non-bonded pairs idx(i, j) par(R*, eps, qi*qj/D, dielModel, is1_4): one row per vdW pair with
+ *         the electrostatic parameters of the same pair (0 charge term where there is none).  When present and the mask
+ *         enables both g5 and g6, it is evaluated INSTEAD of them: one distance, one set of force accumulations per pair
+ *         (the Python layer builds it on the device whenever every g6 pair is also a g5 pair, which is how RDKit and the
+ *         reference's builder emit them: rdkit_extensions/mmff_flattened_builder.cpp addVdW / addEle)
  *   NVMK_FF_UFF  (src/forcefields/uff.h:27-67; term math src/forcefields/uff_kernels_device.cuh:37-580)
  *     g0 bond idx(i, j) par(restLen, k)             g1 angle idx(1,2,3) par(theta0, k, order, C0, C1, C2)
  *     g2 torsion idx(1..4) par(k, order, cosTerm)   g3 inversion idx(1..4) par(k, C0, C1, C2)

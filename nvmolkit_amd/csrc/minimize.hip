@@ -389,7 +389,8 @@ __device__ __forceinline__ int group_rotation(const EvalContext& c, const int gi
   return rot & (NT - 1);
 }
 template <int KIND> struct GroupCount {
-  static constexpr int value = KIND == NVMK_FF_DG ? 3 : KIND == NVMK_FF_ETK ? 6 : KIND == NVMK_FF_MMFF ? 7 : KIND == KIND_MMFF_C ? 11
+  // MMFF: 7 term groups, 4 optional constraint groups (7..10), the optional merged non-bonded group (11)
+  static constexpr int value = KIND == NVMK_FF_DG ? 3 : KIND == NVMK_FF_ETK ? 6 : KIND == NVMK_FF_MMFF ? 12 : KIND == KIND_MMFF_C ? 12
                                : KIND == NVMK_FF_UFF ? 5 : KIND == KIND_UFF_C ? 9 : 0;
 };
 template <int KIND> __device__ __forceinline__ EvalContext eval_context(const Batch& b, const int sys) {
@@ -622,8 +623,10 @@ __device__ __forceinline__ double system_eval(const Batch& b, const EvalContext&
     auto t3 = term_batch<4, 1, 1>(b.g[3], ctx.r[3], group_rotation(ctx, 3));
     auto t4 = term_batch<4, 3, 1>(b.g[4], ctx.r[4], group_rotation(ctx, 4));
     auto t0 = term_batch<2, 2, 1>(b.g[0], ctx.r[0], group_rotation(ctx, 0));
-    auto t5 = term_batch<2, 2, PU>(b.g[5], ctx.r[5], group_rotation(ctx, 5));
-    auto t6 = term_batch<2, 3, PU>(b.g[6], ctx.r[6], group_rotation(ctx, 6));
+    // merged non-bonded pairs (the normal case: groups 5 and 6 are then empty).  The separate tables are only walked when
+    // they could not be merged or a mask selects one of them; their batches are loaded where they are used, not up here,
+    // so that the common case does not hold registers for three pair batches
+    auto t11 = term_batch<2, 5, PU>(b.g[11], ctx.r[11], group_rotation(ctx, 11));
     // angle bend: theta0, ka, isLinear
     run_terms(b.g[1], t1, [&](const int, const int* a, const double* p) {
       if constexpr (GRAD) {
@@ -708,12 +711,25 @@ __device__ __forceinline__ double system_eval(const Batch& b, const EvalContext&
       radial(a, [&](const double r, double& et, double& dE) { mmff_bond(r, p[0], p[1], et, dE); });
     });
     // van der Waals: R*, eps
+    auto t5 = term_batch<2, 2, PU>(b.g[5], ctx.r[5], group_rotation(ctx, 5));
     run_terms(b.g[5], t5, [&](const int, const int* a, const double* p) {
       radial(a, [&](const double r, double& et, double& dE) { mmff_vdw(r, p[0], p[1], et, dE); });
     });
     // electrostatics: chargeTerm, dielModel, is1_4
+    auto t6 = term_batch<2, 3, PU>(b.g[6], ctx.r[6], group_rotation(ctx, 6));
     run_terms(b.g[6], t6, [&](const int, const int* a, const double* p) {
       radial(a, [&](const double r, double& et, double& dE) { mmff_ele(r, p[0], static_cast<int>(p[1]), p[2] != 0.0, et, dE); });
+    });
+    // merged non-bonded pairs: R*, eps, chargeTerm, dielModel, is1_4 — van der Waals and electrostatics of a pair share the
+    // distance, its square root, the position reads and the six atomic adds (the two lists name the same pairs)
+    run_terms(b.g[11], t11, [&](const int, const int* a, const double* p) {
+      radial(a, [&](const double r, double& et, double& dE) {
+        double ev, dv, ee, de;
+        mmff_vdw(r, p[0], p[1], ev, dv);
+        mmff_ele(r, p[2], static_cast<int>(p[3]), p[4] != 0.0, ee, de);
+        et = ev + ee;
+        dE = dv + de;
+      });
     });
     if constexpr (KIND == KIND_MMFF_C) e += constraint_terms<DIM, GRAD>(b, 7, ms, pos, grad);
     return e;
@@ -1199,6 +1215,12 @@ int to_batch(const nvmk_ff_batch* in, Batch& out) {
     for (int g = first; g < first + 4; ++g) {
       if (in->groups[g].starts != nullptr) out.kind = (in->kind == NVMK_FF_MMFF) ? KIND_MMFF_C : KIND_UFF_C;
     }
+  }
+  if (in->kind == NVMK_FF_MMFF) {
+    // groups[11] = the merged non-bonded table (optional): it replaces groups 5 and 6 when BOTH are enabled; a mask that
+    // selects only one of them keeps the separate tables
+    const bool merged = in->groups[11].starts != nullptr && (out.groupMask & 0x60u) == 0x60u;
+    out.groupMask     = merged ? ((out.groupMask & ~0x60u) | 0x800u) : (out.groupMask & ~0x800u);
   }
   for (int g = 0; g < 12; ++g) {
     out.g[g] = {in->groups[g].starts, in->groups[g].idx, in->groups[g].par};

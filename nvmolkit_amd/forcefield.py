@@ -62,6 +62,58 @@ def diagonal_pair_order(starts: torch.Tensor, idx: torch.Tensor, par: torch.Tens
     return idx[perm].contiguous(), par[perm].contiguous()
 
 
+def mmff_merge_enabled() -> bool:
+    """``NVMK_MMFF_MERGE=0`` keeps van der Waals and electrostatics as separate tables (A/B switch)."""
+    return os.environ.get("NVMK_MMFF_MERGE", "1") != "0"
+
+
+def merge_mmff_nonbonded(vdw, ele):
+    """Device-side merge of the MMFF van der Waals group ``(starts, idx, par(R*, eps))`` and electrostatic group
+    ``(starts, idx, par(chargeTerm, dielModel, is1_4))`` into one table ``(starts, idx, par(R*, eps, chargeTerm, dielModel,
+    is1_4))`` with one row per van der Waals pair.  Returns ``None`` when the lists cannot be merged (an electrostatic pair
+    without a van der Waals pair, or a pair listed twice): the kernels then keep walking the two tables."""
+    s5, i5, p5 = vdw
+    s6, i6, p6 = ele
+    n5, n6 = i5.shape[0], i6.shape[0]
+    if n5 == 0 or s5.numel() != s6.numel():
+        return None
+    dev = i5.device
+
+    def keys(starts, idx):
+        counts = (starts[1:] - starts[:-1]).to(torch.int64)
+        seg = torch.repeat_interleave(torch.arange(counts.numel(), device=dev, dtype=torch.int64), counts, output_size=idx.shape[0])
+        a, b = idx[:, 0].to(torch.int64), idx[:, 1].to(torch.int64)
+        return (seg << 40) | (torch.minimum(a, b) << 20) | torch.maximum(a, b)
+
+    k5 = keys(s5, i5)
+    order = torch.argsort(k5, stable=True)
+    k5s = k5[order]
+    if n5 > 1 and bool((k5s[1:] == k5s[:-1]).any()):
+        return None
+    par = torch.zeros((n5, 5), dtype=torch.float64, device=dev)
+    par[:, 0:2] = p5[order]
+    if n6:
+        k6 = keys(s6, i6)
+        pos = torch.searchsorted(k5s, k6)
+        if bool((pos >= n5).any()) or bool((k5s[pos.clamp(max=n5 - 1)] != k6).any()) or torch.unique(k6).numel() != n6:
+            return None
+        par[pos, 2:5] = p6
+    return s5, i5[order].contiguous(), par
+
+
+def _merged_and_ordered(vdw, ele):
+    merged = merge_mmff_nonbonded(vdw, ele)
+    if merged is not None and pair_order_enabled():
+        merged = (merged[0],) + tuple(diagonal_pair_order(*merged))
+    return merged
+
+
+class _GroupList(list):
+    """The resident term groups of a MoleculeTermTables, plus what was derived from them once."""
+
+    merged_nonbonded = None
+
+
 class FlatForcefieldBatch:
     """`n_systems` independent systems with their term tables resident on one GPU.
 
@@ -108,6 +160,7 @@ class FlatForcefieldBatch:
             self._keep.append(sm)
             self._c.system_mol = sm.data_ptr()
             n_rows = None  # validated against the tables below
+        resident_nonbonded = {}
         for g, ((n_idx, n_par), (starts, idx, par)) in enumerate(zip(layout, groups)):
             if isinstance(starts, torch.Tensor):  # already resident (MoleculeTermTables): validated and ordered there
                 t = [starts, idx, par]
@@ -133,6 +186,17 @@ class FlatForcefieldBatch:
             self._c.groups[g].starts = t[0].data_ptr()
             self._c.groups[g].idx = t[1].data_ptr() if t[1].numel() else None
             self._c.groups[g].par = t[2].data_ptr() if t[2].numel() else None
+            if kind == MMFF and g in (5, 6):
+                resident_nonbonded[g] = tuple(t)
+        if kind == MMFF and len(resident_nonbonded) == 2 and mmff_merge_enabled():
+            merged = getattr(groups, "merged_nonbonded", False)  # MoleculeTermTables carries it (None = cannot be merged)
+            if merged is False:
+                merged = _merged_and_ordered(resident_nonbonded[5], resident_nonbonded[6])
+            if merged is not None:
+                self._keep.extend(merged)
+                self._c.groups[11].starts = merged[0].data_ptr()
+                self._c.groups[11].idx = merged[1].data_ptr()
+                self._c.groups[11].par = merged[2].data_ptr()
 
     @property
     def n_atoms_total(self) -> int:
@@ -212,7 +276,7 @@ class MoleculeTermTables:
         if self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.n_mols = len(tables)
-        self.groups = []
+        self.groups = _GroupList()
         with torch.cuda.device(self.device):
             for g, (starts, idx, par) in enumerate(stack_molecule_tables(kind, tables)):
                 t = [torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int32)).to(self.device),
@@ -221,6 +285,8 @@ class MoleculeTermTables:
                 if g in PAIR_ORDER_GROUPS[kind] and pair_order_enabled():
                     t[1], t[2] = diagonal_pair_order(t[0], t[1], t[2])
                 self.groups.append(tuple(t))
+            if kind == MMFF and mmff_merge_enabled():
+                self.groups.merged_nonbonded = _merged_and_ordered(self.groups[5], self.groups[6])
 
 
 def stack_molecule_tables(kind: int, tables: Sequence[Sequence[tuple]]):

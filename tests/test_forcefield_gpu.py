@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from nvmolkit_amd.forcefield import DG, ETK, MMFF, QUARTIC, UFF, FlatForcefieldBatch
+from nvmolkit_amd.forcefield import DG, ETK, MMFF, QUARTIC, UFF, FlatForcefieldBatch, stack_molecule_tables
 from oracle import ff as off
 from tests import util
 
@@ -165,3 +165,29 @@ def test_argument_validation():
         batch.compute_energy(pos.float())
     with pytest.raises(TypeError):
         batch.compute_energy(pos, stream=3)
+
+
+def test_mmff_merged_nonbonded_table_equals_separate_tables(monkeypatch):
+    """The merged van der Waals + electrostatics table (one distance and one force accumulation per pair) against the two
+    separate tables: same energy and gradient up to the summation order; a mask that enables only one of the two groups
+    keeps using the separate tables."""
+    from nvmolkit_amd import synthetic
+
+    lib = synthetic.druglike_library(6, seed=4, mean_atoms=40, processes=1)
+    tables = [m["mmff"] for m in lib]
+    groups = stack_molecule_tables(MMFF, tables)
+    n_at = np.array([m["embed"]["n_atoms"] for m in lib])
+    a_s = np.concatenate([[0], np.cumsum(n_at)]).astype(np.int32)
+    pos = torch.from_numpy(np.concatenate([m["ref"].reshape(-1) for m in lib]) + 0.05 * np.random.default_rng(0).standard_normal(3 * n_at.sum())).cuda()
+    merged = FlatForcefieldBatch(MMFF, a_s, groups)
+    assert merged._c.groups[11].starts is not None
+    monkeypatch.setenv("NVMK_MMFF_MERGE", "0")
+    separate = FlatForcefieldBatch(MMFF, a_s, groups)
+    assert separate._c.groups[11].starts is None
+    e_m, e_s = merged.compute_energy(pos), separate.compute_energy(pos)
+    g_m, g_s = merged.compute_gradient(pos), separate.compute_gradient(pos)
+    assert torch.allclose(e_m, e_s, rtol=1e-12, atol=1e-10) and torch.allclose(g_m, g_s, rtol=1e-11, atol=1e-10)
+    for mask in (0x20, 0x40, 0x3F):          # van der Waals only, electrostatics only, neither
+        merged._c.group_mask = separate._c.group_mask = mask
+        assert torch.allclose(merged.compute_energy(pos), separate.compute_energy(pos), rtol=1e-12, atol=1e-10)
+    merged._c.group_mask = separate._c.group_mask = 0
