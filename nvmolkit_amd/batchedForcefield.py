@@ -22,7 +22,7 @@ import torch
 from nvmolkit_amd.forcefield import CONSTRAINT_LAYOUT, GROUP_LAYOUT, MMFF, UFF, FlatForcefieldBatch
 from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
-__all__ = ["FlatBatchedForcefield", "MMFFBatchedForcefield", "UFFBatchedForcefield"]
+__all__ = ["FlatBatchedForcefield", "MMFFBatchedForcefield", "UFFBatchedForcefield", "MMFFBatchElement", "UFFBatchElement"]
 
 
 @dataclass
@@ -169,6 +169,14 @@ class _BatchElement:
         self._parent._dirty = True
 
 
+class MMFFBatchElement(_BatchElement):
+    """Per-molecule view of an MMFF batch: ``ff[i]`` (reference: nvmolkit/batchedForcefield.py:291-306)."""
+
+
+class UFFBatchElement(_BatchElement):
+    """Per-molecule view of a UFF batch: ``ff[i]`` (reference: nvmolkit/batchedForcefield.py:309-321)."""
+
+
 class FlatBatchedForcefield:
     """A batch of molecules, each with its term tables and conformer coordinates, as ONE force-field object.
 
@@ -184,6 +192,7 @@ class FlatBatchedForcefield:
         if len(tables) != len(conformers):
             raise ValueError("one term table and one conformer array per molecule")
         self.kind = kind
+        self._element_type = MMFFBatchElement if kind == MMFF else UFFBatchElement
         self.device = torch.device(device)
         self._tables = list(tables)
         self._conformers = [np.ascontiguousarray(c, dtype=np.float64).reshape(len(c), -1, 3) for c in conformers]
@@ -205,7 +214,7 @@ class FlatBatchedForcefield:
     def __getitem__(self, idx: int) -> _BatchElement:
         if idx < 0 or idx >= self.num_molecules:
             raise IndexError(f"Batch element index {idx} out of range")
-        return _BatchElement(self, idx)
+        return self._element_type(self, idx)
 
     def _validate_atom_indices(self, batch_idx: int, *indices: int) -> None:
         num_atoms = self._n_atoms[batch_idx]
