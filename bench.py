@@ -501,20 +501,35 @@ def main() -> None:
         # The other half of BASELINE.json's metric line (Butina at threshold 0.7 = cutoff 0.3; mols/s of ETKDG + MMFF),
         # measured after and outside the timed region of the headline number, bounded to a few seconds.
         secondary = {}
+
+        def guarded(name, fn, *fn_args):
+            # a secondary block that fails is reported under its name; the headline line is still printed
+            try:
+                secondary[name] = fn(*fn_args)
+            except Exception as exc:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                secondary[name] = {"error": f"{type(exc).__name__}: {exc}"}
+
         if world == 1 and args.butina_n > 0:
-            secondary["fused_butina"] = butina_block(args.butina_n, words, device, args.cpu_seconds)
+            guarded("fused_butina", butina_block, args.butina_n, words, device, args.cpu_seconds)
         if world == 1 and args.cfg1:
             out = None  # release the 65 GB output block first
             torch.cuda.empty_cache()
-            secondary["cfg1_smiles_to_similarity"] = cfg1_block(device, args.cpu_seconds)
+            guarded("cfg1_smiles_to_similarity", cfg1_block, device, args.cpu_seconds)
     else:
         secondary = {}
     if args.conformer_mols > 0:  # every rank takes part (configs[3]: molecules sharded, no collective on the data path)
         out = queries = ref_gathered = ref_shard = ws_q = ws_r = None  # noqa: F841  (release ~70 GB before the next block)
         torch.cuda.empty_cache()
-        block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds)
-        if rank == 0:
-            secondary["conformers"] = block
+        if world == 1:
+            guarded("conformers", conformer_block, args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank,
+                    args.cpu_seconds)
+        else:  # ranks meet in collectives inside the block: an exception on one rank must end the job, not hang the others
+            block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds)
+            if rank == 0:
+                secondary["conformers"] = block
     if rank == 0:
         if secondary:
             result["secondary"] = secondary
