@@ -416,6 +416,11 @@ int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, co
 #define NVMK_SMILES_NEEDS_AROMATICITY 3  /* Kekule-form ring RDKit would perceive as aromatic */
 #define NVMK_SMILES_TOO_MANY_BONDS 4     /* more than 8 bonds on one atom (kMaxBondsPerAtom of the reference) */
 int nvmk_smiles_parse(const char* const* smiles, int64_t n_mols, int n_threads, void** handle);
+/* flags = NVMK_SMILES_PERCEIVE_AROMATICITY: Kekule-form rings are perceived with RDKit's default aromaticity model (electron
+ * donation rules and fused-ring unions of the RDKit Book; checked against the aromaticity RDKit recorded in the reference's
+ * ChEMBL SMILES) instead of being refused.  Conjugated macrocycles (porphyrins) are refused either way. */
+#define NVMK_SMILES_PERCEIVE_AROMATICITY 1u
+int nvmk_smiles_parse_flags(const char* const* smiles, int64_t n_mols, int n_threads, unsigned flags, void** handle);
 int nvmk_smiles_free(void* handle);
 int nvmk_smiles_counts(const void* handle, int32_t* n_atoms, int32_t* n_bonds, int8_t* status);
 int nvmk_smiles_graph(const void* handle, int64_t mol, int32_t* atom_fields, int32_t* bond_fields);

@@ -75,6 +75,7 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_conformer_prune": (_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
     "nvmk_butina_dense": (_int, [_vp, _vp, _i64, ctypes.c_double, _int, _vp, _vp, ctypes.POINTER(_i64), _vp]),
     "nvmk_smiles_parse": (_int, [ctypes.POINTER(ctypes.c_char_p), _i64, _int, ctypes.POINTER(ctypes.c_void_p)]),
+    "nvmk_smiles_parse_flags": (_int, [ctypes.POINTER(ctypes.c_char_p), _i64, _int, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]),
     "nvmk_smiles_free": (_int, [_vp]),
     "nvmk_smiles_counts": (_int, [_vp, _vp, _vp, _vp]),
     "nvmk_smiles_graph": (_int, [_vp, _i64, _vp, _vp]),

@@ -17,9 +17,17 @@
 //     satisfies Hueckel's rule is therefore REFUSED (status NVMK_SMILES_NEEDS_AROMATICITY) instead of being
 //     fingerprinted with bond types RDKit would not use.  Valences RDKit's sanitisation rejects (or rewrites, like
 //     five-valent nitro groups) are refused as well.
-// Parity against RDKit cannot be pinned in this image; the independent Python restatement oracle/smiles.py, the
-// element-count known answers of the reference's tests/test_morgan_fingerprint_ref.cpp:44-69 and hand-computed invariants
-// are the checks (tests/test_smiles_ingestion.py).
+//   * OPT-IN PERCEPTION (nvmk_smiles_parse_flags, NVMK_SMILES_PERCEIVE_AROMATICITY): RDKit's default aromaticity model
+//     restated from the RDKit Book - candidate rings are the smallest rings through each ring bond whose atoms can all
+//     donate, electrons per atom from its unsaturation / lone pair / exocyclic double bond, 4n+2 over single rings and
+//     over unions of up to six fused rings, whose outer envelope is what gets marked.  The restatement is checked on the
+//     aromaticity RDKit itself recorded: every aromatic ChEMBL SMILES of tests/golden is Kekulised by the oracle, read
+//     back here and must come out with the aromatic atoms and bonds RDKit wrote (tests/test_smiles_aromaticity.py; 8864
+//     molecules).  Conjugated macrocycles (porphyrins) and fused systems of more than 8 candidate rings (fullerene
+//     fragments), where RDKit's result depends on its ring-enumeration order, are refused in this mode too.
+// Parity against RDKit's parser cannot be pinned in this image; the independent Python restatement oracle/smiles.py, the
+// element-count known answers of the reference's tests/test_morgan_fingerprint_ref.cpp:44-69, hand-computed invariants
+// and the ChEMBL round trip above are the checks (tests/test_smiles_ingestion.py, tests/test_smiles_aromaticity.py).
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -47,6 +55,7 @@ enum Status : int8_t {
 
 // RDKit bond type values (Bond::BondType): what the Morgan bond invariant is (morgan_fingerprint_common.cpp:100)
 constexpr uint8_t kSingle = 1, kDouble = 2, kTriple = 3, kQuadruple = 4, kAromatic = 12, kUnspecified = 0;
+constexpr uint8_t kDirectional = 200;  // parser only: '/' or '\\' was written; stored as kUnspecified
 
 struct Atom {
   uint8_t  z        = 0;
@@ -267,7 +276,8 @@ struct Parser {
 
   static uint8_t bond_of(const char c) {
     switch (c) {
-      case '-': case '/': case '\\': return kSingle;
+      case '-': return kSingle;
+      case '/': case '\\': return kDirectional;  // a direction, not an order: aromatic between aromatic ring atoms, else single
       case '=': return kDouble;
       case '#': return kTriple;
       case '$': return kQuadruple;
@@ -293,7 +303,7 @@ struct Parser {
       Bond bd;
       bd.a     = a;
       bd.b     = b;
-      bd.order = order;
+      bd.order = order == kDirectional ? kUnspecified : order;
       g.bonds.push_back(bd);
       return true;
     };
@@ -303,7 +313,7 @@ struct Parser {
       Bond bd;
       bd.a     = a;
       bd.b     = b;
-      bd.order = order;
+      bd.order = order == kDirectional ? kUnspecified : order;
       g.bonds.push_back(bd);
     };
     while (s[pos] == ' ' || s[pos] == '\t') ++pos;  // leading blanks; the SMILES ends at the next blank (name columns follow)
@@ -343,7 +353,12 @@ struct Parser {
           ring[label].order = havePending ? pending : kUnspecified;
         } else {
           uint8_t order = havePending ? pending : ring[label].order;
-          if (havePending && ring[label].order != kUnspecified && ring[label].order != pending) return fail();
+          auto plain = [](const uint8_t o) { return o == kDirectional ? kUnspecified : o; };
+          if (havePending && plain(ring[label].order) != kUnspecified && plain(pending) != kUnspecified &&
+              plain(ring[label].order) != plain(pending)) {
+            return fail();
+          }
+          if (plain(order) == kUnspecified) order = plain(ring[label].order) != kUnspecified ? ring[label].order : order;
           if (!add_bond(ring[label].atom, prev, order)) return fail();
           ring[label].atom = -1;
         }
@@ -524,85 +539,247 @@ bool assign_implicit_hydrogens(Graph& g) {
   return true;
 }
 
-// Would RDKit perceive an aromatic ring in the Kekule-form part of this molecule?  Conservative single-ring test:
-// the smallest ring through every non-aromatic ring double bond is examined; it counts as Hueckel-aromatic when every
-// member is sp2-like (a ring double bond, or a heteroatom / anion that donates a lone pair, or a carbon whose
-// exocyclic double bond goes to an electronegative atom and contributes no electron) and the electrons sum to 4k + 2.
-bool kekule_ring_looks_aromatic(const Graph& g) {
-  const int n = static_cast<int>(g.atoms.size());
-  std::vector<std::vector<std::pair<int, int>>> adj(static_cast<size_t>(n));  // (neighbour, bond)
+// ---- aromaticity of Kekule-form rings: RDKit's default model ------------------------------------------------------------
+// (RDKit Book, "Aromaticity"; the rules below were checked against RDKit's own perception as it is recorded in the
+// aromatic-form SMILES of the reference's ChEMBL files: tests/test_smiles_aromaticity.py turns 8864 such molecules into
+// Kekule forms and asks for the aromatic atoms and bonds back.)
+// Electrons a ring atom gives to an aromatic system, or -1 when it cannot take part: 1 through a ring double bond; through
+// an exocyclic double bond 0 when the partner is the more electronegative end (C=O, C=N, C=S take the electron) and 1
+// otherwise (C=C); 2 from a lone pair (three-coordinate N / P / As, [n-], two-coordinate O / S / Se / Te, three-coordinate
+// [s+], carbanion); 0 from an empty orbital (carbocation, three-coordinate boron).
+int outer_electrons(const int z) {
+  switch (z) {
+    case 1: return 1;
+    case 5: case 13: return 3;
+    case 6: case 14: case 32: return 4;
+    case 7: case 15: case 33: return 5;
+    case 8: case 16: case 34: case 52: return 6;
+    case 9: case 17: case 35: case 53: return 7;
+    default: return 0;
+  }
+}
+
+using Adjacency = std::vector<std::vector<std::pair<int, int>>>;  // per atom: (neighbour, bond)
+
+Adjacency adjacency_of(const Graph& g) {
+  Adjacency adj(g.atoms.size());
   for (size_t k = 0; k < g.bonds.size(); ++k) {
     adj[static_cast<size_t>(g.bonds[k].a)].push_back({g.bonds[k].b, static_cast<int>(k)});
     adj[static_cast<size_t>(g.bonds[k].b)].push_back({g.bonds[k].a, static_cast<int>(k)});
   }
-  for (size_t k0 = 0; k0 < g.bonds.size(); ++k0) {
-    const Bond& b0 = g.bonds[k0];
-    if (!b0.ring || b0.order != kDouble) continue;
-    // shortest path from b0.a to b0.b that avoids b0, over ring bonds: with b0 it is the smallest ring through b0
-    std::vector<int> from(static_cast<size_t>(n), -2), queue;
-    from[static_cast<size_t>(b0.a)] = -1;
-    queue.push_back(b0.a);
-    for (size_t q = 0; q < queue.size() && from[static_cast<size_t>(b0.b)] == -2; ++q) {
-      const int u = queue[q];
-      for (const auto& [v, k] : adj[static_cast<size_t>(u)]) {
-        if (static_cast<size_t>(k) == k0 || !g.bonds[static_cast<size_t>(k)].ring || from[static_cast<size_t>(v)] != -2) continue;
-        from[static_cast<size_t>(v)] = u;
-        queue.push_back(v);
-      }
-    }
-    if (from[static_cast<size_t>(b0.b)] == -2) continue;
-    std::vector<int> ringAtoms;
-    for (int v = b0.b; v != -1; v = from[static_cast<size_t>(v)]) ringAtoms.push_back(v);
-    if (ringAtoms.size() > 8) continue;
-    std::vector<char> inThis(static_cast<size_t>(n), 0);
-    for (const int v : ringAtoms) inThis[static_cast<size_t>(v)] = 1;
-    int  electrons = 0;
-    bool conjugated = true;
-    for (const int v : ringAtoms) {
-      const Atom& a            = g.atoms[static_cast<size_t>(v)];
-      bool        ringDouble   = false, exoDouble = false, exoToHetero = false;
-      int         nBonds       = 0;
-      for (const auto& [w, k] : adj[static_cast<size_t>(v)]) {
-        ++nBonds;
-        const uint8_t o = g.bonds[static_cast<size_t>(k)].order;
-        if (o == kDouble) {
-          if (inThis[static_cast<size_t>(w)]) {
-            ringDouble = true;
-          } else {
-            exoDouble   = true;
-            const int zw = g.atoms[static_cast<size_t>(w)].z;
-            exoToHetero  = zw == 7 || zw == 8 || zw == 16;
-          }
-        }
-        if (o == kTriple || o == kAromatic) conjugated = false;  // aromatic-form rings are the input's business
-      }
-      // RDKit's isAtomCandForArom: main-group ring atoms with at most three neighbours (hydrogens included)
-      const bool element = a.z == 5 || a.z == 6 || a.z == 7 || a.z == 8 || a.z == 15 || a.z == 16 || a.z == 33 || a.z == 34 || a.z == 52;
-      if (!element || nBonds + a.hExplicit + a.hImplicit > 3) conjugated = false;
-      if (!conjugated) break;
-      if (ringDouble) {
-        electrons += 1;
-      } else if (exoDouble) {
-        if (!exoToHetero) conjugated = false;  // exocyclic C=C: RDKit does not count the ring as aromatic
-      } else if ((a.z == 7 || a.z == 15) && a.charge == 0 && nBonds + a.hExplicit + a.hImplicit == 3) {
-        electrons += 2;
-      } else if ((a.z == 8 || a.z == 16 || a.z == 34) && a.charge == 0 && nBonds == 2) {
-        electrons += 2;
-      } else if (a.z == 6 && a.charge == -1) {
-        electrons += 2;
-      } else if ((a.z == 6 && a.charge == 1) || (a.z == 5 && a.charge == 0 && nBonds + a.hExplicit + a.hImplicit == 3)) {
-        electrons += 0;
+  return adj;
+}
+
+int donated_electrons(const Graph& g, const Adjacency& adj, const int i) {
+  const Atom& a = g.atoms[static_cast<size_t>(i)];
+  const int   z = a.z;
+  if (!(z == 5 || z == 6 || z == 7 || z == 8 || z == 15 || z == 16 || z == 33 || z == 34 || z == 52)) return -1;
+  const int degree = static_cast<int>(adj[static_cast<size_t>(i)].size()) + a.hExplicit + a.hImplicit;
+  if (degree > 3) return -1;
+  int  ringDouble = 0, exoDouble = 0;
+  bool exoTakes = false;
+  for (const auto& [v, k] : adj[static_cast<size_t>(i)]) {
+    const Bond& b = g.bonds[static_cast<size_t>(k)];
+    if (b.order == kDouble) {
+      if (b.ring) {
+        ++ringDouble;
       } else {
-        conjugated = false;
+        ++exoDouble;
+        const int zo = g.atoms[static_cast<size_t>(v)].z;
+        exoTakes     = outer_electrons(zo) > outer_electrons(z) || (outer_electrons(zo) == outer_electrons(z) && zo < z);
       }
-      if (!conjugated) break;
+    } else if (b.order == kTriple || b.order == kQuadruple) {
+      return -1;
     }
-    if (conjugated && electrons >= 2 && (electrons - 2) % 4 == 0) return true;
+  }
+  if (ringDouble + exoDouble > 1) return -1;
+  if (ringDouble == 1) return 1;
+  if (exoDouble == 1) return exoTakes ? 0 : 1;
+  if (z == 7 || z == 15 || z == 33) return ((a.charge == 0 && degree == 3) || (a.charge == -1 && degree == 2)) ? 2 : -1;
+  if (z == 8 || z == 16 || z == 34 || z == 52) return ((a.charge == 0 && degree == 2) || (a.charge == 1 && degree == 3)) ? 2 : -1;
+  if (z == 6) return (a.charge == -1 && degree == 3) ? 2 : (a.charge == 1 && degree == 3) ? 0 : -1;
+  return (a.charge == 0 && degree == 3) ? 0 : -1;  // boron
+}
+
+// atoms of the shortest cycle through bond k0 over ring bonds (empty when longer than maxLen)
+std::vector<int> smallest_ring_through(const Graph& g, const Adjacency& adj, const int k0, const int maxLen) {
+  const int        n = static_cast<int>(g.atoms.size());
+  const Bond&      b0 = g.bonds[static_cast<size_t>(k0)];
+  std::vector<int> from(static_cast<size_t>(n), -2), depth(static_cast<size_t>(n), 0), queue;
+  from[static_cast<size_t>(b0.a)] = -1;
+  queue.push_back(b0.a);
+  for (size_t q = 0; q < queue.size() && from[static_cast<size_t>(b0.b)] == -2; ++q) {
+    const int u = queue[q];
+    if (depth[static_cast<size_t>(u)] + 2 > maxLen) continue;
+    for (const auto& [v, k] : adj[static_cast<size_t>(u)]) {
+      if (k == k0 || !g.bonds[static_cast<size_t>(k)].ring || from[static_cast<size_t>(v)] != -2) continue;
+      from[static_cast<size_t>(v)]  = u;
+      depth[static_cast<size_t>(v)] = depth[static_cast<size_t>(u)] + 1;
+      queue.push_back(v);
+    }
+  }
+  std::vector<int> ring;
+  if (from[static_cast<size_t>(b0.b)] == -2) return ring;
+  for (int v = b0.b; v != -1; v = from[static_cast<size_t>(v)]) ring.push_back(v);
+  return ring;
+}
+
+bool huckel(const int electrons) { return electrons >= 2 && (electrons - 2) % 4 == 0; }
+
+// Perceives the aromatic rings of the Kekule-form part of the molecule: single rings of up to 8 atoms first, then unions
+// of 2 .. 6 fused rings (only the envelope of a union becomes aromatic: azulene's fusion bond stays single).  Returns how
+// many bonds are (would be) aromatic that were not before (-1: a fused system too large to decide); with `apply` the atoms
+// and bonds are marked.
+int perceive_aromaticity(Graph& g, const Adjacency& adj, const bool apply) {
+  const int        n = static_cast<int>(g.atoms.size());
+  std::vector<int> donated(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) donated[static_cast<size_t>(i)] = donated_electrons(g, adj, i);
+  std::vector<std::vector<int>> rings;      // atoms in cycle order
+  std::vector<std::vector<int>> ringBonds;  // their bonds
+  {
+    std::vector<std::vector<int>> keys;
+    for (size_t k = 0; k < g.bonds.size(); ++k) {
+      if (!g.bonds[k].ring) continue;
+      std::vector<int> ring = smallest_ring_through(g, adj, static_cast<int>(k), 8);
+      if (ring.empty()) continue;
+      bool ok = true;
+      for (const int v : ring) ok = ok && donated[static_cast<size_t>(v)] >= 0;
+      if (!ok) continue;
+      std::vector<int> key = ring;
+      std::sort(key.begin(), key.end());
+      if (std::find(keys.begin(), keys.end(), key) != keys.end()) continue;
+      std::vector<int> bonds;
+      for (size_t j = 0; j < ring.size() && ok; ++j) {
+        const int u = ring[j], w = ring[(j + 1) % ring.size()];
+        int       found = -1;
+        for (const auto& [v, kb] : adj[static_cast<size_t>(u)])
+          if (v == w && g.bonds[static_cast<size_t>(kb)].ring) found = kb;
+        ok = found >= 0 && g.bonds[static_cast<size_t>(found)].order != kAromatic;  // aromatic-form rings are the input's business
+        bonds.push_back(found);
+      }
+      if (!ok) continue;
+      keys.push_back(key);
+      rings.push_back(ring);
+      ringBonds.push_back(bonds);
+    }
+  }
+  const int nr = static_cast<int>(rings.size());
+  if (nr == 0) return 0;
+  std::vector<std::vector<int>> fused(static_cast<size_t>(nr));
+  for (int i = 0; i < nr; ++i)
+    for (int j = i + 1; j < nr; ++j) {
+      bool share = false;
+      for (const int kb : ringBonds[static_cast<size_t>(i)])
+        share = share || std::find(ringBonds[static_cast<size_t>(j)].begin(), ringBonds[static_cast<size_t>(j)].end(), kb) !=
+                             ringBonds[static_cast<size_t>(j)].end();
+      if (share) {
+        fused[static_cast<size_t>(i)].push_back(j);
+        fused[static_cast<size_t>(j)].push_back(i);
+      }
+    }
+  {  // a fused system of more than 8 candidate rings (fullerene fragments, graphene-like sheets): RDKit reaches its aromatic
+     // atoms through unions larger than the ones grown below, so the molecule is refused rather than guessed (drug-like
+     // molecules have at most 6: tests/test_smiles_aromaticity.py)
+    std::vector<int> comp(static_cast<size_t>(nr), -1);
+    for (int r0 = 0; r0 < nr; ++r0) {
+      if (comp[static_cast<size_t>(r0)] >= 0) continue;
+      std::vector<int> stack{r0};
+      comp[static_cast<size_t>(r0)] = r0;
+      int size                      = 0;
+      while (!stack.empty()) {
+        const int u = stack.back();
+        stack.pop_back();
+        ++size;
+        for (const int w : fused[static_cast<size_t>(u)])
+          if (comp[static_cast<size_t>(w)] < 0) {
+            comp[static_cast<size_t>(w)] = r0;
+            stack.push_back(w);
+          }
+      }
+      if (size > 8) return -1;
+    }
+  }
+  std::vector<char> aromBond(g.bonds.size(), 0), aromAtom(static_cast<size_t>(n), 0), ringDone(static_cast<size_t>(nr), 0);
+  for (int i = 0; i < nr; ++i) {
+    int e = 0;
+    for (const int v : rings[static_cast<size_t>(i)]) e += donated[static_cast<size_t>(v)];
+    if (!huckel(e)) continue;
+    ringDone[static_cast<size_t>(i)] = 1;
+    for (const int v : rings[static_cast<size_t>(i)]) aromAtom[static_cast<size_t>(v)] = 1;
+    for (const int kb : ringBonds[static_cast<size_t>(i)]) aromBond[static_cast<size_t>(kb)] = 1;
+  }
+  // unions of fused rings, smallest first: connected subsets grown one ring at a time
+  std::vector<std::vector<int>> level;
+  for (int i = 0; i < nr; ++i) level.push_back({i});
+  for (int size = 2; size <= 6 && !level.empty(); ++size) {
+    std::vector<std::vector<int>> next;
+    for (const auto& sub : level)
+      for (const int v : sub)
+        for (const int w : fused[static_cast<size_t>(v)]) {
+          if (std::find(sub.begin(), sub.end(), w) != sub.end()) continue;
+          std::vector<int> bigger = sub;
+          bigger.push_back(w);
+          std::sort(bigger.begin(), bigger.end());
+          if (std::find(next.begin(), next.end(), bigger) == next.end()) next.push_back(bigger);
+        }
+    if (next.size() > 4096) return -1;  // a huge fused system (fullerenes): not decided here, the caller refuses the molecule
+    for (const auto& combo : next) {
+      bool allDone = true;
+      for (const int i : combo) allDone = allDone && ringDone[static_cast<size_t>(i)];
+      if (allDone) continue;
+      std::vector<char> inUnion(static_cast<size_t>(n), 0);
+      int               e = 0;
+      for (const int i : combo)
+        for (const int v : rings[static_cast<size_t>(i)])
+          if (!inUnion[static_cast<size_t>(v)]) {
+            inUnion[static_cast<size_t>(v)] = 1;
+            e += donated[static_cast<size_t>(v)];
+          }
+      if (!huckel(e)) continue;
+      std::vector<int> count(g.bonds.size(), 0);
+      for (const int i : combo)
+        for (const int kb : ringBonds[static_cast<size_t>(i)]) ++count[static_cast<size_t>(kb)];
+      for (const int i : combo) ringDone[static_cast<size_t>(i)] = 1;
+      for (int v = 0; v < n; ++v)
+        if (inUnion[static_cast<size_t>(v)]) aromAtom[static_cast<size_t>(v)] = 1;
+      for (size_t kb = 0; kb < count.size(); ++kb)
+        if (count[kb] == 1) aromBond[kb] = 1;  // the envelope of the union
+    }
+    level.swap(next);
+  }
+  int changed = 0;
+  for (size_t kb = 0; kb < aromBond.size(); ++kb)
+    if (aromBond[kb]) {
+      ++changed;
+      if (apply) g.bonds[kb].order = kAromatic;
+    }
+  if (apply)
+    for (int v = 0; v < n; ++v)
+      if (aromAtom[static_cast<size_t>(v)]) g.atoms[static_cast<size_t>(v)].aromatic = true;
+  return changed;
+}
+
+// A conjugated macrocycle (9 .. 24 atoms, e.g. the inner ring of a porphyrin) that satisfies Hueckel's rule: RDKit marks
+// such rings aromatic as part of larger fused unions than are grown here, so the molecule is refused rather than guessed.
+bool conjugated_macrocycle(const Graph& g, const Adjacency& adj) {
+  for (size_t k = 0; k < g.bonds.size(); ++k) {
+    if (!g.bonds[k].ring || g.bonds[k].order != kDouble) continue;
+    const std::vector<int> ring = smallest_ring_through(g, adj, static_cast<int>(k), 24);
+    if (ring.size() < 9) continue;
+    int  e  = 0;
+    bool ok = true;
+    for (const int v : ring) {
+      const int d = donated_electrons(g, adj, v);
+      // atoms already aromatic (pyrrole rings of a porphyrin) count with what they would give
+      ok = ok && (d >= 0 || g.atoms[static_cast<size_t>(v)].aromatic);
+      e += d >= 0 ? d : 1;
+    }
+    if (ok && huckel(e)) return true;
   }
   return false;
 }
 
-void build(const char* s, Graph& g) {
+void build(const char* s, Graph& g, const unsigned flags) {
   g = Graph();
   if (s == nullptr) {
     g.status = kSyntax;
@@ -633,7 +810,12 @@ void build(const char* s, Graph& g) {
       return;
     }
   }
-  if (kekule_ring_looks_aromatic(g)) g.status = kNeedsAromaticity;
+  // Kekule-form rings RDKit would perceive as aromatic: perceived when asked for, refused otherwise (never fingerprinted
+  // with bond types RDKit would not use)
+  const Adjacency adj     = adjacency_of(g);
+  const bool      apply   = (flags & NVMK_SMILES_PERCEIVE_AROMATICITY) != 0u;
+  const int       changed = perceive_aromaticity(g, adj, apply);
+  if (changed < 0 || (changed > 0 && !apply) || conjugated_macrocycle(g, adj)) g.status = kNeedsAromaticity;
 }
 
 uint32_t hash_combine(const uint32_t seed, const uint32_t v) { return seed ^ (v + 0x9e3779b9u + (seed << 6) + (seed >> 2)); }
@@ -668,13 +850,19 @@ template <typename F> void parallel_for(const int64_t n, int threads, F&& body) 
 
 extern "C" {
 
-int nvmk_smiles_parse(const char* const* smiles, const int64_t n_mols, const int n_threads, void** handle) {
+int nvmk_smiles_parse_flags(const char* const* smiles, const int64_t n_mols, const int n_threads, const unsigned flags, void** handle) {
   NVMK_REQUIRE(handle != nullptr && (smiles != nullptr || n_mols == 0) && n_mols >= 0, "nvmk_smiles_parse: NULL argument or negative count");
+  NVMK_REQUIRE((flags & ~static_cast<unsigned>(NVMK_SMILES_PERCEIVE_AROMATICITY)) == 0u, "nvmk_smiles_parse: unknown flag bits 0x%x", flags);
   auto set = std::make_unique<nvmk::smiles::Set>();
   set->graphs.resize(static_cast<size_t>(n_mols));
-  nvmk::smiles::parallel_for(n_mols, n_threads, [&](const int64_t i) { nvmk::smiles::build(smiles[i], set->graphs[static_cast<size_t>(i)]); });
+  nvmk::smiles::parallel_for(n_mols, n_threads,
+                             [&](const int64_t i) { nvmk::smiles::build(smiles[i], set->graphs[static_cast<size_t>(i)], flags); });
   *handle = set.release();
   return NVMK_OK;
+}
+
+int nvmk_smiles_parse(const char* const* smiles, const int64_t n_mols, const int n_threads, void** handle) {
+  return nvmk_smiles_parse_flags(smiles, n_mols, n_threads, 0u, handle);
 }
 
 int nvmk_smiles_free(void* handle) {

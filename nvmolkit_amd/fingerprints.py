@@ -144,14 +144,17 @@ class SmilesSet:
     thing the Morgan path needs from a molecule: its graph with hydrogen counts, charges, ring flags and bond types.
 
     ``status[i]`` is 0 for an ingested molecule; the other codes (``SMILES_STATUS``) mean the molecule was REFUSED — the
-    library never fingerprints a molecule whose bond types RDKit would perceive differently.
+    library never fingerprints a molecule whose bond types RDKit would perceive differently.  Aromaticity is taken from
+    the input; with ``perceive_aromaticity=True`` Kekule-form rings are perceived with RDKit's default model (checked
+    against the aromaticity RDKit recorded in 8864 ChEMBL molecules, tests/test_smiles_aromaticity.py) instead of refused.
     """
 
-    def __init__(self, smiles, num_threads: int = 0):
+    def __init__(self, smiles, num_threads: int = 0, perceive_aromaticity: bool = False):
         self._handle = ctypes.c_void_p()
         items = [s.encode() if isinstance(s, str) else bytes(s) for s in smiles]
         arr = (ctypes.c_char_p * max(len(items), 1))(*items)
-        _native.check(_native.lib().nvmk_smiles_parse(arr, len(items), int(num_threads), ctypes.byref(self._handle)), "nvmk_smiles_parse")
+        _native.check(_native.lib().nvmk_smiles_parse_flags(arr, len(items), int(num_threads), 1 if perceive_aromaticity else 0,
+                                                            ctypes.byref(self._handle)), "nvmk_smiles_parse")
         n = len(items)
         self.n_atoms = np.zeros(n, dtype=np.int32)
         self.n_bonds = np.zeros(n, dtype=np.int32)

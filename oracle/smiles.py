@@ -24,7 +24,8 @@ ELEMENTS = ("* H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn 
 Z_OF = {s: z for z, s in enumerate(ELEMENTS)}
 AROMATIC_SYMBOLS = {"b": 5, "c": 6, "n": 7, "o": 8, "p": 15, "s": 16, "se": 34, "as": 33, "te": 52, "si": 14}
 VALENCES = {5: (3,), 6: (4,), 7: (3,), 8: (2,), 9: (1,), 15: (3, 5, 7), 16: (2, 4, 6), 17: (1,), 35: (1,), 53: (1, 3, 5)}
-BOND_TYPE = {"-": 1, "/": 1, "\\": 1, "=": 2, "#": 3, "$": 4, ":": 12}
+# "/" and "\\" carry a direction, not an order: between two aromatic ring atoms the bond is aromatic, else single (= unmarked)
+BOND_TYPE = {"-": 1, "/": None, "\\": None, "=": 2, "#": 3, "$": 4, ":": 12}
 # average weights and a few exact isotope masses: only what the hand-made test molecules use (H, C, N, O, F, I)
 WEIGHT = {1: 1.008, 6: 12.011, 7: 14.007, 8: 15.999, 9: 18.998, 53: 126.90}
 ISOTOPE = {(1, 2): 2.01410, (1, 3): 3.01605, (6, 13): 13.00335, (6, 14): 14.00324, (7, 15): 15.00011, (8, 18): 17.99916,
@@ -90,11 +91,13 @@ def parse(smiles: str):
             label = int(text.lstrip("%"))
             if label in open_rings:
                 other, sym = open_rings.pop(label)
-                if sym is not None and pending is not None and BOND_TYPE[sym] != BOND_TYPE[pending]:
+                if (sym is not None and pending is not None and BOND_TYPE[sym] is not None and BOND_TYPE[pending] is not None
+                        and BOND_TYPE[sym] != BOND_TYPE[pending]):
                     raise SmilesError("conflicting ring-closure bond symbols")
                 if other == prev or any({a, b} == {other, prev} for a, b, _ in bonds):
                     raise SmilesError("ring closure duplicates a bond")
-                bonds.append([other, prev, BOND_TYPE.get(pending or sym)])
+                t_close = BOND_TYPE.get(pending) if pending is not None else None
+                bonds.append([other, prev, t_close if t_close is not None else BOND_TYPE.get(sym)])
             else:
                 open_rings[label] = (prev, pending)
             pending = None
