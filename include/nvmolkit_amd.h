@@ -402,6 +402,10 @@ int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, co
  * RDKit's sanitisation rejects or rewrites are REFUSED per molecule, never fingerprinted differently from RDKit.
  *   nvmk_smiles_parse        : n_mols NUL- or whitespace-terminated strings -> an opaque set of graphs (n_threads <= 0: all
  *                              host threads).  Never fails on bad chemistry: the per-molecule status says what happened.
+ *   nvmk_smiles_parse_text   : the same for one text buffer with a molecule per line (a .smi file as it is read from disk:
+ *                              the SMILES is the first blank-separated column, "\n" or "\r\n" line ends; every line counts,
+ *                              an empty one is an empty molecule; the buffer need not end in a newline or NUL) - no
+ *                              per-molecule strings on the caller's side.  nvmk_smiles_size says how many molecules there were.
  *   nvmk_smiles_counts       : atoms / bonds (after folding [H] atoms) and status of every molecule; any output may be NULL
  *   nvmk_smiles_graph        : one molecule's graph, for tests and other consumers: atom_fields[6 * n_atoms] =
  *                              (Z, formal charge, isotope, total H count, aromatic, in ring), bond_fields[4 * n_bonds] =
@@ -421,6 +425,8 @@ int nvmk_smiles_parse(const char* const* smiles, int64_t n_mols, int n_threads, 
  * ChEMBL SMILES) instead of being refused.  Conjugated macrocycles (porphyrins) are refused either way. */
 #define NVMK_SMILES_PERCEIVE_AROMATICITY 1u
 int nvmk_smiles_parse_flags(const char* const* smiles, int64_t n_mols, int n_threads, unsigned flags, void** handle);
+int nvmk_smiles_parse_text(const char* text, int64_t n_bytes, int n_threads, unsigned flags, void** handle);
+int nvmk_smiles_size(const void* handle, int64_t* n_mols);
 int nvmk_smiles_free(void* handle);
 int nvmk_smiles_counts(const void* handle, int32_t* n_atoms, int32_t* n_bonds, int8_t* status);
 int nvmk_smiles_graph(const void* handle, int64_t mol, int32_t* atom_fields, int32_t* bond_fields);

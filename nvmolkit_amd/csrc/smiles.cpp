@@ -25,6 +25,8 @@
 //     back here and must come out with the aromatic atoms and bonds RDKit wrote (tests/test_smiles_aromaticity.py; 8864
 //     molecules).  Conjugated macrocycles (porphyrins) and fused systems of more than 8 candidate rings (fullerene
 //     fragments), where RDKit's result depends on its ring-enumeration order, are refused in this mode too.
+// Host throughput: one call parses a whole text buffer (nvmk_smiles_parse_text) or an array of strings on all host threads;
+// each thread works in its own Scratch (no allocation per molecule) and fills chunks of 512 molecules stored back to back.
 // Parity against RDKit's parser cannot be pinned in this image; the independent Python restatement oracle/smiles.py, the
 // element-count known answers of the reference's tests/test_morgan_fingerprint_ref.cpp:44-69, hand-computed invariants
 // and the ChEMBL round trip above are the checks (tests/test_smiles_ingestion.py, tests/test_smiles_aromaticity.py).
@@ -76,6 +78,23 @@ struct Graph {
   std::vector<Atom> atoms;
   std::vector<Bond> bonds;
   int8_t            status = kOk;
+};
+
+// Per-thread working storage of one molecule at a time: every array a pass needs lives here and keeps its capacity from
+// molecule to molecule, so that parsing allocates nothing once a thread has seen its largest molecule (a million small
+// vectors per call was what the parser spent most of its time on, and what kept it from scaling over threads).
+struct Scratch {
+  Graph            g;
+  std::vector<int> branchStack;                     // parser
+  std::vector<int> head, adjBond, adjAtom, fill;    // adjacency in CSR form: neighbours of i are [head[i], head[i + 1])
+  std::vector<int> disc, low, parentBond, it, dfs;  // bridge search
+  std::vector<int> degree, onlyBond, renum, sum2;   // hydrogen folding, valences
+  std::vector<char> drop;
+  std::vector<Atom> keptAtoms;
+  std::vector<Bond> keptBonds;
+  std::vector<int> donated, from, depth, queue, ring;  // aromaticity
+  std::vector<unsigned> seen;                       // visit stamps of the ring search
+  unsigned         stamp = 0;
 };
 
 const char* const kSymbols[] = {
@@ -146,7 +165,8 @@ struct Parser {
   const char* s;
   int         pos = 0;
   Graph&      g;
-  explicit Parser(const char* str, Graph& graph) : s(str), g(graph) {}
+  std::vector<int>& stack;
+  explicit Parser(const char* str, Scratch& sc) : s(str), g(sc.g), stack(sc.branchStack) { stack.clear(); }
 
   bool fail() {
     g.status = kSyntax;
@@ -292,7 +312,6 @@ struct Parser {
       uint8_t order = kUnspecified;
     };
     Open             ring[100];
-    std::vector<int> stack;
     int              prev    = -1;
     uint8_t          pending = kUnspecified;
     bool             havePending = false;
@@ -384,25 +403,39 @@ struct Parser {
   }
 };
 
-// bonds that lie on a cycle (= are not bridges): iterative depth-first search with low-links
-void mark_ring_bonds(Graph& g) {
-  const int n = static_cast<int>(g.atoms.size()), m = static_cast<int>(g.bonds.size());
-  std::vector<int> head(static_cast<size_t>(n) + 1, 0), adjBond(static_cast<size_t>(2 * m)), adjAtom(static_cast<size_t>(2 * m));
+// adjacency of the (hydrogen-folded) graph in CSR form, neighbours in bond order
+void build_adjacency(Scratch& sc) {
+  const Graph& g = sc.g;
+  const int    n = static_cast<int>(g.atoms.size()), m = static_cast<int>(g.bonds.size());
+  sc.head.assign(static_cast<size_t>(n) + 1, 0);
+  sc.adjBond.resize(static_cast<size_t>(2 * m));
+  sc.adjAtom.resize(static_cast<size_t>(2 * m));
   for (const Bond& b : g.bonds) {
-    ++head[static_cast<size_t>(b.a) + 1];
-    ++head[static_cast<size_t>(b.b) + 1];
+    ++sc.head[static_cast<size_t>(b.a) + 1];
+    ++sc.head[static_cast<size_t>(b.b) + 1];
   }
-  for (int i = 0; i < n; ++i) head[static_cast<size_t>(i) + 1] += head[static_cast<size_t>(i)];
-  std::vector<int> fill(head.begin(), head.end() - 1);
+  for (int i = 0; i < n; ++i) sc.head[static_cast<size_t>(i) + 1] += sc.head[static_cast<size_t>(i)];
+  sc.fill.assign(sc.head.begin(), sc.head.end() - 1);
   for (int k = 0; k < m; ++k) {
     const Bond& b = g.bonds[static_cast<size_t>(k)];
-    adjBond[static_cast<size_t>(fill[static_cast<size_t>(b.a)])]   = k;
-    adjAtom[static_cast<size_t>(fill[static_cast<size_t>(b.a)]++)] = b.b;
-    adjBond[static_cast<size_t>(fill[static_cast<size_t>(b.b)])]   = k;
-    adjAtom[static_cast<size_t>(fill[static_cast<size_t>(b.b)]++)] = b.a;
+    sc.adjBond[static_cast<size_t>(sc.fill[static_cast<size_t>(b.a)])]   = k;
+    sc.adjAtom[static_cast<size_t>(sc.fill[static_cast<size_t>(b.a)]++)] = b.b;
+    sc.adjBond[static_cast<size_t>(sc.fill[static_cast<size_t>(b.b)])]   = k;
+    sc.adjAtom[static_cast<size_t>(sc.fill[static_cast<size_t>(b.b)]++)] = b.a;
   }
-  std::vector<int> disc(static_cast<size_t>(n), -1), low(static_cast<size_t>(n), 0), parentBond(static_cast<size_t>(n), -1),
-      it(static_cast<size_t>(n), 0), stack;
+}
+
+// bonds that lie on a cycle (= are not bridges): iterative depth-first search with low-links over the CSR adjacency
+void mark_ring_bonds(Scratch& sc) {
+  Graph&     g = sc.g;
+  const int  n = static_cast<int>(g.atoms.size()), m = static_cast<int>(g.bonds.size());
+  const auto &head = sc.head, &adjBond = sc.adjBond, &adjAtom = sc.adjAtom;
+  auto &     disc = sc.disc, &low = sc.low, &parentBond = sc.parentBond, &it = sc.it, &stack = sc.dfs;
+  disc.assign(static_cast<size_t>(n), -1);
+  low.assign(static_cast<size_t>(n), 0);
+  parentBond.assign(static_cast<size_t>(n), -1);
+  it.assign(static_cast<size_t>(n), 0);
+  stack.clear();
   int timer = 0;
   for (int root = 0; root < n; ++root) {
     if (disc[static_cast<size_t>(root)] >= 0) continue;
@@ -447,44 +480,50 @@ void mark_ring_bonds(Graph& g) {
 
 // RDKit's default removeHs on what a SMILES can express: a hydrogen atom is folded into its neighbour unless it is
 // labelled (isotope), charged, not singly bonded to exactly one non-hydrogen atom.
-void fold_hydrogens(Graph& g) {
-  const int        n = static_cast<int>(g.atoms.size());
-  std::vector<int> degree(static_cast<size_t>(n), 0), onlyBond(static_cast<size_t>(n), -1);
+void fold_hydrogens(Scratch& sc) {
+  Graph&     g = sc.g;
+  const int  n = static_cast<int>(g.atoms.size());
+  bool       anyHydrogen = false;
+  for (const Atom& a : g.atoms) anyHydrogen = anyHydrogen || a.z == 1;
+  if (!anyHydrogen) return;
+  auto &degree = sc.degree, &onlyBond = sc.onlyBond, &renum = sc.renum;
+  degree.assign(static_cast<size_t>(n), 0);
+  onlyBond.assign(static_cast<size_t>(n), -1);
   for (size_t k = 0; k < g.bonds.size(); ++k) {
     ++degree[static_cast<size_t>(g.bonds[k].a)];
     ++degree[static_cast<size_t>(g.bonds[k].b)];
     onlyBond[static_cast<size_t>(g.bonds[k].a)] = onlyBond[static_cast<size_t>(g.bonds[k].b)] = static_cast<int>(k);
   }
-  std::vector<char> drop(static_cast<size_t>(n), 0);
-  bool              any = false;
+  sc.drop.assign(static_cast<size_t>(n), 0);
+  bool any = false;
   for (int i = 0; i < n; ++i) {
     const Atom& a = g.atoms[static_cast<size_t>(i)];
     if (a.z != 1 || a.isotope != 0 || a.charge != 0 || a.hExplicit != 0 || degree[static_cast<size_t>(i)] != 1) continue;
     const Bond& b = g.bonds[static_cast<size_t>(onlyBond[static_cast<size_t>(i)])];
     const int   o = b.a == i ? b.b : b.a;
     if (g.atoms[static_cast<size_t>(o)].z == 1 || (b.order != kSingle && b.order != kUnspecified)) continue;
-    drop[static_cast<size_t>(i)] = 1;
-    any                          = true;
+    sc.drop[static_cast<size_t>(i)] = 1;
+    any                             = true;
     if (g.atoms[static_cast<size_t>(o)].bracket) ++g.atoms[static_cast<size_t>(o)].hExplicit;  // organic-subset atoms recount below
   }
   if (!any) return;
-  std::vector<int> renum(static_cast<size_t>(n), -1);
-  std::vector<Atom> atoms;
+  renum.assign(static_cast<size_t>(n), -1);
+  sc.keptAtoms.clear();
   for (int i = 0; i < n; ++i)
-    if (!drop[static_cast<size_t>(i)]) {
-      renum[static_cast<size_t>(i)] = static_cast<int>(atoms.size());
-      atoms.push_back(g.atoms[static_cast<size_t>(i)]);
+    if (!sc.drop[static_cast<size_t>(i)]) {
+      renum[static_cast<size_t>(i)] = static_cast<int>(sc.keptAtoms.size());
+      sc.keptAtoms.push_back(g.atoms[static_cast<size_t>(i)]);
     }
-  std::vector<Bond> bonds;
+  sc.keptBonds.clear();
   for (const Bond& b : g.bonds)
-    if (!drop[static_cast<size_t>(b.a)] && !drop[static_cast<size_t>(b.b)]) {
+    if (!sc.drop[static_cast<size_t>(b.a)] && !sc.drop[static_cast<size_t>(b.b)]) {
       Bond nb = b;
       nb.a    = renum[static_cast<size_t>(b.a)];
       nb.b    = renum[static_cast<size_t>(b.b)];
-      bonds.push_back(nb);
+      sc.keptBonds.push_back(nb);
     }
-  g.atoms.swap(atoms);
-  g.bonds.swap(bonds);
+  g.atoms.swap(sc.keptAtoms);
+  g.bonds.swap(sc.keptBonds);
 }
 
 // twice the valence contribution of a bond (RDKit counts an aromatic bond as 1.5)
@@ -499,8 +538,10 @@ int half_orders(const uint8_t order) {
 }
 
 // Atom::calcExplicitValence / calcImplicitValence of RDKit for atoms written without brackets
-bool assign_implicit_hydrogens(Graph& g) {
-  std::vector<int> sum2(g.atoms.size(), 0);
+bool assign_implicit_hydrogens(Scratch& sc) {
+  Graph& g    = sc.g;
+  auto&  sum2 = sc.sum2;
+  sum2.assign(g.atoms.size(), 0);
   for (const Bond& b : g.bonds) {
     sum2[static_cast<size_t>(b.a)] += half_orders(b.order);
     sum2[static_cast<size_t>(b.b)] += half_orders(b.order);
@@ -559,16 +600,31 @@ int outer_electrons(const int z) {
   }
 }
 
-using Adjacency = std::vector<std::vector<std::pair<int, int>>>;  // per atom: (neighbour, bond)
-
-Adjacency adjacency_of(const Graph& g) {
-  Adjacency adj(g.atoms.size());
-  for (size_t k = 0; k < g.bonds.size(); ++k) {
-    adj[static_cast<size_t>(g.bonds[k].a)].push_back({g.bonds[k].b, static_cast<int>(k)});
-    adj[static_cast<size_t>(g.bonds[k].b)].push_back({g.bonds[k].a, static_cast<int>(k)});
+// view of the CSR adjacency: adj[i] iterates over (neighbour, bond) pairs in bond order
+struct Neighbours {
+  const int *atom, *bond;
+  int        n;
+  struct It {
+    const int *a, *b;
+    std::pair<int, int> operator*() const { return {*a, *b}; }
+    It&                 operator++() {
+      ++a;
+      ++b;
+      return *this;
+    }
+    bool operator!=(const It& o) const { return a != o.a; }
+  };
+  It     begin() const { return {atom, bond}; }
+  It     end() const { return {atom + n, bond + n}; }
+  size_t size() const { return static_cast<size_t>(n); }
+};
+struct Adjacency {
+  const Scratch& sc;
+  Neighbours     operator[](const size_t i) const {
+    const int lo = sc.head[i];
+    return {sc.adjAtom.data() + lo, sc.adjBond.data() + lo, sc.head[i + 1] - lo};
   }
-  return adj;
-}
+};
 
 int donated_electrons(const Graph& g, const Adjacency& adj, const int i) {
   const Atom& a = g.atoms[static_cast<size_t>(i)];
@@ -601,25 +657,40 @@ int donated_electrons(const Graph& g, const Adjacency& adj, const int i) {
   return (a.charge == 0 && degree == 3) ? 0 : -1;  // boron
 }
 
-// atoms of the shortest cycle through bond k0 over ring bonds (empty when longer than maxLen)
-std::vector<int> smallest_ring_through(const Graph& g, const Adjacency& adj, const int k0, const int maxLen) {
-  const int        n = static_cast<int>(g.atoms.size());
-  const Bond&      b0 = g.bonds[static_cast<size_t>(k0)];
-  std::vector<int> from(static_cast<size_t>(n), -2), depth(static_cast<size_t>(n), 0), queue;
-  from[static_cast<size_t>(b0.a)] = -1;
+// atoms of the shortest cycle through bond k0 over ring bonds, into sc.ring (left empty when longer than maxLen)
+const std::vector<int>& smallest_ring_through(Scratch& sc, const Adjacency& adj, const int k0, const int maxLen) {
+  const Graph& g  = sc.g;
+  const size_t n  = g.atoms.size();
+  const Bond&  b0 = g.bonds[static_cast<size_t>(k0)];
+  if (sc.seen.size() < n) sc.seen.resize(n, 0u);
+  if (sc.from.size() < n) {
+    sc.from.resize(n);
+    sc.depth.resize(n);
+  }
+  if (++sc.stamp == 0u) {  // wrapped: forget every old visit
+    std::fill(sc.seen.begin(), sc.seen.end(), 0u);
+    sc.stamp = 1u;
+  }
+  const unsigned stamp = sc.stamp;
+  auto &         from = sc.from, &depth = sc.depth, &queue = sc.queue, &ring = sc.ring;
+  ring.clear();
+  queue.clear();
+  sc.seen[static_cast<size_t>(b0.a)] = stamp;
+  from[static_cast<size_t>(b0.a)]    = -1;
+  depth[static_cast<size_t>(b0.a)]   = 0;
   queue.push_back(b0.a);
-  for (size_t q = 0; q < queue.size() && from[static_cast<size_t>(b0.b)] == -2; ++q) {
+  for (size_t q = 0; q < queue.size() && sc.seen[static_cast<size_t>(b0.b)] != stamp; ++q) {
     const int u = queue[q];
     if (depth[static_cast<size_t>(u)] + 2 > maxLen) continue;
     for (const auto& [v, k] : adj[static_cast<size_t>(u)]) {
-      if (k == k0 || !g.bonds[static_cast<size_t>(k)].ring || from[static_cast<size_t>(v)] != -2) continue;
-      from[static_cast<size_t>(v)]  = u;
-      depth[static_cast<size_t>(v)] = depth[static_cast<size_t>(u)] + 1;
+      if (k == k0 || !g.bonds[static_cast<size_t>(k)].ring || sc.seen[static_cast<size_t>(v)] == stamp) continue;
+      sc.seen[static_cast<size_t>(v)] = stamp;
+      from[static_cast<size_t>(v)]    = u;
+      depth[static_cast<size_t>(v)]   = depth[static_cast<size_t>(u)] + 1;
       queue.push_back(v);
     }
   }
-  std::vector<int> ring;
-  if (from[static_cast<size_t>(b0.b)] == -2) return ring;
+  if (sc.seen[static_cast<size_t>(b0.b)] != stamp) return ring;
   for (int v = b0.b; v != -1; v = from[static_cast<size_t>(v)]) ring.push_back(v);
   return ring;
 }
@@ -630,20 +701,29 @@ bool huckel(const int electrons) { return electrons >= 2 && (electrons - 2) % 4 
 // of 2 .. 6 fused rings (only the envelope of a union becomes aromatic: azulene's fusion bond stays single).  Returns how
 // many bonds are (would be) aromatic that were not before (-1: a fused system too large to decide); with `apply` the atoms
 // and bonds are marked.
-int perceive_aromaticity(Graph& g, const Adjacency& adj, const bool apply) {
-  const int        n = static_cast<int>(g.atoms.size());
-  std::vector<int> donated(static_cast<size_t>(n));
-  for (int i = 0; i < n; ++i) donated[static_cast<size_t>(i)] = donated_electrons(g, adj, i);
+int perceive_aromaticity(Scratch& sc, const Adjacency& adj, const bool apply) {
+  Graph&    g = sc.g;
+  const int n = static_cast<int>(g.atoms.size());
+  // A candidate ring has no aromatic bond and only atoms that can donate; a ring found through a bond that is aromatic
+  // itself or ends in an atom that cannot donate would be discarded below, so the search starts from the other bonds only
+  // (none at all in most aromatic-form input: the electron counts are then never needed).
+  auto& donated = sc.donated;
+  donated.assign(static_cast<size_t>(n), -2);  // -2: not computed yet
+  auto donates = [&](const int i) {
+    int& d = donated[static_cast<size_t>(i)];
+    if (d == -2) d = donated_electrons(g, adj, i);
+    return d;
+  };
   std::vector<std::vector<int>> rings;      // atoms in cycle order
   std::vector<std::vector<int>> ringBonds;  // their bonds
   {
     std::vector<std::vector<int>> keys;
     for (size_t k = 0; k < g.bonds.size(); ++k) {
-      if (!g.bonds[k].ring) continue;
-      std::vector<int> ring = smallest_ring_through(g, adj, static_cast<int>(k), 8);
+      if (!g.bonds[k].ring || g.bonds[k].order == kAromatic || donates(g.bonds[k].a) < 0 || donates(g.bonds[k].b) < 0) continue;
+      const std::vector<int>& ring = smallest_ring_through(sc, adj, static_cast<int>(k), 8);
       if (ring.empty()) continue;
       bool ok = true;
-      for (const int v : ring) ok = ok && donated[static_cast<size_t>(v)] >= 0;
+      for (const int v : ring) ok = ok && donates(v) >= 0;
       if (!ok) continue;
       std::vector<int> key = ring;
       std::sort(key.begin(), key.end());
@@ -761,10 +841,11 @@ int perceive_aromaticity(Graph& g, const Adjacency& adj, const bool apply) {
 
 // A conjugated macrocycle (9 .. 24 atoms, e.g. the inner ring of a porphyrin) that satisfies Hueckel's rule: RDKit marks
 // such rings aromatic as part of larger fused unions than are grown here, so the molecule is refused rather than guessed.
-bool conjugated_macrocycle(const Graph& g, const Adjacency& adj) {
+bool conjugated_macrocycle(Scratch& sc, const Adjacency& adj) {
+  const Graph& g = sc.g;
   for (size_t k = 0; k < g.bonds.size(); ++k) {
     if (!g.bonds[k].ring || g.bonds[k].order != kDouble) continue;
-    const std::vector<int> ring = smallest_ring_through(g, adj, static_cast<int>(k), 24);
+    const std::vector<int>& ring = smallest_ring_through(sc, adj, static_cast<int>(k), 24);
     if (ring.size() < 9) continue;
     int  e  = 0;
     bool ok = true;
@@ -779,56 +860,82 @@ bool conjugated_macrocycle(const Graph& g, const Adjacency& adj) {
   return false;
 }
 
-void build(const char* s, Graph& g, const unsigned flags) {
-  g = Graph();
+void build(const char* s, Scratch& sc, const unsigned flags) {
+  Graph& g = sc.g;
+  g.atoms.clear();
+  g.bonds.clear();
+  g.status = kOk;
   if (s == nullptr) {
     g.status = kSyntax;
     return;
   }
-  Parser p(s, g);
+  Parser p(s, sc);
   if (!p.run()) {
     g.atoms.clear();
     g.bonds.clear();
     if (g.status == kOk) g.status = kSyntax;
     return;
   }
-  fold_hydrogens(g);
-  mark_ring_bonds(g);
+  fold_hydrogens(sc);
+  build_adjacency(sc);
+  mark_ring_bonds(sc);
   for (Bond& b : g.bonds) {
     if (b.order != kUnspecified) continue;
     const bool arom = g.atoms[static_cast<size_t>(b.a)].aromatic && g.atoms[static_cast<size_t>(b.b)].aromatic && b.ring;
     b.order         = arom ? kAromatic : kSingle;
   }
-  if (!assign_implicit_hydrogens(g)) {
+  if (!assign_implicit_hydrogens(sc)) {
     g.status = kValence;
     return;
   }
-  std::vector<int> degree(g.atoms.size(), 0);
-  for (const Bond& b : g.bonds) {
-    if (++degree[static_cast<size_t>(b.a)] > kMaxBondsPerAtom || ++degree[static_cast<size_t>(b.b)] > kMaxBondsPerAtom) {
+  for (size_t i = 0; i < g.atoms.size(); ++i)
+    if (sc.head[i + 1] - sc.head[i] > kMaxBondsPerAtom) {
       g.status = kTooManyBonds;
       return;
     }
-  }
   // Kekule-form rings RDKit would perceive as aromatic: perceived when asked for, refused otherwise (never fingerprinted
   // with bond types RDKit would not use)
-  const Adjacency adj     = adjacency_of(g);
+  const Adjacency adj{sc};
   const bool      apply   = (flags & NVMK_SMILES_PERCEIVE_AROMATICITY) != 0u;
-  const int       changed = perceive_aromaticity(g, adj, apply);
-  if (changed < 0 || (changed > 0 && !apply) || conjugated_macrocycle(g, adj)) g.status = kNeedsAromaticity;
+  const int       changed = perceive_aromaticity(sc, adj, apply);
+  if (changed < 0 || (changed > 0 && !apply) || conjugated_macrocycle(sc, adj)) g.status = kNeedsAromaticity;
 }
 
 uint32_t hash_combine(const uint32_t seed, const uint32_t v) { return seed ^ (v + 0x9e3779b9u + (seed << 6) + (seed >> 2)); }
 
 }  // namespace
 
+// Parsed molecules are kept in chunks of kChunkMols consecutive molecules; a chunk is filled by one thread and stores its
+// atoms and bonds back to back (two allocations per 512 molecules instead of two per molecule).
+constexpr int64_t kChunkMols = 512;
+struct Chunk {
+  std::vector<Atom>     atoms;
+  std::vector<Bond>     bonds;
+  std::vector<uint32_t> atomStart, bondStart;  // kChunkMols + 1 offsets
+  std::vector<int8_t>   status;
+};
+struct MolView {
+  const Atom* atoms;
+  const Bond* bonds;
+  int         nAtoms, nBonds;
+  int8_t      status;
+};
 struct Set {
-  std::vector<Graph> graphs;
+  int64_t            nMols = 0;
+  std::vector<Chunk> chunks;
+  std::string        tail;  // copy of a last line that had no terminator (nvmk_smiles_parse_text)
+  MolView            view(const int64_t i) const {
+    const Chunk& c = chunks[static_cast<size_t>(i / kChunkMols)];
+    const size_t j = static_cast<size_t>(i % kChunkMols);
+    return {c.atoms.data() + c.atomStart[j], c.bonds.data() + c.bondStart[j], static_cast<int>(c.atomStart[j + 1] - c.atomStart[j]),
+            static_cast<int>(c.bondStart[j + 1] - c.bondStart[j]), c.status[j]};
+  }
 };
 
+// body(i) for i in [0, n) on up to `threads` threads (<= 0: all host threads), items claimed one at a time
 template <typename F> void parallel_for(const int64_t n, int threads, F&& body) {
   if (threads <= 0) threads = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
-  threads = static_cast<int>(std::min<int64_t>(threads, std::max<int64_t>(1, n / 256)));  // a thread is worth starting for >= 256 molecules
+  threads = static_cast<int>(std::min<int64_t>(threads, n));
   if (threads <= 1) {
     for (int64_t i = 0; i < n; ++i) body(i);
     return;
@@ -838,12 +945,42 @@ template <typename F> void parallel_for(const int64_t n, int threads, F&& body) 
   for (int t = 0; t < threads; ++t)
     pool.emplace_back([&] {
       for (;;) {
-        const int64_t lo = next.fetch_add(64);
-        if (lo >= n) return;
-        for (int64_t i = lo; i < std::min(n, lo + 64); ++i) body(i);
+        const int64_t i = next.fetch_add(1);
+        if (i >= n) return;
+        body(i);
       }
     });
   for (std::thread& t : pool) t.join();
+}
+
+Scratch& thread_scratch() {
+  static thread_local Scratch sc;
+  return sc;
+}
+
+// every molecule of `line_of(i)` into the set, one chunk per work item
+template <typename LineOf> void parse_all(Set& set, const int64_t n_mols, const int n_threads, const unsigned flags, LineOf&& line_of) {
+  set.nMols = n_mols;
+  set.chunks.resize(static_cast<size_t>((n_mols + kChunkMols - 1) / kChunkMols));
+  parallel_for(static_cast<int64_t>(set.chunks.size()), n_threads, [&](const int64_t c) {
+    Scratch&      sc = thread_scratch();
+    Chunk&        ch = set.chunks[static_cast<size_t>(c)];
+    const int64_t lo = c * kChunkMols, hi = std::min(n_mols, lo + kChunkMols);
+    ch.atomStart.assign(static_cast<size_t>(hi - lo) + 1, 0u);
+    ch.bondStart.assign(static_cast<size_t>(hi - lo) + 1, 0u);
+    ch.status.assign(static_cast<size_t>(hi - lo), kOk);
+    ch.atoms.reserve(static_cast<size_t>(hi - lo) * 32);
+    ch.bonds.reserve(static_cast<size_t>(hi - lo) * 34);
+    for (int64_t i = lo; i < hi; ++i) {
+      build(line_of(i), sc, flags);
+      const size_t j = static_cast<size_t>(i - lo);
+      ch.atoms.insert(ch.atoms.end(), sc.g.atoms.begin(), sc.g.atoms.end());
+      ch.bonds.insert(ch.bonds.end(), sc.g.bonds.begin(), sc.g.bonds.end());
+      ch.atomStart[j + 1] = static_cast<uint32_t>(ch.atoms.size());
+      ch.bondStart[j + 1] = static_cast<uint32_t>(ch.bonds.size());
+      ch.status[j]        = sc.g.status;
+    }
+  });
 }
 
 }  // namespace nvmk::smiles
@@ -854,15 +991,41 @@ int nvmk_smiles_parse_flags(const char* const* smiles, const int64_t n_mols, con
   NVMK_REQUIRE(handle != nullptr && (smiles != nullptr || n_mols == 0) && n_mols >= 0, "nvmk_smiles_parse: NULL argument or negative count");
   NVMK_REQUIRE((flags & ~static_cast<unsigned>(NVMK_SMILES_PERCEIVE_AROMATICITY)) == 0u, "nvmk_smiles_parse: unknown flag bits 0x%x", flags);
   auto set = std::make_unique<nvmk::smiles::Set>();
-  set->graphs.resize(static_cast<size_t>(n_mols));
-  nvmk::smiles::parallel_for(n_mols, n_threads,
-                             [&](const int64_t i) { nvmk::smiles::build(smiles[i], set->graphs[static_cast<size_t>(i)], flags); });
+  nvmk::smiles::parse_all(*set, n_mols, n_threads, flags, [&](const int64_t i) { return smiles[i]; });
   *handle = set.release();
   return NVMK_OK;
 }
 
 int nvmk_smiles_parse(const char* const* smiles, const int64_t n_mols, const int n_threads, void** handle) {
   return nvmk_smiles_parse_flags(smiles, n_mols, n_threads, 0u, handle);
+}
+
+int nvmk_smiles_parse_text(const char* text, const int64_t n_bytes, const int n_threads, const unsigned flags, void** handle) {
+  NVMK_REQUIRE(handle != nullptr && (text != nullptr || n_bytes == 0) && n_bytes >= 0, "nvmk_smiles_parse_text: NULL argument or negative size");
+  NVMK_REQUIRE((flags & ~static_cast<unsigned>(NVMK_SMILES_PERCEIVE_AROMATICITY)) == 0u, "nvmk_smiles_parse_text: unknown flag bits 0x%x", flags);
+  auto                     set = std::make_unique<nvmk::smiles::Set>();
+  std::vector<const char*> lines;
+  const char *             p = text, *end = text + n_bytes;
+  while (p < end) {
+    const char* nl = static_cast<const char*>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+    if (nl == nullptr) {  // the parser stops at a blank, a line end or NUL: a last line without any gets a terminated copy
+      set->tail.assign(p, static_cast<size_t>(end - p));
+      lines.push_back(nullptr);
+      break;
+    }
+    lines.push_back(p);
+    p = nl + 1;
+  }
+  if (!lines.empty() && lines.back() == nullptr) lines.back() = set->tail.c_str();
+  nvmk::smiles::parse_all(*set, static_cast<int64_t>(lines.size()), n_threads, flags, [&](const int64_t i) { return lines[static_cast<size_t>(i)]; });
+  *handle = set.release();
+  return NVMK_OK;
+}
+
+int nvmk_smiles_size(const void* handle, int64_t* n_mols) {
+  NVMK_REQUIRE(handle != nullptr && n_mols != nullptr, "nvmk_smiles_size: NULL argument");
+  *n_mols = static_cast<const nvmk::smiles::Set*>(handle)->nMols;
+  return NVMK_OK;
 }
 
 int nvmk_smiles_free(void* handle) {
@@ -872,21 +1035,22 @@ int nvmk_smiles_free(void* handle) {
 
 int nvmk_smiles_counts(const void* handle, int32_t* n_atoms, int32_t* n_bonds, int8_t* status) {
   NVMK_REQUIRE(handle != nullptr, "nvmk_smiles_counts: NULL handle");
-  const auto& graphs = static_cast<const nvmk::smiles::Set*>(handle)->graphs;
-  for (size_t i = 0; i < graphs.size(); ++i) {
-    if (n_atoms != nullptr) n_atoms[i] = static_cast<int32_t>(graphs[i].atoms.size());
-    if (n_bonds != nullptr) n_bonds[i] = static_cast<int32_t>(graphs[i].bonds.size());
-    if (status != nullptr) status[i] = graphs[i].status;
+  const auto& set = *static_cast<const nvmk::smiles::Set*>(handle);
+  for (int64_t i = 0; i < set.nMols; ++i) {
+    const nvmk::smiles::MolView m = set.view(i);
+    if (n_atoms != nullptr) n_atoms[i] = m.nAtoms;
+    if (n_bonds != nullptr) n_bonds[i] = m.nBonds;
+    if (status != nullptr) status[i] = m.status;
   }
   return NVMK_OK;
 }
 
 int nvmk_smiles_graph(const void* handle, const int64_t mol, int32_t* atom_fields, int32_t* bond_fields) {
   NVMK_REQUIRE(handle != nullptr, "nvmk_smiles_graph: NULL handle");
-  const auto& graphs = static_cast<const nvmk::smiles::Set*>(handle)->graphs;
-  NVMK_REQUIRE(mol >= 0 && static_cast<size_t>(mol) < graphs.size(), "nvmk_smiles_graph: molecule index out of range");
-  const auto& g = graphs[static_cast<size_t>(mol)];
-  for (size_t i = 0; atom_fields != nullptr && i < g.atoms.size(); ++i) {
+  const auto& set = *static_cast<const nvmk::smiles::Set*>(handle);
+  NVMK_REQUIRE(mol >= 0 && mol < set.nMols, "nvmk_smiles_graph: molecule index out of range");
+  const nvmk::smiles::MolView g = set.view(mol);
+  for (int i = 0; atom_fields != nullptr && i < g.nAtoms; ++i) {
     const auto& a          = g.atoms[i];
     atom_fields[6 * i + 0] = a.z;
     atom_fields[6 * i + 1] = a.charge;
@@ -895,7 +1059,7 @@ int nvmk_smiles_graph(const void* handle, const int64_t mol, int32_t* atom_field
     atom_fields[6 * i + 4] = a.aromatic ? 1 : 0;
     atom_fields[6 * i + 5] = a.inRing ? 1 : 0;
   }
-  for (size_t k = 0; bond_fields != nullptr && k < g.bonds.size(); ++k) {
+  for (int k = 0; bond_fields != nullptr && k < g.nBonds; ++k) {
     bond_fields[4 * k + 0] = g.bonds[k].a;
     bond_fields[4 * k + 1] = g.bonds[k].b;
     bond_fields[4 * k + 2] = g.bonds[k].order;
@@ -911,52 +1075,65 @@ int nvmk_smiles_morgan_inputs(const void* handle, const int64_t* mol_ids, const 
                    n_atoms != nullptr && n_sel >= 0,
                "nvmk_smiles_morgan_inputs: NULL argument");
   NVMK_REQUIRE(max_atoms > 0 && max_atoms <= 32767, "nvmk_smiles_morgan_inputs: max_atoms out of range");
-  const auto& graphs = static_cast<const Set*>(handle)->graphs;
+  const Set& set = *static_cast<const Set*>(handle);
   for (int64_t s = 0; s < n_sel; ++s) {
     const int64_t m = mol_ids != nullptr ? mol_ids[s] : s;
-    NVMK_REQUIRE(m >= 0 && static_cast<size_t>(m) < graphs.size(), "nvmk_smiles_morgan_inputs: molecule index %lld out of range",
-                 static_cast<long long>(m));
-    const Graph& g = graphs[static_cast<size_t>(m)];
+    NVMK_REQUIRE(m >= 0 && m < set.nMols, "nvmk_smiles_morgan_inputs: molecule index %lld out of range", static_cast<long long>(m));
+    const MolView g = set.view(m);
     NVMK_REQUIRE(g.status == kOk, "nvmk_smiles_morgan_inputs: molecule %lld was not ingested (status %d)", static_cast<long long>(m), g.status);
-    NVMK_REQUIRE(static_cast<int>(g.atoms.size()) < max_atoms && static_cast<int>(g.bonds.size()) < max_atoms,
-                 "nvmk_smiles_morgan_inputs: molecule %lld does not fit a %d-atom bucket", static_cast<long long>(m), max_atoms);
+    NVMK_REQUIRE(g.nAtoms < max_atoms && g.nBonds < max_atoms, "nvmk_smiles_morgan_inputs: molecule %lld does not fit a %d-atom bucket",
+                 static_cast<long long>(m), max_atoms);
   }
-  const size_t stride = static_cast<size_t>(max_atoms);
-  parallel_for(n_sel, n_threads, [&](const int64_t s) {
-    const Graph& g   = graphs[static_cast<size_t>(mol_ids != nullptr ? mol_ids[s] : s)];
-    uint32_t*    ai  = atom_inv + static_cast<size_t>(s) * stride;
-    uint32_t*    bi  = bond_inv + static_cast<size_t>(s) * stride;
-    int16_t*     bix = bond_idx + static_cast<size_t>(s) * stride * kMaxBondsPerAtom;
-    int16_t*     bo  = bond_other + static_cast<size_t>(s) * stride * kMaxBondsPerAtom;
-    std::fill(ai, ai + stride, 0u);
-    std::fill(bi, bi + stride, 0u);
-    std::fill(bix, bix + stride * kMaxBondsPerAtom, static_cast<int16_t>(-1));
-    std::fill(bo, bo + stride * kMaxBondsPerAtom, static_cast<int16_t>(-1));
-    const int na = static_cast<int>(g.atoms.size());
-    n_atoms[s]   = static_cast<int16_t>(na);
-    std::vector<int> deg(static_cast<size_t>(na), 0), nbrH(static_cast<size_t>(na), 0);
-    for (size_t k = 0; k < g.bonds.size(); ++k) {
-      const Bond& b = g.bonds[k];
-      bi[k]         = b.order;
-      const int ends[2][2] = {{b.a, b.b}, {b.b, b.a}};
-      for (const auto& e : ends) {
-        const int slot = deg[static_cast<size_t>(e[0])]++;
-        bix[static_cast<size_t>(e[0]) * kMaxBondsPerAtom + static_cast<size_t>(slot)] = static_cast<int16_t>(k);
-        bo[static_cast<size_t>(e[0]) * kMaxBondsPerAtom + static_cast<size_t>(slot)]  = static_cast<int16_t>(e[1]);
-        if (g.atoms[static_cast<size_t>(e[1])].z == 1) ++nbrH[static_cast<size_t>(e[0])];
+  const size_t  stride = static_cast<size_t>(max_atoms);
+  const int64_t block  = 256;  // molecules per work item
+  parallel_for((n_sel + block - 1) / block, n_threads, [&](const int64_t blk) {
+    int deg[4096], nbrH[4096];  // per-atom counters of one molecule; molecules beyond 4096 atoms use the vectors below
+    std::vector<int> degBig, nbrBig;
+    for (int64_t s = blk * block; s < std::min(n_sel, (blk + 1) * block); ++s) {
+      const MolView g   = set.view(mol_ids != nullptr ? mol_ids[s] : s);
+      uint32_t*     ai  = atom_inv + static_cast<size_t>(s) * stride;
+      uint32_t*     bi  = bond_inv + static_cast<size_t>(s) * stride;
+      int16_t*      bix = bond_idx + static_cast<size_t>(s) * stride * kMaxBondsPerAtom;
+      int16_t*      bo  = bond_other + static_cast<size_t>(s) * stride * kMaxBondsPerAtom;
+      std::fill(ai, ai + stride, 0u);
+      std::fill(bi, bi + stride, 0u);
+      std::memset(bix, 0xff, stride * kMaxBondsPerAtom * sizeof(int16_t));  // -1 in every slot
+      std::memset(bo, 0xff, stride * kMaxBondsPerAtom * sizeof(int16_t));
+      const int na = g.nAtoms;
+      n_atoms[s]   = static_cast<int16_t>(na);
+      int *d = deg, *h = nbrH;
+      if (na > 4096) {
+        degBig.assign(static_cast<size_t>(na), 0);
+        nbrBig.assign(static_cast<size_t>(na), 0);
+        d = degBig.data();
+        h = nbrBig.data();
+      } else {
+        std::fill(d, d + na, 0);
+        std::fill(h, h + na, 0);
       }
-    }
-    for (int i = 0; i < na; ++i) {
-      const Atom&    a  = g.atoms[static_cast<size_t>(i)];
-      const int      hs = a.hExplicit + a.hImplicit;
-      const double   mass = a.isotope != 0 ? isotope_mass(a.z, a.isotope) : kWeights[a.z];
-      const uint32_t comps[5] = {a.z, static_cast<uint32_t>(hs + deg[static_cast<size_t>(i)]), static_cast<uint32_t>(hs + nbrH[static_cast<size_t>(i)]),
-                                 static_cast<uint32_t>(static_cast<int32_t>(a.charge)),
-                                 static_cast<uint32_t>(static_cast<int32_t>(mass - kWeights[a.z]))};
-      uint32_t seed = 0;
-      for (const uint32_t c : comps) seed = hash_combine(seed, c);
-      if (a.inRing) seed = hash_combine(seed, 1u);
-      ai[i] = seed;
+      for (int k = 0; k < g.nBonds; ++k) {
+        const Bond& b        = g.bonds[k];
+        bi[k]                = b.order;
+        const int ends[2][2] = {{b.a, b.b}, {b.b, b.a}};
+        for (const auto& e : ends) {
+          const int slot = d[e[0]]++;
+          bix[static_cast<size_t>(e[0]) * kMaxBondsPerAtom + static_cast<size_t>(slot)] = static_cast<int16_t>(k);
+          bo[static_cast<size_t>(e[0]) * kMaxBondsPerAtom + static_cast<size_t>(slot)]  = static_cast<int16_t>(e[1]);
+          if (g.atoms[e[1]].z == 1) ++h[e[0]];
+        }
+      }
+      for (int i = 0; i < na; ++i) {
+        const Atom&    a        = g.atoms[i];
+        const int      hs       = a.hExplicit + a.hImplicit;
+        const double   mass     = a.isotope != 0 ? isotope_mass(a.z, a.isotope) : kWeights[a.z];
+        const uint32_t comps[5] = {a.z, static_cast<uint32_t>(hs + d[i]), static_cast<uint32_t>(hs + h[i]),
+                                   static_cast<uint32_t>(static_cast<int32_t>(a.charge)),
+                                   static_cast<uint32_t>(static_cast<int32_t>(mass - kWeights[a.z]))};
+        uint32_t seed = 0;
+        for (const uint32_t c : comps) seed = hash_combine(seed, c);
+        if (a.inRing) seed = hash_combine(seed, 1u);
+        ai[i] = seed;
+      }
     }
   });
   return NVMK_OK;

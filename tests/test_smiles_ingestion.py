@@ -191,6 +191,129 @@ def test_atom_order_invariance_from_smiles():
     assert all(np.array_equal(fps[0], f) for f in fps[1:])
 
 
+# ---- text buffers, chunked storage, staging blocks (host only) ------------------------------------------
+def _same_sets(a, b):
+    assert len(a) == len(b)
+    assert np.array_equal(a.n_atoms, b.n_atoms) and np.array_equal(a.n_bonds, b.n_bonds) and np.array_equal(a.status, b.status)
+    for i in range(0, len(a), max(1, len(a) // 97)):
+        for x, y in zip(a.graph(i), b.graph(i)):
+            assert np.array_equal(x, y)
+
+
+def test_text_buffers_are_parsed_line_by_line():
+    path = Path(__file__).parent / "golden" / "chembl_1k.smi"
+    lines = path.read_text().split("\n")
+    lines = lines[:-1] if lines[-1] == "" else lines                                           # a final newline ends the last line
+    listed = SmilesSet([line.split()[0] if line.split() else "" for line in lines])
+    _same_sets(SmilesSet.from_file(path), listed)
+    _same_sets(SmilesSet.from_text(path.read_text().replace("\n", "\r\n")), listed)          # DOS line ends
+    _same_sets(SmilesSet.from_text(path.read_bytes().rstrip(b"\n")), listed)                   # no terminator after the last line
+    _same_sets(SmilesSet.from_text(path.read_bytes().rstrip(b"\n") + b"\n"), listed)
+    # the pointer-array entry (strings with a line break inside) and the text entry see the same molecules
+    _same_sets(SmilesSet(CHEMBL + ["CC\nO"]), SmilesSet(CHEMBL + ["CC"]))
+    # every line counts: names are ignored, an empty line is an empty molecule, a header is a syntax error
+    s = SmilesSet.from_text("smiles name\nCCO ethanol\n\nc1ccccc1\tbenzene\n  CC")
+    assert s.n_atoms.tolist() == [0, 3, 0, 6, 2] and s.status.tolist() == [1, 0, 0, 0, 0]
+    assert len(SmilesSet.from_text("")) == 0 and len(SmilesSet.from_text("\n")) == 1 and len(SmilesSet([""])) == 1
+    assert SmilesSet(["C", "", "CC", ""]).n_atoms.tolist() == [1, 0, 2, 0]
+
+
+def test_chunk_boundaries_keep_molecule_order():
+    """Molecules are stored in chunks of 512 filled by different threads: molecule i must stay string i."""
+    smiles = ["C" * (1 + i % 37) + ("O" if i % 3 else "N") for i in range(512 * 5 + 17)]
+    for threads in (1, 3, 8):
+        s = SmilesSet(smiles, threads)
+        assert s.n_atoms.tolist() == [len(x) for x in smiles]
+        for i in (0, 511, 512, 513, 1023, 1024, 2559, 2560, len(smiles) - 1):
+            atoms, _ = s.graph(i)
+            assert atoms[-1, 0] == (8 if i % 3 else 7) and len(atoms) == len(smiles[i])
+
+
+def test_staging_block_holds_the_same_arrays():
+    from nvmolkit_amd import fingerprints as fpmod
+    s = SmilesSet(CHEMBL)
+    size = np.maximum(s.n_atoms, s.n_bonds)
+    idx = np.flatnonzero((size >= 32) & (size < 64) & (s.status == 0))
+    sizes, specs = fpmod._smiles_block_sizes(len(idx), 64)
+    offsets, total = fpmod._block_layout(sizes)
+    assert all(o % 256 == 0 for o in offsets) and total >= sum(sizes)
+    block = np.full(total + 100, 0xAB, dtype=np.uint8)
+    fpmod._fill_smiles_block(block, offsets, s, idx, 64, 4)
+    want = list(s.morgan_inputs(idx, 64)) + [idx.astype(np.int32)]
+    for o, size_b, (shape, dtype), w in zip(offsets, sizes, specs, want):
+        assert np.array_equal(block[o:o + size_b].view(dtype).reshape(shape), w)
+    assert (block[total:] == 0xAB).all()
+    with pytest.raises(ValueError, match="out arrays"):
+        s.morgan_inputs(idx, 64, out=tuple(np.zeros((1, 1), dtype=np.uint32) for _ in range(5)))
+
+
+def test_smiles_to_fingerprints_host_path_with_the_kernel_call_stubbed(monkeypatch):
+    """Everything of GetFingerprintsFromSmiles' bucket path that is not CUDA — bucketing, the staging block, the pointers and
+    the output rows handed to nvmk_morgan_from_invariants — with that one call answered by the oracle on the staged arrays
+    (the real kernel is compared with the same expectation in the GPU test below)."""
+    import contextlib
+    import ctypes
+
+    import torch
+
+    from nvmolkit_amd import _native
+    from nvmolkit_amd import fingerprints as fpmod
+    real = _native.lib()
+    calls = []
+
+    class Stub:
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        @staticmethod
+        def nvmk_morgan_from_invariants(p_ai, p_bi, p_bx, p_bo, p_na, p_rows, n, max_atoms, radius, fp_bits, p_out, stream):
+            def arr(ptr, count, ctype, dtype):
+                return np.frombuffer((ctype * count).from_address(ptr), dtype=dtype).copy()
+            ai = arr(p_ai, n * max_atoms, ctypes.c_uint32, np.uint32).reshape(n, max_atoms)
+            bi = arr(p_bi, n * max_atoms, ctypes.c_uint32, np.uint32).reshape(n, max_atoms)
+            bx = arr(p_bx, n * max_atoms * 8, ctypes.c_int16, np.int16).reshape(n, max_atoms, 8)
+            bo = arr(p_bo, n * max_atoms * 8, ctypes.c_int16, np.int16).reshape(n, max_atoms, 8)
+            na = arr(p_na, n, ctypes.c_int16, np.int16)
+            rows = arr(p_rows, n, ctypes.c_int32, np.int32)
+            fp = oracle.morgan_fingerprints(ai, bi, bx, bo, na, max_atoms, radius, fp_bits)
+            words = fp_bits // 32
+            for r, row in zip(rows.tolist(), fp):
+                dst = (ctypes.c_uint32 * words).from_address(p_out + 4 * words * r)
+                np.frombuffer(dst, dtype=np.uint32)[:] = row
+            calls.append((max_atoms, n))
+            return 0
+
+    monkeypatch.setattr(_native, "lib", lambda: Stub())
+    monkeypatch.setattr(_native, "on_stream", lambda stream, dev: contextlib.nullcontext())
+    monkeypatch.setattr(_native, "stream_ptr", lambda stream: 0)
+    monkeypatch.setattr(fpmod, "_pinned_block", lambda n: torch.empty(n, dtype=torch.uint8))
+    monkeypatch.setattr(fpmod, "_release_pinned_block", lambda *a: None)
+    monkeypatch.setattr(torch.cuda, "device", lambda dev: contextlib.nullcontext())
+    gen = MorganFingerprintGenerator(radius=2, fpSize=2048)
+    mols = SmilesSet(CHEMBL)
+    size = np.maximum(mols.n_atoms, mols.n_bonds)
+    out = torch.zeros((len(mols), 64), dtype=torch.int32)
+    lo = 0
+    for b in (32, 64, 128, 256, 512, 1024):
+        idx = np.flatnonzero((size >= lo) & (size < b) & (mols.status == 0))
+        lo = b
+        if len(idx):
+            gen._launch_smiles(mols, idx, b, out, 0, None)
+            # the array-input seam goes through the same submit step
+            check = torch.zeros((len(mols), 64), dtype=torch.int32)
+            gen._launch(mols.morgan_inputs(idx, b), b, check, idx, None)
+            assert torch.equal(check[idx], out[idx])
+    got = out.numpy().view(np.uint32)
+    assert len(calls) >= 6 and (got != 0).any(axis=1).all()
+    sizes = np.array([max(len(a), len(b)) for a, b in (osmi.molecule(smi) for smi in CHEMBL)])
+    lo = 0
+    for stride in (32, 64, 128, 256, 512, 1024):
+        idx = np.flatnonzero((sizes >= lo) & (sizes < stride))
+        lo = stride
+        if len(idx):
+            assert np.array_equal(got[idx], oracle.morgan_fingerprints(*oracle_inputs([CHEMBL[i] for i in idx], stride), stride, 2, 2048))
+
+
 # ---- on the GPU ----------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_fingerprints_from_smiles_equal_the_oracle_pipeline():

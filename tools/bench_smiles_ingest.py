@@ -35,7 +35,14 @@ for label, threads in (("all_threads", 0), ("one_thread", 1)):
         lo = b
         mols.morgan_inputs(idx, b, threads)
     t_inputs = time.perf_counter() - t
-    out[label] = {"parse_s": t_parse, "morgan_inputs_s": t_inputs, "molecules_per_s": len(smiles) / (t_parse + t_inputs)}
+    text = ("\n".join(smiles) + "\n").encode()
+    t_text = 1e9
+    for _ in range(3):
+        t = time.perf_counter()
+        SmilesSet.from_text(text, threads)
+        t_text = min(t_text, time.perf_counter() - t)
+    out[label] = {"parse_s": t_parse, "parse_text_buffer_s": t_text, "morgan_inputs_s": t_inputs,
+                  "molecules_per_s": len(smiles) / (t_parse + t_inputs)}
 if torch.cuda.is_available():
     gen = MorganFingerprintGenerator(2, 2048)
     gen.GetFingerprintsFromSmiles(smiles[:1000]).torch()
