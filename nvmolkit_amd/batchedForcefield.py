@@ -293,11 +293,19 @@ class FlatBatchedForcefield:
         g = self._batch.compute_gradient(self._positions()).cpu().numpy()
         return self._nest([g[3 * self._atom_starts[s]:3 * self._atom_starts[s + 1]].tolist() for s in range(len(self._systems))])
 
-    def minimize(self, maxIters: int = 200, forceTol: float = 1e-4,
-                 output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, targetGpu: int | None = None):
+    def minimize(self, maxIters: int | None = None, forceTol: float = 1e-4,
+                 output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, target_gpu: int | None = None,
+                 targetGpu: int | None = None):
         """BFGS-minimise every conformer.  ``RDKIT_CONFORMERS``: coordinates are written back (into the stored arrays, and
         into RDKit conformers when the batch was built from molecules) and ``(energies, converged)`` nested lists are
-        returned; ``DEVICE``: a :class:`Device3DResult` and nothing is written back."""
+        returned; ``DEVICE``: a :class:`Device3DResult` and nothing is written back.  ``maxIters`` defaults to the
+        reference's 200 (MMFF) / 1000 (UFF) (nvmolkit/batchedForcefield.py:565-571,681-687); ``target_gpu`` is the reference's
+        keyword, ``targetGpu`` (the spelling of the optimise drivers) is accepted as well."""
+        if maxIters is None:
+            maxIters = 200 if self.kind == MMFF else 1000
+        if target_gpu is not None and targetGpu is not None and int(target_gpu) != int(targetGpu):
+            raise ValueError("target_gpu and targetGpu disagree")
+        targetGpu = target_gpu if target_gpu is not None else targetGpu
         if self.num_molecules == 0:
             if output == CoordinateOutput.DEVICE:
                 raise ValueError("minimize(output=DEVICE) requires at least one molecule")
