@@ -316,7 +316,10 @@ class FlatBatchedForcefield:
         if output == CoordinateOutput.DEVICE:
             gpu = self.device.index if self.device.index is not None else torch.cuda.current_device()
             if targetGpu is not None and int(targetGpu) >= 0 and int(targetGpu) != gpu:
-                raise ValueError(f"targetGpu {targetGpu} is not in the configured set of execution GPUs")
+                name = "MMFFBatchedForcefield" if self.kind == MMFF else "UFFBatchedForcefield"
+                raise ValueError(f"{name}.minimize(output=DEVICE) does not support target_gpu != wrapper GPU "
+                                 f"(target_gpu {int(targetGpu)}, wrapper GPU {gpu}); use the optimise drivers' targetGpu "
+                                 "for cross-GPU consolidation")  # wording: nvmolkit/batchedForcefield.cpp:283,414
             i32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(self.device)  # noqa: E731
             return Device3DResult(pos.view(-1, 3), i32(self._atom_starts), i32([m for m, _ in self._systems]),
                                   i32([k for _, k in self._systems]), gpu, self.num_molecules, energies=energies,

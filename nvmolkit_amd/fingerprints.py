@@ -355,20 +355,22 @@ class MorganFingerprintGenerator:
             raise ValueError(f"Unsupported fpSize {self._fp_size}")
         return AsyncGpuResult(out)
 
-    def GetFingerprintsFromSmiles(self, smiles, num_threads: int = 0, stream=None, on_error: str = "raise") -> AsyncGpuResult:
+    def GetFingerprintsFromSmiles(self, smiles, num_threads: int = 0, stream=None, on_error: str = "raise",
+                                  perceive_aromaticity: bool = False) -> AsyncGpuResult:
         """SMILES strings (or an already parsed :class:`SmilesSet`) -> packed fingerprints, one row per molecule in input
         order, without RDKit: the library parses the strings, derives the invariants on ``num_threads`` host threads
         (0 = all) and launches the same kernels as :meth:`GetFingerprints`.
 
         ``on_error``: ``"raise"`` (default) — a ``ValueError`` listing the refused molecules by index and reason, like the
         reference's ``None`` / parse failures; ``"zero"`` — their rows stay all-zero and ``result.smiles_status`` says why.
+        ``perceive_aromaticity``: accept Kekule-form input (see :class:`SmilesSet`; ignored for an already parsed set).
         """
         _native.stream_ptr(stream)
         if self._fp_size not in _VALID_FP_SIZES:
             raise ValueError(f"Unsupported fpSize {self._fp_size}: must be one of {_VALID_FP_SIZES}")
         if on_error not in ("raise", "zero"):
             raise ValueError("on_error must be 'raise' or 'zero'")
-        mols = smiles if isinstance(smiles, SmilesSet) else SmilesSet(smiles, num_threads)
+        mols = smiles if isinstance(smiles, SmilesSet) else SmilesSet(smiles, num_threads, perceive_aromaticity)
         bad = np.flatnonzero(mols.status != 0)
         if len(bad) and on_error == "raise":
             shown = ", ".join(f"{i}: {SMILES_STATUS.get(int(mols.status[i]), '?')}" for i in bad[:8])

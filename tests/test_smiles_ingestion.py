@@ -344,6 +344,39 @@ def test_refused_smiles_raise_or_stay_zero():
     assert res.smiles_status.tolist() == [0, 3, 0] and not fp[1].any() and fp[0].any() and fp[2].any()
 
 
+BINAP_LIKE = "CC1(C)C2=C(C=CC(=C2)P(C3=CC=CC=C3)C4=CC=CC=C4)OC5=C1C=CC(=C5)P(C6=CC=CC=C6)C7=CC=CC=C7"
+BINAP_LIKE_AROMATIC = "CC1(C)c2c(ccc(c2)P(c3ccccc3)c4ccccc4)Oc5c1ccc(c5)P(c6ccccc6)c7ccccc7"
+
+
+def test_kekule_input_of_the_reference_regression_molecule():
+    """The molecule of the reference's regression test (nvmolkit/tests/test_fingerprints.py:137-148) is written in Kekule
+    form: refused by default, perceived on request, and then the same graph as its aromatic form."""
+    assert SmilesSet([BINAP_LIKE]).status[0] == 3
+    a, b = SmilesSet([BINAP_LIKE], perceive_aromaticity=True), SmilesSet([BINAP_LIKE_AROMATIC])
+    assert a.status[0] == 0 and b.status[0] == 0
+    for x, y in zip(a.graph(0), b.graph(0)):
+        assert np.array_equal(x, y)
+    assert int((a.graph(0)[1][:, 2] == 12).sum()) == 36
+
+
+@pytest.mark.gpu
+def test_repeated_single_molecule_calls_never_come_back_empty():
+    """nvmolkit/tests/test_fingerprints.py:137-148 (GH issue 84) through the SMILES path: 256 single-molecule calls over four
+    generator configurations, none of them an empty fingerprint, all of them equal per configuration."""
+    configs = [(2, 512), (2, 1024), (3, 512), (3, 1024)]
+    first = {}
+    for i in range(256):
+        radius, fp_size = configs[i % len(configs)]
+        gen = MorganFingerprintGenerator(radius=radius, fpSize=fp_size)
+        fp = gen.GetFingerprintsFromSmiles([BINAP_LIKE], perceive_aromaticity=True).torch().cpu().numpy()
+        assert fp.any(), f"empty fingerprint on attempt {i}"
+        assert np.array_equal(first.setdefault((radius, fp_size), fp), fp)
+    mols = SmilesSet([BINAP_LIKE_AROMATIC])
+    for (radius, fp_size), fp in first.items():
+        want = oracle.morgan_fingerprints(*mols.morgan_inputs([0], 64), 64, radius, fp_size)
+        assert np.array_equal(fp.view(np.uint32), want)
+
+
 def test_mutated_smiles_never_crash_and_agree_with_the_oracle():
     """Random edits of real SMILES (mostly invalid afterwards): the parser refuses or ingests exactly what the oracle does,
     with the same graph, and survives everything."""
