@@ -216,21 +216,31 @@ def cfg1_block(device, cpu_seconds: float) -> dict:
 BFGS_KIND_NAMES = {0: "dg", 1: "etk", 2: "mmff"}
 
 
-def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int, rank: int, cpu_seconds: float) -> dict:
-    """BASELINE.json configs[2] (and [3] when world > 1: every rank embeds and optimises its own n_mols molecules, no
-    data-path collective): ETKDG (`confs` conformers per molecule) DEVICE-chained into MMFF94 on the synthetic drug-like
-    set of nvmolkit_amd/synthetic.py.  Roofline = the fused BFGS kernels' inverse-Hessian traffic (SURVEY.md 8(d))."""
-    from nvmolkit_amd import _native, mmffOptimization, synthetic
-    from nvmolkit_amd.embedMolecules import FlatMolecule, FlatMoleculeSet, embed_flat
-    from nvmolkit_amd.types import CoordinateOutput
+def conformer_library(n_mols: int, world: int, rank: int):
+    """The synthetic drug-like molecules of one rank (generated in forked worker processes) and the seconds it took."""
+    from nvmolkit_amd import synthetic
 
     t0 = time.perf_counter()
     procs = max(1, (os.cpu_count() or 2) // (2 * world))
-    library = synthetic.druglike_library(n_mols, seed=SEED + 17 * rank, processes=min(procs, 64))
+    return synthetic.druglike_library(n_mols, seed=SEED + 17 * rank, processes=min(procs, 64)), time.perf_counter() - t0
+
+
+def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int, rank: int, cpu_seconds: float,
+                    library=None, t_library: float = 0.0) -> dict:
+    """BASELINE.json configs[2] (and [3] when world > 1: every rank embeds and optimises its own n_mols molecules, no
+    data-path collective): ETKDG (`confs` conformers per molecule) DEVICE-chained into MMFF94 on the synthetic drug-like
+    set of nvmolkit_amd/synthetic.py.  Roofline = the fused BFGS kernels' inverse-Hessian traffic (SURVEY.md 8(d))."""
+    from nvmolkit_amd import _native, mmffOptimization
+    from nvmolkit_amd.embedMolecules import FlatMolecule, FlatMoleculeSet, embed_flat
+    from nvmolkit_amd.types import CoordinateOutput
+
+    if library is None:
+        library, t_library = conformer_library(n_mols, world, rank)
+    t0 = time.perf_counter()
     molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library], device=device)
     tables = mmffOptimization.resident_tables([m["mmff"] for m in library], device)  # term tables resident before the timed region
     torch.cuda.synchronize()
-    t_prep = time.perf_counter() - t0
+    t_prep = time.perf_counter() - t0 + t_library
     lib = _native.lib()
     embed_flat(FlatMoleculeSet([FlatMolecule(**library[0]["embed"])], device=device), 1, 5)  # warm-up: module load, pools
     stats = torch.zeros(64, dtype=torch.int64, device=device)
@@ -342,6 +352,11 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     distributed = world > 1
+    library, t_library = None, 0.0
+    if distributed and args.conformer_mols > 0:
+        # the generator forks worker processes: under torchrun that happens before this process holds a HIP context and
+        # RCCL's threads (the single-GPU run generates inside the conformer block, after the headline measurement)
+        library, t_library = conformer_library(args.conformer_mols, world, rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
@@ -527,7 +542,8 @@ def main() -> None:
             guarded("conformers", conformer_block, args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank,
                     args.cpu_seconds)
         else:  # ranks meet in collectives inside the block: an exception on one rank must end the job, not hang the others
-            block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds)
+            block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds,
+                                    library, t_library)
             if rank == 0:
                 secondary["conformers"] = block
     if rank == 0:
