@@ -49,3 +49,28 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "_lib", None)
     with pytest.raises(_native.NativeLibraryError):
         _native.lib()
+
+
+def test_null_and_out_of_range_arguments_never_crash():
+    """Every entry point called with NULL pointers and 0 / 1 / -1 / 64 in every integer slot, in a child process: an error
+    code (or a no-op) is fine, a signal is not.  Works without a GPU: arguments are checked before anything touches HIP."""
+    import subprocess
+    import sys
+
+    code = r'''
+import ctypes, sys
+from nvmolkit_amd import _native
+lib = _native.lib()
+ints = (ctypes.c_int, ctypes.c_int64, ctypes.c_uint, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int32)
+calls = 0
+for name, (restype, argtypes) in sorted(_native.SIGNATURES.items()):
+    for variant in range(4):
+        args = [[0, 1, -1, 64][variant] if t in ints else [0.0, 0.5, -1.0, 1e300][variant] if t in (ctypes.c_double, ctypes.c_float) else None
+                for t in argtypes]
+        getattr(lib, name)(*args)
+        calls += 1
+print("calls", calls)
+'''
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
+    assert int(p.stdout.split()[-1]) == 4 * len(_native.SIGNATURES)
