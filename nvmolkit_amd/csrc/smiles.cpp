@@ -18,19 +18,20 @@
 //     fingerprinted with bond types RDKit would not use.  Valences RDKit's sanitisation rejects (or rewrites, like
 //     five-valent nitro groups) are refused as well.
 //   * OPT-IN PERCEPTION (nvmk_smiles_parse_flags, NVMK_SMILES_PERCEIVE_AROMATICITY): RDKit's default aromaticity model
-//     restated from the RDKit Book - candidate rings are the smallest rings through each ring bond whose atoms can all
+//     (perceive_aromaticity below) - candidate rings are the shortest rings through each ring bond whose atoms can all
 //     donate, electrons per atom from its unsaturation / lone pair / exocyclic double bond, 4n+2 over single rings and
-//     over unions of up to six fused rings, whose outer envelope is what gets marked.  The restatement is checked on the
+//     over combinations of up to six rings fused through single shared bonds.  The restatement is checked on the
 //     aromaticity RDKit itself recorded: every aromatic ChEMBL SMILES of tests/golden is Kekulised by the oracle, read
-//     back here and must come out with the aromatic atoms and bonds RDKit wrote (tests/test_smiles_aromaticity.py; 8864
-//     molecules).  Conjugated macrocycles (porphyrins) and fused systems of more than 8 candidate rings (fullerene
-//     fragments), where RDKit's result depends on its ring-enumeration order, are refused in this mode too.
+//     back here and comes out with exactly the aromatic atoms and bonds RDKit wrote - all 8864 molecules of the 10 000,
+//     porphyrins and fullerene adducts included (tests/test_smiles_aromaticity.py).  Only a fused system with more than
+//     400 000 connected ring combinations of one size (nothing in the data comes close) is refused in this mode.
 // Host throughput: one call parses a whole text buffer (nvmk_smiles_parse_text) or an array of strings on all host threads;
 // each thread works in its own Scratch (no allocation per molecule) and fills chunks of 512 molecules stored back to back.
 // Parity against RDKit's parser cannot be pinned in this image; the independent Python restatement oracle/smiles.py, the
 // element-count known answers of the reference's tests/test_morgan_fingerprint_ref.cpp:44-69, hand-computed invariants
 // and the ChEMBL round trip above are the checks (tests/test_smiles_ingestion.py, tests/test_smiles_aromaticity.py).
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -657,50 +658,78 @@ int donated_electrons(const Graph& g, const Adjacency& adj, const int i) {
   return (a.charge == 0 && degree == 3) ? 0 : -1;  // boron
 }
 
-// atoms of the shortest cycle through bond k0 over ring bonds, into sc.ring (left empty when longer than maxLen)
-const std::vector<int>& smallest_ring_through(Scratch& sc, const Adjacency& adj, const int k0, const int maxLen) {
+// Every shortest cycle through bond k0 over ring bonds (cycle order, starting at the bond's second atom), appended to
+// `out`; nothing when the shortest is longer than maxLen.  Taken over all ring bonds these are the rings RDKit's
+// symmetrised SSSR holds for everything but exotic cages: a bond between two hexagons of a fullerene gives both hexagons,
+// a bond of norbornane's one-atom bridge both five-rings, and the six-ring around them is never the shortest for any bond.
+constexpr size_t kMaxRingsPerBond = 16;
+void shortest_rings_through(Scratch& sc, const Adjacency& adj, const int k0, const int maxLen, std::vector<std::vector<int>>& out) {
   const Graph& g  = sc.g;
   const size_t n  = g.atoms.size();
   const Bond&  b0 = g.bonds[static_cast<size_t>(k0)];
   if (sc.seen.size() < n) sc.seen.resize(n, 0u);
-  if (sc.from.size() < n) {
-    sc.from.resize(n);
-    sc.depth.resize(n);
-  }
+  if (sc.depth.size() < n) sc.depth.resize(n);
   if (++sc.stamp == 0u) {  // wrapped: forget every old visit
     std::fill(sc.seen.begin(), sc.seen.end(), 0u);
     sc.stamp = 1u;
   }
   const unsigned stamp = sc.stamp;
-  auto &         from = sc.from, &depth = sc.depth, &queue = sc.queue, &ring = sc.ring;
-  ring.clear();
+  auto &         depth = sc.depth, &queue = sc.queue, &path = sc.ring;
+  const auto     seen  = [&](const int v) { return sc.seen[static_cast<size_t>(v)] == stamp; };
   queue.clear();
   sc.seen[static_cast<size_t>(b0.a)] = stamp;
-  from[static_cast<size_t>(b0.a)]    = -1;
   depth[static_cast<size_t>(b0.a)]   = 0;
   queue.push_back(b0.a);
-  for (size_t q = 0; q < queue.size() && sc.seen[static_cast<size_t>(b0.b)] != stamp; ++q) {
+  for (size_t q = 0; q < queue.size(); ++q) {
     const int u = queue[q];
-    if (depth[static_cast<size_t>(u)] + 2 > maxLen) continue;
+    if (depth[static_cast<size_t>(u)] + 2 > maxLen || (seen(b0.b) && depth[static_cast<size_t>(u)] >= depth[static_cast<size_t>(b0.b)])) break;
     for (const auto& [v, k] : adj[static_cast<size_t>(u)]) {
-      if (k == k0 || !g.bonds[static_cast<size_t>(k)].ring || sc.seen[static_cast<size_t>(v)] == stamp) continue;
+      if (k == k0 || !g.bonds[static_cast<size_t>(k)].ring || seen(v)) continue;
       sc.seen[static_cast<size_t>(v)] = stamp;
-      from[static_cast<size_t>(v)]    = u;
       depth[static_cast<size_t>(v)]   = depth[static_cast<size_t>(u)] + 1;
       queue.push_back(v);
     }
   }
-  if (sc.seen[static_cast<size_t>(b0.b)] != stamp) return ring;
-  for (int v = b0.b; v != -1; v = from[static_cast<size_t>(v)]) ring.push_back(v);
-  return ring;
+  if (!seen(b0.b)) return;
+  // all shortest paths back from the bond's second atom to its first: each step goes one level down
+  const size_t first = out.size();
+  path.assign(1, b0.b);
+  auto descend = [&](auto&& self, const int u) -> void {
+    if (out.size() - first >= kMaxRingsPerBond) return;
+    if (u == b0.a) {
+      out.push_back(path);
+      return;
+    }
+    for (const auto& [v, k] : adj[static_cast<size_t>(u)]) {
+      if (k == k0 || !g.bonds[static_cast<size_t>(k)].ring || !seen(v) || depth[static_cast<size_t>(v)] != depth[static_cast<size_t>(u)] - 1) continue;
+      path.push_back(v);
+      self(self, v);
+      path.pop_back();
+    }
+  };
+  descend(descend, b0.b);
 }
 
 bool huckel(const int electrons) { return electrons >= 2 && (electrons - 2) % 4 == 0; }
 
-// Perceives the aromatic rings of the Kekule-form part of the molecule: single rings of up to 8 atoms first, then unions
-// of 2 .. 6 fused rings (only the envelope of a union becomes aromatic: azulene's fusion bond stays single).  Returns how
-// many bonds are (would be) aromatic that were not before (-1: a fused system too large to decide); with `apply` the atoms
-// and bonds are marked.
+// Perceives the aromatic rings of the Kekule-form part of the molecule the way RDKit's default model does
+// (MolOps::setAromaticity, Code/GraphMol/Aromaticity.cpp):
+//   * candidate rings: rings all of whose atoms can donate (RDKit takes them from its symmetrised SSSR; here every shortest
+//     ring through each ring bond, the same set for everything but exotic cages);
+//   * two candidate rings are FUSED when they share exactly one bond and neither has more than 24 atoms (a porphyrin's
+//     inner 16-ring shares two bonds with each pyrrole ring: not fused, which is why RDKit leaves two C=C of a porphyrin
+//     non-aromatic);
+//   * in every fused system the combinations of 1, 2, ... 6 connected rings are tried in turn: the electrons of the atoms
+//     that lie in one or two of the combination's rings are counted (an atom shared by three rings is skipped), and when
+//     the count is 4n+2 every atom of those rings becomes aromatic and so does every bond that belongs to exactly one of
+//     them (azulene's fusion bond stays single); a system is finished once all its ring bonds are aromatic.
+// Returns how many atoms and bonds are (would be) aromatic that were not before, or -1 when a fused system has more
+// connected ring combinations than are enumerated here (the caller refuses the molecule); with `apply` they are marked.
+constexpr int    kMaxFusedRings      = 6;       // RDKit: maxNumFusedRings
+constexpr size_t kMaxFusedRingAtoms  = 24;      // RDKit: maxFusedAromaticRingSize
+constexpr int    kMaxRingSearch      = 64;      // longest single ring looked for
+constexpr size_t kMaxRingCombinations = 400000;  // per size and fused system (C60 itself stays far below)
+
 int perceive_aromaticity(Scratch& sc, const Adjacency& adj, const bool apply) {
   Graph&    g = sc.g;
   const int n = static_cast<int>(g.atoms.size());
@@ -715,117 +744,146 @@ int perceive_aromaticity(Scratch& sc, const Adjacency& adj, const bool apply) {
     return d;
   };
   std::vector<std::vector<int>> rings;      // atoms in cycle order
-  std::vector<std::vector<int>> ringBonds;  // their bonds
+  std::vector<std::vector<int>> ringBonds;  // their bonds, sorted
   {
-    std::vector<std::vector<int>> keys;
+    std::vector<std::vector<int>> keys, found;
     for (size_t k = 0; k < g.bonds.size(); ++k) {
       if (!g.bonds[k].ring || g.bonds[k].order == kAromatic || donates(g.bonds[k].a) < 0 || donates(g.bonds[k].b) < 0) continue;
-      const std::vector<int>& ring = smallest_ring_through(sc, adj, static_cast<int>(k), 8);
-      if (ring.empty()) continue;
-      bool ok = true;
-      for (const int v : ring) ok = ok && donates(v) >= 0;
-      if (!ok) continue;
-      std::vector<int> key = ring;
-      std::sort(key.begin(), key.end());
-      if (std::find(keys.begin(), keys.end(), key) != keys.end()) continue;
-      std::vector<int> bonds;
-      for (size_t j = 0; j < ring.size() && ok; ++j) {
-        const int u = ring[j], w = ring[(j + 1) % ring.size()];
-        int       found = -1;
-        for (const auto& [v, kb] : adj[static_cast<size_t>(u)])
-          if (v == w && g.bonds[static_cast<size_t>(kb)].ring) found = kb;
-        ok = found >= 0 && g.bonds[static_cast<size_t>(found)].order != kAromatic;  // aromatic-form rings are the input's business
-        bonds.push_back(found);
+      found.clear();
+      shortest_rings_through(sc, adj, static_cast<int>(k), kMaxRingSearch, found);
+      for (const std::vector<int>& ring : found) {
+        bool ok = true;
+        for (const int v : ring) ok = ok && donates(v) >= 0;
+        if (!ok) continue;
+        std::vector<int> key = ring;
+        std::sort(key.begin(), key.end());
+        if (std::find(keys.begin(), keys.end(), key) != keys.end()) continue;
+        std::vector<int> bonds;
+        for (size_t j = 0; j < ring.size() && ok; ++j) {
+          const int u = ring[j], w = ring[(j + 1) % ring.size()];
+          int       between = -1;
+          for (const auto& [v, kb] : adj[static_cast<size_t>(u)])
+            if (v == w && g.bonds[static_cast<size_t>(kb)].ring) between = kb;
+          ok = between >= 0 && g.bonds[static_cast<size_t>(between)].order != kAromatic;  // aromatic-form rings are the input's business
+          bonds.push_back(between);
+        }
+        if (!ok) continue;
+        std::sort(bonds.begin(), bonds.end());
+        keys.push_back(key);
+        rings.push_back(ring);
+        ringBonds.push_back(bonds);
       }
-      if (!ok) continue;
-      keys.push_back(key);
-      rings.push_back(ring);
-      ringBonds.push_back(bonds);
     }
   }
   const int nr = static_cast<int>(rings.size());
   if (nr == 0) return 0;
   std::vector<std::vector<int>> fused(static_cast<size_t>(nr));
-  for (int i = 0; i < nr; ++i)
+  for (int i = 0; i < nr; ++i) {
+    if (rings[static_cast<size_t>(i)].size() > kMaxFusedRingAtoms) continue;
     for (int j = i + 1; j < nr; ++j) {
-      bool share = false;
+      if (rings[static_cast<size_t>(j)].size() > kMaxFusedRingAtoms) continue;
+      int shared = 0;
       for (const int kb : ringBonds[static_cast<size_t>(i)])
-        share = share || std::find(ringBonds[static_cast<size_t>(j)].begin(), ringBonds[static_cast<size_t>(j)].end(), kb) !=
-                             ringBonds[static_cast<size_t>(j)].end();
-      if (share) {
+        shared += std::binary_search(ringBonds[static_cast<size_t>(j)].begin(), ringBonds[static_cast<size_t>(j)].end(), kb) ? 1 : 0;
+      if (shared == 1) {
         fused[static_cast<size_t>(i)].push_back(j);
         fused[static_cast<size_t>(j)].push_back(i);
       }
     }
-  {  // a fused system of more than 8 candidate rings (fullerene fragments, graphene-like sheets): RDKit reaches its aromatic
-     // atoms through unions larger than the ones grown below, so the molecule is refused rather than guessed (drug-like
-     // molecules have at most 6: tests/test_smiles_aromaticity.py)
-    std::vector<int> comp(static_cast<size_t>(nr), -1);
-    for (int r0 = 0; r0 < nr; ++r0) {
-      if (comp[static_cast<size_t>(r0)] >= 0) continue;
-      std::vector<int> stack{r0};
-      comp[static_cast<size_t>(r0)] = r0;
-      int size                      = 0;
-      while (!stack.empty()) {
-        const int u = stack.back();
-        stack.pop_back();
-        ++size;
-        for (const int w : fused[static_cast<size_t>(u)])
-          if (comp[static_cast<size_t>(w)] < 0) {
-            comp[static_cast<size_t>(w)] = r0;
-            stack.push_back(w);
-          }
+  }
+  std::vector<char> aromBond(g.bonds.size(), 0), aromAtom(static_cast<size_t>(n), 0);
+  std::vector<int>  ringCount(static_cast<size_t>(n), 0), bondCount(g.bonds.size(), 0);
+  using Combo = std::array<int, kMaxFusedRings>;  // ring indices in increasing order, -1 beyond the combination's size
+  // tries one combination; true when the whole fused system is aromatic afterwards
+  size_t systemBonds = 0, doneBonds = 0;
+  auto   try_combination = [&](const Combo& combo, const int size) {
+    int electrons = 0;
+    for (int c = 0; c < size; ++c)
+      for (const int v : rings[static_cast<size_t>(combo[static_cast<size_t>(c)])]) ++ringCount[static_cast<size_t>(v)];
+    for (int c = 0; c < size; ++c)
+      for (const int v : rings[static_cast<size_t>(combo[static_cast<size_t>(c)])]) {
+        int& cnt = ringCount[static_cast<size_t>(v)];
+        if (cnt == 1 || cnt == 2) electrons += donated[static_cast<size_t>(v)];
+        cnt = 0;  // each atom is counted once and the counter is ready for the next combination
       }
-      if (size > 8) return -1;
+    if (!huckel(electrons)) return false;
+    for (int c = 0; c < size; ++c) {
+      for (const int v : rings[static_cast<size_t>(combo[static_cast<size_t>(c)])]) aromAtom[static_cast<size_t>(v)] = 1;
+      for (const int kb : ringBonds[static_cast<size_t>(combo[static_cast<size_t>(c)])]) ++bondCount[static_cast<size_t>(kb)];
     }
-  }
-  std::vector<char> aromBond(g.bonds.size(), 0), aromAtom(static_cast<size_t>(n), 0), ringDone(static_cast<size_t>(nr), 0);
-  for (int i = 0; i < nr; ++i) {
-    int e = 0;
-    for (const int v : rings[static_cast<size_t>(i)]) e += donated[static_cast<size_t>(v)];
-    if (!huckel(e)) continue;
-    ringDone[static_cast<size_t>(i)] = 1;
-    for (const int v : rings[static_cast<size_t>(i)]) aromAtom[static_cast<size_t>(v)] = 1;
-    for (const int kb : ringBonds[static_cast<size_t>(i)]) aromBond[static_cast<size_t>(kb)] = 1;
-  }
-  // unions of fused rings, smallest first: connected subsets grown one ring at a time
-  std::vector<std::vector<int>> level;
-  for (int i = 0; i < nr; ++i) level.push_back({i});
-  for (int size = 2; size <= 6 && !level.empty(); ++size) {
-    std::vector<std::vector<int>> next;
-    for (const auto& sub : level)
-      for (const int v : sub)
-        for (const int w : fused[static_cast<size_t>(v)]) {
-          if (std::find(sub.begin(), sub.end(), w) != sub.end()) continue;
-          std::vector<int> bigger = sub;
-          bigger.push_back(w);
-          std::sort(bigger.begin(), bigger.end());
-          if (std::find(next.begin(), next.end(), bigger) == next.end()) next.push_back(bigger);
+    for (int c = 0; c < size; ++c)
+      for (const int kb : ringBonds[static_cast<size_t>(combo[static_cast<size_t>(c)])]) {
+        int& cnt = bondCount[static_cast<size_t>(kb)];
+        if (cnt == 1 && !aromBond[static_cast<size_t>(kb)]) {
+          aromBond[static_cast<size_t>(kb)] = 1;
+          ++doneBonds;
         }
-    if (next.size() > 4096) return -1;  // a huge fused system (fullerenes): not decided here, the caller refuses the molecule
-    for (const auto& combo : next) {
-      bool allDone = true;
-      for (const int i : combo) allDone = allDone && ringDone[static_cast<size_t>(i)];
-      if (allDone) continue;
-      std::vector<char> inUnion(static_cast<size_t>(n), 0);
-      int               e = 0;
-      for (const int i : combo)
-        for (const int v : rings[static_cast<size_t>(i)])
-          if (!inUnion[static_cast<size_t>(v)]) {
-            inUnion[static_cast<size_t>(v)] = 1;
-            e += donated[static_cast<size_t>(v)];
-          }
-      if (!huckel(e)) continue;
-      std::vector<int> count(g.bonds.size(), 0);
-      for (const int i : combo)
-        for (const int kb : ringBonds[static_cast<size_t>(i)]) ++count[static_cast<size_t>(kb)];
-      for (const int i : combo) ringDone[static_cast<size_t>(i)] = 1;
-      for (int v = 0; v < n; ++v)
-        if (inUnion[static_cast<size_t>(v)]) aromAtom[static_cast<size_t>(v)] = 1;
-      for (size_t kb = 0; kb < count.size(); ++kb)
-        if (count[kb] == 1) aromBond[kb] = 1;  // the envelope of the union
+        if (cnt == 1) cnt = 0;
+      }
+    for (int c = 0; c < size; ++c)
+      for (const int kb : ringBonds[static_cast<size_t>(combo[static_cast<size_t>(c)])]) bondCount[static_cast<size_t>(kb)] = 0;
+    return doneBonds >= systemBonds;
+  };
+  std::vector<int>   system(static_cast<size_t>(nr), -1), members, stack;
+  std::vector<char>  bondSeen(g.bonds.size(), 0);
+  std::vector<Combo> level, next;
+  for (int r0 = 0; r0 < nr; ++r0) {
+    if (system[static_cast<size_t>(r0)] >= 0) continue;
+    members.clear();
+    stack.assign(1, r0);
+    system[static_cast<size_t>(r0)] = r0;
+    while (!stack.empty()) {
+      const int u = stack.back();
+      stack.pop_back();
+      members.push_back(u);
+      for (const int w : fused[static_cast<size_t>(u)])
+        if (system[static_cast<size_t>(w)] < 0) {
+          system[static_cast<size_t>(w)] = r0;
+          stack.push_back(w);
+        }
     }
-    level.swap(next);
+    std::sort(members.begin(), members.end());
+    systemBonds = doneBonds = 0;
+    for (const int i : members)
+      for (const int kb : ringBonds[static_cast<size_t>(i)])
+        if (!bondSeen[static_cast<size_t>(kb)]) {
+          bondSeen[static_cast<size_t>(kb)] = 1;
+          ++systemBonds;
+        }
+    for (const int i : members)
+      for (const int kb : ringBonds[static_cast<size_t>(i)]) bondSeen[static_cast<size_t>(kb)] = 0;
+    level.clear();
+    for (const int i : members) {
+      Combo c;
+      c.fill(-1);
+      c[0] = i;
+      level.push_back(c);
+    }
+    bool finished = false;
+    for (int size = 1; size <= kMaxFusedRings && !level.empty() && !finished; ++size) {
+      for (const Combo& combo : level)
+        if (try_combination(combo, size)) {
+          finished = true;
+          break;
+        }
+      if (finished || size == kMaxFusedRings || size >= static_cast<int>(members.size())) break;
+      // connected combinations of size + 1 rings: every combination of this size extended by a ring fused to one of its own
+      next.clear();
+      for (const Combo& combo : level)
+        for (int c = 0; c < size; ++c)
+          for (const int w : fused[static_cast<size_t>(combo[static_cast<size_t>(c)])]) {
+            if (std::find(combo.begin(), combo.begin() + size, w) != combo.begin() + size) continue;
+            Combo bigger                         = combo;
+            bigger[static_cast<size_t>(size)] = w;
+            std::sort(bigger.begin(), bigger.begin() + size + 1);
+            next.push_back(bigger);
+            if (next.size() > 8 * kMaxRingCombinations) return -1;
+          }
+      std::sort(next.begin(), next.end());
+      next.erase(std::unique(next.begin(), next.end()), next.end());
+      if (next.size() > kMaxRingCombinations) return -1;
+      level.swap(next);
+    }
   }
   int changed = 0;
   for (size_t kb = 0; kb < aromBond.size(); ++kb)
@@ -833,31 +891,12 @@ int perceive_aromaticity(Scratch& sc, const Adjacency& adj, const bool apply) {
       ++changed;
       if (apply) g.bonds[kb].order = kAromatic;
     }
-  if (apply)
-    for (int v = 0; v < n; ++v)
-      if (aromAtom[static_cast<size_t>(v)]) g.atoms[static_cast<size_t>(v)].aromatic = true;
-  return changed;
-}
-
-// A conjugated macrocycle (9 .. 24 atoms, e.g. the inner ring of a porphyrin) that satisfies Hueckel's rule: RDKit marks
-// such rings aromatic as part of larger fused unions than are grown here, so the molecule is refused rather than guessed.
-bool conjugated_macrocycle(Scratch& sc, const Adjacency& adj) {
-  const Graph& g = sc.g;
-  for (size_t k = 0; k < g.bonds.size(); ++k) {
-    if (!g.bonds[k].ring || g.bonds[k].order != kDouble) continue;
-    const std::vector<int>& ring = smallest_ring_through(sc, adj, static_cast<int>(k), 24);
-    if (ring.size() < 9) continue;
-    int  e  = 0;
-    bool ok = true;
-    for (const int v : ring) {
-      const int d = donated_electrons(g, adj, v);
-      // atoms already aromatic (pyrrole rings of a porphyrin) count with what they would give
-      ok = ok && (d >= 0 || g.atoms[static_cast<size_t>(v)].aromatic);
-      e += d >= 0 ? d : 1;
+  for (int v = 0; v < n; ++v)
+    if (aromAtom[static_cast<size_t>(v)] && !g.atoms[static_cast<size_t>(v)].aromatic) {
+      ++changed;
+      if (apply) g.atoms[static_cast<size_t>(v)].aromatic = true;
     }
-    if (ok && huckel(e)) return true;
-  }
-  return false;
+  return changed;
 }
 
 void build(const char* s, Scratch& sc, const unsigned flags) {
@@ -898,7 +937,7 @@ void build(const char* s, Scratch& sc, const unsigned flags) {
   const Adjacency adj{sc};
   const bool      apply   = (flags & NVMK_SMILES_PERCEIVE_AROMATICITY) != 0u;
   const int       changed = perceive_aromaticity(sc, adj, apply);
-  if (changed < 0 || (changed > 0 && !apply) || conjugated_macrocycle(sc, adj)) g.status = kNeedsAromaticity;
+  if (changed < 0 || (changed > 0 && !apply)) g.status = kNeedsAromaticity;
 }
 
 uint32_t hash_combine(const uint32_t seed, const uint32_t v) { return seed ^ (v + 0x9e3779b9u + (seed << 6) + (seed >> 2)); }

@@ -9,7 +9,10 @@ against RDKit's model on thousands of real molecules without RDKit being install
 The perception rules restated here are RDKit's default model as documented in the RDKit Book ("Aromaticity") and visible
 in its behaviour: ring atoms donate 1 electron through a ring double bond, 2 through a lone pair (pyrrole-type N, O, S,
 carbanion), 0 when an exocyclic double bond to N / O / S takes the electron or the atom has an empty p orbital (carbocation,
-three-coordinate boron); rings and unions of fused rings with 4k + 2 electrons are aromatic.
+three-coordinate boron); rings and unions of fused rings with 4k + 2 electrons are aromatic.  How the unions are formed
+(rings fused through exactly one shared bond, combinations of up to six rings, atoms shared by three rings left out of the
+count, only bonds of a single ring of the combination marked) follows RDKit's implementation; the 15 porphyrins and 7
+fullerene adducts of the ChEMBL file are what pins those details.
 
 Only tests/ may import this module.
 """
@@ -164,26 +167,40 @@ def write_bracket_smiles(atom_table, bond_types, bond_table):
 
 
 # ---- perception (independent restatement) ----------------------------------------------------------------------------------
-def _smallest_ring_through(n, adj, bond_ring, k0, a, b):
-    """atoms of the shortest cycle through bond k0 = (a, b) that uses ring bonds only, or None."""
-    prev = {a: None}
-    frontier = [a]
-    while frontier and b not in prev:
-        nxt = []
-        for u in frontier:
-            for v, k in adj[u]:
-                if k == k0 or not bond_ring[k] or v in prev:
-                    continue
-                prev[v] = u
-                nxt.append(v)
-        frontier = nxt
-    if b not in prev:
-        return None
-    ring, v = [], b
-    while v is not None:
-        ring.append(v)
-        v = prev[v]
-    return ring
+def _shortest_rings_through(adj, bond_ring, k0, a, b, limit=16):
+    """every shortest cycle through bond k0 = (a, b) that uses ring bonds only (lists of atoms in cycle order).  Found from
+    the two distance maps of the graph without k0: an atom lies on a shortest a-b path iff dist_a + dist_b is minimal."""
+    def distances(src):
+        dist, frontier = {src: 0}, [src]
+        while frontier:
+            nxt = []
+            for u in frontier:
+                for v, k in adj[u]:
+                    if k != k0 and bond_ring[k] and v not in dist:
+                        dist[v] = dist[u] + 1
+                        nxt.append(v)
+            frontier = nxt
+        return dist
+
+    da = distances(a)
+    if b not in da:
+        return []
+    db, total = distances(b), da[b]
+    rings = []
+
+    def walk(path):
+        u = path[-1]
+        if len(rings) >= limit:
+            return
+        if u == b:
+            rings.append(list(path))
+            return
+        for v, k in adj[u]:
+            if k != k0 and bond_ring[k] and da.get(v) == da[u] + 1 and da[v] + db.get(v, total + 1) == total:
+                walk(path + [v])
+
+    walk([a])
+    return rings
 
 
 def _donated_electrons(i, atom_table, adj, types, bond_ring):
@@ -238,9 +255,15 @@ def _donated_electrons(i, atom_table, adj, types, bond_ring):
     return None
 
 
-def perceive(atom_table, bond_table, types=None, max_fused=6):
+def perceive(atom_table, bond_table, types=None, max_fused=6, max_fused_ring_atoms=24):
     """(aromatic atom flags, bond types with 12 on aromatic bonds) for a Kekule-form molecule (``types`` overrides the bond
-    types of ``bond_table``)."""
+    types of ``bond_table``) — RDKit's default model the way its implementation goes about it: candidate rings (all atoms can
+    donate); rings are fused when they share exactly ONE bond (and have at most 24 atoms); per fused system every
+    combination of 1 .. 6 rings that hangs together is tried in order of size: electrons are counted over the atoms that are
+    in one or two of the combination's rings, 4k + 2 makes all atoms of those rings aromatic and the bonds that belong to
+    exactly one of them; a system is finished when all its ring bonds are aromatic."""
+    import itertools
+
     n = len(atom_table)
     types = (bond_table[:, 2] if types is None else np.asarray(types)).copy()
     bond_ring = bond_table[:, 3].astype(bool)
@@ -253,47 +276,74 @@ def perceive(atom_table, bond_table, types=None, max_fused=6):
     for k, (a, b, _, _) in enumerate(bond_table):
         if not bond_ring[k]:
             continue
-        ring = _smallest_ring_through(n, adj, bond_ring, k, int(a), int(b))
-        if ring is None or len(ring) > 8:
-            continue
-        if any(donated[v] is None for v in ring):
-            continue
-        rings[tuple(sorted(ring))] = ring
+        for ring in _shortest_rings_through(adj, bond_ring, k, int(a), int(b)):
+            if all(donated[v] is not None for v in ring):
+                rings.setdefault(tuple(sorted(ring)), ring)
     rings = list(rings.values())
     ring_bonds = []
     for ring in rings:
         members = set(ring)
         ring_bonds.append({k for v in ring for w, k in adj[v] if w in members and bond_ring[k] and _consecutive(ring, v, w)})
-    fused = [[j for j in range(len(rings)) if j != i and ring_bonds[i] & ring_bonds[j]] for i in range(len(rings))]
+    nr = len(rings)
+    fused = [{j for j in range(nr) if j != i and len(ring_bonds[i] & ring_bonds[j]) == 1
+              and len(rings[i]) <= max_fused_ring_atoms and len(rings[j]) <= max_fused_ring_atoms} for i in range(nr)]
     arom_atom = np.zeros(n, dtype=bool)
     arom_bond = np.zeros(len(types), dtype=bool)
-    ring_done = [False] * len(rings)
 
-    def huckel(atom_set):
-        e = sum(donated[v] for v in atom_set)
-        return e >= 2 and (e - 2) % 4 == 0
+    def hangs_together(combo):
+        seen, todo = {combo[0]}, [combo[0]]
+        while todo:
+            u = todo.pop()
+            for w in fused[u]:
+                if w in combo and w not in seen:
+                    seen.add(w)
+                    todo.append(w)
+        return len(seen) == len(combo)
 
-    # single rings first, then unions of 2, 3, ... fused rings (only those with a ring that is not aromatic yet)
-    for i, ring in enumerate(rings):
-        if huckel(set(ring)):
-            ring_done[i] = True
-            arom_atom[list(ring)] = True
-            arom_bond[list(ring_bonds[i])] = True
-    for size in range(2, max_fused + 1):
-        for combo in _connected_subsets(fused, size):
-            if all(ring_done[i] for i in combo):
-                continue
-            atoms = set().union(*(set(rings[i]) for i in combo))
-            if not huckel(atoms):
-                continue
-            count = {}
-            for i in combo:
-                for k in ring_bonds[i]:
-                    count[k] = count.get(k, 0) + 1
-            for i in combo:
-                ring_done[i] = True
-            arom_atom[list(atoms)] = True
-            arom_bond[[k for k, c in count.items() if c == 1]] = True       # the envelope of the union
+    system_of = list(range(nr))                      # union-find over the "fused" relation
+
+    def root(i):
+        while system_of[i] != i:
+            i = system_of[i]
+        return i
+
+    for i in range(nr):
+        for j in fused[i]:
+            system_of[root(i)] = root(j)
+    systems = {}
+    for i in range(nr):
+        systems.setdefault(root(i), []).append(i)
+    for members in systems.values():
+        all_bonds = set().union(*(ring_bonds[i] for i in members))
+        done = set()
+        for size in range(1, min(len(members), max_fused) + 1):
+            n_combos = 1
+            for t in range(size):
+                n_combos = n_combos * (len(members) - t) // (t + 1)
+            combos = itertools.combinations(members, size) if n_combos <= 200000 else _connected_subsets(fused, members, size)
+            for combo in combos:
+                if size > 1 and not hangs_together(combo):
+                    continue
+                in_rings = {}
+                for i in combo:
+                    for v in rings[i]:
+                        in_rings[v] = in_rings.get(v, 0) + 1
+                e = sum(donated[v] for v, c in in_rings.items() if c <= 2)
+                if not (e >= 2 and (e - 2) % 4 == 0):
+                    continue
+                in_bonds = {}
+                for i in combo:
+                    for k in ring_bonds[i]:
+                        in_bonds[k] = in_bonds.get(k, 0) + 1
+                arom_atom[list(in_rings)] = True
+                for k, c in in_bonds.items():
+                    if c == 1:
+                        arom_bond[k] = True
+                        done.add(k)
+                if len(done) >= len(all_bonds):
+                    break
+            if len(done) >= len(all_bonds):
+                break
     types[arom_bond] = 12
     return arom_atom, types
 
@@ -303,17 +353,10 @@ def _consecutive(ring, v, w):
     return ring[(i + 1) % len(ring)] == w or ring[i - 1] == w
 
 
-def _connected_subsets(neigh, size):
-    """all connected subsets of `size` nodes of the graph given by adjacency lists (each once, as sorted tuples)."""
-    level = {frozenset([v]) for v in range(len(neigh))}
+def _connected_subsets(neigh, members, size):
+    """all connected subsets of `size` nodes among `members` of the graph given by neighbour sets (sorted tuples, in order)."""
+    allowed = set(members)
+    level = {frozenset([v]) for v in members}
     for _ in range(size - 1):
-        nxt = set()
-        for sub in level:
-            for v in sub:
-                for w in neigh[v]:
-                    if w not in sub:
-                        nxt.add(sub | {w})
-        level = nxt
-        if len(level) > 20000:      # a huge fused system: give up on unions of this size
-            return []
+        level = {sub | {w} for sub in level for v in sub for w in neigh[v] if w in allowed and w not in sub}
     return sorted(tuple(sorted(sub)) for sub in level)

@@ -1,8 +1,9 @@
 """Aromaticity perception of the SMILES ingestion (SmilesSet(..., perceive_aromaticity=True)) against RDKit itself, without
 RDKit: the reference's ChEMBL SMILES were written by RDKit in aromatic form, so their lower-case atoms ARE RDKit's perception.
 Every aromatic molecule is turned into a Kekule form by the oracle, written out with bracket atoms and handed to the library,
-which must give back exactly the aromatic atoms and bonds RDKit recorded (or refuse: conjugated macrocycles such as
-porphyrins, whose aromaticity RDKit derives from unions of more rings than the library grows)."""
+which must give back exactly the aromatic atoms and bonds RDKit recorded — for every one of them, the 15 porphyrins (two C=C
+stay double: the inner 16-ring shares two bonds with each pyrrole ring, so RDKit does not treat them as fused) and the 7
+fullerene adducts (atoms shared by three rings) included."""
 
 from pathlib import Path
 
@@ -41,7 +42,7 @@ def _check(smiles, max_refused):
     assert np.all(refused.status == 3)
     n_refused = 0
     for j, (i, text, order, atoms, bonds) in enumerate(forms):
-        if got.status[j] == 3:                                       # conjugated macrocycle
+        if got.status[j] == 3:                                       # a fused system with too many ring combinations
             n_refused += 1
             continue
         assert got.status[j] == 0, (smiles[i], int(got.status[j]))
@@ -58,13 +59,13 @@ def _check(smiles, max_refused):
 
 
 def test_perception_reproduces_rdkits_aromaticity_on_chembl_1k():
-    n, refused = _check(_lines("chembl_1k.smi"), max_refused=5)      # the five porphyrins of the file
+    n, refused = _check(_lines("chembl_1k.smi"), max_refused=0)
     assert n > 700
 
 
 def test_perception_reproduces_rdkits_aromaticity_on_chembl_10k():
-    n, refused = _check(_lines("chembl_10k.smi"), max_refused=25)    # 15 porphyrins and 7 fullerene adducts among 8864 aromatic molecules
-    assert n > 8000 and refused > 0
+    n, refused = _check(_lines("chembl_10k.smi"), max_refused=0)     # 8864 aromatic molecules, none refused
+    assert n > 8000 and refused == 0
 
 
 def test_oracle_perception_agrees_with_the_library_on_kekule_forms():
@@ -86,7 +87,11 @@ def test_oracle_perception_agrees_with_the_library_on_kekule_forms():
     ("CN1C=NC2=C1C(=O)N(C)C(=O)N2C", 10),                                                       # caffeine: both rings
     ("C=C1C=CC=CC1=C", 6),                                                                      # o-xylylene: exocyclic C=C gives 1 electron each
     ("C1=CCCCC1", 0), ("O=C1C=CC(=O)C=C1", 0), ("C1=CC=CC1", 0), ("C=C1C=CC=C1", 0), ("C1=CC2=CC=CC2=C1", 0),
-    ("C1=CC=CC=CC=C1", 0), ("C1=CC=CCC=C1", 0), ("O=C1C=CC=C1", 0), ("N1=P(Cl)(Cl)N=P(Cl)(Cl)N=P1(Cl)Cl", 0)])
+    ("C1=CC=CC=CC=C1", 0), ("C1=CC=CCC=C1", 0), ("O=C1C=CC=C1", 0), ("N1=P(Cl)(Cl)N=P(Cl)(Cl)N=P1(Cl)Cl", 0),
+    ("C1=CC2=CC=C3C=CC=C4C=CC(=C1)C2=C34", 19),                                                 # pyrene: the two inner atoms lie in three rings
+    ("C1=CC2=CC=C3C=CC4=CC=C5C=CC6=CC=C1C7=C6C5=C4C3=C27", 30),                                # coronene
+    ("C1=CC2=CC3=CC=C(N3)C=C4C=CC(=N4)C=C5C=CC(=CC1=N2)N5", 22),                               # porphine: two C=C stay double (RDKit)
+    ("C1=CC=CC=CC=CC=CC=CC=CC=CC=C1", 18)])                                                     # [18]annulene: a single 18-ring
 def test_textbook_rings(smi, n_aromatic_bonds):
     s = SmilesSet([smi], perceive_aromaticity=True)
     assert s.status[0] == 0
