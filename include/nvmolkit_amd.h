@@ -397,9 +397,10 @@ int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, co
 /* ---- SMILES ingestion for the fingerprint path (host code, no GPU involved) ----------------
  * Replaces what the reference takes from RDKit before MorganInvariantsGenerator::ComputeInvariantsInto can run
  * (RDKit::SmilesToMol + sanitisation: src/morgan_fingerprint_common.cpp:43-124 works on ROMol objects; the reference's
- * benchmarks read benchmarks/data/chembl_10k.smi through RDKit).  Scope and rules: nvmolkit_amd/csrc/smiles.cpp — aromaticity is
- * taken from the input (aromatic-form SMILES such as RDKit's canonical output); Kekule-form aromatic rings and valences
- * RDKit's sanitisation rejects or rewrites are REFUSED per molecule, never fingerprinted differently from RDKit.
+ * benchmarks read benchmarks/data/chembl_10k.smi through RDKit).  Scope and rules: nvmolkit_amd/csrc/smiles.cpp — like RDKit's
+ * sanitisation every molecule is Kekulised and its aromaticity perceived again (RDKit's default model); by default the result
+ * must equal what the input wrote (true for SMILES written by RDKit), else the molecule is REFUSED per molecule, as are
+ * valences RDKit's sanitisation rejects or rewrites: nothing is ever fingerprinted differently from RDKit.
  *   nvmk_smiles_parse        : n_mols NUL- or whitespace-terminated strings -> an opaque set of graphs (n_threads <= 0: all
  *                              host threads).  Never fails on bad chemistry: the per-molecule status says what happened.
  *   nvmk_smiles_parse_text   : the same for one text buffer with a molecule per line (a .smi file as it is read from disk:
@@ -417,12 +418,13 @@ int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, co
 #define NVMK_SMILES_OK 0
 #define NVMK_SMILES_SYNTAX_ERROR 1
 #define NVMK_SMILES_VALENCE_ERROR 2      /* RDKit: "Explicit valence for atom ... is greater than permitted" */
-#define NVMK_SMILES_NEEDS_AROMATICITY 3  /* Kekule-form ring RDKit would perceive as aromatic */
+#define NVMK_SMILES_NEEDS_AROMATICITY 3  /* RDKit would perceive the aromaticity differently from what the input wrote (Kekule form) */
 #define NVMK_SMILES_TOO_MANY_BONDS 4     /* more than 8 bonds on one atom (kMaxBondsPerAtom of the reference) */
+#define NVMK_SMILES_NO_KEKULE_FORM 5     /* RDKit: "Can't kekulize mol" / "non-ring atom marked aromatic" */
 int nvmk_smiles_parse(const char* const* smiles, int64_t n_mols, int n_threads, void** handle);
-/* flags = NVMK_SMILES_PERCEIVE_AROMATICITY: Kekule-form rings are perceived with RDKit's default aromaticity model (electron
- * donation rules and fused-ring unions of the RDKit Book; checked against the aromaticity RDKit recorded in the reference's
- * ChEMBL SMILES: all 8864 aromatic molecules of the 10 000 reproduced) instead of being refused. */
+/* flags = NVMK_SMILES_PERCEIVE_AROMATICITY: the perceived aromaticity (RDKit's default model: electron donation rules and
+ * fused-ring combinations; checked against the aromaticity RDKit recorded in the reference's ChEMBL SMILES: all 8864 aromatic
+ * molecules of the 10 000 reproduced) is applied, whatever form the input was written in, instead of refusing a difference. */
 #define NVMK_SMILES_PERCEIVE_AROMATICITY 1u
 int nvmk_smiles_parse_flags(const char* const* smiles, int64_t n_mols, int n_threads, unsigned flags, void** handle);
 int nvmk_smiles_parse_text(const char* text, int64_t n_bytes, int n_threads, unsigned flags, void** handle);

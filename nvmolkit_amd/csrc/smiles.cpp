@@ -11,20 +11,20 @@
 //     count their aromatic bonds as 1.5 and take no hydrogen beyond the default valence);
 //   * ring membership = the atom lies on a cycle (it has a bond that is not a bridge of the graph), which is what
 //     RingInfo::numAtomRings(i) > 0 says for a cycle basis;
-//   * AROMATICITY IS TAKEN FROM THE INPUT: lower-case atoms are aromatic and an unmarked ring bond between two of them is
-//     an aromatic bond, as RDKit's canonical SMILES (ChEMBL, the reference's benchmarks/data/chembl_10k.smi) are written.
-//     RDKit would additionally perceive aromaticity in Kekule-form input; a molecule with a Kekule-form ring that
-//     satisfies Hueckel's rule is therefore REFUSED (status NVMK_SMILES_NEEDS_AROMATICITY) instead of being
-//     fingerprinted with bond types RDKit would not use.  Valences RDKit's sanitisation rejects (or rewrites, like
-//     five-valent nitro groups) are refused as well.
-//   * OPT-IN PERCEPTION (nvmk_smiles_parse_flags, NVMK_SMILES_PERCEIVE_AROMATICITY): RDKit's default aromaticity model
-//     (perceive_aromaticity below) - candidate rings are the shortest rings through each ring bond whose atoms can all
+//   * AROMATICITY IS RDKIT'S, NOT THE INPUT'S.  Like RDKit's sanitisation, every molecule is first Kekulised (what the
+//     input wrote in lower case gets alternating single / double bonds; no Kekule structure = refused, RDKit's "Can't
+//     kekulize mol") and its aromaticity is then perceived from the Kekule structure with RDKit's default model
+//     (perceive_aromaticity below: candidate rings are the shortest rings through each ring bond whose atoms can all
 //     donate, electrons per atom from its unsaturation / lone pair / exocyclic double bond, 4n+2 over single rings and
-//     over combinations of up to six rings fused through single shared bonds.  The restatement is checked on the
+//     over combinations of up to six rings fused through single shared bonds).  By default the outcome must EQUAL what the
+//     input said - which is the case for SMILES RDKit wrote (all 10 000 of the reference's benchmark file) - otherwise the
+//     molecule is refused (NVMK_SMILES_NEEDS_AROMATICITY: Kekule-form input, or aromatic input from another toolkit's
+//     model) rather than fingerprinted with bond types RDKit would not use.  With NVMK_SMILES_PERCEIVE_AROMATICITY
+//     (nvmk_smiles_parse_flags) the outcome is applied instead, as RDKit does.  The perception is checked on the
 //     aromaticity RDKit itself recorded: every aromatic ChEMBL SMILES of tests/golden is Kekulised by the oracle, read
-//     back here and comes out with exactly the aromatic atoms and bonds RDKit wrote - all 8864 molecules of the 10 000,
-//     porphyrins and fullerene adducts included (tests/test_smiles_aromaticity.py).  Only a fused system with more than
-//     400 000 connected ring combinations of one size (nothing in the data comes close) is refused in this mode.
+//     back here and comes out with exactly the aromatic atoms and bonds RDKit wrote - all 8864 aromatic molecules of the
+//     10 000, porphyrins and fullerene adducts included (tests/test_smiles_aromaticity.py).  Valences RDKit's
+//     sanitisation rejects (or rewrites, like five-valent nitro groups) are refused as well.
 // Host throughput: one call parses a whole text buffer (nvmk_smiles_parse_text) or an array of strings on all host threads;
 // each thread works in its own Scratch (no allocation per molecule) and fills chunks of 512 molecules stored back to back.
 // Parity against RDKit's parser cannot be pinned in this image; the independent Python restatement oracle/smiles.py, the
@@ -54,6 +54,7 @@ enum Status : int8_t {
   kValence          = NVMK_SMILES_VALENCE_ERROR,
   kNeedsAromaticity = NVMK_SMILES_NEEDS_AROMATICITY,
   kTooManyBonds     = NVMK_SMILES_TOO_MANY_BONDS,
+  kNoKekuleForm     = NVMK_SMILES_NO_KEKULE_FORM,
 };
 
 // RDKit bond type values (Bond::BondType): what the Morgan bond invariant is (morgan_fingerprint_common.cpp:100)
@@ -94,6 +95,15 @@ struct Scratch {
   std::vector<Atom> keptAtoms;
   std::vector<Bond> keptBonds;
   std::vector<int> donated, from, depth, queue, ring;  // aromaticity
+  // candidate rings and fused systems of the perception, all flat: ring r = ringAtoms[ringStart[r] .. ringStart[r + 1]) in
+  // cycle order, its bonds (sorted) at the same positions of ringBonds; shortest_rings_through appends to found*
+  std::vector<int> ringStart, ringAtoms, ringBonds, foundStart, foundAtoms, fusedStart, fusedList, fusedFill;
+  std::vector<int> ringCount, bondCount, systemOf, members, ringStack, pathBonds;
+  std::vector<char> aromAtom, aromBond, bondSeen;
+  std::vector<std::array<int, 6>> level, next;
+  std::vector<int> sigma, partner, free_;           // Kekule structure of the aromatic part
+  std::vector<char> needs, inputAromatic;
+  std::vector<uint8_t> inputOrder;
   std::vector<unsigned> seen;                       // visit stamps of the ring search
   unsigned         stamp = 0;
 };
@@ -659,11 +669,11 @@ int donated_electrons(const Graph& g, const Adjacency& adj, const int i) {
 }
 
 // Every shortest cycle through bond k0 over ring bonds (cycle order, starting at the bond's second atom), appended to
-// `out`; nothing when the shortest is longer than maxLen.  Taken over all ring bonds these are the rings RDKit's
+// sc.foundAtoms / sc.foundStart; nothing when the shortest is longer than maxLen.  Taken over all ring bonds these are the rings RDKit's
 // symmetrised SSSR holds for everything but exotic cages: a bond between two hexagons of a fullerene gives both hexagons,
 // a bond of norbornane's one-atom bridge both five-rings, and the six-ring around them is never the shortest for any bond.
 constexpr size_t kMaxRingsPerBond = 16;
-void shortest_rings_through(Scratch& sc, const Adjacency& adj, const int k0, const int maxLen, std::vector<std::vector<int>>& out) {
+void shortest_rings_through(Scratch& sc, const Adjacency& adj, const int k0, const int maxLen) {
   const Graph& g  = sc.g;
   const size_t n  = g.atoms.size();
   const Bond&  b0 = g.bonds[static_cast<size_t>(k0)];
@@ -692,12 +702,13 @@ void shortest_rings_through(Scratch& sc, const Adjacency& adj, const int k0, con
   }
   if (!seen(b0.b)) return;
   // all shortest paths back from the bond's second atom to its first: each step goes one level down
-  const size_t first = out.size();
+  const size_t first = sc.foundStart.size();
   path.assign(1, b0.b);
   auto descend = [&](auto&& self, const int u) -> void {
-    if (out.size() - first >= kMaxRingsPerBond) return;
+    if (sc.foundStart.size() - first >= kMaxRingsPerBond) return;
     if (u == b0.a) {
-      out.push_back(path);
+      sc.foundStart.push_back(static_cast<int>(sc.foundAtoms.size()));
+      sc.foundAtoms.insert(sc.foundAtoms.end(), path.begin(), path.end());
       return;
     }
     for (const auto& [v, k] : adj[static_cast<size_t>(u)]) {
@@ -731,11 +742,11 @@ constexpr int    kMaxRingSearch      = 64;      // longest single ring looked fo
 constexpr size_t kMaxRingCombinations = 400000;  // per size and fused system (C60 itself stays far below)
 
 int perceive_aromaticity(Scratch& sc, const Adjacency& adj, const bool apply) {
-  Graph&    g = sc.g;
-  const int n = static_cast<int>(g.atoms.size());
+  Graph&       g = sc.g;
+  const int    n = static_cast<int>(g.atoms.size());
+  const size_t m = g.bonds.size();
   // A candidate ring has no aromatic bond and only atoms that can donate; a ring found through a bond that is aromatic
-  // itself or ends in an atom that cannot donate would be discarded below, so the search starts from the other bonds only
-  // (none at all in most aromatic-form input: the electron counts are then never needed).
+  // itself or ends in an atom that cannot donate would be discarded below, so the search starts from the other bonds only.
   auto& donated = sc.donated;
   donated.assign(static_cast<size_t>(n), -2);  // -2: not computed yet
   auto donates = [&](const int i) {
@@ -743,115 +754,167 @@ int perceive_aromaticity(Scratch& sc, const Adjacency& adj, const bool apply) {
     if (d == -2) d = donated_electrons(g, adj, i);
     return d;
   };
-  std::vector<std::vector<int>> rings;      // atoms in cycle order
-  std::vector<std::vector<int>> ringBonds;  // their bonds, sorted
-  {
-    std::vector<std::vector<int>> keys, found;
-    for (size_t k = 0; k < g.bonds.size(); ++k) {
-      if (!g.bonds[k].ring || g.bonds[k].order == kAromatic || donates(g.bonds[k].a) < 0 || donates(g.bonds[k].b) < 0) continue;
-      found.clear();
-      shortest_rings_through(sc, adj, static_cast<int>(k), kMaxRingSearch, found);
-      for (const std::vector<int>& ring : found) {
-        bool ok = true;
-        for (const int v : ring) ok = ok && donates(v) >= 0;
-        if (!ok) continue;
-        std::vector<int> key = ring;
-        std::sort(key.begin(), key.end());
-        if (std::find(keys.begin(), keys.end(), key) != keys.end()) continue;
-        std::vector<int> bonds;
-        for (size_t j = 0; j < ring.size() && ok; ++j) {
-          const int u = ring[j], w = ring[(j + 1) % ring.size()];
-          int       between = -1;
-          for (const auto& [v, kb] : adj[static_cast<size_t>(u)])
-            if (v == w && g.bonds[static_cast<size_t>(kb)].ring) between = kb;
-          ok = between >= 0 && g.bonds[static_cast<size_t>(between)].order != kAromatic;  // aromatic-form rings are the input's business
-          bonds.push_back(between);
-        }
-        if (!ok) continue;
-        std::sort(bonds.begin(), bonds.end());
-        keys.push_back(key);
-        rings.push_back(ring);
-        ringBonds.push_back(bonds);
+  auto& ringStart = sc.ringStart;
+  auto& ringAtoms = sc.ringAtoms;
+  auto& ringBonds = sc.ringBonds;
+  ringStart.assign(1, 0);
+  ringAtoms.clear();
+  ringBonds.clear();
+  // An atom with exactly two ring bonds forces every ring through one of them through the other as well: when that other
+  // bond came earlier in this loop, all shortest rings through the present one have been found with it (or are no
+  // candidates, if it was passed over), and the search is skipped - one search per ring instead of one per bond.
+  auto earlier_twin = [&](const int u, const int k) {
+    int ringBondsOfU = 0, other = -1;
+    for (const auto& [v, kb] : adj[static_cast<size_t>(u)])
+      if (g.bonds[static_cast<size_t>(kb)].ring) {
+        ++ringBondsOfU;
+        if (kb != k) other = kb;
       }
+    return ringBondsOfU == 2 && other < k;
+  };
+  for (size_t k = 0; k < m; ++k) {
+    if (!g.bonds[k].ring || g.bonds[k].order == kAromatic || donates(g.bonds[k].a) < 0 || donates(g.bonds[k].b) < 0) continue;
+    if (earlier_twin(g.bonds[k].a, static_cast<int>(k)) || earlier_twin(g.bonds[k].b, static_cast<int>(k))) continue;
+    sc.foundStart.clear();
+    sc.foundAtoms.clear();
+    shortest_rings_through(sc, adj, static_cast<int>(k), kMaxRingSearch);
+    sc.foundStart.push_back(static_cast<int>(sc.foundAtoms.size()));  // end of the last ring
+    for (size_t f = 0; f + 1 < sc.foundStart.size(); ++f) {
+      // foundStart[f] was pushed BEFORE ring f's atoms: ring f = [foundStart[f], foundStart[f + 1])
+      const int* ring = sc.foundAtoms.data() + sc.foundStart[f];
+      const int  len  = sc.foundStart[f + 1] - sc.foundStart[f];
+      bool       ok   = true;
+      for (int j = 0; j < len && ok; ++j) ok = donates(ring[j]) >= 0;
+      if (!ok) continue;
+      auto& bonds = sc.pathBonds;
+      bonds.clear();
+      for (int j = 0; j < len && ok; ++j) {
+        const int u = ring[j], w = ring[(j + 1) % len];
+        int       between = -1;
+        for (const auto& [v, kb] : adj[static_cast<size_t>(u)])
+          if (v == w && g.bonds[static_cast<size_t>(kb)].ring) between = kb;
+        ok = between >= 0 && g.bonds[static_cast<size_t>(between)].order != kAromatic;  // aromatic-form rings are the input's business
+        bonds.push_back(between);
+      }
+      if (!ok) continue;
+      std::sort(bonds.begin(), bonds.end());
+      bool known = false;  // a ring is its set of bonds
+      for (size_t r = 0; r + 1 < ringStart.size() && !known; ++r)
+        known = ringStart[r + 1] - ringStart[r] == len && std::equal(bonds.begin(), bonds.end(), ringBonds.begin() + ringStart[r]);
+      if (known) continue;
+      ringAtoms.insert(ringAtoms.end(), ring, ring + len);
+      ringBonds.insert(ringBonds.end(), bonds.begin(), bonds.end());
+      ringStart.push_back(static_cast<int>(ringAtoms.size()));
     }
   }
-  const int nr = static_cast<int>(rings.size());
+  const int nr = static_cast<int>(ringStart.size()) - 1;
   if (nr == 0) return 0;
-  std::vector<std::vector<int>> fused(static_cast<size_t>(nr));
+  const auto ring_size  = [&](const int r) { return ringStart[static_cast<size_t>(r) + 1] - ringStart[static_cast<size_t>(r)]; };
+  const auto ring_atoms = [&](const int r) { return ringAtoms.data() + ringStart[static_cast<size_t>(r)]; };
+  const auto ring_bonds = [&](const int r) { return ringBonds.data() + ringStart[static_cast<size_t>(r)]; };
+  // fused = exactly one shared bond, both rings of at most 24 atoms; neighbours in CSR form
+  auto& fusedStart = sc.fusedStart;
+  auto& fusedList  = sc.fusedList;
+  fusedStart.assign(static_cast<size_t>(nr) + 1, 0);
+  fusedList.clear();
+  sc.members.clear();  // pairs (i, j), i < j, used as a temporary list
   for (int i = 0; i < nr; ++i) {
-    if (rings[static_cast<size_t>(i)].size() > kMaxFusedRingAtoms) continue;
+    if (static_cast<size_t>(ring_size(i)) > kMaxFusedRingAtoms) continue;
     for (int j = i + 1; j < nr; ++j) {
-      if (rings[static_cast<size_t>(j)].size() > kMaxFusedRingAtoms) continue;
+      if (static_cast<size_t>(ring_size(j)) > kMaxFusedRingAtoms) continue;
       int shared = 0;
-      for (const int kb : ringBonds[static_cast<size_t>(i)])
-        shared += std::binary_search(ringBonds[static_cast<size_t>(j)].begin(), ringBonds[static_cast<size_t>(j)].end(), kb) ? 1 : 0;
+      for (int x = 0; x < ring_size(i); ++x) shared += std::binary_search(ring_bonds(j), ring_bonds(j) + ring_size(j), ring_bonds(i)[x]) ? 1 : 0;
       if (shared == 1) {
-        fused[static_cast<size_t>(i)].push_back(j);
-        fused[static_cast<size_t>(j)].push_back(i);
+        sc.members.push_back(i);
+        sc.members.push_back(j);
+        ++fusedStart[static_cast<size_t>(i) + 1];
+        ++fusedStart[static_cast<size_t>(j) + 1];
       }
     }
   }
-  std::vector<char> aromBond(g.bonds.size(), 0), aromAtom(static_cast<size_t>(n), 0);
-  std::vector<int>  ringCount(static_cast<size_t>(n), 0), bondCount(g.bonds.size(), 0);
+  for (int i = 0; i < nr; ++i) fusedStart[static_cast<size_t>(i) + 1] += fusedStart[static_cast<size_t>(i)];
+  fusedList.resize(static_cast<size_t>(fusedStart[static_cast<size_t>(nr)]));
+  sc.fusedFill.assign(fusedStart.begin(), fusedStart.end() - 1);
+  for (size_t p = 0; p + 1 < sc.members.size(); p += 2) {
+    const int i = sc.members[p], j = sc.members[p + 1];
+    fusedList[static_cast<size_t>(sc.fusedFill[static_cast<size_t>(i)]++)] = j;
+    fusedList[static_cast<size_t>(sc.fusedFill[static_cast<size_t>(j)]++)] = i;
+  }
+  auto& aromBond  = sc.aromBond;
+  auto& aromAtom  = sc.aromAtom;
+  auto& ringCount = sc.ringCount;
+  auto& bondCount = sc.bondCount;
+  aromBond.assign(m, 0);
+  aromAtom.assign(static_cast<size_t>(n), 0);
+  ringCount.assign(static_cast<size_t>(n), 0);
+  bondCount.assign(m, 0);
   using Combo = std::array<int, kMaxFusedRings>;  // ring indices in increasing order, -1 beyond the combination's size
   // tries one combination; true when the whole fused system is aromatic afterwards
   size_t systemBonds = 0, doneBonds = 0;
   auto   try_combination = [&](const Combo& combo, const int size) {
     int electrons = 0;
     for (int c = 0; c < size; ++c)
-      for (const int v : rings[static_cast<size_t>(combo[static_cast<size_t>(c)])]) ++ringCount[static_cast<size_t>(v)];
+      for (int x = 0; x < ring_size(combo[static_cast<size_t>(c)]); ++x) ++ringCount[static_cast<size_t>(ring_atoms(combo[static_cast<size_t>(c)])[x])];
     for (int c = 0; c < size; ++c)
-      for (const int v : rings[static_cast<size_t>(combo[static_cast<size_t>(c)])]) {
-        int& cnt = ringCount[static_cast<size_t>(v)];
+      for (int x = 0; x < ring_size(combo[static_cast<size_t>(c)]); ++x) {
+        const int v   = ring_atoms(combo[static_cast<size_t>(c)])[x];
+        int&      cnt = ringCount[static_cast<size_t>(v)];
         if (cnt == 1 || cnt == 2) electrons += donated[static_cast<size_t>(v)];
         cnt = 0;  // each atom is counted once and the counter is ready for the next combination
       }
     if (!huckel(electrons)) return false;
-    for (int c = 0; c < size; ++c) {
-      for (const int v : rings[static_cast<size_t>(combo[static_cast<size_t>(c)])]) aromAtom[static_cast<size_t>(v)] = 1;
-      for (const int kb : ringBonds[static_cast<size_t>(combo[static_cast<size_t>(c)])]) ++bondCount[static_cast<size_t>(kb)];
-    }
     for (int c = 0; c < size; ++c)
-      for (const int kb : ringBonds[static_cast<size_t>(combo[static_cast<size_t>(c)])]) {
-        int& cnt = bondCount[static_cast<size_t>(kb)];
-        if (cnt == 1 && !aromBond[static_cast<size_t>(kb)]) {
+      for (int x = 0; x < ring_size(combo[static_cast<size_t>(c)]); ++x) {
+        aromAtom[static_cast<size_t>(ring_atoms(combo[static_cast<size_t>(c)])[x])] = 1;
+        ++bondCount[static_cast<size_t>(ring_bonds(combo[static_cast<size_t>(c)])[x])];
+      }
+    for (int c = 0; c < size; ++c)
+      for (int x = 0; x < ring_size(combo[static_cast<size_t>(c)]); ++x) {
+        const int kb = ring_bonds(combo[static_cast<size_t>(c)])[x];
+        if (bondCount[static_cast<size_t>(kb)] == 1 && !aromBond[static_cast<size_t>(kb)]) {  // not a fusion bond of this combination
           aromBond[static_cast<size_t>(kb)] = 1;
           ++doneBonds;
         }
-        if (cnt == 1) cnt = 0;
       }
     for (int c = 0; c < size; ++c)
-      for (const int kb : ringBonds[static_cast<size_t>(combo[static_cast<size_t>(c)])]) bondCount[static_cast<size_t>(kb)] = 0;
+      for (int x = 0; x < ring_size(combo[static_cast<size_t>(c)]); ++x) bondCount[static_cast<size_t>(ring_bonds(combo[static_cast<size_t>(c)])[x])] = 0;
     return doneBonds >= systemBonds;
   };
-  std::vector<int>   system(static_cast<size_t>(nr), -1), members, stack;
-  std::vector<char>  bondSeen(g.bonds.size(), 0);
-  std::vector<Combo> level, next;
+  auto& systemOf = sc.systemOf;
+  auto& members  = sc.members;
+  auto& stack    = sc.ringStack;
+  auto& bondSeen = sc.bondSeen;
+  auto& level    = sc.level;
+  auto& next     = sc.next;
+  systemOf.assign(static_cast<size_t>(nr), -1);
+  bondSeen.assign(m, 0);
   for (int r0 = 0; r0 < nr; ++r0) {
-    if (system[static_cast<size_t>(r0)] >= 0) continue;
+    if (systemOf[static_cast<size_t>(r0)] >= 0) continue;
     members.clear();
     stack.assign(1, r0);
-    system[static_cast<size_t>(r0)] = r0;
+    systemOf[static_cast<size_t>(r0)] = r0;
     while (!stack.empty()) {
       const int u = stack.back();
       stack.pop_back();
       members.push_back(u);
-      for (const int w : fused[static_cast<size_t>(u)])
-        if (system[static_cast<size_t>(w)] < 0) {
-          system[static_cast<size_t>(w)] = r0;
+      for (int e = fusedStart[static_cast<size_t>(u)]; e < fusedStart[static_cast<size_t>(u) + 1]; ++e) {
+        const int w = fusedList[static_cast<size_t>(e)];
+        if (systemOf[static_cast<size_t>(w)] < 0) {
+          systemOf[static_cast<size_t>(w)] = r0;
           stack.push_back(w);
         }
+      }
     }
     std::sort(members.begin(), members.end());
     systemBonds = doneBonds = 0;
     for (const int i : members)
-      for (const int kb : ringBonds[static_cast<size_t>(i)])
-        if (!bondSeen[static_cast<size_t>(kb)]) {
-          bondSeen[static_cast<size_t>(kb)] = 1;
+      for (int x = 0; x < ring_size(i); ++x)
+        if (!bondSeen[static_cast<size_t>(ring_bonds(i)[x])]) {
+          bondSeen[static_cast<size_t>(ring_bonds(i)[x])] = 1;
           ++systemBonds;
         }
     for (const int i : members)
-      for (const int kb : ringBonds[static_cast<size_t>(i)]) bondSeen[static_cast<size_t>(kb)] = 0;
+      for (int x = 0; x < ring_size(i); ++x) bondSeen[static_cast<size_t>(ring_bonds(i)[x])] = 0;
     level.clear();
     for (const int i : members) {
       Combo c;
@@ -870,15 +933,18 @@ int perceive_aromaticity(Scratch& sc, const Adjacency& adj, const bool apply) {
       // connected combinations of size + 1 rings: every combination of this size extended by a ring fused to one of its own
       next.clear();
       for (const Combo& combo : level)
-        for (int c = 0; c < size; ++c)
-          for (const int w : fused[static_cast<size_t>(combo[static_cast<size_t>(c)])]) {
+        for (int c = 0; c < size; ++c) {
+          const int u = combo[static_cast<size_t>(c)];
+          for (int e = fusedStart[static_cast<size_t>(u)]; e < fusedStart[static_cast<size_t>(u) + 1]; ++e) {
+            const int w = fusedList[static_cast<size_t>(e)];
             if (std::find(combo.begin(), combo.begin() + size, w) != combo.begin() + size) continue;
-            Combo bigger                         = combo;
+            Combo bigger                      = combo;
             bigger[static_cast<size_t>(size)] = w;
             std::sort(bigger.begin(), bigger.begin() + size + 1);
             next.push_back(bigger);
             if (next.size() > 8 * kMaxRingCombinations) return -1;
           }
+        }
       std::sort(next.begin(), next.end());
       next.erase(std::unique(next.begin(), next.end()), next.end());
       if (next.size() > kMaxRingCombinations) return -1;
@@ -886,7 +952,7 @@ int perceive_aromaticity(Scratch& sc, const Adjacency& adj, const bool apply) {
     }
   }
   int changed = 0;
-  for (size_t kb = 0; kb < aromBond.size(); ++kb)
+  for (size_t kb = 0; kb < m; ++kb)
     if (aromBond[kb]) {
       ++changed;
       if (apply) g.bonds[kb].order = kAromatic;
@@ -897,6 +963,85 @@ int perceive_aromaticity(Scratch& sc, const Adjacency& adj, const bool apply) {
       if (apply) g.atoms[static_cast<size_t>(v)].aromatic = true;
     }
   return changed;
+}
+
+// ---- Kekule structure of what the input wrote in aromatic form ------------------------------------------------------------
+// RDKit sanitises a parsed SMILES by first Kekulising it (MolOps::Kekulize) and then perceiving aromaticity from the
+// Kekule structure; a molecule without a Kekule structure ("c1cccc1", "c1ccnc1") is no molecule for it.  The same here:
+// an aromatic atom needs one double bond inside the aromatic system when exactly one unit of its valence is still open with
+// all its aromatic bonds counted as single; the double bonds are a perfect matching of those atoms over aromatic bonds.
+int kekule_valence(const int z, const int q) {  // valence an aromatic atom of this element and charge fills
+  switch (z) {
+    case 5: return 3 - q;                      // [b-]: four bonds
+    case 6: case 14: return 4 - (q < 0 ? -q : q);
+    case 7: case 15: case 33: return 3 + q;    // [n+]: four bonds, [n-]: two
+    case 8: case 16: case 34: case 52: return 2 + q;
+    default: return -1;
+  }
+}
+
+bool match_kekule(Scratch& sc, const Adjacency& adj, long& budget) {
+  const Graph& g = sc.g;
+  // the unmatched atom with the fewest unmatched partners goes next; none left = done, one without partners = dead end
+  int best = -1, bestCount = 1 << 30;
+  for (const int u : sc.free_) {
+    if (sc.partner[static_cast<size_t>(u)] >= 0) continue;
+    int count = 0;
+    for (const auto& [v, k] : adj[static_cast<size_t>(u)])
+      count += (g.bonds[static_cast<size_t>(k)].order == kAromatic && sc.needs[static_cast<size_t>(v)] && sc.partner[static_cast<size_t>(v)] < 0) ? 1 : 0;
+    if (count == 0) return false;
+    if (count < bestCount) {
+      bestCount = count;
+      best      = u;
+    }
+  }
+  if (best < 0) return true;
+  for (const auto& [v, k] : adj[static_cast<size_t>(best)]) {
+    if (g.bonds[static_cast<size_t>(k)].order != kAromatic || !sc.needs[static_cast<size_t>(v)] || sc.partner[static_cast<size_t>(v)] >= 0) continue;
+    if (--budget < 0) return false;
+    sc.partner[static_cast<size_t>(best)] = k;
+    sc.partner[static_cast<size_t>(v)]    = k;
+    if (match_kekule(sc, adj, budget)) return true;
+    sc.partner[static_cast<size_t>(best)] = sc.partner[static_cast<size_t>(v)] = -1;
+  }
+  return false;
+}
+
+// Replaces the aromatic bonds by single and double bonds and drops the aromatic flags; false when the input's aromatic
+// part has no Kekule structure (or marks atoms or bonds outside rings as aromatic).
+bool kekulize(Scratch& sc, const Adjacency& adj) {
+  Graph&       g = sc.g;
+  const size_t n = g.atoms.size();
+  for (const Atom& a : g.atoms)
+    if (a.aromatic && !a.inRing) return false;  // RDKit: "non-ring atom marked aromatic"
+  sc.sigma.assign(n, 0);
+  sc.needs.assign(n, 0);
+  sc.partner.assign(n, -1);
+  sc.free_.clear();
+  for (const Bond& b : g.bonds) {
+    if (b.order == kAromatic && !(b.ring && g.atoms[static_cast<size_t>(b.a)].aromatic && g.atoms[static_cast<size_t>(b.b)].aromatic)) return false;
+    const int w = b.order == kAromatic ? 1 : b.order == kDouble ? 2 : b.order == kTriple ? 3 : b.order == kQuadruple ? 4 : 1;
+    sc.sigma[static_cast<size_t>(b.a)] += w;
+    sc.sigma[static_cast<size_t>(b.b)] += w;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const Atom& a = g.atoms[i];
+    if (!a.aromatic) continue;
+    bool hasAromaticBond = false;
+    for (const auto& [v, k] : adj[i]) hasAromaticBond = hasAromaticBond || g.bonds[static_cast<size_t>(k)].order == kAromatic;
+    if (!hasAromaticBond) continue;
+    if (kekule_valence(a.z, a.charge) - (sc.sigma[i] + a.hExplicit + a.hImplicit) == 1) {
+      sc.needs[i] = 1;
+      sc.free_.push_back(static_cast<int>(i));
+    }
+  }
+  long budget = 200000;  // pairings tried before giving up (RDKit gives up after 100 back-tracks per ring system)
+  if (!match_kekule(sc, adj, budget)) return false;
+  for (Bond& b : g.bonds)
+    if (b.order == kAromatic) b.order = kSingle;
+  for (const int u : sc.free_) g.bonds[static_cast<size_t>(sc.partner[static_cast<size_t>(u)])].order = kDouble;
+  for (Atom& a : g.atoms) a.aromatic = false;
+  return true;
 }
 
 void build(const char* s, Scratch& sc, const unsigned flags) {
@@ -932,12 +1077,36 @@ void build(const char* s, Scratch& sc, const unsigned flags) {
       g.status = kTooManyBonds;
       return;
     }
-  // Kekule-form rings RDKit would perceive as aromatic: perceived when asked for, refused otherwise (never fingerprinted
-  // with bond types RDKit would not use)
+  // RDKit's sanitisation: Kekulise what was written in aromatic form, then perceive aromaticity from the Kekule structure.
+  // The outcome is applied when the caller asked for perception; otherwise it must equal what the input said (as it does
+  // for SMILES RDKit wrote), or the molecule is refused - never fingerprinted with bond types RDKit would not use.
   const Adjacency adj{sc};
-  const bool      apply   = (flags & NVMK_SMILES_PERCEIVE_AROMATICITY) != 0u;
-  const int       changed = perceive_aromaticity(sc, adj, apply);
-  if (changed < 0 || (changed > 0 && !apply)) g.status = kNeedsAromaticity;
+  const size_t    n = g.atoms.size(), m = g.bonds.size();
+  sc.inputAromatic.resize(n);
+  sc.inputOrder.resize(m);
+  bool anyAromatic = false;
+  for (size_t i = 0; i < n; ++i) anyAromatic = (sc.inputAromatic[i] = g.atoms[i].aromatic ? 1 : 0) != 0 || anyAromatic;
+  for (size_t k = 0; k < m; ++k) anyAromatic = (sc.inputOrder[k] = g.bonds[k].order) == kAromatic || anyAromatic;
+  auto restore_input = [&] {
+    for (size_t i = 0; i < n; ++i) g.atoms[i].aromatic = sc.inputAromatic[i] != 0;
+    for (size_t k = 0; k < m; ++k) g.bonds[k].order = sc.inputOrder[k];
+  };
+  if (anyAromatic && !kekulize(sc, adj)) {
+    restore_input();
+    g.status = kNoKekuleForm;
+    return;
+  }
+  if (perceive_aromaticity(sc, adj, true) < 0) {  // a fused system beyond what is enumerated
+    restore_input();
+    g.status = kNeedsAromaticity;
+    return;
+  }
+  if ((flags & NVMK_SMILES_PERCEIVE_AROMATICITY) != 0u) return;
+  bool same = true;
+  for (size_t i = 0; i < n && same; ++i) same = g.atoms[i].aromatic == (sc.inputAromatic[i] != 0);
+  for (size_t k = 0; k < m && same; ++k) same = (g.bonds[k].order == kAromatic) == (sc.inputOrder[k] == kAromatic);
+  restore_input();
+  if (!same) g.status = kNeedsAromaticity;
 }
 
 uint32_t hash_combine(const uint32_t seed, const uint32_t v) { return seed ^ (v + 0x9e3779b9u + (seed << 6) + (seed >> 2)); }

@@ -135,7 +135,8 @@ def morgan_invariants_from_rdkit(mols, max_atoms: int):
 
 
 SMILES_STATUS = {0: "ok", 1: "syntax error", 2: "valence RDKit's sanitisation rejects or rewrites",
-                 3: "Kekule-form aromatic ring (write the SMILES in aromatic form)", 4: "more than 8 bonds on one atom"}
+                 3: "aromaticity differs from what RDKit perceives, e.g. Kekule form (use perceive_aromaticity=True)",
+                 4: "more than 8 bonds on one atom", 5: "the aromatic atoms have no Kekule structure"}
 
 
 class SmilesSet:
@@ -144,9 +145,11 @@ class SmilesSet:
     thing the Morgan path needs from a molecule: its graph with hydrogen counts, charges, ring flags and bond types.
 
     ``status[i]`` is 0 for an ingested molecule; the other codes (``SMILES_STATUS``) mean the molecule was REFUSED — the
-    library never fingerprints a molecule whose bond types RDKit would perceive differently.  Aromaticity is taken from
-    the input; with ``perceive_aromaticity=True`` Kekule-form rings are perceived with RDKit's default model (checked
-    against the aromaticity RDKit recorded in 8864 ChEMBL molecules, tests/test_smiles_aromaticity.py) instead of refused.
+    library never fingerprints a molecule whose bond types RDKit would perceive differently.  Like RDKit's sanitisation
+    every molecule is Kekulised and its aromaticity perceived again with RDKit's default model (checked against the
+    aromaticity RDKit recorded in 8864 ChEMBL molecules, tests/test_smiles_aromaticity.py); by default the result has to
+    equal what the SMILES wrote (true for SMILES written by RDKit), with ``perceive_aromaticity=True`` it is applied
+    whatever form the input was written in (Kekule form, another toolkit's aromaticity).
     """
 
     def __init__(self, smiles, num_threads: int = 0, perceive_aromaticity: bool = False):

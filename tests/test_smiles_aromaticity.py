@@ -108,3 +108,26 @@ def test_kekule_and_aromatic_forms_give_the_same_morgan_inputs():
         k = SmilesSet([kek], perceive_aromaticity=True).morgan_inputs([0], 32)
         for x, y in zip(a, k):
             assert np.array_equal(x, y), (arom, kek)
+
+
+def test_rdkit_written_smiles_survive_kekulisation_and_perception_unchanged():
+    """What the default mode does with every molecule: Kekulise the aromatic form, perceive again, compare with what was
+    written.  All 10 000 SMILES of the reference's benchmark file were written by RDKit, so none may be refused and applying
+    the perceived aromaticity (perceive_aromaticity=True) must give the very same graphs."""
+    smiles = _lines("chembl_10k.smi")
+    default, applied = SmilesSet(smiles), SmilesSet(smiles, perceive_aromaticity=True)
+    assert np.all(default.status == 0) and np.all(applied.status == 0)
+    for i in range(len(smiles)):
+        (a0, b0), (a1, b1) = default.graph(i), applied.graph(i)
+        assert np.array_equal(a0, a1) and np.array_equal(b0, b1), smiles[i]
+
+
+@pytest.mark.parametrize("written,perceived", [
+    ("c1ccccccc1", "C1=CC=CC=CC=C1"),              # cyclooctatetraene is not aromatic however it is written
+    ("C1=CC=CC=C1", "c1ccccc1"), ("c1ccc2ccccc2c1", "C1=CC=C2C=CC=CC2=C1"),
+    ("O=c1cc[nH]cc1", "O=C1C=CNC=C1")])
+def test_applied_perception_does_not_depend_on_how_the_input_was_written(written, perceived):
+    a, b = SmilesSet([written], perceive_aromaticity=True), SmilesSet([perceived], perceive_aromaticity=True)
+    assert a.status[0] == 0 and b.status[0] == 0
+    for x, y in zip(a.graph(0), b.graph(0)):
+        assert np.array_equal(x, y)

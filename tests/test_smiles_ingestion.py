@@ -122,7 +122,11 @@ def test_ring_membership_is_cycle_membership():
 @pytest.mark.parametrize("smi,code", [("C(", 1), ("C1CC", 1), ("C)", 1), ("[Xx]", 1), ("C=", 1), ("C1C1", 1), ("", 0),
                                       ("CN(=O)=O", 2), ("C(C)(C)(C)(C)C", 2), ("OCl(=O)(=O)=O", 2),
                                       ("C1=CC=CC=C1", 3), ("C1=CNC=C1", 3), ("C1=COC=C1", 3), ("C1=CC=C2C=CC=CC2=C1", 3),
-                                      ("C1=CCCCC1", 0), ("O=C1C=CC(=O)C=C1", 0), ("C1=CC=CC1", 0), ("C1=CC=CCC=C1", 0)])
+                                      ("C1=CCCCC1", 0), ("O=C1C=CC(=O)C=C1", 0), ("C1=CC=CC1", 0), ("C1=CC=CCC=C1", 0),
+                                      # no Kekule structure (RDKit: "Can't kekulize mol"), aromatic marks outside rings
+                                      ("c1cccc1", 5), ("c1ccnc1", 5), ("cc", 5), ("C:C", 5), ("c1cc[nH]c1", 0), ("c1ccn(C)c1", 0),
+                                      # written aromatic where RDKit perceives none (cyclooctatetraene, 4-pyranone ring carbon chain)
+                                      ("c1ccccccc1", 3)])
 def test_refusals_and_their_neighbours(smi, code):
     assert int(SmilesSet([smi]).status[0]) == code
 
