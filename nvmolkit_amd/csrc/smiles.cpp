@@ -20,7 +20,7 @@
 //     input said - which is the case for SMILES RDKit wrote (all 10 000 of the reference's benchmark file) - otherwise the
 //     molecule is refused (NVMK_SMILES_NEEDS_AROMATICITY: Kekule-form input, or aromatic input from another toolkit's
 //     model) rather than fingerprinted with bond types RDKit would not use.  With NVMK_SMILES_PERCEIVE_AROMATICITY
-//     (nvmk_smiles_parse_flags) the outcome is applied instead, as RDKit does.  The perception is checked on the
+//     (nvmk_smiles_parse_flags; what the Python classes pass unless told otherwise) the outcome is applied, as RDKit does.  The perception is checked on the
 //     aromaticity RDKit itself recorded: every aromatic ChEMBL SMILES of tests/golden is Kekulised by the oracle, read
 //     back here and comes out with exactly the aromatic atoms and bonds RDKit wrote - all 8864 aromatic molecules of the
 //     10 000, porphyrins and fullerene adducts included (tests/test_smiles_aromaticity.py).  Valences RDKit's

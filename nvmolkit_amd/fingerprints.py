@@ -135,7 +135,7 @@ def morgan_invariants_from_rdkit(mols, max_atoms: int):
 
 
 SMILES_STATUS = {0: "ok", 1: "syntax error", 2: "valence RDKit's sanitisation rejects or rewrites",
-                 3: "aromaticity differs from what RDKit perceives, e.g. Kekule form (use perceive_aromaticity=True)",
+                 3: "aromaticity differs from what RDKit perceives, e.g. Kekule form (strict mode, perceive_aromaticity=False)",
                  4: "more than 8 bonds on one atom", 5: "the aromatic atoms have no Kekule structure"}
 
 
@@ -147,12 +147,13 @@ class SmilesSet:
     ``status[i]`` is 0 for an ingested molecule; the other codes (``SMILES_STATUS``) mean the molecule was REFUSED — the
     library never fingerprints a molecule whose bond types RDKit would perceive differently.  Like RDKit's sanitisation
     every molecule is Kekulised and its aromaticity perceived again with RDKit's default model (checked against the
-    aromaticity RDKit recorded in 8864 ChEMBL molecules, tests/test_smiles_aromaticity.py); by default the result has to
-    equal what the SMILES wrote (true for SMILES written by RDKit), with ``perceive_aromaticity=True`` it is applied
-    whatever form the input was written in (Kekule form, another toolkit's aromaticity).
+    aromaticity RDKit recorded in 8864 ChEMBL molecules, tests/test_smiles_aromaticity.py) and, as in RDKit, applied
+    whatever form the input was written in (Kekule form, another toolkit's aromaticity).  ``perceive_aromaticity=False``
+    is the strict mode (the default of the C entry point ``nvmk_smiles_parse``): the perceived aromaticity has to equal what
+    the SMILES wrote — true for SMILES written by RDKit — or the molecule is refused with status 3.
     """
 
-    def __init__(self, smiles, num_threads: int = 0, perceive_aromaticity: bool = False):
+    def __init__(self, smiles, num_threads: int = 0, perceive_aromaticity: bool = True):
         items = [s.encode() if isinstance(s, str) else bytes(s) for s in smiles]
         flags = 1 if perceive_aromaticity else 0
         # One text buffer with a molecule per line costs milliseconds to build where a million ctypes string pointers cost
@@ -169,7 +170,7 @@ class SmilesSet:
             self._read_counts(len(items))
 
     @classmethod
-    def from_text(cls, text, num_threads: int = 0, perceive_aromaticity: bool = False) -> "SmilesSet":
+    def from_text(cls, text, num_threads: int = 0, perceive_aromaticity: bool = True) -> "SmilesSet":
         """The molecules of a ``.smi``-style text (``str`` or ``bytes``): one per line, the SMILES is the first
         blank-separated column (names may follow), every line counts — also an empty one (an empty molecule) and a header
         line (a syntax error) — so that molecule i is line i."""
@@ -178,7 +179,7 @@ class SmilesSet:
         return self
 
     @classmethod
-    def from_file(cls, path, num_threads: int = 0, perceive_aromaticity: bool = False) -> "SmilesSet":
+    def from_file(cls, path, num_threads: int = 0, perceive_aromaticity: bool = True) -> "SmilesSet":
         """:meth:`from_text` of a file's content (e.g. the reference's ``benchmarks/data/chembl_10k.smi``)."""
         with open(path, "rb") as fh:
             return cls.from_text(fh.read(), num_threads, perceive_aromaticity)
@@ -359,14 +360,14 @@ class MorganFingerprintGenerator:
         return AsyncGpuResult(out)
 
     def GetFingerprintsFromSmiles(self, smiles, num_threads: int = 0, stream=None, on_error: str = "raise",
-                                  perceive_aromaticity: bool = False) -> AsyncGpuResult:
+                                  perceive_aromaticity: bool = True) -> AsyncGpuResult:
         """SMILES strings (or an already parsed :class:`SmilesSet`) -> packed fingerprints, one row per molecule in input
         order, without RDKit: the library parses the strings, derives the invariants on ``num_threads`` host threads
         (0 = all) and launches the same kernels as :meth:`GetFingerprints`.
 
         ``on_error``: ``"raise"`` (default) — a ``ValueError`` listing the refused molecules by index and reason, like the
         reference's ``None`` / parse failures; ``"zero"`` — their rows stay all-zero and ``result.smiles_status`` says why.
-        ``perceive_aromaticity``: accept Kekule-form input (see :class:`SmilesSet`; ignored for an already parsed set).
+        ``perceive_aromaticity``: see :class:`SmilesSet` (``False`` refuses Kekule-form input; ignored for an already parsed set).
         """
         _native.stream_ptr(stream)
         if self._fp_size not in _VALID_FP_SIZES:

@@ -38,7 +38,7 @@ def _kekule_forms(smiles):
 def _check(smiles, max_refused):
     forms = _kekule_forms(smiles)
     got = SmilesSet([f[1] for f in forms], perceive_aromaticity=True)
-    refused = SmilesSet([f[1] for f in forms])                       # default: Kekule-form aromatic rings are refused
+    refused = SmilesSet([f[1] for f in forms], perceive_aromaticity=False)   # strict mode: Kekule-form aromatic rings are refused
     assert np.all(refused.status == 3)
     n_refused = 0
     for j, (i, text, order, atoms, bonds) in enumerate(forms):
@@ -97,7 +97,7 @@ def test_textbook_rings(smi, n_aromatic_bonds):
     assert s.status[0] == 0
     _, bonds = s.graph(0)
     assert int((bonds[:, 2] == 12).sum()) == n_aromatic_bonds
-    assert int(SmilesSet([smi]).status[0]) == (3 if n_aromatic_bonds else 0)      # without the flag: refused iff aromatic
+    assert int(SmilesSet([smi], perceive_aromaticity=False).status[0]) == (3 if n_aromatic_bonds else 0)      # strict mode: refused iff aromatic
 
 
 def test_kekule_and_aromatic_forms_give_the_same_morgan_inputs():
@@ -111,11 +111,11 @@ def test_kekule_and_aromatic_forms_give_the_same_morgan_inputs():
 
 
 def test_rdkit_written_smiles_survive_kekulisation_and_perception_unchanged():
-    """What the default mode does with every molecule: Kekulise the aromatic form, perceive again, compare with what was
+    """What the strict mode does with every molecule: Kekulise the aromatic form, perceive again, compare with what was
     written.  All 10 000 SMILES of the reference's benchmark file were written by RDKit, so none may be refused and applying
     the perceived aromaticity (perceive_aromaticity=True) must give the very same graphs."""
     smiles = _lines("chembl_10k.smi")
-    default, applied = SmilesSet(smiles), SmilesSet(smiles, perceive_aromaticity=True)
+    default, applied = SmilesSet(smiles, perceive_aromaticity=False), SmilesSet(smiles, perceive_aromaticity=True)
     assert np.all(default.status == 0) and np.all(applied.status == 0)
     for i in range(len(smiles)):
         (a0, b0), (a1, b1) = default.graph(i), applied.graph(i)

@@ -128,7 +128,7 @@ def test_ring_membership_is_cycle_membership():
                                       # written aromatic where RDKit perceives none (cyclooctatetraene, 4-pyranone ring carbon chain)
                                       ("c1ccccccc1", 3)])
 def test_refusals_and_their_neighbours(smi, code):
-    assert int(SmilesSet([smi]).status[0]) == code
+    assert int(SmilesSet([smi], perceive_aromaticity=False).status[0]) == code      # the strict mode
 
 
 # ---- against the independent restatement --------------------------------------------------------------
@@ -161,7 +161,7 @@ def test_parallel_and_serial_parsing_agree():
 
 
 def test_morgan_inputs_refuse_what_was_not_ingested():
-    s = SmilesSet(["CCO", "C1=CC=CC=C1", "CCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCC"])
+    s = SmilesSet(["CCO", "C1=CC=CC=C1", "CCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCC"], perceive_aromaticity=False)
     with pytest.raises(ValueError, match="not ingested"):
         s.morgan_inputs([0, 1], 32)
     with pytest.raises(ValueError, match="does not fit"):
@@ -342,10 +342,13 @@ def test_fingerprints_from_smiles_equal_the_oracle_pipeline():
 def test_refused_smiles_raise_or_stay_zero():
     gen = MorganFingerprintGenerator(radius=2, fpSize=1024)
     with pytest.raises(ValueError, match="1 of 3 SMILES were not ingested"):
-        gen.GetFingerprintsFromSmiles(["CCO", "C1=CC=CC=C1", "c1ccccc1"])
-    res = gen.GetFingerprintsFromSmiles(["CCO", "C1=CC=CC=C1", "c1ccccc1"], on_error="zero")
+        gen.GetFingerprintsFromSmiles(["CCO", "C1=CC=CC=C1", "c1ccccc1"], perceive_aromaticity=False)
+    res = gen.GetFingerprintsFromSmiles(["CCO", "C1=CC=CC=C1", "c1ccccc1"], on_error="zero", perceive_aromaticity=False)
     fp = res.torch().cpu().numpy()
     assert res.smiles_status.tolist() == [0, 3, 0] and not fp[1].any() and fp[0].any() and fp[2].any()
+    # default (RDKit's behaviour): the Kekule form is perceived and gives benzene's fingerprint
+    fp = gen.GetFingerprintsFromSmiles(["C1=CC=CC=C1", "c1ccccc1"]).torch().cpu().numpy()
+    assert fp[0].any() and np.array_equal(fp[0], fp[1])
 
 
 BINAP_LIKE = "CC1(C)C2=C(C=CC(=C2)P(C3=CC=CC=C3)C4=CC=CC=C4)OC5=C1C=CC(=C5)P(C6=CC=CC=C6)C7=CC=CC=C7"
@@ -354,8 +357,8 @@ BINAP_LIKE_AROMATIC = "CC1(C)c2c(ccc(c2)P(c3ccccc3)c4ccccc4)Oc5c1ccc(c5)P(c6cccc
 
 def test_kekule_input_of_the_reference_regression_molecule():
     """The molecule of the reference's regression test (nvmolkit/tests/test_fingerprints.py:137-148) is written in Kekule
-    form: refused by default, perceived on request, and then the same graph as its aromatic form."""
-    assert SmilesSet([BINAP_LIKE]).status[0] == 3
+    form: refused in the strict mode, perceived otherwise, and then the same graph as its aromatic form."""
+    assert SmilesSet([BINAP_LIKE], perceive_aromaticity=False).status[0] == 3
     a, b = SmilesSet([BINAP_LIKE], perceive_aromaticity=True), SmilesSet([BINAP_LIKE_AROMATIC])
     assert a.status[0] == 0 and b.status[0] == 0
     for x, y in zip(a.graph(0), b.graph(0)):
@@ -402,7 +405,7 @@ def test_mutated_smiles_never_crash_and_agree_with_the_oracle():
         muts.append("".join(s))
     muts += ["", "[", "]", "[]", "[C", "C]", "%", "%1", "C%1", "((", "C((C))", "[12345C]", "[C" + "+" * 20 + "]", "[CH999]", "C" * 5000,
              "C1CC1C1CC1" * 50, "[*]", "*", "[C@O]", "[C@TH]", "[C@TH1](F)(Cl)(Br)I", " CCO", "CCO name", "C=#C", "C..C", ".C", "C."]
-    got = SmilesSet(muts)
+    got = SmilesSet(muts, perceive_aromaticity=False)        # strict mode: the graph is the written one, as the oracle reads it
     n_ok = 0
     for i, m in enumerate(muts):
         try:
