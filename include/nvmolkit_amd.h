@@ -400,7 +400,8 @@ int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, co
  * benchmarks read benchmarks/data/chembl_10k.smi through RDKit).  Scope and rules: nvmolkit_amd/csrc/smiles.cpp — like RDKit's
  * sanitisation every molecule is Kekulised and its aromaticity perceived again (RDKit's default model); by default the result
  * must equal what the input wrote (true for SMILES written by RDKit), else the molecule is REFUSED per molecule, as are
- * valences RDKit's sanitisation rejects or rewrites: nothing is ever fingerprinted differently from RDKit.
+ * valences RDKit's sanitisation rejects (the spellings its cleanUp step rewrites, e.g. N(=O)=O, are rewritten alike):
+ * nothing is ever fingerprinted differently from RDKit.
  *   nvmk_smiles_parse        : n_mols NUL- or whitespace-terminated strings -> an opaque set of graphs (n_threads <= 0: all
  *                              host threads).  Never fails on bad chemistry: the per-molecule status says what happened.
  *   nvmk_smiles_parse_text   : the same for one text buffer with a molecule per line (a .smi file as it is read from disk:

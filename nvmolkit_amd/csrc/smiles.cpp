@@ -23,8 +23,9 @@
 //     (nvmk_smiles_parse_flags; what the Python classes pass unless told otherwise) the outcome is applied, as RDKit does.  The perception is checked on the
 //     aromaticity RDKit itself recorded: every aromatic ChEMBL SMILES of tests/golden is Kekulised by the oracle, read
 //     back here and comes out with exactly the aromatic atoms and bonds RDKit wrote - all 8864 aromatic molecules of the
-//     10 000, porphyrins and fullerene adducts included (tests/test_smiles_aromaticity.py).  Valences RDKit's
-//     sanitisation rejects (or rewrites, like five-valent nitro groups) are refused as well.
+//     10 000, porphyrins and fullerene adducts included (tests/test_smiles_aromaticity.py).
+//   * the hypervalent spellings RDKit's sanitisation rewrites first (MolOps::cleanUp: N(=O)=O, N=N#N, C=P(=O)X, O=Cl(=O)O)
+//     are rewritten the same way (clean_up below); valences it rejects are refused (NVMK_SMILES_VALENCE_ERROR).
 // Host throughput: one call parses a whole text buffer (nvmk_smiles_parse_text) or an array of strings on all host threads;
 // each thread works in its own Scratch (no allocation per molecule) and fills chunks of 512 molecules stored back to back.
 // Parity against RDKit's parser cannot be pinned in this image; the independent Python restatement oracle/smiles.py, the
@@ -436,6 +437,32 @@ void build_adjacency(Scratch& sc) {
   }
 }
 
+// view of the CSR adjacency: adj[i] iterates over (neighbour, bond) pairs in bond order
+struct Neighbours {
+  const int *atom, *bond;
+  int        n;
+  struct It {
+    const int *a, *b;
+    std::pair<int, int> operator*() const { return {*a, *b}; }
+    It&                 operator++() {
+      ++a;
+      ++b;
+      return *this;
+    }
+    bool operator!=(const It& o) const { return a != o.a; }
+  };
+  It     begin() const { return {atom, bond}; }
+  It     end() const { return {atom + n, bond + n}; }
+  size_t size() const { return static_cast<size_t>(n); }
+};
+struct Adjacency {
+  const Scratch& sc;
+  Neighbours     operator[](const size_t i) const {
+    const int lo = sc.head[i];
+    return {sc.adjAtom.data() + lo, sc.adjBond.data() + lo, sc.head[i + 1] - lo};
+  }
+};
+
 // bonds that lie on a cycle (= are not bridges): iterative depth-first search with low-links over the CSR adjacency
 void mark_ring_bonds(Scratch& sc) {
   Graph&     g = sc.g;
@@ -548,6 +575,70 @@ int half_orders(const uint8_t order) {
   }
 }
 
+// RDKit's MolOps::cleanUp, the first step of its sanitisation (RDKit Book, "Sanitization"): four hypervalent ways of writing
+// a group are turned into the charge-separated form BEFORE valences are checked -
+//   neutral five-valent N with a double bond to O           CN(=O)=O      -> C[N+]([O-])=O   (first such O in bond order)
+//   neutral five-valent N with a triple bond to N           C-N=N#N       -> C-N=[N+]=[N-]
+//   neutral five-valent P with =O and a double bond to C/P  C=P(=O)O      -> C=[P+]([O-])O
+//   neutral Cl / Br / I of valence 3, 5, 7 with only O neighbours   O=Cl(=O)O -> [O-][Cl+2]([O-])O
+// The atoms involved end up with the hydrogen count they were written with (none gets an implicit one afterwards).
+void clean_up(Scratch& sc, const Adjacency& adj) {
+  Graph& g = sc.g;
+  auto   explicit_valence = [&](const size_t i) {
+    int sum2 = 0;
+    for (const auto& [v, k] : adj[i]) sum2 += half_orders(g.bonds[static_cast<size_t>(k)].order);
+    return static_cast<int>(std::lround(0.5 * sum2 + 0.1)) + g.atoms[i].hExplicit;
+  };
+  auto charge_pair = [&](const size_t i, const int nbr, const int bond, const uint8_t newOrder) {
+    g.bonds[static_cast<size_t>(bond)].order = newOrder;
+    g.atoms[i].charge                        = static_cast<int8_t>(g.atoms[i].charge + 1);
+    g.atoms[static_cast<size_t>(nbr)].charge = -1;
+    g.atoms[i].bracket = g.atoms[static_cast<size_t>(nbr)].bracket = true;
+  };
+  for (size_t i = 0; i < g.atoms.size(); ++i) {
+    const Atom& a = g.atoms[i];
+    if (a.charge != 0) continue;
+    if (a.z == 7) {
+      if (explicit_valence(i) != 5) continue;
+      for (const auto& [v, k] : adj[i]) {
+        const Atom&   o     = g.atoms[static_cast<size_t>(v)];
+        const uint8_t order = g.bonds[static_cast<size_t>(k)].order;
+        if (o.z == 8 && o.charge == 0 && order == kDouble) {
+          charge_pair(i, v, k, kSingle);
+          break;
+        }
+        if (o.z == 7 && o.charge == 0 && order == kTriple) {
+          charge_pair(i, v, k, kDouble);
+          break;
+        }
+      }
+    } else if (a.z == 15) {
+      if (explicit_valence(i) != 5 || adj[i].size() != 3) continue;
+      int  oxygen = -1, oxygenBond = -1;
+      bool ylide  = false;
+      for (const auto& [v, k] : adj[i]) {
+        const Atom& o = g.atoms[static_cast<size_t>(v)];
+        if (g.bonds[static_cast<size_t>(k)].order != kDouble) continue;
+        if (o.z == 8 && o.charge == 0) {
+          oxygen     = v;
+          oxygenBond = k;
+        } else if (o.z == 6 || o.z == 15) {
+          ylide = true;
+        }
+      }
+      if (ylide && oxygen >= 0) charge_pair(i, oxygen, oxygenBond, kSingle);
+    } else if (a.z == 17 || a.z == 35 || a.z == 53) {
+      const int ev = explicit_valence(i);
+      if (ev != 3 && ev != 5 && ev != 7) continue;
+      bool onlyOxygen = true;
+      for (const auto& [v, k] : adj[i]) onlyOxygen = onlyOxygen && g.atoms[static_cast<size_t>(v)].z == 8;
+      if (!onlyOxygen) continue;
+      for (const auto& [v, k] : adj[i])
+        if (g.bonds[static_cast<size_t>(k)].order == kDouble) charge_pair(i, v, k, kSingle);
+    }
+  }
+}
+
 // Atom::calcExplicitValence / calcImplicitValence of RDKit for atoms written without brackets
 bool assign_implicit_hydrogens(Scratch& sc) {
   Graph& g    = sc.g;
@@ -610,32 +701,6 @@ int outer_electrons(const int z) {
     default: return 0;
   }
 }
-
-// view of the CSR adjacency: adj[i] iterates over (neighbour, bond) pairs in bond order
-struct Neighbours {
-  const int *atom, *bond;
-  int        n;
-  struct It {
-    const int *a, *b;
-    std::pair<int, int> operator*() const { return {*a, *b}; }
-    It&                 operator++() {
-      ++a;
-      ++b;
-      return *this;
-    }
-    bool operator!=(const It& o) const { return a != o.a; }
-  };
-  It     begin() const { return {atom, bond}; }
-  It     end() const { return {atom + n, bond + n}; }
-  size_t size() const { return static_cast<size_t>(n); }
-};
-struct Adjacency {
-  const Scratch& sc;
-  Neighbours     operator[](const size_t i) const {
-    const int lo = sc.head[i];
-    return {sc.adjAtom.data() + lo, sc.adjBond.data() + lo, sc.head[i + 1] - lo};
-  }
-};
 
 int donated_electrons(const Graph& g, const Adjacency& adj, const int i) {
   const Atom& a = g.atoms[static_cast<size_t>(i)];
@@ -1068,6 +1133,7 @@ void build(const char* s, Scratch& sc, const unsigned flags) {
     const bool arom = g.atoms[static_cast<size_t>(b.a)].aromatic && g.atoms[static_cast<size_t>(b.b)].aromatic && b.ring;
     b.order         = arom ? kAromatic : kSingle;
   }
+  clean_up(sc, Adjacency{sc});
   if (!assign_implicit_hydrogens(sc)) {
     g.status = kValence;
     return;

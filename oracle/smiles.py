@@ -136,6 +136,40 @@ def _connected_without(n, bonds, skip, src, dst):
     return False
 
 
+def _clean_up(atoms, bonds):
+    """RDKit's cleanUp step (RDKit Book, "Sanitization"), in place: N(=O)=O -> [N+]([O-])=O, N=N#N -> N=[N+]=[N-],
+    C=P(=O)X -> C=[P+]([O-])X, O=Cl(=O)O -> [O-][Cl+2]([O-])O.  Atoms it touches keep the hydrogens they were written with."""
+    def around(i):
+        return [(b if a == i else a, k) for k, (a, b, _) in enumerate(bonds) if i in (a, b)]
+
+    def valence(i):
+        return int(np.floor(sum(1.5 if bonds[k][2] == 12 else bonds[k][2] for _, k in around(i)) + 0.1 + 0.5)) + atoms[i]["h_explicit"]
+
+    def separate(i, j, k, new_type):
+        bonds[k][2] = new_type
+        atoms[i]["charge"] += 1
+        atoms[j]["charge"] = -1
+        atoms[i]["bracket"] = atoms[j]["bracket"] = True
+
+    for i, at in enumerate(atoms):
+        if at["charge"] != 0:
+            continue
+        nbrs = around(i)
+        if at["z"] == 7 and valence(i) == 5:
+            for j, k in nbrs:
+                if atoms[j]["charge"] == 0 and (atoms[j]["z"], bonds[k][2]) in ((8, 2), (7, 3)):
+                    separate(i, j, k, bonds[k][2] - 1)
+                    break
+        elif at["z"] == 15 and valence(i) == 5 and len(nbrs) == 3:
+            oxo = [(j, k) for j, k in nbrs if atoms[j]["z"] == 8 and atoms[j]["charge"] == 0 and bonds[k][2] == 2]
+            if oxo and any(atoms[j]["z"] in (6, 15) and bonds[k][2] == 2 for j, k in nbrs):
+                separate(i, oxo[-1][0], oxo[-1][1], 1)
+        elif at["z"] in (17, 35, 53) and valence(i) in (3, 5, 7) and all(atoms[j]["z"] == 8 for j, _ in nbrs):
+            for j, k in nbrs:
+                if bonds[k][2] == 2:
+                    separate(i, j, k, 1)
+
+
 def molecule(smiles: str):
     """SMILES -> (atom table (n, 6) int [Z, charge, isotope, total Hs, aromatic, in ring], bond table (m, 4) int
     [begin, end, RDKit bond type, in ring]) with the rules listed in nvmolkit_amd/csrc/smiles.cpp's header."""
@@ -163,6 +197,7 @@ def molecule(smiles: str):
     for k, bd in enumerate(bonds):
         if bd[2] is None:
             bd[2] = 12 if (atoms[bd[0]]["aromatic"] and atoms[bd[1]]["aromatic"] and in_ring_bond[k]) else 1
+    _clean_up(atoms, bonds)
     # implicit hydrogens of organic-subset atoms
     order_sum = [0.0] * n
     for a, b, t in bonds:

@@ -120,7 +120,7 @@ def test_ring_membership_is_cycle_membership():
 
 
 @pytest.mark.parametrize("smi,code", [("C(", 1), ("C1CC", 1), ("C)", 1), ("[Xx]", 1), ("C=", 1), ("C1C1", 1), ("", 0),
-                                      ("CN(=O)=O", 2), ("C(C)(C)(C)(C)C", 2), ("OCl(=O)(=O)=O", 2),
+                                      ("CN(=O)=O", 0), ("C(C)(C)(C)(C)C", 2), ("OCl(=O)(=O)=O", 0), ("CN(C)(C)(C)C", 2), ("FCl(=O)=O", 2),
                                       ("C1=CC=CC=C1", 3), ("C1=CNC=C1", 3), ("C1=COC=C1", 3), ("C1=CC=C2C=CC=CC2=C1", 3),
                                       ("C1=CCCCC1", 0), ("O=C1C=CC(=O)C=C1", 0), ("C1=CC=CC1", 0), ("C1=CC=CCC=C1", 0),
                                       # no Kekule structure (RDKit: "Can't kekulize mol"), aromatic marks outside rings
@@ -129,6 +129,22 @@ def test_ring_membership_is_cycle_membership():
                                       ("c1ccccccc1", 3)])
 def test_refusals_and_their_neighbours(smi, code):
     assert int(SmilesSet([smi], perceive_aromaticity=False).status[0]) == code      # the strict mode
+
+
+@pytest.mark.parametrize("written,clean", [
+    ("CN(=O)=O", "C[N+]([O-])=O"), ("C1=CC=CN(=O)=C1", "C1=CC=C[N+]([O-])=C1"), ("CN=N#N", "CN=[N+]=[N-]"),
+    ("C=P(=O)O", "C=[P+]([O-])O"), ("O=Cl(=O)O", "[O-][Cl+2]([O-])O"), ("O=N(=O)c1ccccc1", "[O-][N+](=O)c1ccccc1"),
+    ("OCl(=O)(=O)=O", "O[Cl+3]([O-])([O-])[O-]"), ("c1cccn(=O)c1", "c1ccc[n+]([O-])c1")])
+def test_hypervalent_spellings_are_cleaned_up_like_rdkit(written, clean):
+    """The examples of the RDKit Book's "Sanitization" section (MolOps::cleanUp): both spellings are one molecule."""
+    a, b = SmilesSet([written]), SmilesSet([clean])
+    assert a.status[0] == 0 and b.status[0] == 0
+    (aa, ab), (ba, bb) = a.graph(0), b.graph(0)
+    assert np.array_equal(aa, ba) and np.array_equal(ab, bb), (aa.tolist(), ba.tolist())
+    strict = SmilesSet([written], perceive_aromaticity=False)        # the oracle reads aromaticity as written
+    if strict.status[0] == 0:
+        for x, y in zip(osmi.molecule(written), strict.graph(0)):
+            assert np.array_equal(x, y)
 
 
 # ---- against the independent restatement --------------------------------------------------------------
