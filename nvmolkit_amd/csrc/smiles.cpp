@@ -650,7 +650,19 @@ bool assign_implicit_hydrogens(Scratch& sc) {
   }
   for (size_t i = 0; i < g.atoms.size(); ++i) {
     Atom& a = g.atoms[i];
-    if (a.bracket || a.z == 0) continue;
+    if (a.bracket) {
+      // Bracket atoms carry their hydrogens; RDKit still rejects a valence above the element's highest one shifted by the
+      // charge (Atom::calcExplicitValence, strict: "+1 bond per positive charge, one fewer per negative"; boron the other
+      // way round; a carbocation also loses one).  Checked for B, C, N, O, where every RDKit release agrees; an aromatic
+      // atom is exempt there too (it is judged on its Kekule structure).
+      if (!a.aromatic && (a.z == 5 || a.z == 6 || a.z == 7 || a.z == 8)) {
+        const int highest = a.z == 5 ? 3 : a.z == 6 ? 4 : a.z == 7 ? 3 : 2;
+        const int shift   = a.z == 5 ? -a.charge : (a.z == 6 && a.charge > 0) ? -a.charge : a.charge;
+        if (static_cast<int>(std::lround(0.5 * sum2[i] + 0.1)) + a.hExplicit > highest + shift) return false;
+      }
+      continue;
+    }
+    if (a.z == 0) continue;
     int        nv = 0;
     const int* v  = valences_of(a.z, nv);
     if (v == nullptr) return false;

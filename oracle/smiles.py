@@ -208,6 +208,14 @@ def molecule(smiles: str):
     for i, at in enumerate(atoms):
         if at["bracket"] or at["z"] == 0:
             total_h.append(at["h_explicit"])
+            # RDKit's strict valence check on a bracket atom of B / C / N / O: at most the element's highest valence, one more
+            # per positive and one fewer per negative charge (boron: the other way round; a carbocation loses one too)
+            top = {5: 3, 6: 4, 7: 3, 8: 2}.get(at["z"])
+            if at["bracket"] and top is not None and not at["aromatic"]:
+                q = at["charge"]
+                top += -q if at["z"] == 5 else (-abs(q) if at["z"] == 6 else q)
+                if int(np.floor(order_sum[i] + 0.1 + 0.5)) + at["h_explicit"] > top:
+                    raise SmilesError(f"valence of bracket atom {i} is not allowed")
             continue
         allowed = VALENCES[at["z"]]
         acc = order_sum[i]

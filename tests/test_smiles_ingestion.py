@@ -123,6 +123,10 @@ def test_ring_membership_is_cycle_membership():
                                       ("CN(=O)=O", 0), ("C(C)(C)(C)(C)C", 2), ("OCl(=O)(=O)=O", 0), ("CN(C)(C)(C)C", 2), ("FCl(=O)=O", 2),
                                       ("C1=CC=CC=C1", 3), ("C1=CNC=C1", 3), ("C1=COC=C1", 3), ("C1=CC=C2C=CC=CC2=C1", 3),
                                       ("C1=CCCCC1", 0), ("O=C1C=CC(=O)C=C1", 0), ("C1=CC=CC1", 0), ("C1=CC=CCC=C1", 0),
+                                      # bracket atoms are valence-checked too (highest valence shifted by the charge)
+                                      ("[CH5]", 2), ("C[N](C)(C)C", 2), ("C[N+](C)(C)C", 0), ("[O](C)(C)C", 2), ("C[O+](C)C", 0),
+                                      ("[B-](F)(F)(F)F", 0), ("[B](F)(F)(F)F", 2), ("[C-]#[O+]", 0), ("[CH3]", 0), ("[CH2-]C", 0),
+                                      ("[C-](C)(C)(C)C", 2), ("[C+](C)(C)(C)C", 2), ("[NH4+]", 0), ("[NH4]", 2), ("[OH3+]", 0), ("[O-]C", 0), ("[O-](C)C", 2),
                                       # no Kekule structure (RDKit: "Can't kekulize mol"), aromatic marks outside rings
                                       ("c1cccc1", 5), ("c1ccnc1", 5), ("cc", 5), ("C:C", 5), ("c1cc[nH]c1", 0), ("c1ccn(C)c1", 0),
                                       # written aromatic where RDKit perceives none (cyclooctatetraene, 4-pyranone ring carbon chain)
