@@ -77,6 +77,7 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_smiles_parse": (_int, [ctypes.POINTER(ctypes.c_char_p), _i64, _int, ctypes.POINTER(ctypes.c_void_p)]),
     "nvmk_smiles_parse_flags": (_int, [ctypes.POINTER(ctypes.c_char_p), _i64, _int, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]),
     "nvmk_smiles_parse_text": (_int, [ctypes.c_char_p, _i64, _int, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]),
+    "nvmk_sdf_parse_text": (_int, [ctypes.c_char_p, _i64, _int, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]),
     "nvmk_smiles_size": (_int, [_vp, ctypes.POINTER(_i64)]),
     "nvmk_smiles_free": (_int, [_vp]),
     "nvmk_smiles_counts": (_int, [_vp, _vp, _vp, _vp]),

@@ -1,4 +1,5 @@
-// RDKit-free ingestion for the fingerprint path: SMILES -> molecular graph -> the input arrays of
+// RDKit-free ingestion for the fingerprint path: SMILES or SD-file records (MolfileReader near the
+// end of this file; everything from the hydrogen folding on is shared) -> molecular graph -> the input arrays of
 // the Morgan kernel (MorganInvariantsGenerator::ComputeInvariantsInto, reference src/morgan_fingerprint_common.cpp:43-124).
 //
 // What the reference takes from RDKit for this path and how it is restated here (host code, no GPU involved):
@@ -163,6 +164,12 @@ const int* valences_of(const int z, int& n) {
     case 17: n = 1; return vCl;
     case 35: n = 1; return vBr;
     case 53: n = 3; return vI;
+    // not in the SMILES organic subset, but atoms of a molfile are all written without a hydrogen count
+    case 1: n = 1; return vF;     // {1}
+    case 14: n = 1; return vC;    // Si {4}
+    case 33: n = 2; return vP;    // As {3, 5}
+    case 34: n = 3; return vS;    // Se {2, 4, 6}
+    case 52: n = 3; return vS;    // Te {2, 4, 6}
     default: n = 0; return nullptr;
   }
 }
@@ -516,6 +523,17 @@ void mark_ring_bonds(Scratch& sc) {
     if (b.ring) g.atoms[static_cast<size_t>(b.a)].inRing = g.atoms[static_cast<size_t>(b.b)].inRing = true;
 }
 
+// twice the valence contribution of a bond (RDKit counts an aromatic bond as 1.5)
+int half_orders(const uint8_t order) {
+  switch (order) {
+    case kDouble: return 4;
+    case kTriple: return 6;
+    case kQuadruple: return 8;
+    case kAromatic: return 3;
+    default: return 2;
+  }
+}
+
 // RDKit's default removeHs on what a SMILES can express: a hydrogen atom is folded into its neighbour unless it is
 // labelled (isotope), charged, not singly bonded to exactly one non-hydrogen atom.
 void fold_hydrogens(Scratch& sc) {
@@ -542,9 +560,36 @@ void fold_hydrogens(Scratch& sc) {
     if (g.atoms[static_cast<size_t>(o)].z == 1 || (b.order != kSingle && b.order != kUnspecified)) continue;
     sc.drop[static_cast<size_t>(i)] = 1;
     any                             = true;
-    if (g.atoms[static_cast<size_t>(o)].bracket) ++g.atoms[static_cast<size_t>(o)].hExplicit;  // organic-subset atoms recount below
+    if (g.atoms[static_cast<size_t>(o)].bracket) ++g.atoms[static_cast<size_t>(o)].hExplicit;  // the others recount below ...
   }
   if (!any) return;
+  // ... unless the atom sits in one of its HIGHER valence states with the hydrogens drawn (H3P=O, H2S(=O)=O): RDKit's removeHs
+  // then keeps them as an explicit count ("the heavy atom is not in its default valence state"), where a recount from the
+  // remaining bonds would settle for the lowest state (HP=O).
+  sc.sum2.assign(static_cast<size_t>(n), 0);
+  sc.renum.assign(static_cast<size_t>(n), 0);  // hydrogens folded into each atom (renum is rebuilt below)
+  for (const Bond& b : g.bonds) {
+    const int w = half_orders(b.order == kUnspecified ? kSingle : b.order);
+    sc.sum2[static_cast<size_t>(b.a)] += w;
+    sc.sum2[static_cast<size_t>(b.b)] += w;
+    if (sc.drop[static_cast<size_t>(b.a)]) ++sc.renum[static_cast<size_t>(b.b)];
+    if (sc.drop[static_cast<size_t>(b.b)]) ++sc.renum[static_cast<size_t>(b.a)];
+  }
+  for (int i = 0; i < n; ++i) {
+    Atom& a = g.atoms[static_cast<size_t>(i)];
+    if (sc.renum[static_cast<size_t>(i)] == 0 || a.bracket || a.aromatic) continue;
+    int        nv = 0;
+    const int* v  = valences_of(a.z, nv);
+    if (v == nullptr) continue;
+    const int shift = (a.z == 5 || a.z == 13) ? -a.charge : (a.z == 6 && a.charge > 0) ? -a.charge : a.charge;
+    const int ev    = static_cast<int>(std::lround(0.5 * sc.sum2[static_cast<size_t>(i)] + 0.1));
+    int       total = -1;  // the valence state the atom is in with its hydrogens drawn
+    for (int k = 0; k < nv && total < 0; ++k)
+      if (v[k] + shift >= ev) total = v[k] + shift;
+    bool higherState = false;
+    for (int k = 1; k < nv; ++k) higherState = higherState || v[k] == total;
+    if (higherState) a.hExplicit = static_cast<int8_t>(a.hExplicit + sc.renum[static_cast<size_t>(i)]);
+  }
   renum.assign(static_cast<size_t>(n), -1);
   sc.keptAtoms.clear();
   for (int i = 0; i < n; ++i)
@@ -562,17 +607,6 @@ void fold_hydrogens(Scratch& sc) {
     }
   g.atoms.swap(sc.keptAtoms);
   g.bonds.swap(sc.keptBonds);
-}
-
-// twice the valence contribution of a bond (RDKit counts an aromatic bond as 1.5)
-int half_orders(const uint8_t order) {
-  switch (order) {
-    case kDouble: return 4;
-    case kTriple: return 6;
-    case kQuadruple: return 8;
-    case kAromatic: return 3;
-    default: return 2;
-  }
 }
 
 // RDKit's MolOps::cleanUp, the first step of its sanitisation (RDKit Book, "Sanitization"): four hypervalent ways of writing
@@ -665,7 +699,14 @@ bool assign_implicit_hydrogens(Scratch& sc) {
     if (a.z == 0) continue;
     int        nv = 0;
     const int* v  = valences_of(a.z, nv);
-    if (v == nullptr) return false;
+    if (v == nullptr) continue;  // RDKit keeps no valence list for the element (metals, noble gases): no implicit hydrogens
+    // a charged atom without a written hydrogen count only comes from a molfile: every allowed valence moves with the
+    // charge (Atom::calcImplicitValence: one more bond per positive charge; boron / aluminium the other way round; a
+    // carbocation loses one as well)
+    const int shift = (a.z == 5 || a.z == 13) ? -a.charge : (a.z == 6 && a.charge > 0) ? -a.charge : a.charge;
+    int       shifted[4];
+    for (int k = 0; k < nv; ++k) shifted[k] = v[k] + shift;
+    v            = shifted;
     double accum = 0.5 * sum2[i];
     if (a.aromatic) {
       const int dv = v[0];
@@ -680,7 +721,7 @@ bool assign_implicit_hydrogens(Scratch& sc) {
       const int ev = static_cast<int>(std::lround(accum + 0.1));
       a.hImplicit  = static_cast<int8_t>(ev <= dv ? dv - ev : 0);
     } else {
-      const int ev    = static_cast<int>(std::lround(accum + 0.1));
+      const int ev    = static_cast<int>(std::lround(accum + 0.1)) + a.hExplicit;  // hExplicit: drawn hydrogens kept by the folding
       int       found = -1;
       for (int k = 0; k < nv; ++k)
         if (v[k] >= ev) {
@@ -1121,6 +1162,8 @@ bool kekulize(Scratch& sc, const Adjacency& adj) {
   return true;
 }
 
+void sanitise(Scratch& sc, unsigned flags);
+
 void build(const char* s, Scratch& sc, const unsigned flags) {
   Graph& g = sc.g;
   g.atoms.clear();
@@ -1137,6 +1180,13 @@ void build(const char* s, Scratch& sc, const unsigned flags) {
     if (g.status == kOk) g.status = kSyntax;
     return;
   }
+  sanitise(sc, flags);
+}
+
+// What follows the reading of a SMILES or a molfile: hydrogen folding, rings, RDKit's clean-up, valences, Kekule structure
+// and aromaticity (sc.g holds the atoms and bonds as written).
+void sanitise(Scratch& sc, const unsigned flags) {
+  Graph& g = sc.g;
   fold_hydrogens(sc);
   build_adjacency(sc);
   mark_ring_bonds(sc);
@@ -1245,7 +1295,151 @@ Scratch& thread_scratch() {
 }
 
 // every molecule of `line_of(i)` into the set, one chunk per work item
-template <typename LineOf> void parse_all(Set& set, const int64_t n_mols, const int n_threads, const unsigned flags, LineOf&& line_of) {
+// ---- MDL molfile (V2000) records of an SD file ----------------------------------------------------------------------------
+// What RDKit's MolFromMolBlock / SDMolSupplier (sanitize = true, removeHs = true) reads that the fingerprint path needs: the
+// counts line, the atom block (symbol, mass difference, charge code), the bond block (types 1 2 3 and 4 = aromatic) and
+// the M  CHG / M  ISO property lines.  No atom of a molfile carries a hydrogen count: all get implicit hydrogens from the
+// valence model (assign_implicit_hydrogens), and hydrogens drawn as atoms are folded like those of a SMILES.  V3000,
+// query atoms (A, Q, L, R#, *), query bond types and radicals are refused as syntax errors (unsupported).
+struct MolfileReader {
+  const char *p, *end;
+  Graph&      g;
+  MolfileReader(const char* begin, const char* stop, Graph& graph) : p(begin), end(stop), g(graph) {}
+
+  bool next_line(const char*& lo, const char*& hi) {  // without the line end; false at the end of the record
+    if (p >= end) return false;
+    lo                = p;
+    const char* nl    = static_cast<const char*>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+    hi                = nl != nullptr ? nl : end;
+    p                 = nl != nullptr ? nl + 1 : end;
+    if (hi > lo && hi[-1] == '\r') --hi;
+    return true;
+  }
+  static bool number(const char* lo, const char* hi, const int from, const int to, int& out) {  // fixed columns, blank = 0
+    long v = 0;
+    bool neg = false, digits = false;
+    for (const char* c = lo + from; c < hi && c < lo + to; ++c) {
+      if (*c == ' ') {
+        if (digits) return false;
+        continue;
+      }
+      if (*c == '-' && !digits && !neg) {
+        neg = true;
+        continue;
+      }
+      if (*c < '0' || *c > '9') return false;
+      v      = v * 10 + (*c - '0');
+      digits = true;
+      if (v > 100000) return false;
+    }
+    out = static_cast<int>(neg ? -v : v);
+    return true;
+  }
+
+  bool run() {
+    const char *lo, *hi;
+    for (int header = 0; header < 3; ++header)
+      if (!next_line(lo, hi)) return false;
+    if (!next_line(lo, hi)) return false;
+    if (hi - lo >= 39 && std::memcmp(lo + 34, "V3000", 5) == 0) return false;
+    int nAtoms = 0, nBonds = 0;
+    if (hi - lo < 6 || !number(lo, hi, 0, 3, nAtoms) || !number(lo, hi, 3, 6, nBonds) || nAtoms < 0 || nBonds < 0) return false;
+    g.atoms.resize(static_cast<size_t>(nAtoms));
+    for (int i = 0; i < nAtoms; ++i) {
+      if (!next_line(lo, hi) || hi - lo < 32) return false;
+      const char* sym = lo + 31;
+      int         len = 0;
+      while (len < 3 && sym + len < hi && sym[len] != ' ') ++len;
+      Atom a;
+      if (len == 1 && (*sym == 'D' || *sym == 'T')) {
+        a.z       = 1;
+        a.isotope = *sym == 'D' ? 2 : 3;
+      } else {
+        const int z = len > 0 ? element_of(sym, len) : -1;
+        if (z <= 0) return false;  // query atoms, R groups, the "*" of a polymer
+        a.z = static_cast<uint8_t>(z);
+      }
+      int dd = 0, ccc = 0;
+      if (!number(lo, hi, 34, 36, dd) || !number(lo, hi, 36, 39, ccc)) return false;
+      if (dd != 0) a.isotope = static_cast<uint16_t>(std::lround(kWeights[a.z]) + dd);
+      static const int kCharge[8] = {0, 3, 2, 1, 0, -1, -2, -3};
+      if (ccc < 0 || ccc > 7 || ccc == 4) return false;  // 4 = doublet radical
+      a.charge = static_cast<int8_t>(kCharge[ccc]);
+      g.atoms[static_cast<size_t>(i)] = a;
+    }
+    g.bonds.resize(static_cast<size_t>(nBonds));
+    for (int k = 0; k < nBonds; ++k) {
+      int a = 0, b = 0, type = 0;
+      if (!next_line(lo, hi) || hi - lo < 9 || !number(lo, hi, 0, 3, a) || !number(lo, hi, 3, 6, b) || !number(lo, hi, 6, 9, type)) return false;
+      if (a < 1 || b < 1 || a > nAtoms || b > nAtoms || a == b) return false;
+      Bond bd;
+      bd.a = a - 1;
+      bd.b = b - 1;
+      switch (type) {
+        case 1: bd.order = kSingle; break;
+        case 2: bd.order = kDouble; break;
+        case 3: bd.order = kTriple; break;
+        case 4:
+          bd.order = kAromatic;
+          g.atoms[static_cast<size_t>(bd.a)].aromatic = g.atoms[static_cast<size_t>(bd.b)].aromatic = true;
+          break;
+        default: return false;  // query bond types
+      }
+      for (int j = 0; j < k; ++j)
+        if ((g.bonds[static_cast<size_t>(j)].a == bd.a && g.bonds[static_cast<size_t>(j)].b == bd.b) ||
+            (g.bonds[static_cast<size_t>(j)].a == bd.b && g.bonds[static_cast<size_t>(j)].b == bd.a))
+          return false;
+      g.bonds[static_cast<size_t>(k)] = bd;
+    }
+    bool chargesReset = false;
+    while (next_line(lo, hi)) {
+      if (hi - lo >= 6 && std::memcmp(lo, "M  END", 6) == 0) return true;
+      if (hi - lo >= 6 && std::memcmp(lo, "M  RAD", 6) == 0) return false;
+      const bool chg = hi - lo >= 6 && std::memcmp(lo, "M  CHG", 6) == 0, iso = hi - lo >= 6 && std::memcmp(lo, "M  ISO", 6) == 0;
+      if (chg || iso) {
+        if (chg && !chargesReset) {  // the property lines supersede the charge column of the atom block
+          for (Atom& a : g.atoms) a.charge = 0;
+          chargesReset = true;
+        }
+        int count = 0;
+        if (!number(lo, hi, 6, 9, count) || count < 0 || count > 8) return false;
+        for (int e = 0; e < count; ++e) {
+          int atom = 0, value = 0;
+          const int at = 9 + 8 * e;
+          if (hi - lo <= at + 4) return false;  // the entry's value is missing
+          if (!number(lo, hi, at, at + 4, atom) || !number(lo, hi, at + 4, at + 8, value) || atom < 1 || atom > nAtoms) return false;
+          if (chg) {
+            if (value < -15 || value > 15) return false;
+            g.atoms[static_cast<size_t>(atom) - 1].charge = static_cast<int8_t>(value);
+          } else {
+            if (value < 0 || value > 999) return false;
+            g.atoms[static_cast<size_t>(atom) - 1].isotope = static_cast<uint16_t>(value);
+          }
+        }
+      } else if (hi - lo >= 3 && lo[0] == 'A' && lo[1] == ' ' && lo[2] == ' ') {
+        next_line(lo, hi);  // atom alias: its text is on the next line
+      }
+    }
+    return true;  // no M  END before the end of the record: RDKit warns and goes on
+  }
+};
+
+void build_molfile(const char* begin, const char* stop, Scratch& sc, const unsigned flags) {
+  Graph& g = sc.g;
+  g.atoms.clear();
+  g.bonds.clear();
+  g.status = kOk;
+  MolfileReader reader(begin, stop, g);
+  if (!reader.run()) {
+    g.atoms.clear();
+    g.bonds.clear();
+    g.status = kSyntax;
+    return;
+  }
+  sanitise(sc, flags);
+}
+
+template <typename Builder> void parse_all(Set& set, const int64_t n_mols, const int n_threads, Builder&& build_one) {
   set.nMols = n_mols;
   set.chunks.resize(static_cast<size_t>((n_mols + kChunkMols - 1) / kChunkMols));
   parallel_for(static_cast<int64_t>(set.chunks.size()), n_threads, [&](const int64_t c) {
@@ -1258,7 +1452,7 @@ template <typename LineOf> void parse_all(Set& set, const int64_t n_mols, const 
     ch.atoms.reserve(static_cast<size_t>(hi - lo) * 32);
     ch.bonds.reserve(static_cast<size_t>(hi - lo) * 34);
     for (int64_t i = lo; i < hi; ++i) {
-      build(line_of(i), sc, flags);
+      build_one(i, sc);
       const size_t j = static_cast<size_t>(i - lo);
       ch.atoms.insert(ch.atoms.end(), sc.g.atoms.begin(), sc.g.atoms.end());
       ch.bonds.insert(ch.bonds.end(), sc.g.bonds.begin(), sc.g.bonds.end());
@@ -1277,7 +1471,7 @@ int nvmk_smiles_parse_flags(const char* const* smiles, const int64_t n_mols, con
   NVMK_REQUIRE(handle != nullptr && (smiles != nullptr || n_mols == 0) && n_mols >= 0, "nvmk_smiles_parse: NULL argument or negative count");
   NVMK_REQUIRE((flags & ~static_cast<unsigned>(NVMK_SMILES_PERCEIVE_AROMATICITY)) == 0u, "nvmk_smiles_parse: unknown flag bits 0x%x", flags);
   auto set = std::make_unique<nvmk::smiles::Set>();
-  nvmk::smiles::parse_all(*set, n_mols, n_threads, flags, [&](const int64_t i) { return smiles[i]; });
+  nvmk::smiles::parse_all(*set, n_mols, n_threads, [&](const int64_t i, nvmk::smiles::Scratch& sc) { nvmk::smiles::build(smiles[i], sc, flags); });
   *handle = set.release();
   return NVMK_OK;
 }
@@ -1303,7 +1497,34 @@ int nvmk_smiles_parse_text(const char* text, const int64_t n_bytes, const int n_
     p = nl + 1;
   }
   if (!lines.empty() && lines.back() == nullptr) lines.back() = set->tail.c_str();
-  nvmk::smiles::parse_all(*set, static_cast<int64_t>(lines.size()), n_threads, flags, [&](const int64_t i) { return lines[static_cast<size_t>(i)]; });
+  nvmk::smiles::parse_all(*set, static_cast<int64_t>(lines.size()), n_threads,
+                          [&](const int64_t i, nvmk::smiles::Scratch& sc) { nvmk::smiles::build(lines[static_cast<size_t>(i)], sc, flags); });
+  *handle = set.release();
+  return NVMK_OK;
+}
+
+int nvmk_sdf_parse_text(const char* text, const int64_t n_bytes, const int n_threads, const unsigned flags, void** handle) {
+  NVMK_REQUIRE(handle != nullptr && (text != nullptr || n_bytes == 0) && n_bytes >= 0, "nvmk_sdf_parse_text: NULL argument or negative size");
+  NVMK_REQUIRE((flags & ~static_cast<unsigned>(NVMK_SMILES_PERCEIVE_AROMATICITY)) == 0u, "nvmk_sdf_parse_text: unknown flag bits 0x%x", flags);
+  auto set = std::make_unique<nvmk::smiles::Set>();
+  // records end at a line that starts with "$$$$"; text after the last one counts as a record when it is not blank
+  std::vector<std::pair<const char*, const char*>> records;
+  const char *p = text, *end = text + n_bytes, *start = text;
+  while (p < end) {
+    const char* nl   = static_cast<const char*>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+    const char* stop = nl != nullptr ? nl : end;
+    if (stop - p >= 4 && std::memcmp(p, "$$$$", 4) == 0) {
+      records.push_back({start, p});
+      start = nl != nullptr ? nl + 1 : end;
+    }
+    p = nl != nullptr ? nl + 1 : end;
+  }
+  bool blank = true;
+  for (const char* c = start; c < end && blank; ++c) blank = *c == ' ' || *c == '\n' || *c == '\r' || *c == '\t';
+  if (!blank) records.push_back({start, end});
+  nvmk::smiles::parse_all(*set, static_cast<int64_t>(records.size()), n_threads, [&](const int64_t i, nvmk::smiles::Scratch& sc) {
+    nvmk::smiles::build_molfile(records[static_cast<size_t>(i)].first, records[static_cast<size_t>(i)].second, sc, flags);
+  });
   *handle = set.release();
   return NVMK_OK;
 }

@@ -184,10 +184,26 @@ class SmilesSet:
         with open(path, "rb") as fh:
             return cls.from_text(fh.read(), num_threads, perceive_aromaticity)
 
-    def _parse_text(self, text: bytes, num_threads: int, flags: int, expected) -> None:
+    @classmethod
+    def from_sdf_text(cls, text, num_threads: int = 0, perceive_aromaticity: bool = True) -> "SmilesSet":
+        """The molecules of an SD file's content (``str`` or ``bytes``; MDL molfile V2000 records separated by ``$$$$``) — the
+        graphs RDKit's ``SDMolSupplier`` (sanitize, removeHs) would hand to the fingerprint generator: hydrogens drawn as
+        atoms are folded, the others come from the valence model, aromaticity is perceived.  Every record counts; V3000,
+        query atoms and radicals are refused (status 1)."""
+        self = cls.__new__(cls)
+        self._parse_text(text.encode() if isinstance(text, str) else bytes(text), num_threads, 1 if perceive_aromaticity else 0, None,
+                         entry="nvmk_sdf_parse_text")
+        return self
+
+    @classmethod
+    def from_sdf_file(cls, path, num_threads: int = 0, perceive_aromaticity: bool = True) -> "SmilesSet":
+        """:meth:`from_sdf_text` of a file's content."""
+        with open(path, "rb") as fh:
+            return cls.from_sdf_text(fh.read(), num_threads, perceive_aromaticity)
+
+    def _parse_text(self, text: bytes, num_threads: int, flags: int, expected, entry: str = "nvmk_smiles_parse_text") -> None:
         self._handle = ctypes.c_void_p()
-        _native.check(_native.lib().nvmk_smiles_parse_text(text, len(text), int(num_threads), flags, ctypes.byref(self._handle)),
-                      "nvmk_smiles_parse_text")
+        _native.check(getattr(_native.lib(), entry)(text, len(text), int(num_threads), flags, ctypes.byref(self._handle)), entry)
         n = ctypes.c_int64()
         _native.check(_native.lib().nvmk_smiles_size(self._handle, ctypes.byref(n)), "nvmk_smiles_size")
         if expected is not None and n.value != expected:

@@ -180,14 +180,24 @@ def molecule(smiles: str):
         degree[a] += 1
         degree[b] += 1
     drop = set()
+    folded = [0] * len(atoms)
     for i, at in enumerate(atoms):
         if at["z"] == 1 and at["isotope"] == 0 and at["charge"] == 0 and at["h_explicit"] == 0 and degree[i] == 1:
             (a, b, t), = [bd for bd in bonds if i in bd[:2]]
             other = b if a == i else a
             if atoms[other]["z"] != 1 and t in (None, 1):
                 drop.add(i)
+                folded[other] += 1
                 if atoms[other]["bracket"]:
                     atoms[other]["h_explicit"] += 1
+    # an organic-subset atom drawn with its hydrogens in one of its higher valence states keeps them (RDKit's removeHs:
+    # H3P=O stays H3P=O; a recount from the other bonds would make it HP=O); all others are recounted further down
+    for i, at in enumerate(atoms):
+        if folded[i] and not at["bracket"] and not at["aromatic"] and at["z"] in VALENCES:
+            drawn = sum(1.5 if t == 12 else float(t or 1) for a, b, t in bonds if i in (a, b))
+            state = next((v for v in VALENCES[at["z"]] if v >= int(np.floor(drawn + 0.1 + 0.5))), None)
+            if state in VALENCES[at["z"]][1:]:
+                at["kept_h"] = folded[i]
     keep = [i for i in range(len(atoms)) if i not in drop]
     renum = {old: new for new, old in enumerate(keep)}
     atoms = [atoms[i] for i in keep]
@@ -226,11 +236,12 @@ def molecule(smiles: str):
             ev = int(np.floor(acc + 0.1 + 0.5))
             total_h.append(max(default - ev, 0))
         else:
-            ev = int(np.floor(acc + 0.1 + 0.5))
+            kept = at.get("kept_h", 0)
+            ev = int(np.floor(acc + 0.1 + 0.5)) + kept
             fits = [v for v in allowed if v >= ev]
             if not fits:
                 raise SmilesError(f"valence {ev} of atom {i} is not allowed")
-            total_h.append(fits[0] - ev)
+            total_h.append(kept + fits[0] - ev)
     ring_atom = [False] * n
     for k, (a, b, _) in enumerate(bonds):
         if in_ring_bond[k]:
