@@ -73,3 +73,23 @@ def heavy_atom_graph(z, charge, isotope, bonds):
     atoms = np.stack([z[keep], charge[keep], isotope[keep], drawn_h[keep]], 1)
     kept_bonds = np.array([[renum[a], renum[b], t] for a, b, t in bonds if not drop[a] and not drop[b]], dtype=np.int64).reshape(-1, 3)
     return atoms, kept_bonds, keep
+
+
+def write_molblock(atom_table, bond_types, bond_table, name="oracle") -> str:
+    """A V2000 record of a molecule given as tables (oracle.smiles.molecule): heavy atoms only — hydrogen counts cannot be
+    written in a molfile and are left to the reader's valence model — charges and isotopes as M  CHG / M  ISO lines, bond types
+    1 / 2 / 3 (pass a Kekule assignment for aromatic molecules: oracle.aromaticity.kekulize)."""
+    from oracle.smiles import ELEMENTS
+
+    lines = [name, "  oracle", "", f"{len(atom_table):3d}{len(bond_table):3d}  0  0  0  0  0  0  0  0999 V2000"]
+    for row in atom_table:
+        lines.append(f"{0.0:10.4f}{0.0:10.4f}{0.0:10.4f} {ELEMENTS[int(row[0])]:<3s} 0  0  0  0  0  0  0  0  0  0  0  0")
+    for (a, b, _, _), t in zip(bond_table, bond_types):
+        lines.append(f"{int(a) + 1:3d}{int(b) + 1:3d}{int(t):3d}  0")
+    for tag, col in (("CHG", 1), ("ISO", 2)):
+        entries = [(i + 1, int(row[col])) for i, row in enumerate(atom_table) if int(row[col]) != 0]
+        for lo in range(0, len(entries), 8):
+            part = entries[lo:lo + 8]
+            lines.append(f"M  {tag}{len(part):3d}" + "".join(f"{a:4d}{v:4d}" for a, v in part))
+    lines.append("M  END")
+    return "\n".join(lines) + "\n$$$$\n"
