@@ -431,7 +431,7 @@ int nvmk_smiles_parse_flags(const char* const* smiles, int64_t n_mols, int n_thr
 int nvmk_smiles_parse_text(const char* text, int64_t n_bytes, int n_threads, unsigned flags, void** handle);
 /* The same set of graphs from the MDL molfile (V2000) records of an SD file held in memory ("$$$$"-separated; data items are
  * skipped): what RDKit's SDMolSupplier (sanitize, removeHs) would hand to the fingerprint generator.  Every record counts;
- * V3000, query atoms / bonds and radicals give NVMK_SMILES_SYNTAX_ERROR.  All nvmk_smiles_* accessors apply to the handle. */
+ * V3000 and query atoms / bonds give NVMK_SMILES_SYNTAX_ERROR.  All nvmk_smiles_* accessors apply to the handle. */
 int nvmk_sdf_parse_text(const char* text, int64_t n_bytes, int n_threads, unsigned flags, void** handle);
 int nvmk_smiles_size(const void* handle, int64_t* n_mols);
 int nvmk_smiles_free(void* handle);

@@ -72,6 +72,7 @@ struct Atom {
   bool     bracket  = false;
   bool     aromatic = false;
   bool     inRing   = false;
+  uint8_t  radical  = 0;  // unpaired electrons a molfile declares (M  RAD): they take the place of implicit hydrogens
 };
 struct Bond {
   int     a = 0, b = 0;
@@ -721,7 +722,8 @@ bool assign_implicit_hydrogens(Scratch& sc) {
       const int ev = static_cast<int>(std::lround(accum + 0.1));
       a.hImplicit  = static_cast<int8_t>(ev <= dv ? dv - ev : 0);
     } else {
-      const int ev    = static_cast<int>(std::lround(accum + 0.1)) + a.hExplicit;  // hExplicit: drawn hydrogens kept by the folding
+      // hExplicit: drawn hydrogens kept by the folding; radical electrons fill valence like bonds (Atom::calcImplicitValence)
+      const int ev    = static_cast<int>(std::lround(accum + 0.1)) + a.hExplicit + a.radical;
       int       found = -1;
       for (int k = 0; k < nv; ++k)
         if (v[k] >= ev) {
@@ -1299,8 +1301,9 @@ Scratch& thread_scratch() {
 // What RDKit's MolFromMolBlock / SDMolSupplier (sanitize = true, removeHs = true) reads that the fingerprint path needs: the
 // counts line, the atom block (symbol, mass difference, charge code), the bond block (types 1 2 3 and 4 = aromatic) and
 // the M  CHG / M  ISO property lines.  No atom of a molfile carries a hydrogen count: all get implicit hydrogens from the
-// valence model (assign_implicit_hydrogens), and hydrogens drawn as atoms are folded like those of a SMILES.  V3000,
-// query atoms (A, Q, L, R#, *), query bond types and radicals are refused as syntax errors (unsupported).
+// valence model (assign_implicit_hydrogens), and hydrogens drawn as atoms are folded like those of a SMILES.  Radicals of
+// the M  RAD lines count as filled valence.  V3000, query atoms (A, Q, L, R#, *) and query bond types are refused as syntax
+// errors (unsupported).
 struct MolfileReader {
   const char *p, *end;
   Graph&      g;
@@ -1363,8 +1366,9 @@ struct MolfileReader {
       if (!number(lo, hi, 34, 36, dd) || !number(lo, hi, 36, 39, ccc)) return false;
       if (dd != 0) a.isotope = static_cast<uint16_t>(std::lround(kWeights[a.z]) + dd);
       static const int kCharge[8] = {0, 3, 2, 1, 0, -1, -2, -3};
-      if (ccc < 0 || ccc > 7 || ccc == 4) return false;  // 4 = doublet radical
+      if (ccc < 0 || ccc > 7) return false;
       a.charge = static_cast<int8_t>(kCharge[ccc]);
+      if (ccc == 4) a.radical = 1;  // "doublet radical"
       g.atoms[static_cast<size_t>(i)] = a;
     }
     g.bonds.resize(static_cast<size_t>(nBonds));
@@ -1394,11 +1398,14 @@ struct MolfileReader {
     bool chargesReset = false;
     while (next_line(lo, hi)) {
       if (hi - lo >= 6 && std::memcmp(lo, "M  END", 6) == 0) return true;
-      if (hi - lo >= 6 && std::memcmp(lo, "M  RAD", 6) == 0) return false;
-      const bool chg = hi - lo >= 6 && std::memcmp(lo, "M  CHG", 6) == 0, iso = hi - lo >= 6 && std::memcmp(lo, "M  ISO", 6) == 0;
-      if (chg || iso) {
-        if (chg && !chargesReset) {  // the property lines supersede the charge column of the atom block
-          for (Atom& a : g.atoms) a.charge = 0;
+      const bool chg = hi - lo >= 6 && std::memcmp(lo, "M  CHG", 6) == 0, iso = hi - lo >= 6 && std::memcmp(lo, "M  ISO", 6) == 0,
+                 rad = hi - lo >= 6 && std::memcmp(lo, "M  RAD", 6) == 0;
+      if (chg || iso || rad) {
+        if ((chg || rad) && !chargesReset) {  // these property lines supersede the charge / radical column of the atom block
+          for (Atom& a : g.atoms) {
+            a.charge  = 0;
+            a.radical = 0;
+          }
           chargesReset = true;
         }
         int count = 0;
@@ -1411,6 +1418,9 @@ struct MolfileReader {
           if (chg) {
             if (value < -15 || value > 15) return false;
             g.atoms[static_cast<size_t>(atom) - 1].charge = static_cast<int8_t>(value);
+          } else if (rad) {  // 1 = singlet and 3 = triplet: two electrons, 2 = doublet: one
+            if (value < 0 || value > 3) return false;
+            g.atoms[static_cast<size_t>(atom) - 1].radical = static_cast<uint8_t>(value == 2 ? 1 : value == 0 ? 0 : 2);
           } else {
             if (value < 0 || value > 999) return false;
             g.atoms[static_cast<size_t>(atom) - 1].isotope = static_cast<uint16_t>(value);

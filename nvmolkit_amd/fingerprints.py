@@ -188,8 +188,8 @@ class SmilesSet:
     def from_sdf_text(cls, text, num_threads: int = 0, perceive_aromaticity: bool = True) -> "SmilesSet":
         """The molecules of an SD file's content (``str`` or ``bytes``; MDL molfile V2000 records separated by ``$$$$``) — the
         graphs RDKit's ``SDMolSupplier`` (sanitize, removeHs) would hand to the fingerprint generator: hydrogens drawn as
-        atoms are folded, the others come from the valence model, aromaticity is perceived.  Every record counts; V3000,
-        query atoms and radicals are refused (status 1)."""
+        atoms are folded, the others come from the valence model, aromaticity is perceived.  Every record counts; V3000 and
+        query atoms are refused (status 1)."""
         self = cls.__new__(cls)
         self._parse_text(text.encode() if isinstance(text, str) else bytes(text), num_threads, 1 if perceive_aromaticity else 0, None,
                          entry="nvmk_sdf_parse_text")

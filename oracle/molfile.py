@@ -77,7 +77,8 @@ def heavy_atom_graph(z, charge, isotope, bonds):
 
 def write_molblock(atom_table, bond_types, bond_table, name="oracle") -> str:
     """A V2000 record of a molecule given as tables (oracle.smiles.molecule): heavy atoms only — hydrogen counts cannot be
-    written in a molfile and are left to the reader's valence model — charges and isotopes as M  CHG / M  ISO lines, bond types
+    written in a molfile and are left to the reader's valence model — charges, isotopes and radicals as M  CHG / M  ISO /
+    M  RAD lines, bond types
     1 / 2 / 3 (pass a Kekule assignment for aromatic molecules: oracle.aromaticity.kekulize)."""
     from oracle.smiles import ELEMENTS
 
@@ -86,8 +87,23 @@ def write_molblock(atom_table, bond_types, bond_table, name="oracle") -> str:
         lines.append(f"{0.0:10.4f}{0.0:10.4f}{0.0:10.4f} {ELEMENTS[int(row[0])]:<3s} 0  0  0  0  0  0  0  0  0  0  0  0")
     for (a, b, _, _), t in zip(bond_table, bond_types):
         lines.append(f"{int(a) + 1:3d}{int(b) + 1:3d}{int(t):3d}  0")
-    for tag, col in (("CHG", 1), ("ISO", 2)):
-        entries = [(i + 1, int(row[col])) for i, row in enumerate(atom_table) if int(row[col]) != 0]
+    # an atom whose bonds and hydrogens stop short of its (charge-shifted) valence is a radical: M  RAD, 2 = doublet, 3 = triplet
+    from oracle.smiles import VALENCES
+
+    bonded = np.zeros(len(atom_table))
+    for (a, b, _, _), t in zip(bond_table, bond_types):
+        bonded[a] += t
+        bonded[b] += t
+    radicals = []
+    for i, row in enumerate(atom_table):
+        z, q, h = int(row[0]), int(row[1]), int(row[3])
+        if z in VALENCES:
+            shift = -q if z == 5 else (-abs(q) if z == 6 else q)
+            state = next((v + shift for v in VALENCES[z] if v + shift >= bonded[i] + h), None)
+            if state is not None and state - bonded[i] - h > 0:
+                radicals.append((i + 1, 2 if state - bonded[i] - h == 1 else 3))
+    for tag, col in (("CHG", 1), ("ISO", 2), ("RAD", None)):
+        entries = radicals if col is None else [(i + 1, int(row[col])) for i, row in enumerate(atom_table) if int(row[col]) != 0]
         for lo in range(0, len(entries), 8):
             part = entries[lo:lo + 8]
             lines.append(f"M  {tag}{len(part):3d}" + "".join(f"{a:4d}{v:4d}" for a, v in part))

@@ -121,13 +121,19 @@ def test_hand_made_records():
     assert one(molblock([("N", 3), ("O", 0)], [(1, 2, 1)], ["M  CHG  1   2  -1"])).graph(0)[0][:, [0, 1, 3]].tolist() == [[7, 0, 2], [8, -1, 0]]
     assert one(molblock([("C", 0, 1), ("O", 0)], [(1, 2, 1)], ["M  ISO  1   2  18"])).graph(0)[0][:, 2].tolist() == [13, 18]
     assert one(molblock([("D", 0), ("O", 0), ("T", 0)], [(1, 2, 1), (2, 3, 1)])).graph(0)[0][:, [0, 2]].tolist() == [[1, 2], [8, 0], [1, 3]]
+    # radicals take the place of hydrogens: methyl (M  RAD doublet, or charge code 4), methylene (triplet), a nitroxide
+    assert one(molblock([("C", 0)], [], ["M  RAD  1   1   2"])).graph(0)[0][:, 3].tolist() == [3]
+    assert one(molblock([("C", 4)], [])).graph(0)[0][:, 3].tolist() == [3]
+    assert one(molblock([("C", 0)], [], ["M  RAD  1   1   3"])).graph(0)[0][:, 3].tolist() == [2]
+    assert one(molblock([("N", 0), ("O", 0), ("C", 0), ("C", 0)], [(1, 2, 1), (1, 3, 1), (1, 4, 1)],
+                        ["M  RAD  1   2   2"])).graph(0)[0][:, 3].tolist() == [0, 0, 3, 3]
     # salts and metals: no implicit hydrogens where RDKit has no valence list
     assert one(molblock([("Na", 3), ("Cl", 5), ("Fe", 0)], [])).graph(0)[0][:, [0, 1, 3]].tolist() == [[11, 1, 0], [17, -1, 0], [26, 0, 0]]
     # RDKit's clean-up applies to molfiles as well: a five-valent nitro group
     assert one(molblock([("C", 0), ("N", 0), ("O", 0), ("O", 0)], [(1, 2, 1), (2, 3, 2), (2, 4, 2)])).graph(0)[0][:, 1].tolist() == [0, 1, -1, 0]
     # unsupported or broken records are refused one by one; the others of the file are unaffected
-    bad = [molblock([("C", 0)], [], version="V3000"), molblock([("R#", 0)], []), molblock([("C", 0)], [], ["M  RAD  1   1   2"]),
-           molblock([("C", 4)], []), molblock([("C", 0), ("C", 0)], [(1, 2, 5)]), molblock([("C", 0), ("C", 0)], [(1, 3, 1)]),
+    bad = [molblock([("C", 0)], [], version="V3000"), molblock([("R#", 0)], []), molblock([("C", 0)], [], ["M  RAD  1   1   7"]),
+           molblock([("C", 8)], []), molblock([("C", 0), ("C", 0)], [(1, 2, 5)]), molblock([("C", 0), ("C", 0)], [(1, 3, 1)]),
            molblock([("C", 0), ("C", 0)], [(1, 2, 1), (2, 1, 1)]), "too\nshort\n"]
     text = "$$$$\n".join(bad + [benzene]) + "$$$$\n"
     s = SmilesSet.from_sdf_text(text)
@@ -169,6 +175,5 @@ def test_chembl_molecules_written_as_hydrogen_free_kekule_molfiles_come_back_as_
         ga, gb = got.graph(i)
         if not (np.array_equal(ga, atoms) and np.array_equal(gb, bonds)):
             different.append(i)
-    # the one molecule that differs is a nitroxide radical (N-[O]): a radical needs an M  RAD line, which is not written here
-    assert len(different) <= 1 and all("[O]" in smiles[i] for i in different), [smiles[i] for i in different]
+    assert not different, [smiles[i] for i in different]                 # (one of them is a nitroxide radical: M  RAD)
     assert sum(int((a[:, 1] != 0).any()) for a, _ in tables) > 500      # charged molecules took part
