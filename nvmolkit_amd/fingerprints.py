@@ -257,6 +257,9 @@ class SmilesSet:
         return atom_inv, bond_inv, bond_idx, bond_other, n_atoms
 
 
+MoleculeSet = SmilesSet  # the same container under a name that also fits molecules read from SD files
+
+
 # Pinned staging blocks, pooled per process: (tensor, event or None) pairs; a block is reused when the copy that last read it
 # has completed.  Sizes are rounded up to powers of two so that a few blocks serve every bucket.
 _PINNED_POOL: list = []
