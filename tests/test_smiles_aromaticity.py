@@ -68,6 +68,15 @@ def test_perception_reproduces_rdkits_aromaticity_on_chembl_10k():
     assert n > 8000 and refused == 0
 
 
+def test_perception_reproduces_rdkits_aromaticity_on_the_other_reference_smiles():
+    """2 300 more SMILES written by RDKit: the peptides of nvmolkit/tests/testdata/smiles.csv, butina_test_smiles.csv and
+    benchmarks/data/benchmark_smiles.csv.  Strict mode accepts all of them as written, and their Kekule forms come back."""
+    smiles = _lines("more_rdkit_smiles.smi")
+    assert len(smiles) == 2300 and np.all(SmilesSet(smiles, perceive_aromaticity=False).status == 0)
+    n, refused = _check(smiles, max_refused=0)
+    assert n > 700                                                   # the aromatic ones among them (the benchmark file is mostly aliphatic)
+
+
 def test_oracle_perception_agrees_with_the_library_on_kekule_forms():
     forms = _kekule_forms(_lines("chembl_1k.smi")[:300])
     got = SmilesSet([f[1] for f in forms], perceive_aromaticity=True)
