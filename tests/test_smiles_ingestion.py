@@ -271,10 +271,10 @@ def test_staging_block_holds_the_same_arrays():
         s.morgan_inputs(idx, 64, out=tuple(np.zeros((1, 1), dtype=np.uint32) for _ in range(5)))
 
 
-def test_smiles_to_fingerprints_host_path_with_the_kernel_call_stubbed(monkeypatch):
-    """Everything of GetFingerprintsFromSmiles' bucket path that is not CUDA — bucketing, the staging block, the pointers and
-    the output rows handed to nvmk_morgan_from_invariants — with that one call answered by the oracle on the staged arrays
-    (the real kernel is compared with the same expectation in the GPU test below)."""
+def _stub_the_device(monkeypatch):
+    """Replaces everything CUDA of the fingerprint module by host equivalents: device tensors become host tensors, the pinned
+    pool plain memory, streams nothing, and nvmk_morgan_from_invariants is answered by the CPU oracle on the staged arrays.
+    Returns the list the stubbed kernel appends (max_atoms, n_mols) to."""
     import contextlib
     import ctypes
 
@@ -298,7 +298,7 @@ def test_smiles_to_fingerprints_host_path_with_the_kernel_call_stubbed(monkeypat
             bx = arr(p_bx, n * max_atoms * 8, ctypes.c_int16, np.int16).reshape(n, max_atoms, 8)
             bo = arr(p_bo, n * max_atoms * 8, ctypes.c_int16, np.int16).reshape(n, max_atoms, 8)
             na = arr(p_na, n, ctypes.c_int16, np.int16)
-            rows = arr(p_rows, n, ctypes.c_int32, np.int32)
+            rows = arr(p_rows, n, ctypes.c_int32, np.int32) if p_rows else np.arange(n, dtype=np.int32)
             fp = oracle.morgan_fingerprints(ai, bi, bx, bo, na, max_atoms, radius, fp_bits)
             words = fp_bits // 32
             for r, row in zip(rows.tolist(), fp):
@@ -307,12 +307,24 @@ def test_smiles_to_fingerprints_host_path_with_the_kernel_call_stubbed(monkeypat
             calls.append((max_atoms, n))
             return 0
 
+    real_zeros = torch.zeros
     monkeypatch.setattr(_native, "lib", lambda: Stub())
     monkeypatch.setattr(_native, "on_stream", lambda stream, dev: contextlib.nullcontext())
     monkeypatch.setattr(_native, "stream_ptr", lambda stream: 0)
     monkeypatch.setattr(fpmod, "_pinned_block", lambda n: torch.empty(n, dtype=torch.uint8))
     monkeypatch.setattr(fpmod, "_release_pinned_block", lambda *a: None)
     monkeypatch.setattr(torch.cuda, "device", lambda dev: contextlib.nullcontext())
+    monkeypatch.setattr(torch, "zeros", lambda *a, **kw: real_zeros(*a, **{k: v for k, v in kw.items() if k != "device"}))
+    return calls
+
+
+def test_smiles_to_fingerprints_host_path_with_the_kernel_call_stubbed(monkeypatch):
+    """Everything of GetFingerprintsFromSmiles' bucket path that is not CUDA — bucketing, the staging block, the pointers and
+    the output rows handed to nvmk_morgan_from_invariants — with that one call answered by the oracle on the staged arrays
+    (the real kernel is compared with the same expectation in the GPU test below)."""
+    import torch
+
+    calls = _stub_the_device(monkeypatch)
     gen = MorganFingerprintGenerator(radius=2, fpSize=2048)
     mols = SmilesSet(CHEMBL)
     size = np.maximum(mols.n_atoms, mols.n_bonds)
@@ -336,6 +348,20 @@ def test_smiles_to_fingerprints_host_path_with_the_kernel_call_stubbed(monkeypat
         lo = stride
         if len(idx):
             assert np.array_equal(got[idx], oracle.morgan_fingerprints(*oracle_inputs([CHEMBL[i] for i in idx], stride), stride, 2, 2048))
+
+
+def test_the_gpu_tests_of_this_file_on_the_stubbed_device(monkeypatch):
+    """The bodies of the three GPU tests below, run against the stub: what they exercise beyond the kernel (dispatch of string
+    lists, refusals, zero rows, SD files, repeated generators) is host code and is checked here on every CPU run as well."""
+    calls = _stub_the_device(monkeypatch)
+    test_fingerprints_from_smiles_equal_the_oracle_pipeline()
+    test_refused_smiles_raise_or_stay_zero()
+    test_repeated_single_molecule_calls_never_come_back_empty()
+    assert len(calls) > 256
+    # molecules read from an SD file take the same route
+    sdf = SmilesSet.from_sdf_file(Path(__file__).parent / "golden" / "larger_molecules.sdf")
+    fp = MorganFingerprintGenerator(radius=2, fpSize=1024).GetFingerprintsFromSmiles(sdf).torch().numpy().view(np.uint32)
+    assert np.array_equal(fp, oracle.morgan_fingerprints(*sdf.morgan_inputs([0, 1, 2], 64), 64, 2, 1024))
 
 
 # ---- on the GPU ----------------------------------------------------------------------------------------
