@@ -1155,6 +1155,7 @@ bool kekulize(Scratch& sc, const Adjacency& adj) {
       sc.free_.push_back(static_cast<int>(i));
     }
   }
+  if (sc.free_.size() > 20000) return false;  // the pairing recurses once per double bond: keep the stack bounded
   long budget = 200000;  // pairings tried before giving up (RDKit gives up after 100 back-tracks per ring system)
   if (!match_kekule(sc, adj, budget)) return false;
   for (Bond& b : g.bonds)
