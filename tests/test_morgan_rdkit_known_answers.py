@@ -1,0 +1,55 @@
+"""Morgan fingerprints against values RDKit itself publishes (the algorithm is RDKit's; the reference asserts bit-for-bit
+equality with it, tests/test_morgan_fingerprint.cpp:73-108, but holds no literal values).  The numbers below are from the RDKit
+documentation, "Getting Started with the RDKit in Python":
+  * "Explaining bits from Morgan Fingerprints": m = MolFromSmiles('c1cccnc1C'), radius 2 -> 16 non-zero elements;
+    info[98513984] == ((1, 1), (2, 1)) (two atoms, radius 1) and info[4048591891] == ((5, 2),) (one atom, radius 2);
+  * "Generating images of fingerprint bits": mol = MolFromSmiles('c1ccccc1CC1CC1'), GetMorganFingerprintAsBitVect(mol, radius=2)
+    (2048 bits): bi[872] == ((6, 2),) — and bit 29 heads list(fp.GetOnBits());
+  * the radius-0 identifiers every RDKit user has seen in GetNonzeroElements(): 2246728737 (CH3), 2245384272 (CH2),
+    864662311 (OH), 847957139 (NH2), 3218693969 (aromatic CH).
+They go through the whole chain — the library's SMILES ingestion, its atom / bond invariants, then the oracle's environments
+(CPU) and the HIP kernel's bits (GPU) — so they pin the invariant recipe and the hash chain to RDKit, not to a restatement."""
+
+import numpy as np
+import pytest
+
+import oracle
+from nvmolkit_amd.fingerprints import MorganFingerprintGenerator, SmilesSet
+
+
+def environments(smiles, radius):
+    s = SmilesSet([smiles])
+    assert s.status[0] == 0
+    atom_inv, bond_inv, bond_idx, bond_other, n_atoms = s.morgan_inputs([0], 32)
+    return oracle.morgan_environments(atom_inv[0], bond_inv[0], bond_idx[0], bond_other[0], int(n_atoms[0]), radius)
+
+
+def test_explaining_bits_example():
+    codes, layers = environments("c1cccnc1C", 2)
+    assert len(set(codes.tolist())) == 16
+    assert [int(l) for c, l in zip(codes, layers) if int(c) == 98513984] == [1, 1]
+    assert [int(l) for c, l in zip(codes, layers) if int(c) == 4048591891] == [2]
+
+
+def test_bit_image_example():
+    codes, layers = environments("c1ccccc1CC1CC1", 2)
+    bits = sorted({int(c) % 2048 for c in codes})
+    assert bits[0] == 29 and 872 in bits
+    assert [int(l) for c, l in zip(codes, layers) if int(c) % 2048 == 872] == [2]
+
+
+@pytest.mark.parametrize("smiles,want", [("CC", {2246728737}), ("CCO", {864662311, 2245384272, 2246728737}),
+                                         ("CCN", {847957139, 2245384272, 2246728737}), ("c1ccccc1", {3218693969})])
+def test_radius_zero_identifiers(smiles, want):
+    codes, _ = environments(smiles, 0)
+    assert set(codes.tolist()) == want
+
+
+@pytest.mark.gpu
+def test_kernel_bits_of_the_documented_examples():
+    gen = MorganFingerprintGenerator(radius=2, fpSize=2048)
+    fps = gen.GetFingerprints(["c1cccnc1C", "c1ccccc1CC1CC1"]).torch().cpu().numpy().view(np.uint32)
+    on = [sorted(int(w) * 32 + b for w in range(64) for b in range(32) if (int(row[w]) >> b) & 1) for row in fps]
+    codes, _ = environments("c1cccnc1C", 2)
+    assert on[0] == sorted({int(c) % 2048 for c in codes}) and 98513984 % 2048 in on[0] and 4048591891 % 2048 in on[0]
+    assert on[1][0] == 29 and 872 in on[1]
