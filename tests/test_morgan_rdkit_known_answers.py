@@ -7,6 +7,9 @@ documentation, "Getting Started with the RDKit in Python":
     (2048 bits): bi[872] == ((6, 2),) — and bit 29 heads list(fp.GetOnBits());
   * the radius-0 identifiers every RDKit user has seen in GetNonzeroElements(): 2246728737 (CH3), 2245384272 (CH2),
     864662311 (OH), 847957139 (NH2), 3218693969 (aromatic CH).
+  * "Morgan Fingerprints (Circular Fingerprints)": m1 = 'Cc1ccccc1', m2 = 'Cc1ncccc1', radius 2: DiceSimilarity of the count
+    fingerprints prints 0.55..., of the 1024-bit vectors 0.51... (= 14 / 27: 11 and 16 bits set, 7 in common, which makes the
+    Tanimoto similarity 7 / 20).
 They go through the whole chain — the library's SMILES ingestion, its atom / bond invariants, then the oracle's environments
 (CPU) and the HIP kernel's bits (GPU) — so they pin the invariant recipe and the hash chain to RDKit, not to a restatement."""
 
@@ -43,6 +46,28 @@ def test_bit_image_example():
 def test_radius_zero_identifiers(smiles, want):
     codes, _ = environments(smiles, 0)
     assert set(codes.tolist()) == want
+
+
+def test_dice_similarity_example():
+    from collections import Counter
+
+    counts = [Counter(environments(smi, 2)[0].tolist()) for smi in ("Cc1ccccc1", "Cc1ncccc1")]
+    common = sum(min(counts[0][k], counts[1][k]) for k in counts[0])
+    assert 2 * common / (sum(counts[0].values()) + sum(counts[1].values())) == pytest.approx(0.55, abs=1e-12)   # docs: 0.55...
+    s = SmilesSet(["Cc1ccccc1", "Cc1ncccc1"])
+    fp = oracle.morgan_fingerprints(*s.morgan_inputs([0, 1], 32), 32, 2, 1024)
+    a, b, c = (int(np.unpackbits(x.view(np.uint8)).sum()) for x in (fp[0], fp[1], fp[0] & fp[1]))
+    assert (a, b, c) == (11, 16, 7) and str(2 * c / (a + b)).startswith("0.51")                                  # docs: 0.51...
+
+
+@pytest.mark.gpu
+def test_tanimoto_of_the_documented_pair_on_the_gpu():
+    """SMILES -> Morgan kernel -> similarity kernel on the documentation's pair: 7 common bits of 11 and 16 -> 7 / 20."""
+    from nvmolkit_amd.similarity import crossTanimotoSimilarity
+
+    fps = MorganFingerprintGenerator(radius=2, fpSize=1024).GetFingerprints(["Cc1ccccc1", "Cc1ncccc1"]).torch()
+    sim = crossTanimotoSimilarity(fps).torch().cpu().numpy()
+    assert sim[0, 1] == 7 / 20 and sim[1, 0] == 7 / 20 and sim[0, 0] == 1.0 and sim[1, 1] == 1.0
 
 
 @pytest.mark.gpu
