@@ -140,3 +140,19 @@ def test_applied_perception_does_not_depend_on_how_the_input_was_written(written
     assert a.status[0] == 0 and b.status[0] == 0
     for x, y in zip(a.graph(0), b.graph(0)):
         assert np.array_equal(x, y)
+
+
+def test_rdkit_book_examples_of_fused_systems():
+    """Two molecules the RDKit Book's "Aromaticity" section spells out.  'O=C1C=CC(=O)C2=C1OC=CO2': atoms 6 and 7 are aromatic
+    and the bond between them is not (m.GetAtomWithIdx(6).GetIsAromatic() -> True, ...(7)... -> True,
+    m.GetBondBetweenAtoms(6,7).GetIsAromatic() -> False) — neither ring is aromatic by itself, their envelope is.
+    Biphenylene 'C1=CC2=C(C=C1)C1=CC=CC=C21' is written back as 'c1ccc2c(c1)-c1ccccc1-2': two benzene rings, the four-ring's
+    other two bonds single."""
+    s = SmilesSet(["O=C1C=CC(=O)C2=C1OC=CO2", "C1=CC2=C(C=C1)C1=CC=CC=C21"])
+    assert np.all(s.status == 0)
+    atoms, bonds = s.graph(0)
+    assert atoms[6, 4] == 1 and atoms[7, 4] == 1 and int(atoms[:, 4].sum()) == 10
+    assert [int(t) for a, b, t, _ in bonds if {int(a), int(b)} == {6, 7}] == [2] and int((bonds[:, 2] == 12).sum()) == 10
+    atoms, bonds = s.graph(1)
+    assert int(atoms[:, 4].sum()) == 12 and int((bonds[:, 2] == 12).sum()) == 12
+    assert sorted((int(a), int(b), int(t)) for a, b, t, _ in bonds if t != 12) == [(2, 11, 1), (3, 6, 1)]
