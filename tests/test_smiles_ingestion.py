@@ -127,6 +127,9 @@ def test_ring_membership_is_cycle_membership():
                                       ("[CH5]", 2), ("C[N](C)(C)C", 2), ("C[N+](C)(C)C", 0), ("[O](C)(C)C", 2), ("C[O+](C)C", 0),
                                       ("[B-](F)(F)(F)F", 0), ("[B](F)(F)(F)F", 2), ("[C-]#[O+]", 0), ("[CH3]", 0), ("[CH2-]C", 0),
                                       ("[C-](C)(C)(C)C", 2), ("[C+](C)(C)(C)C", 2), ("[NH4+]", 0), ("[NH4]", 2), ("[OH3+]", 0), ("[O-]C", 0), ("[O-](C)C", 2),
+                                      # the two failures RDKit's "Getting Started" shows: 'CO(C)C' ("Explicit valence for atom # 1 O, 3,
+                                      # is greater than permitted") and 'c1cc1' ("Can't kekulize mol")
+                                      ("CO(C)C", 2), ("c1cc1", 5),
                                       # no Kekule structure (RDKit: "Can't kekulize mol"), aromatic marks outside rings
                                       ("c1cccc1", 5), ("c1ccnc1", 5), ("cc", 5), ("C:C", 5), ("c1cc[nH]c1", 0), ("c1ccn(C)c1", 0),
                                       # written aromatic where RDKit perceives none (cyclooctatetraene, 4-pyranone ring carbon chain)
