@@ -469,3 +469,21 @@ def test_mutated_smiles_never_crash_and_agree_with_the_oracle():
             assert np.array_equal(ga, atoms) and np.array_equal(gb, bonds), m
             n_ok += 1
     assert n_ok > 100
+
+
+def test_cfg1_fingerprints_equal_the_committed_digest():
+    """The CPU half of BASELINE configs[0] (ingestion + oracle Morgan on the 10 000 benchmark SMILES) still gives the committed
+    fingerprints (tests/golden/cfg1_chembl_10k_digest.json); the GPU half is held to the same file in test_config_size_gpu.py."""
+    import hashlib
+    import importlib.util
+    import json
+
+    golden_dir = Path(__file__).parent / "golden"
+    spec = importlib.util.spec_from_file_location("make_cfg1_digest", golden_dir / "make_cfg1_digest.py")
+    maker = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(maker)
+    fp = maker.fingerprints(golden_dir / "chembl_10k.smi")
+    golden = json.loads((golden_dir / "cfg1_chembl_10k_digest.json").read_text())
+    assert hashlib.sha256(np.ascontiguousarray(fp).tobytes()).hexdigest() == golden["fingerprints_sha256"]
+    assert int(np.unpackbits(fp.view(np.uint8), axis=1).sum()) == golden["bits_set_total"] == 523296
+    assert sum(golden["similarity_histogram_floor_100x"]) == 10_000 ** 2 and golden["similarity_histogram_floor_100x"][100] >= 10_000
