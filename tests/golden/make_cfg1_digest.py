@@ -38,7 +38,17 @@ def digest(fp):
         hist += np.bincount(np.floor(sim * 100.0).astype(np.int64).ravel(), minlength=101)
     bits = np.unpackbits(fp.view(np.uint8), axis=1)
     return {"molecules": int(len(fp)), "fingerprints_sha256": hashlib.sha256(np.ascontiguousarray(fp).tobytes()).hexdigest(),
-            "bits_set_total": int(bits.sum()), "similarity_histogram_floor_100x": hist.tolist()}
+            "bits_set_total": int(bits.sum()), "similarity_histogram_floor_100x": hist.tolist(),
+            "butina": {str(cutoff): butina_digest(fp, cutoff) for cutoff in (0.3, 0.6)}}
+
+
+def butina_digest(fp, cutoff):
+    """Butina clustering of the fingerprints at a distance cutoff (0.3 = the similarity threshold 0.7 of BASELINE configs[1]):
+    number of clusters, the ten largest sizes, and a hash of (centroid, members) of every cluster in output order."""
+    clusters, sizes, centroids = oracle.butina_fused(fp, cutoff)
+    flat = np.array([v for c, members in zip(centroids, clusters) for v in (c, len(members), *members)], dtype=np.int64)
+    return {"clusters": len(clusters), "largest": [len(c) for c in clusters[:10]], "singletons": sum(len(c) == 1 for c in clusters),
+            "sha256": hashlib.sha256(flat.tobytes()).hexdigest()}
 
 
 if __name__ == "__main__":

@@ -487,3 +487,4 @@ def test_cfg1_fingerprints_equal_the_committed_digest():
     assert hashlib.sha256(np.ascontiguousarray(fp).tobytes()).hexdigest() == golden["fingerprints_sha256"]
     assert int(np.unpackbits(fp.view(np.uint8), axis=1).sum()) == golden["bits_set_total"] == 523296
     assert sum(golden["similarity_histogram_floor_100x"]) == 10_000 ** 2 and golden["similarity_histogram_floor_100x"][100] >= 10_000
+    assert maker.butina_digest(fp, 0.3) == golden["butina"]["0.3"] and golden["butina"]["0.3"]["clusters"] == 6592
