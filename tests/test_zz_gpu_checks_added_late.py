@@ -1,0 +1,95 @@
+"""GPU checks that were written after round 2's last GPU run and have therefore not executed on an MI355X yet (their host
+logic has: tests/test_smiles_ingestion.py runs these bodies against a stubbed device, and every expected value below was
+produced on the CPU).  They live in a file that sorts last so that, under `pytest -x`, a surprise here cannot cut the
+established suite short.  Once they have passed on a GPU they can move next to their neighbours
+(test_smiles_ingestion.py, test_config_size_gpu.py, test_clustering_gpu.py, test_morgan_rdkit_known_answers.py)."""
+
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from nvmolkit_amd.clustering import fused_butina
+from nvmolkit_amd.fingerprints import MorganFingerprintGenerator, SmilesSet
+from nvmolkit_amd.similarity import crossTanimotoSimilarity
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).parent / "golden"
+BINAP_LIKE = "CC1(C)C2=C(C=CC(=C2)P(C3=CC=CC=C3)C4=CC=CC=C4)OC5=C1C=CC(=C5)P(C6=CC=CC=C6)C7=CC=CC=C7"
+BINAP_LIKE_AROMATIC = "CC1(C)c2c(ccc(c2)P(c3ccccc3)c4ccccc4)Oc5c1ccc(c5)P(c6ccccc6)c7ccccc7"
+
+
+def test_repeated_single_molecule_calls_never_come_back_empty():
+    """nvmolkit/tests/test_fingerprints.py:137-148 (GH issue 84) through the SMILES path: 256 single-molecule calls over four
+    generator configurations, none of them an empty fingerprint, all of them equal per configuration."""
+    configs = [(2, 512), (2, 1024), (3, 512), (3, 1024)]
+    first = {}
+    for i in range(256):
+        radius, fp_size = configs[i % len(configs)]
+        gen = MorganFingerprintGenerator(radius=radius, fpSize=fp_size)
+        fp = gen.GetFingerprintsFromSmiles([BINAP_LIKE]).torch().cpu().numpy()
+        assert fp.any(), f"empty fingerprint on attempt {i}"
+        assert np.array_equal(first.setdefault((radius, fp_size), fp), fp)
+    mols = SmilesSet([BINAP_LIKE_AROMATIC])
+    for (radius, fp_size), fp in first.items():
+        want = oracle.morgan_fingerprints(*mols.morgan_inputs([0], 64), 64, radius, fp_size)
+        assert np.array_equal(fp.view(np.uint32), want)
+
+
+def test_kekule_and_aromatic_spellings_give_one_fingerprint():
+    gen = MorganFingerprintGenerator(radius=2, fpSize=1024)
+    fp = gen.GetFingerprintsFromSmiles(["C1=CC=CC=C1", "c1ccccc1", "CN(=O)=O", "C[N+]([O-])=O"]).torch().cpu().numpy()
+    assert fp[0].any() and np.array_equal(fp[0], fp[1]) and fp[2].any() and np.array_equal(fp[2], fp[3])
+
+
+def test_kernel_bits_of_the_documented_examples():
+    """tests/test_morgan_rdkit_known_answers.py on the kernel: the bits of RDKit's documented examples."""
+    from tests.test_morgan_rdkit_known_answers import environments
+
+    gen = MorganFingerprintGenerator(radius=2, fpSize=2048)
+    fps = gen.GetFingerprints(["c1cccnc1C", "c1ccccc1CC1CC1"]).torch().cpu().numpy().view(np.uint32)
+    on = [sorted(int(w) * 32 + b for w in range(64) for b in range(32) if (int(row[w]) >> b) & 1) for row in fps]
+    codes, _ = environments("c1cccnc1C", 2)
+    assert on[0] == sorted({int(c) % 2048 for c in codes}) and 98513984 % 2048 in on[0] and 4048591891 % 2048 in on[0]
+    assert on[1][0] == 29 and 872 in on[1]
+
+
+def test_tanimoto_of_the_documented_pair():
+    """SMILES -> Morgan kernel -> similarity kernel on the pair of RDKit's Dice example: 7 common bits of 11 and 16 -> 7 / 20."""
+    fps = MorganFingerprintGenerator(radius=2, fpSize=1024).GetFingerprints(["Cc1ccccc1", "Cc1ncccc1"]).torch()
+    sim = crossTanimotoSimilarity(fps).torch().cpu().numpy()
+    assert sim[0, 1] == 7 / 20 and sim[1, 0] == 7 / 20 and sim[0, 0] == 1.0 and sim[1, 1] == 1.0
+
+
+@pytest.fixture(scope="module")
+def benchmark_fingerprints():
+    fps = MorganFingerprintGenerator(2, 2048).GetFingerprintsFromSmiles(SmilesSet.from_file(GOLDEN / "chembl_10k.smi")).torch()
+    golden = json.loads((GOLDEN / "cfg1_chembl_10k_digest.json").read_text())
+    return fps, golden
+
+
+def test_cfg1_equals_the_committed_digest(benchmark_fingerprints):
+    """BASELINE configs[0] against tests/golden/cfg1_chembl_10k_digest.json (written on the CPU by make_cfg1_digest.py): the
+    fingerprints' hash and the histogram of all 10^8 similarities (floor(100 x): the same IEEE operations on bit-identical values)."""
+    fps, golden = benchmark_fingerprints
+    assert hashlib.sha256(np.ascontiguousarray(fps.cpu().numpy()).tobytes()).hexdigest() == golden["fingerprints_sha256"]
+    sim = crossTanimotoSimilarity(fps).torch()
+    hist = torch.bincount(torch.floor(sim * 100.0).to(torch.int64).reshape(-1), minlength=101).cpu().numpy()
+    assert hist.tolist() == golden["similarity_histogram_floor_100x"]
+
+
+@pytest.mark.parametrize("cutoff", [0.3, 0.6])
+def test_fused_butina_on_the_benchmark_molecules_equals_the_committed_digest(benchmark_fingerprints, cutoff):
+    """The 10 000 benchmark molecules through the matrix-free Butina: same clusters, members and centroids, in the same order,
+    as the CPU chain recorded.  Cutoff 0.3 is the similarity threshold 0.7 of BASELINE configs[1]."""
+    fps, golden = benchmark_fingerprints
+    clusters, sizes, centroids = fused_butina(fps, cutoff, return_centroids=True)
+    want = golden["butina"][str(cutoff)]
+    assert len(clusters) == want["clusters"] and [len(c) for c in clusters[:10]] == want["largest"]
+    assert sum(len(c) == 1 for c in clusters) == want["singletons"] and sizes[-1] == 10_000
+    flat = np.array([v for c, members in zip(centroids, clusters) for v in (c, len(members), *members)], dtype=np.int64)
+    assert hashlib.sha256(flat.tobytes()).hexdigest() == want["sha256"]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# First GPU call of the next round: everything that was built after round 2's GPU budget ran out gets its first run on an
+# First GPU call of the next round (tests/test_zz_gpu_checks_added_late.py holds the GPU tests that have never run on a GPU): everything that was built after round 2's GPU budget ran out gets its first run on an
 # MI355X here — the full GPU suite (the SMILES staging path, the GH-84 regression through SMILES, the re-worded
 # BatchedForcefield error are new), bench.py, the reworked ingestion end to end and the reference's own benchmark shapes.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_sessions/next_first_call.sh r03_call1'
