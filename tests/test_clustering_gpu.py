@@ -241,4 +241,3 @@ def test_sharded_pairs_assemble_to_the_fused_result(n, n_shards):
     got = butina_from_pairs_gpu(n, counts, pairs)
     assert got == oracle.butina_fused(x, 0.35)
     assert got == fused_butina(d, 0.35, return_centroids=True)
-
