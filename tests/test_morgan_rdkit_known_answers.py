@@ -48,6 +48,16 @@ def test_radius_zero_identifiers(smiles, want):
     assert set(codes.tolist()) == want
 
 
+def test_count_fingerprints_everyone_has_seen():
+    """GetMorganFingerprint(mol, 2).GetNonzeroElements() of benzene and ethanol as RDKit prints them (they turn up in the
+    documentation, in the mailing list and in countless notebooks)."""
+    from collections import Counter
+
+    assert Counter(environments("c1ccccc1", 2)[0].tolist()) == {98513984: 6, 2763854213: 6, 3218693969: 6}
+    assert Counter(environments("CCO", 2)[0].tolist()) == {864662311: 1, 1535166686: 1, 2245384272: 1, 2246728737: 1,
+                                                            3542456614: 1, 4018048386: 1}
+
+
 def test_dice_similarity_example():
     from collections import Counter
 
