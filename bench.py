@@ -396,7 +396,7 @@ def main() -> None:
         ws_q = torch.empty(lib.nvmk_fp4_workspace_bytes(n_q, args.fp_bits), dtype=torch.uint8, device=device)
         ws_r = torch.empty(lib.nvmk_fp4_workspace_bytes(n_ref, args.fp_bits), dtype=torch.uint8, device=device)
     else:
-        os.environ["NVMK_SIM_PATH"] = "valu"
+        _native.set_option("NVMK_SIM_PATH", "valu")
 
     def step() -> None:
         nonlocal ref_gathered

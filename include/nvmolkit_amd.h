@@ -49,6 +49,13 @@ int nvmk_abi_version(void);
 int nvmk_device_count(int* count);
 /* Free / total bytes on the current device (reference: getDeviceFreeMemory, src/utils/device.h). */
 int nvmk_device_memory(size_t* free_bytes, size_t* total_bytes);
+/* Tuning / test switches (the NVMK_* names of DESIGN.md section 5: NVMK_SIM_PATH, NVMK_BFGS_LDS, ...).  The environment is
+ * read ONCE per process, when the first switch is looked up; afterwards a switch changes only through nvmk_set_option
+ * (value NULL or "" = unset), which is safe against concurrent callers of the other entry points: each call takes one
+ * consistent snapshot.  The reference has no counterpart (its tuning lives in compile-time constants and
+ * BatchHardwareOptions, src/utils/host_vector.h / nvmolkit/types.py:44-110).  Unknown names are an invalid argument. */
+int nvmk_set_option(const char* name, const char* value);
+int nvmk_get_option(const char* name, char* value, size_t capacity);
 
 /* ---- S1/S2: dense N x M cross-similarity ------------------------------------------------------
  * Replaces launchCrossTanimotoSimilarity / launchCrossCosineSimilarity

@@ -45,6 +45,8 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_abi_version": (_int, []),
     "nvmk_device_count": (_int, [ctypes.POINTER(_int)]),
     "nvmk_device_memory": (_int, [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "nvmk_set_option": (_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "nvmk_get_option": (_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]),
     "nvmk_cross_tanimoto_f64": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _vp]),
     "nvmk_cross_cosine_f64": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _vp]),
     "nvmk_fp4_workspace_bytes": (ctypes.c_size_t, [_i64, _int]),
@@ -164,6 +166,30 @@ def check(rc: int, what: str = "") -> None:
     if rc == ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
     raise RuntimeError(msg)
+
+
+def set_option(name: str, value) -> None:
+    """Set a library switch (``NVMK_*`` of DESIGN.md); ``None`` unsets it.  The environment is only read once per process."""
+    check(lib().nvmk_set_option(name.encode(), None if value is None else str(value).encode()), "nvmk_set_option")
+
+
+def get_option(name: str) -> str:
+    buf = ctypes.create_string_buffer(64)
+    check(lib().nvmk_get_option(name.encode(), buf, len(buf)), "nvmk_get_option")
+    return buf.value.decode()
+
+
+@contextlib.contextmanager
+def options(**values):
+    """``with options(NVMK_SIM_PATH="valu"): ...`` — set switches for a block, then restore what they held."""
+    old = {k: get_option(k) for k in values}
+    try:
+        for k, v in values.items():
+            set_option(k, v)
+        yield
+    finally:
+        for k, v in old.items():
+            set_option(k, v if v != "" else None)
 
 
 @contextlib.contextmanager

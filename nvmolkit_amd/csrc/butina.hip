@@ -27,6 +27,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
+#include "options.h"
 #include "fp4.h"
 
 namespace nvmk {
@@ -321,20 +322,11 @@ __global__ __launch_bounds__(NT) void neighbor_count_generic_kernel(const uint32
   if (lane == 0 && n != 0) atomicAdd(&counts[px], sign * n);
 }
 
-inline bool force_valu() {
-  const char* e = std::getenv("NVMK_SIM_PATH");
-  return e != nullptr && std::strcmp(e, "valu") == 0;
-}
-inline bool force_mfma() {
-  const char* e = std::getenv("NVMK_SIM_PATH");
-  return e != nullptr && std::strcmp(e, "mfma") == 0;
-}
+inline bool force_valu() { return opt::get(opt::kSimPath).is("valu"); }
+inline bool force_mfma() { return opt::get(opt::kSimPath).is("mfma"); }
 
 // NVMK_BUTINA_ROUNDS=dense keeps the round loop that streams the fingerprint matrix (tests run both formulations)
-inline bool dense_rounds() {
-  const char* e = std::getenv("NVMK_BUTINA_ROUNDS");
-  return e != nullptr && std::strcmp(e, "dense") == 0;
-}
+inline bool dense_rounds() { return opt::get(opt::kButinaRounds).is("dense"); }
 
 struct CountPlan {
   int             metric;
@@ -941,8 +933,7 @@ __global__ void scatter_counts_kernel(const int32_t* __restrict__ sorted, const 
   if (i < n) out[perm[i]] = sorted[i];
 }
 inline bool sorted_first_pass() {  // default on; NVMK_BUTINA_SORT=0 keeps the input order
-  const char* e = std::getenv("NVMK_BUTINA_SORT");
-  return e == nullptr || e[0] != '0';
+  return opt::get(opt::kButinaSort).s[0] != '0';
 }
 
 // Buffers of a fused-Butina run: one scratch block | state | nAliveNext[2] | counts | alive[2] | removed | clusterIndices |

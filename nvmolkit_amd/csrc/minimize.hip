@@ -23,6 +23,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "options.h"
 #include "ff_grad.h"
 #include "hess_pass.h"
 #include "ff_terms.h"
@@ -872,33 +873,69 @@ constexpr int    MAX_LS_ITERS  = 1000;
 // PROFILE (NVMK_BFGS_PROFILE=1; DG, ETK and MMFF): thread 0 accumulates wall-clock ticks (100 MHz) per phase into
 // prof[sys * 8 + k]: 0 line-search energy evaluations, 1 gradient, 2 pass over H (pending update + H g), 3 update scalars + direction,
 // 4 whole kernel, 5 iterations, 6 energy evaluations.
-// Two workgroups per CU (up to 256 VGPRs each) share the LDS.
-template <int KIND, bool PROFILE = false>
-__global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __restrict__ positions, const double w0, const double w1,
-                                                  const int maxIters, const double gradTol, const int scaleGrads,
-                                                  const uint8_t* __restrict__ active, const int64_t* __restrict__ hessStarts,
-                                                  const int32_t* __restrict__ order,
-                                                  double* __restrict__ hessians, double* __restrict__ energies,
-                                                  int16_t* __restrict__ statuses, int32_t* __restrict__ itersOut,
-                                                  int64_t* __restrict__ prof, const int ldsDoubles,
-                                                  unsigned long long* __restrict__ stats) {
+//
+// Size classes (the reference switches between shared and global memory per launch, bfgs_minimize_permol_kernels.cu:796-932,
+// bfgs_types.h:36-43; here every launch is split by what a system's 17 n-vectors need):
+//   class A  vectors <= half the LDS of a CU: one workgroup per system, two workgroups per CU, per-system inverse Hessians;
+//   class B  vectors <= the whole LDS: one workgroup per CU;
+//   class C  anything larger (GVEC): the vectors live in a per-workgroup HBM / L2 work area, any size.
+// Classes B and C run as persistent workgroups that take systems off a counter (largest first) and keep ONE inverse-Hessian
+// slot each, so the memory a launch needs is bounded by the workgroups in flight, not by the number of large systems
+// (a 1000-atom 4-D system has a 64 MB triangle).
+struct BfgsArgs {
+  double*                         positions;
+  double                          w0, w1;
+  int                             maxIters;
+  double                          gradTol;
+  int                             scaleGrads;
+  const uint8_t*                  active;
+  const int64_t*                  hessStarts;   // per-system offsets into `hessians` (slotDoubles == 0)
+  const int32_t*                  order;        // the systems of this launch in hand-out order
+  int                             nItems;
+  int*                            counter;      // persistent launches: next item to hand out (starts at 0); else nullptr
+  double*                         hessians;
+  int64_t                         slotDoubles;  // > 0: workgroup k owns hessians[k * slotDoubles ...)
+  double*                         vecWork;      // GVEC: workgroup k owns vecWork[k * vecStride ...)
+  int64_t                         vecStride;
+  double*                         energies;
+  int16_t*                        statuses;
+  int32_t*                        itersOut;
+  int64_t*                        prof;
+  int                             ldsDoubles;
+  unsigned long long*             stats;
+};
+
+template <int KIND, bool GVEC, bool PROFILE>
+__device__ __forceinline__ void bfgs_system(const Batch& b, const BfgsArgs& A, const int sys, char* smem) {
+  double* __restrict__ const          positions  = A.positions;
+  const double                        w0 = A.w0, w1 = A.w1;
+  const int                           maxIters   = A.maxIters;
+  const double                        gradTol    = A.gradTol;
+  const int                           scaleGrads = A.scaleGrads;
+  double* __restrict__ const          energies   = A.energies;
+  int16_t* __restrict__ const         statuses   = A.statuses;
+  int32_t* __restrict__ const         itersOut   = A.itersOut;
+  int64_t* __restrict__ const         prof       = A.prof;
+  unsigned long long* __restrict__ const stats   = A.stats;
   int64_t tk[7] = {0, 0, 0, 0, 0, 0, 0};
   auto    now   = [&]() -> int64_t { return PROFILE ? static_cast<int64_t>(wall_clock64()) : 0; };
   const int64_t tStart = now();
   (void)tk;
   (void)tStart;
   constexpr int DIM = Dim<KIND>::value;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // workgroups are handed out in launch order: the largest systems go first so that the launch does not end on a long job
-  const int sys = order[blockIdx.x];
-  if (active && !active[sys]) return;
+  if (A.active && !A.active[sys]) return;
   const int tid = threadIdx.x;
   const int a0  = b.atomStarts[sys];
   const int n   = (b.atomStarts[sys + 1] - a0) * DIM;
   double*   gpos = positions + static_cast<int64_t>(a0) * DIM;
-  double*   H    = hessians + hessStarts[sys];
+  double*   H    = A.hessians + (A.slotDoubles > 0 ? static_cast<int64_t>(blockIdx.x) * A.slotDoubles : A.hessStarts[sys]);
 
-  double* pos   = reinterpret_cast<double*>(smem);
+  double* pos;
+  if constexpr (GVEC) {
+    pos = A.vecWork + static_cast<int64_t>(blockIdx.x) * A.vecStride;
+  } else {
+    pos = reinterpret_cast<double*>(smem);
+  }
   double* grad  = pos + n;
   double* dir   = grad + n;   // search direction, then the step actually taken (xi)
   double* trial = dir + n;    // line-search positions
@@ -911,11 +948,19 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   double* pu    = phdg + n;
   double* hdiag = pu + n;     // diagonal of the inverse Hessian (the strict lower triangle is in Hl / H)
   double* part  = hdiag + n;  // (1 + NW) n partial sums of the pass; its first NW slabs double as the per-wave gradients
-  BlockReducer br{part + (1 + NW) * n, 0};  // kRedDoubles of reduction scratch
+  // kRedDoubles of reduction scratch: always LDS
+  double* redScratch;
+  if constexpr (GVEC) {
+    __shared__ double redStatic[kRedDoubles];
+    redScratch = redStatic;
+  } else {
+    redScratch = part + (1 + NW) * n;
+  }
+  BlockReducer br{redScratch, 0};
   // Inverse Hessian: the first Rl rows of the packed triangle live in LDS behind the vectors (as many as the launch's LDS
   // budget holds: all of them for small systems), rows Rl.. stream from HBM as before.
-  double*   Hl = br.red + kRedDoubles;
-  const int Rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n));
+  double*   Hl = GVEC ? nullptr : br.red + kRedDoubles;
+  const int Rl = GVEC ? 0 : resident_rows(n, lds_hessian_doubles(A.ldsDoubles, n));
 
   if (n == 0) {
     if (tid == 0) {
@@ -1193,6 +1238,23 @@ __global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, double* __re
   }
 }
 
+// Two workgroups per CU (up to 256 VGPRs each) share the LDS.
+template <int KIND, bool GVEC = false, bool PROFILE = false>
+__global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, const BfgsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int nextItem;
+  // workgroups are handed out in launch order: the largest systems go first so that the launch does not end on a long job
+  int item = blockIdx.x;
+  while (item < A.nItems) {
+    bfgs_system<KIND, GVEC, PROFILE>(b, A, A.order[item], smem);
+    if (A.counter == nullptr) break;  // one system per workgroup
+    __syncthreads();                  // the system's last reads of its vectors precede the next one's first writes
+    if (threadIdx.x == 0) nextItem = static_cast<int>(gridDim.x) + atomicAdd(A.counter, 1);
+    __syncthreads();
+    item = nextItem;
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 
 int to_batch(const nvmk_ff_batch* in, Batch& out) {
@@ -1251,6 +1313,31 @@ using namespace nvmk::minim;
 namespace {
 // device counters the BFGS kernels add to when set (nvmk_bfgs_set_stats); process-wide, off by default
 std::atomic<unsigned long long*> g_stats{nullptr};
+
+// Two highest-priority streams + their fork / join events per (host thread, device), created on first use and kept: the
+// large size classes of a minimisation run on them next to class A on the caller's stream.
+struct SideStreams {
+  hipStream_t s[2]    = {nullptr, nullptr};
+  hipEvent_t  fork    = nullptr;
+  hipEvent_t  join[2] = {nullptr, nullptr};
+  bool        ok      = false;
+};
+SideStreams* side_streams(const int dev) {
+  thread_local SideStreams table[64];
+  if (dev < 0 || dev >= 64) return nullptr;
+  SideStreams& t = table[dev];
+  if (!t.ok) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
+    for (int k = 0; k < 2; ++k) {
+      if (hipStreamCreateWithPriority(&t.s[k], hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&t.join[k], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    t.ok = true;
+  }
+  return &t;
+}
 }  // namespace
 
 extern "C" {
@@ -1297,60 +1384,54 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
   NVMK_REQUIRE(max_iters >= 0, "bfgs: negative iteration count");
   hipStream_t stream = as_stream(stream_);
   const int   dim    = (b.kind == NVMK_FF_DG || b.kind == NVMK_FF_QUARTIC) ? 4 : 3;
-  // LDS need of the largest system, then the launch's LDS budget.  NVMK_BFGS_LDS: "auto" (default) = what lets two
-  // workgroups share a CU; "full" = the whole 160 KiB (one workgroup per CU); "0" = vectors only (inverse Hessians
-  // entirely in HBM, the round-1 layout); a number = KiB per workgroup.
-  int maxN = 0;
-  for (int s = 0; s < b.nSystems; ++s) {
-    const int64_t n = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
-    NVMK_REQUIRE(n >= 0, "bfgs: atom_starts must be non-decreasing");
-    maxN = std::max<int>(maxN, static_cast<int>(n));
-  }
-  const size_t vecBytes = static_cast<size_t>(lds_vector_doubles(maxN)) * sizeof(double);
   constexpr size_t kLdsPerCu = 160 * 1024, kLdsReserve = 1024;  // static LDS of the kernel + allocation granularity
-  NVMK_REQUIRE(vecBytes <= kLdsPerCu - kLdsReserve, "bfgs: a system with %d coordinates needs %zu bytes of LDS (max 160 KiB)", maxN,
-               vecBytes);
-  // Two workgroups per CU share the LDS.  (A variant compiled for three — 168 VGPRs — was worth +3 % with the round-1
-  // evaluation code and -20 % with the current one, which keeps every group's leading terms in registers: removed.)
-  size_t budget = kLdsPerCu / 2 - kLdsReserve;
-  if (const char* e = std::getenv("NVMK_BFGS_LDS")) {
-    if (std::strcmp(e, "full") == 0) {
-      budget = kLdsPerCu - kLdsReserve;
-    } else if (std::strcmp(e, "auto") != 0) {
-      budget = static_cast<size_t>(std::max(0L, std::atol(e))) * 1024;
+  constexpr size_t kHalf = kLdsPerCu / 2 - kLdsReserve, kFull = kLdsPerCu - kLdsReserve;
+  // LDS budget of a class-A workgroup.  NVMK_BFGS_LDS: "auto" (default) = what lets two workgroups share a CU; "full" = the
+  // whole 160 KiB (one workgroup per CU); "0" = vectors only (inverse Hessians entirely in HBM, the round-1 layout); a
+  // number = KiB per workgroup.  (A variant compiled for three workgroups per CU — 168 VGPRs — was worth +3 % with the
+  // round-1 evaluation code and -20 % with the current one, which keeps every group's leading terms in registers: removed.)
+  size_t budgetA = kHalf;
+  {
+    const opt::Text e = opt::get(opt::kBfgsLds);
+    if (e.is("full")) {
+      budgetA = kFull;
+    } else if (e.set() && !e.is("auto")) {
+      budgetA = std::min(static_cast<size_t>(std::max(0L, e.num(0))) * 1024, kFull);
     }
   }
-  budget = std::min(std::max(budget, vecBytes), kLdsPerCu - kLdsReserve);
-  const size_t shmem = std::min(budget, vecBytes + static_cast<size_t>(hess_row_offset(maxN)) * sizeof(double));
-  const int    ldsDoubles = static_cast<int>(shmem / sizeof(double));
-  // offsets of the HBM part of every inverse Hessian (rows Rl.. of the packed lower triangle)
-  std::vector<int64_t> hs(static_cast<size_t>(b.nSystems) + 1, 0);
+  const bool allGlobal = opt::get(opt::kBfgsVectors).is("global");
+  const bool overlap   = !opt::get(opt::kBfgsOverlap).is("0");
+
+  // ---- size classes
+  struct Class {
+    std::vector<int32_t> order;  // systems, largest first (stable)
+    int                  maxN = 0;
+  };
+  Class cls[3];
   for (int s = 0; s < b.nSystems; ++s) {
-    const int n  = (h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
-    const int rl = resident_rows(n, lds_hessian_doubles(ldsDoubles, n));
-    hs[static_cast<size_t>(s) + 1] = hs[static_cast<size_t>(s)] + hess_row_offset(n) - hess_row_offset(rl);
+    const int64_t n64 = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
+    NVMK_REQUIRE(n64 >= 0, "bfgs: atom_starts must be non-decreasing");
+    NVMK_REQUIRE(n64 <= 46000, "bfgs: a system with %lld coordinates is beyond the packed triangle's 32-bit row offsets",
+                 static_cast<long long>(n64));
+    const size_t vecBytes = static_cast<size_t>(lds_vector_doubles(n64)) * sizeof(double);
+    const int    c        = allGlobal ? 2 : vecBytes <= std::max(kHalf, budgetA) ? 0 : vecBytes <= kFull ? 1 : 2;
+    cls[c].order.push_back(s);
+    cls[c].maxN = std::max(cls[c].maxN, static_cast<int>(n64));
   }
-  StreamScratch hessMem, startsMem, orderMem;
-  NVMK_HIP_CHECK(hessMem.alloc(static_cast<size_t>(hs.back() + kHessTailPadDoubles) * sizeof(double), stream));
-  NVMK_HIP_CHECK(startsMem.alloc(hs.size() * sizeof(int64_t), stream));
-  NVMK_HIP_CHECK(hipMemcpyAsync(startsMem.ptr, hs.data(), hs.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-  // launch order: largest system first (stable), see bfgs_kernel
-  std::vector<int32_t> order(static_cast<size_t>(b.nSystems));
-  for (int s = 0; s < b.nSystems; ++s) order[static_cast<size_t>(s)] = s;
-  std::stable_sort(order.begin(), order.end(), [&](const int32_t x, const int32_t y) {
-    return h_atom_starts[x + 1] - h_atom_starts[x] > h_atom_starts[y + 1] - h_atom_starts[y];
-  });
-  // XCD-aware hand-out: workgroup p runs on XCD p % 8 and every XCD has its own L2.  Conformers of one molecule are
-  // neighbours in `order` (same size, stable sort) and share their term tables (system_mol), so a run of kXcdGroup
+  for (Class& c : cls) {
+    std::stable_sort(c.order.begin(), c.order.end(), [&](const int32_t x, const int32_t y) {
+      return h_atom_starts[x + 1] - h_atom_starts[x] > h_atom_starts[y + 1] - h_atom_starts[y];
+    });
+  }
+  // XCD-aware hand-out of class A: workgroup p runs on XCD p % 8 and every XCD has its own L2.  Conformers of one molecule
+  // are neighbours in `order` (same size, stable sort) and share their term tables (system_mol), so a run of kXcdGroup
   // consecutive systems goes to ONE XCD: its L2 then holds a handful of molecules' tables instead of one per resident
   // workgroup.  Chunks of 8 * kXcdGroup systems keep the sizes balanced over the XCDs.  NVMK_BFGS_XCD_GROUP=1: plain order.
   {
-    static const int kXcdGroup = [] {
-      const char* e = std::getenv("NVMK_BFGS_XCD_GROUP");
-      const int   v = e != nullptr ? std::atoi(e) : 16;
-      return v >= 1 ? v : 16;
-    }();
-    const int64_t n = b.nSystems, chunk = 8LL * kXcdGroup;
+    const long    g         = opt::get(opt::kBfgsXcdGroup).num(16);
+    const int     kXcdGroup = g >= 1 && g <= 4096 ? static_cast<int>(g) : 16;
+    auto&         order     = cls[0].order;
+    const int64_t n = static_cast<int64_t>(order.size()), chunk = 8LL * kXcdGroup;
     if (kXcdGroup > 1 && b.sysMol != nullptr && n >= 2 * chunk) {
       std::vector<int32_t> grouped(order.size());
       const int64_t        full = n / chunk * chunk;  // the ragged tail keeps the plain order
@@ -1362,39 +1443,190 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
       order.swap(grouped);
     }
   }
-  NVMK_HIP_CHECK(orderMem.alloc(order.size() * sizeof(int32_t), stream));
-  NVMK_HIP_CHECK(hipMemcpyAsync(orderMem.ptr, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  static const bool profile = [] {
-    const char* e = std::getenv("NVMK_BFGS_PROFILE");
-    return e != nullptr && e[0] == '1';
-  }();
-  if (profile && (b.kind == NVMK_FF_DG || b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_ETK)) {
-    StreamScratch profMem;
-    const size_t  words = static_cast<size_t>(b.nSystems) * 8;
-    NVMK_HIP_CHECK(profMem.alloc(words * sizeof(int64_t), stream));
-    NVMK_HIP_CHECK(hipMemsetAsync(profMem.ptr, 0, words * sizeof(int64_t), stream));
-    if (shmem > 64 * 1024) {
-      const void* fn = b.kind == NVMK_FF_DG ? reinterpret_cast<const void*>(bfgs_kernel<NVMK_FF_DG, true>)
-                       : b.kind == NVMK_FF_ETK ? reinterpret_cast<const void*>(bfgs_kernel<NVMK_FF_ETK, true>)
-                                               : reinterpret_cast<const void*>(bfgs_kernel<NVMK_FF_MMFF, true>);
-      NVMK_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem)));
-    }
-    if (b.kind == NVMK_FF_DG) {
-      hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_DG, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters,
-                         grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies, d_statuses,
-                         d_iters, profMem.as<int64_t>(), ldsDoubles, g_stats.load());
-    } else if (b.kind == NVMK_FF_ETK) {
-      hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_ETK, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1,
-                         max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies,
-                         d_statuses, d_iters, profMem.as<int64_t>(), ldsDoubles, g_stats.load());
+
+  // ---- per-class launch plans
+  int dev = 0, nCu = 256;
+  NVMK_HIP_CHECK(hipGetDevice(&dev));
+  {
+    static std::atomic<int> cuCache[64] = {};
+    int&                    dummy       = nCu;
+    (void)dummy;
+    if (dev >= 0 && dev < 64 && cuCache[dev].load() > 0) {
+      nCu = cuCache[dev].load();
     } else {
-      hipLaunchKernelGGL((bfgs_kernel<NVMK_FF_MMFF, true>), dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1,
-                         max_iters, grad_tol, scale_grads, d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies,
-                         d_statuses, d_iters, profMem.as<int64_t>(), ldsDoubles, g_stats.load());
+      NVMK_HIP_CHECK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, dev));
+      if (nCu <= 0) nCu = 256;
+      if (dev >= 0 && dev < 64) cuCache[dev].store(nCu);
     }
-    NVMK_LAUNCH_CHECK();
-    std::vector<int64_t> h(words);
-    NVMK_HIP_CHECK(hipMemcpyAsync(h.data(), profMem.ptr, words * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  }
+  struct Plan {
+    bool                 used = false, gvec = false;
+    size_t               shmem = 0;
+    int                  ldsDoubles = 0, grid = 0;
+    int64_t              slotDoubles = 0, vecStride = 0;
+    std::vector<int64_t> hs;  // class A: per-system offsets (indexed by system), else empty
+    StreamScratch        hessMem, startsMem, orderMem, counterMem, vecMem;
+  };
+  Plan plan[3];
+  size_t slotBytes[3] = {0, 0, 0};
+  for (int c = 0; c < 3; ++c) {
+    Plan& P = plan[c];
+    if (cls[c].order.empty()) continue;
+    P.used = true;
+    P.gvec = c == 2;
+    const int    maxN     = cls[c].maxN;
+    const size_t vecBytes = static_cast<size_t>(lds_vector_doubles(maxN)) * sizeof(double);
+    if (P.gvec) {
+      P.shmem      = 0;
+      P.ldsDoubles = 0;
+      P.vecStride  = (lds_vector_doubles(maxN) + 1) & ~int64_t{1};
+    } else {
+      const size_t budget = c == 0 ? std::min(std::max(budgetA, vecBytes), kFull) : kFull;
+      P.shmem      = std::min(budget, vecBytes + static_cast<size_t>(hess_row_offset(maxN)) * sizeof(double));
+      P.ldsDoubles = static_cast<int>(P.shmem / sizeof(double));
+    }
+    if (c == 0) {
+      // offsets of the HBM part of every inverse Hessian (rows Rl.. of the packed lower triangle)
+      P.hs.assign(static_cast<size_t>(b.nSystems) + 1, 0);
+      int64_t at = 0;
+      for (const int32_t s : cls[c].order) {
+        const int n  = (h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
+        const int rl = resident_rows(n, lds_hessian_doubles(P.ldsDoubles, n));
+        P.hs[static_cast<size_t>(s)] = at;
+        at += hess_row_offset(n) - hess_row_offset(rl);
+      }
+      P.hs[static_cast<size_t>(b.nSystems)] = at;
+      P.grid                                = static_cast<int>(cls[c].order.size());
+    } else {
+      int64_t slot = 0;
+      for (const int32_t s : cls[c].order) {
+        const int n  = (h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
+        const int rl = P.gvec ? 0 : resident_rows(n, lds_hessian_doubles(P.ldsDoubles, n));
+        slot         = std::max<int64_t>(slot, hess_row_offset(n) - hess_row_offset(rl));
+      }
+      P.slotDoubles = ((slot + kHessTailPadDoubles) + 1) & ~int64_t{1};
+      slotBytes[c]  = static_cast<size_t>(P.slotDoubles + P.vecStride) * sizeof(double);
+      P.grid        = static_cast<int>(std::min<size_t>(cls[c].order.size(), static_cast<size_t>(nCu) * (c == 1 ? 1 : 2)));
+    }
+  }
+  // the persistent classes together take at most half of the free memory (at least one slot each)
+  if (plan[1].used || plan[2].used) {
+    size_t freeB = 0, totalB = 0;
+    NVMK_HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+    const size_t want = slotBytes[1] * static_cast<size_t>(plan[1].grid) + slotBytes[2] * static_cast<size_t>(plan[2].grid);
+    if (want > freeB / 2) {
+      const double f = static_cast<double>(freeB / 2) / static_cast<double>(want);
+      for (int c = 1; c < 3; ++c)
+        if (plan[c].used) plan[c].grid = std::max(1, static_cast<int>(plan[c].grid * f));
+    }
+  }
+  for (int c = 0; c < 3; ++c) {
+    Plan& P = plan[c];
+    if (!P.used) continue;
+    const auto& order = cls[c].order;
+    NVMK_HIP_CHECK(P.orderMem.alloc(order.size() * sizeof(int32_t), stream));
+    NVMK_HIP_CHECK(hipMemcpyAsync(P.orderMem.ptr, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    if (c == 0) {
+      NVMK_HIP_CHECK(P.hessMem.alloc(static_cast<size_t>(P.hs.back() + kHessTailPadDoubles) * sizeof(double), stream));
+      NVMK_HIP_CHECK(P.startsMem.alloc(P.hs.size() * sizeof(int64_t), stream));
+      NVMK_HIP_CHECK(hipMemcpyAsync(P.startsMem.ptr, P.hs.data(), P.hs.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    } else {
+      NVMK_HIP_CHECK(P.hessMem.alloc(static_cast<size_t>(P.slotDoubles) * static_cast<size_t>(P.grid) * sizeof(double), stream));
+      NVMK_HIP_CHECK(P.counterMem.alloc(sizeof(int), stream));
+      NVMK_HIP_CHECK(hipMemsetAsync(P.counterMem.ptr, 0, sizeof(int), stream));
+      if (P.gvec) NVMK_HIP_CHECK(P.vecMem.alloc(static_cast<size_t>(P.vecStride) * static_cast<size_t>(P.grid) * sizeof(double), stream));
+    }
+  }
+
+  const bool profile = opt::get(opt::kBfgsProfile).is("1") && (b.kind == NVMK_FF_DG || b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_ETK);
+  StreamScratch profMem;
+  const size_t  profWords = static_cast<size_t>(b.nSystems) * 8;
+  if (profile) {
+    NVMK_HIP_CHECK(profMem.alloc(profWords * sizeof(int64_t), stream));
+    NVMK_HIP_CHECK(hipMemsetAsync(profMem.ptr, 0, profWords * sizeof(int64_t), stream));
+  }
+
+  auto launch = [&](const int c, hipStream_t on) -> int {
+    Plan&    P = plan[c];
+    BfgsArgs A;
+    A.positions   = d_pos;
+    A.w0          = w0;
+    A.w1          = w1;
+    A.maxIters    = max_iters;
+    A.gradTol     = grad_tol;
+    A.scaleGrads  = scale_grads;
+    A.active      = d_active;
+    A.hessStarts  = P.startsMem.as<int64_t>();
+    A.order       = P.orderMem.as<int32_t>();
+    A.nItems      = static_cast<int>(cls[c].order.size());
+    A.counter     = P.counterMem.as<int>();
+    A.hessians    = P.hessMem.as<double>();
+    A.slotDoubles = P.slotDoubles;
+    A.vecWork     = P.vecMem.as<double>();
+    A.vecStride   = P.vecStride;
+    A.energies    = d_energies;
+    A.statuses    = d_statuses;
+    A.itersOut    = d_iters;
+    A.prof        = profMem.as<int64_t>();
+    A.ldsDoubles  = P.ldsDoubles;
+    A.stats       = g_stats.load();
+    auto go = [&](auto kern) -> int {
+      if (P.shmem > 64 * 1024) {
+        NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(P.shmem)));
+      }
+      hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(P.grid)), dim3(NT), P.shmem, on, b, A);
+      NVMK_LAUNCH_CHECK();
+      return NVMK_OK;
+    };
+    if (profile && !P.gvec) {
+      if (b.kind == NVMK_FF_DG) return go(bfgs_kernel<NVMK_FF_DG, false, true>);
+      if (b.kind == NVMK_FF_ETK) return go(bfgs_kernel<NVMK_FF_ETK, false, true>);
+      return go(bfgs_kernel<NVMK_FF_MMFF, false, true>);
+    }
+    int r = NVMK_OK;
+    if (P.gvec) {
+      NVMK_FF_DISPATCH(b.kind, r = go(bfgs_kernel<K, true>));
+    } else {
+      NVMK_FF_DISPATCH(b.kind, r = go(bfgs_kernel<K, false>));
+    }
+    return r;
+  };
+
+  // The large classes go first and, when class A has work too, on side streams of the highest priority: their few long
+  // workgroups start at once and the many small systems fill the rest of the chip around them, instead of one class
+  // waiting for the other (a 400-atom distance-geometry minimisation alone takes longer than 4000 drug-sized ones).
+  const int nUsed = (plan[0].used ? 1 : 0) + (plan[1].used ? 1 : 0) + (plan[2].used ? 1 : 0);
+  if (nUsed > 1 && overlap) {
+    SideStreams* side = side_streams(dev);
+    NVMK_REQUIRE(side != nullptr, "bfgs: could not create the side streams of device %d", dev);
+    NVMK_HIP_CHECK(hipEventRecord(side->fork, stream));
+    int k = 0;
+    for (int c = 2; c >= 0; --c) {
+      if (!plan[c].used) continue;
+      if (c == 0 || k >= 2) {
+        rc = launch(c, stream);
+        if (rc != NVMK_OK) return rc;
+        continue;
+      }
+      NVMK_HIP_CHECK(hipStreamWaitEvent(side->s[k], side->fork, 0));
+      rc = launch(c, side->s[k]);
+      if (rc != NVMK_OK) return rc;
+      NVMK_HIP_CHECK(hipEventRecord(side->join[k], side->s[k]));
+      ++k;
+    }
+    for (int j = 0; j < k; ++j) NVMK_HIP_CHECK(hipStreamWaitEvent(stream, side->join[j], 0));
+  } else {
+    for (int c = 2; c >= 0; --c) {
+      if (!plan[c].used) continue;
+      rc = launch(c, stream);
+      if (rc != NVMK_OK) return rc;
+    }
+  }
+
+  if (profile) {
+    std::vector<int64_t> h(profWords);
+    NVMK_HIP_CHECK(hipMemcpyAsync(h.data(), profMem.ptr, profWords * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     NVMK_HIP_CHECK(hipStreamSynchronize(stream));
     double  sum[7] = {0, 0, 0, 0, 0, 0, 0};
     int64_t ran = 0, longest = 0;
@@ -1415,18 +1647,7 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
     }
     return NVMK_OK;
   }
-  NVMK_FF_DISPATCH(b.kind, {
-    auto kern = bfgs_kernel<K>;
-    if (shmem > 64 * 1024) {
-      NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(shmem)));
-    }
-    hipLaunchKernelGGL(kern, dim3(b.nSystems), dim3(NT), shmem, stream, b, d_pos, w0, w1, max_iters, grad_tol, scale_grads,
-                       d_active, startsMem.as<int64_t>(), orderMem.as<int32_t>(), hessMem.as<double>(), d_energies, d_statuses, d_iters,
-                       static_cast<int64_t*>(nullptr), ldsDoubles, g_stats.load());
-  });
-  NVMK_LAUNCH_CHECK();
-  NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // `hs` (pageable) must outlive its async copy; scratch is freed in stream order
+  NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // host staging (pageable) must outlive its async copies; scratch is freed in stream order
   return NVMK_OK;
 }
 

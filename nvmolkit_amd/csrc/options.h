@@ -1,0 +1,39 @@
+// Tuning / test switches of the library (the NVMK_* names of DESIGN.md).  Each is read from the environment ONCE per
+// process, the first time any switch is looked up; afterwards a value changes only through nvmk_set_option (C ABI), under a
+// lock.  Entry points take a consistent snapshot per call, so concurrent callers never race with getenv / setenv.
+#pragma once
+
+#include <cstdlib>
+#include <cstring>
+
+namespace nvmk {
+namespace opt {
+
+enum Id {
+  kSimPath,         // NVMK_SIM_PATH         auto | mfma | valu
+  kCountThreshold,  // NVMK_COUNT_THRESHOLD  (unset) | table
+  kCountSuper,      // NVMK_COUNT_SUPER      supertile edge of the count kernel (experiments)
+  kButinaRounds,    // NVMK_BUTINA_ROUNDS    (unset) | dense | serial
+  kButinaSort,      // NVMK_BUTINA_SORT      (unset) | 0
+  kBfgsLds,         // NVMK_BFGS_LDS         auto | 0 | full | KiB
+  kBfgsXcdGroup,    // NVMK_BFGS_XCD_GROUP   16 | n
+  kBfgsProfile,     // NVMK_BFGS_PROFILE     1
+  kBfgsVectors,     // NVMK_BFGS_VECTORS     auto | global (tests: every system through the HBM-vector kernels)
+  kBfgsOverlap,     // NVMK_BFGS_OVERLAP     1 | 0 (0: size classes run one after the other on the caller's stream)
+  kNumOptions
+};
+
+struct Text {
+  char s[48];
+  bool set() const { return s[0] != '\0'; }
+  bool is(const char* v) const { return std::strcmp(s, v) == 0; }
+  long num(const long dflt) const { return set() ? std::atol(s) : dflt; }
+};
+
+const char* name(Id id);
+Text        get(Id id);
+int         set(const char* name, const char* value);  // 0 = ok, -1 = unknown name; value NULL / "" = unset
+int         find(const char* name);                     // Id or -1
+
+}  // namespace opt
+}  // namespace nvmk

@@ -1,7 +1,9 @@
 // Library-level entry points: error slot, ABI version, device queries.
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
+#include "options.h"
 
 namespace nvmk {
 
@@ -18,6 +20,46 @@ void set_last_error(const char* fmt, ...) {
 
 void clear_last_error() { g_last_error[0] = '\0'; }
 
+namespace opt {
+namespace {
+const char* const kNames[kNumOptions] = {"NVMK_SIM_PATH",       "NVMK_COUNT_THRESHOLD", "NVMK_COUNT_SUPER",  "NVMK_BUTINA_ROUNDS",
+                                         "NVMK_BUTINA_SORT",    "NVMK_BFGS_LDS",        "NVMK_BFGS_XCD_GROUP", "NVMK_BFGS_PROFILE",
+                                         "NVMK_BFGS_VECTORS",   "NVMK_BFGS_OVERLAP"};
+std::mutex g_mutex;
+Text       g_values[kNumOptions];
+bool       g_loaded = false;
+void store(Text& t, const char* v) {
+  std::memset(t.s, 0, sizeof(t.s));
+  if (v != nullptr) std::strncpy(t.s, v, sizeof(t.s) - 1);
+}
+void load_locked() {  // the one place the environment is read
+  if (g_loaded) return;
+  for (int i = 0; i < kNumOptions; ++i) store(g_values[i], std::getenv(kNames[i]));
+  g_loaded = true;
+}
+}  // namespace
+const char* name(const Id id) { return kNames[id]; }
+int find(const char* n) {
+  if (n == nullptr) return -1;
+  for (int i = 0; i < kNumOptions; ++i)
+    if (std::strcmp(kNames[i], n) == 0) return i;
+  return -1;
+}
+Text get(const Id id) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  load_locked();
+  return g_values[id];
+}
+int set(const char* n, const char* value) {
+  const int id = find(n);
+  if (id < 0) return -1;
+  std::lock_guard<std::mutex> lock(g_mutex);
+  load_locked();
+  store(g_values[id], value);
+  return 0;
+}
+}  // namespace opt
+
 }  // namespace nvmk
 
 extern "C" {
@@ -25,6 +67,23 @@ extern "C" {
 const char* nvmk_last_error(void) { return nvmk::g_last_error; }
 
 int nvmk_abi_version(void) { return (0 << 16) | 3; }
+
+int nvmk_set_option(const char* name, const char* value) {
+  NVMK_REQUIRE(name != nullptr, "nvmk_set_option: name is NULL");
+  NVMK_REQUIRE(value == nullptr || std::strlen(value) < sizeof(nvmk::opt::Text::s), "nvmk_set_option: value too long");
+  NVMK_REQUIRE(nvmk::opt::set(name, value) == 0, "nvmk_set_option: unknown option '%s'", name);
+  return NVMK_OK;
+}
+
+int nvmk_get_option(const char* name, char* value, size_t capacity) {
+  NVMK_REQUIRE(name != nullptr && value != nullptr && capacity > 0, "nvmk_get_option: NULL argument");
+  const int id = nvmk::opt::find(name);
+  NVMK_REQUIRE(id >= 0, "nvmk_get_option: unknown option '%s'", name);
+  const nvmk::opt::Text t = nvmk::opt::get(static_cast<nvmk::opt::Id>(id));
+  std::strncpy(value, t.s, capacity - 1);
+  value[capacity - 1] = '\0';
+  return NVMK_OK;
+}
 
 int nvmk_device_count(int* count) {
   NVMK_REQUIRE(count != nullptr, "nvmk_device_count: count is NULL");

@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "options.h"
 #include "fp4.h"
 
 namespace nvmk {
@@ -257,10 +258,9 @@ __global__ __launch_bounds__(NT) void cross_sim_generic_kernel(const uint32_t* _
 enum class Path { kAuto, kValu, kMfma };
 
 inline Path path_override() {
-  const char* e = std::getenv("NVMK_SIM_PATH");
-  if (e == nullptr) return Path::kAuto;
-  if (std::strcmp(e, "valu") == 0) return Path::kValu;
-  if (std::strcmp(e, "mfma") == 0) return Path::kMfma;
+  const opt::Text e = opt::get(opt::kSimPath);
+  if (e.is("valu")) return Path::kValu;
+  if (e.is("mfma")) return Path::kMfma;
   return Path::kAuto;
 }
 

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "fp4.h"
+#include "options.h"
 
 namespace nvmk {
 namespace fp4 {
@@ -681,10 +682,9 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
                "neighbor counts: edge emission needs the symmetric, un-gathered mode and a cursor");
   const int64_t tilesM  = ceil_div<int64_t>(a.nX, TM);
   const int64_t tilesN  = ceil_div<int64_t>(a.nY, TN);
-  static const int64_t superE = [] {  // supertile edge for this kernel (NVMK_COUNT_SUPER overrides for experiments)
-    const char* e = std::getenv("NVMK_COUNT_SUPER");
-    const int   v = e ? std::atoi(e) : 0;
-    return static_cast<int64_t>(v > 0 ? v : SUPER);
+  const int64_t superE = [] {  // supertile edge for this kernel (NVMK_COUNT_SUPER overrides for experiments)
+    const long v = opt::get(opt::kCountSuper).num(0);
+    return static_cast<int64_t>(v > 0 && v <= 256 ? v : SUPER);
   }();
   const int64_t superW  = std::min<int64_t>(tilesN, superE);
   const int64_t superM  = ceil_div<int64_t>(tilesM, superE);
@@ -703,7 +703,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
                         unsigned long long, double, double, double, float, unsigned, unsigned);
   Kern kern;
   ArithThreshold at = arith_threshold(a.thr, F);
-  if (const char* te = std::getenv("NVMK_COUNT_THRESHOLD"); te != nullptr && std::string(te) == "table") at.ok = false;  // tests: force the table form
+  if (opt::get(opt::kCountThreshold).is("table")) at.ok = false;  // tests: force the table form
   if (a.metric == NVMK_METRIC_TANIMOTO && at.ok) {
     kern = emit ? neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, true, true> : neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, false, true>;
   } else if (a.metric == NVMK_METRIC_TANIMOTO) {

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from nvmolkit_amd import synthetic
+from nvmolkit_amd import _native, synthetic
 from nvmolkit_amd.forcefield import DG, ETK, MMFF, UFF, FlatForcefieldBatch, stack_molecule_tables
 from oracle import ffc
 
@@ -29,14 +29,8 @@ def systems_of(kind, sizes, seed):
 def lds_policy(request):
     """LDS residency policy of the inverse Hessian: all in HBM / shared by the two workgroups of a CU / whole LDS for one
     workgroup / an explicit budget in KB."""
-    old = {k: os.environ.get(k) for k in ("NVMK_BFGS_LDS",)}
-    os.environ["NVMK_BFGS_LDS"] = request.param
-    yield request.param
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    with _native.options(NVMK_BFGS_LDS=request.param):
+        yield request.param
 
 
 @pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
@@ -93,15 +87,11 @@ def test_lds_policies_give_identical_results():
     a_s, flat, groups = synthetic.build_ff_batch_arrays(MMFF, systems)
     gpu = FlatForcefieldBatch(MMFF, a_s, groups)
     out = {}
-    old = os.environ.get("NVMK_BFGS_LDS")
-    try:
-        for pol in ("0", "auto", "full", "40"):
-            os.environ["NVMK_BFGS_LDS"] = pol
+    for pol in ("0", "auto", "full", "40"):
+        with _native.options(NVMK_BFGS_LDS=pol):
             pos = torch.from_numpy(flat).cuda()
             gpu.minimize(pos, max_iters=40)
             out[pol] = pos.cpu().numpy()
-    finally:
-        os.environ.pop("NVMK_BFGS_LDS", None) if old is None else os.environ.__setitem__("NVMK_BFGS_LDS", old)
     for pol in ("auto", "full", "40"):
         assert np.array_equal(out[pol], out["0"]), pol
 
@@ -127,3 +117,105 @@ def test_druglike_mmff_minima_agree_statistically():
     close = np.abs(e - ec) <= 1e-3 * np.maximum(1.0, np.abs(ec))
     assert close.mean() >= 0.8, close.mean()
     assert abs(np.median(it.cpu().numpy()) - np.median(itc)) <= 0.25 * np.median(itc)
+
+
+# ---- size classes: the reference's global-memory instantiations take systems of 2048+ atoms
+# (bfgs_minimize_permol_kernels.cu:796-932); here a launch is split into LDS classes and an HBM-vector class ------------
+LARGE_SIZES = [300, 500, 1000]
+
+
+@pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
+@pytest.mark.parametrize("iters,tol", [(1, 1e-9), (3, 1e-8), (10, 1e-6)])
+def test_trajectory_matches_oracle_at_300_500_1000_atoms(kind, iters, tol):
+    """300 atoms = 1200 (4-D) / 900 (3-D) coordinates: class C / class B; 500 and 1000 atoms: class C for every kind."""
+    systems = systems_of(kind, LARGE_SIZES, 900 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    cpu = ffc.Batch(kind, a_s, groups)
+    w0, w1 = W[kind]
+    pos = torch.from_numpy(flat).cuda()
+    e, st, it = gpu.minimize(pos, max_iters=iters, grad_tol=1e-14, w0=w0, w1=w1)
+    x, ec, stc, itc = cpu.minimize(flat, max_iters=iters, grad_tol=1e-14, w0=w0, w1=w1)
+    assert np.array_equal(it.cpu().numpy(), itc)
+    got = pos.cpu().numpy()
+    for s in range(len(LARGE_SIZES)):
+        lo, hi = a_s[s] * gpu.dim, a_s[s + 1] * gpu.dim
+        assert np.max(np.abs(got[lo:hi] - x[lo:hi])) <= tol, (LARGE_SIZES[s], np.max(np.abs(got[lo:hi] - x[lo:hi])))
+    np.testing.assert_allclose(e.cpu().numpy(), ec, rtol=100 * tol, atol=100 * tol)
+
+
+@pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
+@pytest.mark.parametrize("iters,tol", [(1, 1e-9), (3, 1e-8), (10, 1e-6)])
+def test_hbm_vector_kernels_match_oracle_at_every_size(kind, iters, tol):
+    """NVMK_BFGS_VECTORS=global sends EVERY system through the class-C kernels (vectors in an HBM work area, persistent
+    workgroups): the same trajectories as the oracle from 5 to 200 atoms."""
+    systems = systems_of(kind, SIZES, 500 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    cpu = ffc.Batch(kind, a_s, groups)
+    w0, w1 = W[kind]
+    pos = torch.from_numpy(flat).cuda()
+    with _native.options(NVMK_BFGS_VECTORS="global"):
+        e, st, it = gpu.minimize(pos, max_iters=iters, grad_tol=1e-14, w0=w0, w1=w1)
+    x, ec, stc, itc = cpu.minimize(flat, max_iters=iters, grad_tol=1e-14, w0=w0, w1=w1)
+    assert np.array_equal(it.cpu().numpy(), itc)
+    assert np.max(np.abs(pos.cpu().numpy() - x)) <= tol
+    np.testing.assert_allclose(e.cpu().numpy(), ec, rtol=100 * tol, atol=100 * tol)
+
+
+@pytest.mark.parametrize("kind", [DG, MMFF])
+def test_mixed_size_classes_in_one_call_equal_separate_calls(kind):
+    """One call with systems of all three classes (side streams, persistent workgroups taking several systems each) gives
+    every system exactly what it gets in a call of its own: bitwise for the LDS classes (A, B), to rounding for class C
+    (its gradient sums are global atomics whose order within a wave instruction is the hardware's)."""
+    sizes = [40, 1000, 48, 180, 30, 400, 64, 170, 52, 350, 20, 44] + [36] * 40 + [190] * 6
+    systems = systems_of(kind, sizes, 1200 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    w0, w1 = W[kind]
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    pos = torch.from_numpy(flat).cuda()
+    e, st, it = gpu.minimize(pos, max_iters=12, grad_tol=1e-14, w0=w0, w1=w1)
+    got, e, it = pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy()
+    assert it.max() == 12 and it.min() >= 1  # (a system may meet the TOLX test before the cap)
+    dim = gpu.dim
+    vec_bytes = lambda n_atoms: 8 * (17 * n_atoms * dim + 40)
+    for s, n_atoms in enumerate(sizes):
+        if s >= 12 and s not in (12, 52):  # one of each repeated size is enough
+            continue
+        one = FlatForcefieldBatch(kind, np.array([0, n_atoms]), [None if g is None else _slice_group(g, s) for g in groups])
+        lo, hi = a_s[s] * dim, a_s[s + 1] * dim
+        p1 = torch.from_numpy(flat[lo:hi].copy()).cuda()
+        e1, _, it1 = one.minimize(p1, max_iters=12, grad_tol=1e-14, w0=w0, w1=w1)
+        assert int(it1[0]) == it[s], (s, n_atoms)
+        if vec_bytes(n_atoms) <= 159 * 1024:
+            assert np.array_equal(got[lo:hi], p1.cpu().numpy()), (s, n_atoms)
+            assert e[s] == float(e1[0])
+        else:
+            assert np.max(np.abs(got[lo:hi] - p1.cpu().numpy())) <= 1e-6, (s, n_atoms)
+
+
+def _slice_group(g, s):
+    starts, idx, par = g
+    lo, hi = int(starts[s]), int(starts[s + 1])
+    n_idx = idx.shape[1] if idx.ndim == 2 else 1
+    return (np.array([0, hi - lo], dtype=np.int32), idx[lo:hi].copy(), None if par is None else par[lo:hi].copy())
+
+
+def test_large_systems_converge_on_the_quartic_field():
+    """The reference's RDKit-free BFGS known answer (tests/test_bfgs_minimizer.cu:823-1029: sum (x_p - p)^4, minimum at
+    x_p = p) on systems of 400 and 700 atoms at 4 coordinates each (class C: 1600 / 2800 coordinates) next to a 3-atom one;
+    the oracle needs about 300 iterations for them, and so must the kernel."""
+    from nvmolkit_amd.forcefield import QUARTIC
+    rng = np.random.default_rng(42)
+    a_s = np.array([0, 400, 1100, 1103])
+    n = a_s[-1] * 4
+    start = np.arange(n, dtype=np.float64) + rng.uniform(-2, 2, n)
+    gpu = FlatForcefieldBatch(QUARTIC, a_s, [])
+    cpu = ffc.Batch(QUARTIC, a_s, [])
+    pos = torch.from_numpy(start).cuda()
+    e, st, it = gpu.minimize(pos, max_iters=5000, grad_tol=1e-5, scale_grads=False, w0=1.0, w1=0.0)
+    x, ec, stc, itc = cpu.minimize(start, max_iters=5000, grad_tol=1e-5, scale_grads=False, w0=1.0, w1=0.0)
+    got = pos.cpu().numpy()
+    assert np.all(st.cpu().numpy() == 0) and np.all(stc == 0)
+    assert np.max(np.abs(got - np.arange(n))) < 0.1 and (e.cpu().numpy() < 1e-3).all()
+    assert np.all(np.abs(it.cpu().numpy() - itc) <= 0.2 * itc + 2), (it.cpu().numpy(), itc)

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import oracle
+from nvmolkit_amd import _native
 from nvmolkit_amd.clustering import butina, fused_butina, update_neighbor_counts
 from tests import util
 
@@ -13,23 +14,17 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["valu", "mfma", "mfma:dense", "mfma:table", "mfma:nosort", "auto"], autouse=True)
-def sim_path(request, monkeypatch):
+def sim_path(request):
     """Neighbour counting / fused Butina run on the v_bcnt kernels, on the FP4 matrix-core kernels (round loop on the
     sparse neighbour graph; the dense round loop that streams the fingerprint matrix; the tile kernel
     with the threshold TABLE instead of the exact-arithmetic predicate it uses for thresholds in [2^-10, 1]) and on the
-    library's automatic choice (NVMK_SIM_PATH / NVMK_BUTINA_ROUNDS / NVMK_COUNT_THRESHOLD are read per call)."""
+    library's automatic choice (the switches are set through nvmk_set_option: the library reads the environment once)."""
     path, _, variant = request.param.partition(":")
-    monkeypatch.setenv("NVMK_SIM_PATH", path)
-    monkeypatch.delenv("NVMK_BUTINA_ROUNDS", raising=False)
-    monkeypatch.delenv("NVMK_COUNT_THRESHOLD", raising=False)
-    monkeypatch.delenv("NVMK_BUTINA_SORT", raising=False)
-    if variant == "nosort":  # fused Butina: all-pairs pass in input order (default: popcount-sorted copy with tile skipping)
-        monkeypatch.setenv("NVMK_BUTINA_SORT", "0")
-    if variant == "table":
-        monkeypatch.setenv("NVMK_COUNT_THRESHOLD", "table")
-    if variant == "dense":
-        monkeypatch.setenv("NVMK_BUTINA_ROUNDS", "dense")
-    return request.param
+    with _native.options(NVMK_SIM_PATH=path, NVMK_BUTINA_ROUNDS="dense" if variant == "dense" else None,
+                         NVMK_COUNT_THRESHOLD="table" if variant == "table" else None,
+                         # fused Butina: all-pairs pass in input order (default: popcount-sorted copy with tile skipping)
+                         NVMK_BUTINA_SORT="0" if variant == "nosort" else None):
+        yield request.param
 
 METRICS = {"tanimoto": oracle.TANIMOTO, "cosine": oracle.COSINE}
 

@@ -28,7 +28,7 @@ def test_dense_rows_equal_neighbour_counts_at_full_size(data, native_lib, monkey
     the matrix-free kernel (float32 predicate on exact integer counts, symmetric tile walk with column credits) reports;
     sampled rows must equal the CPU oracle bit for bit.  The planted-cluster data have popcounts < 130, so no ratio lies
     within 6e-5 of the threshold other than 7/10 itself, which both predicates accept."""
-    monkeypatch.setenv("NVMK_SIM_PATH", "auto")
+    _native.set_option("NVMK_SIM_PATH", "auto")
     x = data
     counts = torch.zeros(N, dtype=torch.int32, device="cuda")
     update_neighbor_counts(x, x, counts, THR)
@@ -59,7 +59,7 @@ def test_dense_rows_equal_neighbour_counts_at_full_size(data, native_lib, monkey
 
 def test_fused_butina_properties_at_full_size(data, monkeypatch):
     """Partition, greedy head, centroid-member similarity on sampled clusters, singleton tail — at 1M rows."""
-    monkeypatch.setenv("NVMK_SIM_PATH", "auto")
+    _native.set_option("NVMK_SIM_PATH", "auto")
     x = data
     cutoff = 1.0 - THR
     clusters, sizes, centroids = fused_butina(x, cutoff, return_centroids=True)

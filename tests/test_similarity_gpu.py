@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import oracle
+from nvmolkit_amd import _native
 from nvmolkit_amd.similarity import (crossCosineSimilarity, crossCosineSimilarityMemoryConstrained,
                                      crossTanimotoSimilarity, crossTanimotoSimilarityMemoryConstrained)
 from nvmolkit_amd.types import AsyncGpuResult
@@ -16,11 +17,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["valu", "mfma", "auto"], autouse=True)
-def sim_path(request, monkeypatch):
+def sim_path(request):
     """Every parity case runs on the VALU popcount kernel, on the FP4 matrix-core kernel and on the library's automatic
-    choice (NVMK_SIM_PATH is read per call by nvmolkit_amd/csrc/similarity.hip)."""
-    monkeypatch.setenv("NVMK_SIM_PATH", request.param)
-    return request.param
+    choice (NVMK_SIM_PATH, set through nvmk_set_option: the library reads the environment once per process)."""
+    with _native.options(NVMK_SIM_PATH=request.param):
+        yield request.param
 
 FUNCS = {"tanimoto": (crossTanimotoSimilarity, oracle.TANIMOTO), "cosine": (crossCosineSimilarity, oracle.COSINE)}
 
