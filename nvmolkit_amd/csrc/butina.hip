@@ -327,6 +327,8 @@ inline bool force_mfma() { return opt::get(opt::kSimPath).is("mfma"); }
 
 // NVMK_BUTINA_ROUNDS=dense keeps the round loop that streams the fingerprint matrix (tests run both formulations)
 inline bool dense_rounds() { return opt::get(opt::kButinaRounds).is("dense"); }
+// NVMK_BUTINA_ROUNDS=serial: the one-workgroup round loop (sparse_loop_kernel) instead of the parallel rounds
+inline bool serial_rounds() { return opt::get(opt::kButinaRounds).is("serial"); }
 
 struct CountPlan {
   int             metric;
@@ -427,6 +429,11 @@ struct LoopState {
   int32_t            curDegree;   // degree of the bucket in `cand`
   int32_t            nCand;       // rows in `cand` (descending row order)
   int32_t            parity;      // which of L0 / L1 is the harvest list of the next round
+  // parallel rounds (par_* kernels): undecided-candidate lists and where the bucket's clusters are emitted
+  int32_t            nU[2];       // entries of the two undecided lists
+  int32_t            emitFront;   // clusterIndices position / cluster number of the bucket's first cluster
+  int32_t            emitCluster;
+  int32_t            nSel;        // clusters the bucket formed
 };
 static_assert(sizeof(LoopState) <= 32 * sizeof(int32_t), "LoopState must fit the 32-word state block");
 
@@ -445,6 +452,8 @@ __global__ void init_state_kernel(LoopState* __restrict__ st, const int32_t n) {
   st->curDegree   = 0;
   st->nCand       = 0;
   st->parity      = 0;
+  st->nU[0] = st->nU[1] = 0;
+  st->emitFront = st->emitCluster = st->nSel = 0;
 }
 
 __global__ void iota_kernel(int32_t* __restrict__ rows, const int64_t n) {
@@ -897,11 +906,339 @@ __global__ __launch_bounds__(LNT) void sparse_loop_kernel(LoopState* __restrict_
   }
 }
 
-// rows that never had a neighbour (degree 0: all-zero fingerprints) join the singleton tail
+// ---- parallel rounds off a bucket ---------------------------------------------------------------------------------
+// The one-workgroup loop above walks the bucket's candidates c_1 > c_2 > ... one round at a time (10 us per round,
+// 20 183 rounds = 0.19 s of a 0.66 s call at N = 1M).  Which candidates become centroids can be decided for the whole
+// bucket at once: processing c_j changes c_k's closed neighbourhood exactly when the two LIVE closed neighbourhoods
+// intersect (c_k dies as a member, or one of its neighbours does and its degree drops below D), so the sequential
+// loop selects the lexicographically first maximal independent set of the candidates under that conflict relation.
+// Sweeps compute the same set: every undecided candidate stamps its index on its live closed neighbourhood with
+// atomicMin (mark); a candidate that finds its own stamp on all of it has no undecided earlier rival — and no selected
+// one either, that would already have changed its degree — and is selected (decide); the selected clusters' members die
+// and their surviving neighbours lose one degree each (subtract, commutative); candidates whose degree is no longer D
+// are rejected by the next mark.  A candidate can only be rejected by an EARLIER selected one (a later rival never sees
+// its own stamp while the earlier one is undecided), so selected / rejected are exactly the sequential loop's decisions.
+// The first undecided candidate is decided in every sweep: two sweeps run on the whole chip, whatever they leave
+// undecided (dependency chains) is finished by one workgroup sweeping on.  All clusters of a bucket have exactly D
+// members, so the clusters are emitted after the bucket is decided, at offsets that follow from the candidates' order:
+// the output is identical to the sequential loop's, cluster order included.  Rows that drop to degree 1 need no harvest
+// lists here: they are isolated from then on and join the singleton tail at the end; the sequential loop's last act —
+// the highest row that reached degree 1 in the LAST round closes the greedy list as a cluster of one — is par_final_kernel.
+constexpr int PG = 16;  // lanes per candidate
+constexpr int32_t NO_OWNER = 0x7fffffff;
+
+__device__ __forceinline__ bool group_all(const bool ok) {  // AND over the PG lanes of a candidate's group
+  const uint64_t m     = __ballot(ok);
+  const int      shift = (threadIdx.x & 63) & ~(PG - 1);
+  return ((m >> shift) & ((1ull << PG) - 1ull)) == ((1ull << PG) - 1ull);
+}
+
+struct ParArgs {
+  LoopState*                st;
+  const unsigned long long* offsets;
+  const int32_t*            nbr;
+  int32_t*                  counts;
+  const int32_t*            cand;
+  int32_t*                  status;    // per candidate index: 0 undecided, 1 selected, -1 rejected
+  int32_t*                  U[2];      // undecided lists (candidate indices)
+  int32_t*                  owner;     // per row: smallest undecided candidate index whose live closed neighbourhood holds it
+  int32_t*                  memberOf;  // per row: centroid of the cluster it joined (-1: none yet)
+};
+
+// `first`: the input list is the whole bucket 0..nCand-1; otherwise U[p].  Output list U[p ^ 1].
+template <bool FENCED> __device__ __forceinline__ void par_mark(const ParArgs& a, const bool first, const int p, const int group,
+                                                                 const int nGroups, const int l) {
+  LoopState* st  = a.st;
+  const int  D   = st->curDegree;
+  const int  nIn = first ? st->nCand : (FENCED ? ldc(&st->nU[p]) : st->nU[p]);
+  for (int i = group; i < nIn; i += nGroups) {
+    const int k = first ? i : a.U[p][i];
+    if (!first && a.status[k] != 0) continue;  // selected in the previous sweep
+    const int c = a.cand[k];
+    if (a.counts[c] != D) {  // dead, or lost a neighbour to an earlier cluster: it may come back in a later bucket
+      if (l == 0) a.status[k] = -1;
+      continue;
+    }
+    if (l == 0) {
+      a.status[k] = 0;
+      a.U[p ^ 1][atomicAdd(&st->nU[p ^ 1], 1)] = k;
+      atomicMin(&a.owner[c], k);
+    }
+    const unsigned long long o0 = a.offsets[c], o1 = a.offsets[c + 1];
+    for (unsigned long long e = o0 + l; e < o1; e += PG) {
+      const int v = a.nbr[e];
+      if (a.counts[v] > 0) atomicMin(&a.owner[v], k);
+    }
+  }
+}
+
+// list U[p] (what mark wrote); no degree is read here, so the members may die in the same step
+template <bool FENCED> __device__ __forceinline__ void par_decide(const ParArgs& a, const int p, const int group, const int nGroups,
+                                                                   const int l) {
+  const int nIn = FENCED ? ldc(&a.st->nU[p]) : a.st->nU[p];
+  for (int i0 = group - (group % (64 / PG)); i0 < nIn; i0 += nGroups) {  // the groups of a wave stay together (ballots)
+    const int  i     = i0 + group % (64 / PG);
+    const bool valid = i < nIn;
+    const int  k     = valid ? a.U[p][i] : 0;
+    const int  c     = valid ? a.cand[k] : 0;
+    bool       ok    = valid;
+    unsigned long long o0 = 0, o1 = 0;
+    if (valid) {
+      o0 = a.offsets[c];
+      o1 = a.offsets[c + 1];
+      if (l == 0 && a.owner[c] != k) ok = false;
+      for (unsigned long long e = o0 + l; e < o1; e += PG) {
+        const int o = a.owner[a.nbr[e]];
+        if (o != NO_OWNER && o != k) ok = false;  // a live neighbour (it carries a stamp) that an earlier candidate claims
+      }
+    }
+    const bool sel = group_all(ok || !valid) && valid;
+    if (sel) {
+      if (l == 0) {
+        a.status[k] = 1;
+        a.counts[c] = DEAD;
+      }
+      for (unsigned long long e = o0 + l; e < o1; e += PG) {
+        const int v = a.nbr[e];
+        if (a.owner[v] == k) {  // live when it was stamped: a member
+          a.counts[v]   = DEAD;
+          a.memberOf[v] = c;
+        }
+      }
+    }
+  }
+}
+
+// list U[p] again: take the stamps back; the clusters selected in this sweep subtract their members from the survivors
+template <bool FENCED> __device__ __forceinline__ void par_subtract(const ParArgs& a, const int p, const int group, const int nGroups,
+                                                                     const int l) {
+  const int nIn = FENCED ? ldc(&a.st->nU[p]) : a.st->nU[p];
+  for (int i = group; i < nIn; i += nGroups) {
+    const int                k  = a.U[p][i];
+    const int                c  = a.cand[k];
+    const unsigned long long o0 = a.offsets[c], o1 = a.offsets[c + 1];
+    if (l == 0) a.owner[c] = NO_OWNER;
+    for (unsigned long long e = o0 + l; e < o1; e += PG) a.owner[a.nbr[e]] = NO_OWNER;
+    if (a.status[k] != 1) continue;
+    for (unsigned long long e = o0; e < o1; ++e) {
+      const int v = a.nbr[e];
+      if (a.memberOf[v] != c) continue;  // (uniform over the group)
+      const unsigned long long m0 = a.offsets[v], m1 = a.offsets[v + 1];
+      for (unsigned long long f = m0 + l; f < m1; f += PG) {
+        const int j = a.nbr[f];
+        if (a.counts[j] > 0) atomicSub(&a.counts[j], 1);  // every member is DEAD already: only survivors are touched
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void par_mark_kernel(const ParArgs a, const int first, const int p) {
+  if (a.st->done || a.st->curDegree < 2) return;
+  const int t = blockIdx.x * NT + threadIdx.x;
+  par_mark<false>(a, first != 0, p, t / PG, static_cast<int>(gridDim.x) * NT / PG, t % PG);
+}
+__global__ __launch_bounds__(NT) void par_decide_kernel(const ParArgs a, const int p) {
+  if (a.st->done || a.st->curDegree < 2) return;
+  const int t = blockIdx.x * NT + threadIdx.x;
+  par_decide<false>(a, p, t / PG, static_cast<int>(gridDim.x) * NT / PG, t % PG);
+}
+__global__ __launch_bounds__(NT) void par_subtract_kernel(const ParArgs a, const int p) {
+  if (a.st->done || a.st->curDegree < 2) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.st->nU[p ^ 1] = 0;  // this sweep's input list: the next sweep's output
+  const int t = blockIdx.x * NT + threadIdx.x;
+  par_subtract<false>(a, p, t / PG, static_cast<int>(gridDim.x) * NT / PG, t % PG);
+}
+// what the grid sweeps left undecided: one workgroup sweeps on (its own writes are re-read after agent-scope fences)
+__global__ __launch_bounds__(LNT) void par_finish_kernel(const ParArgs a, int p) {
+  if (a.st->done || a.st->curDegree < 2) return;
+  const int group = threadIdx.x / PG, nGroups = LNT / PG, l = threadIdx.x % PG;
+  for (int guard = 0;; ++guard) {
+    if (ldc(&a.st->nU[p]) == 0) break;
+    par_mark<true>(a, false, p, group, nGroups, l);
+    __threadfence();
+    __syncthreads();
+    __threadfence();
+    par_decide<true>(a, p ^ 1, group, nGroups, l);
+    __threadfence();
+    __syncthreads();
+    __threadfence();
+    if (threadIdx.x == 0) a.st->nU[p] = 0;
+    par_subtract<true>(a, p ^ 1, group, nGroups, l);
+    __threadfence();
+    __syncthreads();
+    __threadfence();
+    p ^= 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.st->nU[0] = a.st->nU[1] = 0;
+}
+
+// selected candidates of the bucket, in candidate order -> selList (the count / scan / fill pattern of the bucket kernels)
+__global__ __launch_bounds__(NT) void sel_count_kernel(const LoopState* __restrict__ st, const int32_t* __restrict__ status,
+                                                       int32_t* __restrict__ blockCounts) {
+  if (st->done) return;
+  const int nCand = st->curDegree >= 2 ? st->nCand : 0;
+  int       c     = 0;
+  for (int k = 0; k < BUCKET_ROWS / NT; ++k) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * BUCKET_ROWS + k * NT + threadIdx.x;
+    c += (i < nCand && status[i] == 1) ? 1 : 0;
+  }
+  __shared__ int total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  if (c) atomicAdd(&total, c);
+  __syncthreads();
+  if (threadIdx.x == 0) blockCounts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(NT) void sel_scan_kernel(LoopState* __restrict__ st, int32_t* __restrict__ blockCounts, const int nBlocks) {
+  if (st->done) return;
+  __shared__ int carry;
+  __shared__ int wsum[NT / 64];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nBlocks; base += NT) {
+    const int i = base + threadIdx.x;
+    const int v = i < nBlocks ? blockCounts[i] : 0;
+    int       x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if ((threadIdx.x & 63) >= o) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+    if (i < nBlocks) blockCounts[i] = before + x - v;
+    __syncthreads();
+    if (threadIdx.x == NT - 1) carry = before + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int D = st->curDegree, nSel = carry;
+    st->nSel        = nSel;
+    st->emitFront   = st->front;
+    st->emitCluster = st->nClusters;
+    if (D >= 2) {
+      st->front += nSel * D;  // every cluster of the bucket has exactly D members
+      st->nClusters += nSel;
+      st->lastMax = D;
+    } else {
+      st->done = 1;  // no row of degree >= 2 is left
+    }
+    st->bucketMax = 0;
+  }
+}
+__global__ __launch_bounds__(NT) void sel_fill_kernel(const LoopState* __restrict__ st, const int32_t* __restrict__ status,
+                                                      const int32_t* __restrict__ blockOffsets, int32_t* __restrict__ selList) {
+  if (st->done || st->curDegree < 2) return;
+  const int nCand = st->nCand;
+  __shared__ int wbase[NT / 64];
+  __shared__ int running;
+  if (threadIdx.x == 0) running = blockOffsets[blockIdx.x];
+  __syncthreads();
+  for (int k = 0; k < BUCKET_ROWS / NT; ++k) {
+    const int64_t  i = static_cast<int64_t>(blockIdx.x) * BUCKET_ROWS + k * NT + threadIdx.x;
+    const bool     f = i < nCand && status[i] == 1;
+    const uint64_t m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wbase[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    int before = running;
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) before += wbase[w];
+    if (f) selList[before + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = static_cast<int32_t>(i);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < NT / 64; ++w) t += wbase[w];
+      running += t;
+    }
+    __syncthreads();
+  }
+}
+// cluster r of the bucket: centroid first, then its members (their order is canonicalised on the host)
+__global__ __launch_bounds__(NT) void par_emit_kernel(const ParArgs a, const int32_t* __restrict__ selList, int32_t* __restrict__ clusterIdx,
+                                                      int32_t* __restrict__ clusterOffsets, int32_t* __restrict__ centroids) {
+  const LoopState* st = a.st;
+  if (st->done || st->curDegree < 2) return;
+  const int D = st->curDegree, nSel = st->nSel, front = st->emitFront, first = st->emitCluster;
+  const int t = blockIdx.x * NT + threadIdx.x, l = t % PG, nGroups = static_cast<int>(gridDim.x) * NT / PG;
+  const int shift = (threadIdx.x & 63) & ~(PG - 1);
+  for (int r0 = t / PG - (t / PG) % (64 / PG); r0 < nSel; r0 += nGroups) {  // the groups of a wave stay together (ballots)
+    const int  r     = r0 + (t / PG) % (64 / PG);
+    const bool valid = r < nSel;
+    const int  c     = valid ? a.cand[selList[r]] : 0;
+    const int  base  = front + r * D;
+    if (valid && l == 0) {
+      clusterIdx[base]              = c;
+      centroids[first + r]          = c;
+      clusterOffsets[first + r + 1] = base + D;
+    }
+    const unsigned long long o0 = valid ? a.offsets[c] : 0, o1 = valid ? a.offsets[c + 1] : 0;
+    const unsigned long long steps = (o1 - o0 + PG - 1) / PG;
+    unsigned long long maxSteps = steps;  // all groups of the wave take the same number of ballot steps
+#pragma unroll
+    for (int o = PG; o < 64; o <<= 1) {
+      const unsigned long long other = __shfl_xor(maxSteps, o);
+      maxSteps                       = other > maxSteps ? other : maxSteps;
+    }
+    int written = 1;
+    for (unsigned long long q = 0; q < maxSteps; ++q) {
+      const unsigned long long e = o0 + q * PG + l;
+      const int                v = e < o1 ? a.nbr[e] : -1;
+      const bool               f = v >= 0 && a.memberOf[v] == c;
+      const uint64_t           m = (__ballot(f) >> shift) & ((1ull << PG) - 1ull);
+      if (f) clusterIdx[base + written + __popcll(m & ((1ull << l) - 1ull))] = v;
+      written += __popcll(m);
+    }
+  }
+}
+// The sequential loop's last act: when no row of degree >= 2 is left, the highest of the rows that reached degree 1 in the
+// LAST round (= the degree-1 rows next to a member of the last cluster; with no cluster at all: every degree-1 row) closes
+// the greedy list as a cluster of one.  Every other degree-1 row was, or would be, harvested into the singleton tail.
+__global__ __launch_bounds__(LNT) void par_final_kernel(const ParArgs a, const int32_t n, int32_t* __restrict__ clusterIdx,
+                                                        int32_t* __restrict__ clusterOffsets, int32_t* __restrict__ centroids) {
+  LoopState* st = a.st;
+  __shared__ int sMaxRow;
+  if (threadIdx.x == 0) sMaxRow = -1;
+  __syncthreads();
+  const int nClusters = st->nClusters, front = st->front;
+  if (nClusters > 0) {
+    const int lo = clusterOffsets[nClusters - 1], hi = clusterOffsets[nClusters];
+    const int g = threadIdx.x / PG, l = threadIdx.x % PG;
+    for (int q = lo + g; q < hi; q += LNT / PG) {
+      const int                m  = clusterIdx[q];
+      const unsigned long long m0 = a.offsets[m], m1 = a.offsets[m + 1];
+      for (unsigned long long f = m0 + l; f < m1; f += PG) {
+        const int j = a.nbr[f];
+        if (a.counts[j] == 1) atomicMax(&sMaxRow, j);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += LNT)
+      if (a.counts[i] == 1) atomicMax(&sMaxRow, i);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && sMaxRow >= 0) {
+    const int last                = sMaxRow;
+    clusterIdx[front]             = last;
+    centroids[nClusters]          = last;
+    clusterOffsets[nClusters + 1] = front + 1;
+    a.counts[last]                = DEAD;
+    st->front                     = front + 1;
+    st->nClusters                 = nClusters + 1;
+  }
+}
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, const int64_t n, const int32_t v) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// rows that never had a neighbour (degree 0: all-zero fingerprints) join the singleton tail; after the parallel rounds
+// (withOnes) so do the rows left at degree 1, which the sequential loop harvests round by round
 __global__ void sparse_leftover_kernel(LoopState* __restrict__ st, const int32_t n, const int32_t* __restrict__ counts,
-                                       int32_t* __restrict__ clusterIdx) {
+                                       int32_t* __restrict__ clusterIdx, const int withOnes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && counts[i] == 0) clusterIdx[atomicSub(&st->back, 1)] = i;
+  if (i < n && (counts[i] == 0 || (withOnes && counts[i] == 1))) clusterIdx[atomicSub(&st->back, 1)] = i;
 }
 
 // ---- popcount-sorted first pass (NVMK_BUTINA_SORT=0 turns it off) ---------------------------------------
@@ -1004,13 +1341,35 @@ inline int graph_rounds(const RoundBuffers& b, const int64_t N, const int2* edge
   hipLaunchKernelGGL(sparse_init_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
                      static_cast<int32_t>(N), counts, L0, &nL[0]);
   NVMK_LAUNCH_CHECK();
-  // epochs: build the bucket of the current maximal degree (4 small kernels), run rounds off it (1 persistent kernel)
+  // epochs: build the bucket of the current maximal degree (4 small kernels), then run its rounds — as parallel sweeps
+  // over the whole bucket (default) or one after the other on a persistent workgroup (NVMK_BUTINA_ROUNDS=serial)
+  const bool    serial   = serial_rounds();
   StreamScratch bucketMem;
   const int     nBuckets = static_cast<int>(ceil_div<int64_t>(N, BUCKET_ROWS));
-  NVMK_HIP_CHECK(bucketMem.alloc((n + nBuckets + 16) * sizeof(int32_t), stream));
+  NVMK_HIP_CHECK(bucketMem.alloc(((serial ? 1 : 7) * n + nBuckets + 16) * sizeof(int32_t), stream));
   int32_t*       cand        = bucketMem.as<int32_t>();
-  int32_t*       blockCounts = cand + n;
+  int32_t*       blockCounts = cand + (serial ? 1 : 7) * n;
   const unsigned maxBlocks   = static_cast<unsigned>(std::min<int64_t>(ceil_div<int64_t>(N, NT * 4), 1024));
+  ParArgs        pa{};
+  int32_t*       selList = nullptr;
+  if (!serial) {
+    pa.st       = st;
+    pa.offsets  = offs64;
+    pa.nbr      = nbr;
+    pa.counts   = counts;
+    pa.cand     = cand;
+    pa.status   = cand + n;
+    pa.U[0]     = cand + 2 * n;
+    pa.U[1]     = cand + 3 * n;
+    pa.owner    = cand + 4 * n;
+    pa.memberOf = cand + 5 * n;
+    selList     = cand + 6 * n;
+    const unsigned fb = static_cast<unsigned>(ceil_div<int64_t>(2 * N, 256));
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(fb), dim3(256), 0, stream, pa.owner, static_cast<int64_t>(N), NO_OWNER);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(fb), dim3(256), 0, stream, pa.memberOf, static_cast<int64_t>(N), -1);
+    NVMK_LAUNCH_CHECK();
+  }
+  const unsigned sweepBlocks = static_cast<unsigned>(std::min<int64_t>(std::max<int64_t>(ceil_div<int64_t>(N * PG, NT), 1), 2048));
   for (int64_t guard = 0;; ++guard) {
     // every epoch with a non-empty bucket forms at least one cluster and the empty one ends the loop, so N epochs
     // are an upper bound; anything beyond is a bug and must not spin on the GPU box
@@ -1020,16 +1379,34 @@ inline int graph_rounds(const RoundBuffers& b, const int64_t N, const int2* edge
       hipLaunchKernelGGL(bucket_count_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts);
       hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(NT), 0, stream, st, blockCounts, nBuckets);
       hipLaunchKernelGGL(bucket_fill_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, static_cast<int32_t>(N), counts, blockCounts, cand);
-      hipLaunchKernelGGL(sparse_loop_kernel, dim3(1), dim3(LNT), 0, stream, st, offs64, nbr, counts, clusterIdx, offsets, centroids,
-                         L0, L1, nL, cand);
+      if (serial) {
+        hipLaunchKernelGGL(sparse_loop_kernel, dim3(1), dim3(LNT), 0, stream, st, offs64, nbr, counts, clusterIdx, offsets, centroids,
+                           L0, L1, nL, cand);
+        continue;
+      }
+      // sweep 0 reads the whole bucket and writes U[1]; sweep 1 reads U[1] and writes U[0]; the finishing workgroup goes on from U[0]
+      hipLaunchKernelGGL(par_mark_kernel, dim3(sweepBlocks), dim3(NT), 0, stream, pa, 1, 0);
+      hipLaunchKernelGGL(par_decide_kernel, dim3(sweepBlocks), dim3(NT), 0, stream, pa, 1);
+      hipLaunchKernelGGL(par_subtract_kernel, dim3(sweepBlocks), dim3(NT), 0, stream, pa, 1);
+      hipLaunchKernelGGL(par_mark_kernel, dim3(sweepBlocks), dim3(NT), 0, stream, pa, 0, 1);
+      hipLaunchKernelGGL(par_decide_kernel, dim3(sweepBlocks), dim3(NT), 0, stream, pa, 0);
+      hipLaunchKernelGGL(par_subtract_kernel, dim3(sweepBlocks), dim3(NT), 0, stream, pa, 0);
+      hipLaunchKernelGGL(par_finish_kernel, dim3(1), dim3(LNT), 0, stream, pa, 0);
+      hipLaunchKernelGGL(sel_count_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, pa.status, blockCounts);
+      hipLaunchKernelGGL(sel_scan_kernel, dim3(1), dim3(NT), 0, stream, st, blockCounts, nBuckets);
+      hipLaunchKernelGGL(sel_fill_kernel, dim3(nBuckets), dim3(NT), 0, stream, st, pa.status, blockCounts, selList);
+      hipLaunchKernelGGL(par_emit_kernel, dim3(sweepBlocks), dim3(NT), 0, stream, pa, selList, clusterIdx, offsets, centroids);
     }
     NVMK_LAUNCH_CHECK();
     NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
     NVMK_HIP_CHECK(hipStreamSynchronize(stream));
     if (snap.done) break;
   }
+  if (!serial) {
+    hipLaunchKernelGGL(par_final_kernel, dim3(1), dim3(LNT), 0, stream, pa, static_cast<int32_t>(N), clusterIdx, offsets, centroids);
+  }
   hipLaunchKernelGGL(sparse_leftover_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream,
-                     st, static_cast<int32_t>(N), counts, clusterIdx);
+                     st, static_cast<int32_t>(N), counts, clusterIdx, serial ? 0 : 1);
   NVMK_LAUNCH_CHECK();
   NVMK_HIP_CHECK(hipMemcpyAsync(&snap, st, sizeof(snap), hipMemcpyDeviceToHost, stream));
   NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // csrMem / scanTmp are released in stream order after this

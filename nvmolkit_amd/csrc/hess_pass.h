@@ -9,7 +9,10 @@
 namespace nvmk {
 namespace minim {
 
-constexpr int NT = 256;
+#ifndef NVMK_BFGS_THREADS
+#define NVMK_BFGS_THREADS 256
+#endif
+constexpr int NT = NVMK_BFGS_THREADS;  // threads of a BFGS workgroup (one workgroup per system)
 
 // ---- inverse-Hessian pass -------------------------------------------------------------------------
 // The inverse Hessian is symmetric.  Its DIAGONAL lives in an n-vector (in LDS for the whole minimisation); its strictly
@@ -57,7 +60,7 @@ __host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t
 // LDS layout of bfgs_kernel: 12 vectors (the 12th is the diagonal of the inverse Hessian) + (1 + NW) partial-sum slabs of n
 // doubles (row sums, then one slab of mirrored-entry sums per wave; the per-wave gradient slabs alias them), kRedDoubles of
 // reduction scratch, then the resident rows of the inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
-constexpr int kRedDoubles = 40;  // two alternating buffers of up to 4 values x NW waves (block reductions), padded
+constexpr int kRedDoubles = 8 * NW + 8;  // two alternating buffers of up to 4 values x NW waves (block reductions), padded
 __host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (13 + NW) * n + kRedDoubles; }
 __host__ __device__ constexpr int64_t lds_hessian_doubles(const int64_t ldsDoubles, const int64_t n) {
   return ldsDoubles > lds_vector_doubles(n) ? ldsDoubles - lds_vector_doubles(n) : 0;

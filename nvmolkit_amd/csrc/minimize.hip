@@ -1240,7 +1240,7 @@ __device__ __forceinline__ void bfgs_system(const Batch& b, const BfgsArgs& A, c
 
 // Two workgroups per CU (up to 256 VGPRs each) share the LDS.
 template <int KIND, bool GVEC = false, bool PROFILE = false>
-__global__ __launch_bounds__(NT, 2) void bfgs_kernel(const Batch b, const BfgsArgs A) {
+__global__ __launch_bounds__(NT, 2 * NT / 256) void bfgs_kernel(const Batch b, const BfgsArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int nextItem;
   // workgroups are handed out in launch order: the largest systems go first so that the launch does not end on a long job
