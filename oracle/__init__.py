@@ -70,6 +70,9 @@ def _declare(L: ctypes.CDLL) -> None:
     L.orc_cross_similarity_f64.argtypes = [ctypes.c_int, _u32p, ctypes.c_int64, _u32p, ctypes.c_int64, ctypes.c_int,
                                            _f64p, ctypes.c_int64, ctypes.c_int]
     L.orc_cross_similarity_f64.restype = None
+    L.orc_have_vpopcnt.restype = ctypes.c_int
+    L.orc_set_scalar.argtypes = [ctypes.c_int]
+    L.orc_set_scalar.restype = None
     L.orc_cross_intersection_i32.argtypes = [_u32p, ctypes.c_int64, _u32p, ctypes.c_int64, ctypes.c_int, _i32p]
     L.orc_cross_intersection_i32.restype = None
     L.orc_neighbor_counts.argtypes = [ctypes.c_int, _u32p, ctypes.c_int64, _u32p, ctypes.c_int64, ctypes.c_int,

@@ -70,29 +70,111 @@ int orc_num_threads(void) {
 #endif
 }
 
+static int orc_force_scalar = 0;
+
+#if defined(__AVX512F__) && defined(__AVX512DQ__) && defined(__AVX512VPOPCNTDQ__)
+#include <immintrin.h>
+#define ORC_HAVE_VPOPCNT 1
+/* Eight accumulators of 8 partial qword sums each -> one vector holding the eight totals, in order. */
+static inline __m512i orc_reduce8(const __m512i* a) {
+  const __m512i t0 = _mm512_add_epi64(_mm512_unpacklo_epi64(a[0], a[1]), _mm512_unpackhi_epi64(a[0], a[1]));
+  const __m512i t1 = _mm512_add_epi64(_mm512_unpacklo_epi64(a[2], a[3]), _mm512_unpackhi_epi64(a[2], a[3]));
+  const __m512i t2 = _mm512_add_epi64(_mm512_unpacklo_epi64(a[4], a[5]), _mm512_unpackhi_epi64(a[4], a[5]));
+  const __m512i t3 = _mm512_add_epi64(_mm512_unpacklo_epi64(a[6], a[7]), _mm512_unpackhi_epi64(a[6], a[7]));
+  const __m512i s01 = _mm512_add_epi64(_mm512_shuffle_i64x2(t0, t1, 0x88), _mm512_shuffle_i64x2(t0, t1, 0xdd));
+  const __m512i s23 = _mm512_add_epi64(_mm512_shuffle_i64x2(t2, t3, 0x88), _mm512_shuffle_i64x2(t2, t3, 0xdd));
+  return _mm512_add_epi64(_mm512_shuffle_i64x2(s01, s23, 0x88), _mm512_shuffle_i64x2(s01, s23, 0xdd));
+}
+/* Tanimoto of 8 pairs: c / max(1, pa + pb - c), IEEE double division like the scalar form. */
+static inline __m512d orc_tanimoto8(const __m512i c, const int pa, const int* pb) {
+  const __m512i pbv = _mm512_cvtepi32_epi64(_mm256_loadu_si256((const __m256i*)pb));
+  __m512i       u   = _mm512_sub_epi64(_mm512_add_epi64(_mm512_set1_epi64(pa), pbv), c);
+  u                 = _mm512_max_epi64(u, _mm512_set1_epi64(1));
+  return _mm512_div_pd(_mm512_cvtepi64_pd(c), _mm512_cvtepi64_pd(u));
+}
+/* Rows i0, i0 + 1 (or just i0) against the 8 rows j .. j + 7: every word of B is loaded once for both rows of A.
+ * NV = 512-bit words per fingerprint when known at compile time (4 at 2048 bits: the rows of A stay in registers). */
+#define ORC_TILE_BODY(NVEXPR)                                                                                          \
+  __m512i acc0[8], acc1[8];                                                                                            \
+  const int      nv = (NVEXPR);                                                                                        \
+  const __m512i* a0 = (const __m512i*)(a + i0 * W);                                                                    \
+  const __m512i* a1 = (const __m512i*)(a + (i0 + (nI > 1 ? 1 : 0)) * W);                                               \
+  for (int jj = 0; jj < 8; ++jj) {                                                                                     \
+    const __m512i* bj = (const __m512i*)(b + (j + jj) * W);                                                            \
+    __m512i        s0 = _mm512_setzero_si512(), s1 = _mm512_setzero_si512();                                           \
+    for (int w = 0; w < nv; ++w) {                                                                                     \
+      const __m512i bw = _mm512_loadu_si512(bj + w);                                                                   \
+      s0 = _mm512_add_epi64(s0, _mm512_popcnt_epi64(_mm512_and_si512(bw, _mm512_loadu_si512(a0 + w))));                \
+      s1 = _mm512_add_epi64(s1, _mm512_popcnt_epi64(_mm512_and_si512(bw, _mm512_loadu_si512(a1 + w))));                \
+    }                                                                                                                  \
+    acc0[jj] = s0;                                                                                                     \
+    acc1[jj] = s1;                                                                                                     \
+  }                                                                                                                    \
+  _mm512_storeu_pd(out + i0 * ld + j, orc_tanimoto8(orc_reduce8(acc0), pa[i0], pb + j));                               \
+  if (nI > 1) _mm512_storeu_pd(out + (i0 + 1) * ld + j, orc_tanimoto8(orc_reduce8(acc1), pa[i0 + 1], pb + j));
+static inline void orc_tile_2x8_any(const uint32_t* a, const uint32_t* b, int W, int64_t i0, int nI, int64_t j, const int* pa,
+                                    const int* pb, double* out, int64_t ld) {
+  ORC_TILE_BODY(W / 16)
+}
+static inline void orc_tile_2x8_2048(const uint32_t* a, const uint32_t* b, int W, int64_t i0, int nI, int64_t j, const int* pa,
+                                     const int* pb, double* out, int64_t ld) {
+  ORC_TILE_BODY(4)
+}
+static inline void orc_tile_2x8(const uint32_t* a, const uint32_t* b, int W, int64_t i0, int nI, int64_t j, const int* pa,
+                                const int* pb, double* out, int64_t ld) {
+  if (W == 64) {
+    orc_tile_2x8_2048(a, b, W, i0, nI, j, pa, pb, out, ld);
+  } else {
+    orc_tile_2x8_any(a, b, W, i0, nI, j, pa, pb, out, ld);
+  }
+}
+#endif
+
 /* out[i*ld + j] for i < nA, j < nB.  Follows launchCrossTanimotoSimilarity / launchCrossCosineSimilarity
- * (src/similarity_kernels.cu:505-582, :727-799), SIMT arithmetic.  `threads` <= 0 means all cores. */
+ * (src/similarity_kernels.cu:505-582, :727-799), SIMT arithmetic.  `threads` <= 0 means all cores.
+ * Where the host has AVX-512 VPOPCNTDQ (the GPU boxes' EPYC 9575F does) the Tanimoto pairs of fingerprints that are
+ * whole 512-bit words run 2 x 8 at a time on vector popcounts — same integer counts, same IEEE division, checked
+ * against the scalar loop in tests/test_oracle_similarity.py; the scalar loop is what every other case runs. */
 void orc_cross_similarity_f64(int metric, const uint32_t* a, int64_t nA, const uint32_t* b, int64_t nB, int W,
                               double* out, int64_t ld, int threads) {
   int* pa = (int*)malloc(sizeof(int) * (size_t)(nA > 0 ? nA : 1));
   int* pb = (int*)malloc(sizeof(int) * (size_t)(nB > 0 ? nB : 1));
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(threads)
+#endif
   for (int64_t i = 0; i < nA; ++i) pa[i] = popc_row(a + i * W, W);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads)
+#endif
   for (int64_t j = 0; j < nB; ++j) pb[j] = popc_row(b + j * W, W);
   /* cache blocking only (the arithmetic per pair is unchanged): a thread owns a block of B rows that stays in its
    * cache while it sweeps blocks of A rows, so B is streamed from DRAM once per call instead of once per A row */
-  const int64_t JB = 256, IB = 64;
+  const int64_t JB = 128, IB = 64;
   const int64_t nJB = (nB + JB - 1) / JB;
+#ifdef ORC_HAVE_VPOPCNT
+  const int vec = metric == ORC_TANIMOTO && W % 16 == 0 && W > 0 && !orc_force_scalar;
+#else
+  const int vec = 0;
+#endif
 #ifdef _OPENMP
-  if (threads <= 0) threads = omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
 #endif
   for (int64_t jb = 0; jb < nJB; ++jb) {
     const int64_t j0 = jb * JB, j1 = (j0 + JB < nB) ? j0 + JB : nB;
     for (int64_t i0 = 0; i0 < nA; i0 += IB) {
       const int64_t i1 = (i0 + IB < nA) ? i0 + IB : nA;
+      int64_t       jv = j0;
+#ifdef ORC_HAVE_VPOPCNT
+      if (vec) {
+        for (; jv + 8 <= j1; jv += 8) {
+          for (int64_t i = i0; i < i1; i += 2) orc_tile_2x8(a, b, W, i, (i + 1 < i1) ? 2 : 1, jv, pa, pb, out, ld);
+        }
+      }
+#endif
       for (int64_t i = i0; i < i1; ++i) {
         const uint32_t* ai = a + i * W;
-        for (int64_t j = j0; j < j1; ++j) {
+        for (int64_t j = jv; j < j1; ++j) {
           const int c     = popc_and(ai, b + j * W, W);
           out[i * ld + j] = finish_f64(metric, c, pa[i], pb[j]);
         }
@@ -101,6 +183,18 @@ void orc_cross_similarity_f64(int metric, const uint32_t* a, int64_t nA, const u
   }
   free(pa);
   free(pb);
+}
+
+/* tests: 1 = keep orc_cross_similarity_f64 on the scalar loop */
+void orc_set_scalar(int on) { orc_force_scalar = on; }
+
+/* 1 if orc_cross_similarity_f64 has its vector-popcount form on this host. */
+int orc_have_vpopcnt(void) {
+#ifdef ORC_HAVE_VPOPCNT
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 /* Integer intersection counts only (for bit-exact checks independent of the division). */

@@ -158,3 +158,23 @@ def test_table_free_threshold_predicate_of_ring_kernel_is_exact():
     thrs += [float(np.float32(v)) for v in rng.uniform(2.0 ** -10, 1.0, size=12)]
     for thr in thrs:
         assert oracle.check_threshold_arith(thr, 4096 if thr in (0.7, 0.3) else 1500) == 0, thr
+
+
+@pytest.mark.parametrize("words", [8, 16, 32, 48, 64, 128])
+def test_vector_popcount_form_equals_the_scalar_loop(words):
+    """bench.py's CPU baseline runs the port's AVX-512 VPOPCNTDQ form where the host has it (2 x 8 pairs at a time, fingerprints
+    of whole 512-bit words): bit-identical to the scalar loop that pins the oracle — ragged sizes, empty rows."""
+    lib = oracle.lib()
+    a = random_fingerprints(77, words, 0.05, seed=5)
+    b = random_fingerprints(203, words, 0.3, seed=6)
+    a[0] = 0
+    b[3] = 0
+    try:
+        lib.orc_set_scalar(1)
+        want = oracle.cross_similarity(a, b, oracle.TANIMOTO)
+        lib.orc_set_scalar(0)
+        got = oracle.cross_similarity(a, b, oracle.TANIMOTO)
+        one = oracle.cross_similarity(a, b, oracle.TANIMOTO, threads=1)
+    finally:
+        lib.orc_set_scalar(0)
+    assert np.array_equal(got, want) and np.array_equal(one, want)
