@@ -165,8 +165,8 @@ def test_vector_popcount_form_equals_the_scalar_loop(words):
     """bench.py's CPU baseline runs the port's AVX-512 VPOPCNTDQ form where the host has it (2 x 8 pairs at a time, fingerprints
     of whole 512-bit words): bit-identical to the scalar loop that pins the oracle — ragged sizes, empty rows."""
     lib = oracle.lib()
-    a = random_fingerprints(77, words, 0.05, seed=5)
-    b = random_fingerprints(203, words, 0.3, seed=6)
+    a = util.random_fingerprints(77, words, 0.05, seed=5)
+    b = util.random_fingerprints(203, words, 0.3, seed=6)
     a[0] = 0
     b[3] = 0
     try:
