@@ -429,6 +429,7 @@ int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, co
 #define NVMK_SMILES_NEEDS_AROMATICITY 3  /* RDKit would perceive the aromaticity differently from what the input wrote (Kekule form) */
 #define NVMK_SMILES_TOO_MANY_BONDS 4     /* more than 8 bonds on one atom (kMaxBondsPerAtom of the reference) */
 #define NVMK_SMILES_NO_KEKULE_FORM 5     /* RDKit: "Can't kekulize mol" / "non-ring atom marked aromatic" */
+#define NVMK_SMILES_UNSUPPORTED_ISOTOPE 6 /* isotope label outside the library's mass table whose mass defect could change int(mass - weight) */
 int nvmk_smiles_parse(const char* const* smiles, int64_t n_mols, int n_threads, void** handle);
 /* flags = NVMK_SMILES_PERCEIVE_AROMATICITY: the perceived aromaticity (RDKit's default model: electron donation rules and
  * fused-ring combinations; checked against the aromaticity RDKit recorded in the reference's ChEMBL SMILES: all 8864 aromatic

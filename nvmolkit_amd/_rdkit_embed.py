@@ -176,7 +176,10 @@ def improper_atoms(mol, nbrs, btype):
         z, a = atom.GetAtomicNum(), int(atom.GetIdx())
         if z not in (6, 7, 8) or len(nbrs[a]) != 3 or _name(atom.GetHybridization()) != "SP2":
             continue
-        bound_to_o = z == 6 and any(mol.GetAtomWithIdx(n).GetAtomicNum() == 8 and btype[(a, n)] == "DOUBLE" for n in nbrs[a])
+        # RDKit's rule (the UFF inversion's isBoundToSP2O): a neighbouring oxygen whose own hybridisation is SP2 — the carbonyl
+        # O, but also the ring O of a furan or the O of an ester / phenol conjugated with the centre
+        bound_to_o = z == 6 and any(mol.GetAtomWithIdx(n).GetAtomicNum() == 8 and _name(mol.GetAtomWithIdx(n).GetHybridization()) == "SP2"
+                                    for n in nbrs[a])
         out.append((nbrs[a][0], a, nbrs[a][1], nbrs[a][2], z, bool(bound_to_o)))
     return out
 

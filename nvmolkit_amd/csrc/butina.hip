@@ -1984,6 +1984,33 @@ int nvmk_butina_pairs(int metric, const uint32_t* d_x, int64_t N, int fp_bits, d
   return rc;
 }
 
+}  // extern "C"
+
+namespace {
+// caller-supplied neighbour graph: every index inside [0, N), no self pairs, and the degree vector what the pairs imply
+// (1 + pairs of the row; 0 for a row without any bit set, which has no pair either) — the CSR fill trusts both
+__global__ void check_pairs_kernel(const int2* __restrict__ pairs, const unsigned long long nPairs, const int32_t n,
+                                   int32_t* __restrict__ deg, int32_t* __restrict__ bad) {
+  for (unsigned long long e = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; e < nPairs;
+       e += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+    const int2 p = pairs[e];
+    if (p.x < 0 || p.x >= n || p.y < 0 || p.y >= n || p.x == p.y) {
+      atomicOr(bad, 1);
+    } else {
+      atomicAdd(&deg[p.x], 1);
+      atomicAdd(&deg[p.y], 1);
+    }
+  }
+}
+__global__ void check_degrees_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ deg, const int32_t n,
+                                     int32_t* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && counts[i] != deg[i] + 1 && !(counts[i] == 0 && deg[i] == 0)) atomicOr(bad, 2);
+}
+}  // namespace
+
+extern "C" {
+
 int nvmk_butina_from_pairs(int64_t N, const int32_t* d_counts, const int32_t* d_pairs, uint64_t n_pairs, int32_t* h_cluster_indices,
                            int64_t* h_offsets, int32_t* h_centroids, int64_t* n_clusters, void* stream_) {
   NVMK_REQUIRE(N >= 0 && N <= 0x7fffffffLL, "butina from pairs: bad N %lld", (long long)N);
@@ -1993,6 +2020,26 @@ int nvmk_butina_from_pairs(int64_t N, const int32_t* d_counts, const int32_t* d_
   if (N == 0) return NVMK_OK;
   NVMK_REQUIRE(d_counts && h_cluster_indices && h_centroids && (d_pairs || n_pairs == 0), "butina from pairs: NULL buffer");
   hipStream_t   stream = as_stream(stream_);
+  {
+    StreamScratch chk;
+    NVMK_HIP_CHECK(chk.alloc((static_cast<size_t>(N) + 1) * sizeof(int32_t), stream));
+    NVMK_HIP_CHECK(hipMemsetAsync(chk.ptr, 0, (static_cast<size_t>(N) + 1) * sizeof(int32_t), stream));
+    int32_t* deg = chk.as<int32_t>();
+    int32_t* bad = deg + N;
+    if (n_pairs > 0) {
+      const unsigned eb = static_cast<unsigned>(std::min<unsigned long long>(ceil_div<unsigned long long>(n_pairs, 256), 65535));
+      hipLaunchKernelGGL(check_pairs_kernel, dim3(eb), dim3(256), 0, stream, reinterpret_cast<const int2*>(d_pairs), n_pairs,
+                         static_cast<int32_t>(N), deg, bad);
+    }
+    hipLaunchKernelGGL(check_degrees_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(N, 256))), dim3(256), 0, stream, d_counts, deg,
+                       static_cast<int32_t>(N), bad);
+    NVMK_LAUNCH_CHECK();
+    int32_t hBad = 0;
+    NVMK_HIP_CHECK(hipMemcpyAsync(&hBad, bad, sizeof(hBad), hipMemcpyDeviceToHost, stream));
+    NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+    NVMK_REQUIRE((hBad & 1) == 0, "butina from pairs: a pair names a row outside [0, %lld) or a row twice", (long long)N);
+    NVMK_REQUIRE((hBad & 2) == 0, "butina from pairs: counts is not the degree vector of the pair list (1 + pairs of a row)");
+  }
   StreamScratch mem;
   RoundBuffers  rb{};
   int           rc = alloc_round_buffers(mem, N, stream, rb);

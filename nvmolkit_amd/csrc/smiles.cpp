@@ -57,6 +57,7 @@ enum Status : int8_t {
   kNeedsAromaticity = NVMK_SMILES_NEEDS_AROMATICITY,
   kTooManyBonds     = NVMK_SMILES_TOO_MANY_BONDS,
   kNoKekuleForm     = NVMK_SMILES_NO_KEKULE_FORM,
+  kIsotope          = NVMK_SMILES_UNSUPPORTED_ISOTOPE,
 };
 
 // RDKit bond type values (Bond::BondType): what the Morgan bond invariant is (morgan_fingerprint_common.cpp:100)
@@ -78,6 +79,7 @@ struct Bond {
   int     a = 0, b = 0;
   uint8_t order = kUnspecified;
   bool    ring  = false;
+  bool    dir   = false;  // written '/' or '\\' (kept for RDKit's removeHs rule on stereo-defining hydrogens)
 };
 struct Graph {
   std::vector<Atom> atoms;
@@ -132,8 +134,29 @@ const double kWeights[kNumElements] = {
     251.0,   252.0,   257.0,   258.0,   259.0,   262.0,   267.0,   268.0,   269.0,   270.0,   269.0,   278.0,   281.0,   282.0,
     285.0,   286.0,   289.0,   290.0,   293.0,   294.0,   294.0};
 
-// Mass of a given isotope: exact values for the labels that occur in medicinal chemistry, the mass number otherwise (the
-// mass defect is below 0.1 u, and the invariant only keeps int(mass - average weight)).
+// Mass excess (mass - mass number, in u) of the nuclides of mass number a that chemistry meets: +0.015 for the lightest,
+// falling to -0.1 around a = 120 (tin), back through 0 near a = 214 and up to +0.08 at californium; the band around that
+// curve covers every isotope within a few neutrons of stability (2H +0.014, 14C +0.003, 32P -0.026, 56Fe -0.065,
+// 99Tc -0.094, 120Sn -0.098, 131I -0.094, 180Hf -0.053, 208Pb -0.023, 223Ra +0.019, 238U +0.051, 252Cf +0.082).
+void mass_excess_window(const int a, double& lo, double& hi) {
+  double c, w;
+  if (a <= 12) {
+    c = 0.02, w = 0.025;
+  } else if (a <= 40) {
+    c = 0.015 - (a - 12) * 0.00186, w = 0.02;
+  } else if (a <= 200) {
+    const double x = (a - 120) / 100.0;
+    c = -0.1 * (1.0 - x * x), w = 0.04;
+  } else {
+    c = -0.03 + (a - 200) * 0.0021, w = a <= 260 ? 0.03 : 0.08;
+  }
+  lo = c - w;
+  hi = c + w;
+}
+
+// Mass of a given isotope: exact values for the labels that occur in medicinal chemistry, otherwise the mass number plus
+// the centre of the band of mass excesses at that mass number — used only where the whole band gives the same
+// int(mass - average weight) (isotope_known below).
 double isotope_mass(const int z, const int a) {
   struct Iso {
     int    z, a;
@@ -144,10 +167,24 @@ double isotope_mass(const int z, const int a) {
                              {8, 17, 16.99913},  {8, 18, 17.99916},  {9, 18, 18.00094},  {15, 32, 31.97391}, {15, 33, 32.97173},
                              {16, 34, 33.96787}, {16, 35, 34.96903}, {17, 36, 35.96831}, {17, 37, 36.96590}, {35, 76, 75.92454},
                              {35, 77, 76.92138}, {35, 82, 81.91680}, {53, 123, 122.90559}, {53, 124, 123.90621}, {53, 125, 124.90463},
-                             {53, 131, 130.90612}};
+                             {53, 131, 130.90612}, {27, 57, 56.93629},   {71, 177, 176.94376}};
   for (const Iso& i : kIso)
     if (i.z == z && i.a == a) return i.m;
-  return static_cast<double>(a);
+  double lo, hi;
+  mass_excess_window(a, lo, hi);
+  return static_cast<double>(a) + 0.5 * (lo + hi);
+}
+// The invariant keeps int(mass - average weight).  For an isotope outside the table the mass is only known to lie in the band
+// of mass excesses of the nuclides near the valley of stability (mass_excess_window); the label is taken when every mass in
+// that band truncates to the same integer, and refused otherwise ([177Lu], [211At], [223Ra] ...) rather than risk an
+// invariant RDKit's exact isotope table would not give.
+bool isotope_known(const int z, const int a) {
+  if (z <= 0 || z >= kNumElements) return true;  // dummy atoms: weight 0, the label is the mass
+  double lo, hi;
+  mass_excess_window(a, lo, hi);
+  const double mid = static_cast<double>(a) + 0.5 * (lo + hi);
+  if (isotope_mass(z, a) != mid) return true;    // tabulated
+  return static_cast<int32_t>(a + lo - kWeights[z]) == static_cast<int32_t>(a + hi - kWeights[z]);
 }
 
 // default valence lists of the organic subset (RDKit's periodic table: the first entry is the default valence)
@@ -261,7 +298,10 @@ struct Parser {
       }
       if (q == 1 && s[pos] >= '0' && s[pos] <= '9') {
         q = 0;
-        while (s[pos] >= '0' && s[pos] <= '9') q = q * 10 + (s[pos++] - '0');
+        while (s[pos] >= '0' && s[pos] <= '9') {
+          q = q * 10 + (s[pos++] - '0');
+          if (q > 15) return fail();  // (bounded inside the loop: no overflow on a long digit string)
+        }
       }
       if (q > 15) return fail();
       a.charge = static_cast<int8_t>(sign == '+' ? q : -q);
@@ -343,6 +383,7 @@ struct Parser {
       bd.a     = a;
       bd.b     = b;
       bd.order = order == kDirectional ? kUnspecified : order;
+      bd.dir   = order == kDirectional;
       g.bonds.push_back(bd);
       return true;
     };
@@ -353,6 +394,7 @@ struct Parser {
       bd.a     = a;
       bd.b     = b;
       bd.order = order == kDirectional ? kUnspecified : order;
+      bd.dir   = order == kDirectional;
       g.bonds.push_back(bd);
     };
     while (s[pos] == ' ' || s[pos] == '\t') ++pos;  // leading blanks; the SMILES ends at the next blank (name columns follow)
@@ -536,7 +578,9 @@ int half_orders(const uint8_t order) {
 }
 
 // RDKit's default removeHs on what a SMILES can express: a hydrogen atom is folded into its neighbour unless it is
-// labelled (isotope), charged, not singly bonded to exactly one non-hydrogen atom.
+// labelled (isotope), charged, not singly bonded to exactly one non-hydrogen atom, bonded to a dummy atom
+// (removeDummyNeighbors = false) or defines double-bond stereo — its bond was written '/' or '\\' and the neighbour carries
+// a double bond (removeDefiningBondStereo = false): '[H]/N=C(\\C)c1ccccc1' keeps its hydrogen atom.
 void fold_hydrogens(Scratch& sc) {
   Graph&     g = sc.g;
   const int  n = static_cast<int>(g.atoms.size());
@@ -558,10 +602,25 @@ void fold_hydrogens(Scratch& sc) {
     if (a.z != 1 || a.isotope != 0 || a.charge != 0 || a.hExplicit != 0 || degree[static_cast<size_t>(i)] != 1) continue;
     const Bond& b = g.bonds[static_cast<size_t>(onlyBond[static_cast<size_t>(i)])];
     const int   o = b.a == i ? b.b : b.a;
-    if (g.atoms[static_cast<size_t>(o)].z == 1 || (b.order != kSingle && b.order != kUnspecified)) continue;
+    Atom&       heavy = g.atoms[static_cast<size_t>(o)];
+    if (heavy.z == 1 || heavy.z == 0 || (b.order != kSingle && b.order != kUnspecified)) continue;
+    if (b.dir) {
+      bool onDouble = false;
+      for (const Bond& d : g.bonds) onDouble = onDouble || ((d.a == o || d.b == o) && d.order == kDouble);
+      if (onDouble) continue;
+    }
     sc.drop[static_cast<size_t>(i)] = 1;
     any                             = true;
-    if (g.atoms[static_cast<size_t>(o)].bracket) ++g.atoms[static_cast<size_t>(o)].hExplicit;  // the others recount below ...
+    // bracket atoms count it; so do aromatic atoms written without brackets ('[H]n1cccc1' is [nH]: an aromatic atom has no
+    // implicit hydrogens to recount); the others recount below ...
+    if (heavy.bracket || heavy.aromatic) {
+      if (heavy.hExplicit >= 100) {  // (int8 count: a molecule drawing that many hydrogens on one atom is refused)
+        g.status = kValence;
+        return;
+      }
+      ++heavy.hExplicit;
+      heavy.bracket = true;
+    }
   }
   if (!any) return;
   // ... unless the atom sits in one of its HIGHER valence states with the hydrogens drawn (H3P=O, H2S(=O)=O): RDKit's removeHs
@@ -1191,6 +1250,12 @@ void build(const char* s, Scratch& sc, const unsigned flags) {
 void sanitise(Scratch& sc, const unsigned flags) {
   Graph& g = sc.g;
   fold_hydrogens(sc);
+  if (g.status != kOk) return;
+  for (const Atom& a : g.atoms)
+    if (a.isotope != 0 && !isotope_known(a.z, a.isotope)) {
+      g.status = kIsotope;
+      return;
+    }
   build_adjacency(sc);
   mark_ring_bonds(sc);
   for (Bond& b : g.bonds) {

@@ -124,13 +124,21 @@ def butina_pairs_gpu(x: torch.Tensor, cutoff: float, shard: int, n_shards: int, 
     x = x.contiguous()
     n = x.shape[0]
     cap = int(capacity if capacity is not None else min(n * 128, (1 << 30) - 1))
-    counts = torch.zeros(max(n, 1), dtype=torch.int32, device=x.device)
-    pairs = torch.empty((max(cap, 1), 2), dtype=torch.int32, device=x.device)
-    n_pairs = ctypes.c_uint64(0)
-    with torch.cuda.device(x.device):
-        rc = _native.lib().nvmk_butina_pairs(_METRICS[metric], x.data_ptr(), n, x.shape[1] * 32, float(cutoff), int(shard),
-                                             int(n_shards), counts.data_ptr(), pairs.data_ptr(), cap, ctypes.byref(n_pairs),
-                                             _native.stream_ptr(None))
+    for attempt in range(2):
+        counts = torch.zeros(max(n, 1), dtype=torch.int32, device=x.device)
+        pairs = torch.empty((max(cap, 1), 2), dtype=torch.int32, device=x.device)
+        n_pairs = ctypes.c_uint64(0)
+        with torch.cuda.device(x.device):
+            rc = _native.lib().nvmk_butina_pairs(_METRICS[metric], x.data_ptr(), n, x.shape[1] * 32, float(cutoff), int(shard),
+                                                 int(n_shards), counts.data_ptr(), pairs.data_ptr(), cap, ctypes.byref(n_pairs),
+                                                 _native.stream_ptr(None))
+        # a graph denser than the default buffer (mean degree above ~256): the call reports how many pairs there are —
+        # once more with exactly that capacity
+        if rc == _native.ERR_OUT_OF_MEMORY and attempt == 0 and cap < n_pairs.value <= (1 << 31) - 1:
+            del pairs
+            cap = int(n_pairs.value)
+            continue
+        break
     _native.check(rc, "nvmk_butina_pairs")
     return counts[:n], pairs[: n_pairs.value]
 

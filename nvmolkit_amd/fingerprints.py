@@ -136,7 +136,8 @@ def morgan_invariants_from_rdkit(mols, max_atoms: int):
 
 SMILES_STATUS = {0: "ok", 1: "syntax error", 2: "valence RDKit's sanitisation rejects",
                  3: "aromaticity differs from what RDKit perceives, e.g. Kekule form (strict mode, perceive_aromaticity=False)",
-                 4: "more than 8 bonds on one atom", 5: "the aromatic atoms have no Kekule structure"}
+                 4: "more than 8 bonds on one atom", 5: "the aromatic atoms have no Kekule structure",
+                 6: "isotope label outside the mass table whose mass defect could change the atom invariant"}
 
 
 class SmilesSet:

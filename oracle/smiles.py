@@ -44,7 +44,13 @@ class SmilesError(ValueError):
 
 def parse(smiles: str):
     """-> (atoms, bonds): atoms are dicts (z, charge, isotope, h_explicit, bracket, aromatic), bonds [a, b, type or None]."""
-    atoms, bonds = [], []
+    atoms, bonds, _ = parse_with_directions(smiles)
+    return atoms, bonds
+
+
+def parse_with_directions(smiles: str):
+    """parse() plus the set of bond indices written with '/' or '\\'."""
+    atoms, bonds, directional = [], [], set()
     prev, pending, stack, open_rings = None, None, [], {}
     pos = 0
     while pos < len(smiles):
@@ -79,6 +85,8 @@ def parse(smiles: str):
                 atoms.append(dict(z=AROMATIC_SYMBOLS[text] if aromatic else Z_OF[text], charge=0, isotope=0, h_explicit=0,
                                   bracket=False, aromatic=aromatic))
             if prev is not None:
+                if pending in ("/", "\\"):
+                    directional.add(len(bonds))
                 bonds.append([prev, len(atoms) - 1, BOND_TYPE.get(pending)])
             prev, pending = len(atoms) - 1, None
         elif kind == "bond":
@@ -97,6 +105,8 @@ def parse(smiles: str):
                 if other == prev or any({a, b} == {other, prev} for a, b, _ in bonds):
                     raise SmilesError("ring closure duplicates a bond")
                 t_close = BOND_TYPE.get(pending) if pending is not None else None
+                if pending in ("/", "\\") or sym in ("/", "\\"):
+                    directional.add(len(bonds))
                 bonds.append([other, prev, t_close if t_close is not None else BOND_TYPE.get(sym)])
             else:
                 open_rings[label] = (prev, pending)
@@ -115,7 +125,7 @@ def parse(smiles: str):
             prev = None
     if pending is not None or stack or open_rings:
         raise SmilesError("unterminated bond, branch or ring")
-    return atoms, bonds
+    return atoms, bonds, directional
 
 
 def _connected_without(n, bonds, skip, src, dst):
@@ -173,8 +183,9 @@ def _clean_up(atoms, bonds):
 def molecule(smiles: str):
     """SMILES -> (atom table (n, 6) int [Z, charge, isotope, total Hs, aromatic, in ring], bond table (m, 4) int
     [begin, end, RDKit bond type, in ring]) with the rules listed in nvmolkit_amd/csrc/smiles.cpp's header."""
-    atoms, bonds = parse(smiles.split()[0] if smiles.split() else "")
-    # fold plain hydrogen atoms into their neighbour (RDKit's default removeHs)
+    atoms, bonds, directional = parse_with_directions(smiles.split()[0] if smiles.split() else "")
+    # fold plain hydrogen atoms into their neighbour (RDKit's default removeHs: not next to a dummy atom, and not when the
+    # hydrogen defines double-bond stereo, i.e. its bond carries a direction and the neighbour a double bond)
     degree = [0] * len(atoms)
     for a, b, _ in bonds:
         degree[a] += 1
@@ -183,13 +194,15 @@ def molecule(smiles: str):
     folded = [0] * len(atoms)
     for i, at in enumerate(atoms):
         if at["z"] == 1 and at["isotope"] == 0 and at["charge"] == 0 and at["h_explicit"] == 0 and degree[i] == 1:
-            (a, b, t), = [bd for bd in bonds if i in bd[:2]]
+            (k, (a, b, t)), = [(k, bd) for k, bd in enumerate(bonds) if i in bd[:2]]
             other = b if a == i else a
-            if atoms[other]["z"] != 1 and t in (None, 1):
+            stereo = k in directional and any(other in bd[:2] and bd[2] == 2 for bd in bonds)
+            if atoms[other]["z"] not in (0, 1) and t in (None, 1) and not stereo:
                 drop.add(i)
                 folded[other] += 1
-                if atoms[other]["bracket"]:
+                if atoms[other]["bracket"] or atoms[other]["aromatic"]:  # '[H]n1cccc1' is [nH]
                     atoms[other]["h_explicit"] += 1
+                    atoms[other]["bracket"] = True
     # an organic-subset atom drawn with its hydrogens in one of its higher valence states keeps them (RDKit's removeHs:
     # H3P=O stays H3P=O; a recount from the other bonds would make it HP=O); all others are recounted further down
     for i, at in enumerate(atoms):

@@ -237,3 +237,26 @@ def test_sharded_pairs_assemble_to_the_fused_result(n, n_shards):
     got = butina_from_pairs_gpu(n, counts, pairs)
     assert got == oracle.butina_fused(x, 0.35)
     assert got == fused_butina(d, 0.35, return_centroids=True)
+
+
+def test_from_pairs_refuses_a_graph_it_cannot_trust_and_pairs_retry_with_the_reported_capacity():
+    """nvmk_butina_from_pairs checks the caller's pair list (indices inside [0, N), degrees = 1 + pairs of the row)
+    before the CSR fill trusts it; butina_pairs_gpu asks again with the reported number of pairs when its buffer was too small."""
+    from nvmolkit_amd.distributed import butina_from_pairs_gpu, butina_pairs_gpu
+
+    n = 900
+    x = util.clustered_fingerprints(n, 64, 6, seed=3)
+    d = dev(x)
+    counts, pairs = butina_pairs_gpu(d, 0.35, 0, 1)
+    small_counts, small_pairs = butina_pairs_gpu(d, 0.35, 0, 1, capacity=16)   # far too small: one retry
+    assert torch.equal(small_counts, counts) and small_pairs.shape == pairs.shape
+    want = butina_from_pairs_gpu(n, counts, pairs)
+    assert want == butina_from_pairs_gpu(n, small_counts, small_pairs)
+    bad = pairs.clone()
+    bad[0, 1] = n + 5
+    with pytest.raises(ValueError, match="outside"):
+        butina_from_pairs_gpu(n, counts, bad)
+    with pytest.raises(ValueError, match="degree"):
+        butina_from_pairs_gpu(n, counts + 1, pairs)
+    with pytest.raises(ValueError, match="degree"):
+        butina_from_pairs_gpu(n, counts, pairs[:-3])
