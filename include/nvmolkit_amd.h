@@ -275,6 +275,13 @@ int nvmk_ff_gradient(const nvmk_ff_batch* batch, double w0, double w1, const dou
 int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts, double w0, double w1, int max_iters,
                        double grad_tol, int scale_grads, double* d_pos, const uint8_t* d_active, double* d_energies,
                        int16_t* d_statuses, int32_t* d_iters, void* stream);
+/* The same with repeatUntilConverged inside the launch (reference: etkdg_stage_distgeom_minimize.cu:53-58 relaunches the
+ * minimiser while any system is unconverged): a system that stops at max_iters is minimised again from where it stands, with
+ * a fresh inverse Hessian, up to `restarts` more times.  Results are those of restarts + 1 calls of nvmk_bfgs_minimize on
+ * the still-unconverged systems; d_iters reports the last minimisation's iterations. */
+int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_starts, double w0, double w1, int max_iters,
+                              int restarts, double grad_tol, int scale_grads, double* d_pos, const uint8_t* d_active,
+                              double* d_energies, int16_t* d_statuses, int32_t* d_iters, void* stream);
 
 /* Measurement hook (bench.py's roofline, tests): when d_counters != NULL every BFGS launch of this process — the ones
  * nvmk_etkdg_embed issues included — adds to d_counters[8 * kind + k] (device memory, 64 uint64, caller zeroes it):

@@ -42,7 +42,7 @@ def _digest(paths: list[Path]) -> str:
 
 
 def _deps() -> list[Path]:
-    return sorted(list(CSRC_DIR.glob("*.h")) + list(CSRC_DIR.glob("*.hpp")) + [PKG_DIR.parent / "include" / "nvmolkit_amd.h"])
+    return sorted(list(CSRC_DIR.glob("*.h")) + list(CSRC_DIR.glob("*.hpp")) + list(CSRC_DIR.glob("*.inc")) + [PKG_DIR.parent / "include" / "nvmolkit_amd.h"])
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -60,8 +60,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         "-Wall",
         "-Wno-unused-function",
         f"-I{PKG_DIR.parent / 'include'}",
-    ]
-    dep_digest = _digest(_deps())
+    ] + os.environ.get("NVMK_EXTRA_HIPCC_FLAGS", "").split()  # experiments (e.g. -DNVMK_BFGS_THREADS=512); part of the stamp
+    dep_digest = _digest(_deps()) + hashlib.sha256(os.environ.get("NVMK_EXTRA_HIPCC_FLAGS", "").encode()).hexdigest()
     objs: list[Path] = []
     relink = force or not LIB_PATH.exists()
     for src in sources():

@@ -63,6 +63,8 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_ff_gradient": (_int, [_vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "nvmk_bfgs_minimize": (_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _int, ctypes.c_double, _int, _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
+    "nvmk_bfgs_minimize_repeat": (_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _int, _int, ctypes.c_double, _int, _vp, _vp,
+                                         _vp, _vp, _vp, _vp]),
     "nvmk_bfgs_set_stats": (_int, [_vp]),
     "nvmk_scheduler_create": (_vp, [_int, _int, _int]),
     "nvmk_scheduler_destroy": (None, [_vp]),

@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(NT) void par_subtract_kernel(const ParArgs a, const
 __global__ __launch_bounds__(LNT) void par_finish_kernel(const ParArgs a, int p) {
   if (a.st->done || a.st->curDegree < 2) return;
   const int group = threadIdx.x / PG, nGroups = LNT / PG, l = threadIdx.x % PG;
-  for (int guard = 0;; ++guard) {
+  for (;;) {
     if (ldc(&a.st->nU[p]) == 0) break;
     par_mark<true>(a, false, p, group, nGroups, l);
     __threadfence();

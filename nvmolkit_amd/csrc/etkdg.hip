@@ -532,26 +532,13 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     // BFGS on the active systems, repeated while any of them is unconverged (repeatUntilConverged,
     // etkdg_stage_distgeom_minimize.cu:53-58); `repeat` false = one call (ETK stage)
     auto minimize = [&](const nvmk_ff_batch& b, double w0, double w1, int iters, bool repeat) -> int {
-      std::vector<uint8_t> act(static_cast<size_t>(nSys));
-      std::vector<int16_t> st(static_cast<size_t>(nSys));
       NVMK_HIP_CHECK(hipMemcpyAsync(dSub.p, dActive.p, static_cast<size_t>(nSys), hipMemcpyDeviceToDevice, stream));
-      for (int rep = 0; rep < 50; ++rep) {
-        int rc = nvmk_bfgs_minimize(&b, atomStarts.data(), w0, w1, iters, prm->force_tol, 1, dPos.p, dSub.p, dEnergies.p,
-                                    dStatuses.p, nullptr, stream);
-        if (rc != NVMK_OK) return rc;
-        if (!repeat) break;
-        NVMK_HIP_CHECK(hipMemcpyAsync(act.data(), dSub.p, act.size(), hipMemcpyDeviceToHost, stream));
-        NVMK_HIP_CHECK(hipMemcpyAsync(st.data(), dStatuses.p, st.size() * 2, hipMemcpyDeviceToHost, stream));
-        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
-        bool more = false;
-        for (int s = 0; s < nSys; ++s) {
-          act[static_cast<size_t>(s)] = act[static_cast<size_t>(s)] && st[static_cast<size_t>(s)] != 0;
-          more                        = more || act[static_cast<size_t>(s)];
-        }
-        if (!more) break;
-        NVMK_HIP_CHECK(hipMemcpyAsync(dSub.p, act.data(), act.size(), hipMemcpyHostToDevice, stream));
-        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
-      }
+      // repeatUntilConverged: a system that stops at the iteration limit is minimised again (fresh inverse Hessian) inside
+      // the same launch, up to 49 more times — the host loop this replaces relaunched the few unconverged systems of a batch
+      // on an almost empty chip and synchronised with the host each time
+      int rc = nvmk_bfgs_minimize_repeat(&b, atomStarts.data(), w0, w1, iters, repeat ? 49 : 0, prm->force_tol, 1, dPos.p, dSub.p,
+                                         dEnergies.p, dStatuses.p, nullptr, stream);
+      if (rc != NVMK_OK) return rc;
       return NVMK_OK;
     };
     auto check = [&](int kind) -> int {

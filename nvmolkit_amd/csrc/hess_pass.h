@@ -1,17 +1,21 @@
-// The inverse-Hessian pass of the fused BFGS kernels (one workgroup of 256 threads per system) — shared by
-// minimize.hip and tools/ubench_hess.hip (the pass is the hot spot of the conformer path; the microbenchmark runs it alone).
-#pragma once
-
+// The inverse-Hessian pass of the fused BFGS kernels (one workgroup per system) — shared by minimize.hip (through
+// bfgs_device.inc) and tools/ubench_hess.hip (the pass is the hot spot of the conformer path; the microbenchmark runs it
+// alone).  NO include guard: the file is compiled once per workgroup size, into the namespace NVMK_BFGS_NS (default: t256,
+// 256 threads = four waves per system; minimize.hip also builds t64, one wave per system).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 
+#ifndef NVMK_BFGS_NS
+#define NVMK_BFGS_NS t256
+#define NVMK_BFGS_THREADS 256
+#define NVMK_BFGS_NS_DEFAULTED 1
+#endif
+
 namespace nvmk {
 namespace minim {
+namespace NVMK_BFGS_NS {
 
-#ifndef NVMK_BFGS_THREADS
-#define NVMK_BFGS_THREADS 256
-#endif
 constexpr int NT = NVMK_BFGS_THREADS;  // threads of a BFGS workgroup (one workgroup per system)
 
 // ---- inverse-Hessian pass -------------------------------------------------------------------------
@@ -57,11 +61,11 @@ __host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t
   while (r < n && hess_row_offset(r + 1) <= hldsDoubles) ++r;
   return r;
 }
-// LDS layout of bfgs_kernel: 12 vectors (the 12th is the diagonal of the inverse Hessian) + (1 + NW) partial-sum slabs of n
+// LDS layout of bfgs_kernel: 10 vectors (the 10th is the diagonal of the inverse Hessian) + (1 + NW) partial-sum slabs of n
 // doubles (row sums, then one slab of mirrored-entry sums per wave; the per-wave gradient slabs alias them), kRedDoubles of
 // reduction scratch, then the resident rows of the inverse Hessian in whatever the launch's dynamic LDS (ldsDoubles) leaves.
 constexpr int kRedDoubles = 8 * NW + 8;  // two alternating buffers of up to 4 values x NW waves (block reductions), padded
-__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (13 + NW) * n + kRedDoubles; }
+__host__ __device__ constexpr int64_t lds_vector_doubles(const int64_t n) { return (11 + NW) * n + kRedDoubles; }
 __host__ __device__ constexpr int64_t lds_hessian_doubles(const int64_t ldsDoubles, const int64_t n) {
   return ldsDoubles > lds_vector_doubles(n) ? ldsDoubles - lds_vector_doubles(n) : 0;
 }
@@ -243,7 +247,11 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __r
     }
     rowsum[i] = d * g[i];
   }
-  __syncthreads();
+  if constexpr (NW == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  } else {
+    __syncthreads();
+  }
   for (int cBase = 0; cBase < n; cBase += 256) {  // column super-chunk of 2 x 128 columns: rows before cBase have no column in it
     HessChunk ck[2];
     double    col[2][2];
@@ -271,7 +279,11 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __r
 
 // t = H g from the partial sums of the pass (fixed summation order).
 __device__ __forceinline__ void hess_finish(const int n, const double* part, double* t) {
-  __syncthreads();
+  if constexpr (NW == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  } else {
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < n; i += NT) {
     double v = part[i];
 #pragma unroll
@@ -280,5 +292,12 @@ __device__ __forceinline__ void hess_finish(const int n, const double* part, dou
   }
 }
 
+}  // namespace NVMK_BFGS_NS
 }  // namespace minim
 }  // namespace nvmk
+
+#ifdef NVMK_BFGS_NS_DEFAULTED
+#undef NVMK_BFGS_NS
+#undef NVMK_BFGS_THREADS
+#undef NVMK_BFGS_NS_DEFAULTED
+#endif

@@ -103,7 +103,13 @@ class FlatMoleculeSet:
 # Conformer attempts per launch when the caller does not choose (-1, as HardwareOptions.batchSize): one workgroup per
 # attempt and 2-3 resident workgroups per CU, so 4096 keeps the 256 CUs busy through the tail of slow systems (measured
 # on synthetic 48-atom molecules: 3.9k conformers/s at 500 per launch, 8.1k at 5000).  The reference's default is 500.
-AUTO_BATCH_SIZE = 4096
+AUTO_BATCH_SIZE = 8192
+# Concurrent batches when the caller does not choose (-1, as HardwareOptions.batchesPerGpu) and the work spans more than two
+# batches: the tail of one batch's launches (a few long minimisations, the chip almost idle) overlaps the bulk of the other's.
+# Round 3 sweep on 10 000 molecules x 10 conformers (conformers/s): 8192 x 1 30.3k, 16384 x 1 32.7k, 4096 x 2 31.8k, 8192 x 2 35.1k,
+# 4096 x 3 33.5k, 8192 x 3 30.8k, 4096 x 4 33.2k (profiles/r03_conformers/).  A single batch at a time keeps a seeded run
+# reproducible bit for bit; with concurrent batches the scheduler hands out attempts in the order the batches finish.
+AUTO_BATCHES_PER_GPU = 2
 
 
 @dataclass
@@ -145,7 +151,7 @@ class FlatEmbedResult:
 def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterations: int = -1, batch_size: int = -1,
                use_exp_torsions: bool = True, use_basic_knowledge: bool = True, enforce_chirality: bool = True,
                box_size_mult: float = 2.0, force_tol: float = 1e-3, seed: int = 42, stream=None,
-               output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, batches_per_gpu: int = 1,
+               output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, batches_per_gpu: int = -1,
                prune_rms_thresh: float = -1.0, prune_atom_subsets=None):
     """ETKDG on flattened molecules (reference pipeline: src/etkdg.cpp:90-484 downstream of RDKit).
 
@@ -156,12 +162,10 @@ def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterati
     embedding (``conformerRmsd.prune_conformers``; ``prune_atom_subsets[m]`` = atom indices for onlyHeavyAtomsForRMS) and
     needs ``output=DEVICE`` here — the reference prunes on the CPU and therefore only with RDKit conformer output.
 
-    ``batches_per_gpu`` > 1 runs that many batches concurrently on their own streams (HardwareOptions.batchesPerGpu):
-    kept for parity with the reference's option, default 1.  Measured on MI355X with the default 4096-attempt batches it
-    does not pay (8.0k conformers/s with 1 batch in flight, 6.8k with 2, 4.8k with 4 on 48-atom synthetic molecules: a
-    batch already fills the GPU and the inverse-Hessian traffic of concurrent batches competes for HBM).  With one batch
-    at a time a seed reproduces the same conformers; with several, which random start a molecule's n-th attempt gets
-    depends on batch timing."""
+    ``batches_per_gpu`` > 1 runs that many batches concurrently on their own streams (HardwareOptions.batchesPerGpu); -1
+    (default) = ``AUTO_BATCHES_PER_GPU`` when the work spans more than two batches, else one batch at a time.  With one
+    batch at a time a seed reproduces the same conformers bit for bit; with several, which random start a molecule's n-th
+    attempt gets depends on the order the batches finish (as in the reference)."""
     sptr = _native.stream_ptr(stream)
     if confs_per_molecule <= 0:
         raise ValueError("confsPerMolecule must be greater than 0")
@@ -185,7 +189,9 @@ def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterati
     prm.box_size = 5.0 * box_size_mult if box_size_mult > 0 else -box_size_mult
     prm.force_tol = float(force_tol)
     prm.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    prm.batches_per_gpu = max(1, int(batches_per_gpu))
+    n_attempts = int(len(n_atoms)) * int(confs_per_molecule)
+    prm.batches_per_gpu = (int(batches_per_gpu) if batches_per_gpu > 0
+                           else (AUTO_BATCHES_PER_GPU if n_attempts > 2 * prm.batch_size else 1))
     slot_starts = np.zeros(len(n_atoms) + 1, dtype=np.int64)
     slot_starts[1:] = np.cumsum(n_atoms.astype(np.int64) * confs_per_molecule * 3)
     coords = torch.zeros(int(slot_starts[-1]), dtype=torch.float64, device=molset.device)
@@ -275,7 +281,7 @@ def embed_flat_molecules(flat_mols: Sequence[FlatMolecule], confs_per_molecule: 
                 stream.synchronize()  # the tables were staged on this stream
                 results[slot] = embed_flat(molset, confs_per_molecule, max_iterations,
                                            batch_size=opts.batchSize if opts.batchSize > 0 else -1,
-                                           batches_per_gpu=max(1, opts.batchesPerGpu), stream=stream, output=output, **kw)
+                                           batches_per_gpu=opts.batchesPerGpu, stream=stream, output=output, **kw)
             stream.synchronize()
 
     run_per_gpu(gpu_worker, len(gpu_ids))

@@ -242,11 +242,13 @@ class FlatForcefieldBatch:
         return grad
 
     def minimize(self, pos: torch.Tensor, max_iters: int = 200, grad_tol: float = 1e-4, scale_grads: bool = True,
-                 w0: float = 1.0, w1: float = 1.0, active=None, stream=None):
+                 w0: float = 1.0, w1: float = 1.0, active=None, stream=None, restarts: int = 0):
         """BFGS-minimise every (active) system in place.
 
         Returns ``(energies, statuses, iterations)``; status 0 = converged (reference: BfgsBatchMinimizer::minimize,
-        src/minimizer/bfgs_minimize.cu:978-1084; fused kernel bfgs_minimize_permol_kernels.cu:426-745)."""
+        src/minimizer/bfgs_minimize.cu:978-1084; fused kernel bfgs_minimize_permol_kernels.cu:426-745).  ``restarts`` > 0:
+        a system that stops at ``max_iters`` is minimised again inside the launch, with a fresh inverse Hessian, that many
+        more times (the ETKDG stages' repeatUntilConverged); iterations are the last minimisation's."""
         self._check_pos(pos)
         n = max(self.n_systems, 0)
         energies = torch.zeros(n, dtype=torch.float64, device=self.device)
@@ -254,10 +256,11 @@ class FlatForcefieldBatch:
         iters = torch.zeros(n, dtype=torch.int32, device=self.device)
         m = self._mask(active)
         with torch.cuda.device(self.device):
-            rc = _native.lib().nvmk_bfgs_minimize(ctypes.byref(self._c), self.atom_starts_host.ctypes.data, float(w0), float(w1),
-                                                  int(max_iters), float(grad_tol), int(bool(scale_grads)), pos.data_ptr(),
-                                                  m.data_ptr() if m is not None else None, energies.data_ptr(),
-                                                  statuses.data_ptr(), iters.data_ptr(), _native.stream_ptr(stream))
+            rc = _native.lib().nvmk_bfgs_minimize_repeat(ctypes.byref(self._c), self.atom_starts_host.ctypes.data, float(w0),
+                                                         float(w1), int(max_iters), int(restarts), float(grad_tol),
+                                                         int(bool(scale_grads)), pos.data_ptr(),
+                                                         m.data_ptr() if m is not None else None, energies.data_ptr(),
+                                                         statuses.data_ptr(), iters.data_ptr(), _native.stream_ptr(stream))
         _native.check(rc, "nvmk_bfgs_minimize")
         return energies, statuses, iters
 

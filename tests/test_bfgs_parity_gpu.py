@@ -178,7 +178,7 @@ def test_mixed_size_classes_in_one_call_equal_separate_calls(kind):
     got, e, it = pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy()
     assert it.max() == 12 and it.min() >= 1  # (a system may meet the TOLX test before the cap)
     dim = gpu.dim
-    vec_bytes = lambda n_atoms: 8 * (17 * n_atoms * dim + 40)
+    vec_bytes = lambda n_atoms: 8 * (15 * n_atoms * dim + 40)  # four-wave workgroups: (11 + 4) n-vectors + reduction scratch
     for s, n_atoms in enumerate(sizes):
         if s >= 12 and s not in (12, 52):  # one of each repeated size is enough
             continue
@@ -219,3 +219,29 @@ def test_large_systems_converge_on_the_quartic_field():
     assert np.all(st.cpu().numpy() == 0) and np.all(stc == 0)
     assert np.max(np.abs(got - np.arange(n))) < 0.1 and (e.cpu().numpy() < 1e-3).all()
     assert np.all(np.abs(it.cpu().numpy() - itc) <= 0.2 * itc + 2), (it.cpu().numpy(), itc)
+
+
+@pytest.mark.parametrize("kind", [DG, MMFF])
+def test_restarts_inside_the_launch_equal_repeated_calls(kind):
+    """nvmk_bfgs_minimize_repeat (the ETKDG stages' repeatUntilConverged without going back to the host): bit for bit what
+    repeated calls on the still-unconverged systems give — one-wave and four-wave workgroups, a system that converges at
+    once among them."""
+    sizes = [12, 30, 44, 60, 90, 130]
+    systems = systems_of(kind, sizes, 1500 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    w0, w1 = W[kind]
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    one = torch.from_numpy(flat).cuda()
+    e1, st1, it1 = gpu.minimize(one, max_iters=7, grad_tol=1e-3, w0=w0, w1=w1, restarts=3)
+    many = torch.from_numpy(flat).cuda()
+    active = torch.ones(len(sizes), dtype=torch.uint8, device="cuda")
+    e2 = torch.zeros(len(sizes), dtype=torch.float64, device="cuda")
+    st2 = torch.zeros(len(sizes), dtype=torch.int16, device="cuda")
+    it2 = torch.zeros(len(sizes), dtype=torch.int32, device="cuda")
+    for _ in range(4):
+        e, st, it = gpu.minimize(many, max_iters=7, grad_tol=1e-3, w0=w0, w1=w1, active=active)
+        ran = active.bool()
+        e2[ran], st2[ran], it2[ran] = e[ran], st[ran], it[ran]
+        active = (ran & (st != 0)).to(torch.uint8)
+    assert torch.equal(one, many) and torch.equal(e1, e2) and torch.equal(st1, st2) and torch.equal(it1, it2)
+    assert (st1 != 0).any()  # (seven iterations four times over are not enough for the larger ones)

@@ -28,7 +28,7 @@ ap.add_argument("--confs", type=int, default=10)
 ap.add_argument("--mean-atoms", type=int, default=48)
 ap.add_argument("--batch-size", type=int, default=-1)
 ap.add_argument("--mmff-iters", type=int, default=200)
-ap.add_argument("--batches-per-gpu", type=int, default=1)
+ap.add_argument("--batches-per-gpu", type=int, default=-1)
 ap.add_argument("--repeat", type=int, default=1, help="timed repetitions (the best is reported)")
 args = ap.parse_args()
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))

@@ -12,7 +12,7 @@
 
 #include "../nvmolkit_amd/csrc/hess_pass.h"
 
-using namespace nvmk::minim;
+using namespace nvmk::minim::t256;
 
 #define CHECK(x)                                                                      \
   do {                                                                                \
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(NT, OCC) void pass_kernel(double* __restrict__ hess
   double*   uu   = hdg + n;
   double*   g    = uu + n;
   double*   tvec = g + n;
-  double*   diag = xi + 11 * n;  // same offsets as bfgs_kernel: 11 vectors, the diagonal, then the partial sums
+  double*   diag = xi + 9 * n;  // same offsets as bfgs_kernel: 9 vectors, the diagonal, then the partial sums
   double*   part = diag + n;
   double*   red  = part + (1 + NW) * n;
   double*   Hl   = red + kRedDoubles;
