@@ -123,6 +123,11 @@ def kernel_source_digest(names=("similarity_mfma.hip", "fp4.h", "similarity.hip"
     return h.hexdigest()
 
 
+def conformer_source_digest() -> str:
+    """sha256 over the conformer kernels' sources (as tools/profile_conformer_traffic.sh computes it)."""
+    return kernel_source_digest(("minimize.hip", "bfgs_device.inc", "hess_pass.h", "ff_terms.h", "ff_grad.h", "etkdg.hip"))
+
+
 def butina_block(n: int, words: int, device, cpu_seconds: float) -> dict:
     """Fused Butina (cutoff 0.3 = similarity threshold 0.7, BASELINE.json configs[1]) on n planted-cluster fingerprints,
     with the roofline of its dominant kernel (the FP4 matrix-core neighbour-count pass) and the C oracle timed on a sample."""
@@ -284,6 +289,17 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
                                      "energy_evaluations": int(st[k, 3]), "hbm_resident_bytes": int(st[k, 4]),
                                      "mean_iterations": float(st[k, 1]) / max(int(st[k, 0]), 1)} for k in BFGS_KIND_NAMES}
     algo = float(sum(v["algorithmic_bytes"] for v in per_kind.values()))
+    # HBM bytes of the block from the PMC passes committed under profiles/ (tools/profile_conformer_traffic.sh: separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs on 2000 molecules of the same set, FETCH_SIZE doubled as the guide's
+    # gfx950 note prescribes), scaled by the conformers of this run; only while the kernel sources are the ones measured
+    traffic, traffic_src = None, None
+    for pmc in sorted((ROOT / "profiles").glob("r*/pmc_hbm_traffic_conformers.json"), reverse=True):
+        c = json.loads(pmc.read_text())
+        if c.get("kernel_source_sha256") == conformer_source_digest() and c.get("hbm_bytes_per_conformer"):
+            traffic = float(c["hbm_bytes_per_conformer"]) * n_conf
+            traffic_src = (f"{pmc.relative_to(ROOT)}: (2 x FETCH_SIZE + WRITE_SIZE) per conformer on {c.get('molecules')} molecules of "
+                           f"the same set x this run's {n_conf} conformers, kernel source hash matches")
+            break
     out = {"metric": f"mols/s ETKDG({confs} confs) + MMFF94 optimise (maxIters {mmff_iters})", "value": total_mols / wall,
            "unit": "mols/s", "n_gpus": world, "molecules": total_mols, "confs_per_molecule": confs,
            "mean_atoms": float(np.mean([m["embed"]["n_atoms"] for m in library])), "conformers": n_conf,
@@ -293,7 +309,7 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
            "data": "synthetic drug-like molecules (rings + chains + hydrogens, bounds / ETK / MMFF tables derived from one "
                    "generated 3-D geometry; nvmolkit_amd/synthetic.py) — real SMILES need RDKit",
            "roofline": {"bound": "hbm", "achieved": algo / wall / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": algo / wall / 1e9 / HBM_PEAK_GBPS / world, "traffic": None,
+                        "frac": algo / wall / 1e9 / HBM_PEAK_GBPS / world, "traffic": traffic, "traffic_source": traffic_src,
                         "hbm_bytes_requested_by_the_hessian_pass": float(sum(v["hbm_resident_bytes"] for v in per_kind.values())),
                         "kernel": "nvmk::minim::bfgs_kernel<DG|ETK|MMFF> (> 99 % of the GPU time of this block)",
                         "note": "algorithmic bytes = sum over systems of BFGS iterations x 8 n (n + 2) (read + write of the "
@@ -324,8 +340,10 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
                                "etkdg_seconds": c_embed, "mmff_seconds": c_mmff, "conformers": int(counts.sum()),
                                "mmff_converged_fraction": float((st_c == 0).mean()),
                                "sample": f"first {m} molecules of the same set x {confs} conformers, oracle/oracle_ff.c "
-                                         f"(same stage pipeline, scheduler, BFGS and term tables; OpenMP over attempts / "
-                                         f"conformers on {threads} threads), {c_embed + c_mmff:.1f} s"}
+                                         f"(same stage pipeline, scheduler, BFGS and term tables — like the GPU it evaluates ALL "
+                                         f"N (N - 1) / 2 distance terms of a molecule and a dense inverse Hessian, it is a port of "
+                                         f"this path, not RDKit's embedder; OpenMP over attempts / conformers on {threads} "
+                                         f"threads), {c_embed + c_mmff:.1f} s"}
     return out
 
 

@@ -12,11 +12,14 @@
  * per molecule `stride` atom invariants, `stride` bond invariants (indexed by bond id) and per atom up to 8
  * (bond id, other atom) pairs, -1 padded.
  *
- * Pinning status: "parity unpinned" against RDKit for real molecules (no RDKit in the build or GPU images:
- * SMILES parsing, ring perception and the expected bits all live there).  What IS pinned without RDKit:
- * the environment-deduplication logic, through the element-count known answers RDKit's own test-suite holds
- * and the reference repeats (tests/test_morgan_fingerprint_ref.cpp:44-60) on hand-flattened graphs
- * (tests/test_oracle_morgan.py), and the hash arithmetic, through hand-computed values.
+ * Pinning status: PINNED to RDKit through the values RDKit itself publishes — the environment-deduplication logic through
+ * the element-count known answers RDKit's own test-suite holds and the reference repeats
+ * (tests/test_morgan_fingerprint_ref.cpp:44-60) on hand-flattened graphs (tests/test_oracle_morgan.py); the invariant
+ * recipe and the hash chain through the identifiers of RDKit's documentation (the 16 environments of c1cccnc1C with
+ * 98513984 twice at radius 1 and 4048591891 at radius 2, bit 872 of c1ccccc1CC1CC1, the radius-0 identifiers of CH3 / CH2
+ * / OH / NH2 / aromatic CH, benzene's and ethanol's count fingerprints: tests/test_morgan_rdkit_known_answers.py, reached
+ * through the library's SMILES ingestion); the hash arithmetic also by hand.  Not available in the project's images: a
+ * corpus-wide comparison with RDKit's own fingerprints (tests/test_against_rdkit.py runs it wherever RDKit is installed).
  */
 #include <stdint.h>
 #include <stdlib.h>

@@ -1,8 +1,8 @@
-"""GPU checks that were written after round 2's last GPU run and have therefore not executed on an MI355X yet (their host
-logic has: tests/test_smiles_ingestion.py runs these bodies against a stubbed device, and every expected value below was
-produced on the CPU).  They live in a file that sorts last so that, under `pytest -x`, a surprise here cannot cut the
-established suite short.  Once they have passed on a GPU they can move next to their neighbours
-(test_smiles_ingestion.py, test_config_size_gpu.py, test_clustering_gpu.py, test_morgan_rdkit_known_answers.py)."""
+"""GPU checks on the reference's benchmark molecules and RDKit's documented examples through the SMILES path: the GH-84
+regression (256 single-molecule calls), Kekule / aromatic spellings, the kernel's bits of the documented Morgan examples, and
+BASELINE.json configs[0] end to end — 10 000 benchmark SMILES -> Morgan -> 10k x 10k Tanimoto -> fused Butina — against the
+committed digest (tests/golden/cfg1_chembl_10k_digest.json, written on the CPU).  (Written at the end of round 2 in a file
+that sorted last; they have since passed on the driver's box and in round 3's first GPU call.)"""
 
 import hashlib
 import json

@@ -413,7 +413,7 @@ def test_the_gpu_tests_of_this_file_on_the_stubbed_device(monkeypatch):
     calls = _stub_the_device(monkeypatch)
     test_fingerprints_from_smiles_equal_the_oracle_pipeline()
     test_refused_smiles_raise_or_stay_zero()
-    from tests import test_zz_gpu_checks_added_late as late
+    from tests import test_benchmark_molecules_gpu as late
     late.test_repeated_single_molecule_calls_never_come_back_empty()
     late.test_kekule_and_aromatic_spellings_give_one_fingerprint()
     late.test_kernel_bits_of_the_documented_examples()

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/${1:-r03_call4}
 mkdir -p $O
 cd $ROOT
-( time timeout 900 python -m pytest tests/test_clustering_gpu.py tests/test_zz_gpu_checks_added_late.py tests/test_full_size_gpu.py -m gpu -q -x ) > $O/pytest.log 2>&1
+( time timeout 900 python -m pytest tests/test_clustering_gpu.py tests/test_benchmark_molecules_gpu.py tests/test_full_size_gpu.py -m gpu -q -x ) > $O/pytest.log 2>&1
 tail -15 $O/pytest.log
 python - > $O/butina_ab.jsonl 2> $O/butina_ab.err <<'P'
 import json, sys, time

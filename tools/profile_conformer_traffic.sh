@@ -1,0 +1,41 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): HBM traffic of the conformer pipeline's BFGS kernels, FETCH_SIZE and WRITE_SIZE in separate
+# rocprofv3 --pmc passes (never combined with tracing), on 2000 molecules x 10 conformers of the benchmark's synthetic set.
+# Output: gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json (bytes per conformer; bench.py scales it to its own run
+# while the kernel sources' digest matches).
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_traffic
+MOLS=${1:-2000}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/tools/bench_conformers.py --mols $MOLS"
+export NVMK_ROOT=$ROOT
+timeout 900 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/conf_fetch -- $BENCH > $OUT/conf_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/conf_write -- $BENCH > $OUT/conf_write.log 2>&1
+python - "$OUT" "$MOLS" <<'PY'
+import csv, glob, hashlib, json, os, sys
+out = {"molecules": int(sys.argv[2])}
+h = hashlib.sha256()
+for name in ("minimize.hip", "bfgs_device.inc", "hess_pass.h", "ff_terms.h", "ff_grad.h", "etkdg.hip"):   # = bench.py conformer_source_digest()
+    h.update(open(os.path.join(os.environ["NVMK_ROOT"], "nvmolkit_amd", "csrc", name), "rb").read())
+out["kernel_source_sha256"] = h.hexdigest()
+for line in open(f"{sys.argv[1]}/conf_fetch.log"):
+    if line.startswith("{") and "etkdg_conformers" in line:
+        out["conformers"] = json.loads(line)["etkdg_conformers"]
+for name, sub in (("FETCH_SIZE", "conf_fetch"), ("WRITE_SIZE", "conf_write")):
+    per = {}
+    for f in glob.glob(f"{sys.argv[1]}/{sub}/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "bfgs_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                k = r["Kernel_Name"].split("(")[0].replace("void nvmk::minim::", "")
+                per[k] = per.get(k, 0.0) + float(r["Counter_Value"])
+    out[name] = {"KiB_by_kernel": per, "KiB_total": sum(per.values())}
+if out.get("conformers"):
+    # gfx950 counts FETCH_SIZE in 64-byte units of 128-byte requests: doubled (MI355X_MICROARCH.md, HBM section)
+    out["hbm_bytes_per_conformer"] = (2.0 * out["FETCH_SIZE"]["KiB_total"] + out["WRITE_SIZE"]["KiB_total"]) * 1024.0 / out["conformers"]
+out["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/bench_conformers.py --mols N; sums over "
+               "every bfgs_kernel launch of ETKDG + MMFF (warm-up call included: one molecule)")
+json.dump(out, open(f"{sys.argv[1]}/pmc_hbm_traffic_conformers.json", "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
+PY
