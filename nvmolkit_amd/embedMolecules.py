@@ -100,16 +100,16 @@ class FlatMoleculeSet:
         return counts
 
 
-# Conformer attempts per launch when the caller does not choose (-1, as HardwareOptions.batchSize): one workgroup per
-# attempt and 2-3 resident workgroups per CU, so 4096 keeps the 256 CUs busy through the tail of slow systems (measured
-# on synthetic 48-atom molecules: 3.9k conformers/s at 500 per launch, 8.1k at 5000).  The reference's default is 500.
-AUTO_BATCH_SIZE = 8192
-# Concurrent batches when the caller does not choose (-1, as HardwareOptions.batchesPerGpu) and the work spans more than two
-# batches: the tail of one batch's launches (a few long minimisations, the chip almost idle) overlaps the bulk of the other's.
-# Round 3 sweep on 10 000 molecules x 10 conformers (conformers/s): 8192 x 1 30.3k, 16384 x 1 32.7k, 4096 x 2 31.8k, 8192 x 2 35.1k,
-# 4096 x 3 33.5k, 8192 x 3 30.8k, 4096 x 4 33.2k (profiles/r03_conformers/).  A single batch at a time keeps a seeded run
-# reproducible bit for bit; with concurrent batches the scheduler hands out attempts in the order the batches finish.
-AUTO_BATCHES_PER_GPU = 2
+# Conformer attempts per launch when the caller does not choose (-1, as HardwareOptions.batchSize).  One wave (small systems) or
+# one four-wave workgroup (larger ones) per attempt, 2048 / 512 of them resident: a batch must be several times that, or the
+# tail of its launches — a few long minimisations on an almost idle chip — dominates.  The reference's default is 500.
+# Concurrent batches (HardwareOptions.batchesPerGpu, -1 = this default) overlap one batch's tails with the other's bulk, but a
+# single batch at a time keeps a seeded run reproducible bit for bit (with several, the scheduler hands out attempts in the
+# order the batches finish), and at 16384 attempts it is as fast.  Round 3 sweep, 10 000 molecules x 10 conformers, ETKDG
+# conformers/s (profiles/r03_conformers/batch_sweep_wave176.jsonl): 8192 x 1 37.5k, 16384 x 1 40.5k / 40.2k, 24576 x 1 38.4k,
+# 32768 x 1 36.8k, 4096 x 2 41.0k, 8192 x 2 38.5k, 16384 x 2 37.1k, 4096 x 3 40.6k, 8192 x 3 41.7k.
+AUTO_BATCH_SIZE = 16384
+AUTO_BATCHES_PER_GPU = 1
 
 
 @dataclass
