@@ -81,8 +81,8 @@ def cpu_baseline(ref_words: np.ndarray, target_seconds: float) -> dict:
     lib = oracle.lib()
     ref_words = ref_words[: min(len(ref_words), 100_000)]
     m = ref_words.shape[0]
-    block = min(2048, m)
-    out = np.zeros((block, m), dtype=np.float64)  # touched once: page faults stay out of the timing
+    block = min(max(2048, 16 * threads), m)
+    out = np.empty((block, m), dtype=np.float64)  # first touched by the (untimed) first call, by the threads that keep writing it
 
     def run(n_threads: int, seconds: float):
         lib.orc_cross_similarity_f64(0, np.ascontiguousarray(ref_words[:block]), block, ref_words, m, ref_words.shape[1], out, m, n_threads)

@@ -150,17 +150,43 @@ void orc_cross_similarity_f64(int metric, const uint32_t* a, int64_t nA, const u
   for (int64_t j = 0; j < nB; ++j) pb[j] = popc_row(b + j * W, W);
   /* cache blocking only (the arithmetic per pair is unchanged): a thread owns a block of B rows that stays in its
    * cache while it sweeps blocks of A rows, so B is streamed from DRAM once per call instead of once per A row */
-  const int64_t JB = 128, IB = 64;
+  const int64_t JB = 128, IB = 8;
   const int64_t nJB = (nB + JB - 1) / JB;
 #ifdef ORC_HAVE_VPOPCNT
   const int vec = metric == ORC_TANIMOTO && W % 16 == 0 && W > 0 && !orc_force_scalar;
 #else
   const int vec = 0;
 #endif
+  /* With enough rows of A for every thread, a thread owns whole blocks of output ROWS (contiguous stores, first touched by the
+   * thread that keeps writing them: on a two-socket host the matrix then lies in the writer's own memory); B is re-read per
+   * block of A rows from the shared cache.  Otherwise (few rows of A) the threads split the rows of B. */
+  const int64_t nIB    = (nA + IB - 1) / IB;
+  const int     byRows = nIB >= 2 * (int64_t)threads;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#pragma omp parallel for schedule(static) num_threads(threads) if (byRows)
 #endif
-  for (int64_t jb = 0; jb < nJB; ++jb) {
+  for (int64_t ib = 0; ib < (byRows ? nIB : 0); ++ib) {
+    const int64_t i0 = ib * IB, i1 = (i0 + IB < nA) ? i0 + IB : nA;
+    for (int64_t jb = 0; jb < nJB; ++jb) {
+      const int64_t j0 = jb * JB, j1 = (j0 + JB < nB) ? j0 + JB : nB;
+      int64_t       jv = j0;
+#ifdef ORC_HAVE_VPOPCNT
+      if (vec) {
+        for (; jv + 8 <= j1; jv += 8) {
+          for (int64_t i = i0; i < i1; i += 2) orc_tile_2x8(a, b, W, i, (i + 1 < i1) ? 2 : 1, jv, pa, pb, out, ld);
+        }
+      }
+#endif
+      for (int64_t i = i0; i < i1; ++i) {
+        const uint32_t* ai = a + i * W;
+        for (int64_t j = jv; j < j1; ++j) out[i * ld + j] = finish_f64(metric, popc_and(ai, b + j * W, W), pa[i], pb[j]);
+      }
+    }
+  }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (!byRows)
+#endif
+  for (int64_t jb = 0; jb < (byRows ? 0 : nJB); ++jb) {
     const int64_t j0 = jb * JB, j1 = (j0 + JB < nB) ? j0 + JB : nB;
     for (int64_t i0 = 0; i0 < nA; i0 += IB) {
       const int64_t i1 = (i0 + IB < nA) ? i0 + IB : nA;

@@ -102,8 +102,10 @@ def test_cfg3_etkdg_counts_and_bounds(cfg3):
         p = xyz[a_s[c]:a_s[c + 1]]
         d = np.linalg.norm(p[pairs[:, 0]] - p[pairs[:, 1]], axis=1)
         worst.append(float(np.max(np.maximum(np.maximum(lb - d, d - ub), 0.0) / ub)))
-    # the stage accepts E / atom < 0.05 with E = sum (d^2 / ub^2 - 1)^2: single pairs may be off by several per cent
-    assert np.median(worst) < 0.05 and np.percentile(worst, 95) < 0.12 and max(worst) < 0.3
+    # the stage accepts E / atom < 0.05 with E = sum (d^2 / ub^2 - 1)^2: single pairs may be off by several per cent, and in
+    # the extreme ONE pair of a 96-atom molecule may carry the whole allowance: ((1 + v)^2 - 1)^2 <= 0.05 x 96 gives v <= 0.79
+    # (which of the ~98 000 conformers the 400 sampled ones are depends on the batch size; 0.50 has been seen)
+    assert np.median(worst) < 0.05 and np.percentile(worst, 95) < 0.12 and max(worst) < 0.79
 
 
 def test_cfg3_mmff_energies_decrease_and_match_oracle_energy(cfg3):
