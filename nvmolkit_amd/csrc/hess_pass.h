@@ -59,6 +59,7 @@ __host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t
   if (hess_row_offset(n) <= hldsDoubles) return n;
   int r = 0;
   while (r < n && hess_row_offset(r + 1) <= hldsDoubles) ++r;
+  if (NW == 1 && r < 64) r &= ~7;  // one-wave workgroups walk rows 0..63 in groups of eight that are all LDS or all HBM (hess_packed)
   return r;
 }
 // LDS layout of bfgs_kernel: 10 vectors (the 10th is the diagonal of the inverse Hessian) + (1 + NW) partial-sum slabs of n
@@ -196,6 +197,78 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
   }
 }
 
+// One-wave workgroups only: rows [rFrom, rEnd) inside 0..63 (both multiples of 8), TWO ROWS PER WAVE INSTRUCTION.  A row
+// shorter than 64 columns uses at most half a wave in hess_range; here lanes 0..31 take row r and lanes 32..63 row r + 1,
+// lane & 31 = the same pair of columns in both halves, four such row pairs (eight rows) per group.  Row sums are reduced
+// inside each half (wave_sum4_transposed without its last step), the mirrored-entry sums of the two halves are folded into
+// colOut[0..1] of lanes 0..31 at the end.  Halves the instructions these rows cost (a third of the rows at n = 144).
+template <bool PREFETCH>
+__device__ __forceinline__ void hess_packed(double* __restrict__ H, const int rBase, const int rFrom, const int rEnd, const int lane,
+                                            const HessChunk& ck, const bool pending, const double* __restrict__ xi,
+                                            const double* __restrict__ hdg, const double* __restrict__ uu,
+                                            const double* __restrict__ g, double* __restrict__ rowsum, double (&colAcc)[2]) {
+  constexpr int RU   = 2;  // row pairs per group (four rows): two keep the one-wave kernels free of spills
+  const int     half = lane >> 5;
+  const int     base = hess_row_offset32(rBase);
+  const int     c0   = ck.c0;  // 2 * (lane & 31)
+  auto load_group = [&](const int r0, double2 (&dst)[RU]) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = r0 + 2 * u + half;
+      dst[u]      = *reinterpret_cast<const double2*>(H + (hess_row_offset32(r) - base) + c0);  // unconditional (tail pad / next rows)
+    }
+  };
+  double2 next[RU];
+  if constexpr (PREFETCH) {
+    if (rFrom < rEnd) load_group(rFrom, next);
+  }
+  for (int r0 = rFrom; r0 < rEnd; r0 += 2 * RU) {
+    double2 hv[RU];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int u = 0; u < RU; ++u) hv[u] = next[u];
+      if (r0 + 2 * RU < rEnd) load_group(r0 + 2 * RU, next);
+    } else {
+      load_group(r0, hv);
+    }
+    double rs[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int    r  = r0 + 2 * u + half;
+      const double gr = g[r], xr = xi[r], hr = hdg[r], ur = uu[r];
+      rs[u]           = 0.0;
+      if (c0 < r) {
+        double2    h   = hv[u];
+        const bool two = c0 + 1 < r;
+        if (pending) {
+          h.x += xr * ck.xs0 - hr * ck.hs0 + ur * ck.us0;
+          const double y = h.y + (xr * ck.xs1 - hr * ck.hs1 + ur * ck.us1);
+          h.y            = two ? y : 0.0;
+          *reinterpret_cast<double2*>(H + (hess_row_offset32(r) - base) + c0) = h;
+        }
+        colAcc[0] += h.x * gr;
+        colAcc[1] += h.y * gr;
+        rs[u] = h.x * ck.g0 + h.y * ck.g1;
+      }
+    }
+    // two row sums per half, transposed: even lanes end with row pair 0's total of their half, odd lanes with row pair 1's
+    {
+      const bool odd = (lane & 1) != 0;
+      double     x   = (odd ? rs[1] : rs[0]) + dpp_mov<0xb1>(odd ? rs[0] : rs[1]);  // lane & 1 = u: sum over the lane pair
+      x += dpp_mov<0x4e>(x);   // quad
+      x += dpp_mov<0x124>(x);  // row_ror 4
+      x += dpp_mov<0x128>(x);  // row_ror 8: the row of 16 lanes
+      {
+        const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+        x            = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);  // x + (lane ^ 16): the half's total
+      }
+      const int myRow = r0 + 2 * (lane & 1) + half;
+      if ((lane & 31) < 2) rowsum[myRow] += x;  // one writer per row: this wave, once
+    }
+  }
+}
+
 template <int NCH> __device__ __forceinline__ void hess_chunk_state(HessChunk (&ck)[NCH], double (&col)[NCH][2], const int cBase,
                                                                     const int lane, const int n, const bool pending, const double rfac,
                                                                     const double fad, const double fae, const double* __restrict__ xi,
@@ -252,16 +325,43 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __r
   } else {
     __syncthreads();
   }
+  // one-wave workgroups: rows 0 .. P-1 (P <= 64, a multiple of 8) two at a time; their mirrored-entry sums start the first
+  // chunk's column accumulators of lanes 0..31 below
+  int    packedRows  = 0;
+  double packedCol[2] = {0.0, 0.0};
+  if constexpr (NW == 1) {
+    packedRows = min(n, 64) & ~7;  // (whole groups of four rows, and a boundary resident_rows can land on)
+    if (packedRows > 0) {
+      HessChunk ckp[1];
+      double    colp[1][2];
+      // the chunk state of columns 2 (lane & 31), 2 (lane & 31) + 1 — the first 64 columns, in both halves of the wave
+      hess_chunk_state<1>(ckp, colp, 0, lane & 31, n, pending, rfac, fad, fae, xi, hdg, uu, g);
+      const int split = min(packedRows, Rl);  // a multiple of 8 (resident_rows)
+      if (split > 0) hess_packed<false>(Hl, 0, 0, split, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
+      if (split < packedRows) hess_packed<PREFETCH>(Hg, Rl, split, packedRows, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {  // fold the two halves: lanes 0..31 keep the totals of their columns
+        const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(colp[0][j]), __double2loint(colp[0][j]), false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(colp[0][j]), __double2hiint(colp[0][j]), false, false);
+        const double t = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+        packedCol[j]   = lane < 32 ? t : 0.0;
+      }
+    }
+  }
   for (int cBase = 0; cBase < n; cBase += 256) {  // column super-chunk of 2 x 128 columns: rows before cBase have no column in it
     HessChunk ck[2];
     double    col[2][2];
     hess_chunk_state<2>(ck, col, cBase, lane, n, pending, rfac, fad, fae, xi, hdg, uu, g);
+    if (cBase == 0) {
+      col[0][0] = packedCol[0];
+      col[0][1] = packedCol[1];
+    }
     // rows that reach into the first chunk only ([cBase, cBase + 128]) never touch the second one
     const int mid = min(n, cBase + 129);  // row cBase + 128 is the first with an entry in the second chunk... (c0 < r)
     {
       HessChunk(&ck1)[1]    = reinterpret_cast<HessChunk(&)[1]>(ck[0]);
       double(&col1)[1][2]   = reinterpret_cast<double(&)[1][2]>(col[0]);
-      const int lo = cBase, hi = mid;
+      const int lo = max(cBase, packedRows), hi = mid;
       if (lo < min(hi, Rl)) hess_range<1, false>(Hl, 0, lo, min(hi, Rl), wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
       if (max(lo, Rl) < hi) hess_range<1, PREFETCH>(Hg, Rl, max(lo, Rl), hi, wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
     }

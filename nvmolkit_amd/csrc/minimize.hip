@@ -177,7 +177,6 @@ using namespace nvmk;
 using namespace nvmk::minim;
 using nvmk::minim::t256::hess_row_offset;
 using nvmk::minim::t256::kHessTailPadDoubles;
-using nvmk::minim::t256::resident_rows;
 
 namespace {
 // device counters the BFGS kernels add to when set (nvmk_bfgs_set_stats); process-wide, off by default
@@ -294,6 +293,10 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
   auto vec_doubles = [](const int threads, const int64_t n) { return threads == 64 ? t64::lds_vector_doubles(n) : t256::lds_vector_doubles(n); };
   auto hess_doubles = [](const int threads, const int64_t ldsDoubles, const int64_t n) {
     return threads == 64 ? t64::lds_hessian_doubles(ldsDoubles, n) : t256::lds_hessian_doubles(ldsDoubles, n);
+  };
+  // (rows resident in LDS: the one-wave kernels round a boundary below 64 rows to a multiple of 8, see hess_pass.h)
+  auto resident = [](const int threads, const int n, const int64_t hld) {
+    return threads == 64 ? t64::resident_rows(n, hld) : t256::resident_rows(n, hld);
   };
   const size_t kFull = bin_budget(nBins - 1);
   // NVMK_BFGS_LDS: "auto" (default) = the bins above; "full" = every system gets the whole 160 KiB (one workgroup per CU);
@@ -421,7 +424,7 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
       int64_t at = 0;
       for (const int32_t s : cls[c].order) {
         const int n  = (h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
-        const int rl = resident_rows(n, hess_doubles(P.threads, P.ldsDoubles, n));
+        const int rl = resident(P.threads, n, hess_doubles(P.threads, P.ldsDoubles, n));
         P.hs[static_cast<size_t>(s)] = at;
         at += hess_row_offset(n) - hess_row_offset(rl);
       }
@@ -431,7 +434,7 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
       int64_t slot = 0;
       for (const int32_t s : cls[c].order) {
         const int n  = (h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
-        const int rl = P.gvec ? 0 : resident_rows(n, hess_doubles(P.threads, P.ldsDoubles, n));
+        const int rl = P.gvec ? 0 : resident(P.threads, n, hess_doubles(P.threads, P.ldsDoubles, n));
         slot         = std::max<int64_t>(slot, hess_row_offset(n) - hess_row_offset(rl));
       }
       P.slotDoubles = ((slot + kHessTailPadDoubles) + 1) & ~int64_t{1};
