@@ -283,6 +283,24 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
                               int restarts, double grad_tol, int scale_grads, double* d_pos, const uint8_t* d_active,
                               double* d_energies, int16_t* d_statuses, int32_t* d_iters, void* stream);
 
+/* Two minimisations of every system in ONE launch, each with its own weights, iteration limit and restarts — the first
+ * distance-geometry minimisation of ETKDG (chiral 1.0, 4th dimension 0.1, 400 iterations) and its fourth-dimension stage
+ * (0.2, 1.0, 200; reference: src/etkdg_stage_distgeom_minimize.cu:177-249, two DistGeomMinimizeStage objects with the
+ * stereo checks of etkdg_stage_stereochem_checks.cu in between).  The coordinates after the first minimisation are left in
+ * d_pos_between for the checks that sit between the stages; d_pos, energies, statuses and iterations report the second.  A
+ * system whose first-stage energy exceeds skip_above_energy_per_atom x atoms (< 0: never) is left as the first stage left it:
+ * the caller is going to fail it on that energy anyway.  Each system's results are those of two separate calls. */
+typedef struct nvmk_bfgs_second_stage {
+  double  w0, w1;
+  int32_t max_iters, restarts;
+  double* d_pos_between;
+  double  skip_above_energy_per_atom;
+} nvmk_bfgs_second_stage;
+int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_atom_starts, double w0, double w1, int max_iters,
+                                  int restarts, const nvmk_bfgs_second_stage* second /* NULL: one stage */, double grad_tol,
+                                  int scale_grads, double* d_pos, const uint8_t* d_active, double* d_energies,
+                                  int16_t* d_statuses, int32_t* d_iters, void* stream);
+
 /* Measurement hook (bench.py's roofline, tests): when d_counters != NULL every BFGS launch of this process — the ones
  * nvmk_etkdg_embed issues included — adds to d_counters[8 * kind + k] (device memory, 64 uint64, caller zeroes it):
  * k = 0 systems minimised, 1 BFGS iterations, 2 inverse-Hessian bytes those iterations stand for (read + write of the

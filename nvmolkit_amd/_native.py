@@ -65,6 +65,8 @@ SIGNATURES: dict[str, tuple] = {
                                   _vp, _vp, _vp]),
     "nvmk_bfgs_minimize_repeat": (_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _int, _int, ctypes.c_double, _int, _vp, _vp,
                                          _vp, _vp, _vp, _vp]),
+    "nvmk_bfgs_minimize_two_stages": (_int, [_vp, _vp, ctypes.c_double, ctypes.c_double, _int, _int, _vp, ctypes.c_double, _int, _vp,
+                                             _vp, _vp, _vp, _vp, _vp]),
     "nvmk_bfgs_set_stats": (_int, [_vp]),
     "nvmk_scheduler_create": (_vp, [_int, _int, _int]),
     "nvmk_scheduler_destroy": (None, [_vp]),
@@ -101,6 +103,13 @@ class FFBatch(ctypes.Structure):
                 ("groups", FFGroup * 12), ("system_mol", ctypes.c_void_p), ("group_mask", ctypes.c_uint32),
                 ("etk_ref12_starts", ctypes.c_void_p), ("etk_ref12", ctypes.c_void_p),
                 ("etk_ref13_starts", ctypes.c_void_p), ("etk_ref13", ctypes.c_void_p)]
+
+
+class BfgsSecondStage(ctypes.Structure):
+    """Mirror of ``nvmk_bfgs_second_stage``."""
+
+    _fields_ = [("w0", ctypes.c_double), ("w1", ctypes.c_double), ("max_iters", ctypes.c_int32), ("restarts", ctypes.c_int32),
+                ("d_pos_between", ctypes.c_void_p), ("skip_above_energy_per_atom", ctypes.c_double)]
 
 
 FF_DG, FF_ETK, FF_MMFF, FF_QUARTIC, FF_UFF = 0, 1, 2, 3, 4

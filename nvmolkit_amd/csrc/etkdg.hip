@@ -453,7 +453,7 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
   auto worker = [&](hipStream_t stream) -> int {
   DevBuf<int32_t>  dAtomStarts, dSysMol, dRef12Starts, dRef13Starts, dSrcSys;
   DevBuf<int64_t>  dDstOff;
-  DevBuf<double>   dPos, dPos3, dEnergies, dRef12, dRef13;
+  DevBuf<double>   dPos, dPosMid, dPos3, dEnergies, dRef12, dRef13;
   DevBuf<uint8_t>  dActive, dFailed, dSub;
   DevBuf<int16_t>  dFinished, dStatuses, dFailSum;
   DevBuf<int>      dCount;
@@ -482,6 +482,7 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     NVMK_HIP_CHECK(dAtomStarts.ensure(atomStarts.size()));
     NVMK_HIP_CHECK(dSysMol.ensure(static_cast<size_t>(nSys)));
     NVMK_HIP_CHECK(dPos.ensure(static_cast<size_t>(nAtoms) * 4));
+    NVMK_HIP_CHECK(dPosMid.ensure(static_cast<size_t>(nAtoms) * 4));
     if (useEtk) NVMK_HIP_CHECK(dPos3.ensure(static_cast<size_t>(nAtoms) * 3));
     NVMK_HIP_CHECK(dEnergies.ensure(static_cast<size_t>(nSys)));
     NVMK_HIP_CHECK(dActive.ensure(static_cast<size_t>(nSys)));
@@ -529,22 +530,10 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
       ++stage;
       return NVMK_OK;
     };
-    // BFGS on the active systems, repeated while any of them is unconverged (repeatUntilConverged,
-    // etkdg_stage_distgeom_minimize.cu:53-58); `repeat` false = one call (ETK stage)
-    auto minimize = [&](const nvmk_ff_batch& b, double w0, double w1, int iters, bool repeat) -> int {
-      NVMK_HIP_CHECK(hipMemcpyAsync(dSub.p, dActive.p, static_cast<size_t>(nSys), hipMemcpyDeviceToDevice, stream));
-      // repeatUntilConverged: a system that stops at the iteration limit is minimised again (fresh inverse Hessian) inside
-      // the same launch, up to 49 more times — the host loop this replaces relaunched the few unconverged systems of a batch
-      // on an almost empty chip and synchronised with the host each time
-      int rc = nvmk_bfgs_minimize_repeat(&b, atomStarts.data(), w0, w1, iters, repeat ? 49 : 0, prm->force_tol, 1, dPos.p, dSub.p,
-                                         dEnergies.p, dStatuses.p, nullptr, stream);
-      if (rc != NVMK_OK) return rc;
-      return NVMK_OK;
-    };
-    auto check = [&](int kind) -> int {
+    auto check = [&](int kind, const double* pos4 = nullptr) -> int {
       if (ms->check_starts == nullptr) return NVMK_OK;
       hipLaunchKernelGGL(stereo_check_kernel, dim3(nSys), dim3(64), 0, stream, nSys, dAtomStarts.p, dSysMol.p, ms->check_starts,
-                         ms->check_kind, ms->check_idx, ms->check_par, kind, dPos.p, dActive.p, dFailed.p);
+                         ms->check_kind, ms->check_idx, ms->check_par, kind, pos4 != nullptr ? pos4 : dPos.p, dActive.p, dFailed.p);
       NVMK_LAUNCH_CHECK();
       return NVMK_OK;
     };
@@ -560,23 +549,39 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     hipLaunchKernelGGL(random_coords_kernel, dim3(nSys), dim3(64), 0, stream, nSys, dAtomStarts.p, dActive.p, prm->seed, attemptBase,
                        prm->box_size, dPos.p);
     NVMK_TRY(end_stage());
-    // stage 1: first minimisation (chiral 1.0, 4th dim 0.1, 400 iterations) + energy check
+    // stage 1: first minimisation (chiral 1.0, 4th dim 0.1, 400 iterations) + energy check — and, in the same launch, stage
+    // 4's fourth-dimension minimisation (chiral 0.2, 4th dim 1.0, 200 iterations) of every system right behind its first
+    // one: stage 4 needs two iterations on average but a few systems take all 200, and as a launch of its own it ended every
+    // batch with ~10 ms of an almost idle chip.  The coordinates in between stay in dPosMid for the checks of stages 1-3; a
+    // system those checks fail has been minimised in vain, which changes nothing for the others (a system's minimisation
+    // depends on its own coordinates only).  Systems 2 % beyond the energy limit of stage 1 skip the second minimisation.
     NVMK_TRY(begin_stage());
-    NVMK_TRY(minimize(dg, 1.0, 0.1, 400, true));
-    NVMK_TRY(nvmk_ff_energy(&dg, 1.0, 0.1, dPos.p, nullptr, dEnergies.p, stream));
+    {
+      NVMK_HIP_CHECK(hipMemcpyAsync(dSub.p, dActive.p, static_cast<size_t>(nSys), hipMemcpyDeviceToDevice, stream));
+      NVMK_HIP_CHECK(hipMemcpyAsync(dPosMid.p, dPos.p, static_cast<size_t>(nAtoms) * 4 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      nvmk_bfgs_second_stage second{};
+      second.w0                         = 0.2;
+      second.w1                         = 1.0;
+      second.max_iters                  = 200;
+      second.restarts                   = 49;
+      second.d_pos_between              = dPosMid.p;
+      second.skip_above_energy_per_atom = 0.05 * 1.02;
+      NVMK_TRY(nvmk_bfgs_minimize_two_stages(&dg, atomStarts.data(), 1.0, 0.1, 400, 49, &second, prm->force_tol, 1, dPos.p, dSub.p,
+                                             dEnergies.p, dStatuses.p, nullptr, stream));
+    }
+    NVMK_TRY(nvmk_ff_energy(&dg, 1.0, 0.1, dPosMid.p, nullptr, dEnergies.p, stream));
     hipLaunchKernelGGL(energy_per_atom_check_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, dEnergies.p, dAtomStarts.p,
                        dFailed.p);
     NVMK_TRY(end_stage());
-    // stage 2: tetrahedral centres; stage 3: first chiral check
+    // stage 2: tetrahedral centres; stage 3: first chiral check (on the coordinates the first minimisation left)
     NVMK_TRY(begin_stage());
-    NVMK_TRY(check(NVMK_CHECK_TETRAHEDRAL));
+    NVMK_TRY(check(NVMK_CHECK_TETRAHEDRAL, dPosMid.p));
     NVMK_TRY(end_stage());
     NVMK_TRY(begin_stage());
-    if (prm->enforce_chirality) NVMK_TRY(check(NVMK_CHECK_CHIRAL_VOLUME));
+    if (prm->enforce_chirality) NVMK_TRY(check(NVMK_CHECK_CHIRAL_VOLUME, dPosMid.p));
     NVMK_TRY(end_stage());
-    // stage 4: fourth-dimension minimisation (chiral 0.2, 4th dim 1.0, 200 iterations)
+    // stage 4: fourth-dimension minimisation — ran in stage 1's launch
     NVMK_TRY(begin_stage());
-    NVMK_TRY(minimize(dg, 0.2, 1.0, 200, true));
     NVMK_TRY(end_stage());
     // stage 5: ETK minimisation (300 iterations) + planarity check
     NVMK_TRY(begin_stage());

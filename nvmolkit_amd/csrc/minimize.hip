@@ -83,6 +83,11 @@ struct BfgsArgs {
   double                          w0, w1;
   int                             maxIters;
   int                             restarts;     // further minimisations of a system that stops at maxIters (each from H = I)
+  // optional second minimisation of every system in the same launch (maxItersB < 0: none)
+  double                          w0b, w1b;
+  int                             maxItersB, restartsB;
+  double*                         posMid;       // coordinates after the first minimisation (same layout as positions)
+  double                          skipAbove;    // >= 0: no second minimisation when the first one's energy per atom exceeds it
   double                          gradTol;
   int                             scaleGrads;
   const uint8_t*                  active;
@@ -109,6 +114,11 @@ struct BfgsArgs {
 // four waves per system (every size), then one wave per system (small systems: eight or six of them share a CU)
 #define NVMK_BFGS_NS t256
 #define NVMK_BFGS_THREADS 256
+#include "bfgs_device.inc"
+#undef NVMK_BFGS_NS
+#undef NVMK_BFGS_THREADS
+#define NVMK_BFGS_NS t128
+#define NVMK_BFGS_THREADS 128
 #include "bfgs_device.inc"
 #undef NVMK_BFGS_NS
 #undef NVMK_BFGS_THREADS
@@ -256,7 +266,17 @@ int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts,
 int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_starts, double w0, double w1, int max_iters,
                               int restarts, double grad_tol, int scale_grads, double* d_pos, const uint8_t* d_active,
                               double* d_energies, int16_t* d_statuses, int32_t* d_iters, void* stream_) {
+  return nvmk_bfgs_minimize_two_stages(batch, h_atom_starts, w0, w1, max_iters, restarts, nullptr, grad_tol, scale_grads, d_pos,
+                                       d_active, d_energies, d_statuses, d_iters, stream_);
+}
+
+int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_atom_starts, double w0, double w1, int max_iters,
+                                  int restarts, const nvmk_bfgs_second_stage* second, double grad_tol, int scale_grads,
+                                  double* d_pos, const uint8_t* d_active, double* d_energies, int16_t* d_statuses,
+                                  int32_t* d_iters, void* stream_) {
   NVMK_REQUIRE(restarts >= 0, "bfgs: negative restart count");
+  NVMK_REQUIRE(second == nullptr || (second->max_iters >= 0 && second->restarts >= 0 && second->d_pos_between != nullptr),
+               "bfgs: the second stage needs an iteration limit, a restart count and the buffer for the coordinates in between");
   Batch b;
   int   rc = to_batch(batch, b);
   if (rc != NVMK_OK) return rc;
@@ -285,18 +305,30 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
   constexpr int kNoLimit = 1 << 30;
   const long    waveOpt  = opt::get(opt::kBfgsWave).num(1);
   const int     kWaveMaxN = waveOpt > 1 ? static_cast<int>(std::min<long>(waveOpt, 2000)) : 176;
+  // NVMK_BFGS_WAVE2: the largest system TWO waves take (0 = none), default 256 coordinates: four such systems per CU, between
+  // the one-wave and the four-wave kernels in both respects — measured (10 000 molecules x 10 conformers, mol/s; one-wave
+  // threshold, two-wave threshold): (176, none) 2872, (176, 208) 2935, (176, 240) 2933, (176, 256) 2937, (176, 288) 2912,
+  // (176, 336) 2837, (176, 400) 2859, (144, 256) 2821, (160, 256) 2883, (192, 256) 2832, (128, 232) 2756
+  // (profiles/r03_conformers/wave2_threshold.jsonl).
+  const long    wave2Opt  = opt::get(opt::kBfgsWave2).num(1);
+  const int     kWave2MaxN = wave2Opt > 1 ? static_cast<int>(std::min<long>(wave2Opt, 2000)) : wave2Opt == 0 ? 0 : 256;
   const BinDef  kBins[]  = {{64, 8, 176}, {64, 6, 232}, {64, 4, kNoLimit}, {64, 3, kNoLimit}, {64, 2, kNoLimit}, {64, 1, kNoLimit},
+                            {128, 4, kNoLimit}, {128, 2, kNoLimit}, {128, 1, kNoLimit},
                             {256, 2, kNoLimit}, {256, 1, kNoLimit}};
-  constexpr int nBins = 8, kFirst256 = 6;
+  constexpr int nBins = 11, kFirst128 = 6, kFirst256 = 9;
   // static LDS of the kernel + the 512-byte allocation granularity, per workgroup
   auto bin_budget = [&](const int c) { return kLdsPerCu / static_cast<size_t>(kBins[c].wgPerCu) - (kBins[c].wgPerCu > 2 ? 512 : 1024); };
-  auto vec_doubles = [](const int threads, const int64_t n) { return threads == 64 ? t64::lds_vector_doubles(n) : t256::lds_vector_doubles(n); };
+  auto vec_doubles = [](const int threads, const int64_t n) {
+    return threads == 64 ? t64::lds_vector_doubles(n) : threads == 128 ? t128::lds_vector_doubles(n) : t256::lds_vector_doubles(n);
+  };
   auto hess_doubles = [](const int threads, const int64_t ldsDoubles, const int64_t n) {
-    return threads == 64 ? t64::lds_hessian_doubles(ldsDoubles, n) : t256::lds_hessian_doubles(ldsDoubles, n);
+    return threads == 64    ? t64::lds_hessian_doubles(ldsDoubles, n)
+           : threads == 128 ? t128::lds_hessian_doubles(ldsDoubles, n)
+                            : t256::lds_hessian_doubles(ldsDoubles, n);
   };
   // (rows resident in LDS: the one-wave kernels round a boundary below 64 rows to a multiple of 8, see hess_pass.h)
   auto resident = [](const int threads, const int n, const int64_t hld) {
-    return threads == 64 ? t64::resident_rows(n, hld) : t256::resident_rows(n, hld);
+    return threads == 64 ? t64::resident_rows(n, hld) : threads == 128 ? t128::resident_rows(n, hld) : t256::resident_rows(n, hld);
   };
   const size_t kFull = bin_budget(nBins - 1);
   // NVMK_BFGS_LDS: "auto" (default) = the bins above; "full" = every system gets the whole 160 KiB (one workgroup per CU);
@@ -319,7 +351,9 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
   const bool waveClass = !opt::get(opt::kBfgsWave).is("0") && b.kind != NVMK_FF_QUARTIC;
   const bool allGlobal = opt::get(opt::kBfgsVectors).is("global");
   const bool overlap   = !opt::get(opt::kBfgsOverlap).is("0");
-  auto       budget_of = [&](const int c) { return (c == 0 || c == kFirst256) ? std::max(firstBudget, bin_budget(c)) : bin_budget(c); };
+  auto       budget_of = [&](const int c) {
+    return (c == 0 || c == kFirst128 || c == kFirst256) ? std::max(firstBudget, bin_budget(c)) : bin_budget(c);
+  };
   const int  kGlobal   = nBins;  // class index of the HBM-vector systems
 
   // ---- size classes
@@ -327,7 +361,7 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
     std::vector<int32_t> order;  // systems, largest first (stable)
     int                  maxN = 0;
   };
-  Class cls[9];
+  Class cls[13];
   for (int s = 0; s < b.nSystems; ++s) {
     const int64_t n64 = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
     NVMK_REQUIRE(n64 >= 0, "bfgs: atom_starts must be non-decreasing");
@@ -336,8 +370,9 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
     int c = kGlobal;
     if (!allGlobal) {
       // thread count by size alone, then the bin by the LDS policy
-      const bool wave = waveClass && n64 <= kWaveMaxN;
-      const int  lo = wave ? 0 : kFirst256, hi = wave ? kFirst256 : nBins;
+      const bool wave  = waveClass && n64 <= kWaveMaxN;
+      const bool wave2 = !wave && waveClass && n64 <= kWave2MaxN;
+      const int  lo = wave ? 0 : wave2 ? kFirst128 : kFirst256, hi = wave ? kFirst128 : wave2 ? kFirst256 : nBins;
       for (int k = fullOnly ? hi - 1 : lo; k < hi; ++k)
         if (n64 <= kBins[k].maxN && static_cast<size_t>(vec_doubles(kBins[k].threads, n64)) * sizeof(double) <= budget_of(k)) {
           c = k;
@@ -398,8 +433,8 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
     std::vector<int64_t> hs;  // one-system-per-workgroup bins: per-system offsets (indexed by system), else empty
     StreamScratch        hessMem, startsMem, orderMem, counterMem, vecMem;
   };
-  Plan   plan[9];
-  size_t slotBytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Plan   plan[13];
+  size_t slotBytes[13] = {};
   for (int c = 0; c <= kGlobal; ++c) {
     Plan& P = plan[c];
     if (cls[c].order.empty()) continue;
@@ -492,6 +527,12 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
     A.w1          = w1;
     A.maxIters    = max_iters;
     A.restarts    = restarts;
+    A.w0b         = second ? second->w0 : 0.0;
+    A.w1b         = second ? second->w1 : 0.0;
+    A.maxItersB   = second ? second->max_iters : -1;
+    A.restartsB   = second ? second->restarts : 0;
+    A.posMid      = second ? second->d_pos_between : nullptr;
+    A.skipAbove   = second ? second->skip_above_energy_per_atom : -1.0;
     A.gradTol     = grad_tol;
     A.scaleGrads  = scale_grads;
     A.active      = d_active;
@@ -525,6 +566,11 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
         if (b.kind == NVMK_FF_ETK) return go(t64::bfgs_kernel<NVMK_FF_ETK, false, true>);
         return go(t64::bfgs_kernel<NVMK_FF_MMFF, false, true>);
       }
+      if (P.threads == 128) {
+        if (b.kind == NVMK_FF_DG) return go(t128::bfgs_kernel<NVMK_FF_DG, false, true>);
+        if (b.kind == NVMK_FF_ETK) return go(t128::bfgs_kernel<NVMK_FF_ETK, false, true>);
+        return go(t128::bfgs_kernel<NVMK_FF_MMFF, false, true>);
+      }
       if (b.kind == NVMK_FF_DG) return go(t256::bfgs_kernel<NVMK_FF_DG, false, true>);
       if (b.kind == NVMK_FF_ETK) return go(t256::bfgs_kernel<NVMK_FF_ETK, false, true>);
       return go(t256::bfgs_kernel<NVMK_FF_MMFF, false, true>);
@@ -534,6 +580,8 @@ int nvmk_bfgs_minimize_repeat(const nvmk_ff_batch* batch, const int32_t* h_atom_
       NVMK_FF_DISPATCH(b.kind, r = go(t256::bfgs_kernel<K, true>));
     } else if (P.threads == 64) {
       NVMK_FF_DISPATCH(b.kind, r = go(t64::bfgs_kernel<K, false>));
+    } else if (P.threads == 128) {
+      NVMK_FF_DISPATCH(b.kind, r = go(t128::bfgs_kernel<K, false>));
     } else {
       NVMK_FF_DISPATCH(b.kind, r = go(t256::bfgs_kernel<K, false>));
     }

@@ -20,7 +20,8 @@ enum Id {
   kBfgsProfile,     // NVMK_BFGS_PROFILE     1
   kBfgsVectors,     // NVMK_BFGS_VECTORS     auto | global (tests: every system through the HBM-vector kernels)
   kBfgsOverlap,     // NVMK_BFGS_OVERLAP     1 | 0 (0: size classes run one after the other on the caller's stream)
-  kBfgsWave,        // NVMK_BFGS_WAVE        1 | 0 (0: four waves for every system, none minimised by a single wave)
+  kBfgsWave,        // NVMK_BFGS_WAVE        1 | 0 | n (0: four waves for every system; n: largest system one wave takes)
+  kBfgsWave2,       // NVMK_BFGS_WAVE2       n (largest system, in coordinates, that two waves take; 0: none)
   kNumOptions
 };
 

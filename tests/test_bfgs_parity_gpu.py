@@ -245,3 +245,42 @@ def test_restarts_inside_the_launch_equal_repeated_calls(kind):
         active = (ran & (st != 0)).to(torch.uint8)
     assert torch.equal(one, many) and torch.equal(e1, e2) and torch.equal(st1, st2) and torch.equal(it1, it2)
     assert (st1 != 0).any()  # (seven iterations four times over are not enough for the larger ones)
+
+
+def test_two_stages_in_one_launch_equal_two_calls():
+    """nvmk_bfgs_minimize_two_stages (ETKDG's first minimisation and its fourth-dimension stage in one launch): every system's
+    coordinates in between and at the end, energies, statuses and iterations are those of two separate calls; a system beyond
+    the energy limit keeps what the first stage left."""
+    import ctypes
+
+    sizes = [12, 30, 44, 50, 60, 70, 90, 130]
+    systems = systems_of(DG, sizes, 1700)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(DG, systems)
+    gpu = FlatForcefieldBatch(DG, a_s, groups)
+    n_sys = len(sizes)
+    two = torch.from_numpy(flat).cuda()
+    e1, st1, it1 = gpu.minimize(two, max_iters=9, grad_tol=1e-3, w0=1.0, w1=0.1, restarts=2)
+    between = two.clone()
+    e2, st2, it2 = gpu.minimize(two, max_iters=6, grad_tol=1e-3, w0=0.2, w1=1.0, restarts=1)
+    limit = float(np.median((e1 / torch.from_numpy(np.diff(a_s)).cuda()).cpu().numpy()))  # half of the systems skip stage two
+    skip = (e1 / torch.from_numpy(np.diff(a_s)).cuda() > limit).cpu().numpy()
+    assert skip.any() and not skip.all()
+
+    pos = torch.from_numpy(flat).cuda()
+    mid = torch.zeros_like(pos)
+    energies = torch.zeros(n_sys, dtype=torch.float64, device="cuda")
+    statuses = torch.zeros(n_sys, dtype=torch.int16, device="cuda")
+    iters = torch.zeros(n_sys, dtype=torch.int32, device="cuda")
+    second = _native.BfgsSecondStage(0.2, 1.0, 6, 1, mid.data_ptr(), limit)
+    rc = _native.lib().nvmk_bfgs_minimize_two_stages(ctypes.byref(gpu._c), gpu.atom_starts_host.ctypes.data, 1.0, 0.1, 9, 2,
+                                                      ctypes.byref(second), 1e-3, 1, pos.data_ptr(), None, energies.data_ptr(),
+                                                      statuses.data_ptr(), iters.data_ptr(), None)
+    _native.check(rc, "nvmk_bfgs_minimize_two_stages")
+    torch.cuda.synchronize()
+    assert torch.equal(mid, between)
+    dim = gpu.dim
+    for s in range(n_sys):
+        lo, hi = a_s[s] * dim, a_s[s + 1] * dim
+        want_pos, want = (between, (e1, st1, it1)) if skip[s] else (two, (e2, st2, it2))
+        assert torch.equal(pos[lo:hi], want_pos[lo:hi]), s
+        assert float(energies[s]) == float(want[0][s]) and int(statuses[s]) == int(want[1][s]) and int(iters[s]) == int(want[2][s]), s

@@ -2,7 +2,7 @@
 # Round 3, call 17: one-wave H pass with rows 0..63 two at a time.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$ROOT/gpurun_out/${1:-r03_call17}
+O=$ROOT/gpurun_out/${1:-r03_call23}
 mkdir -p $O
 cd $ROOT
 ( timeout 900 python -m pytest tests/test_bfgs_parity_gpu.py tests/test_forcefield_gpu.py tests/test_etkdg_gpu.py tests/test_constraints.py -m gpu -q ) > $O/pytest.log 2>&1
