@@ -284,3 +284,25 @@ def test_two_stages_in_one_launch_equal_two_calls():
         want_pos, want = (between, (e1, st1, it1)) if skip[s] else (two, (e2, st2, it2))
         assert torch.equal(pos[lo:hi], want_pos[lo:hi]), s
         assert float(energies[s]) == float(want[0][s]) and int(statuses[s]) == int(want[1][s]) and int(iters[s]) == int(want[2][s]), s
+
+
+@pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
+def test_trajectory_still_matches_oracle_after_30_iterations(kind):
+    """Three times deeper than the 10-iteration comparison: after 30 BFGS iterations from H = I the
+    iterates of the kernel and of the C oracle still agree to 1e-5 for every system — measured 2e-7 (DG), 1e-8 (ETK), 1e-9
+    (MMFF) — except that last-digit differences may by then have sent ONE system of a kind through another branch of a
+    line search (seen for one 48-atom UFF system); from 60 iterations on the two runs are different, equally valid,
+    minimisations (tools/probe_trajectory_depth.py prints the whole table)."""
+    systems = systems_of(kind, SIZES, 500 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    cpu = ffc.Batch(kind, a_s, groups)
+    w0, w1 = W[kind]
+    pos = torch.from_numpy(flat).cuda()
+    e, st, it = gpu.minimize(pos, max_iters=30, grad_tol=1e-14, w0=w0, w1=w1)
+    x, ec, stc, itc = cpu.minimize(flat, max_iters=30, grad_tol=1e-14, w0=w0, w1=w1)
+    assert np.array_equal(it.cpu().numpy(), itc)
+    got = pos.cpu().numpy()
+    dev = np.array([np.max(np.abs(got[a_s[s] * gpu.dim:a_s[s + 1] * gpu.dim] - x[a_s[s] * gpu.dim:a_s[s + 1] * gpu.dim]))
+                    for s in range(len(SIZES))])
+    assert (dev <= 1e-5).sum() >= len(SIZES) - 1, dev

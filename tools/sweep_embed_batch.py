@@ -23,7 +23,7 @@ molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library])
 tables = mmffOptimization.resident_tables([m["mmff"] for m in library])
 embed_flat(FlatMoleculeSet([FlatMolecule(**library[0]["embed"])]), 1, 5)
 torch.cuda.synchronize()
-for batch, bpg in ((8192, 1), (16384, 1), (24576, 1), (32768, 1), (4096, 2), (8192, 2), (16384, 2), (4096, 3), (8192, 3), (16384, 1)):
+for batch, bpg in ((16384, 1), (8192, 2), (16384, 2), (12288, 2), (24576, 1), (8192, 3), (32768, 2), (16384, 1)):
     t0 = time.perf_counter()
     dev = embed_flat(molset, confs_per_molecule=10, max_iterations=10, batch_size=batch, seed=1, output=CoordinateOutput.DEVICE,
                      batches_per_gpu=bpg)
