@@ -169,7 +169,7 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
                                                                const int64_t nA, const uint4* __restrict__ B,
                                                                const int32_t* __restrict__ popB, const int64_t nB,
                                                                const int Wp, double* __restrict__ out, const int64_t ld,
-                                                               const unsigned tilesM, const unsigned tilesN) {
+                                                               const unsigned tilesM, const unsigned tilesN, const unsigned superM) {
   // One 8-word chunk buffer: load -> barrier -> multiply; the phases of the 4 co-resident workgroups overlap each other
   // (in-workgroup rings, wider tiles and a producer / consumer split were measured slower: tools/experiments/).
   constexpr int KCW = 8;
@@ -191,12 +191,14 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
   // 32 x 16-tile sub-block x of the supertile (2 x 4 sub-blocks) and walks it with tile_n fastest.  Its L2 then holds the
   // sub-block's 16 B tiles (2 MB, reused 32 times) and the current A tile: (32 + 16) tile loads per XCD and supertile
   // instead of (64 + 8) with the XCDs interleaved over tile_n — a third less traffic from the L2s into the fabric.
+  // With 128 or more tile rows in the launch (16 384-row chunks) the supertile is 128 tiles tall (superM) and an XCD owns
+  // 64 x 16 tiles: its 16 B tiles are then reused 64 times, (64 + 16) tile loads per 1024 tiles instead of (32 + 16) per 512.
   const unsigned superN = (tilesN + SUPER - 1) / SUPER;
   const unsigned sm     = blockIdx.y / superN;
   const unsigned sn     = blockIdx.y - sm * superN;
   const unsigned xcd    = blockIdx.x & 7u;
-  const unsigned local  = blockIdx.x >> 3;  // 0 .. 511 inside the XCD's sub-block
-  const unsigned tile_m = sm * SUPER + (xcd >> 2) * 32u + (local >> 4);
+  const unsigned local  = blockIdx.x >> 3;  // 0 .. 8 superM - 1 inside the XCD's sub-block
+  const unsigned tile_m = sm * superM + (xcd >> 2) * (superM >> 1) + (local >> 4);
   const unsigned tile_n = sn * SUPER + (xcd & 3u) * 16u + (local & 15u);
   if (tile_m >= tilesM || tile_n >= tilesN) return;
 
@@ -645,10 +647,10 @@ int prepare(const uint32_t* d_in, const int32_t* d_rows, int64_t n, int fpBits, 
 
 template <int METRIC>
 int launch_dense_t(const Prepared& A, const Prepared& B, double* out, int64_t ld, dim3 grid, unsigned tilesM,
-                   unsigned tilesN, hipStream_t stream) {
+                   unsigned tilesN, unsigned superM, hipStream_t stream) {
   const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + (TM + TN) * 4;
   hipLaunchKernelGGL(cross_sim_mfma_kernel<METRIC>, grid, dim3(NT), shmem, stream, A.rows, A.popc, A.L.n, B.rows, B.popc,
-                     B.L.n, A.L.Wp, out, ld, tilesM, tilesN);
+                     B.L.n, A.L.Wp, out, ld, tilesM, tilesN, superM);
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }
@@ -662,13 +664,14 @@ int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, 
   NVMK_REQUIRE(A.L.W * 32 < (1 << 24), "cross similarity: fingerprints too wide for the matrix-core path");
   const int64_t tilesM = ceil_div<int64_t>(A.L.n, TM);
   const int64_t tilesN = ceil_div<int64_t>(B.L.n, TN);
-  const int64_t supers = ceil_div<int64_t>(tilesM, SUPER) * ceil_div<int64_t>(tilesN, SUPER);
+  const int64_t superM = tilesM >= 2 * SUPER ? 2 * SUPER : SUPER;  // supertile height in tiles (see the kernel's tile map)
+  const int64_t supers = ceil_div<int64_t>(tilesM, superM) * ceil_div<int64_t>(tilesN, SUPER);
   NVMK_REQUIRE(supers <= 65535, "cross similarity: problem too large for one launch (%lld x %lld tiles)",
                (long long)tilesM, (long long)tilesN);
-  const dim3     grid(static_cast<unsigned>(SUPER * SUPER), static_cast<unsigned>(supers));
-  const unsigned tm = static_cast<unsigned>(tilesM), tn = static_cast<unsigned>(tilesN);
-  if (metric == NVMK_METRIC_TANIMOTO) return launch_dense_t<NVMK_METRIC_TANIMOTO>(A, B, out, ld, grid, tm, tn, stream);
-  return launch_dense_t<NVMK_METRIC_COSINE>(A, B, out, ld, grid, tm, tn, stream);
+  const dim3     grid(static_cast<unsigned>(superM * SUPER), static_cast<unsigned>(supers));
+  const unsigned tm = static_cast<unsigned>(tilesM), tn = static_cast<unsigned>(tilesN), sM = static_cast<unsigned>(superM);
+  if (metric == NVMK_METRIC_TANIMOTO) return launch_dense_t<NVMK_METRIC_TANIMOTO>(A, B, out, ld, grid, tm, tn, sM, stream);
+  return launch_dense_t<NVMK_METRIC_COSINE>(A, B, out, ld, grid, tm, tn, sM, stream);
 }
 
 int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int32_t* counts, hipStream_t stream) {
