@@ -9,11 +9,13 @@
 // at most 1000 steps), TOLX = 1.2e-7, BFGS update guarded by fac^2 > EPS |dg|^2 |xi|^2 with EPS = 3e-8
 // (bfgs_minimize_permol_kernels.cu:29-33, :304-407).
 //
-// MI355X design: one 256-thread workgroup per system; positions, gradient, direction, trial positions and
-// gradient difference live in LDS for the whole minimisation; all arithmetic is fp64; term tables are read
-// straight from HBM/L2 (they are shared by the conformers of a molecule); the inverse Hessian is the only
-// per-system state in HBM.  Term loops are thread-strided over a generic table layout (see nvmolkit_amd.h):
-// every term group is {CSR starts, interleaved local atom indices, interleaved double parameters}.
+// MI355X design: one workgroup per system — ONE wave for small systems, two or four for larger ones (the device code,
+// bfgs_device.inc, is compiled once per workgroup size); positions, gradient, direction, trial positions and gradient
+// difference live in LDS for the whole minimisation; all arithmetic is fp64; term tables are read straight from HBM/L2
+// (they are shared by the conformers of a molecule); the inverse Hessian is the only per-system state in HBM.  Term loops
+// are thread-strided over a generic table layout (see nvmolkit_amd.h): every term group is {CSR starts, interleaved local
+// atom indices, interleaved double parameters}.  This file holds what is common to the workgroup sizes and the host side
+// (size classes, launches).
 #include <algorithm>
 #include <vector>
 
@@ -71,13 +73,13 @@ constexpr int    MAX_LS_ITERS  = 1000;
 // 4 whole kernel, 5 iterations, 6 energy evaluations.
 //
 // Size classes (the reference switches between shared and global memory per launch, bfgs_minimize_permol_kernels.cu:796-932,
-// bfgs_types.h:36-43; here every launch is split by what a system's 17 n-vectors need):
-//   class A  vectors <= half the LDS of a CU: one workgroup per system, two workgroups per CU, per-system inverse Hessians;
-//   class B  vectors <= the whole LDS: one workgroup per CU;
-//   class C  anything larger (GVEC): the vectors live in a per-workgroup HBM / L2 work area, any size.
-// Classes B and C run as persistent workgroups that take systems off a counter (largest first) and keep ONE inverse-Hessian
-// slot each, so the memory a launch needs is bounded by the workgroups in flight, not by the number of large systems
-// (a 1000-atom 4-D system has a 64 MB triangle).
+// bfgs_types.h:36-43; here every launch is split by size, nvmk_bfgs_minimize_two_stages below):
+//   one wave per system up to 176 coordinates (eight per CU), two waves up to 256 (four per CU), four waves beyond —
+//   vectors in LDS while they fit half (two workgroups per CU) or all of it (one), else (GVEC) in a per-workgroup HBM / L2
+//   work area, any size.
+// The one-workgroup-per-CU and the GVEC classes run as persistent workgroups that take systems off a counter (largest
+// first) and keep ONE inverse-Hessian slot each, so the memory a launch needs is bounded by the workgroups in flight, not by
+// the number of large systems (a 1000-atom 4-D system has a 64 MB triangle).
 struct BfgsArgs {
   double*                         positions;
   double                          w0, w1;
@@ -193,7 +195,7 @@ namespace {
 std::atomic<unsigned long long*> g_stats{nullptr};
 
 // Highest-priority streams + their fork / join events per (host thread, device), created on first use and kept: the
-// large size classes of a minimisation run on them next to class A on the caller's stream.
+// larger size classes of a minimisation run on them next to the smallest one on the caller's stream.
 struct SideStreams {
   static constexpr int kStreams = 6;
   hipStream_t          s[kStreams]    = {};
