@@ -1052,7 +1052,10 @@ __global__ __launch_bounds__(NT) void par_subtract_kernel(const ParArgs a, const
 __global__ __launch_bounds__(LNT) void par_finish_kernel(const ParArgs a, int p) {
   if (a.st->done || a.st->curDegree < 2) return;
   const int group = threadIdx.x / PG, nGroups = LNT / PG, l = threadIdx.x % PG;
-  for (;;) {
+  // every sweep decides at least the first undecided candidate, so nCand sweeps are an upper bound; the cap only keeps a bug
+  // from spinning on the GPU box (an unfinished bucket then shows up as an accounting error on the host)
+  const int maxSweeps = a.st->nCand + 2;
+  for (int sweep = 0; sweep < maxSweeps; ++sweep) {
     if (ldc(&a.st->nU[p]) == 0) break;
     par_mark<true>(a, false, p, group, nGroups, l);
     __threadfence();
