@@ -336,7 +336,23 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
         c1 = time.perf_counter()
         _, _, st_c, it_c = batch.minimize(pos, max_iters=mmff_iters)
         c_mmff = time.perf_counter() - c1
+        # the same port on ONE thread, on the first two molecules (all-thread and one-thread numbers)
+        one = None
+        try:
+            oracle.set_num_threads(1)
+            m1 = min(2, m)
+            o0 = time.perf_counter()
+            coords1, counts1, slots1, _, _ = ffc.etkdg_embed(mols[:m1], confs_per_molecule=confs, max_iterations=10, seed=1)
+            sys1 = np.repeat(np.arange(m1), counts1).astype(np.int32)
+            as1 = np.concatenate([[0], np.cumsum(n_at[sys1])])
+            pos1 = np.concatenate([coords1[slots1[i]:slots1[i] + 3 * n_at[i] * counts1[i]] for i in range(m1)])
+            ffc.Batch(KIND_MMFF, as1, stack_molecule_tables(KIND_MMFF, [x["mmff"] for x in sub[:m1]]), system_mol=sys1).minimize(pos1, max_iters=mmff_iters)
+            one = {"value": m1 / (time.perf_counter() - o0), "molecules": m1}
+        finally:
+            oracle.set_num_threads(0)
         out["cpu_baseline"] = {"value": m / (c_embed + c_mmff), "unit": "mols/s", "cores": threads, "kind": "port",
+                               "one_thread_value": one["value"] if one else None,
+                               "one_thread_sample": f"first {one['molecules']} molecules x {confs} conformers" if one else None,
                                "etkdg_seconds": c_embed, "mmff_seconds": c_mmff, "conformers": int(counts.sum()),
                                "mmff_converged_fraction": float((st_c == 0).mean()),
                                "sample": f"first {m} molecules of the same set x {confs} conformers, oracle/oracle_ff.c "

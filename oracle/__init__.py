@@ -67,6 +67,8 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 def _declare(L: ctypes.CDLL) -> None:
     L.orc_num_threads.restype = ctypes.c_int
+    L.orc_set_num_threads.argtypes = [ctypes.c_int]
+    L.orc_set_num_threads.restype = None
     L.orc_cross_similarity_f64.argtypes = [ctypes.c_int, _u32p, ctypes.c_int64, _u32p, ctypes.c_int64, ctypes.c_int,
                                            _f64p, ctypes.c_int64, ctypes.c_int]
     L.orc_cross_similarity_f64.restype = None
@@ -113,6 +115,11 @@ def _as_u32(x) -> np.ndarray:
 
 def num_threads() -> int:
     return int(lib().orc_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    """Threads of the oracle's OpenMP regions from now on (<= 0: all processors)."""
+    lib().orc_set_num_threads(int(n))
 
 
 def cross_similarity(a, b=None, metric: int = TANIMOTO, threads: int = 0) -> np.ndarray:

@@ -62,6 +62,15 @@ static inline double finish_f64(int metric, int c, int pa, int pb) {
   return (c == 0 || denom == 0.0) ? 0.0 : (double)c / denom;
 }
 
+/* threads of the OpenMP regions of every oracle_*.c from now on (<= 0: all processors) — bench.py's one-thread baselines */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
