@@ -238,7 +238,7 @@ def conformer_library(n_mols: int, world: int, rank: int):
 
 
 def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int, rank: int, cpu_seconds: float,
-                    library=None, t_library: float = 0.0) -> dict:
+                    library=None, t_library: float = 0.0, collectives: bool = False) -> dict:
     """BASELINE.json configs[2] (and [3] when world > 1: every rank embeds and optimises its own n_mols molecules, no
     data-path collective): ETKDG (`confs` conformers per molecule) DEVICE-chained into MMFF94 on the synthetic drug-like
     set of nvmolkit_amd/synthetic.py.  Roofline = the fused BFGS kernels' inverse-Hessian traffic."""
@@ -257,7 +257,7 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     embed_flat(FlatMoleculeSet([FlatMolecule(**library[0]["embed"])], device=device), 1, 5)  # warm-up: module load, pools
     stats = torch.zeros(64, dtype=torch.int64, device=device)
     _native.check(lib.nvmk_bfgs_set_stats(stats.data_ptr()))
-    if world > 1:
+    if collectives:
         import torch.distributed as dist
 
         dist.barrier()
@@ -274,7 +274,7 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     _native.check(lib.nvmk_bfgs_set_stats(None))
     n_conf = dev.num_conformers
     converged = int(opt.converged.torch().sum().item())
-    if world > 1:
+    if collectives:
         t = torch.tensor([wall, t_embed, t_mmff], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         c = torch.tensor([n_conf, converged, n_mols], dtype=torch.int64, device=device)
@@ -394,7 +394,9 @@ def main() -> None:
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    distributed = world > 1
+    # NVMK_BENCH_SINGLE_RANK_COLLECTIVES=1 under torch.distributed.run with one rank walks the multi-rank code (RCCL init,
+    # all-gather of the reference block, the max / sum all-reduces) on a one-GPU box; the numbers equal the plain run's
+    distributed = world > 1 or os.environ.get("NVMK_BENCH_SINGLE_RANK_COLLECTIVES") == "1"
     library, t_library = None, 0.0
     if distributed and args.conformer_mols > 0:
         # the generator forks worker processes: under torchrun that happens before this process holds a HIP context and
@@ -590,12 +592,12 @@ def main() -> None:
     if args.conformer_mols > 0:  # every rank takes part (configs[3]: molecules sharded, no collective on the data path)
         out = queries = ref_gathered = ref_shard = ws_q = ws_r = None  # noqa: F841  (release ~70 GB before the next block)
         torch.cuda.empty_cache()
-        if world == 1:
+        if not distributed:
             guarded("conformers", conformer_block, args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank,
                     args.cpu_seconds)
         else:  # ranks meet in collectives inside the block: an exception on one rank must end the job, not hang the others
             block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds,
-                                    library, t_library)
+                                    library, t_library, collectives=True)
             if rank == 0:
                 secondary["conformers"] = block
     if rank == 0:
