@@ -176,8 +176,12 @@ def test_etkdg_pipeline_matches_oracle_pipeline_statistically():
     mols = [FlatMolecule(**m["embed"]) for m in lib]
     gpu = embed_flat(FlatMoleculeSet(mols), confs_per_molecule=4, max_iterations=10, seed=3)
     coords, counts, slots, fails, _ = ffc.etkdg_embed(mols, confs_per_molecule=4, max_iterations=10, seed=3, batch_size=4096)
-    assert abs(int(gpu.conf_counts.sum()) - int(counts.sum())) <= 0.03 * counts.sum()
-    assert np.all(np.abs(gpu.stage_failures - fails) <= np.maximum(4, 0.35 * np.maximum(gpu.stage_failures, fails)))
+    # (tools/etkdg_population_parity.py on 1500 molecules: 5860 conformers on both sides, every molecule with the same count,
+    # stage failures [0 23 458 0 0 0 1 0 5 0 0] against [0 23 459 0 0 0 1 0 6 0 0], Kolmogorov-Smirnov distance of the
+    # violation distributions 0.009 — profiles/r03_conformers/etkdg_population_parity.json)
+    assert abs(int(gpu.conf_counts.sum()) - int(counts.sum())) <= 0.01 * counts.sum()
+    assert np.mean(np.asarray(gpu.conf_counts) == np.asarray(counts)) >= 0.97
+    assert np.all(np.abs(gpu.stage_failures - fails) <= np.maximum(2, 0.15 * np.maximum(gpu.stage_failures, fails)))
     # Geometry: both sides start every attempt from the same coordinates, but 200-400 iteration minimisations on a
     # multi-minimum landscape amplify last-digit differences into different (equally valid) embeddings — measured: the
     # inter-atomic distances of the first conformers agree to 1e-2 A for 1 molecule in 95.  So the populations are compared:
