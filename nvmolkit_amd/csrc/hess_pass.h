@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #ifndef NVMK_BFGS_NS
 #define NVMK_BFGS_NS t256
@@ -59,7 +60,9 @@ __host__ __device__ __forceinline__ int resident_rows(const int n, const int64_t
   if (hess_row_offset(n) <= hldsDoubles) return n;
   int r = 0;
   while (r < n && hess_row_offset(r + 1) <= hldsDoubles) ++r;
-  if (NW == 1 && r < 64) r &= ~7;  // one-wave workgroups walk rows 0..63 in groups of eight that are all LDS or all HBM (hess_packed)
+  // one-wave workgroups walk rows 0..63 in groups of eight that are all LDS or all HBM (hess_packed) and start every later
+  // group of four on an even row (hess_range)
+  if (NW == 1) r &= r < 64 ? ~7 : ~1;
   return r;
 }
 // LDS layout of bfgs_kernel: 10 vectors (the 10th is the diagonal of the inverse Hessian) + (1 + NW) partial-sum slabs of n
@@ -117,12 +120,24 @@ struct HessChunk {
   double g0, g1, xs0, xs1, hs0, hs1, us0, us1;
 };
 
+// rowsum[i] += v by the row's single writer.  Sums in LDS (every class but the HBM-vector one): one ds_add_f64 — no read, no
+// wait for it — which rounds exactly like the read / add / write it replaces.
+template <bool LDS_SUMS> __device__ __forceinline__ void add_to_sum(double* __restrict__ sum, const double v) {
+  if constexpr (LDS_SUMS) {
+    __hip_atomic_fetch_add(sum, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    *sum += v;
+  }
+}
+
 // Rows [rFrom, rEnd) of NCH adjacent column chunks; the matrix row `rBase` starts at H (LDS or HBM: the address space is
 // known at the call).  With PREFETCH (HBM rows) the NEXT group's matrix pairs are requested before the current group is
 // worked on — ahead of the current group's stores, so waiting for them does not wait for the stores (vmcnt is in-order).
 // The wave index is scalar: row numbers, row offsets and the branches on them live on the scalar unit.
 // col[k][0..1] (mirrored-entry sums of the lane's columns) are carried by the caller across ranges.
-template <int NCH, bool PREFETCH>
+// Groups of four rows that lie entirely inside the range take a copy of the group code without the per-row range tests; the
+// last, partial group takes the one with them.
+template <int NCH, bool PREFETCH, bool LDS_SUMS>
 __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBase, const int rFrom, const int rEnd, const int wave,
                                            const int lane, const HessChunk (&ck)[NCH], const bool pending,
                                            const double* __restrict__ xi, const double* __restrict__ hdg,
@@ -130,60 +145,46 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
                                            double (&col)[NCH][2]) {
   constexpr int RU   = 4;
   const int     base = hess_row_offset32(rBase);
-  auto row_ptr = [&](const int r) -> double* { return H + (hess_row_offset32(r) - base); };
-  auto load_group = [&](const int r0, double2 (&dst)[RU][NCH]) {
+  auto entry = [&](const int r, const int c0) -> double* { return H + (hess_row_offset32(r) - base) + c0; };
+  auto load_group = [&](const int r0, double2 (&dst)[RU][NCH], auto fullTag) {
+    constexpr bool FULL = decltype(fullTag)::value;
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-      const int r = min(r0 + NW * u, rEnd - 1);  // rows past the range re-read the last one (never used)
+      const int r = FULL ? r0 + NW * u : min(r0 + NW * u, rEnd - 1);  // rows past the range re-read the last one (never used)
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) dst[u][k] = *reinterpret_cast<const double2*>(row_ptr(r) + ck[k].c0);  // unconditional
+      for (int k = 0; k < NCH; ++k) dst[u][k] = *reinterpret_cast<const double2*>(entry(r, ck[k].c0));  // unconditional
     }
   };
-  int     r0 = rFrom + ((wave - rFrom) % NW + NW) % NW;  // first row of this wave at or after rFrom
-  double2 next[RU][NCH];
-  if constexpr (PREFETCH) {
-    if (r0 < rEnd) load_group(r0, next);
-  }
-  for (; r0 < rEnd; r0 += NW * RU) {
-    double2 hv[RU][NCH];
-    if constexpr (PREFETCH) {
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) hv[u][k] = next[u][k];
-      }
-      if (r0 + NW * RU < rEnd) load_group(r0 + NW * RU, next);
-    } else {
-      load_group(r0, hv);
-    }
-    // the row this LANE will write the sum of (lane & 3 selects it, see wave_sum4_transposed) and its running sum
-    const int    myRow = r0 + NW * (lane & 3);
-    const double rold  = (lane < 4 && myRow < rEnd) ? rowsum[myRow] : 0.0;
-    double       gr[RU], xr[RU], hr[RU], ur[RU], rs[RU];
+  auto work = [&](const int r0, const double2 (&hv)[RU][NCH], auto fullTag) {
+    constexpr bool FULL = decltype(fullTag)::value;
+    // the rows' coefficients: ONE address per vector and constant offsets (paired LDS reads).  Rows past rEnd read whatever
+    // follows in the vector block (every vector is followed by another one) and are never used.
+    double        gr[RU], xr[RU], hr[RU], ur[RU], rs[RU];
+    const double *gp = g + r0, *xp = xi + r0, *hp = hdg + r0, *up = uu + r0;
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-      const int rc = min(r0 + NW * u, rEnd - 1);
-      gr[u]        = g[rc];
-      xr[u]        = xi[rc];
-      hr[u]        = hdg[rc];
-      ur[u]        = uu[rc];
+      gr[u] = gp[NW * u];
+      xr[u] = xp[NW * u];
+      hr[u] = hp[NW * u];
+      ur[u] = up[NW * u];
     }
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
       const int r = r0 + NW * u;
       rs[u]       = 0.0;
-      if (r < rEnd) {  // wave-uniform
+      if (FULL || r < rEnd) {  // wave-uniform
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
           const int c0 = ck[k].c0;
           if (c0 < r) {  // ONE predicated region per row and chunk: the lanes that hold entries of this row
-            double2    h   = hv[u][k];
-            const bool two = c0 + 1 < r;  // false only for the lane holding the pad of an odd-length row
+            double2 h = hv[u][k];
             if (pending) {
               h.x += xr[u] * ck[k].xs0 - hr[u] * ck[k].hs0 + ur[u] * ck[k].us0;
               const double y = h.y + (xr[u] * ck[k].xs1 - hr[u] * ck[k].hs1 + ur[u] * ck[k].us1);
-              h.y            = two ? y : 0.0;  // the pad entry stays 0
-              *reinterpret_cast<double2*>(row_ptr(r) + c0) = h;
+              // the pad entry of an odd-length row stays 0 (its lane: c0 + 1 == r).  One-wave workgroups start their groups
+              // on even rows (hess_pass), so every other row of a group has an even length and no pad at all.
+              h.y = (NW == 1 && (u & 1) == 0) ? y : (c0 + 1 < r ? y : 0.0);
+              *reinterpret_cast<double2*>(entry(r, c0)) = h;
             }
             col[k][0] += h.x * gr[u];  // every stored entry is strictly below the diagonal: it has a mirror image
             col[k][1] += h.y * gr[u];
@@ -192,8 +193,39 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
         }
       }
     }
-    const double tot = wave_sum4_transposed(rs, lane);
-    if (lane < 4 && myRow < rEnd) rowsum[myRow] = rold + tot;  // one writer per row (this wave), column super-chunks in order
+    // the row this LANE adds the sum of (lane & 3 selects it, see wave_sum4_transposed): one writer per row (this wave),
+    // column super-chunks in order
+    const double tot   = wave_sum4_transposed(rs, lane);
+    const int    myRow = r0 + NW * (lane & 3);
+    if (lane < 4 && (FULL || myRow < rEnd)) add_to_sum<LDS_SUMS>(rowsum + myRow, tot);
+  };
+  int           r0   = rFrom + ((wave - rFrom) % NW + NW) % NW;  // first row of this wave at or after rFrom
+  constexpr int STEP = NW * RU;
+  if constexpr (PREFETCH) {
+    double2 next[RU][NCH];
+    if (r0 < rEnd) load_group(r0, next, std::false_type{});
+    for (; r0 + NW * (RU - 1) < rEnd; r0 += STEP) {
+      double2 hv[RU][NCH];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) hv[u][k] = next[u][k];
+      }
+      if (r0 + STEP < rEnd) load_group(r0 + STEP, next, std::false_type{});
+      work(r0, hv, std::true_type{});
+    }
+    if (r0 < rEnd) work(r0, next, std::false_type{});
+  } else {
+    for (; r0 + NW * (RU - 1) < rEnd; r0 += STEP) {
+      double2 hv[RU][NCH];
+      load_group(r0, hv, std::true_type{});
+      work(r0, hv, std::true_type{});
+    }
+    if (r0 < rEnd) {
+      double2 hv[RU][NCH];
+      load_group(r0, hv, std::false_type{});
+      work(r0, hv, std::false_type{});
+    }
   }
 }
 
@@ -202,7 +234,7 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
 // lane & 31 = the same pair of columns in both halves, four such row pairs (eight rows) per group.  Row sums are reduced
 // inside each half (wave_sum4_transposed without its last step), the mirrored-entry sums of the two halves are folded into
 // colOut[0..1] of lanes 0..31 at the end.  Halves the instructions these rows cost (a third of the rows at n = 144).
-template <bool PREFETCH>
+template <bool PREFETCH, bool LDS_SUMS>
 __device__ __forceinline__ void hess_packed(double* __restrict__ H, const int rBase, const int rFrom, const int rEnd, const int lane,
                                             const HessChunk& ck, const bool pending, const double* __restrict__ xi,
                                             const double* __restrict__ hdg, const double* __restrict__ uu,
@@ -264,7 +296,7 @@ __device__ __forceinline__ void hess_packed(double* __restrict__ H, const int rB
         x            = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);  // x + (lane ^ 16): the half's total
       }
       const int myRow = r0 + 2 * (lane & 1) + half;
-      if ((lane & 31) < 2) rowsum[myRow] += x;  // one writer per row: this wave, once
+      if ((lane & 31) < 2) add_to_sum<LDS_SUMS>(rowsum + myRow, x);  // one writer per row: this wave, once
     }
   }
 }
@@ -302,7 +334,7 @@ template <int NCH> __device__ __forceinline__ void hess_chunk_state(HessChunk (&
 // whose first element is row Rl's).  `part` = row sums [n] then NW slabs [n] of mirrored-entry sums (all written here).
 // PREFETCH: the HBM rows' next group is requested one group ahead (more VGPRs; the microbenchmark can switch it off).
 // Must be entered by the whole workgroup after a barrier (it starts by writing the row sums of the diagonal).
-template <bool PREFETCH = true>
+template <bool PREFETCH = true, bool LDS_SUMS = true>
 __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __restrict__ Hl, double* __restrict__ Hg, const int Rl,
                                           const int n, const bool pending, const double rfac, const double fad, const double fae,
                                           const double* __restrict__ xi, const double* __restrict__ hdg, const double* __restrict__ uu,
@@ -337,8 +369,8 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __r
       // the chunk state of columns 2 (lane & 31), 2 (lane & 31) + 1 — the first 64 columns, in both halves of the wave
       hess_chunk_state<1>(ckp, colp, 0, lane & 31, n, pending, rfac, fad, fae, xi, hdg, uu, g);
       const int split = min(packedRows, Rl);  // a multiple of 8 (resident_rows)
-      if (split > 0) hess_packed<false>(Hl, 0, 0, split, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
-      if (split < packedRows) hess_packed<PREFETCH>(Hg, Rl, split, packedRows, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
+      if (split > 0) hess_packed<false, LDS_SUMS>(Hl, 0, 0, split, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
+      if (split < packedRows) hess_packed<PREFETCH, LDS_SUMS>(Hg, Rl, split, packedRows, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {  // fold the two halves: lanes 0..31 keep the totals of their columns
         const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(colp[0][j]), __double2loint(colp[0][j]), false, false);
@@ -357,17 +389,19 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __r
       col[0][1] = packedCol[1];
     }
     // rows that reach into the first chunk only ([cBase, cBase + 128]) never touch the second one
-    const int mid = min(n, cBase + 129);  // row cBase + 128 is the first with an entry in the second chunk... (c0 < r)
+    // row cBase + 129 is the first with an entry in the second chunk (c0 < r); one-wave workgroups split one row earlier so
+    // that both ranges start on an even row (row cBase + 128 then finds no lane of the second chunk: correct, one idle step)
+    const int mid = min(n, cBase + (NW == 1 ? 128 : 129));
     {
       HessChunk(&ck1)[1]    = reinterpret_cast<HessChunk(&)[1]>(ck[0]);
       double(&col1)[1][2]   = reinterpret_cast<double(&)[1][2]>(col[0]);
       const int lo = max(cBase, packedRows), hi = mid;
-      if (lo < min(hi, Rl)) hess_range<1, false>(Hl, 0, lo, min(hi, Rl), wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
-      if (max(lo, Rl) < hi) hess_range<1, PREFETCH>(Hg, Rl, max(lo, Rl), hi, wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
+      if (lo < min(hi, Rl)) hess_range<1, false, LDS_SUMS>(Hl, 0, lo, min(hi, Rl), wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
+      if (max(lo, Rl) < hi) hess_range<1, PREFETCH, LDS_SUMS>(Hg, Rl, max(lo, Rl), hi, wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
     }
     if (mid < n) {
-      if (mid < Rl) hess_range<2, false>(Hl, 0, mid, Rl, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
-      if (max(mid, Rl) < n) hess_range<2, PREFETCH>(Hg, Rl, max(mid, Rl), n, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
+      if (mid < Rl) hess_range<2, false, LDS_SUMS>(Hl, 0, mid, Rl, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
+      if (max(mid, Rl) < n) hess_range<2, PREFETCH, LDS_SUMS>(Hg, Rl, max(mid, Rl), n, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {  // this wave's mirrored-entry sums of its columns: single writer
