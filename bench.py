@@ -151,7 +151,8 @@ def butina_block(n: int, words: int, device, cpu_seconds: float) -> dict:
                         "frac": flops / tb / 1e12 / 10000.0, "traffic": None,
                         "kernel": "nvmk::fp4::neighbor_count_mfma_kernel (FP4 e2m1 x e2m1 -> f32, exact 0/1 products)",
                         "note": "algorithmic flops = n (n + 1) / 2 pairs x 2 x fp_bits, divided by the WHOLE call's wall time "
-                                "(conservative: the pass is ~60 % of the call); peak = ~10 PF dense FP4 MFMA "
+                                "(conservative: the pass is ~83 % of the call, 0.427 of 0.517 s; the rest is the CSR build, the rounds and the Python "
+                                "lists the API returns); peak = ~10 PF dense FP4 MFMA "
                                 "(MI355X_MICROARCH.md; 9.1 PF measured there)"}}
     out["pairs_per_s"] = pairs / tb
     if cpu_seconds > 0:
