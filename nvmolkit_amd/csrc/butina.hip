@@ -19,6 +19,8 @@
 //     enqueued in batches and the host reads one status word per batch instead of syncing per cluster.
 //   * the fingerprint matrix is never compacted; kernels gather rows through index lists.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include <cstdlib>
@@ -1439,20 +1441,51 @@ inline int read_back(const RoundBuffers& b, const int64_t N, const LoopState& sn
   }
   NVMK_HIP_CHECK(hipStreamSynchronize(stream));
 
-  int64_t pos = 0;
+  // A cluster's entries on the device: the centroid once, somewhere, and its members in the order the atomics fell; on the
+  // host: centroid first, members ascending.  Sizes carry over, so every cluster's place is known up front and the clusters
+  // are copied and sorted by a few host threads (one thread took 35 ms for the 20 183 clusters of the 1M-row benchmark, 7 % of
+  // the call).
   h_offsets[0] = 0;
   for (int64_t k = 0; k < nGreedy; ++k) {
-    const int32_t c    = cent[static_cast<size_t>(k)];
-    int32_t*      dst  = h_idx + pos;
-    int64_t       m    = 0;
-    dst[m++]           = c;
-    for (int32_t q = offs[static_cast<size_t>(k)]; q < offs[static_cast<size_t>(k) + 1]; ++q) {
-      if (idx[static_cast<size_t>(q)] != c) dst[m++] = idx[static_cast<size_t>(q)];
+    h_offsets[k + 1] = h_offsets[k] + (offs[static_cast<size_t>(k) + 1] - offs[static_cast<size_t>(k)]);
+    h_centroids[k]   = cent[static_cast<size_t>(k)];
+  }
+  int64_t pos = nGreedy > 0 ? h_offsets[nGreedy] : 0;
+  {
+    std::atomic<int64_t> next{0};
+    std::atomic<int>     bad{0};
+    constexpr int64_t    kBlock = 128;  // clusters per work item
+    auto                 worker = [&] {
+      for (;;) {
+        const int64_t k0 = next.fetch_add(kBlock);
+        if (k0 >= nGreedy) return;
+        for (int64_t k = k0; k < std::min(nGreedy, k0 + kBlock); ++k) {
+          const int32_t c   = cent[static_cast<size_t>(k)];
+          int32_t*      dst = h_idx + h_offsets[k];
+          int64_t       m   = 0;
+          dst[m++]          = c;
+          const int64_t size = h_offsets[k + 1] - h_offsets[k];
+          for (int32_t q = offs[static_cast<size_t>(k)]; q < offs[static_cast<size_t>(k) + 1]; ++q) {
+            if (idx[static_cast<size_t>(q)] != c && m < size) dst[m++] = idx[static_cast<size_t>(q)];
+          }
+          if (m != size) bad.store(1);  // the centroid missing from its cluster, or there twice
+          std::sort(dst + 1, dst + m);
+        }
+      }
+    };
+    const int64_t items   = (nGreedy + kBlock - 1) / kBlock;
+    const int     threads = static_cast<int>(std::min<int64_t>(items, std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
+    if (threads <= 1) {
+      worker();
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+      for (std::thread& t : pool) t.join();
     }
-    std::sort(dst + 1, dst + m);
-    h_centroids[k] = c;
-    pos += m;
-    h_offsets[k + 1] = pos;
+    if (bad.load() != 0) {
+      set_last_error("fused butina: internal accounting error (a cluster without exactly one copy of its centroid)");
+      return NVMK_ERR_INTERNAL;
+    }
   }
   std::vector<int32_t> singles(idx.begin() + (snap.back + 1), idx.end());
   singles.insert(singles.end(), leftovers.begin(), leftovers.end());
