@@ -47,6 +47,53 @@ def test_mmff_terms_closed_form():
     assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(0.75 * 332.0716 * 0.25 / 1.55)
 
 
+def test_mmff_terms_equal_the_published_functional_forms():
+    """MMFF94 as published (Halgren, J. Comput. Chem. 17, 490-519 (1996), eqs. 2-8) with the constants RDKit's MMFF code
+    documents: angle bending 0.043844 ka/2 dt^2 (1 + cb dt) with cb = -0.006981317 / degree, stretch-bend 2.51210 (kba_ijk dr_ij
+    + kba_kji dr_kj) dt, out-of-plane 0.043844 koop/2 chi^2, torsion 0.5 (V1 (1 + cos p) + V2 (1 - cos 2p) + V3 (1 + cos 3p)),
+    buffered 14-7 van der Waals, buffered Coulomb 332.0716 q_i q_j / (D (R + 0.05)).  Every expected value below is written
+    out from those formulas with the geometry computed by hand — none goes through oracle/ff.py's helpers."""
+    empty = lambda n, m: (np.zeros((0, n), int), np.zeros((0, m)))  # noqa: E731
+    groups = [empty(n, m) for n, m in ff.LAYOUT[ff.MMFF]]
+    # a bent three-atom chain: |r01| = 1.1, |r21| = 1.4, angle 100 degrees at atom 1
+    th = np.deg2rad(100.0)
+    pos = np.array([[1.1, 0.0, 0.0], [0.0, 0.0, 0.0], [1.4 * np.cos(th), 1.4 * np.sin(th), 0.0], [0.3, 0.4, 1.2]])
+    g = list(groups)
+    g[1] = (np.array([[0, 1, 2]]), np.array([[109.5, 0.75, 0.0]]))
+    dt = 100.0 - 109.5
+    assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(0.043844 * 0.75 / 2 * dt**2 * (1 - 0.006981317 * dt), rel=2e-5)  # 0.043844 is the published 5-digit value of 143.9325 (pi / 180)^2
+    g = list(groups)
+    g[2] = (np.array([[0, 1, 2]]), np.array([[109.5, 1.0, 1.5, 0.3, 0.2]]))   # theta0, r0_ij, r0_kj, kba_ijk, kba_kji
+    assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(2.51210 * dt * (0.3 * (1.1 - 1.0) + 0.2 * (1.4 - 1.5)), rel=1e-9)
+    # out of plane: atoms 0, 2 and the centre 1 span the xy plane, atom 3 sits at (0.3, 0.4, 1.2): sin(chi) = z / |r| = 1.2 / 1.3
+    g = list(groups)
+    g[3] = (np.array([[0, 1, 2, 3]]), np.array([[0.05]]))
+    chi = np.rad2deg(np.arcsin(1.2 / 1.3))
+    assert ff.system_energy(ff.MMFF, pos, g) == pytest.approx(0.043844 * 0.05 / 2 * chi**2, rel=2e-5)
+    # torsion 0-1-2-3 of 60 degrees: cos p = 0.5, cos 2p = -0.5, cos 3p = -1
+    ph = np.deg2rad(60.0)
+    ptor = np.array([[1.0, 1.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0], [np.cos(ph), 0.0, np.sin(ph)]])
+    ptor[0] = [np.cos(0.0), 1.0, np.sin(0.0)]
+    g = list(groups)
+    g[4] = (np.array([[0, 1, 2, 3]]), np.array([[0.7, -1.1, 0.4]]))
+    assert ff.system_energy(ff.MMFF, ptor, g) == pytest.approx(0.5 * (0.7 * 1.5 + -1.1 * 1.5 + 0.4 * 0.0), rel=1e-12)
+    # buffered 14-7 at R = 3.2 with R* = 3.6, eps = 0.07
+    pv = np.array([[0.0, 0.0, 0.0], [3.2, 0.0, 0.0]])
+    g = list(groups)
+    g[5] = (np.array([[0, 1]]), np.array([[3.6, 0.07]]))
+    want = 0.07 * (1.07 * 3.6 / (3.2 + 0.07 * 3.6)) ** 7 * (1.12 * 3.6**7 / (3.2**7 + 0.12 * 3.6**7) - 2.0)
+    assert ff.system_energy(ff.MMFF, pv, g) == pytest.approx(want, rel=1e-12)
+    assert 0.0 < want < 0.01                                                          # on the repulsive wall, just past the zero crossing
+    g[5] = (np.array([[0, 1]]), np.array([[3.2, 0.07]]))
+    assert ff.system_energy(ff.MMFF, pv, g) == pytest.approx(-0.07, rel=1e-12)      # the minimum: exactly -eps at R = R*
+    # buffered Coulomb, distance-dependent dielectric (model 2) and the 0.75 scaling of 1-4 pairs
+    g = list(groups)
+    g[6] = (np.array([[0, 1]]), np.array([[-0.18, 2.0, 0.0]]))
+    assert ff.system_energy(ff.MMFF, pv, g) == pytest.approx(332.0716 * -0.18 / 3.25**2, rel=1e-12)
+    g[6] = (np.array([[0, 1]]), np.array([[-0.18, 1.0, 1.0]]))
+    assert ff.system_energy(ff.MMFF, pv, g) == pytest.approx(0.75 * 332.0716 * -0.18 / 3.25, rel=1e-12)
+
+
 def test_uff_terms_closed_form():
     """Hand-computable UFF values (functional forms of reference src/forcefields/uff_kernels_device.cuh:37-580)."""
     pos = np.array([[0.0, 0, 0], [1.5, 0, 0], [1.5, 1.2, 0], [1.5, 1.2, 1.0]])
