@@ -74,3 +74,14 @@ print("calls", calls)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(ROOT))
     assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
     assert int(p.stdout.split()[-1]) == 4 * len(_native.SIGNATURES)
+
+
+def test_integration_notes_name_every_entry_point():
+    """INTEGRATION.md shows how each entry of the header would be bound from the reference's side: none may be missing."""
+    import re
+
+    header = (ROOT / "include" / "nvmolkit_amd.h").read_text()
+    notes = (ROOT / "INTEGRATION.md").read_text()
+    symbols = sorted(set(re.findall(r"\b(nvmk_[a-z0-9_]+)\s*\(", header)))
+    assert len(symbols) >= 40
+    assert [s for s in symbols if s not in notes] == []
