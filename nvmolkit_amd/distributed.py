@@ -164,7 +164,9 @@ def butina_from_pairs_gpu(n: int, counts: torch.Tensor, pairs: torch.Tensor):
                                                   ctypes.byref(nc), _native.stream_ptr(None))
     _native.check(rc, "nvmk_butina_from_pairs")
     k = nc.value
-    return [tuple(int(v) for v in idx[offs[c]:offs[c + 1]]) for c in range(k)], [int(v) for v in offs[:k + 1]], [int(v) for v in cent[:k]]
+    bounds = offs[:k + 1].tolist()
+    flat = memoryview(idx)  # tuple() of a slice makes the Python ints directly (as clustering.fused_butina)
+    return [tuple(flat[bounds[c]:bounds[c + 1]]) for c in range(k)], bounds, cent[:k].tolist()
 
 
 def fused_butina_sharded(x: torch.Tensor, cutoff: float, group=None, metric: str = "tanimoto", return_centroids: bool = False,
