@@ -87,3 +87,17 @@ def test_lds_chunk_swizzle(kcw):
     for row in range(128):  # writer and reader apply the same term: an involution, and a permutation of the row's slots
         assert sorted(slot ^ swz(row) for slot in range(kcw)) == list(range(kcw))
         assert all((slot ^ swz(row)) ^ swz(row) == slot for slot in range(kcw))
+
+
+def test_fp4_expansion_of_a_byte():
+    """spread8 (similarity_mfma.hip prepare_kernel): bit k of a byte becomes 0x2 — FP4 e2m1 1.0 — in nibble k, 0x0 — 0.0 — otherwise,
+    so that the FP4 dot product of two expanded rows is popcount(a & b)."""
+    def spread8(x):
+        x = (x | (x << 12)) & 0x000F000F
+        x = (x | (x << 6)) & 0x03030303
+        x = (x | (x << 3)) & 0x11111111
+        return (x << 1) & 0xFFFFFFFF
+
+    for byte in range(256):
+        e = spread8(byte)
+        assert [(e >> (4 * k)) & 0xF for k in range(8)] == [2 * ((byte >> k) & 1) for k in range(8)]
