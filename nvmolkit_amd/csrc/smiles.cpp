@@ -5,7 +5,8 @@
 // What the reference takes from RDKit for this path and how it is restated here (host code, no GPU involved):
 //   * SMILES grammar (OpenSMILES): organic-subset and bracket atoms, isotopes, charges, explicit hydrogen counts, atom
 //     classes (ignored), chirality marks (ignored: the reference fingerprints with includeChirality = false), bond
-//     symbols - = # $ : / \, branches, ring closures (digits, %nn), dot-separated fragments.
+//     symbols - = # $ : / \, branches, ring closures (digits, %nn), dot-separated fragments; and the two spellings RDKit's
+//     parser reads beyond it: ring-closure labels %(n) up to five digits and atoms by atomic number, [#6].
 //   * hydrogens written as atoms ([H]) are folded into their neighbour like RDKit's default removeHs (kept when they
 //     carry an isotope or charge, bond to another hydrogen or have a degree other than one);
 //   * implicit hydrogens of organic-subset atoms from RDKit's valence model (default valence lists below; aromatic atoms
@@ -245,6 +246,15 @@ struct Parser {
     if (s[pos] == '*') {
       a.z = 0;
       ++pos;
+    } else if (s[pos] == '#') {  // the element by atomic number, "[#6]" (RDKit's SMILES parser reads it; 0 = a dummy atom)
+      ++pos;
+      if (!(s[pos] >= '0' && s[pos] <= '9')) return fail();
+      int z = 0;
+      while (s[pos] >= '0' && s[pos] <= '9') {
+        z = z * 10 + (s[pos++] - '0');
+        if (z > 118) return fail();
+      }
+      a.z = static_cast<uint8_t>(z);
     } else if (s[pos] >= 'a' && s[pos] <= 'z') {  // aromatic symbols: b c n o p s se as te si
       int len = (s[pos + 1] >= 'a' && s[pos + 1] <= 'z' && ((s[pos] == 's' && (s[pos + 1] == 'e' || s[pos + 1] == 'i')) ||
                                                              (s[pos] == 'a' && s[pos + 1] == 's') || (s[pos] == 't' && s[pos + 1] == 'e')))
@@ -372,6 +382,11 @@ struct Parser {
       uint8_t order = kUnspecified;
     };
     Open             ring[100];
+    struct Far {  // ring-closure labels written %(n) with n >= 100: rare, kept in a short list
+      int  label;
+      Open open;
+    };
+    std::vector<Far> far;
     int              prev    = -1;
     uint8_t          pending = kUnspecified;
     bool             havePending = false;
@@ -420,7 +435,18 @@ struct Parser {
         ++pos;
       } else if ((c >= '0' && c <= '9') || c == '%') {
         int label;
-        if (c == '%') {
+        if (c == '%' && s[pos + 1] == '(') {  // %(n): RDKit's form for labels beyond 99, up to five digits
+          pos += 2;
+          if (!(s[pos] >= '0' && s[pos] <= '9')) return fail();
+          label      = 0;
+          int digits = 0;
+          while (s[pos] >= '0' && s[pos] <= '9') {
+            label = label * 10 + (s[pos++] - '0');
+            if (++digits > 5) return fail();
+          }
+          if (s[pos] != ')') return fail();
+          ++pos;
+        } else if (c == '%') {
           if (!(s[pos + 1] >= '0' && s[pos + 1] <= '9' && s[pos + 2] >= '0' && s[pos + 2] <= '9')) return fail();
           label = (s[pos + 1] - '0') * 10 + (s[pos + 2] - '0');
           pos += 3;
@@ -429,19 +455,30 @@ struct Parser {
           ++pos;
         }
         if (prev < 0) return fail();
-        if (ring[label].atom < 0) {
-          ring[label].atom  = prev;
-          ring[label].order = havePending ? pending : kUnspecified;
+        Open* slot = nullptr;
+        if (label < 100) {
+          slot = &ring[label];
         } else {
-          uint8_t order = havePending ? pending : ring[label].order;
+          for (Far& f : far)
+            if (f.label == label) slot = &f.open;
+          if (slot == nullptr) {
+            far.push_back({label, Open{}});
+            slot = &far.back().open;
+          }
+        }
+        if (slot->atom < 0) {
+          slot->atom  = prev;
+          slot->order = havePending ? pending : kUnspecified;
+        } else {
+          uint8_t order = havePending ? pending : slot->order;
           auto plain = [](const uint8_t o) { return o == kDirectional ? kUnspecified : o; };
-          if (havePending && plain(ring[label].order) != kUnspecified && plain(pending) != kUnspecified &&
-              plain(ring[label].order) != plain(pending)) {
+          if (havePending && plain(slot->order) != kUnspecified && plain(pending) != kUnspecified &&
+              plain(slot->order) != plain(pending)) {
             return fail();
           }
-          if (plain(order) == kUnspecified) order = plain(ring[label].order) != kUnspecified ? ring[label].order : order;
-          if (!add_bond(ring[label].atom, prev, order)) return fail();
-          ring[label].atom = -1;
+          if (plain(order) == kUnspecified) order = plain(slot->order) != kUnspecified ? slot->order : order;
+          if (!add_bond(slot->atom, prev, order)) return fail();
+          slot->atom = -1;
         }
         havePending = false;
       } else {
@@ -461,6 +498,8 @@ struct Parser {
     if (havePending || !stack.empty()) return fail();
     for (const Open& o : ring)
       if (o.atom >= 0) return fail();
+    for (const Far& f : far)
+      if (f.open.atom >= 0) return fail();
     return true;
   }
 };

@@ -33,8 +33,8 @@ ISOTOPE = {(1, 2): 2.01410, (1, 3): 3.01605, (6, 13): 13.00335, (6, 14): 14.0032
 
 TOKEN = re.compile(r"""
     (?P<bracket>\[[^\]]*\]) | (?P<organic>Cl|Br|[BCNOFPSI]|[bcnops]|\*) | (?P<bond>[-=#$:/\\]) |
-    (?P<ring>%\d\d|\d) | (?P<open>\() | (?P<close>\)) | (?P<dot>\.)""", re.X)
-BRACKET = re.compile(r"^\[(?P<iso>\d+)?(?P<sym>se|as|te|si|[bcnops]|[A-Z][a-z]?|\*)(?P<chiral>@(?:@|(?:TH|AL|SP|TB|OH)\d+)?)?"
+    (?P<ring>%\(\d{1,5}\)|%\d\d|\d) | (?P<open>\() | (?P<close>\)) | (?P<dot>\.)""", re.X)
+BRACKET = re.compile(r"^\[(?P<iso>\d+)?(?P<sym>se|as|te|si|[bcnops]|[A-Z][a-z]?|\*|\#\d+)(?P<chiral>@(?:@|(?:TH|AL|SP|TB|OH)\d+)?)?"
                      r"(?P<h>H\d?)?(?P<charge>\++\d*|-+\d*)?(?::\d+)?\]$")
 
 
@@ -65,8 +65,11 @@ def parse_with_directions(smiles: str):
                 if b is None:
                     raise SmilesError(f"bad bracket atom {text}")
                 sym = b["sym"]
+                by_number = sym.startswith("#")  # "[#6]": the element by atomic number
+                if by_number and int(sym[1:]) > 118:
+                    raise SmilesError(f"atomic number out of range in {text}")
                 aromatic = sym in AROMATIC_SYMBOLS
-                if not aromatic and sym not in Z_OF:
+                if not aromatic and not by_number and sym not in Z_OF:
                     raise SmilesError(f"unknown element {sym}")
                 h = 0 if b["h"] is None else (int(b["h"][1:]) if len(b["h"]) > 1 else 1)
                 q = 0
@@ -78,7 +81,7 @@ def parse_with_directions(smiles: str):
                         q = -q
                 if int(b["iso"] or 0) > 999 or abs(q) > 15:
                     raise SmilesError(f"isotope or charge out of range in {text}")
-                atoms.append(dict(z=AROMATIC_SYMBOLS[sym] if aromatic else Z_OF[sym], charge=q, isotope=int(b["iso"] or 0),
+                atoms.append(dict(z=int(sym[1:]) if by_number else (AROMATIC_SYMBOLS[sym] if aromatic else Z_OF[sym]), charge=q, isotope=int(b["iso"] or 0),
                                   h_explicit=h, bracket=True, aromatic=aromatic))
             else:
                 aromatic = text.islower()
@@ -96,7 +99,7 @@ def parse_with_directions(smiles: str):
         elif kind == "ring":
             if prev is None:
                 raise SmilesError("ring closure before any atom")
-            label = int(text.lstrip("%"))
+            label = int(text.strip("%()"))
             if label in open_rings:
                 other, sym = open_rings.pop(label)
                 if (sym is not None and pending is not None and BOND_TYPE[sym] is not None and BOND_TYPE[pending] is not None

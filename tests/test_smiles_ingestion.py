@@ -165,6 +165,20 @@ def test_isotope_invariants_where_the_mass_number_alone_would_be_wrong():
         assert int(ai[0, 0]) & 0xffffffff == seed, (smi, z)
 
 
+def test_ring_labels_beyond_99_and_elements_by_atomic_number():
+    """Two spellings RDKit's SMILES parser reads beyond OpenSMILES: %(n) ring-closure labels (up to five digits) and [#n] atoms."""
+    for written, plain in [("C%(100)CC%(100)", "C1CC1"), ("C%(7)CC7", "C1CC1"), ("C%(12345)CC%(12345)O", "C1CC1O"),
+                           ("c%(100)ccccc%(100)", "c1ccccc1"), ("C%(100)CC%(100)C%(100)CC%(100)", "C1CC1C1CC1"),
+                           ("[#6]", "[C]"), ("[#6H4]", "[CH4]"), ("[#7+]([#8-])(=O)c1ccccc1", "[N+]([O-])(=O)c1ccccc1"),
+                           ("[#0]C", "*C"), ("[13#6H4]", "[13CH4]"), ("[#6H2]1[#6H2][#8]1", "[CH2]1[CH2][O]1")]:
+        for got, want in zip(graph(written), graph(plain)):
+            assert np.array_equal(got, want), written
+        for got, want in zip(graph(written), osmi.molecule(written)):
+            assert np.array_equal(got, want), written
+    refused = SmilesSet(["C%(123456)CC%(123456)", "C%(100)CC", "C%()CC", "C%(1x)CC%(1x)", "[#119]", "[#]", "[#6", "C%(100"])
+    assert refused.status.tolist() == [1] * 8
+
+
 def test_ring_membership_is_cycle_membership():
     atoms, bonds = graph("C1CC1CC1CCC1")                  # two rings joined by a CH2: the linker is on no cycle
     assert atoms[:, 5].tolist() == [1, 1, 1, 0, 1, 1, 1, 1]
