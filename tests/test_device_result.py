@@ -83,3 +83,68 @@ def test_uff_torsion_and_angle_shape_rules():
     assert _torsion_shape(1.0, 8, 6, True, False, False) == (2, -1.0)      # sp3 group-6 next to sp2 non-group-6
     assert _torsion_shape(1.0, 6, 6, True, False, True) == (3, -1.0)       # propene-like
     assert _torsion_shape(1.0, 6, 6, True, False, False) == (6, 1.0)
+
+
+# ---- the scenarios of the reference's own Device3DResult tests (nvmolkit/tests/test_types.py:105-296), on CPU tensors: values
+# encode (conformer, atom, axis) as conformer * 1000 + atom * 10 + axis, so every view can be checked by value.
+
+def coded(atom_counts, mol_indices, n_mols, conf_indices=None):
+    starts = np.concatenate([[0], np.cumsum(atom_counts)]).astype(np.int64)
+    values = torch.empty((int(starts[-1]), 3), dtype=torch.float64)
+    for c, k in enumerate(atom_counts):
+        for a in range(k):
+            values[starts[c] + a] = torch.tensor([c * 1000 + a * 10 + x for x in range(3)], dtype=torch.float64)
+    if conf_indices is None:
+        seen, conf_indices = {}, []
+        for m in mol_indices:
+            conf_indices.append(seen.get(m, 0))
+            seen[m] = conf_indices[-1] + 1
+    return Device3DResult(values, torch.tensor(starts, dtype=torch.int32), torch.tensor(mol_indices, dtype=torch.int32),
+                          torch.tensor(conf_indices, dtype=torch.int32), gpu_id=0, n_mols=n_mols)
+
+
+def test_reference_scenarios_per_molecule():
+    assert coded([3, 5, 2], [0, 0, 1], 2).num_conformers == 3                                   # :105-111
+    nested = coded([2, 3, 4], [1, 0, 1], 2).per_molecule()                                       # :114-139
+    assert [len(x) for x in nested] == [1, 2]
+    assert nested[0][0].shape == (3, 3) and nested[1][0].shape == (2, 3) and nested[1][1].shape == (4, 3)
+    assert nested[1][0][0, 0] == 0 and nested[0][0][0, 0] == 1000 and nested[1][1][0, 0] == 2000 and nested[0][0][2, 2] == 1022
+    nested = coded([2], [0], 4).per_molecule()                                                   # :142-154
+    assert len(nested) == 4 and len(nested[0]) == 1 and nested[1] == [] and nested[2] == [] and nested[3] == []
+    res = coded([3], [0], 1)                                                                     # :157-167
+    res.per_molecule()[0][0][0, 0] = -7.0
+    assert res.values.torch()[0, 0] == -7.0
+
+
+def test_reference_scenarios_dense():
+    from nvmolkit_amd.types import Dense3DResult
+
+    out = coded([2, 4, 3], [0, 1, 2], 3).dense()                                                 # :170-184
+    assert isinstance(out, Dense3DResult)
+    assert out.values.shape == (3, 1, 4, 3) and out.conf_mask.shape == (3, 1) and out.atom_mask.shape == (3, 1, 4)
+    assert out.values.dtype == torch.float64 and out.conf_mask.dtype == torch.bool and out.atom_mask.dtype == torch.bool
+    counts = [5, 3, 2]                                                                           # :187-233
+    atom_counts, mol_indices, conf_indices = [], [], []
+    for m, k in enumerate(counts):
+        for slot in range(k):
+            atom_counts.append(2 + slot % 3)
+            mol_indices.append(m)
+            conf_indices.append(slot)
+    out = coded(atom_counts, mol_indices, 3, conf_indices).dense()
+    assert out.values.shape == (3, 5, 4, 3) and out.conf_mask.sum(dim=1).tolist() == counts
+    assert out.atom_mask.sum(dim=(1, 2)).tolist() == [sum(atom_counts[:5]), sum(atom_counts[5:8]), sum(atom_counts[8:])]
+    assert out.values[0, 4, 0, 0] == 4000 and out.values[1, 2, 0, 0] == 7000 and out.values[2, 1, 0, 0] == 9000
+    assert torch.isnan(out.values[1, 4, 0, 0]) and torch.isnan(out.values[2, 2, 0, 0])
+    out = coded([3, 2], [0, 2], 3).dense()                                                       # :236-249
+    assert out.conf_mask[0].any() and not out.conf_mask[1].any() and out.conf_mask[2].any()
+    assert torch.isnan(out.values[1]).all() and not out.atom_mask[1].any()
+    out = coded([2, 4], [0, 0], 1).dense()                                                       # :252-266
+    assert out.values.shape == (1, 2, 4, 3) and out.conf_mask[0].tolist() == [True, True]
+    assert out.atom_mask[0, 0].tolist() == [True, True, False, False] and out.atom_mask[0, 1].tolist() == [True] * 4
+    assert torch.isnan(out.values[0, 0, 2, 0]) and not torch.isnan(out.values[0, 0, 1, 0])
+    out = coded([1, 3], [0, 1], 2).dense(pad_value=-1.0)                                         # :269-280
+    assert out.values.shape == (2, 1, 3, 3)
+    assert out.values[0, 0, 1, 0] == -1.0 and out.values[0, 0, 2, 2] == -1.0 and out.values[1, 0, 2, 2] == 1022
+    out = coded([], [], 3).dense()                                                               # :283-296
+    assert out.values.shape == (3, 0, 0, 3) and out.conf_mask.shape == (3, 0) and out.atom_mask.shape == (3, 0, 0)
+    assert out.values.dtype == torch.float64
