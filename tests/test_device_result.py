@@ -148,3 +148,15 @@ def test_reference_scenarios_dense():
     out = coded([], [], 3).dense()                                                               # :283-296
     assert out.values.shape == (3, 0, 0, 3) and out.conf_mask.shape == (3, 0) and out.atom_mask.shape == (3, 0, 0)
     assert out.values.dtype == torch.float64
+
+
+@pytest.mark.parametrize("invalid", [0, -2, -99])
+def test_hardware_options_refuse_invalid_batches_per_gpu(invalid):
+    """nvmolkit/tests/test_types.py:30-38: at construction and through the setter, with the reference's message."""
+    from nvmolkit_amd.types import HardwareOptions
+
+    with pytest.raises(ValueError, match="batchesPerGpu must be greater than 0 or -1"):
+        HardwareOptions(batchesPerGpu=invalid)
+    hw = HardwareOptions()
+    with pytest.raises(ValueError, match="batchesPerGpu must be greater than 0 or -1"):
+        hw.batchesPerGpu = invalid
