@@ -85,3 +85,33 @@ def test_integration_notes_name_every_entry_point():
     symbols = sorted(set(re.findall(r"\b(nvmk_[a-z0-9_]+)\s*\(", header)))
     assert len(symbols) >= 40
     assert [s for s in symbols if s not in notes] == []
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """The boundary is a C ABI: the header compiles as C99 (pedantic) and as C++11, and a C program that takes the address of
+    every declared entry links against the library."""
+    import re
+    import shutil
+    import subprocess
+
+    import pytest
+
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        pytest.skip("needs gcc and g++")
+    header = ROOT / "include" / "nvmolkit_amd.h"
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", str(header)],
+                ["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", str(header)]):
+        run = subprocess.run(cmd, capture_output=True, text=True)
+        assert run.returncode == 0, run.stderr[-1500:]
+    symbols = sorted(set(re.findall(r"\b(nvmk_[a-z0-9_]+)\s*\(", header.read_text())))
+    src = tmp_path / "link_all.c"
+    src.write_text('#include "nvmolkit_amd.h"\n#include <stdio.h>\nint main(void) {\n  const void* entries[] = {\n'
+                   + "".join(f"    (const void*)&{s},\n" for s in symbols)
+                   + '  };\n  printf("%d\\n", (int)(sizeof entries / sizeof entries[0]));\n  return 0;\n}\n')
+    exe = tmp_path / "link_all"
+    lib_dir = ROOT / "nvmolkit_amd" / "lib"
+    run = subprocess.run(["gcc", "-std=c99", f"-I{ROOT / 'include'}", str(src), "-o", str(exe), f"-L{lib_dir}", "-lnvmolkit_amd",
+                          f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr[-1500:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and int(out.stdout.strip()) == len(symbols), out.stdout + out.stderr
