@@ -169,6 +169,7 @@ double isotope_mass(const int z, const int a) {
                              {16, 34, 33.96787}, {16, 35, 34.96903}, {17, 36, 35.96831}, {17, 37, 36.96590}, {35, 76, 75.92454},
                              {35, 77, 76.92138}, {35, 82, 81.91680}, {53, 123, 122.90559}, {53, 124, 123.90621}, {53, 125, 124.90463},
                              {53, 131, 130.90612}, {27, 57, 56.93629},   {71, 177, 176.94376}};
+  if (z <= 0 || z >= kNumElements) return static_cast<double>(a);  // dummy atoms have no nuclide: the label IS the mass (RDKit: isotope as a double)
   for (const Iso& i : kIso)
     if (i.z == z && i.a == a) return i.m;
   double lo, hi;

@@ -27,7 +27,7 @@ VALENCES = {5: (3,), 6: (4,), 7: (3,), 8: (2,), 9: (1,), 15: (3, 5, 7), 16: (2, 
 # "/" and "\\" carry a direction, not an order: between two aromatic ring atoms the bond is aromatic, else single (= unmarked)
 BOND_TYPE = {"-": 1, "/": None, "\\": None, "=": 2, "#": 3, "$": 4, ":": 12}
 # average weights and a few exact isotope masses: only what the hand-made test molecules use (H, C, N, O, F, I)
-WEIGHT = {1: 1.008, 6: 12.011, 7: 14.007, 8: 15.999, 9: 18.998, 53: 126.90}
+WEIGHT = {0: 0.0, 1: 1.008, 6: 12.011, 7: 14.007, 8: 15.999, 9: 18.998, 53: 126.90}
 ISOTOPE = {(1, 2): 2.01410, (1, 3): 3.01605, (6, 13): 13.00335, (6, 14): 14.00324, (7, 15): 15.00011, (8, 18): 17.99916,
            (9, 18): 18.00094, (53, 125): 124.90463, (53, 131): 130.90612}
 

@@ -165,6 +165,21 @@ def test_isotope_invariants_where_the_mass_number_alone_would_be_wrong():
         assert int(ai[0, 0]) & 0xffffffff == seed, (smi, z)
 
 
+def test_labelled_dummy_atoms_take_the_label_as_their_mass():
+    """a dummy atom has no nuclide, its isotope label is the mass itself (RDKit: the label as a double, weight 0) —
+    the band of mass excesses applies to real elements only.  Product == oracle/smiles.py == the hand-computed invariant."""
+    for smi, label in [("[25*]C", 25), ("[120*]C", 120), ("[16*]C", 16), ("[30*]C", 30), ("[1*]C", 1), ("[213*]C", 213)]:
+        s = SmilesSet([smi])
+        assert s.status[0] == 0, smi
+        ai, *_ = s.morgan_inputs([0], 32)
+        comps, _ = osmi.invariant_components(*osmi.molecule(smi))
+        assert comps[0].tolist() == [0, 1, 0, 0, label], smi
+        seed = 0
+        for c in comps[0].tolist():
+            seed = (seed ^ ((c & 0xffffffff) + 0x9e3779b9 + ((seed << 6) & 0xffffffff) + (seed >> 2))) & 0xffffffff
+        assert int(ai[0, 0]) & 0xffffffff == seed, smi
+
+
 def test_ring_labels_beyond_99_and_elements_by_atomic_number():
     """Two spellings RDKit's SMILES parser reads beyond OpenSMILES: %(n) ring-closure labels (up to five digits) and [#n] atoms."""
     for written, plain in [("C%(100)CC%(100)", "C1CC1"), ("C%(7)CC7", "C1CC1"), ("C%(12345)CC%(12345)O", "C1CC1O"),
