@@ -23,10 +23,19 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return None
 
     def create_module(self, spec):
-        return importlib.import_module(_IMPL + "." + spec.name.rpartition(".")[2])
+        # importlib stamps the alias spec onto whatever create_module returns; the implementation module must keep its own
+        # (importlib.reload and tooling read __spec__ / __loader__), so both are put back in exec_module
+        impl = importlib.import_module(_IMPL + "." + spec.name.rpartition(".")[2])
+        self._own[impl.__name__] = (impl.__spec__, getattr(impl, "__loader__", None))
+        return impl
 
     def exec_module(self, module):  # the implementation module is already initialised
-        pass
+        spec, loader = self._own.get(module.__name__, (None, None))
+        if spec is not None:
+            module.__spec__ = spec
+            module.__loader__ = loader
+
+    _own = {}
 
 
 sys.meta_path.insert(0, _AliasFinder())

@@ -1478,8 +1478,15 @@ inline int read_back(const RoundBuffers& b, const int64_t N, const LoopState& sn
     if (threads <= 1) {
       worker();
     } else {
+      // thread creation can throw (thread limits, a cgroup's pid cap): nothing may unwind through the C ABI, so the threads
+      // that did start are joined and the calling thread takes whatever work is left
       std::vector<std::thread> pool;
-      for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+      try {
+        pool.reserve(static_cast<size_t>(threads));
+        for (int t = 0; t + 1 < threads; ++t) pool.emplace_back(worker);
+      } catch (...) {
+      }
+      worker();
       for (std::thread& t : pool) t.join();
     }
     if (bad.load() != 0) {

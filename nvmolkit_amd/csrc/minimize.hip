@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
 #include "options.h"
@@ -80,6 +81,7 @@ constexpr int    MAX_LS_ITERS  = 1000;
 // The one-workgroup-per-CU and the GVEC classes run as persistent workgroups that take systems off a counter (largest
 // first) and keep ONE inverse-Hessian slot each, so the memory a launch needs is bounded by the workgroups in flight, not by
 // the number of large systems (a 1000-atom 4-D system has a 64 MB triangle).
+constexpr int kProfWords = 12;  // per system: 7 phase sums, then the item's first / last clock and its hardware id (timeline)
 struct BfgsArgs {
   double*                         positions;
   double                          w0, w1;
@@ -194,8 +196,11 @@ namespace {
 // device counters the BFGS kernels add to when set (nvmk_bfgs_set_stats); process-wide, off by default
 std::atomic<unsigned long long*> g_stats{nullptr};
 
-// Highest-priority streams + their fork / join events per (host thread, device), created on first use and kept: the
-// larger size classes of a minimisation run on them next to the smallest one on the caller's stream.
+// Highest-priority streams + their fork / join events: the larger size classes of a minimisation run on them next to the
+// smallest one on the caller's stream.  Sets live in a process-wide pool per device and are LEASED for the duration of one
+// call (a thread_local table leaked a full set — six streams, seven events, a pinned word — with every
+// short-lived host thread, and nvmk_etkdg_embed starts fresh threads per call when batches_per_gpu > 1); the pool grows to
+// the number of concurrent calls per device and is kept for the life of the process.
 struct SideStreams {
   static constexpr int kStreams = 6;
   hipStream_t          s[kStreams]    = {};
@@ -203,26 +208,57 @@ struct SideStreams {
   hipEvent_t           join[kStreams] = {};
   int*                 started        = nullptr;  // pinned host word the large classes' workgroups count themselves into
   int*                 startedDev     = nullptr;  // its device address
-  bool                 ok             = false;
-};
-SideStreams* side_streams(const int dev) {
-  thread_local SideStreams table[64];
-  if (dev < 0 || dev >= 64) return nullptr;
-  SideStreams& t = table[dev];
-  if (!t.ok) {
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
-    for (int k = 0; k < SideStreams::kStreams; ++k) {
-      if (hipStreamCreateWithPriority(&t.s[k], hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
-      if (hipEventCreateWithFlags(&t.join[k], hipEventDisableTiming) != hipSuccess) return nullptr;
+  int                  dev            = -1;
+  void destroy() {  // a partially created set: give back what exists
+    for (int k = 0; k < kStreams; ++k) {
+      if (s[k]) (void)hipStreamDestroy(s[k]);
+      if (join[k]) (void)hipEventDestroy(join[k]);
     }
-    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&t.started), 64, hipHostMallocMapped) != hipSuccess) return nullptr;
-    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&t.startedDev), t.started, 0) != hipSuccess) return nullptr;
-    t.ok = true;
+    if (fork) (void)hipEventDestroy(fork);
+    if (started) (void)hipHostFree(started);
   }
-  return &t;
+};
+std::mutex                 g_sideMutex;
+std::vector<SideStreams*>  g_sideFree[64];
+SideStreams* create_side_streams(const int dev) {
+  auto* t = new SideStreams();
+  t->dev  = dev;
+  int  least = 0, greatest = 0;
+  bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+  for (int k = 0; ok && k < SideStreams::kStreams; ++k) {
+    ok = hipStreamCreateWithPriority(&t->s[k], hipStreamNonBlocking, greatest) == hipSuccess &&
+         hipEventCreateWithFlags(&t->join[k], hipEventDisableTiming) == hipSuccess;
+  }
+  ok = ok && hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void**>(&t->started), 64, hipHostMallocMapped) == hipSuccess;
+  ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&t->startedDev), t->started, 0) == hipSuccess;
+  if (!ok) {
+    t->destroy();
+    delete t;
+    return nullptr;
+  }
+  return t;
 }
+struct SideLease {
+  SideStreams* set = nullptr;
+  SideStreams* take(const int dev) {
+    if (set || dev < 0 || dev >= 64) return set;
+    {
+      const std::lock_guard<std::mutex> lock(g_sideMutex);
+      if (!g_sideFree[dev].empty()) {
+        set = g_sideFree[dev].back();
+        g_sideFree[dev].pop_back();
+      }
+    }
+    if (!set) set = create_side_streams(dev);
+    return set;
+  }
+  ~SideLease() {  // every use ends with the caller's stream waiting for the side streams and the host waiting for that stream
+    if (!set) return;
+    const std::lock_guard<std::mutex> lock(g_sideMutex);
+    g_sideFree[set->dev].push_back(set);
+  }
+};
 }  // namespace
 
 extern "C" {
@@ -479,6 +515,38 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       P.grid        = static_cast<int>(std::min<size_t>(cls[c].order.size(), static_cast<size_t>(nCu) * (P.gvec ? 2 : 1)));
     }
   }
+  // A one-system-per-workgroup class holds the HBM part of EVERY system's inverse Hessian for the whole launch (16 384
+  // attempts of ~150-atom molecules: 20-30 GB).  A class that wants more than a quarter of the free memory runs as a
+  // persistent class instead: as many workgroups as fit on the chip, one slot each, systems taken off a counter — same
+  // kernel, same results, memory bounded by the workgroups in flight.
+  {
+    size_t freeB = 0, totalB = 0;
+    bool   asked = false;
+    for (int c = 0; c < nBins; ++c) {
+      Plan& P = plan[c];
+      if (!P.used || P.persistent) continue;
+      const size_t want = static_cast<size_t>(P.hs.back() + kHessTailPadDoubles) * sizeof(double);
+      const long   capOpt = opt::get(opt::kBfgsHessCapMb).num(0);  // NVMK_BFGS_HESS_CAP_MB (tests): the limit in MiB instead of free / 4
+      if (capOpt <= 0 && want < (size_t{1} << 30)) continue;       // below 1 GiB: not worth a query
+      if (!asked && capOpt <= 0) {
+        NVMK_HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+        asked = true;
+      }
+      const size_t limit = capOpt > 0 ? static_cast<size_t>(capOpt) << 20 : freeB / 4;
+      if (want <= limit) continue;
+      int64_t slot = 0;
+      for (const int32_t s : cls[c].order) {
+        const int n  = (h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
+        const int rl = resident(P.threads, n, hess_doubles(P.threads, P.ldsDoubles, n));
+        slot         = std::max<int64_t>(slot, hess_row_offset(n) - hess_row_offset(rl));
+      }
+      P.persistent  = true;
+      P.hs.clear();
+      P.slotDoubles = ((slot + kHessTailPadDoubles) + 1) & ~int64_t{1};
+      slotBytes[c]  = static_cast<size_t>(P.slotDoubles) * sizeof(double);
+      P.grid        = static_cast<int>(std::min<size_t>(cls[c].order.size(), static_cast<size_t>(nCu) * kBins[c].wgPerCu));
+    }
+  }
   // the persistent classes together take at most half of the free memory (at least one slot each)
   {
     size_t want = 0;
@@ -514,13 +582,14 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
 
   const bool profile = opt::get(opt::kBfgsProfile).is("1") && (b.kind == NVMK_FF_DG || b.kind == NVMK_FF_MMFF || b.kind == NVMK_FF_ETK);
   StreamScratch profMem;
-  const size_t  profWords = static_cast<size_t>(b.nSystems) * 8;
+  const size_t  profWords = static_cast<size_t>(b.nSystems) * kProfWords;
   if (profile) {
     NVMK_HIP_CHECK(profMem.alloc(profWords * sizeof(int64_t), stream));
     NVMK_HIP_CHECK(hipMemsetAsync(profMem.ptr, 0, profWords * sizeof(int64_t), stream));
   }
 
-  int* startedDev = nullptr;  // set when several classes run side by side (see below)
+  int*      startedDev = nullptr;  // set when several classes run side by side (see below)
+  SideLease sideLease;            // returned to the pool when this call ends (it ends with a stream synchronisation)
   auto launch = [&](const int c, hipStream_t on) -> int {
     Plan&    P = plan[c];
     BfgsArgs A;
@@ -601,7 +670,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       if (lastUsed < 0) lastUsed = c;  // the bin of the smallest systems in use stays on the caller's stream
     }
   if (nUsed > 1 && overlap) {
-    SideStreams* side = side_streams(dev);
+    SideStreams* side = sideLease.take(dev);
     NVMK_REQUIRE(side != nullptr, "bfgs: could not create the side streams of device %d", dev);
     startedDev                                      = side->startedDev;
     *static_cast<volatile int*>(side->started)      = 0;
@@ -647,10 +716,27 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     double  sum[7] = {0, 0, 0, 0, 0, 0, 0};
     int64_t ran = 0, longest = 0;
     for (int sI = 0; sI < b.nSystems; ++sI) {
-      if (h[static_cast<size_t>(sI) * 8 + 4] == 0) continue;
+      if (h[static_cast<size_t>(sI) * kProfWords + 4] == 0) continue;
       ++ran;
-      longest = std::max(longest, h[static_cast<size_t>(sI) * 8 + 4]);
-      for (int k = 0; k < 7; ++k) sum[k] += static_cast<double>(h[static_cast<size_t>(sI) * 8 + k]);
+      longest = std::max(longest, h[static_cast<size_t>(sI) * kProfWords + 4]);
+      for (int k = 0; k < 7; ++k) sum[k] += static_cast<double>(h[static_cast<size_t>(sI) * kProfWords + k]);
+    }
+    // NVMK_BFGS_TIMELINE=path: one line per system that ran — kind, coordinates, first / last clock of its workgroup (100 MHz,
+    // chip-wide), XCC and CU — appended; tools/bfgs_timeline.py turns the file into occupancy over time and the launch tails
+    {
+      const opt::Text path = opt::get(opt::kBfgsTimeline);
+      if (path.set()) {
+        if (std::FILE* f = std::fopen(path.s, "a")) {
+          for (int sI = 0; sI < b.nSystems; ++sI) {
+            const int64_t* r = h.data() + static_cast<size_t>(sI) * kProfWords;
+            if (r[8] == 0) continue;
+            const unsigned hw = static_cast<unsigned>(r[9] & 0xffffffff), xcc = static_cast<unsigned>(r[9] >> 32) & 0xf;
+            std::fprintf(f, "%d %d %lld %lld %u %u %u %lld %lld\n", b.kind, (h_atom_starts[sI + 1] - h_atom_starts[sI]) * dim,
+                         (long long)r[7], (long long)r[8], xcc, (hw >> 8) & 0xf, (hw >> 4) & 0x3, (long long)r[5], (long long)r[4]);
+          }
+          std::fclose(f);
+        }
+      }
     }
     if (ran > 0) {
       const double us = 0.01;  // 100 MHz ticks

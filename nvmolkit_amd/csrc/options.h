@@ -22,11 +22,13 @@ enum Id {
   kBfgsOverlap,     // NVMK_BFGS_OVERLAP     1 | 0 (0: size classes run one after the other on the caller's stream)
   kBfgsWave,        // NVMK_BFGS_WAVE        1 | 0 | n (0: four waves for every system; n: largest system one wave takes)
   kBfgsWave2,       // NVMK_BFGS_WAVE2       n (largest system, in coordinates, that two waves take; 0: none)
+  kBfgsHessCapMb,   // NVMK_BFGS_HESS_CAP_MB n (tests: inverse-Hessian memory of a one-system-per-workgroup class before it runs persistent; default free / 4)
+  kBfgsTimeline,    // NVMK_BFGS_TIMELINE    path (with NVMK_BFGS_PROFILE=1: per-system start / end clocks appended to this file)
   kNumOptions
 };
 
 struct Text {
-  char s[48];
+  char s[128];
   bool set() const { return s[0] != '\0'; }
   bool is(const char* v) const { return std::strcmp(s, v) == 0; }
   long num(const long dflt) const { return set() ? std::atol(s) : dflt; }

@@ -96,6 +96,22 @@ def test_lds_policies_give_identical_results():
         assert np.array_equal(out[pol], out["0"]), pol
 
 
+def test_capped_hessian_memory_runs_the_class_persistently_with_the_same_bits():
+    """a one-system-per-workgroup class whose inverse Hessians would take more memory than allowed runs as a
+    persistent class (one slot per workgroup in flight, systems off a counter) — same kernel, same arithmetic, same bits.
+    NVMK_BFGS_HESS_CAP_MB forces the switch on a batch that is far below the automatic limit (a quarter of the free memory)."""
+    systems = systems_of(MMFF, [20, 30, 48, 48, 64, 64, 90, 70] * 8, 43)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(MMFF, systems)
+    gpu = FlatForcefieldBatch(MMFF, a_s, groups)
+    out = {}
+    for cap in ("", "1"):
+        with _native.options(NVMK_BFGS_HESS_CAP_MB=cap):
+            pos = torch.from_numpy(flat).cuda()
+            e, st, it = gpu.minimize(pos, max_iters=30)
+            out[cap] = (pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy())
+    assert all(np.array_equal(a, b) for a, b in zip(out[""], out["1"]))
+
+
 def test_druglike_mmff_minima_agree_statistically():
     """200-iteration MMFF runs on the benchmark's molecule generator, from perturbed reference geometries: per-system
     energies of GPU and oracle agree for the bulk of the systems (divergent trajectories may pick another local minimum)."""

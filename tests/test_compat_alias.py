@@ -18,6 +18,9 @@ def test_reference_package_name_resolves_to_this_library():
         "assert c is d and crossTanimotoSimilarity is s.crossTanimotoSimilarity\n"
         "assert nvmolkit.types.AsyncGpuResult is __import__('nvmolkit_amd.types', fromlist=['x']).AsyncGpuResult\n"
         "from nvmolkit.clustering import butina, fused_butina\n"
+        "import importlib\n"
+        "assert s.__spec__.name == 'nvmolkit_amd.similarity' and s.__spec__.origin.endswith('similarity.py'), s.__spec__\n"
+        "assert importlib.reload(s) is s and c.__spec__.name == 'nvmolkit_amd.clustering'\n"
         "try:\n"
         "    import nvmolkit.substructure\n"
         "    raise SystemExit('a module outside the hot path imported')\n"
