@@ -45,8 +45,14 @@ def _deps() -> list[Path]:
     return sorted(list(CSRC_DIR.glob("*.h")) + list(CSRC_DIR.glob("*.hpp")) + list(CSRC_DIR.glob("*.inc")) + [PKG_DIR.parent / "include" / "nvmolkit_amd.h"])
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every source under csrc/ into lib/libnvmolkit_amd.so (incremental per file)."""
+def build(force: bool = False, verbose: bool = False, variant: str = "") -> Path:
+    """Compile every source under csrc/ into lib/libnvmolkit_amd.so (incremental per file).
+
+    ``variant`` (or $NVMK_BUILD_VARIANT): an A/B build beside the product — lib/libnvmolkit_amd_<variant>.so from its own object
+    directory, normally with $NVMK_EXTRA_HIPCC_FLAGS; a process picks it up through $NVMOLKIT_AMD_LIB (tools/ab_conformers.sh)."""
+    variant = variant or os.environ.get("NVMK_BUILD_VARIANT", "")
+    LIB_PATH = LIB_DIR / (f"libnvmolkit_amd_{variant}.so" if variant else "libnvmolkit_amd.so")
+    OBJ_DIR = PKG_DIR / (f"build_{variant}" if variant else "build")
     LIB_DIR.mkdir(exist_ok=True)
     OBJ_DIR.mkdir(exist_ok=True)
     hipcc = _hipcc()

@@ -30,6 +30,8 @@ ap.add_argument("--batch-size", type=int, default=-1)
 ap.add_argument("--mmff-iters", type=int, default=200)
 ap.add_argument("--batches-per-gpu", type=int, default=-1)
 ap.add_argument("--repeat", type=int, default=1, help="timed repetitions (the best is reported)")
+ap.add_argument("--cache", default="", help="directory for the generated molecule library (pickle): A/B runs of several builds in one "
+                "session then generate it once")
 args = ap.parse_args()
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
 if world > 1:
@@ -38,7 +40,23 @@ if world > 1:
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group("nccl")
 t0 = time.perf_counter()
-library = synthetic.druglike_library(args.mols, seed=20260926, mean_atoms=args.mean_atoms)
+def load_library():
+    import pickle
+
+    path = Path(args.cache) / f"druglike_{args.mols}_{args.mean_atoms}.pkl" if args.cache else None
+    if path is not None and path.exists():
+        with open(path, "rb") as f:
+            return pickle.load(f)
+    lib = synthetic.druglike_library(args.mols, seed=20260926, mean_atoms=args.mean_atoms)
+    if path is not None and rank == 0:
+        path.parent.mkdir(parents=True, exist_ok=True)
+        with open(str(path) + ".tmp", "wb") as f:
+            pickle.dump(lib, f, protocol=pickle.HIGHEST_PROTOCOL)
+        os.replace(str(path) + ".tmp", path)
+    return lib
+
+
+library = load_library()
 if world > 1:
     from nvmolkit_amd.distributed import shard_molecules_by_cost
 

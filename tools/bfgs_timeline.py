@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Occupancy over time of the fused BFGS kernels from the per-system records the library writes with NVMK_BFGS_PROFILE=1
+NVMK_BFGS_TIMELINE=<file> (one line per system: kind, coordinates, first / last clock of its workgroup in 100 MHz ticks, XCC, CU,
+SIMD, iterations, busy ticks).  Launches are told apart by gaps in the records; for each launch group (everything that overlaps
+in time = the size classes of one minimisation stage of one batch) the script reports its span, the wave-slot occupancy
+integrated over the span (waves of the systems in flight / 2048 wave slots of the chip at two waves per SIMD) and how much of the span is
+"tail": time during which fewer than half of the slots are occupied.
+Usage: python tools/bfgs_timeline.py FILE [--slots 2048]"""
+import argparse
+import gzip
+import json
+
+import numpy as np
+
+ap = argparse.ArgumentParser()
+ap.add_argument("file")
+ap.add_argument("--slots", type=int, default=2048)
+ap.add_argument("--wave", type=int, default=176)
+ap.add_argument("--wave2", type=int, default=256)
+args = ap.parse_args()
+op = gzip.open if args.file.endswith(".gz") else open
+rec = np.loadtxt(op(args.file, "rt"), dtype=np.int64, ndmin=2)
+kind, n, t0, t1, iters = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 7]
+waves = np.where(n <= args.wave, 1, np.where(n <= args.wave2, 2, 4))
+order = np.argsort(t0)
+kind, n, t0, t1, waves, iters = kind[order], n[order], t0[order], t1[order], waves[order], iters[order]
+# launch groups: a new group starts where a system begins after everything before it has ended (plus 20 us of slack)
+groups, start, end = [], 0, t1[0]
+for i in range(1, len(t0)):
+    if t0[i] > end + 2000:
+        groups.append((start, i))
+        start = i
+    end = max(end, t1[i])
+groups.append((start, len(t0)))
+out = {"systems": int(len(t0)), "launch_groups": len(groups), "groups": []}
+tot_span = tot_busy = tot_tail = 0.0
+for a, b in groups:
+    s, e = t0[a:b].min(), t1[a:b].max()
+    span = (e - s) * 1e-2  # us
+    busy = float(((t1[a:b] - t0[a:b]) * waves[a:b]).sum()) * 1e-2  # wave-us
+    # occupancy curve on a 100-us grid
+    edges = np.arange(s, e + 10000, 10000)
+    occ = np.zeros(len(edges) - 1)
+    for w in (1, 2, 4):
+        m = waves[a:b] == w
+        if not m.any():
+            continue
+        up = np.histogram(t0[a:b][m], bins=edges)[0].cumsum()
+        down = np.histogram(t1[a:b][m], bins=edges)[0].cumsum()
+        occ += w * (up - down + np.histogram(t1[a:b][m], bins=edges)[0] * 0.5)
+    tail = float((occ < 0.5 * args.slots).sum()) * 100.0
+    kinds = {int(k): int((kind[a:b] == k).sum()) for k in np.unique(kind[a:b])}
+    out["groups"].append({"kinds": kinds, "systems": int(b - a), "span_ms": span * 1e-3, "mean_occupancy": busy / (span * args.slots),
+                          "tail_ms_below_half": tail * 1e-3, "mean_iterations": float(iters[a:b].mean()),
+                          "longest_system_ms": float((t1[a:b] - t0[a:b]).max()) * 1e-5})
+    tot_span += span
+    tot_busy += busy
+    tot_tail += tail
+out["total_span_ms"] = tot_span * 1e-3
+out["total_mean_occupancy"] = tot_busy / (tot_span * args.slots)
+out["total_tail_ms_below_half"] = tot_tail * 1e-3
+out["wall_ms_first_to_last"] = float(t1.max() - t0.min()) * 1e-5
+print(json.dumps(out, indent=1))

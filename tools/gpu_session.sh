@@ -1,0 +1,166 @@
+#!/bin/bash
+# The ONE runner handed to gpurun (round 4 on; the per-call scripts of rounds 2-3 are summarised in tools/gpu_sessions/README.md):
+#   gpurun --timeout 1500 -- bash tools/gpu_session.sh <name> <step> [<step> ...]
+# Every step writes into gpurun_out/<name>/ and is wrapped in its own timeout.  Steps:
+#   ubench_hess         inverse-Hessian pass alone, full chip, exact vs padded loads, one / two / four waves per system
+#   ubench_hess_pmc     FETCH_SIZE / WRITE_SIZE of the same (separate --pmc passes)
+#   parity_conformers   BFGS / ETKDG / force-field GPU parity tests
+#   ab_conformers       tools/bench_conformers.py --mols 10000 with every nvmolkit_amd/lib/libnvmolkit_amd_<variant>.so beside the product
+#   timeline            BFGS per-system timeline of one 10 000-molecule run (NVMK_BFGS_PROFILE=1 NVMK_BFGS_TIMELINE)
+#   conformer_traffic   tools/profile_conformer_traffic.sh 2000
+#   pytest_gpu          the whole -m gpu suite
+#   smoke               __graft_entry__.smoke()
+#   bench               python bench.py (default flags), plain
+#   bench_stats         python bench.py under rocprofv3 --kernel-trace --stats
+#   bench_traffic       tools/profile_bench_traffic.sh (PMC of the dense launches)
+#   markers             rocprofv3 --marker-trace --kernel-trace of one ETKDG + MMFF run (roctx ranges of the library)
+#   chembl              the conformer block on the ChEMBL topologies (tools/bench_conformers.py --set chembl)
+#   strong              bench.py strong-scaling conformer mode as one rank over RCCL
+#   butina              tools/bench_butina.py + clustering tests
+#   dist_gpu            tests/test_distributed_gpu.py under torch.distributed.run --nproc 1
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+NAME=${1:?session name}
+shift
+O=$ROOT/gpurun_out/$NAME
+mkdir -p $O
+cd $ROOT
+export TMPDIR=/tmp
+export NVMK_ROOT=$ROOT
+CACHE=/tmp/nvmk_lib_cache
+pick() { python -c "import sys,json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d=json.loads(line); print('$1', {k: (round(d[k],4) if isinstance(d[k],float) else d[k]) for k in d if k in ('mols_per_s_etkdg_plus_mmff','etkdg_s','mmff_s','etkdg_conformers','mmff_converged_frac','mols','mean_atoms')})"; }
+
+for STEP in "$@"; do
+  echo "==== $STEP ($(date +%T))"
+  case $STEP in
+    ubench_hess)
+      for T in 64 128 256; do for E in 0 1; do
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DUBENCH_THREADS=$T -DNVMK_HESS_EXACT=$E tools/ubench_hess.hip -o /tmp/ubh_${T}_$E 2>/dev/null &
+      done; done
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DUBENCH_THREADS=64 -DNVMK_HESS_AUX_LOAD=2 -DNVMK_HESS_AUX_STORE=2 tools/ubench_hess.hip -o /tmp/ubh_64_nt 2>/dev/null &
+      wait
+      : > $O/ubench_hess.jsonl
+      for E in 0 1 nt; do
+        for N in 96 144 176; do timeout 60 /tmp/ubh_64_$E $N 16384 19.5 2 40 >> $O/ubench_hess.jsonl; done
+        timeout 60 /tmp/ubh_64_$E 144 256 19.5 2 40 >> $O/ubench_hess.jsonl     # one system per CU: latency, no contention
+      done
+      for E in 0 1; do
+        for N in 200 256; do timeout 60 /tmp/ubh_128_$E $N 8192 39.5 2 40 >> $O/ubench_hess.jsonl; done
+        for N in 192 300 384; do timeout 60 /tmp/ubh_256_$E $N 4096 79 2 40 >> $O/ubench_hess.jsonl; done
+      done
+      cat $O/ubench_hess.jsonl
+      ;;
+    ubench_hess_pmc)
+      cd /tmp
+      for E in 0 1; do for C in FETCH_SIZE WRITE_SIZE; do
+        timeout 120 rocprofv3 --pmc $C -f csv -d $O/ubh_pmc_${E}_$C -- /tmp/ubh_64_$E 144 16384 19.5 2 40 > $O/ubh_pmc_${E}_$C.log 2>&1
+      done; done
+      cd $ROOT
+      python - "$O" <<'PY'
+import csv, glob, json, sys
+o = sys.argv[1]
+out = {}
+for e in (0, 1):
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        tot = 0.0
+        for f in glob.glob(f"{o}/ubh_pmc_{e}_{c}/**/*_counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "pass_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                    tot += float(r["Counter_Value"])
+        out[f"exact{e}_{c}_KiB"] = tot
+n, systems, iters = 144, 16384, 42   # the warm-up launch runs 2 passes, the timed one 40
+tri = (n * n // 2) * 8
+out["algorithmic_bytes_read_or_written"] = tri * systems * iters
+for e in (0, 1):
+    out[f"exact{e}_read_ratio"] = 2 * out[f"exact{e}_FETCH_SIZE_KiB"] * 1024 / out["algorithmic_bytes_read_or_written"]
+    out[f"exact{e}_write_ratio"] = out[f"exact{e}_WRITE_SIZE_KiB"] * 1024 / out["algorithmic_bytes_read_or_written"]
+json.dump(out, open(f"{o}/ubench_hess_pmc.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+      ;;
+    parity_conformers)
+      ( time timeout 900 python -m pytest tests/test_bfgs_parity_gpu.py tests/test_etkdg_gpu.py tests/test_forcefield_gpu.py tests/test_etkdg_driver_gpu.py -m gpu -q -x ) > $O/parity_conformers.log 2>&1
+      tail -4 $O/parity_conformers.log
+      ;;
+    ab_conformers)
+      : > $O/ab_conformers.txt
+      for i in 1 2; do
+        for L in "" $(ls nvmolkit_amd/lib/ | sed -n 's/^libnvmolkit_amd_\(.*\)\.so$/\1/p'); do
+          LIBP=$ROOT/nvmolkit_amd/lib/libnvmolkit_amd${L:+_$L}.so
+          NVMOLKIT_AMD_LIB=$LIBP timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --cache $CACHE 2>/dev/null | pick "${L:-product}" | tee -a $O/ab_conformers.txt
+        done
+      done
+      ;;
+    timeline)
+      rm -f $O/bfgs_timeline.txt
+      NVMK_BFGS_PROFILE=1 NVMK_BFGS_TIMELINE=$O/bfgs_timeline.txt timeout 300 python tools/bench_conformers.py --mols 10000 --cache $CACHE > $O/timeline_run.log 2>&1
+      tail -2 $O/timeline_run.log | cut -c1-300
+      python tools/bfgs_timeline.py $O/bfgs_timeline.txt > $O/bfgs_timeline_summary.json && cat $O/bfgs_timeline_summary.json | head -60
+      gzip -f $O/bfgs_timeline.txt
+      ;;
+    conformer_traffic)
+      timeout 900 bash tools/profile_conformer_traffic.sh 2000 > $O/conformer_traffic.log 2>&1
+      cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/ 2>/dev/null
+      tail -30 $O/conformer_traffic.log
+      ;;
+    pytest_gpu)
+      ( time timeout 2400 python -m pytest tests -m gpu -q -x ) > $O/pytest_gpu.log 2>&1
+      tail -5 $O/pytest_gpu.log
+      ;;
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+      tail -3 $O/smoke.log
+      ;;
+    bench)
+      timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+      tail -c 3000 $O/bench.json
+      ;;
+    bench_stats)
+      cd /tmp
+      timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_stats -- python $ROOT/bench.py > $O/bench_under_rocprof.json 2> $O/bench_stats.err
+      cd $ROOT
+      f=$(find $O/bench_stats -name '*kernel_stats.csv' | head -1)
+      [ -n "$f" ] && cp $f $O/kernel_stats_bench_py.csv && head -12 $O/kernel_stats_bench_py.csv | cut -c1-200
+      rm -rf $O/bench_stats
+      ;;
+    bench_traffic)
+      timeout 900 bash tools/profile_bench_traffic.sh > $O/bench_traffic.log 2>&1
+      cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json $O/ 2>/dev/null
+      tail -20 $O/bench_traffic.log
+      ;;
+    markers)
+      cd /tmp
+      timeout 600 rocprofv3 --marker-trace --kernel-trace -f csv -d $O/markers -- python $ROOT/tools/bench_conformers.py --mols 2000 --cache $CACHE > $O/markers_run.log 2>&1
+      cd $ROOT
+      f=$(find $O/markers -name '*marker_api_trace.csv' | head -1)
+      [ -n "$f" ] && cp $f $O/marker_trace.csv && python tools/marker_summary.py $O/marker_trace.csv | tee $O/marker_summary.txt | head -60
+      rm -rf $O/markers
+      ;;
+    chembl)
+      timeout 900 python tools/bench_conformers.py --set chembl --mols 10000 --repeat 2 --cache $CACHE 2> $O/chembl.err | tee $O/chembl.json | cut -c1-1500
+      ;;
+    strong)
+      NVMK_BENCH_SINGLE_RANK_COLLECTIVES=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+        bench.py --gpus 1 --steps 3 --warmup 1 --conformer-total 100000 > $O/bench_strong_single_rank.json 2> $O/bench_strong.err
+      tail -c 2500 $O/bench_strong_single_rank.json
+      ;;
+    butina)
+      ( time timeout 900 python -m pytest tests/test_clustering_gpu.py tests/test_full_size_gpu.py tests/test_benchmark_molecules_gpu.py -m gpu -q -x ) > $O/butina_tests.log 2>&1
+      tail -3 $O/butina_tests.log
+      for L in "" $(ls nvmolkit_amd/lib/ | sed -n 's/^libnvmolkit_amd_\(.*\)\.so$/\1/p'); do
+        LIBP=$ROOT/nvmolkit_amd/lib/libnvmolkit_amd${L:+_$L}.so
+        echo "lib ${L:-product}" | tee -a $O/bench_butina.txt
+        NVMOLKIT_AMD_LIB=$LIBP timeout 300 python tools/bench_butina.py 2>/dev/null | tail -4 | tee -a $O/bench_butina.txt
+      done
+      ;;
+    dist_gpu)
+      ( time timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 -m pytest tests/test_distributed_gpu.py -m gpu -q -x ) > $O/dist_gpu.log 2>&1
+      tail -4 $O/dist_gpu.log
+      ;;
+    *) echo "unknown step $STEP" ;;
+  esac
+done
+echo "==== done ($(date +%T))"

@@ -3,16 +3,25 @@
 // the rest in HBM, exactly like bfgs_kernel), run `iters` passes with a pending rank-2 update.  Prints the time per pass
 // (whole launch / iters, and the mean of the workgroups' own clocks) and the HBM bytes the passes requested.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/ubench_hess.hip -o tools/ubench_hess
+//     [-DUBENCH_THREADS=64|128|256]  workgroup size (one, two or four waves per system; default 256)
+//     [-DNVMK_HESS_EXACT=0]          the round-3 pass with plain unconditional loads instead of the per-row buffer descriptors
+//     [-DNVMK_HESS_AUX_LOAD=2 -DNVMK_HESS_AUX_STORE=2]  cache-policy bits of the HBM row accesses
 //   tools/ubench_hess [n=192] [systems=4096] [ldsKB=79] [occ=2] [iters=50]
+// (ldsKB may be fractional: 19.5 = the share of a one-wave workgroup when eight of them sit on a CU)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+#ifndef UBENCH_THREADS
+#define UBENCH_THREADS 256
+#endif
+#define NVMK_BFGS_NS ub
+#define NVMK_BFGS_THREADS UBENCH_THREADS
 #include "../nvmolkit_amd/csrc/hess_pass.h"
 
-using namespace nvmk::minim::t256;
+using namespace nvmk::minim::ub;
 
 #define CHECK(x)                                                                      \
   do {                                                                                \
@@ -73,11 +82,11 @@ __global__ __launch_bounds__(NT, OCC) void pass_kernel(double* __restrict__ hess
 int main(int argc, char** argv) {
   const int n       = argc > 1 ? std::atoi(argv[1]) : 192;
   const int systems = argc > 2 ? std::atoi(argv[2]) : 4096;
-  const int ldsKB   = argc > 3 ? std::atoi(argv[3]) : 79;
+  const double ldsKB = argc > 3 ? std::atof(argv[3]) : 79;
   const int occ     = argc > 4 ? std::atoi(argv[4]) : 2;
   const int iters   = argc > 5 ? std::atoi(argv[5]) : 50;
   const size_t vecBytes = static_cast<size_t>(lds_vector_doubles(n)) * 8;
-  size_t       shmem    = std::max<size_t>(vecBytes, static_cast<size_t>(ldsKB) * 1024);
+  size_t       shmem    = std::max<size_t>(vecBytes, static_cast<size_t>(ldsKB * 1024) & ~size_t{15});
   shmem                 = std::min(shmem, vecBytes + static_cast<size_t>(hess_row_offset(n)) * 8);
   const int ldsDoubles  = static_cast<int>(shmem / 8);
   const int rl          = resident_rows(n, lds_hessian_doubles(ldsDoubles, n));
@@ -121,9 +130,9 @@ int main(int argc, char** argv) {
   for (long long t : ticks) meanTicks += static_cast<double>(t);
   meanTicks /= systems;
   const double hbmBytes = static_cast<double>(perSys) * 16.0 * systems * iters;
-  std::printf("{\"n\": %d, \"systems\": %d, \"lds_bytes\": %zu, \"occ\": %d, \"resident_rows\": %d, \"us_per_pass_per_workgroup\": %.2f, "
+  std::printf("{\"threads\": %d, \"exact\": %d, \"aux\": [%d, %d], \"n\": %d, \"systems\": %d, \"lds_bytes\": %zu, \"occ\": %d, \"resident_rows\": %d, \"us_per_pass_per_workgroup\": %.2f, "
               "\"launch_ms\": %.3f, \"passes_per_us_whole_gpu\": %.2f, \"hbm_GBps\": %.0f, \"checksum\": %.12g}\n",
-              n, systems, shmem, occ, rl, meanTicks * 0.01 / iters, ms, static_cast<double>(systems) * iters / (ms * 1e3),
+              NT, NVMK_HESS_EXACT, NVMK_HESS_AUX_LOAD, NVMK_HESS_AUX_STORE, n, systems, shmem, occ, rl, meanTicks * 0.01 / iters, ms, static_cast<double>(systems) * iters / (ms * 1e3),
               hbmBytes / (ms * 1e-3) / 1e9, sums[0]);
   return 0;
 }
