@@ -130,41 +130,6 @@ template <bool LDS_SUMS> __device__ __forceinline__ void add_to_sum(double* __re
   }
 }
 
-// ---- HBM rows: exact traffic through buffer descriptors ------------------------------------------------------------------
-// A row of the packed triangle is shorter than the 128 columns a wave instruction spans for every row below 128 (and in
-// its last chunk beyond): with plain 16-byte loads the lanes past the end of a row fetched the NEXT rows' data — 128 KB
-// requested per pass for the 83 KB triangle of a 144-coordinate system, reads 1.59 x their share in the counters
-// (profiles/r03_conformers/pmc_hbm_traffic_conformers.json).  HBM rows are therefore addressed through a buffer descriptor
-// PER ROW: base = the row's first entry (scalar), num_records = the row's padded length in bytes, lane offset = 8 c0 — the
-// hardware's range check drops the lanes past the row's end (no memory request, zeros returned, stores discarded), the
-// per-lane 64-bit address arithmetic disappears (one VGPR of byte offsets per chunk), and what the pass requests is the
-// triangle, once.  Everything about a descriptor is wave-uniform and lives on the scalar unit.
-#ifndef NVMK_HESS_AUX_LOAD
-#define NVMK_HESS_AUX_LOAD 0  // cache-policy bits of the HBM row loads / stores (experiments: 2 = nt)
-#endif
-#ifndef NVMK_HESS_AUX_STORE
-#define NVMK_HESS_AUX_STORE 0
-#endif
-#ifndef NVMK_HESS_EXACT
-#define NVMK_HESS_EXACT 1  // 0: the round-3 pass (plain, unconditional 16-byte loads) — kept for A/B builds
-#endif
-constexpr bool kHbmExact = NVMK_HESS_EXACT != 0;
-typedef unsigned int hess_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t hess_row_rsrc(double* rowStart, const int bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(rowStart, 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ double2 hess_buffer_load(const __amdgpu_buffer_rsrc_t rs, const int byteOffset) {
-  const hess_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byteOffset, 0, NVMK_HESS_AUX_LOAD);
-  return make_double2(__hiloint2double(static_cast<int>(v.y), static_cast<int>(v.x)), __hiloint2double(static_cast<int>(v.w), static_cast<int>(v.z)));
-}
-__device__ __forceinline__ void hess_buffer_store(const __amdgpu_buffer_rsrc_t rs, const int byteOffset, const double2 h) {
-  const hess_u32x4 v = {static_cast<unsigned>(__double2loint(h.x)), static_cast<unsigned>(__double2hiint(h.x)),
-                        static_cast<unsigned>(__double2loint(h.y)), static_cast<unsigned>(__double2hiint(h.y))};
-  __builtin_amdgcn_raw_buffer_store_b128(v, rs, byteOffset, 0, NVMK_HESS_AUX_STORE);
-}
-// bytes of row r (padded to an even number of entries)
-__host__ __device__ __forceinline__ int hess_row_bytes(const int r) { return ((r + 1) & ~1) * 8; }
-
 // Rows [rFrom, rEnd) of NCH adjacent column chunks; the matrix row `rBase` starts at H (LDS or HBM: the address space is
 // known at the call).  With PREFETCH (HBM rows) the NEXT group's matrix pairs are requested before the current group is
 // worked on — ahead of the current group's stores, so waiting for them does not wait for the stores (vmcnt is in-order).
@@ -172,7 +137,7 @@ __host__ __device__ __forceinline__ int hess_row_bytes(const int r) { return ((r
 // col[k][0..1] (mirrored-entry sums of the lane's columns) are carried by the caller across ranges.
 // Groups of four rows that lie entirely inside the range take a copy of the group code without the per-row range tests; the
 // last, partial group takes the one with them.
-template <int NCH, bool PREFETCH, bool LDS_SUMS, bool HBM>
+template <int NCH, bool PREFETCH, bool LDS_SUMS>
 __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBase, const int rFrom, const int rEnd, const int wave,
                                            const int lane, const HessChunk (&ck)[NCH], const bool pending,
                                            const double* __restrict__ xi, const double* __restrict__ hdg,
@@ -186,14 +151,8 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
       const int r = FULL ? r0 + NW * u : min(r0 + NW * u, rEnd - 1);  // rows past the range re-read the last one (never used)
-      if constexpr (HBM) {  // lanes past the end of the row: no request, zeros
-        const __amdgpu_buffer_rsrc_t rs = hess_row_rsrc(entry(r, 0), hess_row_bytes(r));
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) dst[u][k] = hess_buffer_load(rs, ck[k].c0 * 8);
-      } else {
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) dst[u][k] = *reinterpret_cast<const double2*>(entry(r, ck[k].c0));  // unconditional
-      }
+      for (int k = 0; k < NCH; ++k) dst[u][k] = *reinterpret_cast<const double2*>(entry(r, ck[k].c0));  // unconditional
     }
   };
   auto work = [&](const int r0, const double2 (&hv)[RU][NCH], auto fullTag) {
@@ -225,11 +184,7 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
               // the pad entry of an odd-length row stays 0 (its lane: c0 + 1 == r).  One-wave workgroups start their groups
               // on even rows (hess_pass), so every other row of a group has an even length and no pad at all.
               h.y = (NW == 1 && (u & 1) == 0) ? y : (c0 + 1 < r ? y : 0.0);
-              if constexpr (HBM) {
-                hess_buffer_store(hess_row_rsrc(entry(r, 0), hess_row_bytes(r)), c0 * 8, h);
-              } else {
-                *reinterpret_cast<double2*>(entry(r, c0)) = h;
-              }
+              *reinterpret_cast<double2*>(entry(r, c0)) = h;
             }
             col[k][0] += h.x * gr[u];  // every stored entry is strictly below the diagonal: it has a mirror image
             col[k][1] += h.y * gr[u];
@@ -279,7 +234,7 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
 // lane & 31 = the same pair of columns in both halves, four such row pairs (eight rows) per group.  Row sums are reduced
 // inside each half (wave_sum4_transposed without its last step), the mirrored-entry sums of the two halves are folded into
 // colOut[0..1] of lanes 0..31 at the end.  Halves the instructions these rows cost (a third of the rows at n = 144).
-template <bool PREFETCH, bool LDS_SUMS, bool HBM>
+template <bool PREFETCH, bool LDS_SUMS>
 __device__ __forceinline__ void hess_packed(double* __restrict__ H, const int rBase, const int rFrom, const int rEnd, const int lane,
                                             const HessChunk& ck, const bool pending, const double* __restrict__ xi,
                                             const double* __restrict__ hdg, const double* __restrict__ uu,
@@ -288,22 +243,11 @@ __device__ __forceinline__ void hess_packed(double* __restrict__ H, const int rB
   const int     half = lane >> 5;
   const int     base = hess_row_offset32(rBase);
   const int     c0   = ck.c0;  // 2 * (lane & 31)
-  // HBM: one descriptor per row PAIR (rows r, r + 1 are adjacent in memory): base = row r's first entry, bound = the end of
-  // row r + 1; the upper half's lanes past their row's end are dropped by the range check, the lower half's read entries of
-  // row r + 1 that the upper half requests in the same instruction anyway (same cache lines) or are dropped too
-  auto pair_rsrc = [&](const int rEven) {
-    return hess_row_rsrc(H + (hess_row_offset32(rEven) - base), (hess_row_offset32(rEven + 2) - hess_row_offset32(rEven)) * 8);
-  };
-  auto pair_offset = [&](const int rEven) { return (half ? hess_row_bytes(rEven) : 0) + c0 * 8; };  // rows are padded to even lengths
   auto load_group = [&](const int r0, double2 (&dst)[RU]) {
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-      if constexpr (HBM) {
-        dst[u] = hess_buffer_load(pair_rsrc(r0 + 2 * u), pair_offset(r0 + 2 * u));
-      } else {
-        const int r = r0 + 2 * u + half;
-        dst[u]      = *reinterpret_cast<const double2*>(H + (hess_row_offset32(r) - base) + c0);  // unconditional (tail pad / next rows)
-      }
+      const int r = r0 + 2 * u + half;
+      dst[u]      = *reinterpret_cast<const double2*>(H + (hess_row_offset32(r) - base) + c0);  // unconditional (tail pad / next rows)
     }
   };
   double2 next[RU];
@@ -332,11 +276,7 @@ __device__ __forceinline__ void hess_packed(double* __restrict__ H, const int rB
           h.x += xr * ck.xs0 - hr * ck.hs0 + ur * ck.us0;
           const double y = h.y + (xr * ck.xs1 - hr * ck.hs1 + ur * ck.us1);
           h.y            = two ? y : 0.0;
-          if constexpr (HBM) {
-            hess_buffer_store(pair_rsrc(r0 + 2 * u), pair_offset(r0 + 2 * u), h);
-          } else {
-            *reinterpret_cast<double2*>(H + (hess_row_offset32(r) - base) + c0) = h;
-          }
+          *reinterpret_cast<double2*>(H + (hess_row_offset32(r) - base) + c0) = h;
         }
         colAcc[0] += h.x * gr;
         colAcc[1] += h.y * gr;
@@ -429,8 +369,8 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __r
       // the chunk state of columns 2 (lane & 31), 2 (lane & 31) + 1 — the first 64 columns, in both halves of the wave
       hess_chunk_state<1>(ckp, colp, 0, lane & 31, n, pending, rfac, fad, fae, xi, hdg, uu, g);
       const int split = min(packedRows, Rl);  // a multiple of 8 (resident_rows)
-      if (split > 0) hess_packed<false, LDS_SUMS, false>(Hl, 0, 0, split, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
-      if (split < packedRows) hess_packed<PREFETCH, LDS_SUMS, kHbmExact>(Hg, Rl, split, packedRows, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
+      if (split > 0) hess_packed<false, LDS_SUMS>(Hl, 0, 0, split, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
+      if (split < packedRows) hess_packed<PREFETCH, LDS_SUMS>(Hg, Rl, split, packedRows, lane, ckp[0], pending, xi, hdg, uu, g, rowsum, colp[0]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {  // fold the two halves: lanes 0..31 keep the totals of their columns
         const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(colp[0][j]), __double2loint(colp[0][j]), false, false);
@@ -456,12 +396,12 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __r
       HessChunk(&ck1)[1]    = reinterpret_cast<HessChunk(&)[1]>(ck[0]);
       double(&col1)[1][2]   = reinterpret_cast<double(&)[1][2]>(col[0]);
       const int lo = max(cBase, packedRows), hi = mid;
-      if (lo < min(hi, Rl)) hess_range<1, false, LDS_SUMS, false>(Hl, 0, lo, min(hi, Rl), wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
-      if (max(lo, Rl) < hi) hess_range<1, PREFETCH, LDS_SUMS, kHbmExact>(Hg, Rl, max(lo, Rl), hi, wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
+      if (lo < min(hi, Rl)) hess_range<1, false, LDS_SUMS>(Hl, 0, lo, min(hi, Rl), wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
+      if (max(lo, Rl) < hi) hess_range<1, PREFETCH, LDS_SUMS>(Hg, Rl, max(lo, Rl), hi, wave, lane, ck1, pending, xi, hdg, uu, g, rowsum, col1);
     }
     if (mid < n) {
-      if (mid < Rl) hess_range<2, false, LDS_SUMS, false>(Hl, 0, mid, Rl, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
-      if (max(mid, Rl) < n) hess_range<2, PREFETCH, LDS_SUMS, kHbmExact>(Hg, Rl, max(mid, Rl), n, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
+      if (mid < Rl) hess_range<2, false, LDS_SUMS>(Hl, 0, mid, Rl, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
+      if (max(mid, Rl) < n) hess_range<2, PREFETCH, LDS_SUMS>(Hg, Rl, max(mid, Rl), n, wave, lane, ck, pending, xi, hdg, uu, g, rowsum, col);
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {  // this wave's mirrored-entry sums of its columns: single writer

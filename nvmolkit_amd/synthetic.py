@@ -560,3 +560,353 @@ def druglike_library(n_mols: int, seed: int = 20260926, mean_atoms: float = 48.0
         with mp.get_context("fork").Pool(procs) as pool:
             parts = pool.map(_druglike_worker, chunks)
     return [m for p in parts for m in p]
+
+
+# ---- real molecular graphs, synthetic parameters: BASELINE configs[2] on the reference's own molecules ----------------
+#
+# benchmarks/etkdg_bench.py:154-161 embeds the molecules of benchmarks/data/chembl_10k.smi after AddHs
+# (benchmarks/bench_utils/molprep.py:21-55).  The library's SMILES ingestion yields their graphs (atoms, bonds, ring
+# membership, hydrogen counts from RDKit's valence model); what is missing without RDKit is the parameter data (UFF bond
+# lengths for the bounds matrix, the experimental-torsion patterns, MMFF94 typing).  graph_molecule() therefore derives every
+# table from the REAL topology with generic parameters, the way RDKit's setTopolBounds does it from the graph alone: 1-2
+# bounds from covalent radii and bond orders, 1-3 from hybridisation / ring-size angles, 1-4 from the cis / trans extremes of
+# the torsion (ring and planar cases pinned), van der Waals floors beyond, triangle smoothing; chiral-centre candidates,
+# impropers at planar centres, torsion preferences by hybridisation; MMFF94-shaped terms with rest values = the same ideal
+# lengths and angles.  No hidden 3-D geometry is involved: whether an embedding succeeds is decided by the bounds, as in RDKit.
+
+_COVALENT = {1: 0.31, 5: 0.84, 6: 0.76, 7: 0.71, 8: 0.66, 9: 0.57, 14: 1.11, 15: 1.07, 16: 1.05, 17: 1.02, 33: 1.19, 34: 1.20,
+             35: 1.20, 53: 1.39}
+_ORDER_SHORTENING = {1: 0.0, 2: 0.18, 3: 0.32, 4: 0.40, 12: 0.12}
+
+
+def _graph_rings(n, nbr, ring_bonds, max_size=8):
+    """The smallest ring through every ring bond (BFS with the bond removed), as sorted tuples; rings beyond max_size are
+    treated as chains by the geometry rules."""
+    rings = set()
+    for a, b in ring_bonds:
+        prev = {a: -1}
+        frontier = [a]
+        found = False
+        for _depth in range(max_size - 1):
+            nxt = []
+            for u in frontier:
+                for v in nbr[u]:
+                    if (u == a and v == b) or v in prev:
+                        continue
+                    prev[v] = u
+                    if v == b:
+                        found = True
+                        break
+                    nxt.append(v)
+                if found:
+                    break
+            if found:
+                break
+            frontier = nxt
+        if found:
+            path, u = [], b
+            while u != -1:
+                path.append(u)
+                u = prev[u]
+            rings.add(tuple(sorted(path)))
+    return [set(r) for r in rings]
+
+
+def graph_molecule(atoms, bonds, rng, with_etk: bool = True, with_mmff: bool = True, max_atoms: int | None = None):
+    """Flattened ETKDG / MMFF tables of one molecule GRAPH as the SMILES ingestion returns it (``SmilesSet.graph``: atoms (n, 6)
+    [Z, charge, isotope, total Hs, aromatic, in ring], bonds (m, 4) [begin, end, RDKit bond type, in ring]) with explicit
+    hydrogens added.  Returns the dict of ``druglike_molecule`` without ``ref`` (there is no hidden geometry), or None when the
+    molecule has more than ``max_atoms`` atoms."""
+    atoms = np.asarray(atoms, dtype=np.int64).reshape(-1, 6)
+    bonds = np.asarray(bonds, dtype=np.int64).reshape(-1, 4)
+    n_heavy = len(atoms)
+    n = n_heavy + int(atoms[:, 3].sum())
+    if n < 2 or (max_atoms is not None and n > max_atoms):
+        return None
+    z = np.ones(n, dtype=np.int64)
+    z[:n_heavy] = atoms[:, 0]
+    nbr = [[] for _ in range(n)]
+    order = {}
+    blist = []
+    for a, b, t, _r in bonds:
+        a, b = int(a), int(b)
+        nbr[a].append(b)
+        nbr[b].append(a)
+        order[(a, b)] = order[(b, a)] = int(t)
+        blist.append((min(a, b), max(a, b)))
+    h = n_heavy
+    for a in range(n_heavy):
+        for _ in range(int(atoms[a, 3])):
+            nbr[a].append(h)
+            nbr[h].append(a)
+            order[(a, h)] = order[(h, a)] = 1
+            blist.append((a, h))
+            h += 1
+    hv = z > 1
+    aromatic = np.zeros(n, dtype=bool)
+    aromatic[:n_heavy] = atoms[:, 4] != 0
+    # hybridisation: 1 = sp, 2 = sp2, 3 = sp3
+    hyb = np.full(n, 3, dtype=np.int64)
+    for a in range(n_heavy):
+        orders = [order[(a, b)] for b in nbr[a]]
+        n_double = sum(1 for t in orders if t == 2)
+        if any(t == 3 for t in orders) or n_double >= 2:
+            hyb[a] = 1
+        elif aromatic[a] or n_double == 1:
+            hyb[a] = 2
+    for a in range(n_heavy):  # nitrogen (and oxygen in rings) next to a planar atom is planar itself (amides, anilines, pyrrole-type)
+        if hyb[a] == 3 and z[a] == 7 and len(nbr[a]) == 3 and any(hyb[b] <= 2 and z[b] > 1 for b in nbr[a]):
+            hyb[a] = 2
+    bonds_all = np.array(sorted(set(blist)), dtype=np.int64).reshape(-1, 2)
+    ring_bonds = [(int(a), int(b)) for a, b, _t, r in bonds if r]
+    rings = _graph_rings(n, nbr, ring_bonds)
+    atom_rings = [[k for k, r in enumerate(rings) if a in r] for a in range(n)]
+
+    def common_ring(*ats):
+        best = None
+        for k in atom_rings[ats[0]]:
+            if all(a in rings[k] for a in ats[1:]) and (best is None or len(rings[k]) < len(rings[best])):
+                best = k
+        return best
+
+    def bond_length(a, b):
+        r = _COVALENT.get(int(z[a]), 1.3) + _COVALENT.get(int(z[b]), 1.3) - _ORDER_SHORTENING.get(order[(a, b)], 0.0)
+        if order[(a, b)] == 1 and hyb[a] <= 2 and hyb[b] <= 2 and hv[a] and hv[b]:
+            r -= 0.04  # conjugated single bond
+        return r
+
+    def ring_angle(size, planar):
+        return {3: 60.0, 4: 90.0, 5: 108.0 if planar else 105.0, 6: 120.0 if planar else 111.0, 7: 124.0 if planar else 114.0,
+                8: 126.0 if planar else 115.0}[size]
+
+    def angle_at(i, j, k):
+        r = common_ring(i, j, k)
+        if r is not None:
+            return ring_angle(len(rings[r]), hyb[j] <= 2)
+        if hyb[j] == 1:
+            return 180.0
+        if atom_rings[j]:
+            size = min(len(rings[q]) for q in atom_rings[j])
+            inner = ring_angle(size, hyb[j] <= 2)
+            if hyb[j] == 2:
+                return (360.0 - inner) / 2.0
+            return {3: 117.0, 4: 113.0}.get(size, 109.5)
+        if hyb[j] == 2:
+            return 120.0
+        return 107.0 if z[j] == 7 else (105.0 if z[j] == 8 else (99.0 if z[j] == 16 and len(nbr[j]) == 2 else 109.5))
+
+    dist12 = {}
+    for a, b in bonds_all:
+        dist12[(int(a), int(b))] = dist12[(int(b), int(a))] = bond_length(int(a), int(b))
+    angles = np.array([(i, j, k) for j in range(n) for x, i in enumerate(nbr[j]) for k in nbr[j][x + 1:]], dtype=np.int64).reshape(-1, 3)
+    ang = np.deg2rad(np.array([angle_at(int(i), int(j), int(k)) for i, j, k in angles])) if len(angles) else np.zeros(0)
+    amap = {}
+    for (i, j, k), a in zip(angles, ang):
+        amap[(int(i), int(j), int(k))] = amap[(int(k), int(j), int(i))] = float(a)
+    torsions = np.array([(i, j, k, l) for j, k in bonds_all for i in nbr[j] if i != k for l in nbr[k] if l != j and l != i],
+                        dtype=np.int64).reshape(-1, 4)
+    topo = _topological_distances(n, bonds_all)
+    iu = np.triu_indices(n, 1)
+    pairs = np.stack(iu, 1).astype(np.int64)
+
+    # ---- bounds matrix --------------------------------------------------------------------------------------------
+    lb = np.zeros((n, n))
+    ub = np.full((n, n), 1000.0)
+    np.fill_diagonal(ub, 0.0)
+    floor = np.where(hv[:, None] & hv[None, :], 3.0, np.where(hv[:, None] | hv[None, :], 2.5, 2.0))
+    floor = np.where(topo == 4, floor * 0.8, floor)
+    lb[:] = floor
+    np.fill_diagonal(lb, 0.0)
+    for (a, b), r in dist12.items():
+        lb[a, b], ub[a, b] = r - 0.01, r + 0.01
+    d13 = {}
+    for (i, j, k), a in zip(angles, ang):
+        i, j, k = int(i), int(j), int(k)
+        if topo[i, k] != 2:
+            continue  # three-membered ring: the pair is bonded
+        r1, r2 = dist12[(i, j)], dist12[(j, k)]
+        d = float(np.sqrt(r1 * r1 + r2 * r2 - 2.0 * r1 * r2 * np.cos(a)))
+        if (i, k) in d13:  # two paths (four-membered ring): keep the mean, widen
+            d = 0.5 * (d + d13[(i, k)])
+        d13[(i, k)] = d13[(k, i)] = d
+        lb[i, k] = lb[k, i] = d - 0.04
+        ub[i, k] = ub[k, i] = d + 0.04
+    seen14 = {}
+    for (i, j, k, l) in torsions:
+        i, j, k, l = int(i), int(j), int(k), int(l)
+        if topo[i, l] != 3:
+            continue
+        a1, a2 = amap[(i, j, k)], amap[(j, k, l)]
+        r12, r23, r34 = dist12[(i, j)], dist12[(j, k)], dist12[(k, l)]
+        cis, trans = _d14(r12, r23, r34, a1, a2, 0.0), _d14(r12, r23, r34, a1, a2, np.pi)
+        rjk = common_ring(j, k)
+        planar_bond = hyb[j] <= 2 and hyb[k] <= 2 and (order[(j, k)] in (2, 12) or (rjk is not None and aromatic[j] and aromatic[k]))
+        if rjk is not None and i in rings[rjk] and l in rings[rjk]:
+            size = len(rings[rjk])
+            phi = 0.0 if (planar_bond or size <= 4) else np.deg2rad({5: 42.0, 6: 66.0, 7: 90.0, 8: 110.0}[size])
+            lo, hi = cis - 0.06, _d14(r12, r23, r34, a1, a2, phi) + 0.06
+        elif planar_bond and rjk is not None:
+            # substituents on a planar ring bond: one in the ring, one outside = trans; both outside = cis
+            inside = (i in rings[rjk]) + (l in rings[rjk])
+            lo, hi = (trans - 0.06, trans + 0.06) if inside == 1 else (cis - 0.06, cis + 0.06)
+        else:
+            lo, hi = cis - 0.06, trans + 0.06
+        key = (min(i, l), max(i, l))
+        if key in seen14:  # several paths between the same pair: the union of their windows
+            lo, hi = min(lo, seen14[key][0]), max(hi, seen14[key][1])
+        seen14[key] = (lo, hi)
+    for (i, l), (lo, hi) in seen14.items():
+        lb[i, l] = lb[l, i] = max(lo, 0.5)
+        ub[i, l] = ub[l, i] = hi
+    for k in range(n):  # triangle smoothing: upper bounds (shortest paths), then lower bounds
+        ub = np.minimum(ub, ub[:, k, None] + ub[None, k, :])
+    for k in range(n):
+        lb = np.maximum(lb, np.maximum(lb[:, k, None] - ub[None, k, :], lb[None, k, :] - ub[:, k, None]))
+    lb = np.minimum(lb, 0.99 * ub)  # generic parameters can contradict each other in strained cages: never an empty window
+    lbp, ubp, tp = lb[iu], ub[iu], topo[iu]
+
+    # ---- chiral-centre candidates and stereo checks ----------------------------------------------------------------
+    checks, chiral_idx, chiral_par = [], [], []
+    n_imp = 0
+    for a in range(n_heavy):
+        deg = len(nbr[a])
+        if deg == 4 and hyb[a] == 3:
+            nb = nbr[a]
+            checks.append((0, (a, nb[0], nb[1], nb[2], nb[3]), (1.0 if len(atom_rings[a]) >= 2 and min(len(rings[q]) for q in atom_rings[a]) <= 4 else 0.0,)))
+            heavy_nb = sum(1 for b in nb if hv[b])
+            if heavy_nb >= 3 and len(atom_rings[a]) <= 1 and z[a] in (6, 7, 14, 15, 16) and rng.random() < 0.35:
+                lo, hi = (5.0, 100.0) if rng.random() < 0.5 else (-100.0, -5.0)
+                chiral_idx.append(nb[:4])
+                chiral_par.append((lo, hi))
+                checks.append((1, (0, nb[0], nb[1], nb[2], nb[3]), (lo, hi)))
+                checks.append((3, (a, nb[0], nb[1], nb[2], nb[3]), ()))
+                for x in range(4):
+                    for y in range(x + 1, 4):
+                        checks.append((2, (nb[x], nb[y]), (lb[nb[x], nb[y]], ub[nb[x], nb[y]])))
+        if deg == 3 and hyb[a] == 2:
+            checks.append((5, (nbr[a][0], a, nbr[a][1]), ()))
+    dg = [(pairs, np.stack([lbp**2, ubp**2, np.ones(len(pairs))], 1)),
+          (np.array(chiral_idx, dtype=np.int64).reshape(-1, 4), np.array(chiral_par, dtype=np.float64).reshape(-1, 2)),
+          (np.arange(n, dtype=np.int64).reshape(-1, 1), np.zeros((n, 0)))]
+
+    etk = None
+    if with_etk:
+        t_idx, t_par, seen = [], [], set()
+        for (i, j, k, l) in torsions:
+            i, j, k, l = int(i), int(j), int(k), int(l)
+            if (j, k) in seen or common_ring(j, k) is not None or not (hv[i] and hv[l]) or hyb[j] == 1 or hyb[k] == 1:
+                continue
+            seen.add((j, k))
+            fc, sg = np.zeros(6), np.ones(6)
+            if hyb[j] == 3 and hyb[k] == 3:
+                fc[2] = rng.uniform(2.0, 6.0)
+            elif hyb[j] == 2 and hyb[k] == 2:
+                fc[1], sg[1] = rng.uniform(3.0, 8.0), -1.0
+            else:
+                fc[int(rng.integers(0, 6))] = rng.uniform(0.5, 3.0)
+                fc[2] += rng.uniform(0.0, 2.0)
+                sg = rng.choice([-1.0, 1.0], size=6)
+            t_idx.append((i, j, k, l))
+            t_par.append(np.concatenate([fc, sg]))
+        imp_idx, imp_par = [], []
+        for a in range(n_heavy):
+            if hyb[a] == 2 and len(nbr[a]) == 3:
+                n_imp += 1
+                x, y, w = nbr[a]
+                for (p, q, r) in ((x, y, w), (x, w, y), (y, w, x)):
+                    imp_idx.append((p, a, q, r))
+                    imp_par.append((1.0, -1.0, 0.0, 10.0))
+        centre = 0.5 * (lbp + ubp)
+
+        def fb(mask, tol, k):
+            sel = pairs[mask]
+            if tol is None:
+                lo, hi = lbp[mask], ubp[mask]
+            else:
+                lo, hi = centre[mask] - tol, centre[mask] + tol
+            return sel, np.stack([lo, hi, np.full(len(sel), k), np.zeros(len(sel))], 1)
+
+        lin = ang > np.deg2rad(175.0) if len(ang) else np.zeros(0, dtype=bool)
+        etk = [(np.array(t_idx, dtype=np.int64).reshape(-1, 4), np.array(t_par).reshape(-1, 12)),
+               (np.array(imp_idx, dtype=np.int64).reshape(-1, 4), np.array(imp_par).reshape(-1, 4)),
+               fb(tp == 1, 0.01, 100.0), fb(tp == 2, 0.01, 100.0),
+               (angles[lin], np.tile([179.0, 180.0], (int(lin.sum()), 1))),
+               fb(tp >= 3, None, 10.0)]
+    embed = dict(n_atoms=n, dg=dg, etk=etk, checks=checks, num_impropers=n_imp)
+    out = dict(embed=embed, bounds=(pairs, lbp, ubp), bonds=bonds_all, heavy=hv.copy(), elements=z.copy())
+
+    if with_mmff:
+        nb_ = len(bonds_all)
+        r0 = np.array([dist12[(int(a), int(b))] for a, b in bonds_all]) if nb_ else np.zeros(0)
+        b_h = ~(hv[bonds_all[:, 0]] & hv[bonds_all[:, 1]]) if nb_ else np.zeros(0, dtype=bool)
+        bond_par = np.stack([r0, np.where(b_h, rng.uniform(4.5, 5.5, nb_), rng.uniform(4.0, 9.0, nb_))], 1) if nb_ else np.zeros((0, 2))
+        th0 = np.degrees(ang)
+        linear = (th0 > 175.0).astype(float)
+        ang_par = np.stack([th0, rng.uniform(0.4, 1.1, len(ang)), linear], 1) if len(ang) else np.zeros((0, 3))
+        sb_par = np.stack([th0, [dist12[(int(i), int(j))] for i, j, _k in angles], [dist12[(int(k), int(j))] for _i, j, k in angles],
+                           np.where(linear > 0, 0.0, rng.uniform(0.0, 0.5, len(ang))), np.where(linear > 0, 0.0, rng.uniform(0.0, 0.5, len(ang)))], 1) \
+            if len(ang) else np.zeros((0, 5))
+        oop_c = [a for a in range(n_heavy) if hyb[a] == 2 and len(nbr[a]) == 3]
+        oop_idx = np.array([perm for a in oop_c for (x, y, w) in [tuple(nbr[a])] for perm in ((x, a, y, w), (x, a, w, y), (y, a, w, x))],
+                           dtype=np.int64).reshape(-1, 4)
+        oop_par = rng.uniform(0.01, 0.15, size=(len(oop_idx), 1))
+        if len(torsions):
+            lin_t = np.array([hyb[int(j)] == 1 or hyb[int(k)] == 1 for _i, j, k, _l in torsions])
+            tors = torsions[~lin_t]  # MMFF has no torsions about linear centres
+        else:
+            tors = torsions
+        planar_t = np.array([hyb[int(j)] <= 2 and hyb[int(k)] <= 2 and order[(int(j), int(k))] in (2, 12) for _i, j, k, _l in tors]) \
+            if len(tors) else np.zeros(0, dtype=bool)
+        tor_par = np.stack([rng.normal(scale=0.3, size=len(tors)),
+                            np.where(planar_t, rng.uniform(3.0, 7.0, len(tors)), rng.normal(scale=0.5, size=len(tors))),
+                            rng.uniform(0.0, 0.6, len(tors))], 1) if len(tors) else np.zeros((0, 3))
+        far = pairs[tp >= 3]
+        rstar = np.where(hv, rng.uniform(3.4, 4.0, n), rng.uniform(2.6, 3.0, n))
+        epsv = np.where(hv, rng.uniform(0.04, 0.12, n), rng.uniform(0.015, 0.03, n))
+        vdw_par = np.stack([0.5 * (rstar[far[:, 0]] + rstar[far[:, 1]]), np.sqrt(epsv[far[:, 0]] * epsv[far[:, 1]])], 1) \
+            if len(far) else np.zeros((0, 2))
+        q = rng.normal(scale=0.08, size=n)
+        q -= q.mean()
+        ele_par = np.stack([q[far[:, 0]] * q[far[:, 1]], np.ones(len(far)), (topo[far[:, 0], far[:, 1]] == 3).astype(float)], 1) \
+            if len(far) else np.zeros((0, 3))
+        out["mmff"] = [(bonds_all, bond_par), (angles, ang_par), (angles, sb_par), (oop_idx, oop_par), (tors, tor_par),
+                       (far, vdw_par), (far, ele_par)]
+    return out
+
+
+def _graph_worker(args):
+    seed, graphs, max_atoms = args
+    rng = np.random.default_rng(seed)
+    return [graph_molecule(a, b, rng, max_atoms=max_atoms) for a, b in graphs]
+
+
+def graph_library(graphs, seed: int = 20260927, max_atoms: int | None = None, processes: int | None = None):
+    """graph_molecule() for a list of (atoms, bonds) graphs, in parallel worker processes; deterministic for (graphs, seed)
+    whatever the process count (fixed chunks of 32 with per-chunk seeds).  Molecules beyond ``max_atoms`` come back as None."""
+    import os
+
+    chunks = [(seed + 1 + c, graphs[lo:lo + 32], max_atoms) for c, lo in enumerate(range(0, len(graphs), 32))]
+    procs = processes if processes is not None else min(len(chunks), max(1, (os.cpu_count() or 1) // 2), 64)
+    if procs <= 1 or len(chunks) <= 1:
+        parts = [_graph_worker(c) for c in chunks]
+    else:
+        import multiprocessing as mp
+
+        with mp.get_context("fork").Pool(procs) as pool:
+            parts = pool.map(_graph_worker, chunks)
+    return [m for p in parts for m in p]
+
+
+def smiles_file_library(path, n_mols: int | None = None, seed: int = 20260927, max_atoms: int | None = None,
+                        processes: int | None = None):
+    """The molecules of a .smi file (e.g. tests/golden/chembl_10k.smi = the reference's benchmarks/data/chembl_10k.smi) through
+    the library's own ingestion -> graph_molecule(): real topologies with explicit hydrogens, synthetic parameters.  Returns
+    (library without the molecules that were refused or exceed max_atoms, indices of the kept molecules)."""
+    from nvmolkit_amd.fingerprints import SmilesSet
+
+    s = SmilesSet.from_file(str(path))
+    ids = [i for i in range(len(s.status)) if s.status[i] == 0][:n_mols]
+    graphs = [s.graph(i) for i in ids]
+    lib = graph_library(graphs, seed=seed, max_atoms=max_atoms, processes=processes)
+    keep = [k for k, m in enumerate(lib) if m is not None]
+    return [lib[k] for k in keep], [ids[k] for k in keep]

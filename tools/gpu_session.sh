@@ -2,7 +2,7 @@
 # The ONE runner handed to gpurun (round 4 on; the per-call scripts of rounds 2-3 are summarised in tools/gpu_sessions/README.md):
 #   gpurun --timeout 1500 -- bash tools/gpu_session.sh <name> <step> [<step> ...]
 # Every step writes into gpurun_out/<name>/ and is wrapped in its own timeout.  Steps:
-#   ubench_hess         inverse-Hessian pass alone, full chip, exact vs padded loads, one / two / four waves per system
+#   ubench_hess         inverse-Hessian pass alone, full chip, one / two / four waves per system
 #   ubench_hess_pmc     FETCH_SIZE / WRITE_SIZE of the same (separate --pmc passes)
 #   parity_conformers   BFGS / ETKDG / force-field GPU parity tests
 #   ab_conformers       tools/bench_conformers.py --mols 10000 with every nvmolkit_amd/lib/libnvmolkit_amd_<variant>.so beside the product
@@ -37,47 +37,32 @@ for STEP in "$@"; do
   echo "==== $STEP ($(date +%T))"
   case $STEP in
     ubench_hess)
-      for T in 64 128 256; do for E in 0 1; do
-        hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DUBENCH_THREADS=$T -DNVMK_HESS_EXACT=$E tools/ubench_hess.hip -o /tmp/ubh_${T}_$E 2>/dev/null &
-      done; done
-      hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DUBENCH_THREADS=64 -DNVMK_HESS_AUX_LOAD=2 -DNVMK_HESS_AUX_STORE=2 tools/ubench_hess.hip -o /tmp/ubh_64_nt 2>/dev/null &
+      for T in 64 128 256; do
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DUBENCH_THREADS=$T tools/ubench_hess.hip -o /tmp/ubh_${T}_0 2>/dev/null &
+      done
       wait
       : > $O/ubench_hess.jsonl
-      for E in 0 1 nt; do
-        for N in 96 144 176; do timeout 60 /tmp/ubh_64_$E $N 16384 19.5 2 40 >> $O/ubench_hess.jsonl; done
-        timeout 60 /tmp/ubh_64_$E 144 256 19.5 2 40 >> $O/ubench_hess.jsonl     # one system per CU: latency, no contention
-      done
-      for E in 0 1; do
-        for N in 200 256; do timeout 60 /tmp/ubh_128_$E $N 8192 39.5 2 40 >> $O/ubench_hess.jsonl; done
-        for N in 192 300 384; do timeout 60 /tmp/ubh_256_$E $N 4096 79 2 40 >> $O/ubench_hess.jsonl; done
-      done
+      for N in 96 144 176; do timeout 60 /tmp/ubh_64_0 $N 16384 19.5 2 40 >> $O/ubench_hess.jsonl; done
+      timeout 60 /tmp/ubh_64_0 144 256 19.5 2 40 >> $O/ubench_hess.jsonl     # one system per CU: latency, no contention
+      for N in 200 256; do timeout 60 /tmp/ubh_128_0 $N 8192 39.5 2 40 >> $O/ubench_hess.jsonl; done
+      for N in 192 300 384; do timeout 60 /tmp/ubh_256_0 $N 4096 79 2 40 >> $O/ubench_hess.jsonl; done
       cat $O/ubench_hess.jsonl
       ;;
     ubench_hess_pmc)
       cd /tmp
-      for E in 0 1; do for C in FETCH_SIZE WRITE_SIZE; do
-        timeout 120 rocprofv3 --pmc $C -f csv -d $O/ubh_pmc_${E}_$C -- /tmp/ubh_64_$E 144 16384 19.5 2 40 > $O/ubh_pmc_${E}_$C.log 2>&1
-      done; done
+      for C in FETCH_SIZE WRITE_SIZE; do
+        timeout 120 rocprofv3 --pmc $C -f csv -d $O/ubh_pmc_$C -- /tmp/ubh_64_0 144 16384 19.5 2 40 > $O/ubh_pmc_$C.log 2>&1
+      done
       cd $ROOT
-      python - "$O" <<'PY'
+      python - "$O" <<'PY' | tee $O/ubench_hess_pmc.json
 import csv, glob, json, sys
-o = sys.argv[1]
 out = {}
-for e in (0, 1):
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        tot = 0.0
-        for f in glob.glob(f"{o}/ubh_pmc_{e}_{c}/**/*_counter_collection.csv", recursive=True):
-            for r in csv.DictReader(open(f)):
-                if "pass_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
-                    tot += float(r["Counter_Value"])
-        out[f"exact{e}_{c}_KiB"] = tot
-n, systems, iters = 144, 16384, 42   # the warm-up launch runs 2 passes, the timed one 40
-tri = (n * n // 2) * 8
-out["algorithmic_bytes_read_or_written"] = tri * systems * iters
-for e in (0, 1):
-    out[f"exact{e}_read_ratio"] = 2 * out[f"exact{e}_FETCH_SIZE_KiB"] * 1024 / out["algorithmic_bytes_read_or_written"]
-    out[f"exact{e}_write_ratio"] = out[f"exact{e}_WRITE_SIZE_KiB"] * 1024 / out["algorithmic_bytes_read_or_written"]
-json.dump(out, open(f"{o}/ubench_hess_pmc.json", "w"), indent=1)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    out[c + "_KiB"] = sum(float(r["Counter_Value"]) for f in glob.glob(f"{sys.argv[1]}/ubh_pmc_{c}/**/*_counter_collection.csv", recursive=True)
+                          for r in csv.DictReader(open(f)) if "pass_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c)
+tri = (144 * 144 // 2) * 8 * 16384 * 42   # warm-up launch 2 passes + timed launch 40
+out["read_ratio"] = 2 * out["FETCH_SIZE_KiB"] * 1024 / tri   # gfx950: FETCH_SIZE counts half the bytes of 128-byte requests
+out["write_ratio"] = out["WRITE_SIZE_KiB"] * 1024 / tri
 print(json.dumps(out, indent=1))
 PY
       ;;

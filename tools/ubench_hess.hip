@@ -4,8 +4,8 @@
 // (whole launch / iters, and the mean of the workgroups' own clocks) and the HBM bytes the passes requested.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/ubench_hess.hip -o tools/ubench_hess
 //     [-DUBENCH_THREADS=64|128|256]  workgroup size (one, two or four waves per system; default 256)
-//     [-DNVMK_HESS_EXACT=0]          the round-3 pass with plain unconditional loads instead of the per-row buffer descriptors
-//     [-DNVMK_HESS_AUX_LOAD=2 -DNVMK_HESS_AUX_STORE=2]  cache-policy bits of the HBM row accesses
+//     (with tools/experiments/hess_exact_rows.patch applied: -DNVMK_HESS_EXACT=0|1, -DNVMK_HESS_AUX_LOAD=2 -DNVMK_HESS_AUX_STORE=2 —
+//     HBM rows through per-row buffer descriptors, measured and rejected in round 4, profiles/r04_conformers/)
 //   tools/ubench_hess [n=192] [systems=4096] [ldsKB=79] [occ=2] [iters=50]
 // (ldsKB may be fractional: 19.5 = the share of a one-wave workgroup when eight of them sit on a CU)
 #include <hip/hip_runtime.h>
@@ -22,6 +22,11 @@
 #include "../nvmolkit_amd/csrc/hess_pass.h"
 
 using namespace nvmk::minim::ub;
+#ifndef NVMK_HESS_EXACT
+#define NVMK_HESS_EXACT 0
+#define NVMK_HESS_AUX_LOAD 0
+#define NVMK_HESS_AUX_STORE 0
+#endif
 
 #define CHECK(x)                                                                      \
   do {                                                                                \
