@@ -98,7 +98,8 @@ struct BfgsArgs {
   const int64_t*                  hessStarts;   // per-system offsets into `hessians` (slotDoubles == 0)
   const int32_t*                  order;        // the systems of this launch in hand-out order
   int                             nItems;
-  int*                            counter;      // persistent launches: next item to hand out (starts at 0); else nullptr
+  int*                            counter;      // persistent launches: eight counters, one per queue (all start at 0); else nullptr
+  int                             queueStart[9]; // persistent launches: queue q holds order[queueStart[q] .. queueStart[q + 1]) — one queue per XCD
   double*                         hessians;
   int64_t                         slotDoubles;  // > 0: workgroup k owns hessians[k * slotDoubles ...)
   double*                         vecWork;      // GVEC: workgroup k owns vecWork[k * vecStride ...)
@@ -389,6 +390,14 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   const bool waveClass = !opt::get(opt::kBfgsWave).is("0") && b.kind != NVMK_FF_QUARTIC;
   const bool allGlobal = opt::get(opt::kBfgsVectors).is("global");
   const bool overlap   = !opt::get(opt::kBfgsOverlap).is("0");
+  // NVMK_BFGS_SCHED: "queue" (default) = every class runs as persistent workgroups that take systems off per-XCD queues,
+  // largest first; "hw" = one workgroup per system, handed out by the hardware dispatcher (rounds 1-3).  With "hw" a freed
+  // wave slot goes to whichever class has the SMALLEST workgroups — a one-wave workgroup fits anywhere, a four-wave one needs
+  // half a CU at once — so the large classes starve as soon as the small ones are on the chip and a launch group ends with
+  // the LONGEST systems running alone (profiles/r04_conformers/bfgs_timeline_summary_before.json: 263 four-wave systems of a
+  // 16 384-attempt batch start only when the two-wave class is exhausted, at 135 of 151 ms).  Persistent workgroups keep their
+  // slots until their class is drained, so the classes finish largest first and a launch ends on the short systems.
+  const bool queueMode = !opt::get(opt::kBfgsSched).is("hw");
   auto       budget_of = [&](const int c) {
     return (c == 0 || c == kFirst128 || c == kFirst256) ? std::max(firstBudget, bin_budget(c)) : bin_budget(c);
   };
@@ -430,7 +439,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // (system_mol), so a run of kXcdGroup consecutive systems goes to ONE XCD: its L2 then holds a handful of molecules'
   // tables instead of one per resident workgroup.  Chunks of 8 * kXcdGroup systems keep the sizes balanced over the XCDs.
   // NVMK_BFGS_XCD_GROUP=1: plain order.
-  auto persistent = [&](const int c) { return c == kGlobal || kBins[c].wgPerCu == 1; };
+  auto persistent = [&](const int c) { return queueMode || c == kGlobal || kBins[c].wgPerCu == 1; };
   for (int c = 0; c < nBins; ++c) {
     if (persistent(c)) continue;
     const long    g         = opt::get(opt::kBfgsXcdGroup).num(16);
@@ -468,6 +477,8 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     size_t               shmem = 0;
     int                  ldsDoubles = 0, grid = 0;
     int64_t              slotDoubles = 0, vecStride = 0;
+    int                  queueStart[9] = {};
+    bool                 oneQueue = false;
     std::vector<int64_t> hs;  // one-system-per-workgroup bins: per-system offsets (indexed by system), else empty
     StreamScratch        hessMem, startsMem, orderMem, counterMem, vecMem;
   };
@@ -512,7 +523,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       }
       P.slotDoubles = ((slot + kHessTailPadDoubles) + 1) & ~int64_t{1};
       slotBytes[c]  = static_cast<size_t>(P.slotDoubles + P.vecStride) * sizeof(double);
-      P.grid        = static_cast<int>(std::min<size_t>(cls[c].order.size(), static_cast<size_t>(nCu) * (P.gvec ? 2 : 1)));
+      P.grid        = static_cast<int>(std::min<size_t>(cls[c].order.size(), static_cast<size_t>(nCu) * (P.gvec ? 2 : kBins[c].wgPerCu)));
     }
   }
   // A one-system-per-workgroup class holds the HBM part of EVERY system's inverse Hessian for the whole launch (16 384
@@ -541,6 +552,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
         slot         = std::max<int64_t>(slot, hess_row_offset(n) - hess_row_offset(rl));
       }
       P.persistent  = true;
+      P.oneQueue    = true;  // its order is already arranged for the hardware hand-out
       P.hs.clear();
       P.slotDoubles = ((slot + kHessTailPadDoubles) + 1) & ~int64_t{1};
       slotBytes[c]  = static_cast<size_t>(P.slotDoubles) * sizeof(double);
@@ -562,6 +574,29 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       }
     }
   }
+  // Queues of the persistent classes: runs of kXcdGroup consecutive systems (conformers of one molecule are neighbours in
+  // `order` and share their term tables) are dealt round-robin to eight queues, one per XCD — a workgroup takes from the
+  // queue of the XCD it runs on (its L2 then holds a handful of molecules' tables) and from the others' once that is empty.
+  // Every queue keeps the largest-first order.  Few items, or no shared tables: one queue.
+  for (int c = 0; c <= kGlobal; ++c) {
+    Plan& P = plan[c];
+    if (!P.used || !P.persistent) continue;
+    auto&         order = cls[c].order;
+    const int64_t n     = static_cast<int64_t>(order.size());
+    const long    g     = opt::get(opt::kBfgsXcdGroup).num(16);
+    const int     kXcdGroup = g >= 1 && g <= 4096 ? static_cast<int>(g) : 16;
+    for (int q = 0; q <= 8; ++q) P.queueStart[q] = q == 0 ? 0 : static_cast<int>(n);
+    if (P.oneQueue || b.sysMol == nullptr || kXcdGroup <= 1 || n < 16LL * kXcdGroup) continue;
+    std::vector<int32_t> queued;
+    queued.reserve(order.size());
+    for (int q = 0; q < 8; ++q) {
+      P.queueStart[q] = static_cast<int>(queued.size());
+      for (int64_t run = q; run * kXcdGroup < n; run += 8)
+        for (int64_t p = run * kXcdGroup; p < std::min<int64_t>(n, (run + 1) * kXcdGroup); ++p) queued.push_back(order[static_cast<size_t>(p)]);
+    }
+    P.queueStart[8] = static_cast<int>(queued.size());
+    order.swap(queued);
+  }
   for (int c = 0; c <= kGlobal; ++c) {
     Plan& P = plan[c];
     if (!P.used) continue;
@@ -574,8 +609,8 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       NVMK_HIP_CHECK(hipMemcpyAsync(P.startsMem.ptr, P.hs.data(), P.hs.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
     } else {
       NVMK_HIP_CHECK(P.hessMem.alloc(static_cast<size_t>(P.slotDoubles) * static_cast<size_t>(P.grid) * sizeof(double), stream));
-      NVMK_HIP_CHECK(P.counterMem.alloc(sizeof(int), stream));
-      NVMK_HIP_CHECK(hipMemsetAsync(P.counterMem.ptr, 0, sizeof(int), stream));
+      NVMK_HIP_CHECK(P.counterMem.alloc(8 * sizeof(int), stream));
+      NVMK_HIP_CHECK(hipMemsetAsync(P.counterMem.ptr, 0, 8 * sizeof(int), stream));
       if (P.gvec) NVMK_HIP_CHECK(P.vecMem.alloc(static_cast<size_t>(P.vecStride) * static_cast<size_t>(P.grid) * sizeof(double), stream));
     }
   }
@@ -611,6 +646,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     A.order       = P.orderMem.as<int32_t>();
     A.nItems      = static_cast<int>(cls[c].order.size());
     A.counter     = P.counterMem.as<int>();
+    for (int q = 0; q <= 8; ++q) A.queueStart[q] = P.queueStart[q];
     A.hessians    = P.hessMem.as<double>();
     A.slotDoubles = P.slotDoubles;
     A.vecWork     = P.vecMem.as<double>();

@@ -24,6 +24,7 @@ enum Id {
   kBfgsWave2,       // NVMK_BFGS_WAVE2       n (largest system, in coordinates, that two waves take; 0: none)
   kBfgsHessCapMb,   // NVMK_BFGS_HESS_CAP_MB n (tests: inverse-Hessian memory of a one-system-per-workgroup class before it runs persistent; default free / 4)
   kBfgsTimeline,    // NVMK_BFGS_TIMELINE    path (with NVMK_BFGS_PROFILE=1: per-system start / end clocks appended to this file)
+  kBfgsSched,       // NVMK_BFGS_SCHED       queue | hw (hw: one workgroup per system, hardware hand-out — rounds 1-3)
   kNumOptions
 };
 

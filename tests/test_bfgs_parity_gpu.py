@@ -112,6 +112,30 @@ def test_capped_hessian_memory_runs_the_class_persistently_with_the_same_bits():
     assert all(np.array_equal(a, b) for a, b in zip(out[""], out["1"]))
 
 
+def test_queue_and_hardware_hand_out_give_the_same_bits():
+    """NVMK_BFGS_SCHED: persistent workgroups taking systems off per-XCD queues (default) against one workgroup per system handed
+    out by the hardware — which workgroup minimises a system changes nothing about its arithmetic.  Shared term tables
+    (system_mol) so that the eight-queue arrangement is the one in use."""
+    lib = synthetic.druglike_library(40, seed=5, processes=1)
+    reps = 12
+    tables = [m["mmff"] for m in lib]
+    groups = stack_molecule_tables(MMFF, tables)
+    n_at = np.array([m["embed"]["n_atoms"] for m in lib])
+    sys_mol = np.repeat(np.arange(len(lib), dtype=np.int32), reps)
+    a_s = np.concatenate([[0], np.cumsum(n_at[sys_mol])])
+    rng = np.random.default_rng(3)
+    flat = np.concatenate([(lib[m]["ref"] + rng.normal(scale=0.1, size=lib[m]["ref"].shape)).reshape(-1) for m in sys_mol])
+    gpu = FlatForcefieldBatch(MMFF, a_s, groups, system_mol=sys_mol)
+    out = {}
+    for mode in ("hw", "queue"):
+        with _native.options(NVMK_BFGS_SCHED=mode):
+            pos = torch.from_numpy(flat).cuda()
+            e, st, it = gpu.minimize(pos, max_iters=25)
+            out[mode] = (pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy())
+    assert all(np.array_equal(a, b) for a, b in zip(out["hw"], out["queue"]))
+    assert out["queue"][2].max() == 25
+
+
 def test_druglike_mmff_minima_agree_statistically():
     """200-iteration MMFF runs on the benchmark's molecule generator, from perturbed reference geometries: per-system
     energies of GPU and oracle agree for the bulk of the systems (divergent trajectories may pick another local minimum)."""

@@ -69,6 +69,10 @@ torch.cuda.synchronize()
 t_prep = time.perf_counter() - t0
 embed_flat(FlatMoleculeSet([FlatMolecule(**library[0]["embed"])]), 1, 5)  # warm-up: module load, allocator pools
 torch.cuda.synchronize()
+from nvmolkit_amd import _native  # noqa: E402
+
+stats = torch.zeros(64, dtype=torch.int64, device="cuda")  # the kernels' own counters: systems, iterations, inverse-Hessian bytes
+_native.check(_native.lib().nvmk_bfgs_set_stats(stats.data_ptr()))
 best = None
 for _ in range(args.repeat):
     t0 = time.perf_counter()
@@ -84,6 +88,10 @@ for _ in range(args.repeat):
     if best is None or t_embed + t_mmff < best[0] + best[1]:
         best = (t_embed, t_mmff, dev.num_conformers, int(opt.converged.torch().sum().item()))
 t_embed, t_mmff, n_conf, n_converged = best
+_native.check(_native.lib().nvmk_bfgs_set_stats(None))
+st = stats.cpu().numpy().reshape(8, 8) // max(args.repeat, 1)
+bfgs = {name: {"systems": int(st[k, 0]), "iterations": int(st[k, 1]), "algorithmic_bytes": int(st[k, 2]), "energy_evaluations": int(st[k, 3]),
+               "hbm_requested_bytes": int(st[k, 4])} for k, name in ((0, "dg"), (1, "etk"), (2, "mmff"))}
 if world > 1:  # whole-job numbers: sums of work, max of time
     t = torch.tensor([t_embed, t_mmff], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -101,4 +109,4 @@ print(json.dumps({
     "etkdg_s": t_embed, "etkdg_conformers": n_conf, "etkdg_confs_per_s": n_conf / t_embed,
     "mmff_s": t_mmff, "mmff_confs_per_s": n_conf / t_mmff, "mmff_max_iters": args.mmff_iters,
     "mmff_converged_frac": n_converged / max(n_conf, 1),
-    "mols_per_s_etkdg_plus_mmff": n_mols / (t_embed + t_mmff), "host_prep_s": t_prep}))
+    "mols_per_s_etkdg_plus_mmff": n_mols / (t_embed + t_mmff), "host_prep_s": t_prep, "bfgs": bfgs}))

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/pmc_traffic
 MOLS=${1:-2000}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/tools/bench_conformers.py --mols $MOLS"
+BENCH="python $ROOT/tools/bench_conformers.py --mols $MOLS --cache /tmp/nvmk_lib_cache ${BENCH_EXTRA:-}"
 export NVMK_ROOT=$ROOT
 timeout 900 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/conf_fetch -- $BENCH > $OUT/conf_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/conf_write -- $BENCH > $OUT/conf_write.log 2>&1
@@ -31,11 +31,21 @@ for name, sub in (("FETCH_SIZE", "conf_fetch"), ("WRITE_SIZE", "conf_write")):
                 k = r["Kernel_Name"].split("(")[0].replace("void nvmk::minim::", "")
                 per[k] = per.get(k, 0.0) + float(r["Counter_Value"])
     out[name] = {"KiB_by_kernel": per, "KiB_total": sum(per.values())}
+    out[name]["bytes_by_kind"] = {kind: sum(v for k, v in per.items() if f"bfgs_kernel<{i}," in k) * 1024.0 * (2.0 if name == "FETCH_SIZE" else 1.0)
+                                  for i, kind in enumerate(("dg", "etk", "mmff"))}
+for line in open(f"{sys.argv[1]}/conf_fetch.log"):
+    if line.startswith("{") and "bfgs" in line:   # the kernels' own counters of the same run: bytes the passes requested from HBM
+        run = json.loads(line)["bfgs"]
+        out["by_kind"] = {kind: {"requested_read_or_write_bytes": v["hbm_requested_bytes"] / 2.0, "iterations": v["iterations"],
+                                 "energy_evaluations": v["energy_evaluations"],
+                                 "read_ratio": out["FETCH_SIZE"]["bytes_by_kind"][kind] / max(v["hbm_requested_bytes"] / 2.0, 1.0),
+                                 "write_ratio": out["WRITE_SIZE"]["bytes_by_kind"][kind] / max(v["hbm_requested_bytes"] / 2.0, 1.0)}
+                          for kind, v in run.items()}
 if out.get("conformers"):
     # gfx950 counts FETCH_SIZE in 64-byte units of 128-byte requests: doubled (MI355X_MICROARCH.md, HBM section)
     out["hbm_bytes_per_conformer"] = (2.0 * out["FETCH_SIZE"]["KiB_total"] + out["WRITE_SIZE"]["KiB_total"]) * 1024.0 / out["conformers"]
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/bench_conformers.py --mols N; sums over "
                "every bfgs_kernel launch of ETKDG + MMFF (warm-up call included: one molecule)")
 json.dump(out, open(f"{sys.argv[1]}/pmc_hbm_traffic_conformers.json", "w"), indent=1)
-print(json.dumps(out, indent=1)[:1500])
+print(json.dumps(out.get("by_kind", out), indent=1)[:2500])
 PY
