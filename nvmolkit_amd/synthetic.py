@@ -358,16 +358,18 @@ def _topological_distances(n, bonds):
 
     b = np.asarray(bonds, dtype=np.int64).reshape(-1, 2)
     adj = coo_matrix((np.ones(len(b)), (b[:, 0], b[:, 1])), shape=(n, n)).tocsr()
-    return shortest_path(adj, directed=False, unweighted=True).astype(np.int64)
+    d = shortest_path(adj, directed=False, unweighted=True)
+    return np.where(np.isfinite(d), d, 1.0e6).astype(np.int64)  # atoms of different fragments (salts): "far apart"
 
 
 def _d14(r12, r23, r34, a123, a234, phi):
-    """1-4 distance for bond lengths, angles (rad) and dihedral phi."""
-    x1 = np.array([-r12 * np.cos(a123), r12 * np.sin(a123), 0.0]) * np.array([-1.0, 1.0, 1.0])  # atom 1, atom 2 at origin, 3 on +x
-    p1 = np.array([r12 * np.cos(a123), r12 * np.sin(a123), 0.0])
-    p4 = np.array([r23 - r34 * np.cos(a234), r34 * np.sin(a234) * np.cos(phi), r34 * np.sin(a234) * np.sin(phi)])
-    del x1
-    return float(np.linalg.norm(p1 - p4))
+    """1-4 distance for bond lengths, angles (rad) and dihedral phi (atom 2 at the origin, atom 3 on +x)."""
+    import math
+
+    x1, y1 = r12 * math.cos(a123), r12 * math.sin(a123)
+    s = r34 * math.sin(a234)
+    x4, y4, z4 = r23 - r34 * math.cos(a234), s * math.cos(phi), s * math.sin(phi)
+    return math.sqrt((x1 - x4) ** 2 + (y1 - y4) ** 2 + z4 * z4)
 
 
 def druglike_molecule(rng, n_atoms: int, with_etk: bool = True, with_mmff: bool = True):
@@ -772,7 +774,10 @@ def graph_molecule(atoms, bonds, rng, with_etk: bool = True, with_mmff: bool = T
         deg = len(nbr[a])
         if deg == 4 and hyb[a] == 3:
             nb = nbr[a]
-            checks.append((0, (a, nb[0], nb[1], nb[2], nb[3]), (1.0 if len(atom_rings[a]) >= 2 and min(len(rings[q]) for q in atom_rings[a]) <= 4 else 0.0,)))
+            # RDKit (findChiralSets) tests the tetrahedral shape only of C / N centres shared by two or more rings, none of them
+            # a three-membered one; the flag marks fused small rings (the check then accepts a quarter of the volume)
+            if z[a] in (6, 7) and len(atom_rings[a]) >= 2 and min(len(rings[q]) for q in atom_rings[a]) > 3:
+                checks.append((0, (a, nb[0], nb[1], nb[2], nb[3]), (1.0 if min(len(rings[q]) for q in atom_rings[a]) <= 4 else 0.0,)))
             heavy_nb = sum(1 for b in nb if hv[b])
             if heavy_nb >= 3 and len(atom_rings[a]) <= 1 and z[a] in (6, 7, 14, 15, 16) and rng.random() < 0.35:
                 lo, hi = (5.0, 100.0) if rng.random() < 0.5 else (-100.0, -5.0)

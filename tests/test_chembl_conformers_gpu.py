@@ -1,0 +1,79 @@
+"""BASELINE configs[2] on the reference's own molecules: the 10 000 SMILES of benchmarks/data/chembl_10k.smi (committed as
+tests/golden/chembl_10k.smi) through the library's ingestion, explicit hydrogens from the valence model, ETKDG (10 conformers)
+chained on the device into MMFF94 (maxIters 200) — real topologies, generic parameters (synthetic.graph_molecule; RDKit's
+parameter tables are in neither image).  Molecules beyond 128 atoms (10.5 % of the file: peptides and macrocycles up to 1063
+atoms) are left out, as the benchmark block does.  Checked like the synthetic set (tests/test_config_size_gpu.py): counts,
+distance bounds of sampled conformers, energies against the C oracle, and the whole pipeline against the oracle's pipeline
+on a subset."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from nvmolkit_amd import mmffOptimization, synthetic
+from nvmolkit_amd.embedMolecules import FlatMolecule, FlatMoleculeSet, embed_flat
+from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch, stack_molecule_tables
+from nvmolkit_amd.types import CoordinateOutput
+from oracle import ffc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def chembl():
+    lib, ids = synthetic.smiles_file_library(GOLDEN / "chembl_10k.smi", max_atoms=128)
+    molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in lib])
+    dev = embed_flat(molset, confs_per_molecule=10, max_iterations=10, seed=1, output=CoordinateOutput.DEVICE)
+    opt = mmffOptimization.optimize_device([m["mmff"] for m in lib], dev, max_iters=200)
+    torch.cuda.synchronize()
+    return lib, dev, opt
+
+
+def test_most_molecules_get_their_ten_conformers_within_the_bounds(chembl):
+    lib, dev, _ = chembl
+    assert 8800 <= len(lib) <= 9100                                   # 8948 of the 10 000 have at most 128 atoms
+    sizes = np.array([m["embed"]["n_atoms"] for m in lib])
+    assert 50 <= sizes.mean() <= 62 and sizes.max() <= 128            # with hydrogens: the size classes see a real tail
+    per_mol = np.bincount(dev.mol_indices.torch().cpu().numpy(), minlength=len(lib))
+    assert per_mol.max() <= 10 and (per_mol == 10).mean() > 0.85 and (per_mol > 0).mean() > 0.93
+    xyz = dev.values.torch().cpu().numpy()
+    a_s = dev.atom_starts.torch().cpu().numpy()
+    mol_of = dev.mol_indices.torch().cpu().numpy()
+    worst = []
+    for c in np.random.default_rng(0).choice(dev.num_conformers, size=400, replace=False):
+        pairs, lb, ub = lib[mol_of[c]]["bounds"]
+        p = xyz[a_s[c]:a_s[c + 1]]
+        d = np.linalg.norm(p[pairs[:, 0]] - p[pairs[:, 1]], axis=1)
+        worst.append(float(np.max(np.maximum(np.maximum(lb - d, d - ub), 0.0) / ub)))
+    assert np.median(worst) < 0.08 and np.percentile(worst, 95) < 0.25 and max(worst) < 0.9
+
+
+def test_mmff_energies_decrease_and_equal_the_oracle_energy(chembl):
+    lib, dev, opt = chembl
+    tables = [m["mmff"] for m in lib]
+    a_s = dev.atom_starts.torch().cpu().numpy()
+    mol_of = dev.mol_indices.torch().to(torch.int32)
+    batch = FlatForcefieldBatch(MMFF, a_s, stack_molecule_tables(MMFF, tables), system_mol=mol_of)
+    e0 = batch.compute_energy(dev.values.torch().reshape(-1).contiguous())
+    e1 = opt.energies.torch()
+    assert bool((e1 <= e0 + 1e-9).all())
+    sel = np.sort(np.random.default_rng(1).choice(dev.num_conformers, size=256, replace=False))
+    xyz = opt.values.torch().cpu().numpy()
+    sub_as = np.concatenate([[0], np.cumsum(np.diff(a_s)[sel])])
+    sub_pos = np.concatenate([xyz[a_s[c]:a_s[c + 1]].reshape(-1) for c in sel])
+    cpu = ffc.Batch(MMFF, sub_as, stack_molecule_tables(MMFF, tables), system_mol=mol_of.cpu().numpy()[sel])
+    np.testing.assert_allclose(e1.cpu().numpy()[sel], cpu.energy(sub_pos), rtol=1e-9, atol=1e-8)
+
+
+def test_pipeline_equals_the_oracle_pipeline_per_population():
+    lib, _ = synthetic.smiles_file_library(GOLDEN / "chembl_10k.smi", n_mols=260, max_atoms=64, processes=4)
+    lib = lib[:96]
+    mols = [FlatMolecule(**m["embed"]) for m in lib]
+    gpu = embed_flat(FlatMoleculeSet(mols), confs_per_molecule=4, max_iterations=10, seed=3)
+    coords, counts, slots, fails, _ = ffc.etkdg_embed(mols, confs_per_molecule=4, max_iterations=10, seed=3, batch_size=4096)
+    assert abs(int(gpu.conf_counts.sum()) - int(counts.sum())) <= 0.03 * counts.sum()
+    assert np.mean(np.asarray(gpu.conf_counts) == np.asarray(counts)) >= 0.9
+    assert np.all(np.abs(gpu.stage_failures - fails) <= np.maximum(3, 0.25 * np.maximum(gpu.stage_failures, fails)))

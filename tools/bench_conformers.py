@@ -30,6 +30,10 @@ ap.add_argument("--batch-size", type=int, default=-1)
 ap.add_argument("--mmff-iters", type=int, default=200)
 ap.add_argument("--batches-per-gpu", type=int, default=-1)
 ap.add_argument("--repeat", type=int, default=1, help="timed repetitions (the best is reported)")
+ap.add_argument("--set", default="synthetic", choices=("synthetic", "chembl"),
+                help="synthetic: generated drug-like graphs (clipped N(48, 12) atoms); chembl: the topologies of tests/golden/chembl_10k.smi "
+                "(the reference's benchmarks/data/chembl_10k.smi) with explicit hydrogens and generic parameters (synthetic.graph_molecule)")
+ap.add_argument("--max-atoms", type=int, default=128, help="chembl: molecules with more atoms (hydrogens included) are left out")
 ap.add_argument("--cache", default="", help="directory for the generated molecule library (pickle): A/B runs of several builds in one "
                 "session then generate it once")
 args = ap.parse_args()
@@ -43,11 +47,15 @@ t0 = time.perf_counter()
 def load_library():
     import pickle
 
-    path = Path(args.cache) / f"druglike_{args.mols}_{args.mean_atoms}.pkl" if args.cache else None
+    tag = f"druglike_{args.mols}_{args.mean_atoms}" if args.set == "synthetic" else f"chembl_{args.mols}_{args.max_atoms}"
+    path = Path(args.cache) / f"{tag}.pkl" if args.cache else None
     if path is not None and path.exists():
         with open(path, "rb") as f:
             return pickle.load(f)
-    lib = synthetic.druglike_library(args.mols, seed=20260926, mean_atoms=args.mean_atoms)
+    if args.set == "chembl":
+        lib, _ = synthetic.smiles_file_library(ROOT / "tests" / "golden" / "chembl_10k.smi", n_mols=args.mols, max_atoms=args.max_atoms)
+    else:
+        lib = synthetic.druglike_library(args.mols, seed=20260926, mean_atoms=args.mean_atoms)
     if path is not None and rank == 0:
         path.parent.mkdir(parents=True, exist_ok=True)
         with open(str(path) + ".tmp", "wb") as f:
@@ -103,7 +111,10 @@ if world > 1:  # whole-job numbers: sums of work, max of time
     dist.destroy_process_group()
     if rank != 0:
         sys.exit(0)
+sizes = np.array([m["embed"]["n_atoms"] for m in library])
 print(json.dumps({
+    "set": args.set, "atoms_percentiles_5_25_50_75_95_max": [int(x) for x in np.percentile(sizes, [5, 25, 50, 75, 95, 100])],
+    "molecules_with_10_conformers": None if world > 1 else int((np.bincount(dev.mol_indices.torch().cpu().numpy(), minlength=n_mols) >= args.confs).sum()),
     "n_gpus": world, "mols": n_mols, "confs_per_mol": args.confs,
     "mean_atoms": float(np.mean([m["embed"]["n_atoms"] for m in library])),
     "etkdg_s": t_embed, "etkdg_conformers": n_conf, "etkdg_confs_per_s": n_conf / t_embed,
