@@ -6,6 +6,9 @@
 #   ubench_hess_pmc     FETCH_SIZE / WRITE_SIZE of the same (separate --pmc passes)
 #   parity_conformers   BFGS / ETKDG / force-field GPU parity tests
 #   ab_conformers       tools/bench_conformers.py --mols 10000 with every nvmolkit_amd/lib/libnvmolkit_amd_<variant>.so beside the product
+#   ab_sched            bench_conformers with NVMK_BFGS_SCHED=hw and queue, alternating
+#   conformer_traffic_seq  the PMC passes with the size classes one after the other (NVMK_BFGS_OVERLAP=0)
+#   chembl_tests        tests/test_chembl_conformers_gpu.py
 #   timeline            BFGS per-system timeline of one 10 000-molecule run (NVMK_BFGS_PROFILE=1 NVMK_BFGS_TIMELINE)
 #   conformer_traffic   tools/profile_conformer_traffic.sh 2000
 #   pytest_gpu          the whole -m gpu suite
@@ -78,6 +81,23 @@ PY
           NVMOLKIT_AMD_LIB=$LIBP timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --cache $CACHE 2>/dev/null | pick "${L:-product}" | tee -a $O/ab_conformers.txt
         done
       done
+      ;;
+    ab_sched)
+      : > $O/ab_sched.txt
+      for i in 1 2; do
+        for M in hw queue; do
+          NVMK_BFGS_SCHED=$M timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --cache $CACHE 2>/dev/null | pick "sched=$M" | tee -a $O/ab_sched.txt
+        done
+      done
+      ;;
+    conformer_traffic_seq)
+      NVMK_BFGS_OVERLAP=0 timeout 900 bash tools/profile_conformer_traffic.sh 2000 > $O/conformer_traffic_seq.log 2>&1
+      cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/pmc_hbm_traffic_conformers_classes_one_after_the_other.json 2>/dev/null
+      tail -30 $O/conformer_traffic_seq.log
+      ;;
+    chembl_tests)
+      ( time timeout 900 python -m pytest tests/test_chembl_conformers_gpu.py -m gpu -q -x ) > $O/chembl_tests.log 2>&1
+      tail -15 $O/chembl_tests.log
       ;;
     timeline)
       rm -f $O/bfgs_timeline.txt
