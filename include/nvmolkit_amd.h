@@ -49,6 +49,33 @@ int nvmk_abi_version(void);
 int nvmk_device_count(int* count);
 /* Free / total bytes on the current device (reference: getDeviceFreeMemory, src/utils/device.h). */
 int nvmk_device_memory(size_t* free_bytes, size_t* total_bytes);
+
+/* ---- multi-GPU contract: device set, peer copies, the one collective of the path -------------------------------------
+ * One process per GPU is the scaling model (BASELINE.json: molecule batches shard with no collective; only the N x M
+ * cross-similarity assembles the sharded reference fingerprints with an all-gather over xGMI), one process driving several
+ * GPUs the reference's (BatchHardwareOptions::gpuIds, src/hardware_options.h:26-35).  Both are served:
+ *
+ * nvmk_set_devices : the GPUs this process works on (n = 0: all visible) with peer access enabled between every pair, both
+ *                    ways, idempotent (reference: enablePeerAccess, src/utils/p2p.cpp:30-58).  nvmk_get_devices reads the set.
+ * nvmk_copy_peer_async : d_src on src_device (ordered after src_stream's work so far) -> d_dst on dst_device, on dst_stream
+ *                    (reference: copyDeviceToDeviceAsync, src/utils/p2p.cpp:60-86; caller device_coord_collector.cpp:86-109,
+ *                    which stitches per-GPU conformer blocks on the target GPU).
+ * nvmk_allgather_rows : every rank contributes rows_per_rank rows of words_per_row uint32 (packed fingerprints) and receives
+ *                    all ranks' rows in rank order: ncclAllGather over RCCL on `stream` (asynchronous).  `comm` is an
+ *                    ncclComm_t — the caller's own, or one made with the three helpers below (thin wrappers of
+ *                    ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy; the 128-byte id travels from rank 0 to the
+ *                    others by whatever means the host has: MPI, a file, a socket).  RCCL is resolved at run time from the
+ *                    process (a communicator belongs to the RCCL copy that made it) or from librccl.so.1; the library
+ *                    does not link against it.  The reference has no counterpart: it drives every GPU from one process. */
+int nvmk_set_devices(const int32_t* device_ids, int n);
+int nvmk_get_devices(int32_t* device_ids, int capacity, int* n);
+int nvmk_copy_peer_async(void* d_dst, int dst_device, void* dst_stream, const void* d_src, int src_device, void* src_stream,
+                         size_t bytes);
+int nvmk_comm_unique_id(char id[128]);
+int nvmk_comm_init_rank(void** comm, int n_ranks, const char id[128], int rank);
+int nvmk_comm_destroy(void* comm);
+int nvmk_allgather_rows(void* comm, const uint32_t* d_send, int64_t rows_per_rank, int words_per_row, uint32_t* d_recv,
+                        void* stream);
 /* Tuning / test switches (the NVMK_* names of DESIGN.md section 5: NVMK_SIM_PATH, NVMK_BFGS_LDS, ...).  The environment is
  * read ONCE per process, when the first switch is looked up; afterwards a switch changes only through nvmk_set_option
  * (value NULL or "" = unset), which is safe against concurrent callers of the other entry points: each call takes one
@@ -378,6 +405,17 @@ typedef struct nvmk_etkdg_params {
 
 int nvmk_etkdg_embed(const nvmk_etkdg_molset* mols, const nvmk_etkdg_params* params, double* d_coords,
                      int32_t* h_conf_counts, int32_t* h_stage_failures, void* stream);
+
+/* Per-stage wall-clock table of the LAST nvmk_etkdg_embed call of the process that ran with the option NVMK_ETKDG_TIMING=1
+ * (reference: ETKDGDriver's debug mode, src/etkdg_impl.cpp:126-139 recordStageTiming, :161-200 printTimingStatistics: total /
+ * min / max / calls per stage).  Rows 0 .. NVMK_ETKDG_N_STAGES - 1 are the stages (one entry per batch), row NVMK_ETKDG_N_STAGES
+ * the host work of a batch outside its stages (scheduler dispatch, uploads, record, pack), row NVMK_ETKDG_N_STAGES + 1 the
+ * whole call.  With the option set every stage ends with a stream synchronisation (what makes the clock meaningful), which
+ * costs throughput; without it nothing is recorded.  `names` (optional) receives pointers to static strings — the stage
+ * names of the reference's pipeline.  Every entry point, ETKDG stage and BFGS size class additionally opens a roctx range
+ * (reference: ScopedNvtxRange, src/utils/nvtx.h:36-69) — `rocprofv3 --marker-trace`; option NVMK_MARKERS=0 turns them off. */
+#define NVMK_ETKDG_TIMING_ROWS (NVMK_ETKDG_N_STAGES + 2)
+int nvmk_etkdg_stage_timings(double* total_ms, double* min_ms, double* max_ms, int32_t* calls, int n_rows, const char** names);
 
 /* Units of the pipeline above exposed on their own so that E2 / E3 can be tested the way the reference tests them.
  *

@@ -95,6 +95,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> Path
             "-Wl,-rpath,/opt/rocm/lib",
             "-Wl,--no-undefined",
             "-lpthread",
+            "-ldl",
         ]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -45,6 +45,13 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_abi_version": (_int, []),
     "nvmk_device_count": (_int, [ctypes.POINTER(_int)]),
     "nvmk_device_memory": (_int, [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "nvmk_set_devices": (_int, [_vp, _int]),
+    "nvmk_get_devices": (_int, [_vp, _int, ctypes.POINTER(_int)]),
+    "nvmk_copy_peer_async": (_int, [_vp, _int, _vp, _vp, _int, _vp, ctypes.c_size_t]),
+    "nvmk_comm_unique_id": (_int, [_vp]),
+    "nvmk_comm_init_rank": (_int, [_vp, _int, _vp, _int]),
+    "nvmk_comm_destroy": (_int, [_vp]),
+    "nvmk_allgather_rows": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "nvmk_set_option": (_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "nvmk_get_option": (_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]),
     "nvmk_cross_tanimoto_f64": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _i64, _vp]),
@@ -73,6 +80,7 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_scheduler_dispatch": (_int, [_vp, _int, _vp, ctypes.POINTER(_int)]),
     "nvmk_scheduler_record": (_int, [_vp, _vp, _vp, _int]),
     "nvmk_etkdg_embed": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "nvmk_etkdg_stage_timings": (_int, [_vp, _vp, _vp, _vp, _int, _vp]),
     "nvmk_etkdg_random_coords": (_int, [ctypes.c_uint64, ctypes.c_uint64, _int, _vp, _vp, ctypes.c_double, _vp, _vp]),
     "nvmk_etkdg_driver_run": (_int, [_int, _int, _int, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32),
                                      ctypes.POINTER(ctypes.c_int32), _vp]),

@@ -1952,6 +1952,7 @@ extern "C" {
 int nvmk_neighbor_counts(int metric, const uint32_t* d_x, const int32_t* d_x_rows, int64_t nX, const uint32_t* d_y,
                          const int32_t* d_y_rows, int64_t nY, int fp_bits, float threshold, int sign,
                          int32_t* d_counts, void* stream) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(sign == 1 || sign == -1, "neighbor counts: sign must be +1 or -1, got %d", sign);
   NVMK_REQUIRE(nX >= 0 && nY >= 0, "neighbor counts: negative row count");
   if (nX == 0 || nY == 0) return NVMK_OK;
@@ -1989,6 +1990,7 @@ int nvmk_neighbor_counts(int metric, const uint32_t* d_x, const int32_t* d_x_row
 int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, double cutoff,
                       int32_t* h_cluster_indices, int64_t* h_offsets, int32_t* h_centroids, int64_t* n_clusters,
                       void* stream) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(metric == NVMK_METRIC_TANIMOTO || metric == NVMK_METRIC_COSINE, "unknown metric %d", metric);
   NVMK_REQUIRE(cutoff >= 0.0 && cutoff <= 1.0, "cutoff must be in [0, 1], got %g", cutoff);
   NVMK_REQUIRE(fp_bits > 0 && fp_bits % 32 == 0, "fp_bits must be a positive multiple of 32, got %d", fp_bits);
@@ -2007,6 +2009,7 @@ int nvmk_butina_fused(int metric, const uint32_t* d_x, int64_t N, int fp_bits, d
 
 int nvmk_butina_pairs(int metric, const uint32_t* d_x, int64_t N, int fp_bits, double cutoff, int shard, int n_shards,
                       int32_t* d_counts, int32_t* d_pairs, uint64_t pair_capacity, uint64_t* h_n_pairs, void* stream) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(metric == NVMK_METRIC_TANIMOTO || metric == NVMK_METRIC_COSINE, "unknown metric %d", metric);
   NVMK_REQUIRE(cutoff >= 0.0 && cutoff <= 1.0, "cutoff must be in [0, 1], got %g", cutoff);
   NVMK_REQUIRE(fp_bits > 0 && fp_bits % 128 == 0, "fp_bits must be a positive multiple of 128, got %d", fp_bits);
@@ -2056,6 +2059,7 @@ extern "C" {
 
 int nvmk_butina_from_pairs(int64_t N, const int32_t* d_counts, const int32_t* d_pairs, uint64_t n_pairs, int32_t* h_cluster_indices,
                            int64_t* h_offsets, int32_t* h_centroids, int64_t* n_clusters, void* stream_) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(N >= 0 && N <= 0x7fffffffLL, "butina from pairs: bad N %lld", (long long)N);
   NVMK_REQUIRE(h_offsets && n_clusters, "NULL output");
   h_offsets[0] = 0;
@@ -2096,6 +2100,7 @@ int nvmk_butina_from_pairs(int64_t N, const int32_t* d_counts, const int32_t* d_
 
 int nvmk_butina_dense(const double* d_dist, const uint8_t* d_hit, int64_t N, double cutoff, int neighborlist_max_size,
                       int32_t* d_clusters, int32_t* d_centroids, int64_t* h_n_clusters, void* stream_) {
+  NVMK_MARK_ENTRY();
   // neighborlist_max_size only tunes the reference's small-cluster phase (src/butina.cu:975-1004: clusters below that
   // size are resolved from per-point neighbour lists instead of matrix rows).  This implementation has a single phase —
   // the hit matrix is thresholded to bytes once and every round reads contiguous rows / columns of it — so the parameter

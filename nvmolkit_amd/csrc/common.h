@@ -55,7 +55,27 @@ struct StreamScratch {
   template <typename T> T* as() const { return static_cast<T*>(ptr); }
 };
 
+// ---- profiler markers (the reference's ScopedNvtxRange, src/utils/nvtx.h:36-69) ----------------------------------------
+// roctx ranges around every C-ABI entry, ETKDG stage and BFGS size class: `rocprofv3 --marker-trace` shows the stage timeline
+// of a batch without bespoke scripts.  The roctx library (rocprofiler-sdk's, else roctracer's) is opened lazily with dlopen
+// the first time a range is pushed — no link-time dependency, no-ops when it is absent or NVMK_MARKERS=0.
+namespace mark {
+void push(const char* name);
+void pop();
+struct Range {
+  explicit Range(const char* name) { push(name); }
+  ~Range() { pop(); }
+  Range(const Range&)            = delete;
+  Range& operator=(const Range&) = delete;
+};
+}  // namespace mark
+
 }  // namespace nvmk
+
+#define NVMK_MARK_CAT2(a, b) a##b
+#define NVMK_MARK_CAT(a, b) NVMK_MARK_CAT2(a, b)
+#define NVMK_MARK(name) ::nvmk::mark::Range NVMK_MARK_CAT(nvmk_mark_, __LINE__)(name)
+#define NVMK_MARK_ENTRY() NVMK_MARK(__func__)
 
 #define NVMK_HIP_CHECK(expr)                                                                              \
   do {                                                                                                    \

@@ -22,10 +22,12 @@
 #include <thread>
 #include <string>
 #include <atomic>
+#include <chrono>
 #include <stdexcept>
 #include <vector>
 
 #include "common.h"
+#include "options.h"
 
 namespace nvmk {
 namespace etkdg {
@@ -77,6 +79,65 @@ class Scheduler {
   uint64_t         dispatched_ = 0;
   std::vector<int> completed_;
   std::vector<int> attempts_;
+};
+
+// ---- demand-driven hand-out (the driver's default) ---------------------------------------------------------------------
+// The reference's rounds hand a molecule that misses ONE conformer another confs_per_mol attempts (limit = confs x round),
+// and every dispatch fills its batch with the next round's attempts before the current ones are known: measured on 10 000
+// molecules x 10 conformers, 131 072 attempts for 97 951 conformers at a failure rate of 8 % per attempt — a fifth of the
+// pipeline's work dropped at the end (profiles/r04_conformers/).  Here a molecule is handed what it still MISSES: confs -
+// completed - in flight attempts, molecules in order, so a batch holds the retries of the earlier molecules followed by the
+// first attempts of the next ones.  Only when a pass over all molecules leaves the batch less than a quarter (a sixteenth)
+// full — the end of a run, where a batch costs its latency, not its size — every molecule is handed twice (four times) what
+// it misses, so that the run ends in one or two small batches instead of five.  Same bound on the attempts of a molecule
+// (max_iterations x confs), same acceptance rule (the first confs_per_mol successes in attempt order).
+// NVMK_ETKDG_SCHED=reference: the reference's Scheduler above drives nvmk_etkdg_embed instead.
+class DemandScheduler {
+ public:
+  DemandScheduler(int nMols, int confsPerMol, int maxIterations)
+      : confs_(confsPerMol), maxTries_(maxIterations * confsPerMol), completed_(static_cast<size_t>(nMols), 0),
+        attempts_(static_cast<size_t>(nMols), 0), inflight_(static_cast<size_t>(nMols), 0) {}
+
+  std::vector<int> dispatch(int batchSize, uint64_t* attemptBase = nullptr) {
+    std::vector<int>                  ids;
+    const std::lock_guard<std::mutex> lock(mutex_);
+    if (attemptBase) *attemptBase = dispatched_;
+    for (int mult = 1; mult <= 4; mult *= 2) {
+      if (mult == 2 && static_cast<int>(ids.size()) >= batchSize / 4) break;
+      if (mult == 4 && static_cast<int>(ids.size()) >= batchSize / 16) break;
+      for (size_t m = 0; m < completed_.size() && static_cast<int>(ids.size()) < batchSize; ++m) {
+        if (completed_[m] >= confs_) continue;
+        const int want = (confs_ - completed_[m]) * mult - inflight_[m];
+        const int give = std::min(std::min(want, maxTries_ - attempts_[m]), batchSize - static_cast<int>(ids.size()));
+        for (int k = 0; k < give; ++k) ids.push_back(static_cast<int>(m));
+        if (give > 0) {
+          attempts_[m] += give;
+          inflight_[m] += give;
+        }
+      }
+    }
+    dispatched_ += ids.size();
+    return ids;
+  }
+
+  int record(const int* molIds, const int16_t* finishedOnIteration, int n) {
+    const std::lock_guard<std::mutex> lock(mutex_);
+    for (int i = 0; i < n; ++i) {
+      if (molIds[i] < 0 || molIds[i] >= static_cast<int>(completed_.size())) return -1;
+    }
+    for (int i = 0; i < n; ++i) {
+      completed_[static_cast<size_t>(molIds[i])] += finishedOnIteration[i] == -1 ? 0 : 1;
+      inflight_[static_cast<size_t>(molIds[i])] -= 1;
+    }
+    return 0;
+  }
+
+ private:
+  std::mutex       mutex_;
+  int              confs_;
+  int              maxTries_;
+  uint64_t         dispatched_ = 0;
+  std::vector<int> completed_, attempts_, inflight_;
 };
 
 // ---- control kernels (src/etkdg_kernels.cu:20-70) -------------------------------------------------------
@@ -279,6 +340,30 @@ __global__ void copy_3d_to_4d_kernel(const int64_t nAtoms, const double* __restr
   p4[4 * a + 2] = p3[3 * a + 2];
 }
 
+// Stage names as the reference's pipeline reports them (src/etkdg.cpp:339-380, etkdg_stage_*.h name()).
+const char* const kStageNames[NVMK_ETKDG_N_STAGES] = {
+  "Coordinate Generation", "First Minimization", "Tetrahedral Checks", "First Chirality Check", "Fourth Dimension Minimization",
+  "ETK 3D Minimization", "Double bond geometry check", "Final Chirality Check", "Chirality Distance Matrix Check",
+  "Final Chiral Center in Volume Check", "Double bond stereo check"};
+
+// Per-stage wall clock of the last nvmk_etkdg_embed that ran with NVMK_ETKDG_TIMING=1 (the reference's debug-mode table,
+// src/etkdg_impl.cpp:126-139,161-200): a stream synchronisation closes every stage, so the table costs throughput.  Two
+// extra rows: the host work between batches (dispatch, uploads, record, pack) and the whole call.
+constexpr int kTimingRows = NVMK_ETKDG_N_STAGES + 2;
+struct StageTimings {
+  double  total[kTimingRows] = {}, lo[kTimingRows] = {}, hi[kTimingRows] = {};
+  int32_t calls[kTimingRows] = {};
+  void    add(const int row, const double ms) {
+    total[row] += ms;
+    lo[row] = calls[row] == 0 ? ms : std::min(lo[row], ms);
+    hi[row] = std::max(hi[row], ms);
+    ++calls[row];
+  }
+};
+std::mutex   g_timingMutex;
+StageTimings g_lastTimings;
+bool         g_haveTimings = false;
+
 template <typename T> struct DevBuf {
   T*          p = nullptr;
   size_t      n = 0;
@@ -332,6 +417,7 @@ int nvmk_etkdg_stereo_check(int kind, int n_systems, const int32_t* d_atom_start
                             const int32_t* d_check_starts, const int32_t* d_check_kind, const int32_t* d_check_idx,
                             const double* d_check_par, const double* d_pos, const uint8_t* d_active, uint8_t* d_failed,
                             void* stream_) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(kind >= NVMK_CHECK_TETRAHEDRAL && kind <= NVMK_CHECK_DOUBLE_BOND_GEOMETRY, "stereo check: unknown kind %d", kind);
   NVMK_REQUIRE(n_systems >= 0, "stereo check: negative system count");
   if (n_systems == 0) return NVMK_OK;
@@ -354,6 +440,7 @@ int nvmk_etkdg_stereo_check(int kind, int n_systems, const int32_t* d_atom_start
 // Start coordinates of stage 0 as a unit of its own (E3): system s of the batch is attempt attempt_base + s.
 int nvmk_etkdg_random_coords(uint64_t seed, uint64_t attempt_base, int n_systems, const int32_t* d_atom_starts,
                              const uint8_t* d_active, double box_size, double* d_pos, void* stream_) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(n_systems >= 0, "random coords: negative system count");
   if (n_systems == 0) return NVMK_OK;
   NVMK_REQUIRE(d_atom_starts && d_pos, "random coords: NULL buffer");
@@ -377,6 +464,7 @@ int nvmk_etkdg_random_coords(uint64_t seed, uint64_t attempt_base, int n_systems
 // (tests/test_etkdg.cu:41-341) are reproduced.
 int nvmk_etkdg_driver_run(int n_systems, int n_stages, int max_iterations, const uint8_t* h_failed, int16_t* h_fail_counts,
                           int16_t* h_finished_on, int32_t* h_n_finished, int32_t* h_iterations, void* stream_) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(n_systems > 0, "driver: no conformers");    // ETKDGDriver throws on an empty context (test NoConformers)
   NVMK_REQUIRE(n_stages > 0, "driver: no stages");         // ... and on an empty stage list (test NoStages)
   NVMK_REQUIRE(max_iterations >= 0 && h_failed && h_fail_counts && h_finished_on && h_n_finished && h_iterations,
@@ -422,6 +510,7 @@ int nvmk_etkdg_driver_run(int n_systems, int n_stages, int max_iterations, const
 
 int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, double* d_coords, int32_t* h_conf_counts,
                      int32_t* h_stage_failures, void* stream_) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(ms && prm && h_conf_counts, "etkdg: NULL argument");
   NVMK_REQUIRE(ms->n_mols >= 0, "etkdg: negative molecule count");
   if (h_stage_failures) std::memset(h_stage_failures, 0, sizeof(int32_t) * NVMK_ETKDG_N_STAGES);
@@ -443,8 +532,21 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     h_conf_counts[m] = 0;
   }
 
-  Scheduler        sched(nMols, prm->confs_per_mol, prm->max_iterations);
-  std::mutex       outMutex;    // h_conf_counts / output slots / h_stage_failures
+  Scheduler        refSched(nMols, prm->confs_per_mol, prm->max_iterations);
+  DemandScheduler  demandSched(nMols, prm->confs_per_mol, prm->max_iterations);
+  const bool       demand = !opt::get(opt::kEtkdgSched).is("reference");
+  struct {
+    Scheduler*       ref;
+    DemandScheduler* dem;
+    std::vector<int> dispatch(int batchSize, uint64_t* base) { return dem ? dem->dispatch(batchSize, base) : ref->dispatch(batchSize, base); }
+    int record(const int* ids, const int16_t* fin, int n) { return dem ? dem->record(ids, fin, n) : ref->record(ids, fin, n); }
+  } sched{&refSched, demand ? &demandSched : nullptr};
+  std::mutex       outMutex;    // h_conf_counts / output slots / h_stage_failures / timings
+  const bool       timing = opt::get(opt::kEtkdgTiming).is("1");
+  StageTimings     timings;
+  using Clock = std::chrono::steady_clock;
+  auto ms_since = [](const Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); };
+  const Clock::time_point tCall = Clock::now();
   std::atomic<int> firstError{NVMK_OK};
 
   // One worker = one stream running whole batches (dispatch -> 11 stages -> record -> pack) until the scheduler is
@@ -461,6 +563,9 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
 
   for (;;) {
     if (firstError.load() != NVMK_OK) return NVMK_OK;
+    const Clock::time_point tHost = Clock::now();
+    double                  hostMs = 0.0;  // host work of this batch outside the stages
+    NVMK_MARK("ETKDG batch");
     uint64_t               attemptBase = 0;
     std::vector<int> ids = sched.dispatch(prm->batch_size, &attemptBase);
     if (ids.empty()) break;
@@ -518,15 +623,30 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     etk.system_mol  = dSysMol.p;
     for (int g = 0; g < 6; ++g) etk.groups[g] = ms->etk[g];
 
-    int  stage = 0;
+    int               stage = 0;
+    Clock::time_point tStage;
+    double            stageMs[NVMK_ETKDG_N_STAGES] = {};
     auto begin_stage = [&]() -> int {
+      mark::push(kStageNames[stage]);
+      if (timing) {
+        if (stage == 0) {
+          NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+          hostMs += ms_since(tHost);
+        }
+        tStage = Clock::now();
+      }
       NVMK_HIP_CHECK(hipMemsetAsync(dFailed.p, 0, static_cast<size_t>(nSys), stream));
       return NVMK_OK;
     };
     auto end_stage = [&]() -> int {
       hipLaunchKernelGGL(collect_failures_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, dFailed.p, dActive.p,
                          dFailSum.p + static_cast<size_t>(stage) * nSys);
+      mark::pop();
       NVMK_LAUNCH_CHECK();
+      if (timing) {
+        NVMK_HIP_CHECK(hipStreamSynchronize(stream));
+        stageMs[stage] = ms_since(tStage);
+      }
       ++stage;
       return NVMK_OK;
     };
@@ -624,6 +744,7 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
       NVMK_TRY(end_stage());
     }
 #undef NVMK_TRY
+    const Clock::time_point tTail = Clock::now();
     // finished = still active after every stage (getFinishedKernels, iteration 0 of this batch)
     NVMK_HIP_CHECK(hipMemsetAsync(dCount.p, 0, sizeof(int), stream));
     hipLaunchKernelGGL(mark_finished_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, 0, dActive.p, dFinished.p, dCount.p);
@@ -663,14 +784,31 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
       NVMK_LAUNCH_CHECK();
       NVMK_HIP_CHECK(hipStreamSynchronize(stream));
     }
+    if (timing) {
+      hostMs += ms_since(tTail);
+      const std::lock_guard<std::mutex> lock(outMutex);
+      for (int st = 0; st < NVMK_ETKDG_N_STAGES; ++st) timings.add(st, stageMs[st]);
+      timings.add(NVMK_ETKDG_N_STAGES, hostMs);
+    }
   }
   return NVMK_OK;
   };  // worker
+  auto publish = [&]() {
+    if (!timing) return;
+    timings.add(NVMK_ETKDG_N_STAGES + 1, ms_since(tCall));
+    const std::lock_guard<std::mutex> lock(g_timingMutex);
+    g_lastTimings = timings;
+    g_haveTimings = true;
+  };
 
   const int64_t totalAttempts = static_cast<int64_t>(nMols) * prm->confs_per_mol;
   int           nWorkers      = prm->batches_per_gpu > 1 ? prm->batches_per_gpu : 1;
   if (totalAttempts <= prm->batch_size) nWorkers = 1;
-  if (nWorkers == 1) return worker(stream);
+  if (nWorkers == 1) {
+    const int rc1 = worker(stream);
+    publish();
+    return rc1;
+  }
 
   int device = 0;
   NVMK_HIP_CHECK(hipGetDevice(&device));
@@ -704,6 +842,22 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
       }
     }
     return firstError.load();
+  }
+  publish();
+  return NVMK_OK;
+}
+
+int nvmk_etkdg_stage_timings(double* total_ms, double* min_ms, double* max_ms, int32_t* calls, int n_rows, const char** names) {
+  NVMK_REQUIRE(n_rows >= 0 && (n_rows == 0 || (total_ms && min_ms && max_ms && calls)), "stage timings: NULL buffer");
+  const std::lock_guard<std::mutex> lock(g_timingMutex);
+  NVMK_REQUIRE(g_haveTimings, "stage timings: no nvmk_etkdg_embed call has run with NVMK_ETKDG_TIMING=1");
+  static const char* const kExtra[2] = {"host work between the stages (dispatch, uploads, record, pack)", "whole call"};
+  for (int r = 0; r < std::min(n_rows, kTimingRows); ++r) {
+    total_ms[r] = g_lastTimings.total[r];
+    min_ms[r]   = g_lastTimings.lo[r];
+    max_ms[r]   = g_lastTimings.hi[r];
+    calls[r]    = g_lastTimings.calls[r];
+    if (names) names[r] = r < NVMK_ETKDG_N_STAGES ? kStageNames[r] : kExtra[r - NVMK_ETKDG_N_STAGES];
   }
   return NVMK_OK;
 }

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 #include "common.h"
 #include "options.h"
@@ -111,6 +112,7 @@ struct BfgsArgs {
   int                             ldsDoubles;
   unsigned long long*             stats;
   int*                            started;      // host-visible counter of workgroups that have begun (NULL: not wanted)
+  int*                            drained;      // host-visible flag, set when the LAST item of this launch's queues has been taken (NULL: not wanted)
 };
 
 }  // namespace minim
@@ -271,6 +273,7 @@ int nvmk_bfgs_set_stats(uint64_t* d_counters) {
 
 int nvmk_ff_energy(const nvmk_ff_batch* batch, double w0, double w1, const double* d_pos, const uint8_t* d_active,
                    double* d_energies, void* stream) {
+  NVMK_MARK_ENTRY();
   Batch b;
   int   rc = to_batch(batch, b);
   if (rc != NVMK_OK) return rc;
@@ -284,6 +287,7 @@ int nvmk_ff_energy(const nvmk_ff_batch* batch, double w0, double w1, const doubl
 
 int nvmk_ff_gradient(const nvmk_ff_batch* batch, double w0, double w1, const double* d_pos, const uint8_t* d_active,
                      double* d_grad, void* stream) {
+  NVMK_MARK_ENTRY();
   Batch b;
   int   rc = to_batch(batch, b);
   if (rc != NVMK_OK) return rc;
@@ -313,6 +317,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
                                   int restarts, const nvmk_bfgs_second_stage* second, double grad_tol, int scale_grads,
                                   double* d_pos, const uint8_t* d_active, double* d_energies, int16_t* d_statuses,
                                   int32_t* d_iters, void* stream_) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(restarts >= 0, "bfgs: negative restart count");
   NVMK_REQUIRE(second == nullptr || (second->max_iters >= 0 && second->restarts >= 0 && second->d_pos_between != nullptr),
                "bfgs: the second stage needs an iteration limit, a restart count and the buffer for the coordinates in between");
@@ -609,8 +614,8 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       NVMK_HIP_CHECK(hipMemcpyAsync(P.startsMem.ptr, P.hs.data(), P.hs.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
     } else {
       NVMK_HIP_CHECK(P.hessMem.alloc(static_cast<size_t>(P.slotDoubles) * static_cast<size_t>(P.grid) * sizeof(double), stream));
-      NVMK_HIP_CHECK(P.counterMem.alloc(8 * sizeof(int), stream));
-      NVMK_HIP_CHECK(hipMemsetAsync(P.counterMem.ptr, 0, 8 * sizeof(int), stream));
+      NVMK_HIP_CHECK(P.counterMem.alloc(9 * sizeof(int), stream));  // eight queue counters + the number of items taken
+      NVMK_HIP_CHECK(hipMemsetAsync(P.counterMem.ptr, 0, 9 * sizeof(int), stream));
       if (P.gvec) NVMK_HIP_CHECK(P.vecMem.alloc(static_cast<size_t>(P.vecStride) * static_cast<size_t>(P.grid) * sizeof(double), stream));
     }
   }
@@ -658,6 +663,12 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     A.ldsDoubles  = P.ldsDoubles;
     A.stats       = g_stats.load();
     A.started     = (on != stream) ? startedDev : nullptr;
+    A.drained     = (startedDev != nullptr && P.persistent) ? startedDev + 1 + c : nullptr;
+    char label[96];
+    std::snprintf(label, sizeof(label), "BFGS %s: %d systems x %d threads%s", b.kind == NVMK_FF_DG ? "DG" : b.kind == NVMK_FF_ETK ? "ETK"
+                  : (b.kind == NVMK_FF_MMFF || b.kind == KIND_MMFF_C) ? "MMFF" : (b.kind == NVMK_FF_UFF || b.kind == KIND_UFF_C) ? "UFF" : "quartic",
+                  A.nItems, P.threads, P.gvec ? " (vectors in HBM)" : "");
+    NVMK_MARK(label);  // the launch of this size class
     auto go = [&](auto kern) -> int {
       if (P.shmem > 64 * 1024) {
         NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -709,18 +720,31 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     SideStreams* side = sideLease.take(dev);
     NVMK_REQUIRE(side != nullptr, "bfgs: could not create the side streams of device %d", dev);
     startedDev                                      = side->startedDev;
-    *static_cast<volatile int*>(side->started)      = 0;
+    for (int w = 0; w < 16; ++w) static_cast<volatile int*>(side->started)[w] = 0;  // [0] started, [1 + c] class c drained
     NVMK_HIP_CHECK(hipEventRecord(side->fork, stream));
-    int k = 0, bigWorkgroups = 0;
+    int k = 0, bigWorkgroups = 0, prevClass = -1;
     for (int c = kGlobal; c >= 0; --c) {
       if (!plan[c].used) continue;
+      if (queueMode && prevClass >= 0 && plan[prevClass].persistent) {
+        // Classes one after the other, WITHOUT waiting for a class to finish: the next (smaller) class is launched when the
+        // last system of the previous one has been taken off its queues, so its workgroups fill the slots the previous class
+        // frees while its last systems run.  Launched together, the classes interleave on a CU and the smallest one's LDS
+        // blocks fragment the allocation: once the one-wave class is through, 3.3 instead of 4 two-wave workgroups fit a CU
+        // for the rest of the launch (profiles/r04_conformers/bfgs_timeline_summary_queue.json: 1698 of 2048 waves).
+        const auto t0 = std::chrono::steady_clock::now();
+        while (static_cast<volatile int*>(side->started)[1 + prevClass] == 0 &&
+               std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20)) {
+          std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+      }
+      prevClass = c;
       if (c == lastUsed || k >= SideStreams::kStreams) {
         // The larger classes must be ON the chip before the small one is launched: a workgroup of theirs needs more LDS
         // (and, with four waves, a slot on every SIMD of a CU) than a finishing small one sets free, so once the small class
         // has filled the CUs the large ones starve until its grid is exhausted — measured: the 1 % of a batch that needs
         // four waves took 127 ms next to a 76 ms launch of the rest.  Their workgroups count themselves into a pinned word;
         // the host waits (at most half a millisecond) until as many have started as can be resident.
-        const int  target = std::min(bigWorkgroups, nCu);
+        const int  target = queueMode ? 0 : std::min(bigWorkgroups, nCu);
         const auto t0     = std::chrono::steady_clock::now();
         while (*static_cast<volatile int*>(side->started) < target &&
                std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(500)) {

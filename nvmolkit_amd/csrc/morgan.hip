@@ -253,6 +253,7 @@ extern "C" int nvmk_morgan_from_invariants(const uint32_t* d_atom_inv, const uin
                                            const int16_t* d_bond_idx, const int16_t* d_bond_other,
                                            const int16_t* d_n_atoms, const int32_t* d_out_idx, int64_t n_mols,
                                            int max_atoms, int radius, int fp_bits, uint32_t* d_out, void* stream) {
+  NVMK_MARK_ENTRY();
   using namespace nvmk;
   NVMK_REQUIRE(max_atoms == 32 || max_atoms == 64 || max_atoms == 128 || max_atoms == 256 || max_atoms == 512 || max_atoms == 1024,
                "morgan: max_atoms must be 32, 64, 128, 256, 512 or 1024, got %d", max_atoms);

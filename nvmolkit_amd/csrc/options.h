@@ -25,6 +25,9 @@ enum Id {
   kBfgsHessCapMb,   // NVMK_BFGS_HESS_CAP_MB n (tests: inverse-Hessian memory of a one-system-per-workgroup class before it runs persistent; default free / 4)
   kBfgsTimeline,    // NVMK_BFGS_TIMELINE    path (with NVMK_BFGS_PROFILE=1: per-system start / end clocks appended to this file)
   kBfgsSched,       // NVMK_BFGS_SCHED       queue | hw (hw: one workgroup per system, hardware hand-out — rounds 1-3)
+  kMarkers,         // NVMK_MARKERS          1 | 0 (0: no roctx ranges)
+  kEtkdgTiming,     // NVMK_ETKDG_TIMING     1 (per-stage wall clock of nvmk_etkdg_embed: a stream synchronisation after every stage)
+  kEtkdgSched,      // NVMK_ETKDG_SCHED      demand | reference (reference: the reference's round scheduler drives nvmk_etkdg_embed)
   kNumOptions
 };
 

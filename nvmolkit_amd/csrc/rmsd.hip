@@ -185,6 +185,7 @@ extern "C" {
 int nvmk_conformer_rmsd_batch(const double* d_coords, const int64_t* d_coord_offsets, const int32_t* d_n_atoms,
                               const int64_t* d_pair_offsets, int n_mols, int64_t total_pairs, int prealigned, double* d_out,
                               void* stream) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(n_mols >= 0 && total_pairs >= 0, "conformer rmsd: negative size");
   if (n_mols == 0 || total_pairs == 0) return NVMK_OK;
   NVMK_REQUIRE(d_coords && d_coord_offsets && d_n_atoms && d_pair_offsets && d_out, "conformer rmsd: NULL buffer");
@@ -198,6 +199,7 @@ int nvmk_conformer_rmsd_batch(const double* d_coords, const int64_t* d_coord_off
 
 int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, const int32_t* d_conf_starts, int n_mols,
                          double threshold, uint8_t* d_keep, void* stream) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(n_mols >= 0, "conformer prune: negative size");
   NVMK_REQUIRE(threshold >= 0.0, "conformer prune: negative threshold");
   if (n_mols == 0) return NVMK_OK;

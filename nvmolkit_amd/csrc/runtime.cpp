@@ -1,5 +1,8 @@
 // Library-level entry points: error slot, ABI version, device queries.
 #include <cstring>
+#include <dlfcn.h>
+
+#include <initializer_list>
 #include <mutex>
 
 #include "common.h"
@@ -25,7 +28,7 @@ namespace {
 const char* const kNames[kNumOptions] = {"NVMK_SIM_PATH",       "NVMK_COUNT_THRESHOLD", "NVMK_COUNT_SUPER",  "NVMK_BUTINA_ROUNDS",
                                          "NVMK_BUTINA_SORT",    "NVMK_BFGS_LDS",        "NVMK_BFGS_XCD_GROUP", "NVMK_BFGS_PROFILE",
                                          "NVMK_BFGS_VECTORS",   "NVMK_BFGS_OVERLAP",    "NVMK_BFGS_WAVE",   "NVMK_BFGS_WAVE2",
-                                         "NVMK_BFGS_HESS_CAP_MB", "NVMK_BFGS_TIMELINE", "NVMK_BFGS_SCHED"};
+                                         "NVMK_BFGS_HESS_CAP_MB", "NVMK_BFGS_TIMELINE", "NVMK_BFGS_SCHED", "NVMK_MARKERS", "NVMK_ETKDG_TIMING", "NVMK_ETKDG_SCHED"};
 std::mutex g_mutex;
 Text       g_values[kNumOptions];
 bool       g_loaded = false;
@@ -60,6 +63,39 @@ int set(const char* n, const char* value) {
   return 0;
 }
 }  // namespace opt
+
+namespace mark {
+namespace {
+using PushFn = int (*)(const char*);
+using PopFn  = int (*)();
+struct Api {
+  PushFn push = nullptr;
+  PopFn  pop  = nullptr;
+};
+const Api& api() {
+  static const Api a = [] {
+    Api x;
+    if (opt::get(opt::kMarkers).is("0")) return x;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      if (void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+        x.push = reinterpret_cast<PushFn>(dlsym(h, "roctxRangePushA"));
+        x.pop  = reinterpret_cast<PopFn>(dlsym(h, "roctxRangePop"));
+        if (x.push != nullptr && x.pop != nullptr) return x;
+        x = Api{};
+      }
+    }
+    return x;
+  }();
+  return a;
+}
+}  // namespace
+void push(const char* name) {
+  if (const PushFn f = api().push) (void)f(name);
+}
+void pop() {
+  if (const PopFn f = api().pop) (void)f();
+}
+}  // namespace mark
 
 }  // namespace nvmk
 

@@ -348,11 +348,13 @@ extern "C" {
 
 int nvmk_cross_tanimoto_f64(const uint32_t* d_a, int64_t nA, const uint32_t* d_b, int64_t nB, int fp_bits,
                             double* d_out, int64_t ld_out, void* stream) {
+  NVMK_MARK_ENTRY();
   return nvmk::sim::launch<NVMK_METRIC_TANIMOTO>(d_a, nA, d_b, nB, fp_bits, d_out, ld_out, nvmk::as_stream(stream));
 }
 
 int nvmk_cross_cosine_f64(const uint32_t* d_a, int64_t nA, const uint32_t* d_b, int64_t nB, int fp_bits, double* d_out,
                           int64_t ld_out, void* stream) {
+  NVMK_MARK_ENTRY();
   return nvmk::sim::launch<NVMK_METRIC_COSINE>(d_a, nA, d_b, nB, fp_bits, d_out, ld_out, nvmk::as_stream(stream));
 }
 

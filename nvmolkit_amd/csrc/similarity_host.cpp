@@ -84,6 +84,7 @@ int init_worker(Worker& w, size_t chunkDoubles) {
 
 extern "C" int nvmk_cross_similarity_host_f64(int metric, const uint32_t* d_a, int64_t nA, const uint32_t* d_b,
                                               int64_t nB, int fp_bits, double* h_out, int64_t max_device_bytes) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(metric == NVMK_METRIC_TANIMOTO || metric == NVMK_METRIC_COSINE, "unknown metric %d", metric);
   NVMK_REQUIRE(fp_bits > 0 && fp_bits % 32 == 0, "fp_bits must be a positive multiple of 32, got %d", fp_bits);
   NVMK_REQUIRE(nA >= 0 && nB >= 0, "negative row count");

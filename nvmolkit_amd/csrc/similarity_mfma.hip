@@ -735,12 +735,14 @@ size_t nvmk_fp4_workspace_bytes(int64_t n, int fp_bits) {
 }
 
 int nvmk_fp4_prepare(const uint32_t* d_in, int64_t n, int fp_bits, void* d_workspace, void* stream) {
+  NVMK_MARK_ENTRY();
   return nvmk::fp4::prepare(d_in, nullptr, n, fp_bits, d_workspace, nvmk::as_stream(stream));
 }
 
 int nvmk_cross_similarity_prepared_f64(int metric, const void* d_ws_a, int64_t nA_total, int64_t a_row0, int64_t a_rows,
                                        const void* d_ws_b, int64_t nB, int fp_bits, double* d_out, int64_t ld_out,
                                        void* stream) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(metric == NVMK_METRIC_TANIMOTO || metric == NVMK_METRIC_COSINE, "unknown metric %d", metric);
   NVMK_REQUIRE(fp_bits > 0 && fp_bits % 32 == 0, "fp_bits must be a positive multiple of 32, got %d", fp_bits);
   NVMK_REQUIRE(nA_total >= 0 && nB >= 0 && a_row0 >= 0 && a_rows >= 0 && a_row0 + a_rows <= nA_total,

@@ -1584,6 +1584,7 @@ template <typename Builder> void parse_all(Set& set, const int64_t n_mols, const
 extern "C" {
 
 int nvmk_smiles_parse_flags(const char* const* smiles, const int64_t n_mols, const int n_threads, const unsigned flags, void** handle) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(handle != nullptr && (smiles != nullptr || n_mols == 0) && n_mols >= 0, "nvmk_smiles_parse: NULL argument or negative count");
   NVMK_REQUIRE((flags & ~static_cast<unsigned>(NVMK_SMILES_PERCEIVE_AROMATICITY)) == 0u, "nvmk_smiles_parse: unknown flag bits 0x%x", flags);
   auto set = std::make_unique<nvmk::smiles::Set>();
@@ -1597,6 +1598,7 @@ int nvmk_smiles_parse(const char* const* smiles, const int64_t n_mols, const int
 }
 
 int nvmk_smiles_parse_text(const char* text, const int64_t n_bytes, const int n_threads, const unsigned flags, void** handle) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(handle != nullptr && (text != nullptr || n_bytes == 0) && n_bytes >= 0, "nvmk_smiles_parse_text: NULL argument or negative size");
   NVMK_REQUIRE((flags & ~static_cast<unsigned>(NVMK_SMILES_PERCEIVE_AROMATICITY)) == 0u, "nvmk_smiles_parse_text: unknown flag bits 0x%x", flags);
   auto                     set = std::make_unique<nvmk::smiles::Set>();
@@ -1620,6 +1622,7 @@ int nvmk_smiles_parse_text(const char* text, const int64_t n_bytes, const int n_
 }
 
 int nvmk_sdf_parse_text(const char* text, const int64_t n_bytes, const int n_threads, const unsigned flags, void** handle) {
+  NVMK_MARK_ENTRY();
   NVMK_REQUIRE(handle != nullptr && (text != nullptr || n_bytes == 0) && n_bytes >= 0, "nvmk_sdf_parse_text: NULL argument or negative size");
   NVMK_REQUIRE((flags & ~static_cast<unsigned>(NVMK_SMILES_PERCEIVE_AROMATICITY)) == 0u, "nvmk_sdf_parse_text: unknown flag bits 0x%x", flags);
   auto set = std::make_unique<nvmk::smiles::Set>();
@@ -1693,6 +1696,7 @@ int nvmk_smiles_graph(const void* handle, const int64_t mol, int32_t* atom_field
 
 int nvmk_smiles_morgan_inputs(const void* handle, const int64_t* mol_ids, const int64_t n_sel, const int max_atoms, uint32_t* atom_inv,
                               uint32_t* bond_inv, int16_t* bond_idx, int16_t* bond_other, int16_t* n_atoms, const int n_threads) {
+  NVMK_MARK_ENTRY();
   using namespace nvmk::smiles;
   NVMK_REQUIRE(handle != nullptr && atom_inv != nullptr && bond_inv != nullptr && bond_idx != nullptr && bond_other != nullptr &&
                    n_atoms != nullptr && n_sel >= 0,

@@ -26,6 +26,33 @@ STAGE_NAMES = ["coordgen", "first minimization", "tetrahedral check", "first chi
                "chiral centre volume", "double bond stereo"]
 
 
+def stage_timings() -> list[dict]:
+    """Per-stage wall clock of the last ETKDG call that ran with ``NVMK_ETKDG_TIMING=1`` (``_native.options(NVMK_ETKDG_TIMING="1")``):
+    one dict per row — the pipeline's stages under the reference's names, then the host work between the stages and the
+    whole call — with total / min / max milliseconds and the number of batches (the reference's debug-mode table,
+    src/etkdg_impl.cpp:161-200)."""
+    import ctypes
+
+    rows = len(STAGE_NAMES) + 2
+    total, lo, hi = (np.zeros(rows) for _ in range(3))
+    calls = np.zeros(rows, dtype=np.int32)
+    names = (ctypes.c_char_p * rows)()
+    _native.check(_native.lib().nvmk_etkdg_stage_timings(total.ctypes.data, lo.ctypes.data, hi.ctypes.data, calls.ctypes.data, rows,
+                                                         ctypes.cast(names, ctypes.c_void_p)), "nvmk_etkdg_stage_timings")
+    return [{"stage": names[r].decode(), "total_ms": float(total[r]), "min_ms": float(lo[r]), "max_ms": float(hi[r]), "calls": int(calls[r])}
+            for r in range(rows)]
+
+
+def format_stage_timings(rows: list[dict] | None = None) -> str:
+    """The table as the reference's driver prints it."""
+    rows = stage_timings() if rows is None else rows
+    out = [f"{'Stage Name':<66}{'Total (ms)':>12}{'Avg (ms)':>12}{'Min (ms)':>12}{'Max (ms)':>12}{'Calls':>8}", "-" * 122]
+    for r in rows:
+        avg = r["total_ms"] / max(r["calls"], 1)
+        out.append(f"{r['stage']:<66}{r['total_ms']:>12.3f}{avg:>12.3f}{r['min_ms']:>12.3f}{r['max_ms']:>12.3f}{r['calls']:>8d}")
+    return "\n".join(out)
+
+
 @dataclass
 class FlatMolecule:
     """One molecule in flattened form: term groups with LOCAL atom indices (layouts: include/nvmolkit_amd.h)."""

@@ -1,5 +1,7 @@
-"""examples/cross_tanimoto_from_cxx.cpp — a C++ caller of the C ABI of the kind INTEGRATION.md describes: it must build against
-the header and the library (CPU), and on a GPU reproduce a host popcount loop bit for bit."""
+"""examples/*.cpp — C++ callers of the C ABI of the kind INTEGRATION.md describes: they must build against the header and the
+library (CPU), and on a GPU reproduce a host popcount loop bit for bit.  cross_tanimoto_from_cxx.cpp: one entry point;
+sharded_reference_from_cxx.cpp: the configs[4] flow (communicator, all-gather of the reference shard, similarity launch), which a
+one-GPU box runs as one rank."""
 
 import shutil
 import subprocess
@@ -10,13 +12,13 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def build(tmp_path):
+def build(tmp_path, name="cross_tanimoto_from_cxx"):
     if shutil.which("g++") is None or not Path("/opt/rocm/include/hip/hip_runtime.h").exists():
         pytest.skip("needs g++ and the HIP headers")
-    exe = tmp_path / "cross_tanimoto"
+    exe = tmp_path / name
     lib_dir = ROOT / "nvmolkit_amd" / "lib"
     run = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", f"-I{ROOT / 'include'}", "-I/opt/rocm/include",
-                          str(ROOT / "examples" / "cross_tanimoto_from_cxx.cpp"), f"-L{lib_dir}", "-lnvmolkit_amd", "-L/opt/rocm/lib",
+                          str(ROOT / "examples" / f"{name}.cpp"), f"-L{lib_dir}", "-lnvmolkit_amd", "-L/opt/rocm/lib",
                           "-lamdhip64", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
                          capture_output=True, text=True)
     assert run.returncode == 0, run.stderr[-2000:]
@@ -25,6 +27,7 @@ def build(tmp_path):
 
 def test_the_example_builds_against_header_and_library(tmp_path):
     build(tmp_path)
+    build(tmp_path, "sharded_reference_from_cxx")
 
 
 @pytest.mark.gpu
@@ -32,3 +35,10 @@ def test_the_example_reproduces_the_host_loop(tmp_path):
     run = subprocess.run([str(build(tmp_path))], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "0 differ from the host loop" in run.stdout
+
+
+@pytest.mark.gpu
+def test_the_sharded_reference_example_runs_as_one_rank(tmp_path):
+    run = subprocess.run([str(build(tmp_path, "sharded_reference_from_cxx"))], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "rank 0 of 1" in run.stdout and " 0 differ from the host loop" in run.stdout

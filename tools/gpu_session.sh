@@ -90,7 +90,20 @@ PY
         done
       done
       ;;
+    ab_etkdg_sched)
+      : > $O/ab_etkdg_sched.txt
+      for i in 1 2; do
+        for M in reference demand; do
+          NVMK_ETKDG_SCHED=$M timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --cache $CACHE 2>/dev/null | pick "etkdg_sched=$M" | tee -a $O/ab_etkdg_sched.txt
+        done
+      done
+      ;;
+    new_abi_tests)
+      ( time timeout 900 python -m pytest tests/test_multi_gpu_abi_gpu.py tests/test_cxx_example.py tests/test_etkdg_gpu.py tests/test_config_size_gpu.py -m gpu -q -x ) > $O/new_abi_tests.log 2>&1
+      tail -8 $O/new_abi_tests.log
+      ;;
     conformer_traffic_seq)
+      rm -rf gpurun_out/pmc_traffic/conf_fetch gpurun_out/pmc_traffic/conf_write
       NVMK_BFGS_OVERLAP=0 timeout 900 bash tools/profile_conformer_traffic.sh 2000 > $O/conformer_traffic_seq.log 2>&1
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/pmc_hbm_traffic_conformers_classes_one_after_the_other.json 2>/dev/null
       tail -30 $O/conformer_traffic_seq.log
@@ -107,6 +120,7 @@ PY
       gzip -f $O/bfgs_timeline.txt
       ;;
     conformer_traffic)
+      rm -rf gpurun_out/pmc_traffic/conf_fetch gpurun_out/pmc_traffic/conf_write
       timeout 900 bash tools/profile_conformer_traffic.sh 2000 > $O/conformer_traffic.log 2>&1
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/ 2>/dev/null
       tail -30 $O/conformer_traffic.log
