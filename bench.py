@@ -37,12 +37,16 @@ SEED = 20260926
 
 
 def synth_fingerprints(n: int, words: int, device, seed: int, n_centres: int | None = None,
-                       density_range: tuple[float, float] | None = None) -> torch.Tensor:
+                       density_range: tuple[float, float] | None = None, row_range: tuple[int, int] | None = None) -> torch.Tensor:
     """BASELINE.md cfg2 generator on the GPU: planted clusters, ~2.3 % density, <= 12 bit flips per row.
     ``density_range=(lo, hi)`` gives every cluster centre its own bit density instead (popcounts spread like real
-    Morgan fingerprints of small to large molecules; used by tools/bench_butina.py --spread)."""
+    Morgan fingerprints of small to large molecules; used by tools/bench_butina.py --spread).
+    ``row_range=(lo, hi)``: only those rows of the n-row set, with every block of 2^18 rows drawn from its own seed — a rank of
+    a sharded run makes its own rows without materialising the whole set (every rank gets the same centres and the same rows
+    for the same indices; the stream differs from the one-generator stream of the unsharded call)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    lo_r, hi_r = row_range if row_range is not None else (0, n)
     nbits = words * 32
     n_centres = n_centres or max(1, n // 50)
     if density_range is None:
@@ -52,22 +56,35 @@ def synth_fingerprints(n: int, words: int, device, seed: int, n_centres: int | N
         centres = torch.rand((n_centres, nbits), generator=g, device=device) < dens
     weights = (torch.ones(32, dtype=torch.int32, device=device) << torch.arange(32, dtype=torch.int32, device=device))
     centres_packed = (centres.reshape(n_centres, words, 32).to(torch.int32) * weights).sum(dim=2, dtype=torch.int32)
-    out = torch.empty((n, words), dtype=torch.int32, device=device)
     step = 1 << 18
+    if row_range is not None:
+        parts = []
+        for lo in range((lo_r // step) * step, hi_r, step):
+            hi = min(n, lo + step)
+            gb = torch.Generator(device=device)
+            gb.manual_seed(seed * 1_000_003 + lo // step + 1)
+            block = _planted_rows(hi - lo, centres_packed, n_centres, nbits, gb, device)
+            parts.append(block[max(lo_r - lo, 0): min(hi_r, hi) - lo])
+        return torch.cat(parts) if parts else torch.empty((0, words), dtype=torch.int32, device=device)
+    out = torch.empty((n, words), dtype=torch.int32, device=device)
     for lo in range(0, n, step):
         hi = min(n, lo + step)
-        m = hi - lo
-        owner = torch.randint(0, n_centres, (m,), generator=g, device=device)
-        rows = centres_packed[owner].clone()
-        k = torch.randint(0, 13, (m, 1), generator=g, device=device)
-        pos = torch.randint(0, nbits, (m, 12), generator=g, device=device)
-        active = torch.arange(12, device=device).unsqueeze(0) < k
-        word = pos // 32
-        bit = (torch.ones_like(pos, dtype=torch.int32) << (pos % 32).to(torch.int32)) * active.to(torch.int32)
-        for j in range(12):  # XOR flips one at a time (duplicates cancel, like repeated flips)
-            rows.scatter_(1, word[:, j:j + 1], rows.gather(1, word[:, j:j + 1]) ^ bit[:, j:j + 1])
-        out[lo:hi] = rows
+        out[lo:hi] = _planted_rows(hi - lo, centres_packed, n_centres, nbits, g, device)
     return out
+
+
+def _planted_rows(m: int, centres_packed: torch.Tensor, n_centres: int, nbits: int, g, device) -> torch.Tensor:
+    """m rows: a random centre each, then up to 12 bit flips."""
+    owner = torch.randint(0, n_centres, (m,), generator=g, device=device)
+    rows = centres_packed[owner].clone()
+    k = torch.randint(0, 13, (m, 1), generator=g, device=device)
+    pos = torch.randint(0, nbits, (m, 12), generator=g, device=device)
+    active = torch.arange(12, device=device).unsqueeze(0) < k
+    word = pos // 32
+    bit = (torch.ones_like(pos, dtype=torch.int32) << (pos % 32).to(torch.int32)) * active.to(torch.int32)
+    for j in range(12):  # XOR flips one at a time (duplicates cancel, like repeated flips)
+        rows.scatter_(1, word[:, j:j + 1], rows.gather(1, word[:, j:j + 1]) ^ bit[:, j:j + 1])
+    return rows
 
 
 def cpu_baseline(ref_words: np.ndarray, target_seconds: float) -> dict:
@@ -229,17 +246,50 @@ def cfg1_block(device, cpu_seconds: float) -> dict:
 BFGS_KIND_NAMES = {0: "dg", 1: "etk", 2: "mmff"}
 
 
-def conformer_library(n_mols: int, world: int, rank: int):
-    """The synthetic drug-like molecules of one rank (generated in forked worker processes) and the seconds it took."""
+def conformer_library(n_mols: int, world: int, rank: int, shared: bool = False):
+    """The synthetic drug-like molecules (generated in forked worker processes) and the seconds it took.
+    ``shared`` (multi-rank runs): the set is generated ONCE — rank 0 writes it to shared memory, the others wait for the file and
+    load it — so that the start-up of --gpus 8 costs one generation, not eight on an eighth of the cores each; every rank then
+    works on the same molecules (weak scaling: with its own seed; strong scaling: on its share of them)."""
+    import pickle
+
     from nvmolkit_amd import synthetic
 
     t0 = time.perf_counter()
-    procs = max(1, (os.cpu_count() or 2) // (2 * world))
-    return synthetic.druglike_library(n_mols, seed=SEED + 17 * rank, processes=min(procs, 64)), time.perf_counter() - t0
+    if not shared:
+        procs = max(1, (os.cpu_count() or 2) // 2)
+        return synthetic.druglike_library(n_mols, seed=SEED, processes=min(procs, 64)), time.perf_counter() - t0
+    base = Path("/dev/shm") if Path("/dev/shm").is_dir() else Path(os.environ.get("TMPDIR", "/tmp"))
+    path = base / f"nvmk_bench_druglike_{n_mols}_{SEED}_{os.environ.get('MASTER_PORT', '0')}.pkl"
+    if rank == 0:
+        lib = synthetic.druglike_library(n_mols, seed=SEED, processes=min(max(1, (os.cpu_count() or 2) // 2), 64))
+        with open(str(path) + ".tmp", "wb") as f:
+            pickle.dump(lib, f, protocol=pickle.HIGHEST_PROTOCOL)
+        os.replace(str(path) + ".tmp", path)
+        return lib, time.perf_counter() - t0
+    while not path.exists():
+        if time.perf_counter() - t0 > 1800:
+            raise SystemExit(f"rank {rank}: no molecule library from rank 0 after 30 minutes ({path})")
+        time.sleep(0.05)
+    with open(path, "rb") as f:
+        return pickle.load(f), time.perf_counter() - t0
+
+
+def strong_scaling_share(library, total: int, world: int, rank: int):
+    """configs[3]: ONE job of ``total`` molecules dealt over the ranks by cost (distributed.shard_molecules_by_cost: largest first
+    to the least loaded rank, the same assignment computed on every rank, no communication).  The job is the generated set
+    repeated as often as needed (every instance is embedded on its own: own attempts, own random start coordinates).
+    Returns (this rank's molecules, modelled cost of every rank's share)."""
+    from nvmolkit_amd.distributed import molecule_owners_by_cost
+
+    sizes = np.array([m["embed"]["n_atoms"] for m in library])
+    owner, load = molecule_owners_by_cost(sizes[np.arange(total) % len(library)], world)
+    return [library[int(i) % len(library)] for i in np.nonzero(owner == rank)[0]], [float(x) for x in load]
 
 
 def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int, rank: int, cpu_seconds: float,
-                    library=None, t_library: float = 0.0, collectives: bool = False) -> dict:
+                    library=None, t_library: float = 0.0, collectives: bool = False, strong_total: int = 0,
+                    data: str | None = None) -> dict:
     """BASELINE.json configs[2] (and [3] when world > 1: every rank embeds and optimises its own n_mols molecules, no
     data-path collective): ETKDG (`confs` conformers per molecule) DEVICE-chained into MMFF94 on the synthetic drug-like
     set of nvmolkit_amd/synthetic.py.  Roofline = the fused BFGS kernels' inverse-Hessian traffic."""
@@ -249,11 +299,16 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
 
     if library is None:
         library, t_library = conformer_library(n_mols, world, rank)
+    share_cost = None
+    if strong_total > 0:
+        library, share_cost = strong_scaling_share(library, strong_total, world, rank)
+        n_mols = len(library)
     t0 = time.perf_counter()
     molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library], device=device)
     tables = mmffOptimization.resident_tables([m["mmff"] for m in library], device)  # term tables resident before the timed region
     torch.cuda.synchronize()
-    t_prep = time.perf_counter() - t0 + t_library
+    t_flatten = time.perf_counter() - t0
+    t_prep = t_flatten + t_library
     lib = _native.lib()
     embed_flat(FlatMoleculeSet([FlatMolecule(**library[0]["embed"])], device=device), 1, 5)  # warm-up: module load, pools
     stats = torch.zeros(64, dtype=torch.int64, device=device)
@@ -276,15 +331,20 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     n_conf = dev.num_conformers
     converged = int(opt.converged.torch().sum().item())
     if collectives:
+        own_wall = wall
         t = torch.tensor([wall, t_embed, t_mmff], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         c = torch.tensor([n_conf, converged, n_mols], dtype=torch.int64, device=device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        walls = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(walls, torch.tensor([own_wall], dtype=torch.float64, device=device))
+        per_rank_wall = [float(w.item()) for w in walls]
         wall, t_embed, t_mmff = (float(x) for x in t.tolist())
         n_conf, converged, total_mols = (int(x) for x in c.tolist())
     else:
         total_mols = n_mols
+        per_rank_wall = [wall]
     st = stats.cpu().numpy().reshape(8, 8)
     per_kind = {BFGS_KIND_NAMES[k]: {"systems": int(st[k, 0]), "iterations": int(st[k, 1]), "algorithmic_bytes": int(st[k, 2]),
                                      "energy_evaluations": int(st[k, 3]), "hbm_resident_bytes": int(st[k, 4]),
@@ -306,9 +366,15 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
            "mean_atoms": float(np.mean([m["embed"]["n_atoms"] for m in library])), "conformers": n_conf,
            "etkdg_seconds": t_embed, "etkdg_conformers_per_s": n_conf / t_embed, "mmff_seconds": t_mmff,
            "mmff_conformers_per_s": n_conf / t_mmff, "mmff_converged_fraction": converged / max(n_conf, 1),
-           "host_preparation_seconds": t_prep, "scaling": "weak", "bfgs": per_kind,
-           "data": "synthetic drug-like molecules (rings + chains + hydrogens, bounds / ETK / MMFF tables derived from one "
-                   "generated 3-D geometry; nvmolkit_amd/synthetic.py) — real SMILES need RDKit",
+           "host_preparation_seconds": t_prep, "library_generation_seconds": t_library,
+           "flatten_and_table_upload_seconds": t_flatten,   # FlatMoleculeSet + resident term tables: the analogue of the
+                                                            # reference's per-batch host flattening (src/minimizer/bfgs_mmff.cpp:159,195-201)
+           "scaling": "strong" if strong_total > 0 else "weak", "per_rank_seconds": per_rank_wall,
+           "imbalance_max_over_mean": max(per_rank_wall) / (sum(per_rank_wall) / len(per_rank_wall)),
+           "modelled_cost_share_max_over_mean": (max(share_cost) / (sum(share_cost) / len(share_cost))) if share_cost else None,
+           "bfgs": per_kind,
+           "data": data or ("synthetic drug-like molecules (rings + chains + hydrogens, bounds / ETK / MMFF tables derived from one "
+                            "generated 3-D geometry; nvmolkit_amd/synthetic.py) — real SMILES need RDKit"),
            "roofline": {"bound": "hbm", "achieved": algo / wall / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": algo / wall / 1e9 / HBM_PEAK_GBPS / world, "traffic": traffic, "traffic_source": traffic_src,
                         "hbm_bytes_requested_by_the_hessian_pass": float(sum(v["hbm_resident_bytes"] for v in per_kind.values())),
@@ -364,6 +430,33 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     return out
 
 
+def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int = 128) -> dict:
+    """BASELINE.json configs[2] on the reference's own molecules: the 10 000 SMILES of benchmarks/data/chembl_10k.smi through
+    the library's ingestion (benchmarks/etkdg_bench.py:154-161 reads them with RDKit), explicit hydrogens from the valence
+    model (benchmarks/bench_utils/molprep.py:21-55: AddHs), ETKDG + MMFF94 on the REAL topologies with generic parameters
+    (synthetic.graph_molecule).  Molecules beyond ``max_atoms`` atoms are left out and counted."""
+    from nvmolkit_amd import synthetic
+    from nvmolkit_amd.fingerprints import SmilesSet
+
+    path = ROOT / "tests" / "golden" / "chembl_10k.smi"
+    t0 = time.perf_counter()
+    s = SmilesSet.from_file(str(path))
+    totals = np.array([int(s.graph(i)[0][:, 3].sum()) + int(s.n_atoms[i]) for i in range(len(s.status)) if s.status[i] == 0])
+    library, _ = synthetic.smiles_file_library(path, max_atoms=max_atoms)
+    t_library = time.perf_counter() - t0
+    out = conformer_block(len(library), confs, mmff_iters, device, 1, 0, 0.0, library, t_library,
+                          data=f"topologies of tests/golden/chembl_10k.smi (the reference's benchmarks/data/chembl_10k.smi) with explicit "
+                               f"hydrogens, at most {max_atoms} atoms; synthetic (generic) parameters: bounds from covalent radii, hybridisation "
+                               f"and ring-size angles, cis / trans 1-4 windows, triangle smoothing; MMFF94-shaped terms with the same rest values")
+    out["atoms_histogram_of_the_whole_file"] = {"molecules": int(len(totals)), "mean": float(totals.mean()),
+                                                "percentiles_1_10_50_90_99_max": [int(x) for x in np.percentile(totals, [1, 10, 50, 90, 99, 100])],
+                                                "fraction_beyond_the_cut": float((totals > max_atoms).mean())}
+    sizes = np.array([m["embed"]["n_atoms"] for m in library])
+    out["atoms_percentiles_of_the_run_5_25_50_75_95_max"] = [int(x) for x in np.percentile(sizes, [5, 25, 50, 75, 95, 100])]
+    out.pop("roofline", None)  # the PMC traffic file is for the synthetic set; the block is reported as throughput
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -384,6 +477,11 @@ def main() -> None:
     ap.add_argument("--conformer-mols", type=int, default=10_000,
                     help="also time ETKDG (10 conformers) + MMFF94 optimise on this many synthetic drug-like molecules PER "
                          "GPU (BASELINE.json configs[2]: 10k; configs[3] when --gpus > 1), reported under 'secondary' (0 = skip)")
+    ap.add_argument("--conformer-total", type=int, default=0,
+                    help="STRONG scaling of the conformer block (BASELINE.json configs[3]: 100000): this many molecules for the whole "
+                         "job, dealt over the ranks by cost (distributed.shard_molecules_by_cost); 0 = weak scaling, --conformer-mols per GPU")
+    ap.add_argument("--chembl", type=int, default=1,
+                    help="1: also run the conformer block on the ChEMBL topologies of tests/golden/chembl_10k.smi (single GPU), 0: skip")
     ap.add_argument("--conformer-confs", type=int, default=10)
     ap.add_argument("--cfg1", type=int, default=1, help="1: also run BASELINE configs[0] (10k SMILES -> Morgan -> 10k x 10k), 0: skip")
     ap.add_argument("--mmff-iters", type=int, default=200, help="MMFF maxIters (the reference benchmark's default)")
@@ -402,7 +500,7 @@ def main() -> None:
     if distributed and args.conformer_mols > 0:
         # the generator forks worker processes: under torchrun that happens before this process holds a HIP context and
         # RCCL's threads (the single-GPU run generates inside the conformer block, after the headline measurement)
-        library, t_library = conformer_library(args.conformer_mols, world, rank)
+        library, t_library = conformer_library(args.conformer_mols, world, rank, shared=world > 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
@@ -424,9 +522,7 @@ def main() -> None:
         from nvmolkit_amd.distributed import all_gather_rows, shard_bounds
 
         lo, hi = shard_bounds(n_ref, world, rank)
-        ref_full_seeded = synth_fingerprints(n_ref, words, device, SEED)  # same seed on every rank
-        ref_shard = ref_full_seeded[lo:hi].contiguous()
-        del ref_full_seeded
+        ref_shard = synth_fingerprints(n_ref, words, device, SEED, row_range=(lo, hi)).contiguous()  # this rank's rows only
         ref_gathered = all_gather_rows(ref_shard, n_ref)
     else:
         ref_shard = None
@@ -596,9 +692,11 @@ def main() -> None:
         if not distributed:
             guarded("conformers", conformer_block, args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank,
                     args.cpu_seconds)
+            if args.chembl:
+                guarded("conformers_chembl", chembl_block, args.conformer_confs, args.mmff_iters, device)
         else:  # ranks meet in collectives inside the block: an exception on one rank must end the job, not hang the others
             block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds,
-                                    library, t_library, collectives=True)
+                                    library, t_library, collectives=True, strong_total=args.conformer_total)
             if rank == 0:
                 secondary["conformers"] = block
     if rank == 0:

@@ -23,6 +23,7 @@
 
 #include "fp4.h"
 #include "options.h"
+#include "tile_maps.h"
 
 namespace nvmk {
 namespace fp4 {
@@ -193,13 +194,8 @@ __global__ __launch_bounds__(NT, 4) void cross_sim_mfma_kernel(const uint4* __re
   // instead of (64 + 8) with the XCDs interleaved over tile_n — a third less traffic from the L2s into the fabric.
   // With 128 or more tile rows in the launch (16 384-row chunks) the supertile is 128 tiles tall (superM) and an XCD owns
   // 64 x 16 tiles: its 16 B tiles are then reused 64 times, (64 + 16) tile loads per 1024 tiles instead of (32 + 16) per 512.
-  const unsigned superN = (tilesN + SUPER - 1) / SUPER;
-  const unsigned sm     = blockIdx.y / superN;
-  const unsigned sn     = blockIdx.y - sm * superN;
-  const unsigned xcd    = blockIdx.x & 7u;
-  const unsigned local  = blockIdx.x >> 3;  // 0 .. 8 superM - 1 inside the XCD's sub-block
-  const unsigned tile_m = sm * superM + (xcd >> 2) * (superM >> 1) + (local >> 4);
-  const unsigned tile_n = sn * SUPER + (xcd & 3u) * 16u + (local & 15u);
+  unsigned tile_m, tile_n;
+  maps::dense_tile(blockIdx.x, blockIdx.y, tilesN, superM, tile_m, tile_n);  // tile_maps.h (host-tested: tests/test_tile_maps.py)
   if (tile_m >= tilesM || tile_n >= tilesN) return;
 
   const int     tid   = threadIdx.x;
@@ -399,29 +395,15 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   if (symmetric) {
     // only the supertiles on or above the diagonal are launched (the strictly lower ones would be 2 M workgroups that
     // exit at once at N = 1M): sidx enumerates row sm = 0.., columns sn = sm..superN-1
-    const double S = static_cast<double>(superN);
-    unsigned     r = static_cast<unsigned>((2.0 * S + 1.0 - sqrt((2.0 * S + 1.0) * (2.0 * S + 1.0) - 8.0 * static_cast<double>(sidx))) * 0.5);
-    auto rowStart  = [&](const unsigned q) { return static_cast<unsigned long long>(q) * (2ull * superN - q + 1ull) / 2ull; };
-    while (r > 0 && rowStart(r) > sidx) --r;
-    while (rowStart(r + 1) <= sidx) ++r;
-    sm = r;
-    sn = r + static_cast<unsigned>(sidx - rowStart(r));
-    if (sm >= superN) return;  // padding of the 2-D supertile grid
+    if (!maps::symmetric_supertile(sidx, superN, sm, sn)) return;  // padding of the 2-D supertile grid (tile_maps.h)
   } else {
     sm = sidx / superN;
     sn = sidx - sm * superN;
   }
   unsigned tile_m, tile_n;
-  if (superH == 64u && superW == 64u) {
-    // XCD-aware walk of a full supertile, as in the dense kernel: workgroup b runs on XCD b % 8, which gets its own
-    // 32 x 16-tile sub-block, so that its L2 keeps 16 column tiles and one row tile instead of sharing all 64 row tiles
-    const unsigned xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
-    tile_m = sm * 64u + (xcd >> 2) * 32u + (local >> 4);
-    tile_n = sn * 64u + (xcd & 3u) * 16u + (local & 15u);
-  } else {
-    tile_m = sm * superH + blockIdx.x / superW;
-    tile_n = sn * superW + (blockIdx.x - (blockIdx.x / superW) * superW);
-  }
+  // XCD-aware walk of a full supertile, as in the dense kernel: workgroup b runs on XCD b % 8, which gets its own
+  // 32 x 16-tile sub-block, so that its L2 keeps 16 column tiles and one row tile instead of sharing all 64 row tiles
+  maps::count_tile(blockIdx.x, sm, sn, superH, superW, tile_m, tile_n);
   if (tile_m >= tilesM || tile_n >= tilesN) return;
   if (symmetric && tile_n < tile_m) return;
   if (tileRowHi != 0u && (tile_m < tileRowLo || tile_m >= tileRowHi)) return;  // another shard's tile rows
@@ -664,7 +646,7 @@ int launch_dense(int metric, const Prepared& A, const Prepared& B, double* out, 
   NVMK_REQUIRE(A.L.W * 32 < (1 << 24), "cross similarity: fingerprints too wide for the matrix-core path");
   const int64_t tilesM = ceil_div<int64_t>(A.L.n, TM);
   const int64_t tilesN = ceil_div<int64_t>(B.L.n, TN);
-  const int64_t superM = tilesM >= 2 * SUPER ? 2 * SUPER : SUPER;  // supertile height in tiles (see the kernel's tile map)
+  const int64_t superM = maps::dense_super_m(tilesM);  // supertile height in tiles (tile_maps.h)
   const int64_t supers = ceil_div<int64_t>(tilesM, superM) * ceil_div<int64_t>(tilesN, SUPER);
   NVMK_REQUIRE(supers <= 65535, "cross similarity: problem too large for one launch (%lld x %lld tiles)",
                (long long)tilesM, (long long)tilesN);

@@ -50,6 +50,13 @@ def shard_molecules_by_cost(n_atoms, world_size: int, rank: int, exponent: float
     communication.  The reference round-robins batches over GPUs (src/etkdg.cpp:330-380, bfgs_mmff.cpp:139-157)."""
     import numpy as np
 
+    return np.nonzero(molecule_owners_by_cost(n_atoms, world_size, exponent)[0] == rank)[0]
+
+
+def molecule_owners_by_cost(n_atoms, world_size: int, exponent: float = 2.0):
+    """(owner rank of every molecule, modelled load of every rank) of :func:`shard_molecules_by_cost`."""
+    import numpy as np
+
     cost = np.asarray(n_atoms, dtype=np.float64) ** exponent
     order = np.lexsort((np.arange(len(cost)), -cost))  # largest first, index as tie-break
     load = np.zeros(world_size)
@@ -58,7 +65,7 @@ def shard_molecules_by_cost(n_atoms, world_size: int, rank: int, exponent: float
         r = int(np.argmin(load))  # first minimum: deterministic
         owner[i] = r
         load[r] += cost[i]
-    return np.nonzero(owner == rank)[0]
+    return owner, load
 
 
 def merge_device_results(local, global_mol_ids, n_mols_total: int, group=None):
