@@ -38,7 +38,7 @@ class _Params(ctypes.Structure):
     _fields_ = [("confs_per_mol", ctypes.c_int32), ("max_iterations", ctypes.c_int32), ("batch_size", ctypes.c_int32),
                 ("use_exp_torsions", ctypes.c_int32), ("use_basic_knowledge", ctypes.c_int32),
                 ("enforce_chirality", ctypes.c_int32), ("box_size", ctypes.c_double), ("force_tol", ctypes.c_double),
-                ("seed", ctypes.c_uint64), ("demand_dispatch", ctypes.c_int32)]
+                ("seed", ctypes.c_uint64), ("demand_dispatch", ctypes.c_int32), ("oversub", ctypes.c_double)]
 
 
 _declared = False
