@@ -23,8 +23,6 @@
 #include <string>
 #include <atomic>
 #include <chrono>
-#include <cmath>
-#include <cstdlib>
 #include <stdexcept>
 #include <vector>
 
@@ -81,82 +79,6 @@ class Scheduler {
   uint64_t         dispatched_ = 0;
   std::vector<int> completed_;
   std::vector<int> attempts_;
-};
-
-// ---- demand-driven hand-out (the driver's default) ---------------------------------------------------------------------
-// The reference's rounds hand a molecule that misses ONE conformer another confs_per_mol attempts (limit = confs x round),
-// and every dispatch fills its batch with the next round's attempts before the current ones are known: measured on 10 000
-// molecules x 10 conformers, 131 072 attempts for 97 951 conformers — a fifth of the pipeline's work dropped at the end
-// (profiles/r04_conformers/).  Here a molecule is handed what it is EXPECTED to need: a fresh molecule its confs_per_mol
-// attempts; a molecule whose earlier attempts are known, oversub x missing / p attempts with p its own success rate so far
-// ((successes + 1) / (known attempts + 1)), at most confs_per_mol per hand-out like a round of the reference, minus what is
-// still in flight — molecules in order, so a batch holds the retries of the earlier molecules followed by the first attempts
-// of the next ones.  A hand-out that would fill less than an eighth of the batch (the end of a run, where a batch costs its
-// latency, not its size) doubles the oversubscription.  With several batches in flight (batches_per_gpu > 1) the in-flight
-// count keeps a second batch from repeating the first one's attempts, which the reference's rounds do.
-// Same bound on the attempts of a molecule (max_iterations x confs), same acceptance rule (the first confs_per_mol successes in
-// attempt order).  NVMK_ETKDG_SCHED=reference: the reference's Scheduler above drives nvmk_etkdg_embed instead.
-class DemandScheduler {
- public:
-  DemandScheduler(int nMols, int confsPerMol, int maxIterations, double oversub)
-      : confs_(confsPerMol), maxTries_(maxIterations * confsPerMol), oversub_(oversub), completed_(static_cast<size_t>(nMols), 0),
-        attempts_(static_cast<size_t>(nMols), 0), inflight_(static_cast<size_t>(nMols), 0) {}
-
-  std::vector<int> dispatch(int batchSize, uint64_t* attemptBase = nullptr) {
-    const std::lock_guard<std::mutex> lock(mutex_);
-    if (attemptBase) *attemptBase = dispatched_;
-    std::vector<int> give = plan(batchSize, oversub_);
-    int64_t          total = 0;
-    for (const int g : give) total += g;
-    if (total > 0 && total < batchSize / 8) give = plan(batchSize, 2.0 * oversub_);
-    std::vector<int> ids;
-    for (size_t m = 0; m < give.size(); ++m) {
-      for (int k = 0; k < give[m]; ++k) ids.push_back(static_cast<int>(m));
-      attempts_[m] += give[m];
-      inflight_[m] += give[m];
-    }
-    dispatched_ += ids.size();
-    return ids;
-  }
-
-  int record(const int* molIds, const int16_t* finishedOnIteration, int n) {
-    const std::lock_guard<std::mutex> lock(mutex_);
-    for (int i = 0; i < n; ++i) {
-      if (molIds[i] < 0 || molIds[i] >= static_cast<int>(completed_.size())) return -1;
-    }
-    for (int i = 0; i < n; ++i) {
-      completed_[static_cast<size_t>(molIds[i])] += finishedOnIteration[i] == -1 ? 0 : 1;
-      inflight_[static_cast<size_t>(molIds[i])] -= 1;
-    }
-    return 0;
-  }
-
- private:
-  std::vector<int> plan(const int batchSize, const double oversub) const {
-    std::vector<int> give(completed_.size(), 0);
-    int              room = batchSize;
-    for (size_t m = 0; m < completed_.size() && room > 0; ++m) {
-      if (completed_[m] >= confs_) continue;
-      const int need  = confs_ - completed_[m];
-      const int known = attempts_[m] - inflight_[m];  // attempts whose outcome has been recorded
-      int       want  = need;
-      if (attempts_[m] > 0) {
-        const double p = (completed_[m] + 1.0) / (known + 1.0);
-        want           = std::min(confs_, static_cast<int>(std::ceil(oversub * need / p)));
-      }
-      const int g = std::max(0, std::min(std::min(want - inflight_[m], maxTries_ - attempts_[m]), room));
-      give[m]     = g;
-      room -= g;
-    }
-    return give;
-  }
-
-  mutable std::mutex mutex_;
-  int                confs_;
-  int                maxTries_;
-  double             oversub_;
-  uint64_t           dispatched_ = 0;
-  std::vector<int>   completed_, attempts_, inflight_;
 };
 
 // ---- control kernels (src/etkdg_kernels.cu:20-70) -------------------------------------------------------
@@ -551,21 +473,11 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     h_conf_counts[m] = 0;
   }
 
-  Scheduler        refSched(nMols, prm->confs_per_mol, prm->max_iterations);
-  // NVMK_ETKDG_OVERSUB: retries handed out per expected need (default 1.5; experiments)
-  const double     oversub = [] {
-    const opt::Text t = opt::get(opt::kEtkdgOversub);
-    const double    v = t.set() ? std::atof(t.s) : 1.5;
-    return v >= 1.0 && v <= 10.0 ? v : 1.5;
-  }();
-  DemandScheduler  demandSched(nMols, prm->confs_per_mol, prm->max_iterations, oversub);
-  const bool       demand = !opt::get(opt::kEtkdgSched).is("reference");
-  struct {
-    Scheduler*       ref;
-    DemandScheduler* dem;
-    std::vector<int> dispatch(int batchSize, uint64_t* base) { return dem ? dem->dispatch(batchSize, base) : ref->dispatch(batchSize, base); }
-    int record(const int* ids, const int16_t* fin, int n) { return dem ? dem->record(ids, fin, n) : ref->record(ids, fin, n); }
-  } sched{&refSched, demand ? &demandSched : nullptr};
+  // One batch at a time and the reference's rounds: measured against a demand-driven hand-out (a molecule is handed what it is
+  // expected to still need) and against two to four concurrent batches, both slower at 10 000 molecules — the rounds' surplus
+  // attempts (131 072 for 97 951 conformers) cost less than the small, latency-bound batches a frugal hand-out ends a run with
+  // (profiles/r04_conformers/ab_etkdg_handout_and_workers_rejected.txt).
+  Scheduler        sched(nMols, prm->confs_per_mol, prm->max_iterations);
   std::mutex       outMutex;    // h_conf_counts / output slots / h_stage_failures / timings
   const bool       timing = opt::get(opt::kEtkdgTiming).is("1");
   StageTimings     timings;

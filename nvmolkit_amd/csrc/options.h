@@ -27,8 +27,6 @@ enum Id {
   kBfgsSched,       // NVMK_BFGS_SCHED       queue | hw (hw: one workgroup per system, hardware hand-out — rounds 1-3)
   kMarkers,         // NVMK_MARKERS          1 | 0 (0: no roctx ranges)
   kEtkdgTiming,     // NVMK_ETKDG_TIMING     1 (per-stage wall clock of nvmk_etkdg_embed: a stream synchronisation after every stage)
-  kEtkdgSched,      // NVMK_ETKDG_SCHED      demand | reference (reference: the reference's round scheduler drives nvmk_etkdg_embed)
-  kEtkdgOversub,    // NVMK_ETKDG_OVERSUB    x (demand hand-out: retries per expected need, default 1.5)
   kNumOptions
 };
 

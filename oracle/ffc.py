@@ -38,7 +38,7 @@ class _Params(ctypes.Structure):
     _fields_ = [("confs_per_mol", ctypes.c_int32), ("max_iterations", ctypes.c_int32), ("batch_size", ctypes.c_int32),
                 ("use_exp_torsions", ctypes.c_int32), ("use_basic_knowledge", ctypes.c_int32),
                 ("enforce_chirality", ctypes.c_int32), ("box_size", ctypes.c_double), ("force_tol", ctypes.c_double),
-                ("seed", ctypes.c_uint64), ("demand_dispatch", ctypes.c_int32), ("oversub", ctypes.c_double)]
+                ("seed", ctypes.c_uint64)]
 
 
 _declared = False
@@ -146,7 +146,7 @@ def random_coords(seed: int, attempt: int, n_atoms: int, box: float) -> np.ndarr
 
 def etkdg_embed(mols, confs_per_molecule: int = 1, max_iterations: int = -1, batch_size: int = 4096,
                 use_exp_torsions: bool = True, use_basic_knowledge: bool = True, enforce_chirality: bool = True,
-                box_size_mult: float = 2.0, force_tol: float = 1e-3, seed: int = 42, demand_dispatch: bool = True):
+                box_size_mult: float = 2.0, force_tol: float = 1e-3, seed: int = 42):
     """CPU twin of nvmolkit_amd.embedMolecules.embed_flat on a list of FlatMolecule-like objects (attributes n_atoms, dg,
     etk, checks, num_impropers).  Returns (coords flat float64, conf_counts, slot_starts, stage_failures, bfgs_iterations)."""
     n_atoms = np.array([m.n_atoms for m in mols], dtype=np.int32)
@@ -200,7 +200,6 @@ def etkdg_embed(mols, confs_per_molecule: int = 1, max_iterations: int = -1, bat
     prm.box_size = 5.0 * box_size_mult if box_size_mult > 0 else -box_size_mult
     prm.force_tol = force_tol
     prm.seed = seed & 0xFFFFFFFFFFFFFFFF
-    prm.demand_dispatch = 1 if demand_dispatch else 0
     slot = np.zeros(len(mols) + 1, dtype=np.int64)
     slot[1:] = np.cumsum(n_atoms.astype(np.int64) * confs_per_molecule * 3)
     coords = np.zeros(int(slot[-1]))

@@ -907,8 +907,6 @@ typedef struct {
   double   box_size;
   double   force_tol;
   uint64_t seed;
-  int32_t  demand_dispatch; /* != 0: the product's demand-driven hand-out (DemandScheduler of nvmolkit_amd/csrc/etkdg.hip); 0: the reference's rounds */
-  double   oversub;         /* demand hand-out: retries per expected need (0: the product's default, 1.5) */
 } orc_etkdg_params;
 
 static uint64_t splitmix64(uint64_t x) {
@@ -1100,7 +1098,6 @@ int64_t orc_etkdg_embed(const orc_molset* ms, const orc_etkdg_params* prm, doubl
   int64_t*  slot = (int64_t*)calloc((size_t)nMols + 1, sizeof(int64_t));
   int*      completed = (int*)calloc((size_t)nMols, sizeof(int));
   int*      attempts  = (int*)calloc((size_t)nMols, sizeof(int));
-  int*      give      = (int*)calloc((size_t)nMols, sizeof(int));
   int       maxAtoms = 0, maxRef = 1;
   for (int m = 0; m < nMols; ++m) {
     slot[m + 1]    = slot[m] + (int64_t)ms->n_atoms[m] * confs * 3;
@@ -1120,40 +1117,6 @@ int64_t orc_etkdg_embed(const orc_molset* ms, const orc_etkdg_params* prm, doubl
   int        round = 1;
   for (;;) {
     int n = 0, prev = -1;
-    if (prm->demand_dispatch) { /* DemandScheduler::dispatch (nothing is in flight here: a batch is recorded before the next is handed out) */
-      double oversub = prm->oversub >= 1.0 ? prm->oversub : 1.5;
-      for (int pass = 0; pass < 2; ++pass) {
-        int room = prm->batch_size, total = 0;
-        for (int m = 0; m < nMols; ++m) {
-          give[m] = 0;
-          if (room <= 0 || completed[m] >= confs) continue;
-          const int need = confs - completed[m];
-          int       want = need;
-          if (attempts[m] > 0) {
-            const double p = (completed[m] + 1.0) / (attempts[m] + 1.0);
-            want           = (int)ceil(oversub * need / p);
-            if (want > confs) want = confs;
-          }
-          int g = want;
-          if (g > maxTries - attempts[m]) g = maxTries - attempts[m];
-          if (g > room) g = room;
-          if (g < 0) g = 0;
-          give[m] = g;
-          room -= g;
-          total += g;
-        }
-        if (!(total > 0 && total < prm->batch_size / 8)) break;
-        oversub *= 2.0; /* a nearly empty batch: the end of the run */
-      }
-      for (int m = 0; m < nMols; ++m) {
-        for (int k = 0; k < give[m]; ++k) {
-          ids[n] = (sort_item){m, n};
-          ++n;
-        }
-        attempts[m] += give[m];
-      }
-      prev = n; /* skip the reference's loop below */
-    }
     while (n < prm->batch_size && prev != n) { /* Scheduler::dispatch */
       prev            = n;
       const int limit = maxTries < confs * round ? maxTries : confs * round;
@@ -1213,6 +1176,5 @@ int64_t orc_etkdg_embed(const orc_molset* ms, const orc_etkdg_params* prm, doubl
   free(slot);
   free(completed);
   free(attempts);
-  free(give);
   return totalIters;
 }

@@ -90,20 +90,12 @@ PY
         done
       done
       ;;
-    ab_etkdg_sched)
-      : > $O/ab_etkdg_sched.txt
-      for i in 1 2; do
-        for M in reference demand; do
-          NVMK_ETKDG_SCHED=$M timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --cache $CACHE 2>/dev/null | pick "etkdg_sched=$M" | tee -a $O/ab_etkdg_sched.txt
-        done
-      done
-      ;;
     ab_workers)
       : > $O/ab_workers.txt
-      for M in reference demand; do for W in "16384 1" "16384 2" "8192 2" "8192 3" "4096 4"; do
+      for W in "16384 1" "16384 2" "8192 2" "8192 3" "4096 4"; do
         set -- $W
-        NVMK_ETKDG_SCHED=$M timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --batch-size $1 --batches-per-gpu $2 --cache $CACHE 2>/dev/null | pick "sched=$M batch=$1 workers=$2" | tee -a $O/ab_workers.txt
-      done; done
+        timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --batch-size $1 --batches-per-gpu $2 --cache $CACHE 2>/dev/null | pick "batch=$1 workers=$2" | tee -a $O/ab_workers.txt
+      done
       ;;
     new_abi_tests)
       ( time timeout 900 python -m pytest tests/test_multi_gpu_abi_gpu.py tests/test_cxx_example.py tests/test_etkdg_gpu.py tests/test_config_size_gpu.py -m gpu -q -x ) > $O/new_abi_tests.log 2>&1
