@@ -168,10 +168,9 @@ PY
     butina)
       ( time timeout 900 python -m pytest tests/test_clustering_gpu.py tests/test_full_size_gpu.py tests/test_benchmark_molecules_gpu.py -m gpu -q -x ) > $O/butina_tests.log 2>&1
       tail -3 $O/butina_tests.log
-      for L in "" $(ls nvmolkit_amd/lib/ | sed -n 's/^libnvmolkit_amd_\(.*\)\.so$/\1/p'); do
-        LIBP=$ROOT/nvmolkit_amd/lib/libnvmolkit_amd${L:+_$L}.so
-        echo "lib ${L:-product}" | tee -a $O/bench_butina.txt
-        NVMOLKIT_AMD_LIB=$LIBP timeout 300 python tools/bench_butina.py 2>/dev/null | tail -4 | tee -a $O/bench_butina.txt
+      for T in small large small large; do
+        echo "NVMK_COUNT_TILE=$T" | tee -a $O/bench_butina.txt
+        NVMK_COUNT_TILE=$T timeout 300 python tools/bench_butina.py 2>/dev/null | tail -4 | tee -a $O/bench_butina.txt
       done
       ;;
     dist_gpu)
