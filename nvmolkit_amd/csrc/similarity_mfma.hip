@@ -833,13 +833,17 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   const bool    emit    = a.edges != nullptr;
   NVMK_REQUIRE(!emit || (a.symmetric && a.xRows == nullptr && a.yRows == nullptr && a.edgeCursor != nullptr),
                "neighbor counts: edge emission needs the symmetric, un-gathered mode and a cursor");
-  // Tile form.  Large problems take the 256 x 256 tile (4 x 4 matrix-instruction blocks per wave, one workgroup per CU,
-  // double-buffered chunks: half the LDS traffic per pair); small or skinny ones — a Butina subtract pass has one column
-  // tile — and shards whose tile-row bounds are not multiples of two 128-row tiles keep the 128 x 128 tile at four workgroups
-  // per CU.  NVMK_COUNT_TILE=small / large forces one form (tests run both on every case).
+  // Tile form: 128 x 128 at four workgroups per CU (default), or — NVMK_COUNT_TILE=large — 256 x 256 (4 x 4 matrix-instruction
+  // blocks per wave, one workgroup per CU, double-buffered chunks: half the LDS and operand traffic per pair).  Measured on the
+  // 1M x 1M pass: 0.848 s with the small tile, 1.256 s with the large one (profiles/r04_similarity/count_kernel_large_tile.txt):
+  // one workgroup per CU keeps ONE 64 KB chunk in flight against the 4 x 32 KB of four co-resident small-tile workgroups, and at
+  // ~1.8 us from request to data that is 36 GB/s per CU for a form that needs 75 GB/s to keep its matrix instructions fed —
+  // bound by the bytes in flight that 160 KB of LDS can hold, not by the LDS port.  Kept as an opt-in that every clustering
+  // test runs on every case (tests/test_clustering_gpu.py: mfma:large, mfma:largetable); shards whose tile-row bounds are not
+  // multiples of two 128-row tiles keep the small tile.
   const opt::Text tileOpt = opt::get(opt::kCountTile);
   const bool      evenRows = (a.tileRowLo % 2u == 0u) && (a.tileRowHi % 2u == 0u || static_cast<int64_t>(a.tileRowHi) * TM >= a.nX);
-  const bool      large = !tileOpt.is("small") && evenRows && (tileOpt.is("large") || (a.nX >= 4096 && a.nY >= 4096));
+  const bool      large = tileOpt.is("large") && evenRows;
   const int64_t   tile  = large ? 256 : TM;
   const int64_t tilesM  = ceil_div<int64_t>(a.nX, tile);
   const int64_t tilesN  = ceil_div<int64_t>(a.nY, tile);
@@ -856,8 +860,8 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   NVMK_REQUIRE(gz <= 65535, "neighbor counts: problem too large for one launch");
   const dim3   grid(static_cast<unsigned>(superE * superW), static_cast<unsigned>(gy), static_cast<unsigned>(gz));
   const size_t blocks = large ? 4 : 1;  // 128 x 128 units of the tile
-  const size_t shmem  = (large ? 2 : 1) * static_cast<size_t>(2 * tile) * 8 * 16 + 4 * static_cast<size_t>(tile) * 4 +
-                        (emit ? EDGE_STAGE * blocks * 8 + 16 : 0);
+  // (the large form's second chunk buffer is a static object of the kernel: 64 KB more)
+  const size_t shmem  = static_cast<size_t>(2 * tile) * 8 * 16 + 4 * static_cast<size_t>(tile) * 4 + (emit ? EDGE_STAGE * blocks * 8 + 16 : 0);
   NVMK_REQUIRE(std::max(X.L.nPad, Y.L.nPad) * X.L.Wp < (int64_t{1} << 32),
                "neighbor counts: prepared set too large for 32-bit piece offsets");
   using Kern = void (*)(const uint4*, const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, const uint4*,
