@@ -1745,10 +1745,7 @@ int pairs_impl(const uint32_t* d_x, int64_t N, int fpBits, double cutoff, int sh
   a.edgeCursor   = curMem.as<unsigned long long>();
   a.edgeCapacity = capacity;
   a.bandSkip     = sortPass;
-  // bands of 256-row tile rows, given in 128-row units (even bounds: the count kernel's large-tile form applies to a shard too)
-  shard_tile_rows(ceil_div<int64_t>(N, 2 * fp4::ROW_PAD), shard, nShards, a.tileRowLo, a.tileRowHi);
-  a.tileRowLo *= 2u;
-  a.tileRowHi *= 2u;
+  shard_tile_rows(ceil_div<int64_t>(N, fp4::ROW_PAD), shard, nShards, a.tileRowLo, a.tileRowHi);
   if (a.tileRowHi > a.tileRowLo) {  // an empty band (more shards than tile rows) contributes nothing
     rc = fp4::launch_counts(a, PX, PX, counts, stream);
     if (rc != NVMK_OK) return rc;

@@ -27,7 +27,6 @@ enum Id {
   kBfgsSched,       // NVMK_BFGS_SCHED       queue | hw (hw: one workgroup per system, hardware hand-out — rounds 1-3)
   kMarkers,         // NVMK_MARKERS          1 | 0 (0: no roctx ranges)
   kEtkdgTiming,     // NVMK_ETKDG_TIMING     1 (per-stage wall clock of nvmk_etkdg_embed: a stream synchronisation after every stage)
-  kCountTile,       // NVMK_COUNT_TILE       (unset) | small | large (tile form of the neighbour-count kernel: 128 x 128 / 256 x 256)
   kNumOptions
 };
 

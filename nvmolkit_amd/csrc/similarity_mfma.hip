@@ -37,8 +37,6 @@ constexpr int SUPER = 64;  // supertile edge in tiles: 64 x 64 tiles = 8 MB + 8 
 
 typedef int   v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void*       lptr_t;
 
 __device__ __forceinline__ uint32_t spread8(uint32_t x) {  // bit k of the low byte -> 0x2 in nibble k
   x = (x | (x << 12)) & 0x000F000Fu;
@@ -94,15 +92,6 @@ template <int KCW> struct Chunk {
   }
 };
 
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N - 1>) — the epilogue of the count kernel indexes 256
-// accumulator registers, which must never become a run-time index (the arrays would live in scratch memory)
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
 // One K chunk of MFMAs for this wave's 64 x 64 tile.
 template <int KCW>
 __device__ __forceinline__ void chunk_mma(v16f (&acc)[2][2], const char* sA, const char* sB, const int wm, const int wn,
@@ -133,106 +122,6 @@ __device__ __forceinline__ void chunk_mma(v16f (&acc)[2][2], const char* sA, con
   }
 }
 
-// The same for a wave tile of (32 WMI) x (32 WNI): WMI + WNI fragment reads feed WMI x WNI matrix instructions — 1.0 reads
-// per instruction at 2 x 2, 0.5 at 4 x 4 (the count kernel's large-tile form).  Rows + 32 keep the swizzle term.
-template <int KCW, int WMI, int WNI>
-__device__ __forceinline__ void chunk_mma_blocked(v16f (&acc)[WMI][WNI], const char* sA, const char* sB, const int wm, const int wn,
-                                                  const int lane) {
-  using C              = Chunk<KCW>;
-  const int      l31   = lane & 31;
-  const unsigned half  = static_cast<unsigned>(lane >> 5);
-  const unsigned rowA0 = static_cast<unsigned>(wm * 32 * WMI + l31);
-  const unsigned rowB0 = static_cast<unsigned>(wn * 32 * WNI + l31);
-  const unsigned baseA = rowA0 * C::ROWBYTES, baseB = rowB0 * C::ROWBYTES;
-  const unsigned swA = C::swz(rowA0), swB = C::swz(rowB0);
-#pragma unroll
-  for (int ks = 0; ks < KCW / 2; ++ks) {
-    const unsigned slot = static_cast<unsigned>(ks * 2) + half;
-    const unsigned offA = baseA + ((slot ^ swA) << 4);
-    const unsigned offB = baseB + ((slot ^ swB) << 4);
-    uint4          a[WMI], b[WNI];
-#pragma unroll
-    for (int i = 0; i < WMI; ++i) a[i] = *reinterpret_cast<const uint4*>(sA + offA + i * 32 * C::ROWBYTES);
-#pragma unroll
-    for (int j = 0; j < WNI; ++j) b[j] = *reinterpret_cast<const uint4*>(sB + offB + j * 32 * C::ROWBYTES);
-#pragma unroll
-    for (int i = 0; i < WMI; ++i) {
-#pragma unroll
-      for (int j = 0; j < WNI; ++j) acc[i][j] = mfma_fp4(a[i], b[j], acc[i][j]);
-    }
-  }
-}
-
-// The 4 x 4 form with the LDS reads written as assembly.  The compiler waits for EVERY outstanding LDS DMA (s_waitcnt vmcnt(0))
-// before any LDS read it knows of — it cannot tell the chunk buffer being filled from the one being read — which would put the
-// next chunk's DMA in series with this chunk's matrix instructions.  Reads it does not know of get no such wait; their own
-// completion is waited for by hand (s_waitcnt lgkmcnt(0), tied to the fragment registers so that the matrix instructions
-// stay behind it).  Inside a chunk the reads of K step ks + 1 are issued ahead of the 16 matrix instructions of step ks.
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-template <int OFF> __device__ __forceinline__ v4u lds_read16_asm(const unsigned addr) {
-  v4u v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
-}
-__device__ __forceinline__ void lds_wait_asm(v4u (&a)[4], v4u (&b)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-               :
-               : "memory");
-}
-__device__ __forceinline__ v16f mfma_fp4_v(const v4u a, const v4u b, const v16f c) {
-  const v8i av = {static_cast<int>(a.x), static_cast<int>(a.y), static_cast<int>(a.z), static_cast<int>(a.w), 0, 0, 0, 0};
-  const v8i bv = {static_cast<int>(b.x), static_cast<int>(b.y), static_cast<int>(b.z), static_cast<int>(b.w), 0, 0, 0, 0};
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-}
-template <int KCW>
-__device__ __forceinline__ void chunk_mma_4x4_asm(v16f (&acc)[4][4], const char* sA, const char* sB, const int wm, const int wn,
-                                                  const int lane) {
-  using C = Chunk<KCW>;
-  static_assert(KCW == 8, "written for 8-word chunks: four K steps");
-  const int      l31   = lane & 31;
-  const unsigned half  = static_cast<unsigned>(lane >> 5);
-  const unsigned rowA0 = static_cast<unsigned>(wm * 128 + l31);
-  const unsigned rowB0 = static_cast<unsigned>(wn * 128 + l31);
-  // LDS byte addresses (the low 32 bits of a shared-memory address are its offset in the workgroup's LDS)
-  const unsigned ldsA  = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)sA)) + rowA0 * C::ROWBYTES;
-  const unsigned ldsB  = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)sB)) + rowB0 * C::ROWBYTES;
-  const unsigned swA = C::swz(rowA0), swB = C::swz(rowB0);
-  constexpr int  R32 = 32 * C::ROWBYTES;  // 32 rows further down
-  auto read_step = [&](const int ks, v4u (&a)[4], v4u (&b)[4]) {
-    const unsigned slot = static_cast<unsigned>(ks * 2) + half;
-    const unsigned pa = ldsA + ((slot ^ swA) << 4), pb = ldsB + ((slot ^ swB) << 4);
-    a[0] = lds_read16_asm<0>(pa);
-    b[0] = lds_read16_asm<0>(pb);
-    a[1] = lds_read16_asm<R32>(pa);
-    b[1] = lds_read16_asm<R32>(pb);
-    a[2] = lds_read16_asm<2 * R32>(pa);
-    b[2] = lds_read16_asm<2 * R32>(pb);
-    a[3] = lds_read16_asm<3 * R32>(pa);
-    b[3] = lds_read16_asm<3 * R32>(pb);
-  };
-  auto mma_step = [&](const v4u (&a)[4], const v4u (&b)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_fp4_v(a[i], b[j], acc[i][j]);
-    }
-  };
-  v4u a0[4], b0[4], a1[4], b1[4];
-  read_step(0, a0, b0);
-  lds_wait_asm(a0, b0);
-  read_step(1, a1, b1);
-  mma_step(a0, b0);
-  lds_wait_asm(a1, b1);
-  read_step(2, a0, b0);
-  mma_step(a1, b1);
-  lds_wait_asm(a0, b0);
-  read_step(3, a1, b1);
-  mma_step(a0, b0);
-  lds_wait_asm(a1, b1);
-  mma_step(a1, b1);
-}
-
 // ---- dense cross-similarity ----------------------------------------------------------------------
 // Operand chunks go global -> LDS directly (global_load_lds_dwordx4: 1 KB per wave instruction, no staging
 // VGPRs, no ds_write pass).  The DMA destination is wave-uniform base + lane * 16, so the LDS image is linear in
@@ -251,6 +140,9 @@ __device__ __forceinline__ void chunk_mma_4x4_asm(v16f (&acc)[4][4], const char*
 // Checked exhaustively for u <= 16384 on the CPU for every possible 1-ulp seed (oracle_similarity.c
 // orc_check_newton_division) and for u <= 4096 on the device
 // (tests/test_similarity_gpu.py::test_prefix_fingerprints_exhaust_all_ratios).
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void*       lptr_t;
+
 __device__ __forceinline__ double ratio_by_newton(const int c, const int u) {
   const double ud = static_cast<double>(u);
   const double cd = static_cast<double>(c);
@@ -460,15 +352,10 @@ inline ArithThreshold arith_threshold(const float thr, const int F) {
   return t;
 }
 
-constexpr int EDGE_STAGE = 256;  // neighbour pairs a workgroup of the tile count kernel stages in LDS (per 128 x 128 of its tile)
+constexpr int EDGE_STAGE = 256;  // neighbour pairs a workgroup of the tile count kernel stages in LDS
 
-// WMI x WNI = matrix-instruction blocks of a wave (2 x 2 waves per workgroup): 2 x 2 is the 128 x 128 tile at four workgroups
-// per CU (every problem, small or skinny); 4 x 4 the 256 x 256 tile of the large symmetric / rectangular passes — 256
-// accumulator registers, one wave per SIMD, ONE workgroup per CU, operand chunks double-buffered in 128 KB of LDS with the next
-// chunk's DMA in flight under the current chunk's 64 matrix instructions per wave.  Per 128 x 128 pairs the 2 x 2 form moves
-// 768 KB through the CU's 128 B/clk LDS port (2.56 us at 2.4 GHz for 1.7 us of matrix work: port bound), the 4 x 4 form 384 KB.
-template <int METRIC, bool EMIT, bool ARITH = false, int WMI = 2, int WNI = 2>
-__global__ __launch_bounds__(NT, (WMI * WNI > 4) ? 1 : 4) void neighbor_count_mfma_kernel(
+template <int METRIC, bool EMIT, bool ARITH = false>
+__global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   const uint4* __restrict__ X, const int32_t* __restrict__ popX, const int32_t* __restrict__ xRows,
   const int32_t* __restrict__ xIds, int64_t nX,
   const int32_t* __restrict__ nXdev, const uint4* __restrict__ Y, const int32_t* __restrict__ popY,
@@ -477,26 +364,21 @@ __global__ __launch_bounds__(NT, (WMI * WNI > 4) ? 1 : 4) void neighbor_count_mf
   const unsigned superW, const unsigned superH, int2* __restrict__ edges, unsigned long long* __restrict__ edgeCursor,
   const unsigned long long edgeCapacity, const double K1, const double K2, const double adj, const float bandThr,
   const unsigned tileRowLo, const unsigned tileRowHi) {
-  constexpr int  KCW    = 8;
-  constexpr int  TM     = 64 * WMI, TN = 64 * WNI;  // (shadow the file's 128 x 128: this kernel's tile)
-  constexpr int  PPA    = TM / 32, PPB = TN / 32;   // DMA pieces (1 KB wave instructions: 8 rows x 8 slots) per wave and operand
-  constexpr int  RPP    = 64 / KCW;
-  constexpr bool DOUBLE = WMI == 4 && WNI == 4;      // two chunk buffers, the next chunk's DMA under the current chunk's MFMAs
-  constexpr int  STAGED = EDGE_STAGE * (WMI * WNI / 4);
-  using C               = Chunk<KCW>;
-  constexpr int  STAGE  = (TM + TN) * C::ROWBYTES;
+  constexpr int KCW = 8;
+  constexpr int PPW = KCW / 2;
+  constexpr int RPP = 64 / KCW;
+  using C           = Chunk<KCW>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  // DOUBLE: the second chunk buffer is an object of its own, so that the compiler can tell a DMA into one buffer from the
-  // reads of the other (it otherwise waits for every outstanding LDS DMA before any LDS read: no overlap)
-  __shared__ __attribute__((aligned(1024))) char smemOther[DOUBLE ? STAGE : 16];
-  int*  pcA    = reinterpret_cast<int*>(smem + STAGE);
+  char* sA     = smem;
+  char* sB     = smem + TM * C::ROWBYTES;
+  int*  pcA    = reinterpret_cast<int*>(smem + (TM + TN) * C::ROWBYTES);
   int*  pcB    = pcA + TM;
   int*  rowsum = pcB + TN;
   int*  colsum = rowsum + TM;
   // EMIT: neighbour pairs of the tile are staged here and leave with ONE atomic on the global cursor per workgroup
   // (one per non-empty ballot serialised 2.3 M returning atomics on a single address at N = 100k: 27 ms for a 5 ms pass)
-  int2* edgeBuf  = reinterpret_cast<int2*>(colsum + TN);  // [STAGED]
-  int*  edgeMeta = reinterpret_cast<int*>(edgeBuf + STAGED);  // [0] staged, [1..2] global base
+  int2* edgeBuf  = reinterpret_cast<int2*>(colsum + TN);  // [EDGE_STAGE]
+  int*  edgeMeta = reinterpret_cast<int*>(edgeBuf + EDGE_STAGE);  // [0] staged, [1..2] global base
 
   if (nXdev) nX = *nXdev;
   if (nYdev) nY = *nYdev;
@@ -545,16 +427,15 @@ __global__ __launch_bounds__(NT, (WMI * WNI > 4) ? 1 : 4) void neighbor_count_mf
     const int64_t rc = r < nY ? r : nY - 1;
     return yRows ? yRows[rc] : static_cast<int>(rc);
   };
-  for (int t = tid; t < TM + TN; t += NT) {  // (128 + 128 = one entry per thread in the 2 x 2 form)
-    if (t < TM) {
-      const int64_t r = rowA0 + t;
-      pcA[t]          = r < nX ? popX[physX(r)] : SENT;
-      rowsum[t]       = 0;
-    } else {
-      const int64_t r = rowB0 + (t - TM);
-      pcB[t - TM]     = r < nY ? popY[physY(r)] : SENT;
-      colsum[t - TM]  = 0;
-    }
+  if (tid < TM) {
+    const int64_t r = rowA0 + tid;
+    pcA[tid]        = r < nX ? popX[physX(r)] : SENT;
+    rowsum[tid]     = 0;
+  } else {
+    const int     t = tid - TM;
+    const int64_t r = rowB0 + t;
+    pcB[t]          = r < nY ? popY[physY(r)] : SENT;
+    colsum[t]       = 0;
   }
   if (EMIT && tid == 0) edgeMeta[0] = 0;
   if (bandThr > 0.0f) {
@@ -567,68 +448,41 @@ __global__ __launch_bounds__(NT, (WMI * WNI > 4) ? 1 : 4) void neighbor_count_mf
     if (maxB < t * minA || maxA < t * minB) return;
   }
 
-  v16f acc[WMI][WNI];
+  v16f acc[2][2];
 #pragma unroll
-  for (int mi = 0; mi < WMI; ++mi) {
+  for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < WNI; ++ni) {
+    for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
     }
   }
 
   {
-    // piece p = (wave * PP + t) * 64 + lane lands at LDS byte 16 p: row p / KCW, physical slot p % KCW; its source
+    // piece p = (wave * PPW + t) * 64 + lane lands at LDS byte 16 p: row p / KCW, physical slot p % KCW; its source
     // is the (gathered) row's logical slot physical ^ swz(row)
-    const unsigned lrow = static_cast<unsigned>(lane >> C::LOG);
-    unsigned       oa[PPA], ob[PPB];  // offsets in uint4 units: < 2^31 rows * Wp is checked by the launcher
+    const unsigned prow = static_cast<unsigned>(wave * 32 + (lane >> C::LOG));
+    unsigned       oa[PPW], ob[PPW];  // offsets in uint4 units: < 2^31 rows * Wp is checked by the launcher
 #pragma unroll
-    for (int t = 0; t < PPA; ++t) {
-      const unsigned row  = static_cast<unsigned>(wave * (TM / 4)) + lrow + RPP * t;
+    for (int t = 0; t < PPW; ++t) {
+      const unsigned row  = prow + RPP * t;
       const unsigned slot = (static_cast<unsigned>(lane) & (KCW - 1u)) ^ C::swz(row);
       oa[t]               = static_cast<unsigned>(physX(rowA0 + row)) * static_cast<unsigned>(Wp) + slot;
-    }
-#pragma unroll
-    for (int t = 0; t < PPB; ++t) {
-      const unsigned row  = static_cast<unsigned>(wave * (TN / 4)) + lrow + RPP * t;
-      const unsigned slot = (static_cast<unsigned>(lane) & (KCW - 1u)) ^ C::swz(row);
       ob[t]               = static_cast<unsigned>(physY(rowB0 + row)) * static_cast<unsigned>(Wp) + slot;
     }
-    auto issue = [&](const int ch, char* buf) {  // the chunk's DMA: this wave's share of both operands
-      char* sA = buf;
-      char* sB = buf + TM * C::ROWBYTES;
-#pragma unroll
-      for (int t = 0; t < PPA; ++t) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(X + oa[t] + ch * KCW), (lptr_t)(sA + (wave * PPA + t) * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int t = 0; t < PPB; ++t) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(Y + ob[t] + ch * KCW), (lptr_t)(sB + (wave * PPB + t) * 1024), 16, 0, 0);
-      }
-    };
     const int nChunks = Wp / KCW;
-    if constexpr (!DOUBLE) {
-      for (int ch = 0; ch < nChunks; ++ch) {
-        if (ch > 0) __syncthreads();
-        issue(ch, smem);
-        __syncthreads();
-        chunk_mma_blocked<KCW, WMI, WNI>(acc, smem, smem + TM * C::ROWBYTES, wm, wn, lane);
+    for (int ch = 0; ch < nChunks; ++ch) {
+      if (ch > 0) __syncthreads();
+#pragma unroll
+      for (int t = 0; t < PPW; ++t) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(X + oa[t] + ch * KCW), (lptr_t)(sA + (wave * PPW + t) * 1024), 16, 0, 0);
       }
-    } else {
-      // chunk ch sits in buffer ch & 1.  The barrier at the top of an iteration says: every wave's DMA of chunk ch has landed
-      // (each waited for its own, s_waitcnt vmcnt(0), before arriving) AND every wave has finished reading chunk ch - 1 —
-      // so the other buffer is free for chunk ch + 1, whose DMA then runs under this chunk's matrix instructions.
-      issue(0, smem);
-      for (int ch = 0; ch < nChunks; ch += 2) {  // (Wp is a multiple of 16 words in the prepared layout: an even chunk count)
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), lgkmcnt / expcnt untouched
-        __syncthreads();
-        issue(ch + 1, smemOther);
-        chunk_mma_4x4_asm<KCW>(acc, smem, smem + TM * C::ROWBYTES, wm, wn, lane);
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        if (ch + 2 < nChunks) issue(ch + 2, smem);
-        chunk_mma_4x4_asm<KCW>(acc, smemOther, smemOther + TM * C::ROWBYTES, wm, wn, lane);
+#pragma unroll
+      for (int t = 0; t < PPW; ++t) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(Y + ob[t] + ch * KCW), (lptr_t)(sB + (wave * PPW + t) * 1024), 16, 0, 0);
       }
+      __syncthreads();
+      chunk_mma<KCW>(acc, sA, sB, wm, wn, lane);
     }
   }
 
@@ -636,67 +490,51 @@ __global__ __launch_bounds__(NT, (WMI * WNI > 4) ? 1 : 4) void neighbor_count_mf
   // lanes 32-63: row il + 4), its two popcounts are scalar, and a select drops them into the lane that owns the row.
   // (Shuffle reductions cost 160 ds_bpermute per lane and tile: the 1M x 1M pass ran at 13 us per tile and CU against
   // 5 us for the dense kernel with the same main loop.)
-  int cc[WNI];
-  int myRow[(WMI + 1) / 2];  // lane L of word h: neighbours of row wm * 32 WMI + 64 h + L found in this tile
-  int pbv[WNI];
-#pragma unroll
-  for (int ni = 0; ni < WNI; ++ni) {
-    cc[ni]  = 0;
-    pbv[ni] = pcB[wn * 32 * WNI + ni * 32 + (lane & 31)];
-  }
-#pragma unroll
-  for (int h = 0; h < (WMI + 1) / 2; ++h) myRow[h] = 0;
+  int       cc[2] = {0, 0};
+  int       myRow = 0;  // lane L: neighbours of row wm * 64 + L found in this tile
+  const int pb0   = pcB[wn * 64 + (lane & 31)];
+  const int pb1   = pcB[wn * 64 + 32 + (lane & 31)];
   // The epilogue is VALU-issue bound (4 waves per SIMD run it back to back: 40 VALU cycles per pair cost 3.4 us per
   // tile and CU).  Kept lean: thresholds are floats compared against the f32 accumulators (exact integers, no
   // conversion), the table offset is one add per pair (byte offsets of row and column popcounts prepared once).
-  const char* tabB = reinterpret_cast<const char*>(table);
-  unsigned    pbOff[WNI];
+  const unsigned pbOff0 = static_cast<unsigned>(pb0) * 4u, pbOff1 = static_cast<unsigned>(pb1) * 4u;
+  const char*    tabB   = reinterpret_cast<const char*>(table);
   // ARITH: popcounts that can have no neighbour (padding sentinel, empty fingerprint) become +inf
-  double pbK[WNI];
-  float  pbF[WNI];
+  const double pbK0 = (pb0 == 0 || pb0 >= SENT) ? __builtin_inf() : static_cast<double>(pb0) * K2;
+  const double pbK1 = (pb1 == 0 || pb1 >= SENT) ? __builtin_inf() : static_cast<double>(pb1) * K2;
   // ... and a single-precision screen in front of the exact test: the accumulators are floats already, and with
   // |c (1 + m)|, |s m| < 2^13 the f32 evaluation of c (1 + m) - pb m - pa m is within 0.01 of the exact value, so a
   // slot whose best lane is below -0.02 holds no neighbour (2 FMAs + max + compare per slot instead of the f64 chain)
   const float K1f = static_cast<float>(K1), K2f = static_cast<float>(K2);
+  const float pbF0 = (pb0 == 0 || pb0 >= SENT) ? __builtin_inff() : static_cast<float>(pb0) * K2f;
+  const float pbF1 = (pb1 == 0 || pb1 >= SENT) ? __builtin_inff() : static_cast<float>(pb1) * K2f;
 #pragma unroll
-  for (int ni = 0; ni < WNI; ++ni) {
-    const bool never = pbv[ni] == 0 || pbv[ni] >= SENT;
-    pbOff[ni]        = static_cast<unsigned>(pbv[ni]) * 4u;
-    pbK[ni]          = never ? __builtin_inf() : static_cast<double>(pbv[ni]) * K2;
-    pbF[ni]          = never ? __builtin_inff() : static_cast<float>(pbv[ni]) * K2f;
-  }
-  static_for<WMI * 16>([&](auto slotTag) {
-    {
-      constexpr int  mi    = decltype(slotTag)::value / 16, r = decltype(slotTag)::value % 16;
-      constexpr int  rowLo = mi * 32 + (r & 3) + 8 * (r >> 2);  // wave-local row of lanes 0-31; lanes 32-63 hold rowLo + 4
-      const int      pav   = pcA[wm * 32 * WMI + rowLo + 4 * (lane >> 5)];
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int      rowLo = mi * 32 + (r & 3) + 8 * (r >> 2);  // wave-local row of lanes 0-31; lanes 32-63 hold rowLo + 4
+      const int      pav   = pcA[wm * 64 + rowLo + 4 * (lane >> 5)];
       const unsigned paOff = static_cast<unsigned>(pav) * 4u;
-      double         dv[WNI], paK = 0.0;
+      double         d0 = 0.0, d1 = 0.0, paK = 0.0;
       if constexpr (ARITH) {
         const float paF = (pav == 0 || pav >= SENT) ? __builtin_inff() : static_cast<float>(pav) * K2f;
-        float       best = fmaf(acc[mi][0][r], K1f, -pbF[0]);
-#pragma unroll
-        for (int ni = 1; ni < WNI; ++ni) best = fmaxf(best, fmaf(acc[mi][ni][r], K1f, -pbF[ni]));
-        if (__ballot(best - paF > -0.02f) == 0) return;  // screened out (the common case)
-        paK         = (pav == 0 || pav >= SENT) ? __builtin_inf() : __builtin_fma(static_cast<double>(pav), K2, -adj);
-        double dmax = -__builtin_inf();
-#pragma unroll
-        for (int ni = 0; ni < WNI; ++ni) {
-          dv[ni] = __builtin_fma(static_cast<double>(acc[mi][ni][r]), K1, -pbK[ni]);
-          dmax   = fmax(dmax, dv[ni]);
-        }
-        if (__ballot(dmax > paK) == 0) return;  // no neighbour in this row slot (the common case)
+        const float s0 = fmaf(acc[mi][0][r], K1f, -pbF0), s1 = fmaf(acc[mi][1][r], K1f, -pbF1);
+        if (__ballot(fmaxf(s0, s1) - paF > -0.02f) == 0) continue;  // screened out (the common case)
+        paK = (pav == 0 || pav >= SENT) ? __builtin_inf() : __builtin_fma(static_cast<double>(pav), K2, -adj);
+        d0  = __builtin_fma(static_cast<double>(acc[mi][0][r]), K1, -pbK0);
+        d1  = __builtin_fma(static_cast<double>(acc[mi][1][r]), K1, -pbK1);
+        if (__ballot(fmax(d0, d1) > paK) == 0) continue;  // no neighbour in this row slot (the common case)
       }
       int lo = 0, hi = 0;
 #pragma unroll
-      for (int ni = 0; ni < WNI; ++ni) {
+      for (int ni = 0; ni < 2; ++ni) {
         bool p;
         if constexpr (ARITH) {
-          p = dv[ni] > paK;
+          p = (ni ? d1 : d0) > paK;
         } else if constexpr (METRIC == NVMK_METRIC_TANIMOTO) {
-          p = acc[mi][ni][r] >= *reinterpret_cast<const float*>(tabB + (paOff + pbOff[ni]));
+          p = acc[mi][ni][r] >= *reinterpret_cast<const float*>(tabB + (paOff + (ni ? pbOff1 : pbOff0)));
         } else {
-          p = cosine_neighbor(static_cast<int>(acc[mi][ni][r]), pav, pbv[ni], thr);
+          p = cosine_neighbor(static_cast<int>(acc[mi][ni][r]), pav, ni ? pb1 : pb0, thr);
         }
         cc[ni] += p ? 1 : 0;
         const uint64_t m = __ballot(p);
@@ -707,8 +545,8 @@ __global__ __launch_bounds__(NT, (WMI * WNI > 4) ? 1 : 4) void neighbor_count_mf
           // Symmetric un-gathered mode only: logical row == physical row.  Pairs i < j once; the diagonal tile
           // holds both orientations and the self pairs, which are dropped here.
           if (m != 0) {
-            const int64_t  gi = rowA0 + wm * 32 * WMI + rowLo + 4 * (lane >> 5);
-            const int64_t  gj = rowB0 + wn * 32 * WNI + ni * 32 + (lane & 31);
+            const int64_t  gi = rowA0 + wm * 64 + rowLo + 4 * (lane >> 5);
+            const int64_t  gj = rowB0 + wn * 64 + ni * 32 + (lane & 31);
             const bool     e  = p && gi < gj && gi < nX && gj < nY;
             const uint64_t me = __ballot(e);
             if (me != 0) {
@@ -718,7 +556,7 @@ __global__ __launch_bounds__(NT, (WMI * WNI > 4) ? 1 : 4) void neighbor_count_mf
               base = __shfl(base, first);
               if (e) {
                 const int slot = base + __popcll(me & ((1ull << lane) - 1ull));
-                if (slot < STAGED) {
+                if (slot < EDGE_STAGE) {
                   edgeBuf[slot] = make_int2(static_cast<int>(gi), static_cast<int>(gj));
                 } else {  // a tile with more pairs than the staging area: straight to memory
                   const unsigned long long gs = atomicAdd(edgeCursor, 1ull);
@@ -730,27 +568,22 @@ __global__ __launch_bounds__(NT, (WMI * WNI > 4) ? 1 : 4) void neighbor_count_mf
         }
       }
       // drop the two scalar row counts into the lanes that own rows rowLo and rowLo + 4 (v_writelane: lane select in M0)
-      int mine = myRow[rowLo >> 6];  // (an asm operand cannot name a captured variable)
-      asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mine) : "s"(lo), "s"(rowLo & 63));
-      asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mine) : "s"(hi), "s"((rowLo + 4) & 63));
-      myRow[rowLo >> 6] = mine;
+      asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myRow) : "s"(lo), "s"(rowLo));
+      asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(myRow) : "s"(hi), "s"(rowLo + 4));
     }
-  });
-#pragma unroll
-  for (int h = 0; h < (WMI + 1) / 2; ++h) {
-    if (myRow[h] != 0) atomicAdd(&rowsum[wm * 32 * WMI + 64 * h + lane], myRow[h]);
   }
+  if (myRow != 0) atomicAdd(&rowsum[wm * 64 + lane], myRow);
   if (creditCols) {
 #pragma unroll
-    for (int ni = 0; ni < WNI; ++ni) {
+    for (int ni = 0; ni < 2; ++ni) {
       int v = cc[ni];
       v += __shfl_xor(v, 32);
-      if (lane < 32 && v != 0) atomicAdd(&colsum[wn * 32 * WNI + ni * 32 + lane], v);
+      if (lane < 32 && v != 0) atomicAdd(&colsum[wn * 64 + ni * 32 + lane], v);
     }
   }
   __syncthreads();
   if constexpr (EMIT) {
-    const int staged = edgeMeta[0] < STAGED ? edgeMeta[0] : STAGED;
+    const int staged = edgeMeta[0] < EDGE_STAGE ? edgeMeta[0] : EDGE_STAGE;
     if (staged > 0) {  // workgroup-uniform
       if (tid == 0) {
         const unsigned long long gb = atomicAdd(edgeCursor, static_cast<unsigned long long>(staged));
@@ -764,16 +597,15 @@ __global__ __launch_bounds__(NT, (WMI * WNI > 4) ? 1 : 4) void neighbor_count_mf
       }
     }
   }
-  for (int t = tid; t < TM + TN; t += NT) {
-    if (t < TM) {
-      const int     v = rowsum[t];
-      const int64_t r = rowA0 + t;
-      if (v != 0 && r < nX) atomicAdd(&counts[xIds ? xIds[r] : physX(r)], sign * v);
-    } else if (creditCols) {
-      const int     v = colsum[t - TM];
-      const int64_t r = rowB0 + (t - TM);
-      if (v != 0 && r < nY) atomicAdd(&counts[yIds ? yIds[r] : physY(r)], sign * v);
-    }
+  if (tid < TM) {
+    const int     v = rowsum[tid];
+    const int64_t r = rowA0 + tid;
+    if (v != 0 && r < nX) atomicAdd(&counts[xIds ? xIds[r] : physX(r)], sign * v);
+  } else if (creditCols) {
+    const int     t = tid - TM;
+    const int     v = colsum[t];
+    const int64_t r = rowB0 + t;
+    if (v != 0 && r < nY) atomicAdd(&counts[yIds ? yIds[r] : physY(r)], sign * v);
   }
 }
 
@@ -833,23 +665,11 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   const bool    emit    = a.edges != nullptr;
   NVMK_REQUIRE(!emit || (a.symmetric && a.xRows == nullptr && a.yRows == nullptr && a.edgeCursor != nullptr),
                "neighbor counts: edge emission needs the symmetric, un-gathered mode and a cursor");
-  // Tile form: 128 x 128 at four workgroups per CU (default), or — NVMK_COUNT_TILE=large — 256 x 256 (4 x 4 matrix-instruction
-  // blocks per wave, one workgroup per CU, double-buffered chunks: half the LDS and operand traffic per pair).  Measured on the
-  // 1M x 1M pass: 0.848 s with the small tile, 1.256 s with the large one (profiles/r04_similarity/count_kernel_large_tile.txt):
-  // one workgroup per CU keeps ONE 64 KB chunk in flight against the 4 x 32 KB of four co-resident small-tile workgroups, and at
-  // ~1.8 us from request to data that is 36 GB/s per CU for a form that needs 75 GB/s to keep its matrix instructions fed —
-  // bound by the bytes in flight that 160 KB of LDS can hold, not by the LDS port.  Kept as an opt-in that every clustering
-  // test runs on every case (tests/test_clustering_gpu.py: mfma:large, mfma:largetable); shards whose tile-row bounds are not
-  // multiples of two 128-row tiles keep the small tile.
-  const opt::Text tileOpt = opt::get(opt::kCountTile);
-  const bool      evenRows = (a.tileRowLo % 2u == 0u) && (a.tileRowHi % 2u == 0u || static_cast<int64_t>(a.tileRowHi) * TM >= a.nX);
-  const bool      large = tileOpt.is("large") && evenRows;
-  const int64_t   tile  = large ? 256 : TM;
-  const int64_t tilesM  = ceil_div<int64_t>(a.nX, tile);
-  const int64_t tilesN  = ceil_div<int64_t>(a.nY, tile);
-  const int64_t superE = [&] {  // supertile edge for this kernel (NVMK_COUNT_SUPER overrides for experiments)
+  const int64_t tilesM  = ceil_div<int64_t>(a.nX, TM);
+  const int64_t tilesN  = ceil_div<int64_t>(a.nY, TN);
+  const int64_t superE = [] {  // supertile edge for this kernel (NVMK_COUNT_SUPER overrides for experiments)
     const long v = opt::get(opt::kCountSuper).num(0);
-    return static_cast<int64_t>(v > 0 && v <= 256 ? v : (large ? 32 : SUPER));
+    return static_cast<int64_t>(v > 0 && v <= 256 ? v : SUPER);
   }();
   const int64_t superW  = std::min<int64_t>(tilesN, superE);
   const int64_t superM  = ceil_div<int64_t>(tilesM, superE);
@@ -859,9 +679,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   const int64_t gz     = ceil_div<int64_t>(supers, gy);
   NVMK_REQUIRE(gz <= 65535, "neighbor counts: problem too large for one launch");
   const dim3   grid(static_cast<unsigned>(superE * superW), static_cast<unsigned>(gy), static_cast<unsigned>(gz));
-  const size_t blocks = large ? 4 : 1;  // 128 x 128 units of the tile
-  // (the large form's second chunk buffer is a static object of the kernel: 64 KB more)
-  const size_t shmem  = static_cast<size_t>(2 * tile) * 8 * 16 + 4 * static_cast<size_t>(tile) * 4 + (emit ? EDGE_STAGE * blocks * 8 + 16 : 0);
+  const size_t shmem = static_cast<size_t>(TM + TN) * 8 * 16 + 4 * 128 * 4 + (emit ? EDGE_STAGE * 8 + 16 : 0);
   NVMK_REQUIRE(std::max(X.L.nPad, Y.L.nPad) * X.L.Wp < (int64_t{1} << 32),
                "neighbor counts: prepared set too large for 32-bit piece offsets");
   using Kern = void (*)(const uint4*, const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*, const uint4*,
@@ -872,27 +690,18 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   ArithThreshold at = arith_threshold(a.thr, F);
   if (opt::get(opt::kCountThreshold).is("table")) at.ok = false;  // tests: force the table form
   if (a.metric == NVMK_METRIC_TANIMOTO && at.ok) {
-    kern = large ? (emit ? neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, true, true, 4, 4> : neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, false, true, 4, 4>)
-                 : (emit ? neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, true, true> : neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, false, true>);
+    kern = emit ? neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, true, true> : neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, false, true>;
   } else if (a.metric == NVMK_METRIC_TANIMOTO) {
-    kern = large ? (emit ? neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, true, false, 4, 4> : neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, false, false, 4, 4>)
-                 : (emit ? neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, true> : neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, false>);
+    kern = emit ? neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, true> : neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, false>;
   } else {
-    kern = large ? (emit ? neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, true, false, 4, 4> : neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, false, false, 4, 4>)
-                 : (emit ? neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, true> : neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, false>);
+    kern = emit ? neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, true> : neighbor_count_mfma_kernel<NVMK_METRIC_COSINE, false>;
   }
-  if (shmem > 64 * 1024) {
-    NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem)));
-  }
-  // tile-row bounds of a shard are given in 128-row tiles
-  const unsigned rowLo = a.symmetric ? a.tileRowLo / (large ? 2u : 1u) : 0u;
-  const unsigned rowHi = a.symmetric ? (large ? (a.tileRowHi + 1u) / 2u : a.tileRowHi) : 0u;
   hipLaunchKernelGGL(kern, grid, dim3(NT), shmem, stream, X.rows, X.popc, a.xRows, a.xIds, a.nX, a.nXdev, Y.rows, Y.popc,
                      a.yRows, a.yIds, a.nY, a.nYdev, X.L.Wp, F, a.tableF, a.thr, a.sign, a.symmetric ? 1 : 0, counts,
                      static_cast<unsigned>(superN), static_cast<unsigned>(superW), static_cast<unsigned>(superE), a.edges,
                      a.edgeCursor, a.edgeCapacity, at.k1, at.k2, at.adj,
                      (a.bandSkip && a.metric == NVMK_METRIC_TANIMOTO && a.thr > 0.0f && a.xRows == nullptr && a.yRows == nullptr) ? a.thr : 0.0f,
-                     rowLo, rowHi);
+                     a.symmetric ? a.tileRowLo : 0u, a.symmetric ? a.tileRowHi : 0u);
   NVMK_LAUNCH_CHECK();
   return NVMK_OK;
 }

@@ -40,18 +40,14 @@ __host__ __device__ inline bool symmetric_supertile(const unsigned long long sid
   return sm < superN;
 }
 
-// Count kernel: tile of workgroup bx inside supertile (sm, sn) of superH x superW tiles; a full 64 x 64 (128-row tiles) or
-// 32 x 32 (256-row tiles) supertile is walked XCD-aware like the dense kernel's, any other (skinny problems) row-major.
+// Count kernel: tile of workgroup bx inside supertile (sm, sn) of superH x superW tiles; a full 64 x 64 supertile is walked
+// XCD-aware like the dense kernel's, a smaller one (skinny problems) row-major.
 __host__ __device__ inline void count_tile(const unsigned bx, const unsigned sm, const unsigned sn, const unsigned superH,
                                            const unsigned superW, unsigned& tile_m, unsigned& tile_n) {
   if (superH == 64u && superW == 64u) {
     const unsigned xcd = bx & 7u, local = bx >> 3;
     tile_m = sm * 64u + (xcd >> 2) * 32u + (local >> 4);
     tile_n = sn * 64u + (xcd & 3u) * 16u + (local & 15u);
-  } else if (superH == 32u && superW == 32u) {  // the 256 x 256-tile form: an XCD owns a 16 x 8-tile sub-block
-    const unsigned xcd = bx & 7u, local = bx >> 3;
-    tile_m = sm * 32u + (xcd >> 2) * 16u + (local >> 3);
-    tile_n = sn * 32u + (xcd & 3u) * 8u + (local & 7u);
   } else {
     tile_m = sm * superH + bx / superW;
     tile_n = sn * superW + (bx - (bx / superW) * superW);

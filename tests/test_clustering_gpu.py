@@ -13,8 +13,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["valu", "mfma", "mfma:dense", "mfma:serial", "mfma:table", "mfma:nosort", "mfma:large", "mfma:largetable", "mfma:small",
-                        "auto"], autouse=True)
+@pytest.fixture(params=["valu", "mfma", "mfma:dense", "mfma:serial", "mfma:table", "mfma:nosort", "auto"], autouse=True)
 def sim_path(request):
     """Neighbour counting / fused Butina run on the v_bcnt kernels, on the FP4 matrix-core kernels (round loop on the
     sparse neighbour graph, as parallel sweeps over a bucket or — serial — one round at a time on a persistent workgroup;
@@ -22,12 +21,8 @@ def sim_path(request):
     with the threshold TABLE instead of the exact-arithmetic predicate it uses for thresholds in [2^-10, 1]) and on the
     library's automatic choice (the switches are set through nvmk_set_option: the library reads the environment once)."""
     path, _, variant = request.param.partition(":")
-    # large / small: the 256 x 256-tile form of the matrix-core count kernel (4 x 4 blocks per wave, double-buffered chunks, LDS
-    # reads in assembly) forced on EVERY case, however small or ragged, and the 128 x 128 form forced where the library would
-    # pick the large one
     with _native.options(NVMK_SIM_PATH=path, NVMK_BUTINA_ROUNDS=variant if variant in ("dense", "serial") else None,
-                         NVMK_COUNT_THRESHOLD="table" if variant in ("table", "largetable") else None,
-                         NVMK_COUNT_TILE="large" if variant in ("large", "largetable") else ("small" if variant == "small" else None),
+                         NVMK_COUNT_THRESHOLD="table" if variant == "table" else None,
                          # fused Butina: all-pairs pass in input order (default: popcount-sorted copy with tile skipping)
                          NVMK_BUTINA_SORT="0" if variant == "nosort" else None):
         yield request.param
