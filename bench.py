@@ -350,6 +350,7 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
                                      "energy_evaluations": int(st[k, 3]), "hbm_resident_bytes": int(st[k, 4]),
                                      "mean_iterations": float(st[k, 1]) / max(int(st[k, 0]), 1)} for k in BFGS_KIND_NAMES}
     algo = float(sum(v["algorithmic_bytes"] for v in per_kind.values()))
+    requested = float(sum(v["hbm_resident_bytes"] for v in per_kind.values()))
     # HBM bytes of the block from the PMC passes committed under profiles/ (tools/profile_conformer_traffic.sh: separate
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs on 2000 molecules of the same set, FETCH_SIZE doubled as the guide's
     # gfx950 note prescribes), scaled by the conformers of this run; only while the kernel sources are the ones measured
@@ -377,7 +378,14 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
                             "generated 3-D geometry; nvmolkit_amd/synthetic.py) — real SMILES need RDKit"),
            "roofline": {"bound": "hbm", "achieved": algo / wall / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": algo / wall / 1e9 / HBM_PEAK_GBPS / world, "traffic": traffic, "traffic_source": traffic_src,
-                        "hbm_bytes_requested_by_the_hessian_pass": float(sum(v["hbm_resident_bytes"] for v in per_kind.values())),
+                        # which bytes a fraction counts: every byte of the packed inverse Hessians the iterations stand for
+                        # (rows served from LDS included) / only those the passes request from HBM / what crossed the L2s
+                        "frac_algorithmic": algo / wall / 1e9 / HBM_PEAK_GBPS / world,
+                        "frac_hbm_requested": requested / wall / 1e9 / HBM_PEAK_GBPS / world,
+                        "frac_measured_traffic": (traffic / wall / 1e9 / HBM_PEAK_GBPS / world) if traffic else None,
+                        "traffic_over_requested": (traffic / requested) if traffic and requested else None,
+                        "traffic_over_algorithmic": (traffic / algo) if traffic and algo else None,
+                        "hbm_bytes_requested_by_the_hessian_pass": requested,
                         "kernel": "nvmk::minim::bfgs_kernel<DG|ETK|MMFF> (> 99 % of the GPU time of this block)",
                         "note": "algorithmic bytes = sum over systems of BFGS iterations x 8 n (n + 2) (read + write of the "
                                 "packed inverse Hessian, counted by the kernels themselves: nvmk_bfgs_set_stats), divided by "

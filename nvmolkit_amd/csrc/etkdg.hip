@@ -124,6 +124,24 @@ __global__ void random_coords_kernel(const int nSystems, const int32_t* __restri
   }
 }
 
+// Surplus attempts leave before the second half of the pipeline.  The reference's rounds hand a molecule that misses one
+// conformer another confs_per_mol attempts (Scheduler above), and nearly every attempt that survives the first minimisation
+// and its checks is accepted in the end (failures per stage on the benchmark set: [0 23 458 0 0 0 1 0 5 0 0]) — so after stage
+// 3 a molecule's attempts beyond what it still misses, plus ONE spare, would run the ETK minimisation (half of the pipeline's
+// time) only to be dropped as extras when the batch is packed: 131 072 attempts for 97 951 conformers on 10 000 molecules x 10.
+// Attempt s of a batch is kept when fewer than keep[s] active attempts of the same molecule precede it (attempts of a molecule
+// are neighbours in a batch, in the scheduler's order, which is the order conformers are accepted in); the others are switched
+// off without a failure being counted.  `before` is a snapshot of the active flags.
+__global__ void prune_surplus_kernel(const int n, const int32_t* __restrict__ sysMol, const int32_t* __restrict__ keep,
+                                     const uint8_t* __restrict__ before, uint8_t* __restrict__ active) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !before[i]) return;
+  const int m    = sysMol[i];
+  int       rank = 0;
+  for (int j = i - 1; j >= 0 && sysMol[j] == m && rank < keep[i]; --j) rank += before[j];
+  if (rank >= keep[i]) active[i] = 0;
+}
+
 // E / atom >= 0.05 after the first minimisation fails the attempt (etkdg_stage_distgeom_minimize.cu:36-51)
 __global__ void energy_per_atom_check_kernel(const int n, const double* __restrict__ energies, const int32_t* __restrict__ atomStarts,
                                              uint8_t* __restrict__ failed) {
@@ -480,6 +498,7 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
   Scheduler        sched(nMols, prm->confs_per_mol, prm->max_iterations);
   std::mutex       outMutex;    // h_conf_counts / output slots / h_stage_failures / timings
   const bool       timing = opt::get(opt::kEtkdgTiming).is("1");
+  const bool       pruneSurplus = !opt::get(opt::kEtkdgPrune).is("0");  // NVMK_ETKDG_PRUNE=0: every attempt runs every stage
   StageTimings     timings;
   using Clock = std::chrono::steady_clock;
   auto ms_since = [](const Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); };
@@ -490,7 +509,7 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
   // dry.  batches_per_gpu workers run concurrently (the reference's batchesPerGpu, src/etkdg.cpp:330-380): the long
   // tail of one batch (a handful of systems still iterating, the GPU almost idle) overlaps with the bulk of another.
   auto worker = [&](hipStream_t stream) -> int {
-  DevBuf<int32_t>  dAtomStarts, dSysMol, dRef12Starts, dRef13Starts, dSrcSys;
+  DevBuf<int32_t>  dAtomStarts, dSysMol, dRef12Starts, dRef13Starts, dSrcSys, dKeep;
   DevBuf<int64_t>  dDstOff;
   DevBuf<double>   dPos, dPosMid, dPos3, dEnergies, dRef12, dRef13;
   DevBuf<uint8_t>  dActive, dFailed, dSub;
@@ -521,6 +540,14 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
       }
     }
     const int nAtoms = atomStarts.back();
+    // attempts of a molecule that may go on past stage 3: what it still misses, and one spare (prune_surplus_kernel)
+    std::vector<int32_t> keep(static_cast<size_t>(nSys), prm->confs_per_mol);
+    if (pruneSurplus) {
+      const std::lock_guard<std::mutex> lock(outMutex);
+      for (int s = 0; s < nSys; ++s) keep[static_cast<size_t>(s)] = prm->confs_per_mol - h_conf_counts[ids[static_cast<size_t>(s)]] + 1;
+      NVMK_HIP_CHECK(dKeep.ensure(static_cast<size_t>(nSys)));
+      NVMK_HIP_CHECK(hipMemcpyAsync(dKeep.p, keep.data(), static_cast<size_t>(nSys) * 4, hipMemcpyHostToDevice, stream));
+    }
     NVMK_HIP_CHECK(dAtomStarts.ensure(atomStarts.size()));
     NVMK_HIP_CHECK(dSysMol.ensure(static_cast<size_t>(nSys)));
     NVMK_HIP_CHECK(dPos.ensure(static_cast<size_t>(nAtoms) * 4));
@@ -640,6 +667,11 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     // stage 4: fourth-dimension minimisation — ran in stage 1's launch
     NVMK_TRY(begin_stage());
     NVMK_TRY(end_stage());
+    if (pruneSurplus) {  // between the halves of the pipeline: surplus attempts of a molecule leave (no failure counted)
+      NVMK_HIP_CHECK(hipMemcpyAsync(dSub.p, dActive.p, static_cast<size_t>(nSys), hipMemcpyDeviceToDevice, stream));
+      hipLaunchKernelGGL(prune_surplus_kernel, dim3(blocks(nSys)), dim3(256), 0, stream, nSys, dSysMol.p, dKeep.p, dSub.p, dActive.p);
+      NVMK_LAUNCH_CHECK();
+    }
     // stage 5: ETK minimisation (300 iterations) + planarity check
     NVMK_TRY(begin_stage());
     if (useEtk) {

@@ -27,6 +27,7 @@ enum Id {
   kBfgsSched,       // NVMK_BFGS_SCHED       queue | hw (hw: one workgroup per system, hardware hand-out — rounds 1-3)
   kMarkers,         // NVMK_MARKERS          1 | 0 (0: no roctx ranges)
   kEtkdgTiming,     // NVMK_ETKDG_TIMING     1 (per-stage wall clock of nvmk_etkdg_embed: a stream synchronisation after every stage)
+  kEtkdgPrune,      // NVMK_ETKDG_PRUNE      1 | 0 (0: surplus attempts of a molecule also run the second half of the pipeline)
   kNumOptions
 };
 

@@ -996,10 +996,12 @@ static int check_fails(const orc_molset* ms, int m, int kind, const double* p) {
   return 0;
 }
 
-/* One attempt: the eleven stages of src/etkdg.cpp:331-419 on one molecule.  Returns the index of the failing stage or
- * -1; pos4 holds the coordinates on exit. */
+/* One attempt: the eleven stages of src/etkdg.cpp:331-419 on one molecule, in two halves — `half` 0: stages 0-4 (start
+ * coordinates, first minimisation, its checks, fourth-dimension minimisation), `half` 1: stages 5-10 on the coordinates the first
+ * half left in pos4 — because the product drops a molecule's surplus attempts between them (prune_surplus_kernel of
+ * nvmolkit_amd/csrc/etkdg.hip).  Returns the index of the failing stage or -1; pos4 holds the coordinates on exit. */
 static int etkdg_attempt(const orc_molset* ms, const orc_etkdg_params* prm, int m, uint64_t attempt, double* pos4, double* pos3,
-                         double* ref, bfgs_ws* w, int64_t* bfgs_iters) {
+                         double* ref, bfgs_ws* w, int64_t* bfgs_iters, int half) {
   const int    na    = ms->n_atoms[m];
   const int    useEtk = prm->use_exp_torsions || prm->use_basic_knowledge;
   const int32_t starts01[2] = {0, na};
@@ -1014,19 +1016,22 @@ static int etkdg_attempt(const orc_molset* ms, const orc_etkdg_params* prm, int 
   const sysref rdg = {&dg, 0, m};
   double       e;
   int          conv;
-  orc_etkdg_random_coords(prm->seed, attempt, na, prm->box_size, pos4);
-  /* stage 1: first minimisation, repeated until converged (etkdg_stage_distgeom_minimize.cu:53-58), E / atom < 0.05 */
-  for (int rep = 0; rep < 50; ++rep) {
-    *bfgs_iters += bfgs_one(rdg, pos4, na, 0, 1.0, 0.1, 400, prm->force_tol, 1, w, &e, &conv, NULL);
-    if (conv) break;
-  }
-  e = system_eval(rdg, pos4, NULL, 1.0, 0.1, na, 0);
-  if (na > 0 && e / na >= 0.05) return 1;
-  if (check_fails(ms, m, 0, pos4)) return 2;
-  if (prm->enforce_chirality && check_fails(ms, m, 1, pos4)) return 3;
-  for (int rep = 0; rep < 50; ++rep) { /* stage 4: fourth-dimension minimisation */
-    *bfgs_iters += bfgs_one(rdg, pos4, na, 0, 0.2, 1.0, 200, prm->force_tol, 1, w, &e, &conv, NULL);
-    if (conv) break;
+  if (half == 0) {
+    orc_etkdg_random_coords(prm->seed, attempt, na, prm->box_size, pos4);
+    /* stage 1: first minimisation, repeated until converged (etkdg_stage_distgeom_minimize.cu:53-58), E / atom < 0.05 */
+    for (int rep = 0; rep < 50; ++rep) {
+      *bfgs_iters += bfgs_one(rdg, pos4, na, 0, 1.0, 0.1, 400, prm->force_tol, 1, w, &e, &conv, NULL);
+      if (conv) break;
+    }
+    e = system_eval(rdg, pos4, NULL, 1.0, 0.1, na, 0);
+    if (na > 0 && e / na >= 0.05) return 1;
+    if (check_fails(ms, m, 0, pos4)) return 2;
+    if (prm->enforce_chirality && check_fails(ms, m, 1, pos4)) return 3;
+    for (int rep = 0; rep < 50; ++rep) { /* stage 4: fourth-dimension minimisation */
+      *bfgs_iters += bfgs_one(rdg, pos4, na, 0, 0.2, 1.0, 200, prm->force_tol, 1, w, &e, &conv, NULL);
+      if (conv) break;
+    }
+    return -1;
   }
   if (useEtk) { /* stage 5 */
     orc_ff_batch etk;
@@ -1144,7 +1149,27 @@ int64_t orc_etkdg_embed(const orc_molset* ms, const orc_etkdg_params* prm, doubl
       int64_t its  = 0;
 #pragma omp for schedule(dynamic, 1)
       for (int s = 0; s < n; ++s) {
-        result[s] = etkdg_attempt(ms, prm, ids[s].mol, base + (uint64_t)s, batchPos + 4 * (size_t)maxAtoms * s, pos3, ref, &w, &its);
+        result[s] = etkdg_attempt(ms, prm, ids[s].mol, base + (uint64_t)s, batchPos + 4 * (size_t)maxAtoms * s, pos3, ref, &w, &its, 0);
+      }
+#pragma omp single
+      {
+        /* between the halves: a molecule's attempts beyond what it still misses plus one spare leave, in batch order, without a
+         * failure being counted (-2); what it misses is what it missed when the batch was handed out */
+        for (int s = 0; s < n; ++s) {
+          if (result[s] != -1) continue;
+          const int m = ids[s].mol, keep = confs - conf_counts[m] + 1;
+          int       rank = 0;
+          for (int j = s - 1; j >= 0 && ids[j].mol == m; --j) rank += (result[j] == -1 || result[j] == -3);
+          if (rank >= keep) result[s] = -3; /* marked, still counted by the attempts after it */
+        }
+        for (int s = 0; s < n; ++s) {
+          if (result[s] == -3) result[s] = -2;
+        }
+      }
+#pragma omp for schedule(dynamic, 1)
+      for (int s = 0; s < n; ++s) {
+        if (result[s] == -1)
+          result[s] = etkdg_attempt(ms, prm, ids[s].mol, base + (uint64_t)s, batchPos + 4 * (size_t)maxAtoms * s, pos3, ref, &w, &its, 1);
       }
 #pragma omp atomic
       totalIters += its;
@@ -1154,6 +1179,7 @@ int64_t orc_etkdg_embed(const orc_molset* ms, const orc_etkdg_params* prm, doubl
     }
     for (int s = 0; s < n; ++s) { /* record + pack, in batch order like the product */
       const int m = ids[s].mol;
+      if (result[s] == -2) continue; /* a surplus attempt that left between the halves */
       if (result[s] >= 0) {
         if (stage_failures) ++stage_failures[result[s]];
         continue;

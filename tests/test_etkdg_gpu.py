@@ -156,3 +156,27 @@ def test_concurrent_batches_reach_the_same_counts_and_satisfy_bounds():
     # accepted conformers passed the same stage checks in both modes: the worst bound violation is of the same size
     w_serial, w_par = worst(serial), worst(par)
     assert w_par < max(0.1, 2.0 * w_serial), (w_serial, w_par)
+
+
+def test_surplus_attempts_leave_before_the_second_half_without_changing_what_is_accepted():
+    """A molecule that misses one conformer is handed confs_per_mol more attempts by the reference's rounds; after the first
+    minimisation and its checks only what it still misses plus one spare go on to the ETK stage (prune_surplus_kernel).  The
+    conformers that are accepted are the first successes in attempt order either way: same counts, same coordinates, except
+    where one of the kept attempts fails late and the spare is used up too (rare; then another round supplies it).  Small
+    batches, so that most of the run is made of retry rounds."""
+    from nvmolkit_amd import _native, synthetic
+
+    lib = synthetic.druglike_library(120, seed=21, mean_atoms=32, processes=1)
+    molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in lib])
+    out = {}
+    for prune in ("0", "1"):
+        with _native.options(NVMK_ETKDG_PRUNE=prune):
+            out[prune] = embed_flat(molset, confs_per_molecule=6, max_iterations=10, seed=11, batch_size=96, batches_per_gpu=1)
+    a, b = out["0"], out["1"]
+    assert int(a.conf_counts.sum()) >= 0.9 * 6 * len(lib)
+    same = np.asarray(a.conf_counts) == np.asarray(b.conf_counts)
+    assert same.mean() >= 0.97 and abs(int(a.conf_counts.sum()) - int(b.conf_counts.sum())) <= 3
+    equal = [torch.equal(a.conformers(m), b.conformers(m)) for m in np.nonzero(same)[0]]
+    assert np.mean(equal) >= 0.9                                   # (a differing batch changes every later attempt's start coordinates)
+    # failures are only counted for attempts that ran the stage: never more with pruning
+    assert np.all(b.stage_failures[5:] <= a.stage_failures[5:] + 1)
