@@ -90,6 +90,15 @@ PY
         done
       done
       ;;
+    ab_prune)
+      : > $O/ab_prune.txt
+      for i in 1 2; do for M in 0 1; do
+        NVMK_ETKDG_PRUNE=$M timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --cache $CACHE 2>/dev/null | pick "prune=$M" | tee -a $O/ab_prune.txt
+      done; done
+      for M in 0 1; do
+        NVMK_ETKDG_PRUNE=$M timeout 600 python tools/bench_conformers.py --set chembl --mols 10000 --repeat 2 --cache $CACHE 2>/dev/null | pick "chembl prune=$M" | tee -a $O/ab_prune.txt
+      done
+      ;;
     ab_workers)
       : > $O/ab_workers.txt
       for W in "16384 1" "16384 2" "8192 2" "8192 3" "4096 4"; do
