@@ -99,6 +99,18 @@ PY
         NVMK_ETKDG_PRUNE=$M timeout 600 python tools/bench_conformers.py --set chembl --mols 10000 --repeat 2 --cache $CACHE 2>/dev/null | pick "chembl prune=$M" | tee -a $O/ab_prune.txt
       done
       ;;
+    sweep_conformers)
+      : > $O/sweep_conformers.txt
+      run() { env "$@" timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --cache $CACHE $EXTRA 2>/dev/null | pick "$* $EXTRA" | tee -a $O/sweep_conformers.txt; }
+      EXTRA=""
+      run NVMK_X=0
+      for G in 8 32 64; do run NVMK_BFGS_XCD_GROUP=$G; done
+      for W in 144 160 200; do run NVMK_BFGS_WAVE=$W; done
+      for W in 224 288; do run NVMK_BFGS_WAVE2=$W; done
+      for B in 12288 24576 32768; do EXTRA="--batch-size $B"; run NVMK_X=0; done
+      EXTRA=""
+      run NVMK_X=0
+      ;;
     ab_workers)
       : > $O/ab_workers.txt
       for W in "16384 1" "16384 2" "8192 2" "8192 3" "4096 4"; do
