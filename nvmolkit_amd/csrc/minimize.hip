@@ -447,8 +447,8 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   auto persistent = [&](const int c) { return queueMode || c == kGlobal || kBins[c].wgPerCu == 1; };
   for (int c = 0; c < nBins; ++c) {
     if (persistent(c)) continue;
-    const long    g         = opt::get(opt::kBfgsXcdGroup).num(16);
-    const int     kXcdGroup = g >= 1 && g <= 4096 ? static_cast<int>(g) : 16;
+    const long    g         = opt::get(opt::kBfgsXcdGroup).num(32);
+    const int     kXcdGroup = g >= 1 && g <= 4096 ? static_cast<int>(g) : 32;
     auto&         order     = cls[c].order;
     const int64_t n = static_cast<int64_t>(order.size()), chunk = 8LL * kXcdGroup;
     if (kXcdGroup > 1 && b.sysMol != nullptr && n >= 2 * chunk) {
@@ -588,8 +588,8 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     if (!P.used || !P.persistent) continue;
     auto&         order = cls[c].order;
     const int64_t n     = static_cast<int64_t>(order.size());
-    const long    g     = opt::get(opt::kBfgsXcdGroup).num(16);
-    const int     kXcdGroup = g >= 1 && g <= 4096 ? static_cast<int>(g) : 16;
+    const long    g     = opt::get(opt::kBfgsXcdGroup).num(32);
+    const int     kXcdGroup = g >= 1 && g <= 4096 ? static_cast<int>(g) : 32;
     for (int q = 0; q <= 8; ++q) P.queueStart[q] = q == 0 ? 0 : static_cast<int>(n);
     if (P.oneQueue || b.sysMol == nullptr || kXcdGroup <= 1 || n < 16LL * kXcdGroup) continue;
     std::vector<int32_t> queued;
