@@ -128,6 +128,9 @@ PY
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/pmc_hbm_traffic_conformers_classes_one_after_the_other.json 2>/dev/null
       tail -30 $O/conformer_traffic_seq.log
       ;;
+    chembl256)
+      timeout 600 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 256 --cache $CACHE 2> $O/chembl256.err | tee $O/chembl256.json | cut -c1-700
+      ;;
     chembl_tests)
       ( time timeout 900 python -m pytest tests/test_chembl_conformers_gpu.py -m gpu -q -x ) > $O/chembl_tests.log 2>&1
       tail -15 $O/chembl_tests.log
@@ -143,6 +146,8 @@ PY
       rm -rf gpurun_out/pmc_traffic/conf_fetch gpurun_out/pmc_traffic/conf_write
       timeout 900 bash tools/profile_conformer_traffic.sh 2000 > $O/conformer_traffic.log 2>&1
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/ 2>/dev/null
+      # (bench.py quotes the file from profiles/ while the kernel sources' digest matches: in place for the bench steps of this session)
+      mkdir -p profiles/r04_conformers && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json profiles/r04_conformers/ 2>/dev/null
       tail -30 $O/conformer_traffic.log
       ;;
     pytest_gpu)
@@ -166,8 +171,10 @@ PY
       rm -rf $O/bench_stats
       ;;
     bench_traffic)
+      rm -rf gpurun_out/pmc_traffic/fetch gpurun_out/pmc_traffic/write
       timeout 900 bash tools/profile_bench_traffic.sh > $O/bench_traffic.log 2>&1
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json $O/ 2>/dev/null
+      mkdir -p profiles/r04_similarity && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json profiles/r04_similarity/ 2>/dev/null
       tail -20 $O/bench_traffic.log
       ;;
     markers)
