@@ -357,10 +357,16 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     traffic, traffic_src = None, None
     for pmc in sorted((ROOT / "profiles").glob("r*/pmc_hbm_traffic_conformers.json"), reverse=True):
         c = json.loads(pmc.read_text())
-        if c.get("kernel_source_sha256") == conformer_source_digest() and c.get("hbm_bytes_per_conformer"):
-            traffic = float(c["hbm_bytes_per_conformer"]) * n_conf
-            traffic_src = (f"{pmc.relative_to(ROOT)}: (2 x FETCH_SIZE + WRITE_SIZE) per conformer on {c.get('molecules')} molecules of "
-                           f"the same set x this run's {n_conf} conformers, kernel source hash matches")
+        if c.get("kernel_source_sha256") == conformer_source_digest() and c.get("by_kind"):
+            # per kind: (bytes read + bytes written past the L2s) / (bytes the passes requested from HBM) of the PMC run, whose
+            # requested bytes come from the kernels' counters of that SAME run — applied to this run's requested bytes (a
+            # 2000-molecule run does more iterations per conformer than a 10 000-molecule one: bytes per conformer do not carry over)
+            traffic = sum(0.5 * per_kind[k]["hbm_resident_bytes"] * (c["by_kind"][k]["read_ratio"] + c["by_kind"][k]["write_ratio"])
+                          for k in per_kind if k in c["by_kind"])
+            traffic_src = (f"{pmc.relative_to(ROOT)}: per kind (2 x FETCH_SIZE + WRITE_SIZE) / requested bytes of a {c.get('molecules')}-molecule "
+                           f"run of the same set (reads " + " / ".join(f"{c['by_kind'][k]['read_ratio']:.2f}" for k in ("dg", "etk", "mmff")) +
+                           ", writes " + " / ".join(f"{c['by_kind'][k]['write_ratio']:.2f}" for k in ("dg", "etk", "mmff")) +
+                           " x requested for DG / ETK / MMFF) x this run's requested bytes, kernel source hash matches")
             break
     out = {"metric": f"mols/s ETKDG({confs} confs) + MMFF94 optimise (maxIters {mmff_iters})", "value": total_mols / wall,
            "unit": "mols/s", "n_gpus": world, "molecules": total_mols, "confs_per_molecule": confs,

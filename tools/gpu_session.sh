@@ -20,7 +20,6 @@
 #   chembl              the conformer block on the ChEMBL topologies (tools/bench_conformers.py --set chembl)
 #   strong              bench.py strong-scaling conformer mode as one rank over RCCL
 #   butina              tools/bench_butina.py + clustering tests
-#   dist_gpu            tests/test_distributed_gpu.py under torch.distributed.run --nproc 1
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 NAME=${1:?session name}
@@ -200,10 +199,6 @@ PY
         echo "NVMK_COUNT_TILE=$T" | tee -a $O/bench_butina.txt
         NVMK_COUNT_TILE=$T timeout 300 python tools/bench_butina.py 2>/dev/null | tail -4 | tee -a $O/bench_butina.txt
       done
-      ;;
-    dist_gpu)
-      ( time timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 -m pytest tests/test_distributed_gpu.py -m gpu -q -x ) > $O/dist_gpu.log 2>&1
-      tail -4 $O/dist_gpu.log
       ;;
     *) echo "unknown step $STEP" ;;
   esac
