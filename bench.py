@@ -310,7 +310,13 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     t_flatten = time.perf_counter() - t0
     t_prep = t_flatten + t_library
     lib = _native.lib()
-    embed_flat(FlatMoleculeSet([FlatMolecule(**library[0]["embed"])], device=device), 1, 5)  # warm-up: module load, pools
+    # warm-up (untimed, like the headline's warm-up steps): the pipeline once on the first 1000 molecules — module load, and the
+    # stream-ordered pool then holds blocks of the sizes the full run asks for (per-workgroup inverse-Hessian slots of every class)
+    n_warm = min(1000, n_mols)
+    warm = embed_flat(FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library[:n_warm]], device=device), confs_per_molecule=confs,
+                      max_iterations=10, seed=99, output=CoordinateOutput.DEVICE)
+    mmffOptimization.optimize_device([m["mmff"] for m in library[:n_warm]], warm, max_iters=mmff_iters)
+    del warm
     stats = torch.zeros(64, dtype=torch.int64, device=device)
     _native.check(lib.nvmk_bfgs_set_stats(stats.data_ptr()))
     if collectives:

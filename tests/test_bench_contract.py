@@ -47,3 +47,39 @@ def test_committed_bench_line_has_every_field_of_the_contract():
     for name in ("fused_butina", "conformers"):
         block = line["secondary"][name]
         assert "roofline" in block and "cpu_baseline" in block and block["roofline"]["frac"] > 0.0
+
+
+def test_multi_rank_start_up_pieces_without_a_gpu(tmp_path):
+    """What `bench.py --gpus N` does before its first collective, on the CPU: the molecule library generated once by rank 0 and
+    loaded by the others (no rank generates it again), every rank drawing only its own rows of the seeded reference set (the
+    rows agree with the full set drawn block by block), and the strong-scaling deal of one job over the ranks."""
+    import os
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    # reference fingerprints: a rank's rows == the same rows of the whole blocked set; ranges that straddle a 2^18-row block
+    full = bench.synth_fingerprints(600_000, 4, "cpu", 5, row_range=(0, 600_000))
+    for lo, hi in ((0, 75_000), (250_000, 300_000), (524_000, 600_000)):
+        assert torch.equal(bench.synth_fingerprints(600_000, 4, "cpu", 5, row_range=(lo, hi)), full[lo:hi])
+    assert bench.synth_fingerprints(600_000, 4, "cpu", 5, row_range=(10, 10)).shape == (0, 4)
+
+    # the shared library: two "ranks" as two processes, rank 1 started first
+    code = ("import sys, os, json; sys.path.insert(0, r'%s'); os.environ['MASTER_PORT'] = '%d'; import bench\n"
+            "lib, t = bench.conformer_library(24, 2, int(sys.argv[1]), shared=True)\n"
+            "print(json.dumps([len(lib), int(sum(m['embed']['n_atoms'] for m in lib)), float(lib[3]['bounds'][1].sum())]))\n") % (ROOT, 40000 + os.getpid() % 20000)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r1 = subprocess.Popen([sys.executable, "-c", code, "1"], stdout=subprocess.PIPE, text=True, env=env)
+    r0 = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=600, env=env)
+    out1, _ = r1.communicate(timeout=600)
+    assert r0.returncode == 0 and r1.returncode == 0, r0.stderr[-1500:]
+    assert json.loads(r0.stdout.strip().splitlines()[-1]) == json.loads(out1.strip().splitlines()[-1])
+
+    # one job of 100 molecule instances dealt over 4 ranks: every instance once, loads within a few per cent
+    lib = [{"embed": {"n_atoms": int(n)}} for n in np.random.default_rng(0).integers(12, 96, size=30)]
+    shares = [bench.strong_scaling_share(lib, 100, 4, r) for r in range(4)]
+    assert sum(len(s[0]) for s in shares) == 100 and all(s[1] == shares[0][1] for s in shares)
+    load = np.array(shares[0][1])
+    assert load.max() / load.mean() < 1.05
