@@ -459,6 +459,15 @@ int nvmk_conformer_rmsd_batch(const double* d_coords, const int64_t* d_coord_off
                               const int64_t* d_pair_offsets, int n_mols, int64_t total_pairs, int prealigned, double* d_out,
                               void* stream);
 
+/* The same with the molecule's symmetry: every molecule m brings K_m atom mappings of L_m atoms each (d_matches, mapping k of
+ * molecule m at d_match_offsets[m] + k * d_match_len[m]; K_m = (d_match_offsets[m + 1] - d_match_offsets[m]) / d_match_len[m],
+ * at least one) and the entry of a pair is the SMALLEST optimally superposed RMSD over the mappings — conformer i's atoms of
+ * mapping 0 against conformer j's atoms of mapping k (reference: _isConfFarFromRest, conformer_pruning.cpp:88-114, which loops
+ * over the self matches and rejects a conformer as soon as one of them brings it within the threshold of a kept one).  With one
+ * mapping per molecule this is the RMSD over an atom subset (onlyHeavyAtomsForRMS).  Condensed pair order as above. */
+int nvmk_conformer_rmsd_batch_sym(const double* d_coords, const int64_t* d_coord_offsets, const int32_t* d_n_atoms,
+                                  const int64_t* d_pair_offsets, int n_mols, int64_t total_pairs, const int64_t* d_match_offsets,
+                                  const int32_t* d_match_len, const int32_t* d_matches, double* d_out, void* stream);
 /* Greedy pruning on the matrices above: conformer i of a molecule is kept (d_keep[conf_starts[m] + i] = 1) iff its RMSD
  * to every conformer kept before it is >= threshold.  conf_starts has n_mols + 1 entries. */
 int nvmk_conformer_prune(const double* d_rmsd, const int64_t* d_pair_offsets, const int32_t* d_conf_starts, int n_mols,
@@ -508,6 +517,13 @@ int nvmk_smiles_size(const void* handle, int64_t* n_mols);
 int nvmk_smiles_free(void* handle);
 int nvmk_smiles_counts(const void* handle, int32_t* n_atoms, int32_t* n_bonds, int8_t* status);
 int nvmk_smiles_graph(const void* handle, int64_t mol, int32_t* atom_fields, int32_t* bond_fields);
+/* Self-matches of one molecule's (hydrogen-free) graph for symmetry-aware RMS pruning — what the reference takes from RDKit:
+ * SubstructMatch(mol, mol, maxMatches = 1000, uniquify = false) after removeHs, optionally on the copy whose conjugated
+ * terminal groups were made symmetric (rdkit_extensions/conformer_pruning.cpp:24-60 getMolSelfMatches;
+ * EmbedParameters::symmetrizeConjugatedTerminalGroupsForPruning).  out[k * n_atoms + i] = image of atom i in match k, the
+ * identity first; at most max_matches matches are written (out must hold max_matches * n_atoms ints), *n_matches says how many. */
+int nvmk_smiles_self_matches(const void* handle, int64_t mol, int symmetrize_terminal, int max_matches, int32_t* out,
+                             int32_t* n_matches);
 int nvmk_smiles_morgan_inputs(const void* handle, const int64_t* mol_ids, int64_t n_sel, int max_atoms, uint32_t* atom_inv,
                               uint32_t* bond_inv, int16_t* bond_idx, int16_t* bond_other, int16_t* n_atoms, int n_threads);
 

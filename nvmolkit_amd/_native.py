@@ -86,6 +86,7 @@ SIGNATURES: dict[str, tuple] = {
                                      ctypes.POINTER(ctypes.c_int32), _vp]),
     "nvmk_etkdg_stereo_check": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nvmk_conformer_rmsd_batch": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
+    "nvmk_conformer_rmsd_batch_sym": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp]),
     "nvmk_conformer_prune": (_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
     "nvmk_butina_dense": (_int, [_vp, _vp, _i64, ctypes.c_double, _int, _vp, _vp, ctypes.POINTER(_i64), _vp]),
     "nvmk_smiles_parse": (_int, [ctypes.POINTER(ctypes.c_char_p), _i64, _int, ctypes.POINTER(ctypes.c_void_p)]),
@@ -95,6 +96,7 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_smiles_size": (_int, [_vp, ctypes.POINTER(_i64)]),
     "nvmk_smiles_free": (_int, [_vp]),
     "nvmk_smiles_counts": (_int, [_vp, _vp, _vp, _vp]),
+    "nvmk_smiles_self_matches": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "nvmk_smiles_graph": (_int, [_vp, _i64, _vp, _vp]),
     "nvmk_smiles_morgan_inputs": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int]),
 }

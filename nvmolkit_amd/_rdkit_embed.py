@@ -303,3 +303,29 @@ def write_conformers(mol, coords: np.ndarray, clear: bool = True) -> Sequence[in
             conf.SetAtomPosition(a, Point3D(float(x), float(y), float(z)))
         ids.append(mol.AddConformer(conf, assignId=True))
     return ids
+
+
+def self_matches_for_pruning(mol, symmetrize_terminal_groups: bool = True, max_matches: int = 1000) -> np.ndarray:
+    """(K, n_heavy) atom indices of ``mol`` for symmetry-aware RMS pruning, row 0 the heavy atoms themselves and rows k > 0 their
+    images under the molecule's other self matches — RDKit's own substructure search on the hydrogen-stripped molecule, as the
+    reference asks for it (getMolSelfMatches, rdkit_extensions/conformer_pruning.cpp:24-60).  With
+    ``symmetrize_terminal_groups`` the query copy has its conjugated terminal N / O groups made alike (what
+    MolAlign::details::symmetrizeTerminalAtoms does in C++, which RDKit does not export to Python: the atoms become
+    atomic-number queries and their bonds single-or-double queries)."""
+    from rdkit import Chem
+
+    ps = Chem.RemoveHsParameters()
+    stripped = Chem.RemoveHs(mol, ps, sanitize=False)
+    query = Chem.RWMol(stripped)
+    if symmetrize_terminal_groups:
+        pattern = Chem.MolFromSmarts("[O,N;D1;$([O,N;D1]-[*]=[O,N;D1]),$([O,N;D1]=[*]-[O,N;D1])]~[*]")
+        either = Chem.MolFromSmarts("*-,=*").GetBondWithIdx(0)
+        for end, centre in stripped.GetSubstructMatches(pattern, uniquify=False):
+            query.ReplaceAtom(end, Chem.AtomFromSmarts(f"[#{stripped.GetAtomWithIdx(end).GetAtomicNum()}]"))
+            query.ReplaceBond(query.GetBondBetweenAtoms(end, centre).GetIdx(), either)
+    to_full = mol.GetSubstructMatches(query, uniquify=True, maxMatches=1)
+    if len(to_full) != 1:
+        raise RuntimeError("the hydrogen-stripped molecule was not found in the molecule")
+    found = stripped.GetSubstructMatches(query, uniquify=False, maxMatches=int(max_matches))
+    full = np.asarray(to_full[0], dtype=np.int32)
+    return np.stack([full[np.asarray(m, dtype=np.int64)] for m in found]).astype(np.int32)

@@ -15,7 +15,8 @@ import torch
 from nvmolkit_amd import _native
 from nvmolkit_amd.types import AsyncGpuResult, Device3DResult
 
-__all__ = ["GetConformerRMSMatrix", "GetConformerRMSMatrixBatch", "conformer_rms_matrix_flat", "prune_conformers"]
+__all__ = ["GetConformerRMSMatrix", "GetConformerRMSMatrixBatch", "conformer_rms_matrix_flat", "conformer_rms_matrix_sym_flat",
+           "prune_conformers"]
 
 
 def _check_stream(stream):
@@ -57,6 +58,55 @@ def conformer_rms_matrix_flat(coords: list[torch.Tensor], prealigned: bool = Fal
     return [out[pair_off[m]:pair_off[m + 1]] for m in range(len(coords))]
 
 
+def conformer_rms_matrix_sym_flat(coords: list[torch.Tensor], matches: list, stream=None) -> list[torch.Tensor]:
+    """Symmetry-aware RMSD matrices: ``matches[m]`` is an integer array (K_m, L_m) of atom mappings of molecule m (row 0 = the
+    reference atoms, normally the identity over the heavy atoms; rows k > 0 the molecule's other self matches — RDKit's
+    ``mol.GetSubstructMatches(mol, uniquify=False, maxMatches=1000)`` on the hydrogen-stripped molecule, or
+    ``SmilesSet.self_matches``).  Entry (i, j) is the smallest optimally superposed RMSD of conformer i's atoms ``matches[m][0]``
+    against conformer j's atoms ``matches[m][k]`` over k — the quantity the reference's ``_isConfFarFromRest`` thresholds
+    (rdkit_extensions/conformer_pruning.cpp:88-114).  One launch for the batch."""
+    _check_stream(stream)
+    if not coords:
+        return []
+    if len(matches) != len(coords):
+        raise ValueError("matches must have one entry per molecule")
+    device = coords[0].device
+    n_confs = np.array([int(c.shape[0]) for c in coords], dtype=np.int64)
+    n_atoms = np.array([int(c.shape[1]) for c in coords], dtype=np.int64)
+    tables = []
+    for m, (c, mt) in enumerate(zip(coords, matches)):
+        if not (isinstance(c, torch.Tensor) and c.is_cuda and c.dtype == torch.float64 and c.dim() == 3 and c.shape[2] == 3):
+            raise ValueError(f"coords[{m}] must be a float64 CUDA tensor of shape (n_confs, n_atoms, 3)")
+        t = np.ascontiguousarray(np.asarray(mt, dtype=np.int32))
+        if t.ndim != 2 or t.shape[0] < 1 or t.shape[1] < 1:
+            raise ValueError(f"matches[{m}] must be a non-empty (K, L) integer array")
+        if t.min() < 0 or t.max() >= n_atoms[m]:
+            raise ValueError(f"matches[{m}] names atoms outside the molecule")
+        tables.append(t)
+    pairs = n_confs * (n_confs - 1) // 2
+    pair_off = np.zeros(len(coords) + 1, dtype=np.int64)
+    pair_off[1:] = np.cumsum(pairs)
+    coord_off = np.zeros(len(coords) + 1, dtype=np.int64)
+    coord_off[1:] = np.cumsum(n_confs * n_atoms * 3)
+    match_off = np.zeros(len(coords) + 1, dtype=np.int64)
+    match_off[1:] = np.cumsum([t.size for t in tables])
+    match_len = np.array([t.shape[1] for t in tables], dtype=np.int32)
+    total = int(pair_off[-1])
+    with _native.on_stream(stream, device):
+        out = torch.empty(total, dtype=torch.float64, device=device)
+        if total > 0:
+            flat = torch.cat([c.reshape(-1) for c in coords]) if len(coords) > 1 else coords[0].reshape(-1).contiguous()
+            to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)  # noqa: E731
+            d_coff, d_na, d_poff = to_dev(coord_off, np.int64), to_dev(n_atoms, np.int32), to_dev(pair_off, np.int64)
+            d_moff, d_mlen, d_m = to_dev(match_off, np.int64), to_dev(match_len, np.int32), to_dev(np.concatenate([t.reshape(-1) for t in tables]), np.int32)
+            with torch.cuda.device(device):
+                rc = _native.lib().nvmk_conformer_rmsd_batch_sym(flat.data_ptr(), d_coff.data_ptr(), d_na.data_ptr(), d_poff.data_ptr(),
+                                                                 len(coords), total, d_moff.data_ptr(), d_mlen.data_ptr(), d_m.data_ptr(),
+                                                                 out.data_ptr(), _native.stream_ptr(stream))
+            _native.check(rc, "nvmk_conformer_rmsd_batch_sym")
+    return [out[pair_off[m]:pair_off[m + 1]] for m in range(len(coords))]
+
+
 def _positions(mol, device) -> torch.Tensor:
     confs = list(mol.GetConformers())
     n = mol.GetNumAtoms()
@@ -86,12 +136,19 @@ def GetConformerRMSMatrixBatch(mols, prealigned: bool = False, stream=None) -> l
     return [AsyncGpuResult(t) for t in conformer_rms_matrix_flat([_positions(m, device) for m in mols], prealigned, stream)]
 
 
-def prune_conformers(conformers: Device3DResult, threshold: float, atom_subsets=None) -> Device3DResult:
+def prune_conformers(conformers: Device3DResult, threshold: float, atom_subsets=None, self_matches=None) -> Device3DResult:
     """RMS pruning of a :class:`Device3DResult` on its GPU (EmbedParameters.pruneRmsThresh; reference:
     addConformersToMoleculeWithPruning): per molecule, in conformer order, a conformer is kept iff its aligned RMSD to every
     conformer kept before it is >= ``threshold``.  ``atom_subsets[m]`` (optional index array) restricts the RMSD of molecule
-    m to those atoms (``onlyHeavyAtomsForRMS``); symmetry-aware pruning needs RDKit's substructure matches and is not done
-    here.  Returns a compacted result (conformer indices renumbered 0..k-1 per molecule)."""
+    m to those atoms (``onlyHeavyAtomsForRMS``).  ``self_matches[m]`` (optional (K, L) integer array, row 0 the reference atoms)
+    makes the pruning symmetry-aware as in the reference (``useSymmetryForPruning``: getMolSelfMatches /
+    _isConfFarFromRest, rdkit_extensions/conformer_pruning.cpp:24-114): the RMSD of a pair is the smallest over the molecule's
+    self matches, so conformers that differ by a permutation of equivalent atoms count as the same.  The matches come from
+    RDKit where it exists (``mol.GetSubstructMatches(mol, uniquify=False, maxMatches=1000)`` on the hydrogen-stripped molecule)
+    or from the library's own ingestion (``SmilesSet.self_matches``).  Returns a compacted result (conformer indices
+    renumbered 0..k-1 per molecule)."""
+    if atom_subsets is not None and self_matches is not None:
+        raise ValueError("pass atom_subsets or self_matches (whose rows already name the atoms), not both")
     if threshold <= 0.0:
         return conformers
     values = conformers.values.torch()
@@ -116,7 +173,12 @@ def prune_conformers(conformers: Device3DResult, threshold: float, atom_subsets=
         if atom_subsets is not None and atom_subsets[m] is not None:
             block = block[:, torch.as_tensor(atom_subsets[m], dtype=torch.int64, device=dev)]
         coords.append(block.contiguous())
-    mats = conformer_rms_matrix_flat(coords)
+    if self_matches is not None:
+        tables = [np.asarray(self_matches[m], dtype=np.int32) if self_matches[m] is not None and coords[m].shape[0] > 0
+                  else np.arange(max(int(coords[m].shape[1]), 1), dtype=np.int32)[None, :] for m in range(conformers.n_mols)]
+        mats = conformer_rms_matrix_sym_flat(coords, tables)
+    else:
+        mats = conformer_rms_matrix_flat(coords)
     counts = np.diff(conf_starts).astype(np.int64)
     pair_off = np.zeros(conformers.n_mols + 1, dtype=np.int64)
     pair_off[1:] = np.cumsum(counts * (counts - 1) // 2)

@@ -1694,6 +1694,147 @@ int nvmk_smiles_graph(const void* handle, const int64_t mol, int32_t* atom_field
   return NVMK_OK;
 }
 
+// Self-matches of a molecule's heavy-atom graph for symmetry-aware RMS pruning: what the reference obtains from RDKit's
+// SubstructMatch(tmol, tmol, maxMatches = 1000, uniquify = false) on the hydrogen-stripped molecule
+// (rdkit_extensions/conformer_pruning.cpp:24-60, getMolSelfMatches) — every bijection of the atoms onto themselves that keeps
+// element, formal charge, isotope and every bond with its type.  symmetrize_terminal != 0 first makes conjugated terminal groups
+// symmetric the way RDKit's MolAlign::details::symmetrizeTerminalAtoms does (params.symmetrizeConjugatedTerminalGroupsForPruning):
+// a terminal N / O in X-[*]=X or X=[*]-X (carboxylate, nitro, amidine, sulfonyl ...) loses its charge and its bond becomes
+// single, so that the two ends are interchangeable.  Backtracking over the atoms in breadth-first order (an atom is placed next
+// to an already placed neighbour, so its candidates are the unused neighbours of that neighbour's image); the identity is the
+// first mapping returned.  out: n_matches x n_atoms target indices (out[k * n + i] = image of atom i).
+int nvmk_smiles_self_matches(const void* handle, const int64_t mol, const int symmetrize_terminal, const int max_matches, int32_t* out,
+                             int32_t* n_matches) {
+  NVMK_REQUIRE(handle != nullptr && n_matches != nullptr, "nvmk_smiles_self_matches: NULL argument");
+  const auto& set = *static_cast<const nvmk::smiles::Set*>(handle);
+  NVMK_REQUIRE(mol >= 0 && mol < set.nMols, "nvmk_smiles_self_matches: molecule index out of range");
+  NVMK_REQUIRE(max_matches > 0 && out != nullptr, "nvmk_smiles_self_matches: needs room for at least one match");
+  const nvmk::smiles::MolView g = set.view(mol);
+  const int                   n = g.nAtoms;
+  *n_matches                    = 0;
+  if (n == 0) return NVMK_OK;
+  struct Nb {
+    int to, order;
+  };
+  std::vector<std::vector<Nb>> adj(static_cast<size_t>(n));
+  std::vector<int>             z(static_cast<size_t>(n)), q(static_cast<size_t>(n)), iso(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    z[static_cast<size_t>(i)]   = g.atoms[i].z;
+    q[static_cast<size_t>(i)]   = g.atoms[i].charge;
+    iso[static_cast<size_t>(i)] = g.atoms[i].isotope;
+  }
+  for (int k = 0; k < g.nBonds; ++k) {
+    adj[static_cast<size_t>(g.bonds[k].a)].push_back({g.bonds[k].b, g.bonds[k].order});
+    adj[static_cast<size_t>(g.bonds[k].b)].push_back({g.bonds[k].a, g.bonds[k].order});
+  }
+  if (symmetrize_terminal) {
+    // RDKit's symmetrizeTerminalAtoms: a one-coordinate N or O single-bonded to an atom that is double-bonded to another
+    // one-coordinate N or O (carboxylate, nitro, amidine, primary amide ...), and that other atom, lose their charge and the two
+    // bonds become one class of their own ("single or double"), which only bonds of such groups belong to.
+    constexpr int kSingleOrDouble = 100;
+    auto terminal = [&](const int a) { return adj[static_cast<size_t>(a)].size() == 1 && (z[static_cast<size_t>(a)] == 7 || z[static_cast<size_t>(a)] == 8); };
+    std::vector<std::pair<int, int>> marked;  // (centre, terminal atom): decided on the bond orders as read, applied afterwards
+    for (int c = 0; c < n; ++c) {
+      for (const Nb& x : adj[static_cast<size_t>(c)]) {
+        if (!terminal(x.to) || x.order != 1) continue;
+        for (const Nb& y : adj[static_cast<size_t>(c)]) {
+          if (y.to == x.to || !terminal(y.to) || y.order != 2) continue;
+          marked.emplace_back(c, x.to);
+          marked.emplace_back(c, y.to);
+        }
+      }
+    }
+    for (const auto& [c, t] : marked) {
+      q[static_cast<size_t>(t)] = 0;
+      for (Nb& e : adj[static_cast<size_t>(c)])
+        if (e.to == t) e.order = kSingleOrDouble;
+      adj[static_cast<size_t>(t)][0].order = kSingleOrDouble;
+    }
+  }
+  // placement order: breadth first over every fragment; parent[i] = an earlier atom bonded to order[i] (-1: first of a fragment)
+  std::vector<int> order, parent(static_cast<size_t>(n), -1), pos(static_cast<size_t>(n), -1);
+  for (int root = 0; root < n; ++root) {
+    if (pos[static_cast<size_t>(root)] >= 0) continue;
+    pos[static_cast<size_t>(root)] = static_cast<int>(order.size());
+    order.push_back(root);
+    for (size_t head = order.size() - 1; head < order.size(); ++head) {
+      for (const Nb& e : adj[static_cast<size_t>(order[head])]) {
+        if (pos[static_cast<size_t>(e.to)] < 0) {
+          pos[static_cast<size_t>(e.to)]    = static_cast<int>(order.size());
+          parent[static_cast<size_t>(e.to)] = order[head];
+          order.push_back(e.to);
+        }
+      }
+    }
+  }
+  std::vector<int>  image(static_cast<size_t>(n), -1);
+  std::vector<char> used(static_cast<size_t>(n), 0);
+  auto compatible = [&](const int a, const int t) {
+    if (z[static_cast<size_t>(a)] != z[static_cast<size_t>(t)] || q[static_cast<size_t>(a)] != q[static_cast<size_t>(t)] ||
+        iso[static_cast<size_t>(a)] != iso[static_cast<size_t>(t)] || adj[static_cast<size_t>(a)].size() != adj[static_cast<size_t>(t)].size())
+      return false;
+    for (const Nb& e : adj[static_cast<size_t>(a)]) {  // every bond to an already placed atom must exist between the images, same type
+      const int im = image[static_cast<size_t>(e.to)];
+      if (im < 0) continue;
+      bool found = false;
+      for (const Nb& f : adj[static_cast<size_t>(t)]) found = found || (f.to == im && f.order == e.order);
+      if (!found) return false;
+    }
+    return true;
+  };
+  // iterative depth-first search; cand[d] = the next candidate to try at depth d.  The atom's own index is tried first, so that
+  // the first complete mapping is the identity (the reference takes its reference points from match 0).
+  std::vector<std::vector<int>> cands(static_cast<size_t>(n));
+  std::vector<size_t>           next(static_cast<size_t>(n), 0);
+  auto fill = [&](const int d) {
+    const int         a = order[static_cast<size_t>(d)];
+    std::vector<int>& c = cands[static_cast<size_t>(d)];
+    c.clear();
+    if (parent[static_cast<size_t>(a)] >= 0) {
+      for (const Nb& f : adj[static_cast<size_t>(image[static_cast<size_t>(parent[static_cast<size_t>(a)])])])
+        if (!used[static_cast<size_t>(f.to)]) c.push_back(f.to);
+    } else {
+      for (int t = 0; t < n; ++t)
+        if (!used[static_cast<size_t>(t)]) c.push_back(t);
+    }
+    std::stable_sort(c.begin(), c.end(), [&](const int x, const int y) { return (x == a) > (y == a); });
+    next[static_cast<size_t>(d)] = 0;
+  };
+  int     d     = 0;
+  int64_t steps = 0;
+  fill(0);
+  while (d >= 0 && *n_matches < max_matches && steps < 50'000'000) {
+    ++steps;
+    const int a = order[static_cast<size_t>(d)];
+    if (image[static_cast<size_t>(a)] >= 0) {  // coming back to this depth: undo its placement
+      used[static_cast<size_t>(image[static_cast<size_t>(a)])] = 0;
+      image[static_cast<size_t>(a)]                           = -1;
+    }
+    bool placed = false;
+    while (next[static_cast<size_t>(d)] < cands[static_cast<size_t>(d)].size()) {
+      const int t = cands[static_cast<size_t>(d)][next[static_cast<size_t>(d)]++];
+      if (!used[static_cast<size_t>(t)] && compatible(a, t)) {
+        image[static_cast<size_t>(a)] = t;
+        used[static_cast<size_t>(t)]  = 1;
+        placed                        = true;
+        break;
+      }
+    }
+    if (!placed) {
+      --d;
+      continue;
+    }
+    if (d + 1 == n) {
+      for (int i = 0; i < n; ++i) out[static_cast<size_t>(*n_matches) * n + i] = image[static_cast<size_t>(i)];
+      ++*n_matches;
+      continue;  // stay at this depth: try its next candidate
+    }
+    ++d;
+    fill(d);
+  }
+  return NVMK_OK;
+}
+
 int nvmk_smiles_morgan_inputs(const void* handle, const int64_t* mol_ids, const int64_t n_sel, const int max_atoms, uint32_t* atom_inv,
                               uint32_t* bond_inv, int16_t* bond_idx, int16_t* bond_other, int16_t* n_atoms, const int n_threads) {
   NVMK_MARK_ENTRY();

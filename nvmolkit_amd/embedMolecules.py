@@ -179,14 +179,15 @@ def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterati
                use_exp_torsions: bool = True, use_basic_knowledge: bool = True, enforce_chirality: bool = True,
                box_size_mult: float = 2.0, force_tol: float = 1e-3, seed: int = 42, stream=None,
                output: CoordinateOutput = CoordinateOutput.RDKIT_CONFORMERS, batches_per_gpu: int = -1,
-               prune_rms_thresh: float = -1.0, prune_atom_subsets=None):
+               prune_rms_thresh: float = -1.0, prune_atom_subsets=None, prune_self_matches=None):
     """ETKDG on flattened molecules (reference pipeline: src/etkdg.cpp:90-484 downstream of RDKit).
 
     Returns a :class:`FlatEmbedResult`, or with ``output=CoordinateOutput.DEVICE`` a :class:`Device3DResult` that the
     MMFF / UFF ``optimize_device`` entry points consume without a host round trip.
 
     ``prune_rms_thresh`` > 0 (EmbedParameters.pruneRmsThresh) prunes the conformers of every molecule on the GPU after the
-    embedding (``conformerRmsd.prune_conformers``; ``prune_atom_subsets[m]`` = atom indices for onlyHeavyAtomsForRMS) and
+    embedding (``conformerRmsd.prune_conformers``; ``prune_atom_subsets[m]`` = atom indices for onlyHeavyAtomsForRMS, or
+    ``prune_self_matches[m]`` = the molecule's (K, L) self matches for useSymmetryForPruning, e.g. ``SmilesSet.self_matches``) and
     needs ``output=DEVICE`` here — the reference prunes on the CPU and therefore only with RDKit conformer output.
 
     ``batches_per_gpu`` > 1 runs that many batches concurrently on their own streams (HardwareOptions.batchesPerGpu); -1
@@ -235,7 +236,7 @@ def embed_flat(molset: FlatMoleculeSet, confs_per_molecule: int = 1, max_iterati
     if prune_rms_thresh > 0.0:
         from nvmolkit_amd.conformerRmsd import prune_conformers
 
-        dev = prune_conformers(dev, float(prune_rms_thresh), prune_atom_subsets)
+        dev = prune_conformers(dev, float(prune_rms_thresh), prune_atom_subsets, prune_self_matches)
     return dev
 
 
@@ -394,14 +395,15 @@ def EmbedMolecules(molecules, params, confsPerMolecule: int = 1, maxIterations: 
         return embed_flat_molecules(flat, confsPerMolecule, maxIterations, hardwareOptions, output, targetGpu, **kw)
     coords = embed_flat_molecules(flat, confsPerMolecule, maxIterations, hardwareOptions, output, None, **kw)
     if prune > 0:
-        coords = [_prune_host(c, prune, m, bool(getattr(params, "onlyHeavyAtomsForRMS", False))) for c, m in zip(coords, molecules)]
+        coords = [_prune_host(c, prune, m, params) for c, m in zip(coords, molecules)]
     for mol, xyz in zip(molecules, coords):
         _rdkit_embed.write_conformers(mol, xyz)
     return None
 
 
-def _prune_host(xyz: np.ndarray, threshold: float, mol, heavy_only: bool) -> np.ndarray:
-    """RMS pruning of one molecule's conformers with the GPU pruning kernels (conformerRmsd.prune_conformers)."""
+def _prune_host(xyz: np.ndarray, threshold: float, mol, params) -> np.ndarray:
+    """RMS pruning of one molecule's conformers with the GPU pruning kernels (conformerRmsd.prune_conformers), on the atoms and
+    with the self matches the reference uses (getMolSelfMatches, rdkit_extensions/conformer_pruning.cpp:24-72)."""
     if len(xyz) < 2:
         return xyz
     from nvmolkit_amd.conformerRmsd import prune_conformers
@@ -412,10 +414,14 @@ def _prune_host(xyz: np.ndarray, threshold: float, mol, heavy_only: bool) -> np.
     res = Device3DResult(torch.from_numpy(np.ascontiguousarray(xyz.reshape(-1, 3))).to(dev), starts,
                          torch.zeros(len(xyz), dtype=torch.int32, device=dev),
                          torch.arange(len(xyz), dtype=torch.int32, device=dev), dev.index, 1)
-    subset = None
-    if heavy_only:
+    subset = matches = None
+    if bool(getattr(params, "useSymmetryForPruning", False)):
+        from nvmolkit_amd import _rdkit_embed
+
+        matches = [_rdkit_embed.self_matches_for_pruning(mol, bool(getattr(params, "symmetrizeConjugatedTerminalGroupsForPruning", True)))]
+    elif bool(getattr(params, "onlyHeavyAtomsForRMS", False)):
         subset = [[a.GetIdx() for a in mol.GetAtoms() if a.GetAtomicNum() > 1]]
-    kept = prune_conformers(res, threshold, subset)
+    kept = prune_conformers(res, threshold, subset, matches)
     return kept.values.torch().cpu().numpy().reshape(-1, n, 3)
 
 

@@ -39,3 +39,30 @@ def prune(confs: np.ndarray, threshold: float) -> np.ndarray:
     for i in range(len(confs)):
         keep[i] = all(pair_rmsd(confs[i], confs[k]) >= threshold for k in range(i) if keep[k])
     return keep
+
+
+def pair_rmsd_sym(a: np.ndarray, b: np.ndarray, matches: np.ndarray) -> float:
+    """Smallest superposed RMSD of a[matches[0]] against b[matches[k]] over the self matches k — what the reference's
+    _isConfFarFromRest compares with the threshold (rdkit_extensions/conformer_pruning.cpp:88-114: reference points from
+    selfMatches[0], probe points from each match, AlignPoints' sum of squares)."""
+    matches = np.asarray(matches, dtype=np.int64)
+    ref = np.asarray(a, dtype=np.float64)[matches[0]]
+    return min(pair_rmsd(ref, np.asarray(b, dtype=np.float64)[mt]) for mt in matches)
+
+
+def rms_matrix_sym(confs: np.ndarray, matches: np.ndarray) -> np.ndarray:
+    """Condensed lower triangle of pair_rmsd_sym: entry i (i - 1) / 2 + j = conformer i as the reference, conformer j probed."""
+    n = len(confs)
+    out = np.zeros(n * (n - 1) // 2)
+    for i in range(1, n):
+        for j in range(i):
+            out[i * (i - 1) // 2 + j] = pair_rmsd_sym(confs[i], confs[j], matches)
+    return out
+
+
+def prune_sym(confs: np.ndarray, threshold: float, matches: np.ndarray) -> np.ndarray:
+    """Greedy pruning with symmetry (addConformersToMoleculeWithPruning with useSymmetryForPruning)."""
+    keep = np.zeros(len(confs), dtype=bool)
+    for i in range(len(confs)):
+        keep[i] = all(pair_rmsd_sym(confs[i], confs[k], matches) >= threshold for k in range(i) if keep[k])
+    return keep

@@ -284,3 +284,43 @@ def invariant_components(atom_table, bond_table):
             dmass[i] = int(ISOTOPE.get((int(z), int(iso)), float(iso)) - WEIGHT[int(z)])
     comps = np.stack([atom_table[:, 0], atom_table[:, 3] + degree, atom_table[:, 3] + nbr_h, atom_table[:, 1], dmass], 1)
     return comps, atom_table[:, 5].astype(bool)
+
+
+def self_matches(atom_table, bond_table, symmetrize_terminal_groups: bool = True):
+    """Every mapping of the (hydrogen-free) graph onto itself that keeps element, charge, isotope and each bond with its type, as
+    a sorted list of tuples: image[i] of atom i.  By exhaustion over the permutations within each class of like atoms, so only
+    for small molecules; the count and the set are what RDKit's SubstructMatch(mol, mol, uniquify=False) returns
+    (rdkit_extensions/conformer_pruning.cpp:24-60).  ``symmetrize_terminal_groups``: the two terminal N / O atoms of a
+    conjugated X-A=Y group (X, Y one-coordinate N or O) are made alike first, as RDKit's MolAlign::details::symmetrizeTerminalAtoms
+    does for the query molecule: charges ignored, both bonds "single or double"."""
+    import itertools
+
+    atoms = np.array(atom_table, dtype=np.int64).reshape(-1, 6)
+    bonds = {}
+    for a, b, t, _ in np.asarray(bond_table, dtype=np.int64).reshape(-1, 4):
+        bonds[(int(a), int(b))] = bonds[(int(b), int(a))] = int(t)
+    n = len(atoms)
+    degree = [sum(1 for (a, _b) in bonds if a == i) for i in range(n)]
+    if symmetrize_terminal_groups:
+        read = dict(bonds)
+        for c in range(n):
+            ends = [x for x in range(n) if (c, x) in read and degree[x] == 1 and atoms[x, 0] in (7, 8)]
+            for x in ends:
+                for y in ends:
+                    if x != y and read[(c, x)] == 1 and read[(c, y)] == 2:
+                        for t in (x, y):
+                            bonds[(c, t)] = bonds[(t, c)] = -1        # "single or double": a class only such bonds are in
+                            atoms[t, 1] = 0
+    classes = {}
+    for i in range(n):
+        classes.setdefault((int(atoms[i, 0]), int(atoms[i, 1]), int(atoms[i, 2]), degree[i]), []).append(i)
+    groups = list(classes.values())
+    found = []
+    for perms in itertools.product(*(itertools.permutations(g) for g in groups)):
+        image = [0] * n
+        for g, p in zip(groups, perms):
+            for i, t in zip(g, p):
+                image[i] = t
+        if all(bonds.get((image[a], image[b])) == t for (a, b), t in bonds.items()):
+            found.append(tuple(image))
+    return sorted(found)

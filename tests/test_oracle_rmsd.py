@@ -60,3 +60,24 @@ def test_greedy_pruning():
     assert keep.tolist() == [True, False, True, False, False]       # rotated copy, noisy copy and translated copy go
     assert rmsd.prune(confs, 0.0).all()
     assert rmsd.prune(confs, 1e9).tolist() == [True, False, False, False, False]
+
+
+def test_symmetric_rmsd_is_the_smallest_over_the_self_matches():
+    """A conformer whose equivalent atoms are swapped is the same conformer once the self matches are searched (reference:
+    _isConfFarFromRest loops the matches, rdkit_extensions/conformer_pruning.cpp:101-112)."""
+    rng = np.random.default_rng(2)
+    a = rng.normal(size=(6, 3)) * 2.0
+    swap = np.array([1, 0, 2, 3, 5, 4])
+    b = a[swap]                                        # atoms 0 <-> 1 and 4 <-> 5 exchanged: a relabelling, not a new shape
+    ident = np.arange(6)
+    matches = np.stack([ident, swap])
+    assert rmsd.pair_rmsd(a, b) > 0.5
+    assert rmsd.pair_rmsd_sym(a, b, matches) == pytest.approx(0.0, abs=1e-7)
+    assert rmsd.pair_rmsd_sym(a, b, ident[None]) == pytest.approx(rmsd.pair_rmsd(a, b))
+    sub = np.stack([ident[:4], swap[:4]])              # matches over an atom subset (the heavy atoms): RMSD on those atoms only
+    assert rmsd.pair_rmsd_sym(a, b, sub) == pytest.approx(min(rmsd.pair_rmsd(a[:4], b[:4]), rmsd.pair_rmsd(a[:4], b[swap[:4]])))
+    confs = np.stack([a, b, a + 0.4 * rng.normal(size=a.shape), a[swap] + 1e-3])
+    assert rmsd.prune(confs, 0.1).tolist() == [True, True, True, False]      # the last is conformer 1 shifted: plain RMSD sees that much
+    assert rmsd.prune_sym(confs, 0.1, matches).tolist() == [True, False, True, False]
+    m = rmsd.rms_matrix_sym(confs, matches)
+    assert m[0] == pytest.approx(0.0, abs=1e-7) and m[3 * 2 // 2 + 1] < 0.01 and m[1] > 0.1

@@ -129,3 +129,79 @@ def test_embedding_with_rms_pruning():
         assert (m >= 0.5 - 1e-9).all()
     with pytest.raises(ValueError):
         embed_flat(molset, confs_per_molecule=2, prune_rms_thresh=0.5)
+
+
+def permuted_copies(rng, n_confs, n_atoms, matches, spread):
+    """Conformers around one shape, each relabelled by a random self match: plain RMSD sees them far apart."""
+    base = rng.normal(size=(n_atoms, 3)) * 2.0
+    out = []
+    for _ in range(n_confs):
+        c = base + spread * rng.normal(size=base.shape)
+        full = np.arange(n_atoms)
+        full[matches[0]] = matches[rng.integers(len(matches))]
+        out.append(c[full])
+    return np.stack(out)
+
+
+def random_matches(rng, n_atoms, length, k):
+    first = rng.permutation(n_atoms)[:length]
+    return np.stack([first] + [rng.permutation(first) for _ in range(k - 1)]).astype(np.int32)
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 2, 1), (4, 9, 9, 2), (7, 20, 14, 12), (6, 70, 64, 5), (5, 130, 65, 3), (3, 40, 40, 144)])
+def test_symmetric_matrix_matches_oracle(shape):
+    n_confs, n_atoms, length, k = shape
+    rng = np.random.default_rng(sum(shape))
+    matches = random_matches(rng, n_atoms, length, k)
+    c = permuted_copies(rng, n_confs, n_atoms, matches, 0.3)
+    from nvmolkit_amd.conformerRmsd import conformer_rms_matrix_sym_flat
+
+    got = conformer_rms_matrix_sym_flat([torch.from_numpy(c).cuda()], [matches])[0].cpu().numpy()
+    np.testing.assert_allclose(got, orc.rms_matrix_sym(c, matches), rtol=0, atol=1e-7 if length <= 3 else 1e-9)
+    if k == 1 and length == n_atoms:
+        np.testing.assert_allclose(got, orc.rms_matrix(c[:, matches[0]]), rtol=0, atol=1e-7)
+
+
+def test_symmetric_batch_is_one_launch_with_ragged_molecules_and_match_tables():
+    from nvmolkit_amd.conformerRmsd import conformer_rms_matrix_sym_flat
+
+    rng = np.random.default_rng(19)
+    sizes = [(4, 10, 10, 3), (0, 7, 5, 2), (1, 5, 5, 1), (9, 33, 20, 24), (2, 3, 3, 6)]
+    tables = [random_matches(rng, na, ln, k) for _, na, ln, k in sizes]
+    batch = [permuted_copies(rng, nc, na, t, 0.2) if nc else np.zeros((0, na, 3)) for (nc, na, _, _), t in zip(sizes, tables)]
+    got = conformer_rms_matrix_sym_flat([torch.from_numpy(c).cuda() for c in batch], tables)
+    assert [g.numel() for g in got] == [6, 0, 0, 36, 1]
+    for g, c, t in zip(got, batch, tables):
+        np.testing.assert_allclose(g.cpu().numpy(), orc.rms_matrix_sym(c, t), rtol=0, atol=1e-7)
+    with pytest.raises(ValueError):
+        conformer_rms_matrix_sym_flat([torch.from_numpy(batch[0]).cuda()], [np.array([[0, 1, 99]])])
+    with pytest.raises(ValueError):
+        conformer_rms_matrix_sym_flat([torch.from_numpy(batch[0]).cuda()], [])
+
+
+def test_pruning_with_symmetry_drops_relabelled_copies():
+    """useSymmetryForPruning (reference: getMolSelfMatches + _isConfFarFromRest): conformers that differ by a permutation of
+    equivalent atoms are one conformer.  para-xylene from the library's own SMILES ingestion, eight heavy atoms, four self
+    matches; hydrogens ride along in the conformers but not in the RMSD."""
+    from nvmolkit_amd.fingerprints import SmilesSet
+
+    s = SmilesSet(["Cc1ccc(C)cc1", "CCO"], perceive_aromaticity=True)
+    tables = [s.self_matches(0), s.self_matches(1)]
+    assert tables[0].shape == (4, 8) and tables[1].shape == (1, 3)
+    rng = np.random.default_rng(77)
+    per_mol = [permuted_copies(rng, 8, 18, tables[0], 0.01), permuted_copies(rng, 5, 9, tables[1], 0.6)]
+    values = torch.from_numpy(np.concatenate([c.reshape(-1, 3) for c in per_mol])).cuda()
+    starts = np.concatenate([[0], np.cumsum([c.shape[1] for c in per_mol for _ in range(len(c))])]).astype(np.int32)
+    mols = np.concatenate([np.full(len(c), m) for m, c in enumerate(per_mol)]).astype(np.int32)
+    cidx = np.concatenate([np.arange(len(c)) for c in per_mol]).astype(np.int32)
+    dev = Device3DResult(values, torch.from_numpy(starts).cuda(), torch.from_numpy(mols).cuda(), torch.from_numpy(cidx).cuda(), 0, 2)
+    thr = 0.25
+    with_sym = prune_conformers(dev, thr, self_matches=tables)
+    want = [orc.prune_sym(c, thr, t) for c, t in zip(per_mol, tables)]
+    assert [len(p) for p in with_sym.per_molecule()] == [int(w.sum()) for w in want]
+    assert want[0].sum() == 1                                    # every relabelled copy is recognised
+    heavy_only = prune_conformers(dev, thr, atom_subsets=[t[0] for t in tables])
+    assert len(heavy_only.per_molecule()[0]) > 1                  # without the matches the copies look different
+    assert len(heavy_only.per_molecule()[1]) == len(with_sym.per_molecule()[1])      # ethanol has no symmetry to use
+    with pytest.raises(ValueError):
+        prune_conformers(dev, thr, atom_subsets=[None, None], self_matches=tables)
