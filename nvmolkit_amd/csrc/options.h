@@ -16,7 +16,7 @@ enum Id {
   kButinaRounds,    // NVMK_BUTINA_ROUNDS    (unset) | dense | serial
   kButinaSort,      // NVMK_BUTINA_SORT      (unset) | 0
   kBfgsLds,         // NVMK_BFGS_LDS         auto | 0 | full | KiB
-  kBfgsXcdGroup,    // NVMK_BFGS_XCD_GROUP   16 | n
+  kBfgsXcdGroup,    // NVMK_BFGS_XCD_GROUP   32 | n
   kBfgsProfile,     // NVMK_BFGS_PROFILE     1
   kBfgsVectors,     // NVMK_BFGS_VECTORS     auto | global (tests: every system through the HBM-vector kernels)
   kBfgsOverlap,     // NVMK_BFGS_OVERLAP     1 | 0 (0: size classes run one after the other on the caller's stream)

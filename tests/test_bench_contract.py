@@ -21,7 +21,7 @@ def test_flags_and_defaults():
 
 
 def test_committed_bench_line_has_every_field_of_the_contract():
-    line = json.loads((ROOT / "profiles" / "r03_head_bench.json").read_text().strip().splitlines()[-1])
+    line = json.loads((ROOT / "profiles" / "r04_head_bench.json").read_text().strip().splitlines()[-1])
     baseline = json.loads((ROOT / "BASELINE.json").read_text())
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -47,6 +47,16 @@ def test_committed_bench_line_has_every_field_of_the_contract():
     for name in ("fused_butina", "conformers"):
         block = line["secondary"][name]
         assert "roofline" in block and "cpu_baseline" in block and block["roofline"]["frac"] > 0.0
+    # round 4: the conformer roofline names which bytes each fraction divides, the host preparation is split, and the same block
+    # runs on the topologies of the reference's chembl_10k.smi
+    conf = line["secondary"]["conformers"]
+    for key in ("frac_algorithmic", "frac_hbm_requested"):
+        assert 0.0 < conf["roofline"][key] < 1.0, key
+    assert conf["roofline"]["frac_hbm_requested"] <= conf["roofline"]["frac_algorithmic"]
+    for key in ("library_generation_seconds", "flatten_and_table_upload_seconds", "per_rank_seconds", "imbalance_max_over_mean"):
+        assert key in conf, key
+    chembl = line["secondary"]["conformers_chembl"]
+    assert chembl["molecules"] > 8000 and chembl["value"] > 0.0 and "chembl_10k.smi" in chembl["data"]
 
 
 def test_multi_rank_start_up_pieces_without_a_gpu(tmp_path):
