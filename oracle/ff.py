@@ -413,12 +413,22 @@ def bfgs_minimize(energy, gradient, x0: np.ndarray, max_iters: int = 200, grad_t
         if float((np.abs(g) * np.maximum(np.abs(x), 1.0)).max()) / max(e_prev * gscale, 1.0) < grad_tol:
             converged = True
             break
-        hdg = hinv @ dg
-        fac, fae = float(dg @ xi), float(dg @ hdg)
-        if fac > 0 and fac * fac > EPS * float(dg @ dg) * float(xi @ xi):
-            fac, fad = 1.0 / fac, 1.0 / fae
-            dgv = fac * xi - fad * hdg
-            hinv = hinv + fac * np.outer(xi, xi) - fad * np.outer(hdg, hdg) + fae * np.outer(dgv, dgv)
-        d = -(hinv @ g)
+        hinv, _, _, d = inverse_hessian_update(hinv, dg, xi, g)
         it += 1
     return x.reshape(np.shape(x0)), e_prev, converged, it
+
+
+def inverse_hessian_update(hinv: np.ndarray, dgrad: np.ndarray, xi: np.ndarray, grad: np.ndarray):
+    """One BFGS update of the inverse Hessian and the next search direction, as a step of its own (the operation the reference
+    tests in isolation: updateInverseHessianBFGSBatch, src/minimizer/bfgs_hessian.cu, against the loop of
+    tests/test_bfgs_hessian.cpp:27-78, i.e. RDKit's BFGSOpt.h): hessDGrad = H dGrad; when dGrad . xi > sqrt(EPS |dGrad|^2 |xi|^2)
+    the rank-two update H += xi xi^T / fac - hdg hdg^T / fae + fae u u^T with u = xi / fac - hdg / fae, which also replaces
+    dGrad; then xi = -H grad.  Returns (H, hessDGrad, dGrad, xi); the arguments are left alone."""
+    hinv, dgrad, xi, grad = (np.array(a, dtype=np.float64) for a in (hinv, dgrad, xi, grad))
+    hdg = hinv @ dgrad
+    fac, fae = float(dgrad @ xi), float(dgrad @ hdg)
+    if fac > 0 and fac * fac > EPS * float(dgrad @ dgrad) * float(xi @ xi):
+        fac, fad = 1.0 / fac, 1.0 / fae
+        dgrad = fac * xi - fad * hdg
+        hinv = hinv + fac * np.outer(xi, xi) - fad * np.outer(hdg, hdg) + fae * np.outer(dgrad, dgrad)
+    return hinv, hdg, dgrad, -(hinv @ grad)
