@@ -13,6 +13,7 @@ enum Id {
   kSimPath,         // NVMK_SIM_PATH         auto | mfma | valu
   kCountThreshold,  // NVMK_COUNT_THRESHOLD  (unset) | table
   kCountSuper,      // NVMK_COUNT_SUPER      supertile edge of the count kernel (experiments)
+  kCountKernel,     // NVMK_COUNT_KERNEL     auto | tile | panel (symmetric all-pairs pass: 128 x 128 tiles, or row panels with the A operand in registers)
   kButinaRounds,    // NVMK_BUTINA_ROUNDS    (unset) | dense | serial
   kButinaSort,      // NVMK_BUTINA_SORT      (unset) | 0
   kBfgsLds,         // NVMK_BFGS_LDS         auto | 0 | full | KiB

@@ -14,6 +14,7 @@
 // LDS rows are XOR-swizzled in 16-byte slots: every ds_read_b128 lane group touches 16 different slots of the
 // 256-byte bank row.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -609,6 +610,8 @@ __global__ __launch_bounds__(NT, 4) void neighbor_count_mfma_kernel(
   }
 }
 
+#include "count_panel.inc"
+
 }  // namespace
 
 int prepare(const uint32_t* d_in, const int32_t* d_rows, int64_t n, int fpBits, void* ws, hipStream_t stream) {
@@ -689,6 +692,54 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
   Kern kern;
   ArithThreshold at = arith_threshold(a.thr, F);
   if (opt::get(opt::kCountThreshold).is("table")) at.ok = false;  // tests: force the table form
+  {
+    // Row-panel form (count_panel.inc) for the all-pairs pass of one un-gathered set: NVMK_COUNT_KERNEL=panel forces it wherever
+    // it applies, tile never uses it, unset = by size.
+    const opt::Text which   = opt::get(opt::kCountKernel);
+    const bool      sameSet = X.rows == Y.rows && X.popc == Y.popc && a.nX == a.nY;
+    const bool      whole   = a.tileRowHi == 0u || a.tileRowHi >= static_cast<unsigned>(tilesM);
+    const bool      applies = a.symmetric && sameSet && !a.xRows && !a.yRows && !a.xIds && !a.yIds && !a.nXdev && !a.nYdev &&
+                         a.metric == NVMK_METRIC_TANIMOTO && at.ok && (X.L.Wp == 64 || X.L.Wp == 32 || X.L.Wp == 16) &&
+                         a.tileRowLo % 2u == 0u && (whole || a.tileRowHi % 2u == 0u);
+    // auto: the whole pass of a set with at least 1024 panels (four per CU: below that the sweeps are too few to fill the chip and the
+    // 128 x 128 tiles win, 23.5 against 24.4 ms at 100 000 rows); a row shard of the pass stays on the tile kernel unless forced
+    const bool large = whole && a.tileRowLo == 0u && a.nX >= 1024 * static_cast<int64_t>(panel::ROWS);
+    if (applies && (which.is("panel") || (large && !which.is("tile")))) {
+      static std::atomic<int> cus{0};
+      int                     nCu = cus.load();
+      if (nCu <= 0) {
+        int dev = 0;
+        NVMK_HIP_CHECK(hipGetDevice(&dev));
+        NVMK_HIP_CHECK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (nCu < 8) nCu = 8;
+        cus.store(nCu);
+      }
+      const int      slots   = nCu / 8;
+      const unsigned panels  = static_cast<unsigned>(ceil_div<int64_t>(a.nX, panel::ROWS));
+      const unsigned panelLo = a.tileRowLo / 2u, panelHi = whole ? panels : a.tileRowHi / 2u;
+      using PKern = void (*)(const uint4*, const int32_t*, int64_t, int, int32_t*, int2*, unsigned long long*, unsigned long long, double,
+                             double, double, float, unsigned, unsigned, int, int*);
+      PKern pk;
+      if (X.L.Wp == 64) {
+        pk = emit ? neighbor_count_panel_kernel<true, 32> : neighbor_count_panel_kernel<false, 32>;
+      } else if (X.L.Wp == 32) {
+        pk = emit ? neighbor_count_panel_kernel<true, 16> : neighbor_count_panel_kernel<false, 16>;
+      } else {
+        pk = emit ? neighbor_count_panel_kernel<true, 8> : neighbor_count_panel_kernel<false, 8>;
+      }
+      NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, panel::LDS_BYTES));
+      int* groupBarrier = nullptr;  // one arrival counter per XCD group, stream-ordered like the launch itself
+      NVMK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&groupBarrier), 8 * sizeof(int), stream));
+      NVMK_HIP_CHECK(hipMemsetAsync(groupBarrier, 0, 8 * sizeof(int), stream));
+      hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(slots * 8)), dim3(256), panel::LDS_BYTES, stream, X.rows, X.popc, a.nX, a.sign, counts,
+                         a.edges, a.edgeCursor, a.edgeCapacity, at.k1, at.k2, at.adj,
+                         (a.bandSkip && a.thr > 0.0f) ? a.thr : 0.0f, panelLo, panelHi, slots, groupBarrier);
+      const hipError_t launched = hipGetLastError();
+      NVMK_HIP_CHECK(hipFreeAsync(groupBarrier, stream));
+      NVMK_REQUIRE(launched == hipSuccess, "neighbor counts (panel kernel): %s", hipGetErrorString(launched));
+      return NVMK_OK;
+    }
+  }
   if (a.metric == NVMK_METRIC_TANIMOTO && at.ok) {
     kern = emit ? neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, true, true> : neighbor_count_mfma_kernel<NVMK_METRIC_TANIMOTO, false, true>;
   } else if (a.metric == NVMK_METRIC_TANIMOTO) {

@@ -19,7 +19,7 @@
 #   markers             rocprofv3 --marker-trace --kernel-trace of one ETKDG + MMFF run (roctx ranges of the library)
 #   chembl              the conformer block on the ChEMBL topologies (tools/bench_conformers.py --set chembl)
 #   strong              bench.py strong-scaling conformer mode as one rank over RCCL
-#   butina              tools/bench_butina.py + clustering tests
+#   butina              tools/bench_butina.py + clustering tests (ab_butina: the bench alone, tile against panel kernel)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 NAME=${1:?session name}
@@ -192,12 +192,18 @@ PY
         bench.py --gpus 1 --steps 3 --warmup 1 --conformer-total 100000 > $O/bench_strong_single_rank.json 2> $O/bench_strong.err
       tail -c 2500 $O/bench_strong_single_rank.json
       ;;
+    ab_butina)
+      for T in tile panel tile panel; do
+        echo "NVMK_COUNT_KERNEL=$T" | tee -a $O/bench_butina.txt
+        NVMK_COUNT_KERNEL=$T timeout 300 python tools/bench_butina.py 2>/dev/null | tail -4 | cut -c1-600 | tee -a $O/bench_butina.txt
+      done
+      ;;
     butina)
       ( time timeout 900 python -m pytest tests/test_clustering_gpu.py tests/test_full_size_gpu.py tests/test_benchmark_molecules_gpu.py -m gpu -q -x ) > $O/butina_tests.log 2>&1
       tail -3 $O/butina_tests.log
-      for T in small large small large; do
-        echo "NVMK_COUNT_TILE=$T" | tee -a $O/bench_butina.txt
-        NVMK_COUNT_TILE=$T timeout 300 python tools/bench_butina.py 2>/dev/null | tail -4 | tee -a $O/bench_butina.txt
+      for T in tile panel tile panel; do
+        echo "NVMK_COUNT_KERNEL=$T" | tee -a $O/bench_butina.txt
+        NVMK_COUNT_KERNEL=$T timeout 300 python tools/bench_butina.py 2>/dev/null | tail -4 | tee -a $O/bench_butina.txt
       done
       ;;
     *) echo "unknown step $STEP" ;;
