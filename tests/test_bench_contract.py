@@ -21,7 +21,7 @@ def test_flags_and_defaults():
 
 
 def test_committed_bench_line_has_every_field_of_the_contract():
-    line = json.loads((ROOT / "profiles" / "r04_head_bench.json").read_text().strip().splitlines()[-1])
+    line = json.loads((ROOT / "profiles" / "r04_final_bench_panel_kernel.json").read_text().strip().splitlines()[-1])
     baseline = json.loads((ROOT / "BASELINE.json").read_text())
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
