@@ -139,6 +139,8 @@ int nvmk_cross_similarity_host_f64(int metric, const uint32_t* d_a, int64_t nA, 
  * the logical row r of x is the physical row d_x_rows[r] of d_x, which lets a caller keep the
  * fingerprint matrix in place instead of compacting it every round.  counts is indexed by the
  * PHYSICAL row (counts[d_x_rows[r]]), i.e. it stays aligned with d_x across rounds.
+ * d_y == d_x with nY == nX and no row lists (a set against itself, the first pass of fused Butina) is recognised: only the
+ * pairs on or above the diagonal are evaluated and each credits both rows — the same counts for half the work.
  */
 int nvmk_neighbor_counts(int metric, const uint32_t* d_x, const int32_t* d_x_rows, int64_t nX, const uint32_t* d_y,
                          const int32_t* d_y_rows, int64_t nY, int fp_bits, float threshold, int sign,

@@ -1970,9 +1970,24 @@ int nvmk_neighbor_counts(int metric, const uint32_t* d_x, const int32_t* d_x_row
   // gather + expand both operands into compact prepared sets; counts stay indexed by the caller's row ids
   StreamScratch wsX, wsY;
   NVMK_HIP_CHECK(wsX.alloc(fp4::layout(nX, fp_bits).bytes, s));
-  NVMK_HIP_CHECK(wsY.alloc(fp4::layout(nY, fp_bits).bytes, s));
   int rc2 = fp4::prepare(d_x, d_x_rows, nX, fp_bits, wsX.ptr, s);
   if (rc2 != NVMK_OK) return rc2;
+  if (d_x == d_y && nX == nY && d_x_rows == nullptr && d_y_rows == nullptr) {
+    // a set against ITSELF: the similarity is symmetric, so only the tiles on or above the diagonal are evaluated and every pair
+    // credits both of its rows — half the pairs for the same counts (self pairs included, as in the rectangular pass)
+    fp4::CountArgs a{};
+    a.metric    = metric;
+    a.thr       = threshold;
+    a.table     = plan.table;
+    a.tableF    = plan.tableF;
+    a.sign      = sign;
+    a.nX        = nX;
+    a.nY        = nX;
+    a.symmetric = true;
+    const fp4::Prepared P = fp4::view(wsX.ptr, nX, fp_bits);
+    return fp4::launch_counts(a, P, P, d_counts, s);
+  }
+  NVMK_HIP_CHECK(wsY.alloc(fp4::layout(nY, fp_bits).bytes, s));
   rc2 = fp4::prepare(d_y, d_y_rows, nY, fp_bits, wsY.ptr, s);
   if (rc2 != NVMK_OK) return rc2;
   fp4::CountArgs a{};

@@ -50,6 +50,22 @@ def test_neighbor_counts_match_oracle(metric, words, thr):
     assert not counts.any()
 
 
+@pytest.mark.parametrize("metric", ["tanimoto", "cosine"])
+@pytest.mark.parametrize("rows,words", [(391, 16), (1500, 64), (700, 32), (5000, 64), (263, 12)])
+def test_neighbor_counts_of_a_set_against_itself(rows, words, metric):
+    """x against x (the same buffer): the library evaluates the upper triangle only and credits both rows of a pair — the counts
+    must be those of the full square, self pairs included (the first pass of the reference's fused Butina,
+    nvmolkit/clustering.py:138-160, is this call)."""
+    x = util.clustered_fingerprints(rows, words, 11, max_flips=10, density=0.15, seed=rows + words)
+    dx = dev(x)
+    counts = torch.zeros(rows, dtype=torch.int32, device="cuda")
+    update_neighbor_counts(dx, dx, counts, 0.55, metric=metric)
+    want = oracle.neighbor_counts(x, x, 0.55, metric=METRICS[metric])
+    assert np.array_equal(counts.cpu().numpy(), want) and (want >= 1).all()
+    update_neighbor_counts(dx, dx, counts, 0.55, subtract=True, metric=metric)
+    assert not counts.any()
+
+
 def test_neighbor_counts_threshold_boundaries():
     """Exact float32 boundary behaviour: pairs whose similarity equals the threshold are neighbours."""
     words = 4
