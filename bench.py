@@ -166,7 +166,7 @@ def butina_block(n: int, words: int, device, cpu_seconds: float) -> dict:
            "timing": "second call on the same set (whole call: all-pairs pass + CSR + device round loop + host lists)",
            "roofline": {"bound": "mfma", "achieved": flops / tb / 1e12, "peak": 10000.0, "unit": "TFLOP/s",
                         "frac": flops / tb / 1e12 / 10000.0, "traffic": None,
-                        "kernel": "nvmk::fp4::neighbor_count_mfma_kernel (FP4 e2m1 x e2m1 -> f32, exact 0/1 products)",
+                        "kernel": "nvmk::fp4::neighbor_count_panel_kernel at this size (row panels, csrc/count_panel.inc; below 262 144 rows neighbor_count_mfma_kernel) — FP4 e2m1 x e2m1 -> f32, exact 0/1 products",
                         "note": "algorithmic flops = n (n + 1) / 2 pairs x 2 x fp_bits, divided by the WHOLE call's wall time "
                                 "(conservative: the pass is ~83 % of the call, 0.427 of 0.517 s; the rest is the CSR build, the rounds and the Python "
                                 "lists the API returns); peak = ~10 PF dense FP4 MFMA "
