@@ -1426,6 +1426,12 @@ inline int read_back(const RoundBuffers& b, const int64_t N, const LoopState& sn
   const int32_t *clusterIdx = b.clusterIdx, *offsets = b.offsets, *centroids = b.centroids, *alive0 = b.alive0, *alive1 = b.alive1;
   // ---- read back and canonicalise on the host (member order from atomics is unspecified) ----
   const int64_t nGreedy = snap.nClusters;
+  // (the loop state comes from the device: nothing below may index with it unchecked — the caller's arrays hold N entries)
+  if (nGreedy < 0 || nGreedy > N || snap.nAlive < 0 || snap.nAlive > N || snap.back < -1 || snap.back >= N) {
+    set_last_error("fused butina: internal accounting error (loop state: %lld clusters, %lld alive, tail at %lld of %lld rows)",
+                   (long long)nGreedy, (long long)snap.nAlive, (long long)snap.back, (long long)N);
+    return NVMK_ERR_INTERNAL;
+  }
   std::vector<int32_t> idx(n), offs(static_cast<size_t>(nGreedy) + 1), cent(static_cast<size_t>(nGreedy));
   NVMK_HIP_CHECK(hipMemcpyAsync(idx.data(), clusterIdx, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   NVMK_HIP_CHECK(hipMemcpyAsync(offs.data(), offsets, offs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -1445,6 +1451,16 @@ inline int read_back(const RoundBuffers& b, const int64_t N, const LoopState& sn
   // host: centroid first, members ascending.  Sizes carry over, so every cluster's place is known up front and the clusters
   // are copied and sorted by a few host threads (one thread took 35 ms for the 20 183 clusters of the 1M-row benchmark, 7 % of
   // the call).
+  {
+    // every row is in exactly one place: the greedy clusters' entries, the singleton tail, the leftovers
+    bool ok = offs[0] >= 0 && offs[static_cast<size_t>(nGreedy)] <= N;
+    for (int64_t k = 0; ok && k < nGreedy; ++k) ok = offs[static_cast<size_t>(k) + 1] > offs[static_cast<size_t>(k)];
+    const int64_t accounted = static_cast<int64_t>(offs[static_cast<size_t>(nGreedy)]) - offs[0] + (N - (snap.back + 1)) + snap.nAlive;
+    if (!ok || accounted != N || nGreedy + (N - (snap.back + 1)) + snap.nAlive > N) {
+      set_last_error("fused butina: internal accounting error (%lld of %lld rows assigned)", (long long)accounted, (long long)N);
+      return NVMK_ERR_INTERNAL;
+    }
+  }
   h_offsets[0] = 0;
   for (int64_t k = 0; k < nGreedy; ++k) {
     h_offsets[k + 1] = h_offsets[k] + (offs[static_cast<size_t>(k) + 1] - offs[static_cast<size_t>(k)]);
