@@ -54,5 +54,29 @@ __host__ __device__ inline void count_tile(const unsigned bx, const unsigned sm,
   }
 }
 
+// ---- row-panel count kernel (count_panel.inc) --------------------------------------------------------------------------------
+// Panel of workgroup `block` (grid = 8 * slotsPerXcd; block & 7 = the XCD it runs on, block >> 3 = its slot there) in `round`:
+// a round deals 8 groups of slotsPerXcd consecutive panels, one group per XCD, in boustrophedon order over the rounds (later
+// panels have shorter sweeps: every XCD gets the same mix).  false: no panel for this workgroup in this round.
+__host__ __device__ inline bool panel_of(const unsigned block, const unsigned round, const unsigned slotsPerXcd, const unsigned panelLo,
+                                         const unsigned panelHi, unsigned& pnl) {
+  const unsigned xcd = block & 7u, slot = block >> 3;
+  const unsigned g   = (round & 1u) ? 7u - xcd : xcd;
+  pnl                = panelLo + round * 8u * slotsPerXcd + g * slotsPerXcd + slot;
+  return pnl < panelHi;
+}
+__host__ __device__ inline bool panel_round_exists(const unsigned round, const unsigned slotsPerXcd, const unsigned panelLo,
+                                                   const unsigned panelHi) {
+  return panelLo + round * 8u * slotsPerXcd < panelHi;
+}
+// Ring of chunk buffers: chunk q of a sweep (CH chunks per 64-column tile) lives in buffer q % ring; its DMA is issued `dist`
+// steps before the step that reads it.  What a wave has issued after chunk (tile, ch)'s own data DMA when it waits for it: two DMA
+// instructions for each of the dist - 1 chunks after it, plus the column-popcount DMA of every tile that starts among them.
+__host__ __device__ constexpr int panel_pending_after(const int chunksPerTile, const int dist, const int ch) {
+  int n = 0;
+  for (int j = 1; j < dist; ++j) n += 2 + (((ch + j) % chunksPerTile) == 0 ? 1 : 0);
+  return n;
+}
+
 }  // namespace maps
 }  // namespace nvmk

@@ -37,6 +37,12 @@ void chk_count_tile(unsigned bx, unsigned sm, unsigned sn, unsigned superH, unsi
   nvmk::maps::count_tile(bx, sm, sn, superH, superW, *tm, *tn);
 }
 
+int chk_panel_of(unsigned block, unsigned round, unsigned slots, unsigned lo, unsigned hi, unsigned* pnl) {
+  return nvmk::maps::panel_of(block, round, slots, lo, hi, *pnl) ? 1 : 0;
+}
+int chk_panel_round_exists(unsigned round, unsigned slots, unsigned lo, unsigned hi) { return nvmk::maps::panel_round_exists(round, slots, lo, hi) ? 1 : 0; }
+int chk_panel_pending_after(int chunksPerTile, int dist, int ch) { return nvmk::maps::panel_pending_after(chunksPerTile, dist, ch); }
+
 int64_t chk_hess_row_offset(int64_t r) { return t256::hess_row_offset(r); }
 int     chk_hess_row_offset32(int r) { return t64::hess_row_offset32(r); }
 int64_t chk_lds_vector_doubles(int threads, int64_t n) {

@@ -37,6 +37,9 @@ def maps(tmp_path_factory):
     lib.chk_lds_hessian_doubles.argtypes, lib.chk_lds_hessian_doubles.restype = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64], ctypes.c_int64
     lib.chk_resident_rows.argtypes, lib.chk_resident_rows.restype = [ctypes.c_int, ctypes.c_int, ctypes.c_int64], ctypes.c_int
     lib.chk_tail_pad_doubles.restype = ctypes.c_int64
+    lib.chk_panel_of.argtypes, lib.chk_panel_of.restype = [u, u, u, u, u, up], ctypes.c_int
+    lib.chk_panel_round_exists.argtypes, lib.chk_panel_round_exists.restype = [u, u, u, u], ctypes.c_int
+    lib.chk_panel_pending_after.argtypes, lib.chk_panel_pending_after.restype = [ctypes.c_int] * 3, ctypes.c_int
     return lib
 
 
@@ -135,3 +138,48 @@ def test_lds_layout_and_resident_rows(maps, threads):
                 assert rl == n or rl % (8 if rl < 64 else 2) == 0
     # the whole triangle resident when it fits
     assert maps.chk_resident_rows(threads, 40, maps.chk_hess_row_offset(40)) == 40
+
+
+@pytest.mark.parametrize("slots,lo,hi", [(32, 0, 3907), (32, 0, 1), (32, 0, 256), (32, 0, 257), (38, 0, 1000), (32, 100, 612), (4, 3, 77), (1, 0, 9)])
+def test_row_panel_hand_out_covers_every_panel_once(maps, slots, lo, hi):
+    """count_panel.inc: the panels [lo, hi) over the rounds of a grid of 8 x slots workgroups — each exactly once, a group of
+    `slots` consecutive panels on one XCD (block & 7), the XCD order reversed every other round, and with it every XCD's sum of
+    sweep lengths (a panel's sweep is shorter the later the panel) within a round's worth of the mean."""
+    seen, per_xcd, rounds = {}, [0] * 8, 0
+    while maps.chk_panel_round_exists(rounds, slots, lo, hi):
+        groups = {}
+        for block in range(8 * slots):
+            pnl = ctypes.c_uint(0)
+            if maps.chk_panel_of(block, rounds, slots, lo, hi, ctypes.byref(pnl)):
+                assert pnl.value not in seen
+                seen[pnl.value] = (rounds, block)
+                groups.setdefault(block & 7, []).append(pnl.value)
+                per_xcd[block & 7] += hi - pnl.value          # the sweep's length, in panels
+        for xcd, members in groups.items():
+            assert sorted(members) == list(range(min(members), min(members) + len(members))), "a group is one run of consecutive panels"
+        if rounds >= 1 and len(groups) == 8:
+            first = [min(groups[x]) for x in range(8)]
+            assert first == sorted(first, reverse=bool(rounds & 1))
+        rounds += 1
+    assert sorted(seen) == list(range(lo, hi)) and rounds == -(-(hi - lo) // (8 * slots))
+    if rounds >= 4 and rounds % 2 == 0:
+        assert max(per_xcd) - min(per_xcd) <= 8 * slots * slots      # the boustrophedon order evens the XCDs out
+
+
+def test_row_panel_dma_accounting(maps):
+    """The hand-written `s_waitcnt vmcnt(k)` of count_panel.inc: k = vector-memory operations issued after a chunk's own DMA.
+    Counted here by replaying the issue order of a sweep (per chunk: the tile's popcount DMA if it is the tile's first chunk,
+    then two data DMAs; `dist` chunks are issued before the first wait, then one per step after its wait)."""
+    for chunks_per_tile in (2, 4, 8):
+        for dist in (4, 10, 14):
+            ops = []                                      # (chunk index, kind) in issue order
+            def issue(q):
+                if q % chunks_per_tile == 0:
+                    ops.append((q, "popcounts"))
+                ops.extend([(q, "data"), (q, "data")])
+            for q in range(dist):
+                issue(q)
+            for q in range(40):
+                last_own = max(i for i, (c, kind) in enumerate(ops) if c == q and kind == "data")
+                assert maps.chk_panel_pending_after(chunks_per_tile, dist, q % chunks_per_tile) == len(ops) - 1 - last_own
+                issue(q + dist)
