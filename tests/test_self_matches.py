@@ -3,11 +3,15 @@ rdkit_extensions/conformer_pruning.cpp:24-60, which asks RDKit's SubstructMatch(
 hydrogen-stripped molecule).  Pinned two ways: the automorphism-group orders of molecules whose symmetry is textbook, and the
 exhaustive search of oracle/smiles.py on the same graphs."""
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 
 from nvmolkit_amd.fingerprints import SmilesSet
 from oracle import smiles as osm
+
+ROOT = Path(__file__).resolve().parents[1]
 
 KNOWN_ORDERS = [
     ("c1ccccc1", 12),            # D6h acting on six atoms
@@ -80,3 +84,38 @@ def test_bad_arguments_are_refused():
         s.self_matches(5)
     with pytest.raises(Exception):
         s.self_matches(0, max_matches=0)
+
+
+def test_matches_of_real_molecules_form_a_group():
+    """The self matches of a molecule are its automorphism group: on the first molecules of the reference's chembl_10k.smi the
+    returned set holds the identity, is closed under composition and under inversion, and every member keeps elements, charges,
+    isotopes and bond types (checked against the graph the ingestion returns) — unless the 1000-match cap cut the set short."""
+    path = ROOT / "tests" / "golden" / "chembl_10k.smi"
+    lines = [ln.split()[0] for ln in path.read_text().splitlines()[:400] if ln.strip()]
+    s = SmilesSet(lines, perceive_aromaticity=True)
+    checked = symmetric = 0
+    for i in range(len(lines)):
+        if s.status[i] != 0 or s.n_atoms[i] > 60:
+            continue
+        m = s.self_matches(i, symmetrize_terminal_groups=False)
+        n = int(s.n_atoms[i])
+        assert m.shape[1] == n and (m[0] == np.arange(n)).all()
+        if len(m) == 1000:
+            continue                                    # capped: closure cannot be expected
+        members = {tuple(int(x) for x in r) for r in m}
+        assert len(members) == len(m)
+        atoms, bonds = s.graph(i)
+        have = {(int(a), int(b)): int(t) for a, b, t, _ in bonds} | {(int(b), int(a)): int(t) for a, b, t, _ in bonds}
+        for r in m:
+            assert (atoms[r, :3] == atoms[:, :3]).all()                                   # element, charge, isotope
+            assert all(have.get((int(r[a]), int(r[b]))) == t for (a, b), t in have.items())
+            inv = np.empty(n, dtype=np.int64)
+            inv[r] = np.arange(n)
+            assert tuple(int(x) for x in inv) in members
+        if len(m) <= 48:
+            for p in m:
+                for q in m:
+                    assert tuple(int(x) for x in p[q]) in members
+        checked += 1
+        symmetric += len(m) > 1
+    assert checked > 200 and symmetric > 60, (checked, symmetric)
