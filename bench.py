@@ -248,31 +248,48 @@ BFGS_KIND_NAMES = {0: "dg", 1: "etk", 2: "mmff"}
 
 def conformer_library(n_mols: int, world: int, rank: int, shared: bool = False):
     """The synthetic drug-like molecules (generated in forked worker processes) and the seconds it took.
-    ``shared`` (multi-rank runs): the set is generated ONCE — rank 0 writes it to shared memory, the others wait for the file and
-    load it — so that the start-up of --gpus 8 costs one generation, not eight on an eighth of the cores each; every rank then
-    works on the same molecules (weak scaling: with its own seed; strong scaling: on its share of them)."""
-    import pickle
-
+    ``shared`` (multi-rank runs): only rank 0 generates — the start-up of --gpus 8 costs one generation, not eight on an eighth
+    of the cores each — and the others get ``None`` here and the set itself from :func:`share_library` once the process group
+    is up; every rank then works on the same molecules (weak scaling: with its own seed; strong scaling: on its share of them)."""
     from nvmolkit_amd import synthetic
 
     t0 = time.perf_counter()
-    if not shared:
-        procs = max(1, (os.cpu_count() or 2) // 2)
-        return synthetic.druglike_library(n_mols, seed=SEED, processes=min(procs, 64)), time.perf_counter() - t0
-    base = Path("/dev/shm") if Path("/dev/shm").is_dir() else Path(os.environ.get("TMPDIR", "/tmp"))
-    path = base / f"nvmk_bench_druglike_{n_mols}_{SEED}_{os.environ.get('MASTER_PORT', '0')}.pkl"
+    if shared and rank != 0:
+        return None, 0.0
+    procs = max(1, (os.cpu_count() or 2) // 2)
+    return synthetic.druglike_library(n_mols, seed=SEED, processes=min(procs, 64)), time.perf_counter() - t0
+
+
+def share_library(library, rank: int):
+    """Rank 0's molecule library to every rank, through a file in a PRIVATE directory (``mkdtemp``: mode 0700, fresh name) whose
+    path travels over the process group — not a predictable name in world-writable /dev/shm that a stale run or another user
+    could have put there first.  The others check that the directory is theirs alone before unpickling, and rank 0 removes it
+    once everybody has read it.  Call after ``init_process_group``."""
+    import pickle
+    import shutil
+    import tempfile
+
+    import torch.distributed as dist
+
+    box = [None]
     if rank == 0:
-        lib = synthetic.druglike_library(n_mols, seed=SEED, processes=min(max(1, (os.cpu_count() or 2) // 2), 64))
-        with open(str(path) + ".tmp", "wb") as f:
-            pickle.dump(lib, f, protocol=pickle.HIGHEST_PROTOCOL)
-        os.replace(str(path) + ".tmp", path)
-        return lib, time.perf_counter() - t0
-    while not path.exists():
-        if time.perf_counter() - t0 > 1800:
-            raise SystemExit(f"rank {rank}: no molecule library from rank 0 after 30 minutes ({path})")
-        time.sleep(0.05)
-    with open(path, "rb") as f:
-        return pickle.load(f), time.perf_counter() - t0
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        box[0] = tempfile.mkdtemp(prefix="nvmk_bench_", dir=base)
+        with open(os.path.join(box[0], "library.pkl"), "wb") as f:
+            pickle.dump(library, f, protocol=pickle.HIGHEST_PROTOCOL)
+    dist.broadcast_object_list(box, src=0)
+    try:
+        if rank != 0:
+            st = os.stat(box[0])
+            if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+                raise SystemExit(f"rank {rank}: {box[0]} is not a private directory of this user; refusing to load from it")
+            with open(os.path.join(box[0], "library.pkl"), "rb") as f:
+                library = pickle.load(f)
+        dist.barrier()
+    finally:
+        if rank == 0:
+            shutil.rmtree(box[0], ignore_errors=True)
+    return library
 
 
 def strong_scaling_share(library, total: int, world: int, rank: int):
@@ -303,19 +320,15 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     if strong_total > 0:
         library, share_cost = strong_scaling_share(library, strong_total, world, rank)
         n_mols = len(library)
-    t0 = time.perf_counter()
-    molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library], device=device)
-    tables = mmffOptimization.resident_tables([m["mmff"] for m in library], device)  # term tables resident before the timed region
-    torch.cuda.synchronize()
-    t_flatten = time.perf_counter() - t0
-    t_prep = t_flatten + t_library
     lib = _native.lib()
-    # warm-up (untimed, like the headline's warm-up steps): the pipeline once on the first 1000 molecules — module load, and the
-    # stream-ordered pool then holds blocks of the sizes the full run asks for (per-workgroup inverse-Hessian slots of every class)
+    # warm-up (untimed, like the headline's warm-up steps): the pipeline once on the first 1000 molecules — module load, the
+    # table builder's pinned staging ring, and the stream-ordered pool then holds blocks of the sizes the full run asks for
+    # (per-workgroup inverse-Hessian slots of every class)
     n_warm = min(1000, n_mols)
     warm = embed_flat(FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library[:n_warm]], device=device), confs_per_molecule=confs,
                       max_iterations=10, seed=99, output=CoordinateOutput.DEVICE)
-    mmffOptimization.optimize_device([m["mmff"] for m in library[:n_warm]], warm, max_iters=mmff_iters)
+    mmffOptimization.optimize_device(mmffOptimization.resident_tables([m["mmff"] for m in library[:n_warm]], device, wait=False), warm,
+                                     max_iters=mmff_iters)
     del warm
     stats = torch.zeros(64, dtype=torch.int64, device=device)
     _native.check(lib.nvmk_bfgs_set_stats(stats.data_ptr()))
@@ -324,21 +337,42 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
 
         dist.barrier()
     torch.cuda.synchronize()
+    # The timed region starts with the molecules as the generator left them (per-molecule numpy term arrays: what an RDKit
+    # molecule is to the reference) and holds everything the reference's benchmark times inside EmbedMolecules +
+    # MMFFOptimizeMoleculesConfs (benchmarks/etkdg_bench.py:108-124): table assembly on the host threads, uploads, both GPU stages.
+    # The MMFF tables are assembled on a host thread and stream of their own while ETKDG runs (resident_tables(wait=False)).
     t0 = time.perf_counter()
+    molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library], device=device)
+    t_molset = time.perf_counter() - t0   # host side of the assembly; its last uploads are still in flight
+    pending = mmffOptimization.resident_tables([m["mmff"] for m in library], device, wait=False)
     dev = embed_flat(molset, confs_per_molecule=confs, max_iterations=10, seed=1 + rank, output=CoordinateOutput.DEVICE)
     torch.cuda.synchronize()
     t_embed = time.perf_counter() - t0
     t1 = time.perf_counter()
+    tables = pending.result()
+    t_tables_wait = time.perf_counter() - t1  # what of the MMFF assembly ETKDG did not hide
     opt = mmffOptimization.optimize_device(tables, dev, max_iters=mmff_iters)
     torch.cuda.synchronize()
     t_mmff = time.perf_counter() - t1
     wall = time.perf_counter() - t0
     _native.check(lib.nvmk_bfgs_set_stats(None))
+    # the same job again on the tables that are now resident (rounds 2-4 reported only this figure): same seed, same work
+    torch.cuda.synchronize()
+    r0 = time.perf_counter()
+    dev_r = embed_flat(molset, confs_per_molecule=confs, max_iterations=10, seed=1 + rank, output=CoordinateOutput.DEVICE)
+    torch.cuda.synchronize()
+    r_embed = time.perf_counter() - r0
+    opt_r = mmffOptimization.optimize_device(tables, dev_r, max_iters=mmff_iters)
+    torch.cuda.synchronize()
+    wall_resident = time.perf_counter() - r0
+    same_bits = bool(torch.equal(opt_r.values.torch(), opt.values.torch()))
+    del dev_r, opt_r
+    t_flatten = t_molset + t_tables_wait
     n_conf = dev.num_conformers
     converged = int(opt.converged.torch().sum().item())
     if collectives:
         own_wall = wall
-        t = torch.tensor([wall, t_embed, t_mmff], dtype=torch.float64, device=device)
+        t = torch.tensor([wall, t_embed, t_mmff, wall_resident, r_embed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         c = torch.tensor([n_conf, converged, n_mols], dtype=torch.int64, device=device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
@@ -346,7 +380,7 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
         walls = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
         dist.all_gather(walls, torch.tensor([own_wall], dtype=torch.float64, device=device))
         per_rank_wall = [float(w.item()) for w in walls]
-        wall, t_embed, t_mmff = (float(x) for x in t.tolist())
+        wall, t_embed, t_mmff, wall_resident, r_embed = (float(x) for x in t.tolist())
         n_conf, converged, total_mols = (int(x) for x in c.tolist())
     else:
         total_mols = n_mols
@@ -379,9 +413,15 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
            "mean_atoms": float(np.mean([m["embed"]["n_atoms"] for m in library])), "conformers": n_conf,
            "etkdg_seconds": t_embed, "etkdg_conformers_per_s": n_conf / t_embed, "mmff_seconds": t_mmff,
            "mmff_conformers_per_s": n_conf / t_mmff, "mmff_converged_fraction": converged / max(n_conf, 1),
-           "host_preparation_seconds": t_prep, "library_generation_seconds": t_library,
-           "flatten_and_table_upload_seconds": t_flatten,   # FlatMoleculeSet + resident term tables: the analogue of the
-                                                            # reference's per-batch host flattening (src/minimizer/bfgs_mmff.cpp:159,195-201)
+           "timed_region": "per-molecule host term arrays -> table assembly (library's host threads, pinned staging, chunked uploads; "
+                           "the MMFF tables on a thread and stream of their own under ETKDG) -> ETKDG -> MMFF, end to end",
+           "library_generation_seconds": t_library,            # outside the clock: the generator stands in for reading molecules
+           "table_assembly_host_seconds": t_molset,            # inside the clock (part of etkdg_seconds): FlatMoleculeSet's host side
+           "mmff_tables_wait_seconds": t_tables_wait,          # inside the clock (part of mmff_seconds): MMFF assembly not hidden by ETKDG
+           "flatten_and_table_upload_seconds": t_flatten,      # the two above: what of the flattening is on the critical path
+           "resident_tables_value": total_mols / wall_resident,  # the same job with both table sets already resident (rounds 2-4's figure)
+           "resident_tables_seconds": wall_resident, "resident_tables_etkdg_seconds": r_embed,
+           "resident_tables_run_gave_the_same_bits": same_bits,
            "scaling": "strong" if strong_total > 0 else "weak", "per_rank_seconds": per_rank_wall,
            "imbalance_max_over_mean": max(per_rank_wall) / (sum(per_rank_wall) / len(per_rank_wall)),
            "modelled_cost_share_max_over_mean": (max(share_cost) / (sum(share_cost) / len(share_cost))) if share_cost else None,
@@ -528,6 +568,8 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
+        if world > 1 and args.conformer_mols > 0:
+            library = share_library(library, rank)
 
     from nvmolkit_amd import _native
 

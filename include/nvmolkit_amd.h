@@ -408,6 +408,66 @@ typedef struct nvmk_etkdg_params {
 int nvmk_etkdg_embed(const nvmk_etkdg_molset* mols, const nvmk_etkdg_params* params, double* d_coords,
                      int32_t* h_conf_counts, int32_t* h_stage_failures, void* stream);
 
+/* ---- host-side table assembly: per-molecule host arrays -> the resident, device-ordered tables above ----------------------
+ * Replaces the reference's per-batch host preprocessing between RDKit and its kernels: the flatteners' "add to batch" step
+ * (addMoleculeToBatch / addMoleculeToMolecularSystem, src/forcefields/dist_geom.h / mmff.h; callers src/etkdg.cpp:175-191,
+ * :211-240 on `preprocessingThreads` OpenMP threads, src/minimizer/bfgs_mmff.cpp:139-201), which its benchmarks time as part
+ * of EmbedMolecules / MMFFOptimizeMoleculesConfs (benchmarks/etkdg_bench.py:108-124).
+ *
+ * Input: one descriptor per molecule pointing at the caller's own per-molecule term arrays (nvmk_host_terms: n_terms rows of
+ * n_idx LOCAL atom indices — int32, or int64 as numpy makes them by default — and n_par doubles, C order; layouts as
+ * nvmk_ff_batch).  Work: n_threads host threads (<= 0: all, at most 64; the reference's preprocessingThreads) concatenate
+ * the groups molecule by molecule, convert the indices, bring the O(N^2) pair groups into the order the kernels want (along
+ * the diagonals of the pair matrix: (|j - i|, min(i, j)), stable — 64 consecutive terms then touch 128 distinct atoms instead
+ * of sharing atom i; DG g0, ETK g5, MMFF g5 / g6, UFF g4), and for MMFF merge van der Waals and electrostatic pairs into
+ * group 11; they write into a ring of pinned staging slots owned by the library, from which the chunks go to ONE device
+ * allocation with hipMemcpyAsync on `stream` while the threads fill the next slots (build of chunk k + 1 overlaps the upload
+ * of chunk k).  Blocking on the host work; on return the last uploads are still in flight on `stream`: work enqueued on
+ * `stream` afterwards sees complete tables, other streams wait for it first.  The handle owns the device memory;
+ * nvmk_*_view fills the plain structs the entry points above take (valid until nvmk_*_free, which waits for the uploads).
+ *   NVMK_BUILD_KEEP_PAIR_ORDER : pair groups keep the caller's row order (measurements)
+ *   NVMK_BUILD_NO_MMFF_MERGE   : no group 11
+ *   NVMK_BUILD_HOST            : the tables are written to HOST memory instead (no GPU involved; the views then hold host
+ *                                pointers) — how the CPU test-suite checks the assembly row by row
+ * MMFF group 11 exists only if EVERY molecule's electrostatic pairs are a subset of its van der Waals pairs and no pair is
+ * listed twice (how RDKit and the reference's builder emit them); otherwise the view's groups[11] stays NULL. */
+typedef struct nvmk_host_terms {
+  int32_t       n_terms;
+  int32_t       idx_bytes; /* 4: idx is int32_t[], 8: int64_t[]; ignored when n_terms == 0 */
+  const void*   idx;       /* n_terms x n_idx */
+  const double* par;       /* n_terms x n_par (ignored for groups without parameters) */
+} nvmk_host_terms;
+
+typedef struct nvmk_flat_molecule {
+  int32_t         n_atoms;
+  int32_t         num_impropers; /* planarity tolerance of the basic-knowledge check = 0.7 x this */
+  int32_t         has_etk;       /* 0: etk[] is ignored (all molecules of a set must agree) */
+  int32_t         n_checks;
+  nvmk_host_terms dg[3];
+  nvmk_host_terms etk[6];
+  const int32_t*  check_kind;    /* [n_checks] NVMK_CHECK_* */
+  const int32_t*  check_idx;     /* [n_checks][5] */
+  const double*   check_par;     /* [n_checks][2] */
+} nvmk_flat_molecule;
+
+#define NVMK_BUILD_KEEP_PAIR_ORDER 1u
+#define NVMK_BUILD_NO_MMFF_MERGE 2u
+#define NVMK_BUILD_HOST 4u
+
+int nvmk_etkdg_molset_build(const nvmk_flat_molecule* h_mols, int32_t n_mols, int n_threads, unsigned flags, void* stream,
+                            void** handle);
+int nvmk_etkdg_molset_view(const void* handle, nvmk_etkdg_molset* out);
+int nvmk_etkdg_molset_free(void* handle);
+/* Per-MOLECULE term tables of one force field (kind NVMK_FF_DG / ETK / MMFF / UFF) for nvmk_ff_batch.system_mol batches:
+ * h_terms[m * n_groups + g] are molecule m's rows of group g; n_groups = the kind's group count (3 / 6 / 7 / 5), for MMFF and
+ * UFF optionally followed by up to four constraint groups (distance, position, angle, torsion).  The view fills
+ * groups[0 .. n_groups) and, for MMFF, groups[11]; every `starts` array has n_mols + 1 entries.  A "molecule" here is whatever
+ * shares one copy of the tables: with one row per SYSTEM and no system_mol the same call assembles a plain batch. */
+int nvmk_ff_tables_build(int kind, const nvmk_host_terms* h_terms, int32_t n_mols, int n_groups, int n_threads, unsigned flags,
+                         void* stream, void** handle);
+int nvmk_ff_tables_view(const void* handle, nvmk_ff_group groups[12], int32_t* n_mols);
+int nvmk_ff_tables_free(void* handle);
+
 /* Per-stage wall-clock table of the LAST nvmk_etkdg_embed call of the process that ran with the option NVMK_ETKDG_TIMING=1
  * (reference: ETKDGDriver's debug mode, src/etkdg_impl.cpp:126-139 recordStageTiming, :161-200 printTimingStatistics: total /
  * min / max / calls per stage).  Rows 0 .. NVMK_ETKDG_N_STAGES - 1 are the stages (one entry per batch), row NVMK_ETKDG_N_STAGES

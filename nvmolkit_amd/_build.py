@@ -100,7 +100,36 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> Path
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
+    if not variant:
+        build_pyglue(force=force, verbose=verbose)
     return LIB_PATH
+
+
+PYGLUE_SRC = PKG_DIR / "pyglue" / "gather.c"
+PYGLUE_PATH = LIB_DIR / "_nvmk_pyglue.so"
+
+
+def build_pyglue(force: bool = False, verbose: bool = False) -> Path:
+    """The CPython glue of the host layer (pyglue/gather.c: fills the C ABI's descriptor arrays from Python molecule lists) ->
+    lib/_nvmk_pyglue.so, with the C compiler against this interpreter's headers.  It links against nothing: the Python symbols
+    come from the interpreter that loads it (ctypes.PyDLL)."""
+    import sysconfig
+
+    LIB_DIR.mkdir(exist_ok=True)
+    stamp = OBJ_DIR / "pyglue.sha"
+    OBJ_DIR.mkdir(exist_ok=True)
+    digest = _digest([PYGLUE_SRC, PKG_DIR.parent / "include" / "nvmolkit_amd.h"]) + sysconfig.get_python_version()
+    if force or not PYGLUE_PATH.exists() or not stamp.exists() or stamp.read_text() != digest:
+        cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+        if not cc:
+            raise RuntimeError("no C compiler found for nvmolkit_amd/pyglue/gather.c")
+        cmd = [cc, "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", f"-I{sysconfig.get_paths()['include']}",
+               f"-I{PKG_DIR.parent / 'include'}", str(PYGLUE_SRC), "-o", str(PYGLUE_PATH)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        stamp.write_text(digest)
+    return PYGLUE_PATH
 
 
 if __name__ == "__main__":

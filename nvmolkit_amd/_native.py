@@ -80,6 +80,12 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_scheduler_dispatch": (_int, [_vp, _int, _vp, ctypes.POINTER(_int)]),
     "nvmk_scheduler_record": (_int, [_vp, _vp, _vp, _int]),
     "nvmk_etkdg_embed": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "nvmk_etkdg_molset_build": (_int, [_vp, ctypes.c_int32, _int, ctypes.c_uint, _vp, ctypes.POINTER(ctypes.c_void_p)]),
+    "nvmk_etkdg_molset_view": (_int, [_vp, _vp]),
+    "nvmk_etkdg_molset_free": (_int, [_vp]),
+    "nvmk_ff_tables_build": (_int, [_int, _vp, ctypes.c_int32, _int, _int, ctypes.c_uint, _vp, ctypes.POINTER(ctypes.c_void_p)]),
+    "nvmk_ff_tables_view": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
+    "nvmk_ff_tables_free": (_int, [_vp]),
     "nvmk_etkdg_stage_timings": (_int, [_vp, _vp, _vp, _vp, _int, _vp]),
     "nvmk_etkdg_random_coords": (_int, [ctypes.c_uint64, ctypes.c_uint64, _int, _vp, _vp, ctypes.c_double, _vp, _vp]),
     "nvmk_etkdg_driver_run": (_int, [_int, _int, _int, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32),
@@ -143,6 +149,22 @@ class EtkdgParams(ctypes.Structure):
                 ("seed", ctypes.c_uint64), ("batches_per_gpu", ctypes.c_int32)]
 
 
+class HostTerms(ctypes.Structure):
+    """Mirror of ``nvmk_host_terms``: one molecule's rows of one term group, in the caller's own arrays."""
+
+    _fields_ = [("n_terms", ctypes.c_int32), ("idx_bytes", ctypes.c_int32), ("idx", ctypes.c_void_p), ("par", ctypes.c_void_p)]
+
+
+class FlatMoleculeDesc(ctypes.Structure):
+    """Mirror of ``nvmk_flat_molecule``."""
+
+    _fields_ = [("n_atoms", ctypes.c_int32), ("num_impropers", ctypes.c_int32), ("has_etk", ctypes.c_int32), ("n_checks", ctypes.c_int32),
+                ("dg", HostTerms * 3), ("etk", HostTerms * 6), ("check_kind", ctypes.c_void_p), ("check_idx", ctypes.c_void_p),
+                ("check_par", ctypes.c_void_p)]
+
+
+BUILD_KEEP_PAIR_ORDER, BUILD_NO_MMFF_MERGE, BUILD_HOST = 1, 2, 4
+
 CHECK_TETRAHEDRAL, CHECK_CHIRAL_VOLUME, CHECK_CHIRAL_DISTANCE = 0, 1, 2
 CHECK_CHIRAL_CENTER_VOLUME, CHECK_DOUBLE_BOND_STEREO, CHECK_DOUBLE_BOND_GEOMETRY = 3, 4, 5
 ETKDG_N_STAGES = 11
@@ -168,6 +190,44 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = argtypes
         _lib = L
     return _lib
+
+
+PYGLUE_PATH = _PKG / "lib" / "_nvmk_pyglue.so"
+_pyglue: ctypes.PyDLL | None = None
+
+
+def pyglue() -> ctypes.PyDLL:
+    """The CPython glue (pyglue/gather.c): fills ``nvmk_flat_molecule`` / ``nvmk_host_terms`` arrays from lists of Python molecule
+    descriptions without a Python-level loop.  Loaded with ``PyDLL`` — its functions run with the GIL held and raise Python
+    exceptions themselves.  Built next to the product library; missing = not built, there is no slower stand-in."""
+    global _pyglue
+    if _pyglue is None:
+        if not PYGLUE_PATH.exists():
+            raise NativeLibraryError(f"{PYGLUE_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        G = ctypes.PyDLL(str(PYGLUE_PATH))
+        G.nvmk_py_gather_flat_molecules.restype = ctypes.c_int64
+        G.nvmk_py_gather_flat_molecules.argtypes = [ctypes.py_object, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.py_object, ctypes.py_object]
+        G.nvmk_py_gather_term_tables.restype = _int
+        G.nvmk_py_gather_term_tables.argtypes = [ctypes.py_object, _vp, _vp, _int, _vp, ctypes.py_object, ctypes.py_object]
+        _pyglue = G
+    return _pyglue
+
+
+def _as_term_array(obj, is_par: int):
+    """Slow path of the glue: anything that is not already a C-contiguous int32 / int64 / float64 array."""
+    import numpy as np
+
+    return np.ascontiguousarray(obj, dtype=np.float64 if is_par else np.int32)
+
+
+def build_flags() -> int:
+    """``NVMK_PAIR_ORDER=input`` / ``NVMK_MMFF_MERGE=0`` (A/B switches of DESIGN.md section 5) as nvmk_*_build flags."""
+    flags = 0
+    if os.environ.get("NVMK_PAIR_ORDER", "diagonal") == "input":
+        flags |= BUILD_KEEP_PAIR_ORDER
+    if os.environ.get("NVMK_MMFF_MERGE", "1") == "0":
+        flags |= BUILD_NO_MMFF_MERGE
+    return flags
 
 
 def last_error() -> str:

@@ -29,6 +29,7 @@ enum Id {
   kMarkers,         // NVMK_MARKERS          1 | 0 (0: no roctx ranges)
   kEtkdgTiming,     // NVMK_ETKDG_TIMING     1 (per-stage wall clock of nvmk_etkdg_embed: a stream synchronisation after every stage)
   kEtkdgPrune,      // NVMK_ETKDG_PRUNE      1 | 0 (0: surplus attempts of a molecule also run the second half of the pipeline)
+  kBuildSlotKb,     // NVMK_BUILD_SLOT_KB    n (tests: size of a pinned staging slot of the table builder, default 32768)
   kNumOptions
 };
 

@@ -10,6 +10,7 @@ Two entry points:
 from __future__ import annotations
 
 import ctypes
+import weakref
 from dataclasses import dataclass, field
 from typing import Sequence
 
@@ -17,7 +18,6 @@ import numpy as np
 import torch
 
 from nvmolkit_amd import _native
-from nvmolkit_amd.forcefield import GROUP_LAYOUT, DG, ETK, PAIR_ORDER_GROUPS, diagonal_pair_order, pair_order_enabled
 from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
 N_STAGES = _native.ETKDG_N_STAGES
@@ -65,66 +65,41 @@ class FlatMolecule:
 
 
 class FlatMoleculeSet:
-    """Unique molecules resident on the device, ready for :func:`embed_flat`."""
+    """Unique molecules resident on the device, ready for :func:`embed_flat`.
 
-    def __init__(self, mols: Sequence[FlatMolecule], device="cuda"):
+    The tables are assembled by the library (``nvmk_etkdg_molset_build``: host threads concatenate the molecules' term groups,
+    bring the pair tables into the kernels' order and upload chunk by chunk through pinned staging, on the current stream of
+    ``device``) — the counterpart of the reference's host flattening on ``preprocessingThreads`` threads
+    (src/etkdg.cpp:175-191), and like it part of what an ``EmbedMolecules`` call costs.  The Python side only hands over
+    pointers into the molecules' own arrays (``_native.pyglue``).  ``device="cpu"`` assembles the same tables in host memory
+    (no GPU involved; the CPU test-suite reads them back through ``self.c``)."""
+
+    def __init__(self, mols: Sequence[FlatMolecule], device="cuda", preprocessing_threads: int = -1):
         self.device = torch.device(device)
         self.mols = list(mols)
-        self.n_atoms = np.array([m.n_atoms for m in self.mols], dtype=np.int32)
-        self._keep: list = []
+        n = len(self.mols)
+        self.n_atoms = np.fromiter((m.n_atoms for m in self.mols), dtype=np.int32, count=n)
+        n_checks = sum(len(m.checks) for m in self.mols)
+        descs = (_native.FlatMoleculeDesc * max(n, 1))()
+        kinds, idx, par = np.empty(n_checks, np.int32), np.empty((n_checks, 5), np.int32), np.empty((n_checks, 2), np.float64)
+        keep: list = []
+        _native.pyglue().nvmk_py_gather_flat_molecules(self.mols, ctypes.addressof(descs), kinds.ctypes.data, idx.ctypes.data,
+                                                       par.ctypes.data, n_checks, keep, _native._as_term_array)
+        handle = ctypes.c_void_p()
+        flags = _native.build_flags()
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                rc = _native.lib().nvmk_etkdg_molset_build(ctypes.addressof(descs), n, int(preprocessing_threads), flags,
+                                                           _native.stream_ptr(None), ctypes.byref(handle))
+        else:
+            rc = _native.lib().nvmk_etkdg_molset_build(ctypes.addressof(descs), n, int(preprocessing_threads),
+                                                       flags | _native.BUILD_HOST, None, ctypes.byref(handle))
+        _native.check(rc, "nvmk_etkdg_molset_build")
+        self._handle = handle
+        self._finalizer = weakref.finalize(self, _native.lib().nvmk_etkdg_molset_free, handle)
         self.c = _native.EtkdgMolset()
-        self.c.n_mols = len(self.mols)
-        self.c.h_n_atoms = self.n_atoms.ctypes.data
-        self.has_etk = bool(self.mols) and all(m.etk is not None for m in self.mols)
-        self._fill_groups(self.c.dg, GROUP_LAYOUT[DG], [m.dg for m in self.mols], PAIR_ORDER_GROUPS[DG])
-        if self.has_etk:
-            counts = self._fill_groups(self.c.etk, GROUP_LAYOUT[ETK], [m.etk for m in self.mols], PAIR_ORDER_GROUPS[ETK])
-            self.d12 = np.ascontiguousarray(counts[2], dtype=np.int32)
-            self.d13 = np.ascontiguousarray(counts[3], dtype=np.int32)
-            self.c.h_etk_d12_counts = self.d12.ctypes.data
-            self.c.h_etk_d13_counts = self.d13.ctypes.data
-        starts = np.zeros(len(self.mols) + 1, dtype=np.int32)
-        kinds, idxs, pars = [], [], []
-        for i, m in enumerate(self.mols):
-            starts[i + 1] = starts[i] + len(m.checks)
-            for kind, idx, par in m.checks:
-                kinds.append(kind)
-                idxs.append(list(idx) + [0] * (5 - len(idx)))
-                pars.append(list(par) + [0.0] * (2 - len(par)))
-        if kinds:
-            t = [self._dev(starts), self._dev(np.array(kinds, dtype=np.int32)), self._dev(np.array(idxs, dtype=np.int32)),
-                 self._dev(np.array(pars, dtype=np.float64))]
-            self.c.check_starts, self.c.check_kind, self.c.check_idx, self.c.check_par = (x.data_ptr() for x in t)
-        self.c.num_impropers = self._dev(np.array([m.num_impropers for m in self.mols], dtype=np.int32)).data_ptr()
-
-    def _dev(self, arr: np.ndarray) -> torch.Tensor:
-        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
-        self._keep.append(t)
-        return t
-
-    def _fill_groups(self, c_groups, layout, per_mol_groups, reorder=()):
-        counts = []
-        for g, (n_idx, n_par) in enumerate(layout):
-            starts = np.zeros(len(per_mol_groups) + 1, dtype=np.int32)
-            idx_all, par_all = [], []
-            for i, groups in enumerate(per_mol_groups):
-                idx, par = groups[g]
-                idx = np.asarray(idx, dtype=np.int32).reshape(-1, n_idx)
-                par = np.asarray(par, dtype=np.float64).reshape(len(idx), n_par)
-                starts[i + 1] = starts[i] + len(idx)
-                idx_all.append(idx)
-                par_all.append(par)
-            counts.append(np.diff(starts))
-            idx_cat = np.concatenate(idx_all) if idx_all else np.zeros((0, n_idx), np.int32)
-            par_cat = np.concatenate(par_all) if par_all else np.zeros((0, n_par))
-            d_starts, d_idx, d_par = self._dev(starts), self._dev(idx_cat), self._dev(par_cat)
-            if g in reorder and pair_order_enabled():
-                d_idx, d_par = diagonal_pair_order(d_starts, d_idx, d_par)
-                self._keep += [d_idx, d_par]
-            c_groups[g].starts = d_starts.data_ptr()
-            c_groups[g].idx = d_idx.data_ptr() if idx_cat.size else None
-            c_groups[g].par = d_par.data_ptr() if par_cat.size else None
-        return counts
+        _native.check(_native.lib().nvmk_etkdg_molset_view(handle, ctypes.byref(self.c)), "nvmk_etkdg_molset_view")
+        self.has_etk = bool(self.c.h_etk_d12_counts)
 
 
 # Conformer attempts per launch when the caller does not choose (-1, as HardwareOptions.batchSize).  One wave (small systems) or
@@ -305,8 +280,8 @@ def embed_flat_molecules(flat_mols: Sequence[FlatMolecule], confs_per_molecule: 
         with torch.cuda.device(device):
             stream = torch.cuda.Stream(device=device)
             with torch.cuda.stream(stream):
-                molset = FlatMoleculeSet([flat_mols[i] for i in mine], device=device)
-                stream.synchronize()  # the tables were staged on this stream
+                # assembled by opts.preprocessingThreads host threads and uploaded on this stream; the embedding is queued behind it
+                molset = FlatMoleculeSet([flat_mols[i] for i in mine], device=device, preprocessing_threads=opts.preprocessingThreads)
                 results[slot] = embed_flat(molset, confs_per_molecule, max_iterations,
                                            batch_size=opts.batchSize if opts.batchSize > 0 else -1,
                                            batches_per_gpu=opts.batchesPerGpu, stream=stream, output=output, **kw)

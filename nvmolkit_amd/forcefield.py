@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from typing import Sequence
 
 import numpy as np
@@ -29,89 +30,15 @@ GROUP_LAYOUT = {
     UFF: [(2, 2), (3, 6), (4, 3), (4, 4), (2, 3)],
 }
 DIM = {DG: 4, ETK: 3, MMFF: 3, QUARTIC: 4, UFF: 3}
-#: pair-term groups whose rows are re-ordered on the device when a batch is built (see :func:`diagonal_pair_order`);
-#: the small 1-2 / 1-3 groups keep the caller's order (ETK groups 2 and 3 are tied to per-system reference distances)
+#: pair-term groups whose rows the table builder (csrc/table_build.cpp) re-orders along the diagonals of the pair matrix:
+#: RDKit (and every natural builder) emits the O(N^2) pair lists i-major, so 64 consecutive terms share atom i, the 64 lanes
+#: of a wavefront add their forces into the SAME three LDS words and the hardware serialises the atomic adds lane by lane;
+#: along a diagonal consecutive terms touch distinct atoms on both sides.  Energy and gradient are sums over terms, so only the
+#: floating-point summation order changes.  The small 1-2 / 1-3 groups keep the caller's order (ETK groups 2 and 3 are tied to
+#: per-system reference distances).  ``NVMK_PAIR_ORDER=input`` / ``NVMK_MMFF_MERGE=0`` switch ordering / merging off (A/B).
 PAIR_ORDER_GROUPS = {DG: (0,), ETK: (5,), MMFF: (5, 6), UFF: (4,), QUARTIC: ()}
 # MMFF / UFF batches may append up to four constraint groups (distance, position, angle, torsion; include/nvmolkit_amd.h)
 CONSTRAINT_LAYOUT = [(2, 3), (1, 5), (3, 3), (4, 3)]
-
-
-def pair_order_enabled() -> bool:
-    """``NVMK_PAIR_ORDER=input`` keeps the caller's row order of the pair tables (A/B switch for measurements)."""
-    return os.environ.get("NVMK_PAIR_ORDER", "diagonal") != "input"
-
-
-def diagonal_pair_order(starts: torch.Tensor, idx: torch.Tensor, par: torch.Tensor):
-    """Re-order the rows of a pair-term group inside every system by (|j - i|, min(i, j)).
-
-    RDKit (and every natural builder) emits the O(N^2) pair lists i-major: 64 consecutive terms share atom i, so the 64
-    lanes of a wavefront accumulate their forces into the SAME three LDS words and the hardware serialises the atomic
-    adds lane by lane.  Along a diagonal of the pair matrix consecutive terms touch distinct atoms on both sides.  The
-    energy and gradient are sums over terms, so only the floating-point summation order changes.  Runs on the device
-    (one key computation + one sort per group and batch).
-    """
-    n_terms = idx.shape[0]
-    if n_terms == 0:
-        return idx, par
-    counts = (starts[1:] - starts[:-1]).to(torch.int64)
-    seg = torch.repeat_interleave(torch.arange(counts.numel(), device=idx.device, dtype=torch.int64), counts, output_size=n_terms)
-    a, b = idx[:, 0].to(torch.int64), idx[:, 1].to(torch.int64)
-    lo = torch.minimum(a, b)
-    key = (seg << 40) | ((torch.maximum(a, b) - lo) << 20) | lo
-    perm = torch.argsort(key, stable=True)
-    return idx[perm].contiguous(), par[perm].contiguous()
-
-
-def mmff_merge_enabled() -> bool:
-    """``NVMK_MMFF_MERGE=0`` keeps van der Waals and electrostatics as separate tables (A/B switch)."""
-    return os.environ.get("NVMK_MMFF_MERGE", "1") != "0"
-
-
-def merge_mmff_nonbonded(vdw, ele):
-    """Device-side merge of the MMFF van der Waals group ``(starts, idx, par(R*, eps))`` and electrostatic group
-    ``(starts, idx, par(chargeTerm, dielModel, is1_4))`` into one table ``(starts, idx, par(R*, eps, chargeTerm, dielModel,
-    is1_4))`` with one row per van der Waals pair.  Returns ``None`` when the lists cannot be merged (an electrostatic pair
-    without a van der Waals pair, or a pair listed twice): the kernels then keep walking the two tables."""
-    s5, i5, p5 = vdw
-    s6, i6, p6 = ele
-    n5, n6 = i5.shape[0], i6.shape[0]
-    if n5 == 0 or s5.numel() != s6.numel():
-        return None
-    dev = i5.device
-
-    def keys(starts, idx):
-        counts = (starts[1:] - starts[:-1]).to(torch.int64)
-        seg = torch.repeat_interleave(torch.arange(counts.numel(), device=dev, dtype=torch.int64), counts, output_size=idx.shape[0])
-        a, b = idx[:, 0].to(torch.int64), idx[:, 1].to(torch.int64)
-        return (seg << 40) | (torch.minimum(a, b) << 20) | torch.maximum(a, b)
-
-    k5 = keys(s5, i5)
-    order = torch.argsort(k5, stable=True)
-    k5s = k5[order]
-    if n5 > 1 and bool((k5s[1:] == k5s[:-1]).any()):
-        return None
-    par = torch.zeros((n5, 5), dtype=torch.float64, device=dev)
-    par[:, 0:2] = p5[order]
-    if n6:
-        k6 = keys(s6, i6)
-        pos = torch.searchsorted(k5s, k6)
-        if bool((pos >= n5).any()) or bool((k5s[pos.clamp(max=n5 - 1)] != k6).any()) or torch.unique(k6).numel() != n6:
-            return None
-        par[pos, 2:5] = p6
-    return s5, i5[order].contiguous(), par
-
-
-def _merged_and_ordered(vdw, ele):
-    merged = merge_mmff_nonbonded(vdw, ele)
-    if merged is not None and pair_order_enabled():
-        merged = (merged[0],) + tuple(diagonal_pair_order(*merged))
-    return merged
-
-
-class _GroupList(list):
-    """The resident term groups of a MoleculeTermTables, plus what was derived from them once."""
-
-    merged_nonbonded = None
 
 
 class FlatForcefieldBatch:
@@ -131,12 +58,6 @@ class FlatForcefieldBatch:
     def __init__(self, kind: int, atom_starts, groups: Sequence[tuple], device="cuda", system_mol=None):
         if kind not in GROUP_LAYOUT:
             raise ValueError(f"unknown force-field kind {kind}")
-        layout = list(GROUP_LAYOUT[kind])
-        n_extra = len(groups) - len(layout)
-        if n_extra < 0 or (n_extra > 0 and (kind not in (MMFF, UFF) or n_extra > len(CONSTRAINT_LAYOUT))):
-            raise ValueError(f"kind {kind} needs {len(layout)} term groups"
-                             f"{' (+ up to 4 constraint groups)' if kind in (MMFF, UFF) else ''}, got {len(groups)}")
-        layout += CONSTRAINT_LAYOUT[:n_extra]
         self.kind = kind
         self.dim = DIM[kind]
         self.device = torch.device(device)
@@ -160,43 +81,23 @@ class FlatForcefieldBatch:
             self._keep.append(sm)
             self._c.system_mol = sm.data_ptr()
             n_rows = None  # validated against the tables below
-        resident_nonbonded = {}
-        for g, ((n_idx, n_par), (starts, idx, par)) in enumerate(zip(layout, groups)):
-            if isinstance(starts, torch.Tensor):  # already resident (MoleculeTermTables): validated and ordered there
-                t = [starts, idx, par]
-                if any(x.device != self.device for x in t):
-                    raise ValueError(f"term group {g}: resident tables live on {starts.device}, the batch on {self.device}")
-                if n_rows is None:
-                    n_rows = starts.numel() - 1
-                if starts.numel() != n_rows + 1:
-                    raise ValueError(f"term group {g}: inconsistent starts / idx / par sizes")
-            else:
-                starts = np.ascontiguousarray(starts, dtype=np.int32)
-                idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, n_idx)
-                par = (np.ascontiguousarray(par, dtype=np.float64).reshape(-1, n_par) if n_par else np.zeros((len(idx), 0)))
-                if n_rows is None:
-                    n_rows = len(starts) - 1
-                if len(starts) != n_rows + 1 or (len(starts) and starts[-1] != len(idx)) or len(par) != len(idx):
-                    raise ValueError(f"term group {g}: inconsistent starts / idx / par sizes")
-                t = [torch.from_numpy(starts).to(self.device), torch.from_numpy(idx.copy()).to(self.device),
-                     torch.from_numpy(np.ascontiguousarray(par)).to(self.device)]
-                if g in PAIR_ORDER_GROUPS[kind] and pair_order_enabled():
-                    t[1], t[2] = diagonal_pair_order(t[0], t[1], t[2])
-            self._keep.extend(t)
-            self._c.groups[g].starts = t[0].data_ptr()
-            self._c.groups[g].idx = t[1].data_ptr() if t[1].numel() else None
-            self._c.groups[g].par = t[2].data_ptr() if t[2].numel() else None
-            if kind == MMFF and g in (5, 6):
-                resident_nonbonded[g] = tuple(t)
-        if kind == MMFF and len(resident_nonbonded) == 2 and mmff_merge_enabled():
-            merged = getattr(groups, "merged_nonbonded", False)  # MoleculeTermTables carries it (None = cannot be merged)
-            if merged is False:
-                merged = _merged_and_ordered(resident_nonbonded[5], resident_nonbonded[6])
-            if merged is not None:
-                self._keep.extend(merged)
-                self._c.groups[11].starts = merged[0].data_ptr()
-                self._c.groups[11].idx = merged[1].data_ptr()
-                self._c.groups[11].par = merged[2].data_ptr()
+        if isinstance(groups, MoleculeTermTables):  # resident: assembled, ordered and (MMFF) merged when they were built
+            if system_mol is None:
+                raise ValueError("resident per-molecule term tables need system_mol")
+            if groups.kind != kind:
+                raise ValueError("the resident term tables belong to another force field")
+            if groups.device != self.device:
+                raise ValueError(f"resident tables live on {groups.device}, the batch on {self.device}")
+            tables = groups
+        elif kind == QUARTIC:
+            if len(groups):
+                raise ValueError("the quartic field has no term groups")
+            return
+        else:
+            tables = MoleculeTermTables.from_stacked(kind, groups, self.device, n_rows)
+        self._keep.append(tables)
+        for g in range(12):
+            self._c.groups[g] = tables.view[g]
 
     @property
     def n_atoms_total(self) -> int:
@@ -266,30 +167,124 @@ class FlatForcefieldBatch:
 
 
 class MoleculeTermTables:
-    """Per-MOLECULE term tables of `kind`, stacked, uploaded and pair-ordered ONCE, for any number of conformer batches.
+    """Per-MOLECULE term tables of `kind`, assembled, pair-ordered and uploaded ONCE, for any number of conformer batches.
 
     ``tables[m][g] = (idx, par)`` as for :func:`stack_molecule_tables`.  The reference flattens once per unique molecule
     and copies into every batch (src/minimizer/bfgs_mmff.cpp:159,195-201); here the tables stay where they are and a
     batch only adds its atom offsets and its system -> molecule map (``FlatForcefieldBatch(..., system_mol=...)``).
+    Assembly is the library's (``nvmk_ff_tables_build``: host threads, pinned staging, chunked upload on the current stream
+    of ``device``; for MMFF the merged non-bonded table, group 11, is made in the same pass); ``device="cpu"`` builds the
+    same tables in host memory for the CPU test-suite.
     """
 
-    def __init__(self, kind: int, tables: Sequence[Sequence[tuple]], device="cuda"):
+    def __init__(self, kind: int, tables: Sequence[Sequence[tuple]], device="cuda", preprocessing_threads: int = -1):
+        layout = self._start(kind, device, len(GROUP_LAYOUT.get(kind, ())))
+        self.n_mols = len(tables)
+        n_idx = (ctypes.c_int32 * len(layout))(*[a for a, _ in layout])
+        n_par = (ctypes.c_int32 * len(layout))(*[b for _, b in layout])
+        terms = (_native.HostTerms * max(self.n_mols * len(layout), 1))()
+        keep: list = []
+        _native.pyglue().nvmk_py_gather_term_tables(tables, ctypes.addressof(n_idx), ctypes.addressof(n_par), len(layout),
+                                                    ctypes.addressof(terms), keep, _native._as_term_array)
+        self._build(ctypes.addressof(terms), len(layout), preprocessing_threads)
+
+    @classmethod
+    def from_stacked(cls, kind: int, groups: Sequence[tuple], device="cuda", n_rows: int | None = None, preprocessing_threads: int = -1):
+        """The same from STACKED groups ``(starts, idx, par)`` (host arrays; ``starts`` has one more entry than there are rows —
+        molecules, or systems for a batch without ``system_mol``); MMFF / UFF may append up to four constraint groups."""
+        self = cls.__new__(cls)
+        layout = self._start(kind, device, len(groups))
+        arrays, counts = [], []
+        for g, ((n_idx, n_par), (starts, idx, par)) in enumerate(zip(layout, groups)):
+            starts = np.ascontiguousarray(starts, dtype=np.int32)
+            idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, n_idx)
+            par = np.ascontiguousarray(par, dtype=np.float64).reshape(-1, n_par) if n_par else np.zeros((len(idx), 0))
+            if n_rows is None:
+                n_rows = len(starts) - 1
+            if (len(starts) != n_rows + 1 or (len(starts) and (starts[0] != 0 or starts[-1] != len(idx))) or len(par) != len(idx)
+                    or np.any(np.diff(starts) < 0)):
+                raise ValueError(f"term group {g}: inconsistent starts / idx / par sizes")
+            arrays.append((starts, idx, par))
+        self.n_mols = int(n_rows or 0)
+        terms = np.zeros((self.n_mols, len(layout)), dtype=_HOST_TERMS_DTYPE)
+        for g, ((n_idx, n_par), (starts, idx, par)) in enumerate(zip(layout, arrays)):
+            if self.n_mols == 0:
+                continue
+            first = starts[:-1].astype(np.uint64)
+            terms["n_terms"][:, g] = np.diff(starts)
+            terms["idx_bytes"][:, g] = 4
+            terms["idx"][:, g] = np.uint64(idx.ctypes.data) + first * np.uint64(4 * n_idx)
+            terms["par"][:, g] = np.uint64(par.ctypes.data) + first * np.uint64(8 * n_par)
+        self._build(terms.ctypes.data, len(layout), preprocessing_threads)
+        del arrays  # the rows were copied during the build
+        return self
+
+    def _start(self, kind: int, device, n_groups: int):
+        if kind not in (DG, ETK, MMFF, UFF):
+            raise ValueError(f"no term tables for force-field kind {kind}")
+        layout = list(GROUP_LAYOUT[kind])
+        n_extra = n_groups - len(layout)
+        if n_extra < 0 or (n_extra > 0 and (kind not in (MMFF, UFF) or n_extra > len(CONSTRAINT_LAYOUT))):
+            raise ValueError(f"kind {kind} needs {len(layout)} term groups"
+                             f"{' (+ up to 4 constraint groups)' if kind in (MMFF, UFF) else ''}, got {n_groups}")
         self.kind = kind
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.n_mols = len(tables)
-        self.groups = _GroupList()
-        with torch.cuda.device(self.device):
-            for g, (starts, idx, par) in enumerate(stack_molecule_tables(kind, tables)):
-                t = [torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int32)).to(self.device),
-                     torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device),
-                     torch.from_numpy(np.ascontiguousarray(par, dtype=np.float64)).to(self.device)]
-                if g in PAIR_ORDER_GROUPS[kind] and pair_order_enabled():
-                    t[1], t[2] = diagonal_pair_order(t[0], t[1], t[2])
-                self.groups.append(tuple(t))
-            if kind == MMFF and mmff_merge_enabled():
-                self.groups.merged_nonbonded = _merged_and_ordered(self.groups[5], self.groups[6])
+        return layout + CONSTRAINT_LAYOUT[:n_extra]
+
+    def _build(self, terms_address: int, n_groups: int, preprocessing_threads: int) -> None:
+        handle = ctypes.c_void_p()
+        flags = _native.build_flags()
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                rc = _native.lib().nvmk_ff_tables_build(self.kind, terms_address, self.n_mols, n_groups, int(preprocessing_threads), flags,
+                                                        _native.stream_ptr(None), ctypes.byref(handle))
+        else:
+            rc = _native.lib().nvmk_ff_tables_build(self.kind, terms_address, self.n_mols, n_groups, int(preprocessing_threads),
+                                                    flags | _native.BUILD_HOST, None, ctypes.byref(handle))
+        _native.check(rc, "nvmk_ff_tables_build")
+        self._handle = handle
+        self._finalizer = weakref.finalize(self, _native.lib().nvmk_ff_tables_free, handle)
+        self.view = (_native.FFGroup * 12)()
+        _native.check(_native.lib().nvmk_ff_tables_view(handle, ctypes.addressof(self.view), None), "nvmk_ff_tables_view")
+
+
+class PendingTermTables:
+    """:class:`MoleculeTermTables` under construction on a host thread and a side stream of its own while the caller keeps the
+    GPU busy with something else — the MMFF tables of a molecule set while its ETKDG embedding runs, which is how the
+    reference hides its per-batch flattening behind the previous batch's kernels (src/minimizer/bfgs_mmff.cpp:139-201).
+    ``result()`` joins the thread and makes the caller's current stream wait for the upload."""
+
+    def __init__(self, kind: int, tables, device="cuda", preprocessing_threads: int = -1):
+        import threading
+
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._tables = self._error = None
+
+        def work():
+            try:
+                with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
+                    self._tables = MoleculeTermTables(kind, tables, self.device, preprocessing_threads)
+            except BaseException as exc:  # noqa: BLE001 - re-raised in result()
+                self._error = exc
+
+        self._thread = threading.Thread(target=work, name="nvmk-term-tables")
+        self._thread.start()
+
+    def result(self) -> "MoleculeTermTables":
+        self._thread.join()
+        if self._error is not None:
+            raise self._error
+        torch.cuda.current_stream(self.device).wait_stream(self._stream)
+        return self._tables
+
+
+_HOST_TERMS_DTYPE = np.dtype([("n_terms", np.int32), ("idx_bytes", np.int32), ("idx", np.uint64), ("par", np.uint64)])
+assert _HOST_TERMS_DTYPE.itemsize == ctypes.sizeof(_native.HostTerms)
 
 
 def stack_molecule_tables(kind: int, tables: Sequence[Sequence[tuple]]):
@@ -306,7 +301,7 @@ def stack_molecule_tables(kind: int, tables: Sequence[Sequence[tuple]]):
         idx = (np.concatenate([np.asarray(t[g][0], dtype=np.int32).reshape(-1, n_idx) for t in tables])
                if tables else np.zeros((0, n_idx), dtype=np.int32))
         par = (np.concatenate([np.asarray(t[g][1], dtype=np.float64).reshape(-1, n_par) for t in tables])
-               if tables else np.zeros((0, n_par)))
+               if tables and n_par else np.zeros((len(idx), n_par)))
         groups.append((starts, idx, par))
     return groups
 
@@ -321,6 +316,8 @@ def minimize_device_conformers(kind: int, tables, conformers: Device3DResult, ma
     new ``Device3DResult`` carrying ``energies`` and ``converged``.  The input result is left untouched."""
     if kind not in (MMFF, UFF):
         raise ValueError("minimize_device_conformers supports the MMFF and UFF kinds")
+    if isinstance(tables, PendingTermTables):
+        tables = tables.result()
     n_tables = tables.n_mols if isinstance(tables, MoleculeTermTables) else len(tables)
     if n_tables != conformers.n_mols:
         raise ValueError(f"expected term tables for {conformers.n_mols} molecules, got {n_tables}")
@@ -331,9 +328,10 @@ def minimize_device_conformers(kind: int, tables, conformers: Device3DResult, ma
     if isinstance(tables, MoleculeTermTables):
         if tables.kind != kind:
             raise ValueError("the resident term tables belong to another force field")
-        groups = tables.groups
+        groups = tables
     else:
-        groups = stack_molecule_tables(kind, tables)
+        with torch.cuda.device(device):
+            groups = MoleculeTermTables(kind, tables, device)
     batch = FlatForcefieldBatch(kind, atom_starts.cpu().numpy(), groups, device=device, system_mol=mols)
     pos = values.reshape(-1).clone()
     energies, statuses, _ = batch.minimize(pos, max_iters=max_iters, grad_tol=grad_tol, scale_grads=True, stream=stream)

@@ -14,7 +14,7 @@ from typing import Sequence
 import numpy as np
 import torch
 
-from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch, MoleculeTermTables, minimize_device_conformers
+from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch, MoleculeTermTables, PendingTermTables, minimize_device_conformers
 from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
 _LINEAR_MMFF_TYPES = frozenset({4, 53, 61})  # MMFFPROP.PAR rows with linh = 1 (CSP, =N=, NR%)
@@ -33,11 +33,14 @@ def optimize_flat(atom_starts, groups, positions: torch.Tensor, max_iters: int =
     return energies, statuses == 0
 
 
-def resident_tables(tables, device="cuda") -> MoleculeTermTables:
-    """Upload the per-molecule MMFF term tables once (see :class:`MoleculeTermTables`); pass the result to
-    :func:`optimize_device` instead of ``tables`` when the same molecules are optimised more than once, or to keep the
-    upload out of a timed region."""
-    return MoleculeTermTables(MMFF, tables, device)
+def resident_tables(tables, device="cuda", preprocessing_threads: int = -1, wait: bool = True):
+    """Assemble and upload the per-molecule MMFF term tables once (see :class:`MoleculeTermTables`); pass the result to
+    :func:`optimize_device` instead of ``tables`` when the same molecules are optimised more than once.  ``wait=False`` returns at
+    once with a :class:`PendingTermTables`: the tables are put together on a host thread and a side stream while the caller runs
+    something else (the ETKDG embedding of the same molecules), and :func:`optimize_device` picks them up when it needs them."""
+    if not wait:
+        return PendingTermTables(MMFF, tables, device, preprocessing_threads)
+    return MoleculeTermTables(MMFF, tables, device, preprocessing_threads)
 
 
 def optimize_device(tables, conformers: Device3DResult, max_iters: int = 200, grad_tol: float = 1e-4) -> Device3DResult:

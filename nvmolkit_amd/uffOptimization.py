@@ -15,7 +15,7 @@ from typing import Sequence
 import numpy as np
 import torch
 
-from nvmolkit_amd.forcefield import UFF, FlatForcefieldBatch, MoleculeTermTables, minimize_device_conformers
+from nvmolkit_amd.forcefield import UFF, FlatForcefieldBatch, MoleculeTermTables, PendingTermTables, minimize_device_conformers
 from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 
 _TORSION_BOND_SMARTS = "[!$([D1]);!$([#1])]~[!$([D1]);!$([#1])]"  # RDKit DefaultTorsionBondSmarts
@@ -35,9 +35,14 @@ def optimize_flat(atom_starts, groups, positions: torch.Tensor, max_iters: int =
     return energies, statuses == 0
 
 
-def resident_tables(tables, device="cuda") -> MoleculeTermTables:
-    """Upload the per-molecule UFF term tables once; pass the result to :func:`optimize_device` instead of ``tables``."""
-    return MoleculeTermTables(UFF, tables, device)
+def resident_tables(tables, device="cuda", preprocessing_threads: int = -1, wait: bool = True):
+    """Assemble and upload the per-molecule UFF term tables once (see :class:`MoleculeTermTables`); pass the result to
+    :func:`optimize_device` instead of ``tables`` when the same molecules are optimised more than once.  ``wait=False`` returns at
+    once with a :class:`PendingTermTables`: the tables are put together on a host thread and a side stream while the caller runs
+    something else (the ETKDG embedding of the same molecules), and :func:`optimize_device` picks them up when it needs them."""
+    if not wait:
+        return PendingTermTables(UFF, tables, device, preprocessing_threads)
+    return MoleculeTermTables(UFF, tables, device, preprocessing_threads)
 
 
 def optimize_device(tables, conformers: Device3DResult, max_iters: int = 1000, grad_tol: float = 1e-4) -> Device3DResult:

@@ -61,7 +61,7 @@ def test_committed_bench_line_has_every_field_of_the_contract():
 
 def test_multi_rank_start_up_pieces_without_a_gpu(tmp_path):
     """What `bench.py --gpus N` does before its first collective, on the CPU: the molecule library generated once by rank 0 and
-    loaded by the others (no rank generates it again), every rank drawing only its own rows of the seeded reference set (the
+    handed to the others through a private directory (no rank generates it again), every rank drawing only its own rows of the seeded reference set (the
     rows agree with the full set drawn block by block), and the strong-scaling deal of one job over the ranks."""
     import os
     import numpy as np
@@ -76,16 +76,24 @@ def test_multi_rank_start_up_pieces_without_a_gpu(tmp_path):
         assert torch.equal(bench.synth_fingerprints(600_000, 4, "cpu", 5, row_range=(lo, hi)), full[lo:hi])
     assert bench.synth_fingerprints(600_000, 4, "cpu", 5, row_range=(10, 10)).shape == (0, 4)
 
-    # the shared library: two "ranks" as two processes, rank 1 started first
-    code = ("import sys, os, json; sys.path.insert(0, r'%s'); os.environ['MASTER_PORT'] = '%d'; import bench\n"
-            "lib, t = bench.conformer_library(24, 2, int(sys.argv[1]), shared=True)\n"
-            "print(json.dumps([len(lib), int(sum(m['embed']['n_atoms'] for m in lib)), float(lib[3]['bounds'][1].sum())]))\n") % (ROOT, 40000 + os.getpid() % 20000)
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    r1 = subprocess.Popen([sys.executable, "-c", code, "1"], stdout=subprocess.PIPE, text=True, env=env)
+    # the shared library: two ranks as two processes over gloo; rank 0 generates, rank 1 gets None and then rank 0's set through a
+    # private directory whose path travels over the process group; the directory is gone afterwards
+    code = ("import sys, os, json; sys.path.insert(0, r'%s'); import bench, torch.distributed as dist\n"
+            "rank = int(sys.argv[1])\n"
+            "lib, t = bench.conformer_library(24, 2, rank, shared=True)\n"
+            "assert (lib is None) == (rank == 1)\n"
+            "dist.init_process_group('gloo', rank=rank, world_size=2)\n"
+            "lib = bench.share_library(lib, rank)\n"
+            "left = [d for d in os.listdir('/dev/shm') if d.startswith('nvmk_bench_') and os.path.isdir('/dev/shm/' + d)] if os.path.isdir('/dev/shm') else []\n"
+            "print(json.dumps([len(lib), int(sum(m['embed']['n_atoms'] for m in lib)), float(lib[3]['bounds'][1].sum()), left]))\n"
+            "dist.destroy_process_group()\n") % ROOT
+    env = dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(40000 + os.getpid() % 20000))
+    r1 = subprocess.Popen([sys.executable, "-c", code, "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     r0 = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=600, env=env)
-    out1, _ = r1.communicate(timeout=600)
-    assert r0.returncode == 0 and r1.returncode == 0, r0.stderr[-1500:]
-    assert json.loads(r0.stdout.strip().splitlines()[-1]) == json.loads(out1.strip().splitlines()[-1])
+    out1, err1 = r1.communicate(timeout=600)
+    assert r0.returncode == 0 and r1.returncode == 0, (r0.stderr[-1500:], err1[-1500:])
+    got0, got1 = json.loads(r0.stdout.strip().splitlines()[-1]), json.loads(out1.strip().splitlines()[-1])
+    assert got0[:3] == got1[:3] and got0[0] == 24 and got0[3] == []   # rank 0 removes the directory after the barrier
 
     # one job of 100 molecule instances dealt over 4 ranks: every instance once, loads within a few per cent
     lib = [{"embed": {"n_atoms": int(n)}} for n in np.random.default_rng(0).integers(12, 96, size=30)]

@@ -1,10 +1,11 @@
-"""Host-side (torch, any device) preparation of the force-field term tables: the diagonal ordering of the O(N^2) pair
-groups and the merge of the MMFF van der Waals and electrostatic tables — pure index work, checked on the CPU."""
+"""The restatement the table builder is held to (tests/table_model.py: the diagonal ordering of the O(N^2) pair groups and the
+merge of the MMFF van der Waals and electrostatic tables) checked against first principles — pure index work on the CPU.
+tests/test_table_build.py then compares the library's builder with it row by row."""
 
 import numpy as np
 import torch
 
-from nvmolkit_amd.forcefield import diagonal_pair_order, merge_mmff_nonbonded
+from tests.table_model import diagonal_pair_order, merge_mmff_nonbonded
 
 
 def _random_pair_group(rng, n_systems, n_atoms, n_par, density=0.6):
