@@ -104,7 +104,7 @@ extern "C" {
 
 const char* nvmk_last_error(void) { return nvmk::g_last_error; }
 
-int nvmk_abi_version(void) { return (0 << 16) | 3; }
+int nvmk_abi_version(void) { return (0 << 16) | 4; }
 
 int nvmk_set_option(const char* name, const char* value) {
   NVMK_REQUIRE(name != nullptr, "nvmk_set_option: name is NULL");

@@ -10,6 +10,7 @@ Two entry points:
 from __future__ import annotations
 
 import ctypes
+import time
 import weakref
 from dataclasses import dataclass, field
 from typing import Sequence
@@ -75,6 +76,7 @@ class FlatMoleculeSet:
     (no GPU involved; the CPU test-suite reads them back through ``self.c``)."""
 
     def __init__(self, mols: Sequence[FlatMolecule], device="cuda", preprocessing_threads: int = -1):
+        t0 = time.perf_counter()
         self.device = torch.device(device)
         self.mols = list(mols)
         n = len(self.mols)
@@ -87,6 +89,7 @@ class FlatMoleculeSet:
                                                        par.ctypes.data, n_checks, keep, _native._as_term_array)
         handle = ctypes.c_void_p()
         flags = _native.build_flags()
+        t1 = time.perf_counter()
         if self.device.type == "cuda":
             with torch.cuda.device(self.device):
                 rc = _native.lib().nvmk_etkdg_molset_build(ctypes.addressof(descs), n, int(preprocessing_threads), flags,
@@ -100,6 +103,8 @@ class FlatMoleculeSet:
         self.c = _native.EtkdgMolset()
         _native.check(_native.lib().nvmk_etkdg_molset_view(handle, ctypes.byref(self.c)), "nvmk_etkdg_molset_view")
         self.has_etk = bool(self.c.h_etk_d12_counts)
+        #: host seconds of the two steps: descriptors from the Python objects (GIL held), the library's assembly + upload calls
+        self.timings = {"gather_seconds": t1 - t0, "build_seconds": time.perf_counter() - t1}
 
 
 # Conformer attempts per launch when the caller does not choose (-1, as HardwareOptions.batchSize).  One wave (small systems) or

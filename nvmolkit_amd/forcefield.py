@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 import weakref
 from typing import Sequence
 
@@ -98,6 +99,7 @@ class FlatForcefieldBatch:
         self._keep.append(tables)
         for g in range(12):
             self._c.groups[g] = tables.view[g]
+        self._c.packed_mask = tables.packed_mask
 
     @property
     def n_atoms_total(self) -> int:
@@ -247,7 +249,9 @@ class MoleculeTermTables:
         self._handle = handle
         self._finalizer = weakref.finalize(self, _native.lib().nvmk_ff_tables_free, handle)
         self.view = (_native.FFGroup * 12)()
-        _native.check(_native.lib().nvmk_ff_tables_view(handle, ctypes.addressof(self.view), None), "nvmk_ff_tables_view")
+        packed = ctypes.c_uint32(0)
+        _native.check(_native.lib().nvmk_ff_tables_view(handle, ctypes.addressof(self.view), ctypes.byref(packed), None), "nvmk_ff_tables_view")
+        self.packed_mask = int(packed.value)  # which pair groups hold packed rows (nvmk_ff_batch.packed_mask)
 
 
 class PendingTermTables:
@@ -267,6 +271,9 @@ class PendingTermTables:
 
         def work():
             try:
+                # the first step (walking the Python lists into descriptors) holds the GIL for tens of milliseconds: let the
+                # caller get into its own blocking library call (which releases the GIL) first, instead of stalling it
+                time.sleep(0.003)
                 with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
                     self._tables = MoleculeTermTables(kind, tables, self.device, preprocessing_threads)
             except BaseException as exc:  # noqa: BLE001 - re-raised in result()

@@ -11,7 +11,9 @@
 #   chembl_tests        tests/test_chembl_conformers_gpu.py
 #   timeline            BFGS per-system timeline of one 10 000-molecule run (NVMK_BFGS_PROFILE=1 NVMK_BFGS_TIMELINE)
 #   conformer_traffic   tools/profile_conformer_traffic.sh 2000
-#   pytest_gpu          the whole -m gpu suite
+#   table_tests         the table builder's GPU tests + the suites that build batches through it
+#   conf10k             tools/bench_conformers.py --mols 10000 (resident tables, and end to end from the host arrays)
+#   pytest_gpu          the whole -m gpu suite (stops at the first failure; pytest_gpu_all: runs on)
 #   smoke               __graft_entry__.smoke()
 #   bench               python bench.py (default flags), plain
 #   bench_stats         python bench.py under rocprofv3 --kernel-trace --stats
@@ -33,7 +35,7 @@ CACHE=/tmp/nvmk_lib_cache
 pick() { python -c "import sys,json
 for line in sys.stdin:
     if line.startswith('{'):
-        d=json.loads(line); print('$1', {k: (round(d[k],4) if isinstance(d[k],float) else d[k]) for k in d if k in ('mols_per_s_etkdg_plus_mmff','etkdg_s','mmff_s','etkdg_conformers','mmff_converged_frac','mols','mean_atoms')})"; }
+        d=json.loads(line); print('$1', {k: (round(d[k],4) if isinstance(d[k],float) else d[k]) for k in d if k in ('mols_per_s_etkdg_plus_mmff','etkdg_s','mmff_s','etkdg_conformers','mmff_converged_frac','mols','mean_atoms','mols_per_s_end_to_end','end_to_end_s','table_assembly_host_s','mmff_tables_wait_s')})"; }
 
 for STEP in "$@"; do
   echo "==== $STEP ($(date +%T))"
@@ -146,8 +148,20 @@ PY
       timeout 900 bash tools/profile_conformer_traffic.sh 2000 > $O/conformer_traffic.log 2>&1
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/ 2>/dev/null
       # (bench.py quotes the file from profiles/ while the kernel sources' digest matches: in place for the bench steps of this session)
-      mkdir -p profiles/r04_conformers && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json profiles/r04_conformers/ 2>/dev/null
+      mkdir -p profiles/r05_conformers && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json profiles/r05_conformers/ 2>/dev/null
       tail -30 $O/conformer_traffic.log
+      ;;
+    table_tests)
+      ( time timeout 900 python -m pytest tests/test_table_build_gpu.py tests/test_cxx_example.py tests/test_device_chain_gpu.py tests/test_etkdg_gpu.py tests/test_forcefield_gpu.py tests/test_constraints.py -m gpu -q ) > $O/table_tests.log 2>&1
+      tail -15 $O/table_tests.log
+      ;;
+    conf10k)
+      timeout 600 python tools/bench_conformers.py --mols 10000 --repeat 2 --cache $CACHE 2> $O/conf10k.err | tee $O/conf10k.json | pick conf10k
+      tail -3 $O/conf10k.err
+      ;;
+    pytest_gpu_all)
+      ( time timeout 2400 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
+      tail -25 $O/pytest_gpu.log
       ;;
     pytest_gpu)
       ( time timeout 2400 python -m pytest tests -m gpu -q -x ) > $O/pytest_gpu.log 2>&1
@@ -173,7 +187,7 @@ PY
       rm -rf gpurun_out/pmc_traffic/fetch gpurun_out/pmc_traffic/write
       timeout 900 bash tools/profile_bench_traffic.sh > $O/bench_traffic.log 2>&1
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json $O/ 2>/dev/null
-      mkdir -p profiles/r04_similarity && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json profiles/r04_similarity/ 2>/dev/null
+      mkdir -p profiles/r05_similarity && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json profiles/r05_similarity/ 2>/dev/null
       tail -20 $O/bench_traffic.log
       ;;
     markers)
