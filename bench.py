@@ -142,7 +142,7 @@ def kernel_source_digest(names=("similarity_mfma.hip", "fp4.h", "similarity.hip"
 
 def conformer_source_digest() -> str:
     """sha256 over the conformer kernels' sources (as tools/profile_conformer_traffic.sh computes it)."""
-    return kernel_source_digest(("minimize.hip", "bfgs_device.inc", "hess_pass.h", "ff_terms.h", "ff_grad.h", "etkdg.hip"))
+    return kernel_source_digest(("minimize.hip", "bfgs_device.inc", "hess_pass.h", "ff_terms.h", "ff_grad.h", "etkdg.hip", "table_build.cpp"))
 
 
 def butina_block(n: int, words: int, device, cpu_seconds: float) -> dict:
@@ -240,6 +240,53 @@ def cfg1_block(device, cpu_seconds: float) -> dict:
                                          "(OpenMP) for the 10k x 10k matrix"}
         out["matches_cpu_port"] = bool(np.array_equal(fps.cpu().numpy().view(np.uint32), want)
                                        and np.array_equal(sim[rows].cpu().numpy(), ref[rows]))
+    return out
+
+
+def morgan_block(device) -> dict:
+    """the Morgan kernel (radius 2, 2048 bit) on RESIDENT inputs, per size bucket — the molecules of the
+    reference's benchmark file that fall into the 32 / 64 / 128-slot buckets (atoms and bonds below the slot count: the
+    reference's bucketing rule), their invariant arrays made by the library's ingestion and tiled on the device to 2^20 (32, 64)
+    or 2^18 (128) molecules; three launches per bucket timed with events on the launch stream."""
+    from nvmolkit_amd import _native
+    from nvmolkit_amd.fingerprints import SmilesSet
+
+    lib = _native.lib()
+    mols = SmilesSet.from_file(str(ROOT / "tests" / "golden" / "chembl_10k.smi"))
+    size = np.maximum(mols.n_atoms, mols.n_bonds)
+    stream = torch.cuda.current_stream()
+    out, lo = {"radius": 2, "fp_bits": 2048, "data": "tests/golden/chembl_10k.smi by bucket, tiled on the device", "buckets": {}}, 0
+    for stride, target in ((32, 1 << 20), (64, 1 << 20), (128, 1 << 18)):
+        idx = np.flatnonzero((size >= lo) & (size < stride) & (mols.status == 0))
+        lo = stride
+        if len(idx) == 0:
+            continue
+        host = mols.morgan_inputs(idx, stride)
+        reps = (target + len(idx) - 1) // len(idx)
+        d = [torch.from_numpy(np.ascontiguousarray(a.view(np.int32) if a.dtype == np.uint32 else a)).to(device) for a in host]
+        d = [t.repeat((reps,) + (1,) * (t.dim() - 1))[:target].contiguous() for t in d]
+        fps = torch.empty((target, 64), dtype=torch.int32, device=device)
+
+        def launch():
+            _native.check(lib.nvmk_morgan_from_invariants(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                                          None, target, stride, 2, 2048, fps.data_ptr(), int(stream.cuda_stream)))
+
+        launch()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for _ in range(3):
+            launch()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        dt = ev0.elapsed_time(ev1) * 1e-3 / 3
+        nbytes = sum(t.numel() * t.element_size() for t in d) + fps.numel() * 4
+        out["buckets"][str(stride)] = {"molecules": target, "distinct_molecules": int(len(idx)), "mean_atoms": float(mols.n_atoms[idx].mean()),
+                                       "seconds_per_launch": dt, "mols_per_s": target / dt,
+                                       "algorithmic_GB_per_s": nbytes / dt / 1e9,   # five input arrays read once + fingerprints written once
+                                       "frac_of_hbm_peak": nbytes / dt / 1e9 / HBM_PEAK_GBPS}
+        del d, fps
+    out["note"] = ("kernel nvmk::morgan::morgan_kernel: one wave per molecule (two molecules per wave in the 32 bucket), all state in "
+                   "LDS; bound by LDS traffic and latency, not by HBM (DESIGN.md 4.3) - the HBM fraction is given for scale")
     return out
 
 
@@ -428,8 +475,13 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
            "bfgs": per_kind,
            "data": data or ("synthetic drug-like molecules (rings + chains + hydrogens, bounds / ETK / MMFF tables derived from one "
                             "generated 3-D geometry; nvmolkit_amd/synthetic.py) — real SMILES need RDKit"),
-           "roofline": {"bound": "hbm", "achieved": algo / wall / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": algo / wall / 1e9 / HBM_PEAK_GBPS / world, "traffic": traffic, "traffic_source": traffic_src,
+           # achieved / frac: the bytes that crossed the L2s (PMC ratios of the same kernel sources applied to this run's requested
+           # bytes) when such a file exists, else the bytes the inverse-Hessian passes requested from HBM — never the algorithmic
+           # figure, which also counts the rows served from LDS
+           "roofline": {"bound": "hbm", "achieved": (traffic if traffic else requested) / wall / 1e9 / world, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": (traffic if traffic else requested) / wall / 1e9 / HBM_PEAK_GBPS / world,
+                        "frac_is": "frac_measured_traffic" if traffic else "frac_hbm_requested",
+                        "traffic": traffic, "traffic_source": traffic_src,
                         # which bytes a fraction counts: every byte of the packed inverse Hessians the iterations stand for
                         # (rows served from LDS included) / only those the passes request from HBM / what crossed the L2s
                         "frac_algorithmic": algo / wall / 1e9 / HBM_PEAK_GBPS / world,
@@ -746,6 +798,7 @@ def main() -> None:
             out = None  # release the 65 GB output block first
             torch.cuda.empty_cache()
             guarded("cfg1_smiles_to_similarity", cfg1_block, device, args.cpu_seconds)
+            guarded("morgan", morgan_block, device)
     else:
         secondary = {}
     if args.conformer_mols > 0:  # every rank takes part (configs[3]: molecules sharded, no collective on the data path)
@@ -764,6 +817,10 @@ def main() -> None:
     if rank == 0:
         if secondary:
             result["secondary"] = secondary
+        # the sources this line was measured on: tests/test_bench_contract.py refuses a committed line whose hashes differ from
+        # those of the PMC files it quotes
+        result["kernel_source_sha256"] = {"similarity": kernel_source_digest(), "conformers": conformer_source_digest(),
+                                          "neighbour_count": kernel_source_digest(("similarity_mfma.hip", "count_panel.inc", "fp4.h", "tile_maps.h"))}
         print(json.dumps(result))
     if distributed:
         dist.barrier()

@@ -218,7 +218,7 @@ int main() {
   batch.n_systems   = nSys;
   batch.atom_starts = dAtomStarts;
   batch.system_mol  = dSystemMol;
-  NVMK_DO(nvmk_ff_tables_view(tablesHandle, batch.groups, &batch.packed_mask, nullptr));
+  NVMK_DO(nvmk_ff_tables_view(tablesHandle, batch.groups, nullptr));
   NVMK_DO(nvmk_ff_energy(&batch, 1.0, 1.0, dPos, nullptr, dBefore, stream));
   NVMK_DO(nvmk_bfgs_minimize(&batch, atomStarts.data(), 1.0, 1.0, /*max_iters=*/200, /*grad_tol=*/1e-4, /*scale_grads=*/1, dPos, nullptr, dAfter,
                              dStatus, dIters, stream));

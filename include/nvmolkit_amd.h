@@ -291,14 +291,6 @@ typedef struct nvmk_ff_batch {
   const double*  etk_ref12;
   const int32_t* etk_ref13_starts;
   const double*  etk_ref13;
-  /* Bit g set: pair group g (two atom indices, at least three parameters: DG g0, ETK g5, UFF g4, MMFF g11) holds PACKED rows —
-   * idx is ONE 32-bit word per row (atom i in bits 0-12, atom j in bits 13-25, flag A in bit 26, flag B in bit 27) and par is
-   * THREE doubles per row: 28 bytes instead of 32 / 40 / 32 / 48.  The three doubles are the row's first three parameters;
-   * for MMFF g11 flag A = (dielModel == 2) and flag B = is1_4, for ETK g5 the fourth parameter (`pinned`, which the kernels
-   * never read for that group) is dropped.  This is the form nvmk_ff_tables_build / nvmk_etkdg_molset_build emit (molecules of
-   * up to 8191 atoms); 0 = every group in the plain form documented above.  Same arithmetic on the same doubles: bit-identical
-   * results either way. */
-  uint32_t       packed_mask;
 } nvmk_ff_batch;
 
 /* energies[s] / gradient (same layout as d_pos) of every system with d_active[s] != 0 (NULL = all). */
@@ -396,8 +388,6 @@ typedef struct nvmk_etkdg_molset {
   const int32_t* num_impropers;    /* DEVICE [n_mols] (planarity tolerance 0.7 * num_impropers) */
   const int32_t* h_etk_d12_counts; /* HOST [n_mols]: terms of etk[2] / etk[3] per molecule */
   const int32_t* h_etk_d13_counts;
-  uint32_t       dg_packed_mask;   /* nvmk_ff_batch.packed_mask of the dg[] / etk[] groups (0 for tables a caller lays out by hand) */
-  uint32_t       etk_packed_mask;
 } nvmk_etkdg_molset;
 
 typedef struct nvmk_etkdg_params {
@@ -437,9 +427,6 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* mols, const nvmk_etkdg_params* par
  * nvmk_*_view fills the plain structs the entry points above take (valid until nvmk_*_free, which waits for the uploads).
  *   NVMK_BUILD_KEEP_PAIR_ORDER : pair groups keep the caller's row order (measurements)
  *   NVMK_BUILD_NO_MMFF_MERGE   : no group 11
- *   NVMK_BUILD_UNPACKED_PAIRS  : pair groups in the plain (two indices, all parameters) form instead of the packed rows of
- *                                nvmk_ff_batch.packed_mask (measurements; sets with a molecule of more than 8191 atoms are
- *                                built this way by themselves)
  *   NVMK_BUILD_HOST            : the tables are written to HOST memory instead (no GPU involved; the views then hold host
  *                                pointers) — how the CPU test-suite checks the assembly row by row
  * MMFF group 11 exists only if EVERY molecule's electrostatic pairs are a subset of its van der Waals pairs and no pair is
@@ -466,7 +453,6 @@ typedef struct nvmk_flat_molecule {
 #define NVMK_BUILD_KEEP_PAIR_ORDER 1u
 #define NVMK_BUILD_NO_MMFF_MERGE 2u
 #define NVMK_BUILD_HOST 4u
-#define NVMK_BUILD_UNPACKED_PAIRS 8u
 
 int nvmk_etkdg_molset_build(const nvmk_flat_molecule* h_mols, int32_t n_mols, int n_threads, unsigned flags, void* stream,
                             void** handle);
@@ -475,12 +461,11 @@ int nvmk_etkdg_molset_free(void* handle);
 /* Per-MOLECULE term tables of one force field (kind NVMK_FF_DG / ETK / MMFF / UFF) for nvmk_ff_batch.system_mol batches:
  * h_terms[m * n_groups + g] are molecule m's rows of group g; n_groups = the kind's group count (3 / 6 / 7 / 5), for MMFF and
  * UFF optionally followed by up to four constraint groups (distance, position, angle, torsion).  The view fills
- * groups[0 .. n_groups), for MMFF groups[11], and the packed_mask to put into the nvmk_ff_batch that uses them; every `starts`
- * array has n_mols + 1 entries.  A "molecule" here is whatever
+ * groups[0 .. n_groups) and, for MMFF, groups[11]; every `starts` array has n_mols + 1 entries.  A "molecule" here is whatever
  * shares one copy of the tables: with one row per SYSTEM and no system_mol the same call assembles a plain batch. */
 int nvmk_ff_tables_build(int kind, const nvmk_host_terms* h_terms, int32_t n_mols, int n_groups, int n_threads, unsigned flags,
                          void* stream, void** handle);
-int nvmk_ff_tables_view(const void* handle, nvmk_ff_group groups[12], uint32_t* packed_mask, int32_t* n_mols);
+int nvmk_ff_tables_view(const void* handle, nvmk_ff_group groups[12], int32_t* n_mols);
 int nvmk_ff_tables_free(void* handle);
 
 /* Per-stage wall-clock table of the LAST nvmk_etkdg_embed call of the process that ran with the option NVMK_ETKDG_TIMING=1

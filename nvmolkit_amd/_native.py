@@ -84,7 +84,7 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_etkdg_molset_view": (_int, [_vp, _vp]),
     "nvmk_etkdg_molset_free": (_int, [_vp]),
     "nvmk_ff_tables_build": (_int, [_int, _vp, ctypes.c_int32, _int, _int, ctypes.c_uint, _vp, ctypes.POINTER(ctypes.c_void_p)]),
-    "nvmk_ff_tables_view": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32)]),
+    "nvmk_ff_tables_view": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
     "nvmk_ff_tables_free": (_int, [_vp]),
     "nvmk_etkdg_stage_timings": (_int, [_vp, _vp, _vp, _vp, _int, _vp]),
     "nvmk_etkdg_random_coords": (_int, [ctypes.c_uint64, ctypes.c_uint64, _int, _vp, _vp, ctypes.c_double, _vp, _vp]),
@@ -118,7 +118,7 @@ class FFBatch(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("n_systems", ctypes.c_int32), ("atom_starts", ctypes.c_void_p),
                 ("groups", FFGroup * 12), ("system_mol", ctypes.c_void_p), ("group_mask", ctypes.c_uint32),
                 ("etk_ref12_starts", ctypes.c_void_p), ("etk_ref12", ctypes.c_void_p),
-                ("etk_ref13_starts", ctypes.c_void_p), ("etk_ref13", ctypes.c_void_p), ("packed_mask", ctypes.c_uint32)]
+                ("etk_ref13_starts", ctypes.c_void_p), ("etk_ref13", ctypes.c_void_p)]
 
 
 class BfgsSecondStage(ctypes.Structure):
@@ -137,8 +137,7 @@ class EtkdgMolset(ctypes.Structure):
     _fields_ = [("n_mols", ctypes.c_int32), ("h_n_atoms", ctypes.c_void_p), ("dg", FFGroup * 3), ("etk", FFGroup * 6),
                 ("check_starts", ctypes.c_void_p), ("check_kind", ctypes.c_void_p), ("check_idx", ctypes.c_void_p),
                 ("check_par", ctypes.c_void_p), ("num_impropers", ctypes.c_void_p),
-                ("h_etk_d12_counts", ctypes.c_void_p), ("h_etk_d13_counts", ctypes.c_void_p),
-                ("dg_packed_mask", ctypes.c_uint32), ("etk_packed_mask", ctypes.c_uint32)]
+                ("h_etk_d12_counts", ctypes.c_void_p), ("h_etk_d13_counts", ctypes.c_void_p)]
 
 
 class EtkdgParams(ctypes.Structure):
@@ -164,7 +163,7 @@ class FlatMoleculeDesc(ctypes.Structure):
                 ("check_par", ctypes.c_void_p)]
 
 
-BUILD_KEEP_PAIR_ORDER, BUILD_NO_MMFF_MERGE, BUILD_HOST, BUILD_UNPACKED_PAIRS = 1, 2, 4, 8
+BUILD_KEEP_PAIR_ORDER, BUILD_NO_MMFF_MERGE, BUILD_HOST = 1, 2, 4
 
 CHECK_TETRAHEDRAL, CHECK_CHIRAL_VOLUME, CHECK_CHIRAL_DISTANCE = 0, 1, 2
 CHECK_CHIRAL_CENTER_VOLUME, CHECK_DOUBLE_BOND_STEREO, CHECK_DOUBLE_BOND_GEOMETRY = 3, 4, 5
@@ -222,15 +221,12 @@ def _as_term_array(obj, is_par: int):
 
 
 def build_flags() -> int:
-    """``NVMK_PAIR_ORDER=input`` / ``NVMK_MMFF_MERGE=0`` / ``NVMK_PAIR_PACK=0`` (A/B switches of DESIGN.md section 5) as
-    nvmk_*_build flags."""
+    """``NVMK_PAIR_ORDER=input`` / ``NVMK_MMFF_MERGE=0`` (A/B switches of DESIGN.md section 5) as nvmk_*_build flags."""
     flags = 0
     if os.environ.get("NVMK_PAIR_ORDER", "diagonal") == "input":
         flags |= BUILD_KEEP_PAIR_ORDER
     if os.environ.get("NVMK_MMFF_MERGE", "1") == "0":
         flags |= BUILD_NO_MMFF_MERGE
-    if os.environ.get("NVMK_PAIR_PACK", "1") == "0":
-        flags |= BUILD_UNPACKED_PAIRS
     return flags
 
 

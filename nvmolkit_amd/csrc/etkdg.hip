@@ -579,14 +579,12 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     dg.n_systems   = nSys;
     dg.atom_starts = dAtomStarts.p;
     dg.system_mol  = dSysMol.p;
-    dg.packed_mask = ms->dg_packed_mask;
     for (int g = 0; g < 3; ++g) dg.groups[g] = ms->dg[g];
     nvmk_ff_batch etk{};
     etk.kind = NVMK_FF_ETK;
     etk.n_systems   = nSys;
     etk.atom_starts = dAtomStarts.p;
     etk.system_mol  = dSysMol.p;
-    etk.packed_mask = ms->etk_packed_mask;
     for (int g = 0; g < 6; ++g) etk.groups[g] = ms->etk[g];
 
     int               stage = 0;

@@ -49,7 +49,6 @@ struct Batch {
   Group          g[12];
   const int32_t* sysMol;      // optional: term tables are per MOLECULE and system s uses row sysMol[s] of every `starts`
   unsigned       groupMask;   // bit g set = evaluate term group g
-  unsigned       packedMask;  // bit g set = pair group g holds packed rows (nvmk_ff_batch.packed_mask)
   // ETK only, optional: per-system reference distances for the 1-2 / 1-3 restraints (the reference re-centres
   // those bounds on the current geometry before the ETK minimisation, etkdg_stage_etk_minimization.cu:32-64)
   const int32_t* refStarts[2];
@@ -152,10 +151,6 @@ int to_batch(const nvmk_ff_batch* in, Batch& out) {
   out.atomStarts   = in->atom_starts;
   out.sysMol       = in->system_mol;
   out.groupMask    = in->group_mask ? in->group_mask : 0xfffu;
-  static const unsigned packable[5] = {0x1u, 0x20u, 0x800u, 0u, 0x10u};  // DG g0, ETK g5, MMFF g11, -, UFF g4
-  NVMK_REQUIRE((in->packed_mask & ~packable[in->kind]) == 0u, "ff: packed_mask 0x%x names a group of kind %d that has no packed form",
-               in->packed_mask, in->kind);
-  out.packedMask = in->packed_mask;
   out.refStarts[0] = in->etk_ref12_starts;
   out.refStarts[1] = in->etk_ref13_starts;
   out.ref[0]       = in->etk_ref12;

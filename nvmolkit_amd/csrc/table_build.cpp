@@ -33,15 +33,13 @@ inline size_t    align_bytes(const size_t x) { return (x + kAlign - 1) / kAlign 
 
 struct GroupShape {
   int  nIdx, nPar;
-  bool pairOrder;         // an O(N^2) pair table: rows go along the diagonals of the pair matrix
-  bool packable = false;  // ... whose rows the kernels also read in the packed form (nvmk_ff_batch.packed_mask)
+  bool pairOrder;
 };
-// (n_idx, n_par) of every term group per kind (include/nvmolkit_amd.h).  The separate MMFF van der Waals / electrostatic
-// tables stay plain: the kernels walk the merged group 11 instead whenever it exists.
-const GroupShape kDg[3]   = {{2, 3, true, true}, {4, 2, false}, {1, 0, false}};
-const GroupShape kEtk[6]  = {{4, 12, false}, {4, 4, false}, {2, 4, false}, {2, 4, false}, {3, 2, false}, {2, 4, true, true}};
+// (n_idx, n_par) of every term group per kind (include/nvmolkit_amd.h); pairOrder marks the O(N^2) tables
+const GroupShape kDg[3]   = {{2, 3, true}, {4, 2, false}, {1, 0, false}};
+const GroupShape kEtk[6]  = {{4, 12, false}, {4, 4, false}, {2, 4, false}, {2, 4, false}, {3, 2, false}, {2, 4, true}};
 const GroupShape kMmff[7] = {{2, 2, false}, {3, 3, false}, {3, 5, false}, {4, 1, false}, {4, 3, false}, {2, 2, true}, {2, 3, true}};
-const GroupShape kUff[5]  = {{2, 2, false}, {3, 6, false}, {4, 3, false}, {4, 4, false}, {2, 3, true, true}};
+const GroupShape kUff[5]  = {{2, 2, false}, {3, 6, false}, {4, 3, false}, {4, 4, false}, {2, 3, true}};
 // optional constraint groups behind the MMFF / UFF groups: distance, position, angle, torsion
 const GroupShape kConstraint[4] = {{2, 3, false}, {1, 5, false}, {3, 3, false}, {4, 3, false}};
 
@@ -122,11 +120,10 @@ struct Group {
   const char* src2      = nullptr;
   size_t      srcStride = 0;  // bytes between the descriptors of consecutive molecules
   bool        checkIdx  = true;
-  bool        packed    = false;  // pair rows as ONE index word (i | j << 13 | flags << 26) + THREE doubles: 28 bytes
   std::vector<int32_t> starts;                                        // [n_mols + 1]
   size_t               startsOff = 0, idxOff = 0, parOff = 0;         // byte offsets in the destination block
-  size_t               idx_row() const { return packed ? 4 : static_cast<size_t>(nIdx) * 4; }
-  size_t               par_row() const { return packed ? 24 : static_cast<size_t>(nPar) * 8; }
+  size_t               idx_row() const { return static_cast<size_t>(nIdx) * 4; }
+  size_t               par_row() const { return static_cast<size_t>(nPar) * 8; }
   const nvmk_host_terms& terms(const int m) const { return *reinterpret_cast<const nvmk_host_terms*>(src + static_cast<size_t>(m) * srcStride); }
   const nvmk_host_terms& terms2(const int m) const { return *reinterpret_cast<const nvmk_host_terms*>(src2 + static_cast<size_t>(m) * srcStride); }
 };
@@ -140,17 +137,15 @@ struct PairRow {
   int32_t  row, ele;
 };
 struct Scratch {
-  std::vector<PairRow> pairs;
+  std::vector<uint64_t> keys;  // (sort key << 24) | source row
+  std::vector<PairRow>  pairs;
 };
 constexpr int kMaxPairRows = 1 << 24;
 
-constexpr int64_t kPackedAtomLimit = 1 << 13;
-
-// Rows of molecule m of group g, written to dstIdx / dstPar in their final order and form.  Returns false on an atom index
-// outside [0, nAtoms) (nAtoms < 0: not checked).  A packed group that meets an atom index of 8192 or more sets packOverflow:
-// the caller then builds the set again with unpacked pair rows.
+// Rows of molecule m of group g, written to dstIdx / dstPar in their final order.  Returns false on an atom index outside
+// [0, nAtoms) (nAtoms < 0: not checked).
 bool fill_rows(const Group& g, const int m, const int nAtoms, const unsigned flags, int32_t* dstIdx, double* dstPar, Scratch& sc,
-               std::atomic<int>& mergeImpossible, std::atomic<int>& packOverflow) {
+               std::atomic<int>& mergeImpossible) {
   const nvmk_host_terms& t = g.terms(m);
   const int              n = t.n_terms;
   if (n <= 0) return true;
@@ -161,7 +156,7 @@ bool fill_rows(const Group& g, const int m, const int nAtoms, const unsigned fla
     if (checked && (v < 0 || v >= nAtoms)) ok = false;
     return static_cast<int32_t>(v);
   };
-  if (g.fill == kPlain && !g.packed) {
+  if (g.fill == kPlain || (g.fill == kPairOrdered && keepOrder)) {
     const size_t cells = static_cast<size_t>(n) * g.nIdx;
     if (t.idx_bytes == 4 && !checked) {
       std::memcpy(dstIdx, t.idx, cells * 4);
@@ -171,79 +166,72 @@ bool fill_rows(const Group& g, const int m, const int nAtoms, const unsigned fla
     if (g.nPar > 0) std::memcpy(dstPar, t.par, static_cast<size_t>(n) * g.par_row());
     return ok;
   }
-  // ---- pair groups: the order of the rows first, then one emit loop for both forms
   if (n >= kMaxPairRows) return false;
+  if (g.fill == kPairOrdered) {  // by (|j - i|, min(i, j)), rows with equal keys in the caller's order
+    sc.keys.resize(static_cast<size_t>(n));
+    for (int r = 0; r < n; ++r) {
+      const int64_t  a = take(read_idx(t, 2 * static_cast<size_t>(r))), b = take(read_idx(t, 2 * static_cast<size_t>(r) + 1));
+      const uint64_t lo = static_cast<uint64_t>(std::min(a, b)) & 0xfffff, d = static_cast<uint64_t>(std::max(a, b) - std::min(a, b)) & 0xfffff;
+      sc.keys[static_cast<size_t>(r)] = (((d << 20) | lo) << 24) | static_cast<uint64_t>(r);
+    }
+    std::sort(sc.keys.begin(), sc.keys.end());
+    for (int r = 0; r < n; ++r) {
+      const size_t s    = static_cast<size_t>(sc.keys[static_cast<size_t>(r)] & 0xffffff);
+      dstIdx[2 * r]     = static_cast<int32_t>(read_idx(t, 2 * s));
+      dstIdx[2 * r + 1] = static_cast<int32_t>(read_idx(t, 2 * s + 1));
+      if (g.nPar > 0) std::memcpy(dstPar + static_cast<size_t>(r) * g.nPar, t.par + s * g.nPar, g.par_row());
+    }
+    return ok;
+  }
+  // kMergedNonbonded: one row per van der Waals pair — (R*, eps) of that row, (chargeTerm, dielModel, is1_4) of the electrostatic
+  // row of the same pair or zeros.  Impossible (no group 11 for the whole set) when a pair is listed twice or an electrostatic
+  // pair has no van der Waals row.
+  const nvmk_host_terms& e = g.terms2(m);
+  if (e.n_terms >= kMaxPairRows) return false;
   sc.pairs.resize(static_cast<size_t>(n));
   for (int r = 0; r < n; ++r) {
     const int64_t a = take(read_idx(t, 2 * static_cast<size_t>(r))), b = take(read_idx(t, 2 * static_cast<size_t>(r) + 1));
     sc.pairs[static_cast<size_t>(r)] = {static_cast<uint32_t>(std::min(a, b)), static_cast<uint32_t>(std::max(a, b)), r, -1};
   }
-  const nvmk_host_terms* e = nullptr;
-  if (g.fill == kMergedNonbonded) {
-    // one row per van der Waals pair — (R*, eps) of that row, (chargeTerm, dielModel, is1_4) of the electrostatic row of the same
-    // pair or zeros.  Impossible (no group 11 for the whole set) when a pair is listed twice or an electrostatic pair has no
-    // van der Waals row.
-    e = &g.terms2(m);
-    if (e->n_terms >= kMaxPairRows) return false;
-    const auto byPair = [](const PairRow& x, const PairRow& y) { return x.lo != y.lo ? x.lo < y.lo : x.hi < y.hi; };
-    std::sort(sc.pairs.begin(), sc.pairs.end(), byPair);
-    for (int r = 1; r < n; ++r) {
-      if (sc.pairs[static_cast<size_t>(r)].lo == sc.pairs[static_cast<size_t>(r) - 1].lo &&
-          sc.pairs[static_cast<size_t>(r)].hi == sc.pairs[static_cast<size_t>(r) - 1].hi) {
-        mergeImpossible.store(1);
-        return ok;
-      }
-    }
-    for (int r = 0; r < e->n_terms; ++r) {
-      const int64_t a = read_idx(*e, 2 * static_cast<size_t>(r)), b = read_idx(*e, 2 * static_cast<size_t>(r) + 1);
-      const PairRow key{static_cast<uint32_t>(std::min(a, b)), static_cast<uint32_t>(std::max(a, b)), 0, 0};
-      const auto    it = std::lower_bound(sc.pairs.begin(), sc.pairs.end(), key, byPair);
-      if (it == sc.pairs.end() || it->lo != key.lo || it->hi != key.hi || it->ele >= 0) {
-        mergeImpossible.store(1);
-        return ok;
-      }
-      it->ele = r;
+  const auto byPair = [](const PairRow& x, const PairRow& y) { return x.lo != y.lo ? x.lo < y.lo : x.hi < y.hi; };
+  std::sort(sc.pairs.begin(), sc.pairs.end(), byPair);
+  for (int r = 1; r < n; ++r) {
+    if (sc.pairs[static_cast<size_t>(r)].lo == sc.pairs[static_cast<size_t>(r) - 1].lo &&
+        sc.pairs[static_cast<size_t>(r)].hi == sc.pairs[static_cast<size_t>(r) - 1].hi) {
+      mergeImpossible.store(1);
+      return ok;
     }
   }
-  if (!keepOrder) {  // along the diagonals: by (|j - i|, min(i, j)), rows with equal keys in the caller's order
+  for (int r = 0; r < e.n_terms; ++r) {
+    const int64_t a = read_idx(e, 2 * static_cast<size_t>(r)), b = read_idx(e, 2 * static_cast<size_t>(r) + 1);
+    const PairRow key{static_cast<uint32_t>(std::min(a, b)), static_cast<uint32_t>(std::max(a, b)), 0, 0};
+    const auto    it = std::lower_bound(sc.pairs.begin(), sc.pairs.end(), key, byPair);
+    if (it == sc.pairs.end() || it->lo != key.lo || it->hi != key.hi || it->ele >= 0) {
+      mergeImpossible.store(1);
+      return ok;
+    }
+    it->ele = r;
+  }
+  if (!keepOrder) {  // along the diagonals; the pairs are unique, so the keys alone decide
     std::sort(sc.pairs.begin(), sc.pairs.end(), [](const PairRow& x, const PairRow& y) {
       const uint32_t dx = x.hi - x.lo, dy = y.hi - y.lo;
-      return dx != dy ? dx < dy : (x.lo != y.lo ? x.lo < y.lo : x.row < y.row);
+      return dx != dy ? dx < dy : x.lo < y.lo;
     });
   }
-  const int outPar = g.packed ? 3 : g.nPar;
   for (int r = 0; r < n; ++r) {
     const PairRow& p  = sc.pairs[static_cast<size_t>(r)];
     const size_t   s  = static_cast<size_t>(p.row);
-    const int64_t  a0 = read_idx(t, 2 * s), a1 = read_idx(t, 2 * s + 1);  // the caller's orientation of the pair
-    double         row[5];
-    if (g.fill == kMergedNonbonded) {
-      row[0] = t.par[2 * s];
-      row[1] = t.par[2 * s + 1];
-      if (p.ele >= 0) {
-        const double* ep = e->par + static_cast<size_t>(p.ele) * 3;
-        row[2] = ep[0], row[3] = ep[1], row[4] = ep[2];
-      } else {
-        row[2] = row[3] = row[4] = 0.0;
-      }
+    dstIdx[2 * r]     = static_cast<int32_t>(read_idx(t, 2 * s));
+    dstIdx[2 * r + 1] = static_cast<int32_t>(read_idx(t, 2 * s + 1));
+    double* q         = dstPar + static_cast<size_t>(r) * 5;
+    q[0]              = t.par[2 * s];
+    q[1]              = t.par[2 * s + 1];
+    if (p.ele >= 0) {
+      const double* ep = e.par + static_cast<size_t>(p.ele) * 3;
+      q[2] = ep[0], q[3] = ep[1], q[4] = ep[2];
     } else {
-      for (int q = 0; q < g.nPar; ++q) row[q] = t.par[s * g.nPar + q];
+      q[2] = q[3] = q[4] = 0.0;
     }
-    if (g.packed) {
-      if (a0 < 0 || a1 < 0 || a0 >= kPackedAtomLimit || a1 >= kPackedAtomLimit) {
-        packOverflow.store(1);
-        return ok;
-      }
-      // flag 0 / flag 1 stand for the 4th / 5th parameter of the merged MMFF rows (dielModel == 2: distance dependent; is1_4);
-      // the 4th parameter of the other kinds' pair rows is not read by the kernels (ETK long-range rows: their `pinned`)
-      uint32_t w = static_cast<uint32_t>(a0) | (static_cast<uint32_t>(a1) << 13);
-      if (g.fill == kMergedNonbonded) w |= (static_cast<int>(row[3]) == 2 ? 1u << 26 : 0u) | (row[4] != 0.0 ? 1u << 27 : 0u);
-      dstIdx[r] = static_cast<int32_t>(w);
-    } else {
-      dstIdx[2 * r]     = static_cast<int32_t>(a0);
-      dstIdx[2 * r + 1] = static_cast<int32_t>(a1);
-    }
-    for (int q = 0; q < outPar; ++q) dstPar[static_cast<size_t>(r) * outPar + q] = row[q];
   }
   return ok;
 }
@@ -265,7 +253,7 @@ struct Build {
   int                  device     = -1;
   hipStream_t          stream     = nullptr;
   hipEvent_t           done       = nullptr;  // after the last upload
-  std::atomic<int>     mergeImpossible{0}, packOverflow{0};
+  std::atomic<int>     mergeImpossible{0};
   int                  mergedGroup = -1;
 
   int n_atoms_of(const int m) const {
@@ -425,7 +413,7 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
           dIdx = reinterpret_cast<int32_t*>(slot + cs.slotOff[2 * gi] + r0 * g.idx_row());
           dPar = reinterpret_cast<double*>(slot + cs.slotOff[2 * gi + 1] + r0 * g.par_row());
         }
-        if (!fill_rows(g, m, atoms, b.flags, dIdx, dPar, sc, b.mergeImpossible, b.packOverflow)) {
+        if (!fill_rows(g, m, atoms, b.flags, dIdx, dPar, sc, b.mergeImpossible)) {
           int expected = -1;
           if (badMol.compare_exchange_strong(expected, m)) badGroup.store(static_cast<int>(gi));
         }
@@ -492,8 +480,6 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
   return NVMK_OK;
 }
 
-uint32_t packed_bit(const Group& g, const int slot) { return g.packed ? 1u << slot : 0u; }
-
 void view_group(const Build& b, const Group& g, nvmk_ff_group* out) {
   out->starts = reinterpret_cast<const int32_t*>(b.block + g.startsOff);
   out->idx    = g.starts.back() > 0 ? reinterpret_cast<const int32_t*>(b.block + g.idxOff) : nullptr;
@@ -506,7 +492,6 @@ void add_groups(Build& b, const GroupShape* shapes, const int n, const char* src
     x.nIdx      = shapes[g].nIdx;
     x.nPar      = shapes[g].nPar;
     x.fill      = shapes[g].pairOrder ? kPairOrdered : kPlain;
-    x.packed    = shapes[g].packable && (b.flags & NVMK_BUILD_UNPACKED_PAIRS) == 0;
     x.src       = src + static_cast<size_t>(g) * sizeof(nvmk_host_terms);
     x.srcStride = stride;
     b.groups.push_back(std::move(x));
@@ -594,10 +579,6 @@ int nvmk_etkdg_molset_build(const nvmk_flat_molecule* h_mols, int32_t n_mols, in
   b.nAtoms       = h->nAtoms.data();
   b.nAtomsStride = sizeof(int32_t);
   if (const int rc = run(b, n_threads, "nvmk_etkdg_molset_build")) return rc;
-  if (b.packOverflow.load() != 0) {  // a molecule of more than 8191 atoms: the whole set again with plain pair rows
-    h.reset();
-    return nvmk_etkdg_molset_build(h_mols, n_mols, n_threads, flags | NVMK_BUILD_UNPACKED_PAIRS, stream, handle);
-  }
   *handle = h.release();
   return NVMK_OK;
 }
@@ -610,15 +591,9 @@ int nvmk_etkdg_molset_view(const void* handle, nvmk_etkdg_molset* out) {
   out->n_mols    = b.nMols;
   out->h_n_atoms = h->nAtoms.data();
   size_t gi = 0;
-  for (int g = 0; g < 3; ++g) {
-    out->dg_packed_mask |= packed_bit(b.groups[gi], g);
-    view_group(b, b.groups[gi++], &out->dg[g]);
-  }
+  for (int g = 0; g < 3; ++g) view_group(b, b.groups[gi++], &out->dg[g]);
   if (h->hasEtk) {
-    for (int g = 0; g < 6; ++g) {
-      out->etk_packed_mask |= packed_bit(b.groups[gi], g);
-      view_group(b, b.groups[gi++], &out->etk[g]);
-    }
+    for (int g = 0; g < 6; ++g) view_group(b, b.groups[gi++], &out->etk[g]);
     out->h_etk_d12_counts = h->d12.data();
     out->h_etk_d13_counts = h->d13.data();
   }
@@ -680,7 +655,6 @@ int nvmk_ff_tables_build(int kind, const nvmk_host_terms* h_terms, int32_t n_mol
     x.nIdx      = 2;
     x.nPar      = 5;
     x.fill      = kMergedNonbonded;
-    x.packed    = (flags & NVMK_BUILD_UNPACKED_PAIRS) == 0;
     x.src       = reinterpret_cast<const char*>(h_terms + 5);
     x.src2      = reinterpret_cast<const char*>(h_terms + 6);
     x.srcStride = stride;
@@ -688,29 +662,17 @@ int nvmk_ff_tables_build(int kind, const nvmk_host_terms* h_terms, int32_t n_mol
     b.groups.push_back(std::move(x));
   }
   if (const int rc = run(b, n_threads, "nvmk_ff_tables_build")) return rc;
-  if (b.packOverflow.load() != 0) {
-    h.reset();
-    return nvmk_ff_tables_build(kind, h_terms, n_mols, n_groups, n_threads, flags | NVMK_BUILD_UNPACKED_PAIRS, stream, handle);
-  }
   *handle = h.release();
   return NVMK_OK;
 }
 
-int nvmk_ff_tables_view(const void* handle, nvmk_ff_group groups[12], uint32_t* packed_mask, int32_t* n_mols) {
+int nvmk_ff_tables_view(const void* handle, nvmk_ff_group groups[12], int32_t* n_mols) {
   const TablesHandle* h = static_cast<const TablesHandle*>(handle);
-  NVMK_REQUIRE(h != nullptr && h->magic == 0x5441424c && groups != nullptr && packed_mask != nullptr,
-               "nvmk_ff_tables_view: not a term-table handle, or NULL output");
+  NVMK_REQUIRE(h != nullptr && h->magic == 0x5441424c && groups != nullptr, "nvmk_ff_tables_view: not a term-table handle");
   std::memset(groups, 0, sizeof(nvmk_ff_group) * 12);
   const Build& b = h->build;
-  *packed_mask   = 0;
-  for (int g = 0; g < h->nGroups; ++g) {
-    view_group(b, b.groups[static_cast<size_t>(g)], &groups[g]);
-    *packed_mask |= packed_bit(b.groups[static_cast<size_t>(g)], g);
-  }
-  if (b.mergedGroup >= 0 && b.mergeImpossible.load() == 0) {
-    view_group(b, b.groups[static_cast<size_t>(b.mergedGroup)], &groups[11]);
-    *packed_mask |= packed_bit(b.groups[static_cast<size_t>(b.mergedGroup)], 11);
-  }
+  for (int g = 0; g < h->nGroups; ++g) view_group(b, b.groups[static_cast<size_t>(g)], &groups[g]);
+  if (b.mergedGroup >= 0 && b.mergeImpossible.load() == 0) view_group(b, b.groups[static_cast<size_t>(b.mergedGroup)], &groups[11]);
   if (n_mols != nullptr) *n_mols = b.nMols;
   return NVMK_OK;
 }

@@ -99,7 +99,6 @@ class FlatForcefieldBatch:
         self._keep.append(tables)
         for g in range(12):
             self._c.groups[g] = tables.view[g]
-        self._c.packed_mask = tables.packed_mask
 
     @property
     def n_atoms_total(self) -> int:
@@ -249,9 +248,7 @@ class MoleculeTermTables:
         self._handle = handle
         self._finalizer = weakref.finalize(self, _native.lib().nvmk_ff_tables_free, handle)
         self.view = (_native.FFGroup * 12)()
-        packed = ctypes.c_uint32(0)
-        _native.check(_native.lib().nvmk_ff_tables_view(handle, ctypes.addressof(self.view), ctypes.byref(packed), None), "nvmk_ff_tables_view")
-        self.packed_mask = int(packed.value)  # which pair groups hold packed rows (nvmk_ff_batch.packed_mask)
+        _native.check(_native.lib().nvmk_ff_tables_view(handle, ctypes.addressof(self.view), None), "nvmk_ff_tables_view")
 
 
 class PendingTermTables:

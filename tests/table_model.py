@@ -127,39 +127,14 @@ def _read(ptr, nbytes: int, on_device: bool) -> bytes:
     return buf.raw
 
 
-def read_group(group, n_rows: int, n_idx: int, n_par: int, on_device: bool, packed: bool = False, merged: bool = False):
-    """One nvmk_ff_group (``_native.FFGroup``) -> (starts, idx, par) numpy arrays; None when the group is absent.  A PACKED pair
-    group (one index word + three doubles per row, nvmk_ff_batch.packed_mask) comes back in the plain form: idx (n, 2), par
-    (n, 3), and for the merged MMFF group par (n, 5) with the two flags as the values the kernels rebuild (dielModel 2.0 / 1.0,
-    is1_4 1.0 / 0.0)."""
+def read_group(group, n_rows: int, n_idx: int, n_par: int, on_device: bool):
+    """One nvmk_ff_group (``_native.FFGroup``) -> (starts, idx, par) numpy arrays; None when the group is absent."""
     if not group.starts:
         return None
     starts = np.frombuffer(_read(group.starts, 4 * (n_rows + 1), on_device), dtype=np.int32)
     n = int(starts[-1])
-    if not packed:
-        idx = np.frombuffer(_read(group.idx, 4 * n * n_idx, on_device), dtype=np.int32).reshape(n, n_idx)
-        par = np.frombuffer(_read(group.par, 8 * n * n_par, on_device), dtype=np.float64).reshape(n, n_par)
-        return starts, idx, par
-    w = np.frombuffer(_read(group.idx, 4 * n, on_device), dtype=np.uint32)
-    idx = np.stack([w & 0x1FFF, (w >> 13) & 0x1FFF], 1).astype(np.int32)
-    par = np.frombuffer(_read(group.par, 24 * n, on_device), dtype=np.float64).reshape(n, 3)
-    if merged:
-        par = np.concatenate([par, np.where((w >> 26) & 1, 2.0, 1.0)[:, None], ((w >> 27) & 1).astype(np.float64)[:, None]], 1)
-    else:
-        assert not (w >> 26).any(), "flag bits set in a packed group that has no flags"
-    return starts, idx, par
-
-
-def as_kernels_see_it(kind: int, g: int, group, merged: bool = False):
-    """The restatement's plain rows in the form a PACKED group is read back in: three parameters (the ETK long-range rows lose
-    their unused `pinned`), the merged MMFF rows with canonical flag values."""
-    if group is None:
-        return None
-    starts, idx, par = group
-    if merged:
-        par = np.concatenate([par[:, :3], np.where(par[:, 3].astype(np.int64) == 2, 2.0, 1.0)[:, None], (par[:, 4] != 0.0).astype(np.float64)[:, None]], 1)
-    else:
-        par = par[:, :3]
+    idx = np.frombuffer(_read(group.idx, 4 * n * n_idx, on_device), dtype=np.int32).reshape(n, n_idx)
+    par = np.frombuffer(_read(group.par, 8 * n * n_par, on_device), dtype=np.float64).reshape(n, n_par)
     return starts, idx, par
 
 
@@ -169,11 +144,11 @@ def read_tables(tables):
     layout = list(GROUP_LAYOUT[tables.kind]) + list(CONSTRAINT_LAYOUT)
     groups = []
     for g in range(11):
-        t = read_group(tables.view[g], tables.n_mols, *layout[g], on_device, bool(tables.packed_mask >> g & 1)) if g < len(layout) else None
+        t = read_group(tables.view[g], tables.n_mols, *layout[g], on_device) if g < len(layout) else None
         if t is None:
             break
         groups.append(t)
-    return groups, read_group(tables.view[11], tables.n_mols, 2, 5, on_device, bool(tables.packed_mask >> 11 & 1), merged=True)
+    return groups, read_group(tables.view[11], tables.n_mols, 2, 5, on_device)
 
 
 def read_molset(molset):
@@ -182,9 +157,8 @@ def read_molset(molset):
     on_device = molset.device.type == "cuda"
     out = {"n_atoms": np.frombuffer(ctypes.string_at(c.h_n_atoms, 4 * n), dtype=np.int32) if n else np.zeros(0, np.int32),
            "num_impropers": np.frombuffer(_read(c.num_impropers, 4 * n, on_device), dtype=np.int32)}
-    out["dg"] = [read_group(c.dg[g], n, *GROUP_LAYOUT[DG][g], on_device, bool(c.dg_packed_mask >> g & 1)) for g in range(3)]
-    out["etk"] = ([read_group(c.etk[g], n, *GROUP_LAYOUT[ETK][g], on_device, bool(c.etk_packed_mask >> g & 1)) for g in range(6)]
-                  if c.h_etk_d12_counts else None)
+    out["dg"] = [read_group(c.dg[g], n, *GROUP_LAYOUT[DG][g], on_device) for g in range(3)]
+    out["etk"] = [read_group(c.etk[g], n, *GROUP_LAYOUT[ETK][g], on_device) for g in range(6)] if c.h_etk_d12_counts else None
     if c.check_starts:
         starts = np.frombuffer(_read(c.check_starts, 4 * (n + 1), on_device), dtype=np.int32)
         k = int(starts[-1])
@@ -199,10 +173,7 @@ def read_molset(molset):
     return out
 
 
-def assert_groups_equal(got, want, what="", packed=False, kind=None, g=None, merged=False):
-    """``packed``: ``got`` was read from a packed group; ``want`` (plain rows of the restatement) is compared in that form."""
-    if packed:
-        want = as_kernels_see_it(kind, g, want, merged)
+def assert_groups_equal(got, want, what=""):
     assert (got is None) == (want is None), f"{what}: present / absent mismatch"
     if got is None:
         return

@@ -24,15 +24,14 @@ def library():
     return synthetic.druglike_library(40, seed=11, mean_atoms=30, processes=1)
 
 
-def _check_molset(got, want, packed=True):
-    """``packed``: the pair groups (DG g0, ETK g5) were built as packed rows (the default)."""
+def _check_molset(got, want):
     assert np.array_equal(got["n_atoms"], want["n_atoms"]) and np.array_equal(got["num_impropers"], want["num_impropers"])
     for g in range(3):
-        tm.assert_groups_equal(got["dg"][g], want["dg"][g], f"dg group {g}", packed=packed and g == 0)
+        tm.assert_groups_equal(got["dg"][g], want["dg"][g], f"dg group {g}")
     assert (got["etk"] is None) == (want["etk"] is None)
     if want["etk"] is not None:
         for g in range(6):
-            tm.assert_groups_equal(got["etk"][g], want["etk"][g], f"etk group {g}", packed=packed and g == 5)
+            tm.assert_groups_equal(got["etk"][g], want["etk"][g], f"etk group {g}")
         assert np.array_equal(got["d12"], np.diff(want["etk"][2][0])) and np.array_equal(got["d13"], np.diff(want["etk"][3][0]))
     assert (got["checks"] is None) == (want["checks"] is None)
     if want["checks"] is not None:
@@ -104,21 +103,18 @@ def test_term_tables_equal_the_restatement(kind, library):
         tables = [synthetic.random_ff_system(UFF, int(n), rng)[1] for n in rng.integers(5, 40, 12)]
     else:
         tables = [m["embed"]["dg" if kind == DG else "etk"] for m in library]
-    built = MoleculeTermTables(kind, tables, device="cpu")
-    packed_group = {DG: 0, ETK: 5, MMFF: 11, UFF: 4}[kind]      # the pair group with three or more parameters is packed
-    assert built.packed_mask == 1 << packed_group
-    got, got_merged = tm.read_tables(built)
+    got, got_merged = tm.read_tables(MoleculeTermTables(kind, tables, device="cpu"))
     want, want_merged = tm.expected_term_tables(kind, tables)
     assert len(got) == len(want)
     for g, (a, b) in enumerate(zip(got, want)):
-        tm.assert_groups_equal(a, b, f"kind {kind} group {g}", packed=g == packed_group)
-    tm.assert_groups_equal(got_merged, want_merged, "merged non-bonded group", packed=True, merged=True)
+        tm.assert_groups_equal(a, b, f"kind {kind} group {g}")
+    tm.assert_groups_equal(got_merged, want_merged, "merged non-bonded group")
     assert (want_merged is not None) == (kind == MMFF)
     # the stacked form (a batch without system_mol) goes through the same builder
     got2, merged2 = tm.read_tables(MoleculeTermTables.from_stacked(kind, stack_molecule_tables(kind, tables), device="cpu"))
     for g, (a, b) in enumerate(zip(got2, want)):
-        tm.assert_groups_equal(a, b, f"stacked kind {kind} group {g}", packed=g == packed_group)
-    tm.assert_groups_equal(merged2, want_merged, "stacked merged group", packed=True, merged=True)
+        tm.assert_groups_equal(a, b, f"stacked kind {kind} group {g}")
+    tm.assert_groups_equal(merged2, want_merged, "stacked merged group")
 
 
 def test_switches_keep_the_callers_order_and_the_separate_tables(library, monkeypatch):
@@ -128,38 +124,9 @@ def test_switches_keep_the_callers_order_and_the_separate_tables(library, monkey
     want, want_merged = tm.expected_term_tables(MMFF, tables, pair_order=False)
     for g, (a, b) in enumerate(zip(got, want)):
         tm.assert_groups_equal(a, b, f"group {g}")
-    tm.assert_groups_equal(merged, want_merged, "merged group in (min, max) order", packed=True, merged=True)
+    tm.assert_groups_equal(merged, want_merged, "merged group in (min, max) order")
     monkeypatch.setenv("NVMK_MMFF_MERGE", "0")
     assert tm.read_tables(MoleculeTermTables(MMFF, tables, device="cpu"))[1] is None
-    # plain pair rows on request: every group exactly as the restatement lays it out
-    monkeypatch.delenv("NVMK_PAIR_ORDER")
-    monkeypatch.delenv("NVMK_MMFF_MERGE")
-    monkeypatch.setenv("NVMK_PAIR_PACK", "0")
-    plain = MoleculeTermTables(MMFF, tables, device="cpu")
-    assert plain.packed_mask == 0
-    got, merged = tm.read_tables(plain)
-    want, want_merged = tm.expected_term_tables(MMFF, tables)
-    for g, (a, b) in enumerate(zip(got, want)):
-        tm.assert_groups_equal(a, b, f"group {g}")
-    tm.assert_groups_equal(merged, want_merged, "merged group, plain rows")
-    mols = [FlatMolecule(**m["embed"]) for m in library[:10]]
-    molset = FlatMoleculeSet(mols, device="cpu")
-    assert molset.c.dg_packed_mask == 0 and molset.c.etk_packed_mask == 0
-    _check_molset(tm.read_molset(molset), tm.expected_molset(mols), packed=False)
-
-
-def test_a_molecule_too_large_for_packed_rows_gets_plain_ones():
-    """Packed rows hold 13-bit atom indices; a set with an atom index of 8192 or more is built with plain pair rows by itself."""
-    idx = np.array([[0, 8191], [1, 2]])
-    par = np.arange(6, dtype=np.float64).reshape(2, 3)
-    other = [(np.zeros((0, 4), int), np.zeros((0, 2))), (np.arange(3).reshape(-1, 1), np.zeros((3, 0)))]
-    small = MoleculeTermTables(DG, [[(idx, par)] + other], device="cpu")
-    assert small.packed_mask == 1
-    tm.assert_groups_equal(tm.read_tables(small)[0][0], tm.expected_term_tables(DG, [[(idx, par)] + other])[0][0], packed=True)
-    big_idx = np.array([[0, 8192], [1, 2]])
-    big = MoleculeTermTables(DG, [[(big_idx, par)] + other], device="cpu")
-    assert big.packed_mask == 0
-    tm.assert_groups_equal(tm.read_tables(big)[0][0], tm.expected_term_tables(DG, [[(big_idx, par)] + other])[0][0])
 
 
 def test_merged_group_only_when_every_molecule_allows_it(library):
@@ -181,7 +148,7 @@ def test_merged_group_only_when_every_molecule_allows_it(library):
         want, want_merged = tm.expected_term_tables(MMFF, tables)
         assert merged is None and want_merged is None, case
         for g, (a, b) in enumerate(zip(groups, want)):
-            tm.assert_groups_equal(a, b, f"{case}: group {g}")       # the separate tables are complete all the same (plain rows)
+            tm.assert_groups_equal(a, b, f"{case}: group {g}")       # the separate tables are complete all the same
 
 
 def test_constraint_groups_travel_behind_the_force_field_groups(library):
@@ -198,7 +165,7 @@ def test_constraint_groups_travel_behind_the_force_field_groups(library):
     assert len(got) == 9
     for g, (a, b) in enumerate(zip(got, want)):
         tm.assert_groups_equal(a, b, f"group {g}")
-    tm.assert_groups_equal(merged, want_merged, packed=True, merged=True)
+    tm.assert_groups_equal(merged, want_merged)
     with pytest.raises(ValueError, match="needs 3 term groups"):
         MoleculeTermTables.from_stacked(DG, stack_molecule_tables(DG, [m["embed"]["dg"] for m in library[:2]]) + [stacked[7]], device="cpu")
     with pytest.raises(ValueError, match="inconsistent"):
@@ -221,14 +188,6 @@ def test_builder_through_the_c_abi_alone():
     _native.check(lib.nvmk_etkdg_molset_build(ctypes.addressof(mol), 1, 0, _native.BUILD_HOST, None, ctypes.byref(handle)))
     view = _native.EtkdgMolset()
     _native.check(lib.nvmk_etkdg_molset_view(handle, ctypes.byref(view)))
-    assert view.dg_packed_mask == 1 and view.etk_packed_mask == 0
-    words = np.frombuffer(ctypes.string_at(view.dg[0].idx, 12), dtype=np.uint32)
-    assert words.tolist() == [0 | 1 << 13, 1 | 2 << 13, 0 | 2 << 13]          # (0, 1), (1, 2), (0, 2): one word per row
-    _native.check(lib.nvmk_etkdg_molset_free(handle))
-    _native.check(lib.nvmk_etkdg_molset_build(ctypes.addressof(mol), 1, 0, _native.BUILD_HOST | _native.BUILD_UNPACKED_PAIRS, None,
-                                              ctypes.byref(handle)))
-    _native.check(lib.nvmk_etkdg_molset_view(handle, ctypes.byref(view)))
-    assert view.dg_packed_mask == 0
     starts, oidx, opar = tm.read_group(view.dg[0], 1, 2, 3, False)
     assert starts.tolist() == [0, 3] and oidx.tolist() == [[0, 1], [1, 2], [0, 2]] and opar.tolist() == [[3, 4, 5], [6, 7, 8], [0, 1, 2]]
     assert tm.read_group(view.dg[1], 1, 4, 2, False)[0].tolist() == [0, 0] and not view.dg[1].idx

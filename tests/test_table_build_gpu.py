@@ -36,7 +36,7 @@ def test_device_tables_equal_the_restatement(library, slot_kb):
     want, want_merged = tm.expected_term_tables(MMFF, tables)
     for g, (a, b) in enumerate(zip(got, want)):
         tm.assert_groups_equal(a, b, f"group {g}")
-    tm.assert_groups_equal(merged, want_merged, "merged group", packed=True, merged=True)
+    tm.assert_groups_equal(merged, want_merged, "merged group")
 
 
 def test_builds_on_a_side_stream_and_from_two_threads(library):
@@ -89,36 +89,3 @@ def test_minimisation_on_resident_tables_while_they_are_still_uploading(library)
         with _native.options(NVMK_BUILD_SLOT_KB=64):
             got = mmffOptimization.optimize_device(mmffOptimization.resident_tables(tables), dev, max_iters=30)
         assert torch.equal(got.values.torch(), want.values.torch()) and torch.equal(got.energies.torch(), want.energies.torch())
-
-
-def test_packed_and_plain_pair_rows_give_the_same_bits(library, monkeypatch):
-    """The kernels read the pair tables either as packed rows (one index word + three doubles, the builder's default) or as the
-    plain rows of the C ABI: the same doubles enter the same arithmetic in the same order — energies, gradients, a whole ETKDG
-    run and an MMFF minimisation are bit-identical."""
-    from nvmolkit_amd.forcefield import DG, ETK, UFF, FlatForcefieldBatch
-    from tests import util
-
-    lib = library[:30]
-    results = {}
-    for pack in ("1", "0"):
-        monkeypatch.setenv("NVMK_PAIR_PACK", pack)
-        out = []
-        for kind in (DG, ETK, MMFF, UFF):
-            r = np.random.default_rng(5)
-            systems = [util.random_ff_system(kind, int(n), r) for n in (7, 19, 33, 64, 90)]
-            a_s, flat, groups = util.build_ff_batch_arrays(kind, systems)
-            batch = FlatForcefieldBatch(kind, a_s, groups)
-            assert (batch._c.packed_mask != 0) == (pack == "1")
-            pos = torch.from_numpy(flat).cuda()
-            out += [batch.compute_energy(pos, 0.7, 0.3).cpu().numpy(), batch.compute_gradient(pos, 0.7, 0.3).cpu().numpy()]
-            p2 = pos.clone()
-            e, st, it = batch.minimize(p2, max_iters=25)
-            out += [p2.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy()]
-        molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in lib])
-        assert (molset.c.dg_packed_mask != 0) == (pack == "1") and (molset.c.etk_packed_mask != 0) == (pack == "1")
-        dev = embed_flat(molset, confs_per_molecule=2, max_iterations=10, seed=6, output=CoordinateOutput.DEVICE)
-        opt = mmffOptimization.optimize_device(mmffOptimization.resident_tables([m["mmff"] for m in lib]), dev, max_iters=40)
-        out += [dev.values.torch().cpu().numpy(), opt.values.torch().cpu().numpy(), opt.energies.torch().cpu().numpy()]
-        results[pack] = out
-    for a, b in zip(results["1"], results["0"]):
-        assert np.array_equal(a, b)

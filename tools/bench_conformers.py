@@ -34,6 +34,8 @@ ap.add_argument("--set", default="synthetic", choices=("synthetic", "chembl"),
                 help="synthetic: generated drug-like graphs (clipped N(48, 12) atoms); chembl: the topologies of tests/golden/chembl_10k.smi "
                 "(the reference's benchmarks/data/chembl_10k.smi) with explicit hydrogens and generic parameters (synthetic.graph_molecule)")
 ap.add_argument("--max-atoms", type=int, default=128, help="chembl: molecules with more atoms (hydrogens included) are left out")
+ap.add_argument("--end-to-end", action="store_true", help="after the timed repetitions on resident tables, run the job once more from the "
+                "per-molecule host arrays with the table assembly inside the clock (what bench.py times)")
 ap.add_argument("--cache", default="", help="directory for the generated molecule library (pickle): A/B runs of several builds in one "
                 "session then generate it once")
 args = ap.parse_args()
@@ -97,22 +99,26 @@ for _ in range(args.repeat):
         best = (t_embed, t_mmff, dev.num_conformers, int(opt.converged.torch().sum().item()))
 t_embed, t_mmff, n_conf, n_converged = best
 _native.check(_native.lib().nvmk_bfgs_set_stats(None))
-# the same job from the per-molecule host arrays (what bench.py times): table assembly inside the clock, MMFF tables under ETKDG
-torch.cuda.synchronize()
-e0 = time.perf_counter()
-molset2 = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library])
-e_molset = time.perf_counter() - e0
-pending = mmffOptimization.resident_tables([m["mmff"] for m in library], wait=False)
-dev2 = embed_flat(molset2, confs_per_molecule=args.confs, max_iterations=10, batch_size=args.batch_size, seed=1,
-                  output=CoordinateOutput.DEVICE, batches_per_gpu=args.batches_per_gpu)
-torch.cuda.synchronize()
-e1 = time.perf_counter()
-tables2 = pending.result()
-e_wait = time.perf_counter() - e1
-mmffOptimization.optimize_device(tables2, dev2, max_iters=args.mmff_iters)
-torch.cuda.synchronize()
-t_end_to_end = time.perf_counter() - e0
-del molset2, tables2, dev2
+t_end_to_end = e_molset = e_wait = float("nan")
+molset_timings = {}
+if args.end_to_end:
+    # the same job from the per-molecule host arrays (what bench.py times): table assembly inside the clock, MMFF tables under ETKDG
+    torch.cuda.synchronize()
+    e0 = time.perf_counter()
+    molset2 = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library])
+    e_molset = time.perf_counter() - e0
+    molset_timings = dict(molset2.timings)
+    pending = mmffOptimization.resident_tables([m["mmff"] for m in library], wait=False)
+    dev2 = embed_flat(molset2, confs_per_molecule=args.confs, max_iterations=10, batch_size=args.batch_size, seed=1,
+                      output=CoordinateOutput.DEVICE, batches_per_gpu=args.batches_per_gpu)
+    torch.cuda.synchronize()
+    e1 = time.perf_counter()
+    tables2 = pending.result()
+    e_wait = time.perf_counter() - e1
+    mmffOptimization.optimize_device(tables2, dev2, max_iters=args.mmff_iters)
+    torch.cuda.synchronize()
+    t_end_to_end = time.perf_counter() - e0
+    del molset2, tables2, dev2
 st = stats.cpu().numpy().reshape(8, 8) // max(args.repeat, 1)
 bfgs = {name: {"systems": int(st[k, 0]), "iterations": int(st[k, 1]), "algorithmic_bytes": int(st[k, 2]), "energy_evaluations": int(st[k, 3]),
                "hbm_requested_bytes": int(st[k, 4])} for k, name in ((0, "dg"), (1, "etk"), (2, "mmff"))}
@@ -138,4 +144,4 @@ print(json.dumps({
     "mmff_converged_frac": n_converged / max(n_conf, 1),
     "mols_per_s_etkdg_plus_mmff": n_mols / (t_embed + t_mmff), "host_prep_s": t_prep,
     "end_to_end_s": t_end_to_end, "mols_per_s_end_to_end": (n_mols if world == 1 else float("nan")) / t_end_to_end,
-    "table_assembly_host_s": e_molset, "mmff_tables_wait_s": e_wait, "bfgs": bfgs}))
+    "table_assembly_host_s": e_molset, "table_assembly_steps": molset_timings, "mmff_tables_wait_s": e_wait, "bfgs": bfgs}))

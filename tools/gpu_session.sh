@@ -35,7 +35,7 @@ CACHE=/tmp/nvmk_lib_cache
 pick() { python -c "import sys,json
 for line in sys.stdin:
     if line.startswith('{'):
-        d=json.loads(line); print('$1', {k: (round(d[k],4) if isinstance(d[k],float) else d[k]) for k in d if k in ('mols_per_s_etkdg_plus_mmff','etkdg_s','mmff_s','etkdg_conformers','mmff_converged_frac','mols','mean_atoms','mols_per_s_end_to_end','end_to_end_s','table_assembly_host_s','mmff_tables_wait_s')})"; }
+        d=json.loads(line); print('$1', {k: (round(d[k],4) if isinstance(d[k],float) else d[k]) for k in d if k in ('mols_per_s_etkdg_plus_mmff','etkdg_s','mmff_s','etkdg_conformers','mmff_converged_frac','mols','mean_atoms','mols_per_s_end_to_end','end_to_end_s','table_assembly_host_s','mmff_tables_wait_s','table_assembly_steps')})"; }
 
 for STEP in "$@"; do
   echo "==== $STEP ($(date +%T))"
@@ -156,7 +156,7 @@ PY
       tail -15 $O/table_tests.log
       ;;
     conf10k)
-      timeout 600 python tools/bench_conformers.py --mols 10000 --repeat 2 --cache $CACHE 2> $O/conf10k.err | tee $O/conf10k.json | pick conf10k
+      timeout 600 python tools/bench_conformers.py --mols 10000 --repeat 2 --end-to-end --cache $CACHE 2> $O/conf10k.err | tee $O/conf10k.json | pick conf10k
       tail -3 $O/conf10k.err
       ;;
     pytest_gpu_all)

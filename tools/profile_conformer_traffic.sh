@@ -17,7 +17,7 @@ python - "$OUT" "$MOLS" <<'PY'
 import csv, glob, hashlib, json, os, sys
 out = {"molecules": int(sys.argv[2])}
 h = hashlib.sha256()
-for name in ("minimize.hip", "bfgs_device.inc", "hess_pass.h", "ff_terms.h", "ff_grad.h", "etkdg.hip"):   # = bench.py conformer_source_digest()
+for name in ("minimize.hip", "bfgs_device.inc", "hess_pass.h", "ff_terms.h", "ff_grad.h", "etkdg.hip", "table_build.cpp"):   # = bench.py conformer_source_digest()
     h.update(open(os.path.join(os.environ["NVMK_ROOT"], "nvmolkit_amd", "csrc", name), "rb").read())
 out["kernel_source_sha256"] = h.hexdigest()
 for line in open(f"{sys.argv[1]}/conf_fetch.log"):
