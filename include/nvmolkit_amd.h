@@ -34,6 +34,7 @@ extern "C" {
 #define NVMK_ERR_OUT_OF_MEMORY (-3)    /* reference: std::runtime_error("Not enough memory…"), src/similarity.cpp:137-139 */
 #define NVMK_ERR_UNSUPPORTED (-4)
 #define NVMK_ERR_INTERNAL (-5)
+#define NVMK_TRUNCATED 1 /* success with a notice: the output is valid but incomplete (only where an entry point says so) */
 
 /* Similarity metric selector (reference: enum SimilarityType, src/similarity_kernels.cu). */
 #define NVMK_METRIC_TANIMOTO 0
@@ -583,7 +584,9 @@ int nvmk_smiles_graph(const void* handle, int64_t mol, int32_t* atom_fields, int
  * SubstructMatch(mol, mol, maxMatches = 1000, uniquify = false) after removeHs, optionally on the copy whose conjugated
  * terminal groups were made symmetric (rdkit_extensions/conformer_pruning.cpp:24-60 getMolSelfMatches;
  * EmbedParameters::symmetrizeConjugatedTerminalGroupsForPruning).  out[k * n_atoms + i] = image of atom i in match k, the
- * identity first; at most max_matches matches are written (out must hold max_matches * n_atoms ints), *n_matches says how many. */
+ * identity first; at most max_matches matches are written (out must hold max_matches * n_atoms ints), *n_matches says how many.
+ * Returns NVMK_TRUNCATED (> 0, the matches written are valid) when the backtracking search gave up on its step budget of 5e7
+ * before it had found max_matches matches or exhausted the mappings: the list is then NOT the whole group. */
 int nvmk_smiles_self_matches(const void* handle, int64_t mol, int symmetrize_terminal, int max_matches, int32_t* out,
                              int32_t* n_matches);
 int nvmk_smiles_morgan_inputs(const void* handle, const int64_t* mol_ids, int64_t n_sel, int max_atoms, uint32_t* atom_inv,

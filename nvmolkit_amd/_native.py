@@ -19,6 +19,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "lib" / "libnvmolkit_amd.so"
 
 OK = 0
+TRUNCATED = 1  # success with a notice (nvmk_smiles_self_matches: the search gave up before the list was complete)
 ERR_INVALID_ARGUMENT = -1
 ERR_HIP = -2
 ERR_OUT_OF_MEMORY = -3

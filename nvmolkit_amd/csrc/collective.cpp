@@ -139,21 +139,23 @@ int nvmk_copy_peer_async(void* d_dst, int dst_device, void* dst_stream, const vo
   NVMK_REQUIRE(d_dst != nullptr && d_src != nullptr, "copy_peer: NULL buffer");
   int current = 0;
   NVMK_HIP_CHECK(hipGetDevice(&current));
-  if (src_device == dst_device) {
-    NVMK_HIP_CHECK(hipSetDevice(dst_device));
-    const hipError_t e = hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, nvmk::as_stream(dst_stream));
-    (void)hipSetDevice(current);
-    NVMK_HIP_CHECK(e);
-    return NVMK_OK;
-  }
-  // the source stream's work so far must precede the copy: an event recorded there, waited for on the destination stream
-  hipEvent_t ready = nullptr;
+  // the source stream's work so far must precede the copy: an event recorded there, waited for on the destination stream —
+  // also when both buffers live on ONE device (two streams of a device are not ordered either; the reference's same-device branch
+  // copies on the destination stream without waiting, src/utils/p2p.cpp:66-70, and leaves the ordering to its caller)
+  const bool sameStream = src_device == dst_device && src_stream == dst_stream;
+  hipEvent_t ready      = nullptr;
   NVMK_HIP_CHECK(hipSetDevice(src_device));
-  hipError_t e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventRecord(ready, nvmk::as_stream(src_stream));
+  hipError_t e = hipSuccess;
+  if (!sameStream) {
+    e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ready, nvmk::as_stream(src_stream));
+  }
   if (e == hipSuccess) e = hipSetDevice(dst_device);
-  if (e == hipSuccess) e = hipStreamWaitEvent(nvmk::as_stream(dst_stream), ready, 0);
-  if (e == hipSuccess) e = hipMemcpyPeerAsync(d_dst, dst_device, d_src, src_device, bytes, nvmk::as_stream(dst_stream));
+  if (e == hipSuccess && ready != nullptr) e = hipStreamWaitEvent(nvmk::as_stream(dst_stream), ready, 0);
+  if (e == hipSuccess) {
+    e = src_device == dst_device ? hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, nvmk::as_stream(dst_stream))
+                                 : hipMemcpyPeerAsync(d_dst, dst_device, d_src, src_device, bytes, nvmk::as_stream(dst_stream));
+  }
   if (ready != nullptr) (void)hipEventDestroy(ready);  // released once the recorded work has completed
   (void)hipSetDevice(current);
   NVMK_HIP_CHECK(e);

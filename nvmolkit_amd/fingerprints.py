@@ -237,18 +237,23 @@ class SmilesSet:
         _native.check(_native.lib().nvmk_smiles_graph(self._handle, int(i), atoms.ctypes.data, bonds.ctypes.data), "nvmk_smiles_graph")
         return atoms, bonds
 
-    def self_matches(self, i: int, symmetrize_terminal_groups: bool = True, max_matches: int = 1000) -> np.ndarray:
+    def self_matches(self, i: int, symmetrize_terminal_groups: bool = True, max_matches: int = 1000, return_truncated: bool = False):
         """(K, n_atoms) self matches of molecule i's (hydrogen-free) graph, the identity first: every mapping of the atoms onto
         themselves that keeps element, charge, isotope and all bonds with their types — what the reference takes from RDKit's
         ``SubstructMatch(mol, mol, uniquify=False, maxMatches=1000)`` for symmetry-aware RMS pruning
         (rdkit_extensions/conformer_pruning.cpp:24-60).  ``symmetrize_terminal_groups``: conjugated terminal N / O pairs
-        (carboxylate, nitro, amidine ...) are interchangeable, RDKit's ``symmetrizeConjugatedTerminalGroupsForPruning``."""
+        (carboxylate, nitro, amidine ...) are interchangeable, RDKit's ``symmetrizeConjugatedTerminalGroupsForPruning``.
+        ``return_truncated``: also return whether the search gave up on its step budget before the list was complete (the matches
+        are valid either way; pruning with fewer symmetries keeps more conformers, never wrong ones)."""
         n = int(self.n_atoms[i])
         out = np.zeros((int(max_matches), max(n, 1)), dtype=np.int32)
         k = ctypes.c_int32(0)
-        _native.check(_native.lib().nvmk_smiles_self_matches(self._handle, int(i), int(bool(symmetrize_terminal_groups)), int(max_matches),
-                                                             out.ctypes.data, ctypes.byref(k)), "nvmk_smiles_self_matches")
-        return out[:k.value, :n].copy()
+        rc = _native.lib().nvmk_smiles_self_matches(self._handle, int(i), int(bool(symmetrize_terminal_groups)), int(max_matches),
+                                                    out.ctypes.data, ctypes.byref(k))
+        if rc != _native.TRUNCATED:
+            _native.check(rc, "nvmk_smiles_self_matches")
+        matches = out[:k.value, :n].copy()
+        return (matches, rc == _native.TRUNCATED) if return_truncated else matches
 
     def morgan_inputs(self, mol_ids, max_atoms: int, num_threads: int = 0, out=None):
         """The five host arrays of ``nvmk_morgan_from_invariants`` for the listed molecules, in ``max_atoms`` slots.

@@ -29,16 +29,22 @@ def test_device_set_and_peer_copy():
     twice = np.array([0, 0], dtype=np.int32)
     assert lib.nvmk_set_devices(twice.ctypes.data, 2) == _native.ERR_INVALID_ARGUMENT
     _native.check(lib.nvmk_set_devices(None, 0), "nvmk_set_devices(all)")
-    # same-device "peer" copy ordered behind the source stream's work
+    # same-device "peer" copy: ordered behind the SOURCE stream's work although it runs on the destination stream — the source
+    # stream is still busy producing the buffer when the copy is asked for (300 dependent updates of 32 MB; nothing waits for them)
     src_stream, dst_stream = torch.cuda.Stream(), torch.cuda.Stream()
+    src = torch.zeros(1 << 22, dtype=torch.float64, device="cuda")
+    dst = torch.full_like(src, -1.0)
+    torch.cuda.synchronize()
     with torch.cuda.stream(src_stream):
-        src = torch.arange(1 << 20, dtype=torch.float64, device="cuda") * 3.0
-    dst = torch.zeros_like(src)
-    torch.cuda.current_stream().synchronize()
+        for _ in range(300):
+            src.add_(1.0)
     _native.check(lib.nvmk_copy_peer_async(dst.data_ptr(), 0, dst_stream.cuda_stream, src.data_ptr(), 0, src_stream.cuda_stream, src.numel() * 8),
                   "nvmk_copy_peer_async")
     dst_stream.synchronize()
-    assert torch.equal(dst, src)
+    assert float(dst.min()) == 300.0 and float(dst.max()) == 300.0
+    # one stream on both sides: plain stream order, no event
+    _native.check(lib.nvmk_copy_peer_async(dst.data_ptr(), 0, src_stream.cuda_stream, src.data_ptr(), 0, src_stream.cuda_stream, 4096), "same stream")
+    src_stream.synchronize()
 
 
 def test_all_gather_of_fingerprint_rows_as_one_rank():

@@ -78,6 +78,15 @@ def test_the_cap_on_the_number_of_matches_and_every_match_keeps_the_bonds():
         assert all(have.get((int(r[a]), int(r[b]))) == t for (a, b), t in have.items())
 
 
+def test_a_complete_list_is_not_reported_as_truncated():
+    """NVMK_TRUNCATED is the notice for a search abandoned on its step budget; complete lists and lists cut by max_matches are not."""
+    s = SmilesSet(["c1ccccc1", "CC(C)(C)CC(C)(C)CC(C)(C)C"], perceive_aromaticity=True)
+    m, truncated = s.self_matches(0, return_truncated=True)
+    assert len(m) == 12 and truncated is False
+    m, truncated = s.self_matches(1, max_matches=7, return_truncated=True)
+    assert len(m) == 7 and truncated is False
+
+
 def test_bad_arguments_are_refused():
     s = SmilesSet(["CC"], perceive_aromaticity=True)
     with pytest.raises(Exception):

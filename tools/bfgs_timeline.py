@@ -56,6 +56,33 @@ for a, b in groups:
     tot_span += span
     tot_busy += busy
     tot_tail += tail
+# Per size class over the whole file (round 5: what bounds the large molecules?): the classes of csrc/minimize.hip by coordinates —
+# one wave (<= 176), two waves (<= 256), four waves with vectors in LDS at two workgroups per CU (A, <= 655) or one per CU (B, <= 1320),
+# vectors in HBM (C).  For every class: systems, summed run time of its workgroups, the longest single system, and how much of the
+# wall the class spends with fewer workgroups in flight than the chip has CUs (256) / XCDs x 8 (64): that is time in which a system's
+# triangle streams at one CU's bandwidth while the rest of the chip idles — the "tail" a cooperative class would attack; a class that
+# keeps >= 256 workgroups in flight for most of its wall is bound by the chip's bytes instead.
+bounds = [(args.wave, "one wave"), (args.wave2, "two waves"), (655, "four waves A"), (1320, "four waves B"), (1 << 30, "four waves C (HBM vectors)")]
+out["by_class"] = []
+lo = 0
+for hi, name in bounds:
+    m = (n > lo) & (n <= hi)
+    lo = hi
+    if not m.any():
+        continue
+    a0, a1 = t0[m], t1[m]
+    ev = np.concatenate([np.stack([a0, np.ones_like(a0)], 1), np.stack([a1, -np.ones_like(a1)], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind="stable")]
+    level = np.cumsum(ev[:, 1])[:-1]
+    dt = np.diff(ev[:, 0]).astype(np.float64)
+    busy_wall = float(dt[level > 0].sum())
+    out["by_class"].append({"class": name, "coordinates_min_max": [int(n[m].min()), int(n[m].max())], "systems": int(m.sum()),
+                            "workgroup_ms_total": float((a1 - a0).sum()) * 1e-5, "longest_system_ms": float((a1 - a0).max()) * 1e-5,
+                            "mean_system_ms": float((a1 - a0).mean()) * 1e-5, "mean_iterations": float(iters[m].mean()),
+                            "wall_ms_with_any_in_flight": busy_wall * 1e-5,
+                            "wall_fraction_below_256_in_flight": float(dt[(level > 0) & (level < 256)].sum()) / max(busy_wall, 1.0),
+                            "wall_fraction_below_64_in_flight": float(dt[(level > 0) & (level < 64)].sum()) / max(busy_wall, 1.0),
+                            "mean_in_flight": float((dt * level).sum()) / max(busy_wall, 1.0)})
 out["total_span_ms"] = tot_span * 1e-3
 out["total_mean_occupancy"] = tot_busy / (tot_span * args.slots)
 out["total_tail_ms_below_half"] = tot_tail * 1e-3

@@ -12,6 +12,9 @@
 #   timeline            BFGS per-system timeline of one 10 000-molecule run (NVMK_BFGS_PROFILE=1 NVMK_BFGS_TIMELINE)
 #   conformer_traffic   tools/profile_conformer_traffic.sh 2000
 #   table_tests         the table builder's GPU tests + the suites that build batches through it
+#   ab_batch            bench_conformers with the default 16384 attempts per batch against equalised batches (16667 x 6, 14286 x 7)
+#   chembl256_timeline  the ChEMBL topologies of up to 256 atoms with the per-system BFGS timeline, summarised per size class
+#   chembl_all          every molecule of the ChEMBL file (up to 1063 atoms)
 #   conf10k             tools/bench_conformers.py --mols 10000 (resident tables, and end to end from the host arrays)
 #   pytest_gpu          the whole -m gpu suite (stops at the first failure; pytest_gpu_all: runs on)
 #   smoke               __graft_entry__.smoke()
@@ -154,6 +157,23 @@ PY
     table_tests)
       ( time timeout 900 python -m pytest tests/test_table_build_gpu.py tests/test_cxx_example.py tests/test_device_chain_gpu.py tests/test_etkdg_gpu.py tests/test_forcefield_gpu.py tests/test_constraints.py -m gpu -q ) > $O/table_tests.log 2>&1
       tail -15 $O/table_tests.log
+      ;;
+    ab_batch)
+      : > $O/ab_batch.txt
+      for i in 1 2; do for B in -1 16667 14286; do
+        timeout 300 python tools/bench_conformers.py --mols 10000 --repeat 2 --batch-size $B --cache $CACHE 2>/dev/null | pick "batch=$B" | tee -a $O/ab_batch.txt
+      done; done
+      ;;
+    chembl256_timeline)
+      rm -f $O/chembl256_timeline.txt
+      NVMK_BFGS_PROFILE=1 NVMK_BFGS_TIMELINE=$O/chembl256_timeline.txt timeout 900 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 256 --cache $CACHE > $O/chembl256_timeline_run.log 2>&1
+      grep '^{' $O/chembl256_timeline_run.log | tail -1 | cut -c1-600
+      python tools/bfgs_timeline.py $O/chembl256_timeline.txt > $O/chembl256_timeline_summary.json && python -c "import json; d=json.load(open('$O/chembl256_timeline_summary.json')); print(json.dumps({k: d[k] for k in ('systems','launch_groups','total_mean_occupancy','total_tail_ms_below_half','wall_ms_first_to_last')})); print(json.dumps(d['by_class'], indent=0))"
+      gzip -f $O/chembl256_timeline.txt; rm -f $O/chembl256_timeline.txt.gz
+      ;;
+    chembl_all)
+      timeout 1200 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --end-to-end --cache $CACHE 2> $O/chembl_all.err | tee $O/chembl_all.json | cut -c1-900
+      tail -3 $O/chembl_all.err
       ;;
     conf10k)
       timeout 600 python tools/bench_conformers.py --mols 10000 --repeat 2 --end-to-end --cache $CACHE 2> $O/conf10k.err | tee $O/conf10k.json | pick conf10k
