@@ -366,6 +366,12 @@ int   nvmk_scheduler_record(void* scheduler, const int32_t* h_mol_ids, const int
  *   NVMK_CHECK_CHIRAL_CENTER_VOLUME  idx as TETRAHEDRAL                     -
  *   NVMK_CHECK_DOUBLE_BOND_STEREO    idx(0, 1, 2, 3, -)                     par(sign, -)
  *   NVMK_CHECK_DOUBLE_BOND_GEOMETRY  idx(0, 1, 2, -, -)                     -
+ * Surplus attempts (option NVMK_ETKDG_PRUNE, default 1): a molecule that misses k conformers when a batch starts sends only k + 1
+ * of its surviving attempts past stage 4 (ETK minimisation onwards); the others leave without a failure being counted, but they DO
+ * count against the molecule's attempt budget (confs_per_mol x max_iterations), so with a very small max_iterations a molecule
+ * whose kept attempts fail late can end with fewer conformers than the unpruned pipeline, and WHICH attempts are accepted
+ * depends on the molecule's count at the start of the batch.  NVMK_ETKDG_PRUNE=0 runs every attempt through every stage (the
+ * reference's behaviour).
  * Output: conformer c of molecule m starts at d_coords[3 * (confs_per_mol * sum_{k<m} n_atoms[k] + c * n_atoms[m])],
  * h_conf_counts[m] conformers are valid.  h_stage_failures (optional, NVMK_ETKDG_N_STAGES ints) totals failures per
  * stage (the reference's ETKDGContext::totalFailures).  Blocking. */

@@ -25,44 +25,21 @@ from nvmolkit_amd.types import CoordinateOutput, Device3DResult, HardwareOptions
 __all__ = ["FlatBatchedForcefield", "MMFFBatchedForcefield", "UFFBatchedForcefield", "MMFFBatchElement", "UFFBatchElement"]
 
 
-@dataclass
-class _DistanceConstraint:
-    idx1: int
-    idx2: int
+@dataclass(frozen=True)
+class _Restraint:
+    """One restraint as the caller stated it: which quantity, on which atoms, and a window [lower, upper] with a force constant.
+    ``relative`` windows are offsets from the quantity's value in each conformer; a position restraint has no window, only the
+    radius ``upper`` around the atom's position in each conformer."""
+
+    quantity: str          # "distance" | "position" | "angle" | "torsion" — also the order of the four constraint groups
+    atoms: tuple
     relative: bool
-    min_len: float
-    max_len: float
+    lower: float
+    upper: float
     force_constant: float
 
 
-@dataclass
-class _PositionConstraint:
-    idx: int
-    max_displ: float
-    force_constant: float
-
-
-@dataclass
-class _AngleConstraint:
-    idx1: int
-    idx2: int
-    idx3: int
-    relative: bool
-    min_angle_deg: float
-    max_angle_deg: float
-    force_constant: float
-
-
-@dataclass
-class _TorsionConstraint:
-    idx1: int
-    idx2: int
-    idx3: int
-    idx4: int
-    relative: bool
-    min_dihedral_deg: float
-    max_dihedral_deg: float
-    force_constant: float
+_QUANTITIES = ("distance", "position", "angle", "torsion")
 
 
 def _normalize_deg(a: float) -> float:
@@ -90,83 +67,85 @@ def _dihedral_deg(xyz, i, j, k, l) -> float:  # noqa: E741
     return float(np.degrees(-np.arctan2(float(m @ t1) / max(float(np.linalg.norm(m)), 1e-5), cos_phi)))
 
 
-def _resolve_constraints(xyz: np.ndarray, dist, posn, ang, tors):
-    """Constraint specs of one molecule + the coordinates of ONE conformer -> the four (idx, par) groups
-    (forcefield_constraints.cpp:128-232: relative bounds, anchors, validation)."""
-    rows = [[], [], [], []]
-    for c in dist:
-        lo, hi = c.min_len, c.max_len
-        if hi < lo:
-            raise ValueError("Distance constraint maxLen must be >= minLen")
-        if c.relative:
-            d = float(np.linalg.norm(xyz[c.idx1] - xyz[c.idx2]))
-            lo, hi = max(lo + d, 0.0), max(hi + d, 0.0)
-        rows[0].append((c.idx1, c.idx2, lo, hi, c.force_constant))
-    for c in posn:
-        rows[1].append((c.idx, *xyz[c.idx], c.max_displ, c.force_constant))
-    for c in ang:
-        lo, hi = c.min_angle_deg, c.max_angle_deg
-        if hi < lo:
-            raise ValueError("Angle constraint maxAngleDeg must be >= minAngleDeg")
-        if c.relative:
-            a = _angle_deg(xyz, c.idx1, c.idx2, c.idx3)
-            lo, hi = lo + a, hi + a
-        if lo < 0.0 or lo > 180.0 or hi < 0.0 or hi > 180.0:
-            raise ValueError("Angle constraint bounds must be within [0, 180]")
-        rows[2].append((c.idx1, c.idx2, c.idx3, lo, hi, c.force_constant))
-    for c in tors:
-        lo, hi = c.min_dihedral_deg, c.max_dihedral_deg
-        if hi < lo:
-            raise ValueError("Torsion constraint maxDihedralDeg must be >= minDihedralDeg")
-        if c.relative:
-            d = _dihedral_deg(xyz, c.idx1, c.idx2, c.idx3, c.idx4)
-            lo, hi = lo + d, hi + d
-        rows[3].append((c.idx1, c.idx2, c.idx3, c.idx4, _normalize_deg(lo), _normalize_deg(hi), c.force_constant))
-    out = []
-    for r, (n_idx, n_par) in zip(rows, CONSTRAINT_LAYOUT):
-        a = np.array(r, dtype=np.float64).reshape(-1, n_idx + n_par)
-        out.append((a[:, :n_idx].astype(np.int32), a[:, n_idx:]))
-    return out
+class _MoleculeRestraints:
+    """Everything a caller asked of ONE molecule of the batch.  Adding to it tells the owning batch that its device tables are
+    out of date (``notify``); ``rows_for(xyz)`` turns the statements into the four constraint term groups for ONE conformer —
+    relative windows are centred on that conformer's current value, position restraints anchor where its atom is now
+    (semantics: src/forcefields/forcefield_constraints.cpp:128-232)."""
+
+    def __init__(self, molecule: int, n_atoms: int, notify):
+        self.molecule, self.n_atoms, self._notify = molecule, n_atoms, notify
+        self.items: list[_Restraint] = []
+
+    def add(self, quantity: str, atoms, relative: bool, lower: float, upper: float, force_constant: float) -> None:
+        atoms = tuple(int(a) for a in atoms)
+        for a in atoms:
+            if not 0 <= a < self.n_atoms:
+                raise IndexError(f"molecule {self.molecule} of the batch has {self.n_atoms} atoms: there is no atom {a}")
+        self.items.append(_Restraint(quantity, atoms, bool(relative), float(lower), float(upper), float(force_constant)))
+        self._notify()
+
+    def __bool__(self) -> bool:
+        return bool(self.items)
+
+    def rows_for(self, xyz: np.ndarray):
+        rows = {q: [] for q in _QUANTITIES}
+        for r in self.items:
+            lo, hi = r.lower, r.upper
+            if r.quantity == "position":
+                rows["position"].append((*r.atoms, *xyz[r.atoms[0]], hi, r.force_constant))
+                continue
+            if hi < lo:
+                raise ValueError({"distance": "Distance constraint maxLen must be >= minLen",
+                                  "angle": "Angle constraint maxAngleDeg must be >= minAngleDeg",
+                                  "torsion": "Torsion constraint maxDihedralDeg must be >= minDihedralDeg"}[r.quantity])
+            if r.quantity == "distance":
+                if r.relative:
+                    d = float(np.linalg.norm(xyz[r.atoms[0]] - xyz[r.atoms[1]]))
+                    lo, hi = max(lo + d, 0.0), max(hi + d, 0.0)
+            elif r.quantity == "angle":
+                if r.relative:
+                    now = _angle_deg(xyz, *r.atoms)
+                    lo, hi = lo + now, hi + now
+                if not (0.0 <= lo <= 180.0 and 0.0 <= hi <= 180.0):
+                    raise ValueError("Angle constraint bounds must be within [0, 180]")
+            else:
+                if r.relative:
+                    now = _dihedral_deg(xyz, *r.atoms)
+                    lo, hi = lo + now, hi + now
+                lo, hi = _normalize_deg(lo), _normalize_deg(hi)
+            rows[r.quantity].append((*r.atoms, lo, hi, r.force_constant))
+        groups = []
+        for q, (n_idx, n_par) in zip(_QUANTITIES, CONSTRAINT_LAYOUT):
+            a = np.array(rows[q], dtype=np.float64).reshape(-1, n_idx + n_par)
+            groups.append((a[:, :n_idx].astype(np.int32), a[:, n_idx:]))
+        return groups
 
 
 class _BatchElement:
     """``ff[i]``: one molecule of the batch; constraints added here apply to all of its conformers."""
 
-    def __init__(self, parent, idx: int):
-        self._parent = parent
-        self._idx = idx
+    def __init__(self, restraints: _MoleculeRestraints):
+        self._restraints = restraints
 
     @property
     def num_atoms(self) -> int:
-        return self._parent._n_atoms[self._idx]
+        return self._restraints.n_atoms
 
     def add_distance_constraint(self, idx1: int, idx2: int, relative: bool, min_len: float, max_len: float,
                                 force_constant: float) -> None:
-        self._parent._validate_atom_indices(self._idx, idx1, idx2)
-        self._parent._distance_constraints[self._idx].append(
-            _DistanceConstraint(int(idx1), int(idx2), bool(relative), float(min_len), float(max_len), float(force_constant)))
-        self._parent._dirty = True
+        self._restraints.add("distance", (idx1, idx2), relative, min_len, max_len, force_constant)
 
     def add_position_constraint(self, idx: int, max_displ: float, force_constant: float) -> None:
-        self._parent._validate_atom_indices(self._idx, idx)
-        self._parent._position_constraints[self._idx].append(_PositionConstraint(int(idx), float(max_displ), float(force_constant)))
-        self._parent._dirty = True
+        self._restraints.add("position", (idx,), False, 0.0, max_displ, force_constant)
 
     def add_angle_constraint(self, idx1: int, idx2: int, idx3: int, relative: bool, min_angle_deg: float, max_angle_deg: float,
                              force_constant: float) -> None:
-        self._parent._validate_atom_indices(self._idx, idx1, idx2, idx3)
-        self._parent._angle_constraints[self._idx].append(
-            _AngleConstraint(int(idx1), int(idx2), int(idx3), bool(relative), float(min_angle_deg), float(max_angle_deg),
-                             float(force_constant)))
-        self._parent._dirty = True
+        self._restraints.add("angle", (idx1, idx2, idx3), relative, min_angle_deg, max_angle_deg, force_constant)
 
     def add_torsion_constraint(self, idx1: int, idx2: int, idx3: int, idx4: int, relative: bool, min_dihedral_deg: float,
                                max_dihedral_deg: float, force_constant: float) -> None:
-        self._parent._validate_atom_indices(self._idx, idx1, idx2, idx3, idx4)
-        self._parent._torsion_constraints[self._idx].append(
-            _TorsionConstraint(int(idx1), int(idx2), int(idx3), int(idx4), bool(relative), float(min_dihedral_deg),
-                               float(max_dihedral_deg), float(force_constant)))
-        self._parent._dirty = True
+        self._restraints.add("torsion", (idx1, idx2, idx3, idx4), relative, min_dihedral_deg, max_dihedral_deg, force_constant)
 
 
 class MMFFBatchElement(_BatchElement):
@@ -196,75 +175,51 @@ class FlatBatchedForcefield:
         self.device = torch.device(device)
         self._tables = list(tables)
         self._conformers = [np.ascontiguousarray(c, dtype=np.float64).reshape(len(c), -1, 3) for c in conformers]
-        self._n_atoms = [int(c.shape[1]) for c in self._conformers]
         n = len(self._tables)
-        self._distance_constraints = [[] for _ in range(n)]
-        self._position_constraints = [[] for _ in range(n)]
-        self._angle_constraints = [[] for _ in range(n)]
-        self._torsion_constraints = [[] for _ in range(n)]
-        self._batch = None
-        self._dirty = True
+        # a counter that every added restraint advances; the device tables remember the count they were made at
+        self._edits = 0
+        self._restraints = [_MoleculeRestraints(m, int(c.shape[1]), self._edited) for m, c in enumerate(self._conformers)]
+        self._device_tables = None   # (edit count, FlatForcefieldBatch, systems, atom_starts)
         self.num_molecules = n
         self.data_dim = 3
+
+    def _edited(self) -> None:
+        self._edits += 1
 
     # ---- container protocol ----
     def __len__(self) -> int:
         return self.num_molecules
 
     def __getitem__(self, idx: int) -> _BatchElement:
-        if idx < 0 or idx >= self.num_molecules:
-            raise IndexError(f"Batch element index {idx} out of range")
-        return self._element_type(self, idx)
+        if not 0 <= idx < self.num_molecules:
+            raise IndexError(f"the batch holds {self.num_molecules} molecules: there is no molecule {idx}")
+        return self._element_type(self._restraints[idx])
 
-    def _validate_atom_indices(self, batch_idx: int, *indices: int) -> None:
-        num_atoms = self._n_atoms[batch_idx]
-        for idx in indices:
-            if idx < 0 or idx >= num_atoms:
-                raise IndexError(f"Atom index {idx} out of range for molecule {batch_idx} with {num_atoms} atoms")
-
-    # ---- build ----
-    def _has_constraints(self) -> bool:
-        return any(any(lst) for group in (self._distance_constraints, self._position_constraints, self._angle_constraints,
-                                          self._torsion_constraints) for lst in group)
-
-    def _build(self) -> None:
+    # ---- device tables: made on first use, made again after a restraint was added ----
+    def rebuild(self) -> None:
+        """Make the device tables again from the CURRENT coordinates (relative windows and position anchors move with them)."""
         self._systems = [(m, k) for m, c in enumerate(self._conformers) for k in range(len(c))]
-        atom_starts = np.zeros(len(self._systems) + 1, dtype=np.int32)
-        for s, (m, _) in enumerate(self._systems):
-            atom_starts[s + 1] = atom_starts[s] + self._n_atoms[m]
-        self._atom_starts = atom_starts
-        layout = list(GROUP_LAYOUT[self.kind])
-        constrained = self._has_constraints()
-        if constrained:
-            layout += CONSTRAINT_LAYOUT
-        per_system = []
-        for m, k in self._systems:
-            groups = list(self._tables[m])
-            if constrained:  # resolved against THIS conformer's coordinates
-                groups += _resolve_constraints(self._conformers[m][k], self._distance_constraints[m],
-                                               self._position_constraints[m], self._angle_constraints[m],
-                                               self._torsion_constraints[m])
-            per_system.append(groups)
+        sizes = np.array([self._restraints[m].n_atoms for m, _ in self._systems], dtype=np.int64)
+        self._atom_starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        restrained = any(self._restraints)
+        layout = list(GROUP_LAYOUT[self.kind]) + (list(CONSTRAINT_LAYOUT) if restrained else [])
+        per_system = [list(self._tables[m]) + (self._restraints[m].rows_for(self._conformers[m][k]) if restrained else [])
+                      for m, k in self._systems]
         stacked = []
         for g, (n_idx, n_par) in enumerate(layout):
-            starts = np.zeros(len(per_system) + 1, dtype=np.int32)
-            for s, groups in enumerate(per_system):
-                starts[s + 1] = starts[s] + len(groups[g][0])
+            counts = [len(groups[g][0]) for groups in per_system]
             idx = (np.concatenate([np.asarray(groups[g][0], dtype=np.int32).reshape(-1, n_idx) for groups in per_system])
                    if per_system else np.zeros((0, n_idx), dtype=np.int32))
             par = (np.concatenate([np.asarray(groups[g][1], dtype=np.float64).reshape(-1, n_par) for groups in per_system])
                    if per_system else np.zeros((0, n_par)))
-            stacked.append((starts, idx, par))
-        self._batch = FlatForcefieldBatch(self.kind, atom_starts, stacked, device=self.device)
-        self._dirty = False
+            stacked.append((np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), idx, par))
+        self._device_tables = (self._edits, FlatForcefieldBatch(self.kind, self._atom_starts, stacked, device=self.device))
 
-    def rebuild(self) -> None:
-        """Re-resolve the constraints against the current coordinates and rebuild the device batch."""
-        self._build()
-
-    def _ensure_built(self) -> None:
-        if self._dirty or self._batch is None:
-            self._build()
+    @property
+    def _batch(self) -> FlatForcefieldBatch:
+        if self._device_tables is None or self._device_tables[0] != self._edits:
+            self.rebuild()
+        return self._device_tables[1]
 
     def _positions(self) -> torch.Tensor:
         flat = (np.concatenate([self._conformers[m][k].reshape(-1) for m, k in self._systems]) if self._systems
@@ -282,15 +237,15 @@ class FlatBatchedForcefield:
         """``result[mol][conf]``: one energy per conformer."""
         if self.num_molecules == 0:
             return []
-        self._ensure_built()
-        return self._nest([float(e) for e in self._batch.compute_energy(self._positions()).cpu().numpy()])
+        batch = self._batch
+        return self._nest([float(e) for e in batch.compute_energy(self._positions()).cpu().numpy()])
 
     def compute_gradients(self) -> list[list[list[float]]]:
         """``result[mol][conf]``: the flattened ``[x0, y0, z0, ...]`` gradient of every conformer."""
         if self.num_molecules == 0:
             return []
-        self._ensure_built()
-        g = self._batch.compute_gradient(self._positions()).cpu().numpy()
+        batch = self._batch
+        g = batch.compute_gradient(self._positions()).cpu().numpy()
         return self._nest([g[3 * self._atom_starts[s]:3 * self._atom_starts[s + 1]].tolist() for s in range(len(self._systems))])
 
     def minimize(self, maxIters: int | None = None, forceTol: float = 1e-4,
@@ -310,9 +265,9 @@ class FlatBatchedForcefield:
             if output == CoordinateOutput.DEVICE:
                 raise ValueError("minimize(output=DEVICE) requires at least one molecule")
             return [], []
-        self._ensure_built()
+        batch = self._batch
         pos = self._positions()
-        energies, statuses, _ = self._batch.minimize(pos, max_iters=int(maxIters), grad_tol=float(forceTol), scale_grads=True)
+        energies, statuses, _ = batch.minimize(pos, max_iters=int(maxIters), grad_tol=float(forceTol), scale_grads=True)
         if output == CoordinateOutput.DEVICE:
             gpu = self.device.index if self.device.index is not None else torch.cuda.current_device()
             if targetGpu is not None and int(targetGpu) >= 0 and int(targetGpu) != gpu:

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import ff as off
-from nvmolkit_amd.batchedForcefield import FlatBatchedForcefield, _resolve_constraints
+from nvmolkit_amd.batchedForcefield import FlatBatchedForcefield, _MoleculeRestraints
 from nvmolkit_amd.forcefield import MMFF, UFF
 from nvmolkit_amd.types import CoordinateOutput, Device3DResult
 from tests import util
@@ -49,23 +49,32 @@ def test_constraint_energies_closed_form():
 
 def test_constraint_resolution_relative_bounds_and_validation():
     xyz = np.array([[0.0, 0, 0], [2.0, 0, 0], [2.0, 1.0, 0], [2.0, 1.0, 1.0]])
-    from nvmolkit_amd.batchedForcefield import (_AngleConstraint, _DistanceConstraint, _PositionConstraint,
-                                                _TorsionConstraint)
+    edits = []
 
-    g = _resolve_constraints(xyz, [_DistanceConstraint(0, 1, True, -0.5, 0.25, 7.0), _DistanceConstraint(0, 1, True, -5.0, -4.0, 1.0)],
-                             [_PositionConstraint(3, 0.1, 9.0)], [_AngleConstraint(0, 1, 2, True, -5.0, 5.0, 2.0)],
-                             [_TorsionConstraint(0, 1, 2, 3, True, 100.0, 120.0, 3.0)])
+    def restraints():
+        return _MoleculeRestraints(0, 4, lambda: edits.append(1))
+
+    r = restraints()
+    r.add("distance", (0, 1), True, -0.5, 0.25, 7.0)
+    r.add("distance", (0, 1), True, -5.0, -4.0, 1.0)
+    r.add("position", (3,), False, 0.0, 0.1, 9.0)
+    r.add("angle", (0, 1, 2), True, -5.0, 5.0, 2.0)
+    r.add("torsion", (0, 1, 2, 3), True, 100.0, 120.0, 3.0)
+    assert len(edits) == 5 and bool(r) and not bool(restraints())                                             # every addition is announced
+    g = r.rows_for(xyz)
     assert g[0][0].tolist() == [[0, 1], [0, 1]] and g[0][1].tolist() == [[1.5, 2.25, 7.0], [0.0, 0.0, 1.0]]   # clamped at 0
-    assert g[1][1].tolist() == [[2.0, 1.0, 1.0, 0.1, 9.0]]                                                    # anchored here
+    assert g[1][0].tolist() == [[3]] and g[1][1].tolist() == [[2.0, 1.0, 1.0, 0.1, 9.0]]                      # anchored here
     assert g[2][1][0] == pytest.approx([85.0, 95.0, 2.0])
     phi = off.signed_dihedral_deg(*(xyz[[k]] for k in range(4)))[0]
     assert g[3][1][0] == pytest.approx([off._normalize_deg(phi + 100.0), off._normalize_deg(phi + 120.0), 3.0])
-    with pytest.raises(ValueError, match="maxLen"):
-        _resolve_constraints(xyz, [_DistanceConstraint(0, 1, False, 2.0, 1.0, 1.0)], [], [], [])
-    with pytest.raises(ValueError, match=r"\[0, 180\]"):
-        _resolve_constraints(xyz, [], [], [_AngleConstraint(0, 1, 2, True, 0.0, 100.0, 1.0)], [])
-    with pytest.raises(ValueError, match="maxDihedralDeg"):
-        _resolve_constraints(xyz, [], [], [], [_TorsionConstraint(0, 1, 2, 3, False, 10.0, 5.0, 1.0)])
+    for quantity, atoms, relative, lo, hi, message in (("distance", (0, 1), False, 2.0, 1.0, "maxLen"), ("angle", (0, 1, 2), True, 0.0, 100.0, r"\[0, 180\]"),
+                                                       ("torsion", (0, 1, 2, 3), False, 10.0, 5.0, "maxDihedralDeg")):
+        bad = restraints()
+        bad.add(quantity, atoms, relative, lo, hi, 1.0)
+        with pytest.raises(ValueError, match=message):
+            bad.rows_for(xyz)
+    with pytest.raises(IndexError, match="no atom 4"):
+        restraints().add("distance", (0, 4), False, 0.0, 1.0, 1.0)
 
 
 # ---------------- GPU parity ----------------
