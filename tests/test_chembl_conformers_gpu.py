@@ -59,7 +59,21 @@ def test_mmff_energies_decrease_and_equal_the_oracle_energy(chembl):
     batch = FlatForcefieldBatch(MMFF, a_s, stack_molecule_tables(MMFF, tables), system_mol=mol_of)
     e0 = batch.compute_energy(dev.values.torch().reshape(-1).contiguous())
     e1 = opt.energies.torch()
-    assert bool((e1 <= e0 + 1e-9).all())
+    # A minimisation should never end above its start.  One conformer in 88 251 does for seed 1 with five equal batches (84.682 ->
+    # 84.912 kcal/mol, "converged" after 0 iterations; none with 16 384-attempt batches: the population differs) — and the C oracle's
+    # BFGS, a restatement of RDKit's, does exactly the same from the same start: its line search backtracks to a step shorter than
+    # its resolution (lambda < MOVETOL / test), takes that trial point without the sufficient-decrease test, and TOLX ends the
+    # minimisation there; a step of 1e-7 that raises the energy by 0.23 means the start sits on a DISCONTINUITY of this energy
+    # surface (generic parameters on real topologies; tools/diag_chembl_energy.py prints the term groups).  So the check is parity:
+    # every such conformer must be reproduced by the oracle, and there must be very few.
+    uphill = torch.nonzero(~(e1 <= e0 + 1e-9)).flatten().cpu().numpy()
+    assert len(uphill) <= max(3, dev.num_conformers // 20000), f"{len(uphill)} minimisations ended above their start"
+    start = dev.values.torch().cpu().numpy()
+    for c in uphill:
+        n = int(a_s[c + 1] - a_s[c])
+        one = ffc.Batch(MMFF, np.array([0, n]), stack_molecule_tables(MMFF, [tables[int(mol_of[c])]]))
+        _, e_cpu, st_cpu, it_cpu = one.minimize(start[a_s[c]:a_s[c + 1]].reshape(-1), max_iters=200)
+        assert it_cpu[0] == 0 and abs(e_cpu[0] - float(e1[c])) <= 1e-8 * max(1.0, abs(e_cpu[0])), (int(c), float(e0[c]), float(e1[c]), float(e_cpu[0]))
     sel = np.sort(np.random.default_rng(1).choice(dev.num_conformers, size=256, replace=False))
     xyz = opt.values.torch().cpu().numpy()
     sub_as = np.concatenate([[0], np.cumsum(np.diff(a_s)[sel])])
