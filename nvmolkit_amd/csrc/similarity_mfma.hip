@@ -704,7 +704,7 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
     // auto: the whole pass of a set with at least 1024 panels (four per CU: below that the sweeps are too few to fill the chip and the
     // 128 x 128 tiles win, 23.5 against 24.4 ms at 100 000 rows); a row shard of the pass stays on the tile kernel unless forced
     const bool large = whole && a.tileRowLo == 0u && a.nX >= 1024 * static_cast<int64_t>(panel::ROWS);
-    if (applies && (which.is("panel") || which.is("panel_barrier") || (large && !which.is("tile")))) {
+    if (applies && (which.is("panel") || (large && !which.is("tile")))) {
       static std::atomic<int> cus[64] = {};  // per device
       int                     dev = 0;
       NVMK_HIP_CHECK(hipGetDevice(&dev));
@@ -719,16 +719,14 @@ int launch_counts(const CountArgs& a, const Prepared& X, const Prepared& Y, int3
       const unsigned panelLo = a.tileRowLo / 2u, panelHi = whole ? panels : a.tileRowHi / 2u;
       using PKern = void (*)(const uint4*, const int32_t*, int64_t, int, int32_t*, int2*, unsigned long long*, unsigned long long, double,
                              double, double, float, unsigned, unsigned, int, int*);
-      // NVMK_COUNT_KERNEL=panel_barrier: the four waves of a workgroup meet at an s_barrier per chunk (round 4's form); otherwise
-      // they run free of each other on arrival counters (count_panel.inc)
-      const bool freeWaves = !which.is("panel_barrier");
-      auto pick = [&](auto ksteps) -> PKern {
-        constexpr int K = decltype(ksteps)::value;
-        if (freeWaves) return emit ? neighbor_count_panel_kernel<true, K, true> : neighbor_count_panel_kernel<false, K, true>;
-        return emit ? neighbor_count_panel_kernel<true, K, false> : neighbor_count_panel_kernel<false, K, false>;
-      };
-      const PKern pk = X.L.Wp == 64 ? pick(std::integral_constant<int, 32>{}) : X.L.Wp == 32 ? pick(std::integral_constant<int, 16>{})
-                                                                                          : pick(std::integral_constant<int, 8>{});
+      PKern pk;
+      if (X.L.Wp == 64) {
+        pk = emit ? neighbor_count_panel_kernel<true, 32> : neighbor_count_panel_kernel<false, 32>;
+      } else if (X.L.Wp == 32) {
+        pk = emit ? neighbor_count_panel_kernel<true, 16> : neighbor_count_panel_kernel<false, 16>;
+      } else {
+        pk = emit ? neighbor_count_panel_kernel<true, 8> : neighbor_count_panel_kernel<false, 8>;
+      }
       NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, panel::LDS_BYTES));
       int* groupBarrier = nullptr;  // one arrival counter per XCD group, stream-ordered like the launch itself
       NVMK_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&groupBarrier), 16 * sizeof(int), stream));  // [8 + xcd]: that group gave up waiting

@@ -13,22 +13,20 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["valu", "mfma", "mfma:dense", "mfma:serial", "mfma:table", "mfma:nosort", "mfma:panel", "mfma:panel-nosort", "mfma:panel_barrier", "auto"],
-                autouse=True)
+@pytest.fixture(params=["valu", "mfma", "mfma:dense", "mfma:serial", "mfma:table", "mfma:nosort", "mfma:panel", "mfma:panel-nosort", "auto"], autouse=True)
 def sim_path(request):
     """Neighbour counting / fused Butina run on the v_bcnt kernels, on the FP4 matrix-core kernels (round loop on the
     sparse neighbour graph, as parallel sweeps over a bucket or — serial — one round at a time on a persistent workgroup;
     the dense round loop that streams the fingerprint matrix; the tile kernel
     with the threshold TABLE instead of the exact-arithmetic predicate it uses for thresholds in [2^-10, 1]; the all-pairs pass
-    on the row-panel kernel, csrc/count_panel.inc — its waves running free on arrival counters, with and without the popcount-sorted
-    copy, and meeting at a barrier per chunk, round 4's form) and on the
+    on the row-panel kernel, csrc/count_panel.inc, with and without the popcount-sorted copy) and on the
     library's automatic choice (the switches are set through nvmk_set_option: the library reads the environment once)."""
     path, _, variant = request.param.partition(":")
     with _native.options(NVMK_SIM_PATH=path, NVMK_BUTINA_ROUNDS=variant if variant in ("dense", "serial") else None,
                          NVMK_COUNT_THRESHOLD="table" if variant == "table" else None,
                          # fused Butina: all-pairs pass in input order (default: popcount-sorted copy with tile skipping)
                          NVMK_BUTINA_SORT="0" if variant in ("nosort", "panel-nosort") else None,
-                         NVMK_COUNT_KERNEL="panel_barrier" if variant == "panel_barrier" else "panel" if variant.startswith("panel") else None):
+                         NVMK_COUNT_KERNEL="panel" if variant.startswith("panel") else None):
         yield request.param
 
 METRICS = {"tanimoto": oracle.TANIMOTO, "cosine": oracle.COSINE}

@@ -86,21 +86,16 @@ def test_fused_butina_properties_at_full_size(data, monkeypatch):
     assert tail == sorted(tail)                                     # singleton tail ascending
 
 
-def test_free_running_panel_waves_lose_no_signal_over_twenty_passes(data):
-    """Lost-signal detection for the row-panel count kernel whose waves synchronise through LDS arrival counters (round 5,
-    csrc/count_panel.inc): twenty all-pairs passes over the 1M rows, neighbour counts AND the emitted pair list (through the fused
-    clustering, which consumes every pair) bit for bit equal to the barrier form's."""
-    from nvmolkit_amd.clustering import fused_butina
-
+def test_twenty_passes_of_the_row_panel_kernel_give_the_same_counts(data):
+    """The row-panel count kernel synchronises its workgroups through global arrival counters (the group start barrier) and its
+    waves through hand-placed waits: twenty all-pairs passes over the 1M rows must give the same neighbour counts every time, and
+    those of the 128 x 128 tile kernel."""
     x = data
-    with _native.options(NVMK_SIM_PATH="mfma", NVMK_COUNT_KERNEL="panel_barrier"):
+    with _native.options(NVMK_SIM_PATH="mfma", NVMK_COUNT_KERNEL="tile"):
         want = torch.zeros(N, dtype=torch.int32, device="cuda")
         update_neighbor_counts(x, x, want, THR)
-        want_clusters = fused_butina(x, 1.0 - THR)
     with _native.options(NVMK_SIM_PATH="mfma", NVMK_COUNT_KERNEL="panel"):
         for k in range(20):
             got = torch.zeros(N, dtype=torch.int32, device="cuda")
             update_neighbor_counts(x, x, got, THR)
             assert torch.equal(got, want), f"pass {k}: {int((got != want).sum())} rows differ"
-        for k in range(3):
-            assert fused_butina(x, 1.0 - THR) == want_clusters, f"clustering {k}"

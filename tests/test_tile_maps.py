@@ -183,30 +183,3 @@ def test_row_panel_dma_accounting(maps):
                 last_own = max(i for i, (c, kind) in enumerate(ops) if c == q and kind == "data")
                 assert maps.chk_panel_pending_after(chunks_per_tile, dist, q % chunks_per_tile) == len(ops) - 1 - last_own
                 issue(q + dist)
-
-
-def test_row_panel_dma_accounting_of_free_running_waves(maps):
-    """Round 5: the waves of a workgroup signal a chunk AHEAD steps before its use — at step c a wave waits for ITS DMA of chunk
-    c + AHEAD (count_panel.inc: vm_wait<panel_pending_after(CH, D - AHEAD, (ch + AHEAD) % CH)>), and before the first step for chunks
-    0 .. AHEAD - 1 (vm_wait<panel_pending_after(CH, D - (AHEAD - 1), (AHEAD - 1) % CH)>).  Replayed like the test above — for the
-    kernel's (AHEAD, D) = (2, 12) and the first form tried, (3, 10); also the buffer a step's DMA lands in belongs to a chunk every
-    wave has finished reading although the slowest may be AHEAD steps behind."""
-    ring = 16
-    for chunks_per_tile in (2, 4, 8):
-        for ahead, dist in ((2, 12), (3, 10)):
-            ops = []
-            def issue(q):
-                if q % chunks_per_tile == 0:
-                    ops.append((q, "popcounts"))
-                ops.extend([(q, "data"), (q, "data")])
-            for q in range(dist):
-                issue(q)
-            last = max(i for i, (c, kind) in enumerate(ops) if c == ahead - 1 and kind == "data")
-            assert maps.chk_panel_pending_after(chunks_per_tile, dist - (ahead - 1), (ahead - 1) % chunks_per_tile) == len(ops) - 1 - last
-            for c in range(60):
-                last = max(i for i, (q, kind) in enumerate(ops) if q == c + ahead and kind == "data")
-                assert maps.chk_panel_pending_after(chunks_per_tile, dist - ahead, (c + ahead) % chunks_per_tile) == len(ops) - 1 - last
-                issue(c + dist)
-                # the DMA of chunk c + dist lands in the buffer of chunk c + dist - ring; the slowest wave has passed the signal of its
-                # step c - ahead, i.e. finished reading every chunk up to c - ahead - 1
-                assert c + dist - ring <= c - ahead - 1

@@ -24,7 +24,6 @@
 #   markers             rocprofv3 --marker-trace --kernel-trace of one ETKDG + MMFF run (roctx ranges of the library)
 #   chembl              the conformer block on the ChEMBL topologies (tools/bench_conformers.py --set chembl)
 #   strong              bench.py strong-scaling conformer mode as one rank over RCCL
-#   ab_panel            tools/bench_butina.py with the row-panel kernel's waves at a barrier per chunk / running free, alternating
 #   butina_tests        the clustering, full-size, benchmark-molecule and sharded-Butina GPU tests
 #   diag_chembl         tools/diag_chembl_energy.py (which conformers end an MMFF minimisation above their starting energy)
 #   butina              tools/bench_butina.py + clustering tests (ab_butina: the bench alone, tile against panel kernel)
@@ -228,12 +227,6 @@ PY
       NVMK_BENCH_SINGLE_RANK_COLLECTIVES=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
         bench.py --gpus 1 --steps 3 --warmup 1 --conformer-total 100000 > $O/bench_strong_single_rank.json 2> $O/bench_strong.err
       tail -c 2500 $O/bench_strong_single_rank.json
-      ;;
-    ab_panel)
-      for T in panel_barrier panel panel_barrier panel; do
-        echo "NVMK_COUNT_KERNEL=$T" | tee -a $O/ab_panel.txt
-        NVMK_COUNT_KERNEL=$T timeout 300 python tools/bench_butina.py 2>/dev/null | tail -4 | cut -c1-700 | tee -a $O/ab_panel.txt
-      done
       ;;
     butina_tests)
       ( time timeout 1200 python -m pytest tests/test_clustering_gpu.py tests/test_full_size_gpu.py tests/test_benchmark_molecules_gpu.py tests/test_distributed_gpu.py -m gpu -q -x ) > $O/butina_tests.log 2>&1
