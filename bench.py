@@ -542,11 +542,13 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     return out
 
 
-def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int = 128) -> dict:
+def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int | None = 128) -> dict:
     """BASELINE.json configs[2] on the reference's own molecules: the 10 000 SMILES of benchmarks/data/chembl_10k.smi through
     the library's ingestion (benchmarks/etkdg_bench.py:154-161 reads them with RDKit), explicit hydrogens from the valence
     model (benchmarks/bench_utils/molprep.py:21-55: AddHs), ETKDG + MMFF94 on the REAL topologies with generic parameters
-    (synthetic.graph_molecule).  Molecules beyond ``max_atoms`` atoms are left out and counted."""
+    (synthetic.graph_molecule).  Molecules beyond ``max_atoms`` atoms are left out and counted (``None``: the whole file, to 1063
+    atoms — two minutes on one MI355X, dominated by a few hundred peptides and macrocycles whose 5 - 72 MB inverse Hessians stream
+    through one workgroup each: --chembl-all, not part of the default line)."""
     from nvmolkit_amd import synthetic
     from nvmolkit_amd.fingerprints import SmilesSet
 
@@ -558,11 +560,11 @@ def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int = 128) -> d
     t_library = time.perf_counter() - t0
     out = conformer_block(len(library), confs, mmff_iters, device, 1, 0, 0.0, library, t_library,
                           data=f"topologies of tests/golden/chembl_10k.smi (the reference's benchmarks/data/chembl_10k.smi) with explicit "
-                               f"hydrogens, at most {max_atoms} atoms; synthetic (generic) parameters: bounds from covalent radii, hybridisation "
+                               f"hydrogens, {'every molecule' if max_atoms is None else f'at most {max_atoms} atoms'}; synthetic (generic) parameters: bounds from covalent radii, hybridisation "
                                f"and ring-size angles, cis / trans 1-4 windows, triangle smoothing; MMFF94-shaped terms with the same rest values")
     out["atoms_histogram_of_the_whole_file"] = {"molecules": int(len(totals)), "mean": float(totals.mean()),
                                                 "percentiles_1_10_50_90_99_max": [int(x) for x in np.percentile(totals, [1, 10, 50, 90, 99, 100])],
-                                                "fraction_beyond_the_cut": float((totals > max_atoms).mean())}
+                                                "fraction_beyond_the_cut": float((totals > max_atoms).mean()) if max_atoms is not None else 0.0}
     sizes = np.array([m["embed"]["n_atoms"] for m in library])
     out["atoms_percentiles_of_the_run_5_25_50_75_95_max"] = [int(x) for x in np.percentile(sizes, [5, 25, 50, 75, 95, 100])]
     out.pop("roofline", None)  # the PMC traffic file is for the synthetic set; the block is reported as throughput
@@ -594,6 +596,9 @@ def main() -> None:
                          "job, dealt over the ranks by cost (distributed.shard_molecules_by_cost); 0 = weak scaling, --conformer-mols per GPU")
     ap.add_argument("--chembl", type=int, default=1,
                     help="1: also run the conformer block on the ChEMBL topologies of tests/golden/chembl_10k.smi (single GPU), 0: skip")
+    ap.add_argument("--chembl-all", type=int, default=0,
+                    help="1: also run the conformer block on EVERY molecule of that file (to 1063 atoms; about two minutes), reported as "
+                         "secondary.conformers_chembl_all")
     ap.add_argument("--conformer-confs", type=int, default=10)
     ap.add_argument("--cfg1", type=int, default=1, help="1: also run BASELINE configs[0] (10k SMILES -> Morgan -> 10k x 10k), 0: skip")
     ap.add_argument("--mmff-iters", type=int, default=200, help="MMFF maxIters (the reference benchmark's default)")
@@ -809,6 +814,8 @@ def main() -> None:
                     args.cpu_seconds)
             if args.chembl:
                 guarded("conformers_chembl", chembl_block, args.conformer_confs, args.mmff_iters, device)
+            if args.chembl_all:
+                guarded("conformers_chembl_all", chembl_block, args.conformer_confs, args.mmff_iters, device, None)
         else:  # ranks meet in collectives inside the block: an exception on one rank must end the job, not hang the others
             block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds,
                                     library, t_library, collectives=True, strong_total=args.conformer_total)

@@ -1,0 +1,88 @@
+"""The reference's benchmark file WITHOUT a size cut: every molecule of benchmarks/data/chembl_10k.smi
+(tests/golden/chembl_10k.smi) that the ingestion accepts — 10 000 molecules, 12 to 1063 atoms with hydrogens, 1052 of them beyond 128
+atoms, 63 beyond 512 — through ETKDG and MMFF94 (real topologies, generic parameters: synthetic.graph_molecule).  The reference's
+benchmarks/etkdg_bench.py feeds the whole file too; its kernels fall back to global memory for the large ones
+(src/minimizer/bfgs_minimize_permol_kernels.cu:796-932), here they run in the four-wave classes B (vectors in one CU's LDS, up to 1320
+coordinates) and C (vectors in HBM).  TWO conformers per molecule instead of the benchmark's ten keep the test to about a minute of
+GPU time (the ten-conformer run takes 125 s, profiles/r05_conformers/chembl_topologies_whole_file.json: a 4252-coordinate triangle is
+72 MB, read and written once per BFGS iteration by ONE workgroup).  Checked like the cut set: counts, distance bounds of sampled
+conformers of every size class, energies against the C oracle, no minimisation ending above its start unless the oracle's does too."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from nvmolkit_amd import mmffOptimization, synthetic
+from nvmolkit_amd.embedMolecules import FlatMolecule, FlatMoleculeSet, embed_flat
+from nvmolkit_amd.forcefield import MMFF, FlatForcefieldBatch, stack_molecule_tables
+from nvmolkit_amd.types import CoordinateOutput
+from oracle import ffc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def whole_file():
+    lib, ids = synthetic.smiles_file_library(GOLDEN / "chembl_10k.smi")
+    molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in lib])
+    pending = mmffOptimization.resident_tables([m["mmff"] for m in lib], wait=False)      # assembled while ETKDG runs
+    dev = embed_flat(molset, confs_per_molecule=2, max_iterations=10, seed=1, output=CoordinateOutput.DEVICE)
+    opt = mmffOptimization.optimize_device(pending, dev, max_iters=200)
+    torch.cuda.synchronize()
+    return lib, dev, opt
+
+
+def test_every_size_class_of_the_file_gets_conformers_within_its_bounds(whole_file):
+    lib, dev, _ = whole_file
+    sizes = np.array([m["embed"]["n_atoms"] for m in lib])
+    assert len(lib) == 10_000 and sizes.max() == 1063 and (sizes > 128).sum() > 1000 and (sizes > 512).sum() > 50
+    mol_of = dev.mol_indices.torch().cpu().numpy()
+    per_mol = np.bincount(mol_of, minlength=len(lib))
+    assert per_mol.max() <= 2 and (per_mol > 0).mean() > 0.93
+    for lo, hi, least in ((0, 128, 0.93), (128, 256, 0.85), (256, 2000, 0.5)):        # the yield falls with size (more checks to pass), never to nothing
+        band = (sizes > lo) & (sizes <= hi)
+        assert (per_mol[band] > 0).mean() > least, (lo, hi, float((per_mol[band] > 0).mean()))
+    xyz = dev.values.torch().cpu().numpy()
+    a_s = dev.atom_starts.torch().cpu().numpy()
+    rng = np.random.default_rng(0)
+    conf_size = sizes[mol_of]
+    picks = np.concatenate([rng.choice(np.flatnonzero((conf_size > lo) & (conf_size <= hi)), size=k, replace=False)
+                            for lo, hi, k in ((0, 128, 150), (128, 256, 60), (256, 2000, 25))])
+    worst = []
+    for c in picks:
+        pairs, lb, ub = lib[mol_of[c]]["bounds"]
+        p = xyz[a_s[c]:a_s[c + 1]]
+        d = np.linalg.norm(p[pairs[:, 0]] - p[pairs[:, 1]], axis=1)
+        worst.append(float(np.max(np.maximum(np.maximum(lb - d, d - ub), 0.0) / ub)))
+    assert np.median(worst) < 0.1 and np.percentile(worst, 95) < 0.3 and max(worst) < 0.9
+
+
+def test_mmff_on_the_whole_file_equals_the_oracle_energy(whole_file):
+    lib, dev, opt = whole_file
+    tables = [m["mmff"] for m in lib]
+    a_s = dev.atom_starts.torch().cpu().numpy()
+    mol_of = dev.mol_indices.torch().to(torch.int32)
+    sizes = np.diff(a_s)
+    batch = FlatForcefieldBatch(MMFF, a_s, stack_molecule_tables(MMFF, tables), system_mol=mol_of)
+    e0 = batch.compute_energy(dev.values.torch().reshape(-1).contiguous())
+    e1 = opt.energies.torch()
+    assert bool(torch.isfinite(e1).all())
+    uphill = torch.nonzero(~(e1 <= e0 + 1e-9)).flatten().cpu().numpy()      # see tests/test_chembl_conformers_gpu.py: must be the oracle's too
+    assert len(uphill) <= 3
+    start = dev.values.torch().cpu().numpy()
+    for c in uphill:
+        one = ffc.Batch(MMFF, np.array([0, sizes[c]]), stack_molecule_tables(MMFF, [tables[int(mol_of[c])]]))
+        _, e_cpu, _, it_cpu = one.minimize(start[a_s[c]:a_s[c + 1]].reshape(-1), max_iters=200)
+        assert it_cpu[0] == 0 and abs(e_cpu[0] - float(e1[c])) <= 1e-8 * max(1.0, abs(e_cpu[0]))
+    # energies of the returned coordinates, re-evaluated by the C oracle: a sample of every size class, the largest conformer included
+    rng = np.random.default_rng(1)
+    sel = np.unique(np.concatenate([rng.choice(np.flatnonzero((sizes > lo) & (sizes <= hi)), size=k, replace=False)
+                                    for lo, hi, k in ((0, 128, 120), (128, 256, 50), (256, 2000, 20))] + [[int(np.argmax(sizes))]]))
+    xyz = opt.values.torch().cpu().numpy()
+    sub_as = np.concatenate([[0], np.cumsum(sizes[sel])])
+    sub_pos = np.concatenate([xyz[a_s[c]:a_s[c + 1]].reshape(-1) for c in sel])
+    cpu = ffc.Batch(MMFF, sub_as, stack_molecule_tables(MMFF, tables), system_mol=mol_of.cpu().numpy()[sel])
+    np.testing.assert_allclose(e1.cpu().numpy()[sel], cpu.energy(sub_pos), rtol=1e-9, atol=1e-7)

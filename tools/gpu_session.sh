@@ -8,7 +8,8 @@
 #   ab_conformers       tools/bench_conformers.py --mols 10000 with every nvmolkit_amd/lib/libnvmolkit_amd_<variant>.so beside the product
 #   ab_sched            bench_conformers with NVMK_BFGS_SCHED=hw and queue, alternating
 #   conformer_traffic_seq  the PMC passes with the size classes one after the other (NVMK_BFGS_OVERLAP=0)
-#   chembl_tests        tests/test_chembl_conformers_gpu.py
+#   chembl_tests        tests/test_chembl_conformers_gpu.py + tests/test_chembl_whole_file_gpu.py
+#   sq_counters         SQ PMC counters of the BFGS kernels and the row-panel count kernel -> sq_counters.json (tools/sq_summary.py)
 #   timeline            BFGS per-system timeline of one 10 000-molecule run (NVMK_BFGS_PROFILE=1 NVMK_BFGS_TIMELINE)
 #   conformer_traffic   tools/profile_conformer_traffic.sh 2000
 #   table_tests         the table builder's GPU tests + the suites that build batches through it
@@ -138,8 +139,22 @@ PY
       timeout 600 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 256 --cache $CACHE 2> $O/chembl256.err | tee $O/chembl256.json | cut -c1-700
       ;;
     chembl_tests)
-      ( time timeout 900 python -m pytest tests/test_chembl_conformers_gpu.py -m gpu -q -x ) > $O/chembl_tests.log 2>&1
+      ( time timeout 1500 python -m pytest tests/test_chembl_conformers_gpu.py tests/test_chembl_whole_file_gpu.py -m gpu -q ) > $O/chembl_tests.log 2>&1
       tail -15 $O/chembl_tests.log
+      ;;
+    sq_counters)
+      # SQ counters of the BFGS kernels (2000 molecules of the benchmark set) and of the row-panel count kernel (1M rows), two passes
+      # of eight SQ counters each (MI355X_MICROARCH.md: 8 SQ slots per pass), never combined with tracing
+      cd /tmp
+      CONF="python $ROOT/tools/bench_conformers.py --mols 2000 --cache $CACHE"
+      PANEL="python $ROOT/tools/bench_butina.py 1000000 --skip-butina"
+      timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES -f csv -d $O/sq_conf_1 -- $CONF > $O/sq_conf_1.log 2>&1
+      timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD -f csv -d $O/sq_conf_2 -- $CONF > $O/sq_conf_2.log 2>&1
+      timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES -f csv -d $O/sq_panel_1 -- $PANEL > $O/sq_panel_1.log 2>&1
+      timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE -f csv -d $O/sq_panel_2 -- $PANEL > $O/sq_panel_2.log 2>&1
+      cd $ROOT
+      python tools/sq_summary.py $O > $O/sq_counters.json && head -c 3500 $O/sq_counters.json
+      rm -rf $O/sq_conf_1 $O/sq_conf_2 $O/sq_panel_1 $O/sq_panel_2
       ;;
     timeline)
       rm -f $O/bfgs_timeline.txt
