@@ -8,6 +8,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
+COMMITTED_LINE = "r05_final_bench.json"
 
 
 def test_flags_and_defaults():
@@ -21,7 +22,7 @@ def test_flags_and_defaults():
 
 
 def test_committed_bench_line_has_every_field_of_the_contract():
-    line = json.loads((ROOT / "profiles" / "r04_final_bench_panel_kernel.json").read_text().strip().splitlines()[-1])
+    line = json.loads((ROOT / "profiles" / COMMITTED_LINE).read_text().strip().splitlines()[-1])
     baseline = json.loads((ROOT / "BASELINE.json").read_text())
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -55,8 +56,51 @@ def test_committed_bench_line_has_every_field_of_the_contract():
     assert conf["roofline"]["frac_hbm_requested"] <= conf["roofline"]["frac_algorithmic"]
     for key in ("library_generation_seconds", "flatten_and_table_upload_seconds", "per_rank_seconds", "imbalance_max_over_mean"):
         assert key in conf, key
+    # round 5: table assembly is inside the clock (the figure with tables already resident beside it, same bits), the roofline
+    # fraction says which bytes it divides, and Morgan has a block of its own
+    assert "table assembly" in conf["timed_region"] and conf["resident_tables_run_gave_the_same_bits"] is True
+    assert 0.0 < conf["table_assembly_host_seconds"] < 0.2 * conf["per_rank_seconds"][0]
+    assert conf["mmff_tables_wait_seconds"] < 0.05 * conf["per_rank_seconds"][0]          # hidden under ETKDG
+    assert conf["value"] <= conf["resident_tables_value"] <= 1.25 * conf["value"]
+    assert abs(conf["value"] - conf["molecules"] / conf["per_rank_seconds"][0]) < 1e-6 * conf["value"]
+    croof = conf["roofline"]
+    assert croof["frac_is"] in ("frac_measured_traffic", "frac_hbm_requested") and croof["frac"] == croof[croof["frac_is"]]
+    assert (croof["frac_is"] == "frac_measured_traffic") == (croof["traffic"] is not None)
+    morgan = line["secondary"]["morgan"]["buckets"]
+    assert set(morgan) == {"32", "64", "128"} and all(b["mols_per_s"] > 1e6 and b["algorithmic_GB_per_s"] > 0 for b in morgan.values())
     chembl = line["secondary"]["conformers_chembl"]
     assert chembl["molecules"] > 8000 and chembl["value"] > 0.0 and "chembl_10k.smi" in chembl["data"]
+
+
+def test_committed_bench_line_quotes_counter_files_of_the_same_kernel_sources():
+    """A traffic figure measured on other kernels is not this line's traffic: every PMC file a roofline object names under profiles/
+    must exist and carry the kernel-source digest the line itself carries for that path (bench.py refuses a mismatch at run time;
+    this refuses a committed pair that does not belong together)."""
+    line = json.loads((ROOT / "profiles" / COMMITTED_LINE).read_text().strip().splitlines()[-1])
+    digests = line["kernel_source_sha256"]
+    assert set(digests) >= {"similarity", "conformers", "neighbour_count"} and all(len(v) == 64 for v in digests.values())
+    quoted = 0
+    for which, roof in (("similarity", line["roofline"]), ("conformers", line["secondary"]["conformers"]["roofline"])):
+        if roof["traffic"] is None:
+            continue
+        name = roof["traffic_source"].split(":")[0]
+        assert name.startswith("profiles/r05_"), name
+        pmc = json.loads((ROOT / name).read_text())
+        assert pmc["kernel_source_sha256"] == digests[which], (name, which)
+        quoted += 1
+    assert quoted == 2                                   # the round's line has both figures measured
+
+
+def test_committed_bench_line_was_measured_on_the_kernel_sources_in_the_tree():
+    """profiles/ holds the line of THIS tree: whoever edits a kernel source re-measures (tools/gpu_session.sh final ...) and commits
+    the new line with it.  Comments count as edits; that is the price of a digest."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    line = json.loads((ROOT / "profiles" / COMMITTED_LINE).read_text().strip().splitlines()[-1])
+    now = {"similarity": bench.kernel_source_digest(), "conformers": bench.conformer_source_digest(),
+           "neighbour_count": bench.kernel_source_digest(("similarity_mfma.hip", "count_panel.inc", "fp4.h", "tile_maps.h"))}
+    assert line["kernel_source_sha256"] == now
 
 
 def test_multi_rank_start_up_pieces_without_a_gpu(tmp_path):
