@@ -118,7 +118,13 @@ struct BfgsArgs {
 }  // namespace minim
 }  // namespace nvmk
 
-// four waves per system (every size), then one wave per system (small systems: eight or six of them share a CU)
+// four waves per system (every size), eight for the largest (one system per CU), two and one for the small ones (four / eight of
+// them share a CU)
+#define NVMK_BFGS_NS t512
+#define NVMK_BFGS_THREADS 512
+#include "bfgs_device.inc"
+#undef NVMK_BFGS_NS
+#undef NVMK_BFGS_THREADS
 #define NVMK_BFGS_NS t256
 #define NVMK_BFGS_THREADS 256
 #include "bfgs_device.inc"
@@ -358,21 +364,30 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   const int     kWave2MaxN = wave2Opt > 1 ? static_cast<int>(std::min<long>(wave2Opt, 2000)) : wave2Opt == 0 ? 0 : 256;
   const BinDef  kBins[]  = {{64, 8, 176}, {64, 6, 232}, {64, 4, kNoLimit}, {64, 3, kNoLimit}, {64, 2, kNoLimit}, {64, 1, kNoLimit},
                             {128, 4, kNoLimit}, {128, 2, kNoLimit}, {128, 1, kNoLimit},
-                            {256, 2, kNoLimit}, {256, 1, kNoLimit}};
-  constexpr int nBins = 11, kFirst128 = 6, kFirst256 = 9;
+                            {256, 2, kNoLimit}, {256, 1, kNoLimit}, {512, 1, kNoLimit}};
+  constexpr int nBins = 12, kFirst128 = 6, kFirst256 = 9, kFirst512 = 11;
+  // NVMK_BFGS_WAVE8: the smallest system (coordinates) EIGHT waves take (0 = none), default 656 — where the vectors of a four-wave
+  // system stop fitting half a CU's LDS, so that it would have a CU to itself anyway: with four waves such a system streams its
+  // inverse Hessian at ~15 GB/s, the rate four waves keep in flight, and a batch's large molecules END the batch
+  // (profiles/r05_conformers/bfgs_timeline_summary_chembl_up_to_256_atoms.json: the one-per-CU class spends half of its wall with
+  // fewer than 256 systems in flight).  Eight waves fill the CU's second wave slot per SIMD; their 8 gradient slabs fit LDS up to
+  // 1067 coordinates, beyond that the vectors live in HBM (eight waves as well).
+  const long    wave8Opt  = opt::get(opt::kBfgsWave8).num(1);
+  const int     kWave8MinN = wave8Opt > 1 ? static_cast<int>(std::min<long>(wave8Opt, kNoLimit)) : wave8Opt == 0 ? kNoLimit : 656;
   // static LDS of the kernel + the 512-byte allocation granularity, per workgroup
   auto bin_budget = [&](const int c) { return kLdsPerCu / static_cast<size_t>(kBins[c].wgPerCu) - (kBins[c].wgPerCu > 2 ? 512 : 1024); };
   auto vec_doubles = [](const int threads, const int64_t n) {
-    return threads == 64 ? t64::lds_vector_doubles(n) : threads == 128 ? t128::lds_vector_doubles(n) : t256::lds_vector_doubles(n);
+    return threads == 64 ? t64::lds_vector_doubles(n) : threads == 128 ? t128::lds_vector_doubles(n) : threads == 256 ? t256::lds_vector_doubles(n) : t512::lds_vector_doubles(n);
   };
   auto hess_doubles = [](const int threads, const int64_t ldsDoubles, const int64_t n) {
     return threads == 64    ? t64::lds_hessian_doubles(ldsDoubles, n)
            : threads == 128 ? t128::lds_hessian_doubles(ldsDoubles, n)
-                            : t256::lds_hessian_doubles(ldsDoubles, n);
+           : threads == 256 ? t256::lds_hessian_doubles(ldsDoubles, n)
+                            : t512::lds_hessian_doubles(ldsDoubles, n);
   };
   // (rows resident in LDS: the one-wave kernels round a boundary below 64 rows to a multiple of 8, see hess_pass.h)
   auto resident = [](const int threads, const int n, const int64_t hld) {
-    return threads == 64 ? t64::resident_rows(n, hld) : threads == 128 ? t128::resident_rows(n, hld) : t256::resident_rows(n, hld);
+    return threads == 64 ? t64::resident_rows(n, hld) : threads == 128 ? t128::resident_rows(n, hld) : threads == 256 ? t256::resident_rows(n, hld) : t512::resident_rows(n, hld);
   };
   const size_t kFull = bin_budget(nBins - 1);
   // NVMK_BFGS_LDS: "auto" (default) = the bins above; "full" = every system gets the whole 160 KiB (one workgroup per CU);
@@ -404,27 +419,28 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // slots until their class is drained, so the classes finish largest first and a launch ends on the short systems.
   const bool queueMode = !opt::get(opt::kBfgsSched).is("hw");
   auto       budget_of = [&](const int c) {
-    return (c == 0 || c == kFirst128 || c == kFirst256) ? std::max(firstBudget, bin_budget(c)) : bin_budget(c);
+    return (c == 0 || c == kFirst128 || c == kFirst256 || c == kFirst512) ? std::max(firstBudget, bin_budget(c)) : bin_budget(c);
   };
-  const int  kGlobal   = nBins;  // class index of the HBM-vector systems
+  const int  kGlobal = nBins, kGlobal8 = nBins + 1;  // class indices of the HBM-vector systems: four waves, eight waves
 
   // ---- size classes
   struct Class {
     std::vector<int32_t> order;  // systems, largest first (stable)
     int                  maxN = 0;
   };
-  Class cls[13];
+  Class cls[14];
   for (int s = 0; s < b.nSystems; ++s) {
     const int64_t n64 = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
     NVMK_REQUIRE(n64 >= 0, "bfgs: atom_starts must be non-decreasing");
     NVMK_REQUIRE(n64 <= 46000, "bfgs: a system with %lld coordinates is beyond the packed triangle's 32-bit row offsets",
                  static_cast<long long>(n64));
-    int c = kGlobal;
+    const bool wave8 = waveClass && n64 >= kWave8MinN;
+    int        c     = wave8 ? kGlobal8 : kGlobal;
     if (!allGlobal) {
       // thread count by size alone, then the bin by the LDS policy
       const bool wave  = waveClass && n64 <= kWaveMaxN;
       const bool wave2 = !wave && waveClass && n64 <= kWave2MaxN;
-      const int  lo = wave ? 0 : wave2 ? kFirst128 : kFirst256, hi = wave ? kFirst128 : wave2 ? kFirst256 : nBins;
+      const int  lo = wave ? 0 : wave2 ? kFirst128 : wave8 ? kFirst512 : kFirst256, hi = wave ? kFirst128 : wave2 ? kFirst256 : wave8 ? nBins : kFirst512;
       for (int k = fullOnly ? hi - 1 : lo; k < hi; ++k)
         if (n64 <= kBins[k].maxN && static_cast<size_t>(vec_doubles(kBins[k].threads, n64)) * sizeof(double) <= budget_of(k)) {
           c = k;
@@ -444,7 +460,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // (system_mol), so a run of kXcdGroup consecutive systems goes to ONE XCD: its L2 then holds a handful of molecules'
   // tables instead of one per resident workgroup.  Chunks of 8 * kXcdGroup systems keep the sizes balanced over the XCDs.
   // NVMK_BFGS_XCD_GROUP=1: plain order.
-  auto persistent = [&](const int c) { return queueMode || c == kGlobal || kBins[c].wgPerCu == 1; };
+  auto persistent = [&](const int c) { return queueMode || c >= kGlobal || kBins[c].wgPerCu == 1; };
   for (int c = 0; c < nBins; ++c) {
     if (persistent(c)) continue;
     const long    g         = opt::get(opt::kBfgsXcdGroup).num(32);
@@ -487,21 +503,21 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     std::vector<int64_t> hs;  // one-system-per-workgroup bins: per-system offsets (indexed by system), else empty
     StreamScratch        hessMem, startsMem, orderMem, counterMem, vecMem;
   };
-  Plan   plan[13];
-  size_t slotBytes[13] = {};
-  for (int c = 0; c <= kGlobal; ++c) {
+  Plan   plan[14];
+  size_t slotBytes[14] = {};
+  for (int c = 0; c <= kGlobal8; ++c) {
     Plan& P = plan[c];
     if (cls[c].order.empty()) continue;
     P.used       = true;
-    P.gvec       = c == kGlobal;
+    P.gvec       = c >= kGlobal;
     P.persistent = persistent(c);
-    P.threads    = P.gvec ? 256 : kBins[c].threads;
+    P.threads    = c == kGlobal8 ? 512 : P.gvec ? 256 : kBins[c].threads;
     const int    maxN     = cls[c].maxN;
     const size_t vecBytes = static_cast<size_t>(vec_doubles(P.threads, maxN)) * sizeof(double);
     if (P.gvec) {
       P.shmem      = 0;
       P.ldsDoubles = 0;
-      P.vecStride  = (vec_doubles(256, maxN) + 1) & ~int64_t{1};
+      P.vecStride  = (vec_doubles(P.threads, maxN) + 1) & ~int64_t{1};
     } else {
       const size_t budget = vectorsOnly ? vecBytes : budget_of(c);
       P.shmem      = std::min(budget, vecBytes + static_cast<size_t>(hess_row_offset(maxN)) * sizeof(double));
@@ -528,7 +544,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       }
       P.slotDoubles = ((slot + kHessTailPadDoubles) + 1) & ~int64_t{1};
       slotBytes[c]  = static_cast<size_t>(P.slotDoubles + P.vecStride) * sizeof(double);
-      P.grid        = static_cast<int>(std::min<size_t>(cls[c].order.size(), static_cast<size_t>(nCu) * (P.gvec ? 2 : kBins[c].wgPerCu)));
+      P.grid        = static_cast<int>(std::min<size_t>(cls[c].order.size(), static_cast<size_t>(nCu) * (P.gvec ? (P.threads == 512 ? 1 : 2) : kBins[c].wgPerCu)));
     }
   }
   // A one-system-per-workgroup class holds the HBM part of EVERY system's inverse Hessian for the whole launch (16 384
@@ -567,14 +583,14 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // the persistent classes together take at most half of the free memory (at least one slot each)
   {
     size_t want = 0;
-    for (int c = 0; c <= kGlobal; ++c)
+    for (int c = 0; c <= kGlobal8; ++c)
       if (plan[c].used && plan[c].persistent) want += slotBytes[c] * static_cast<size_t>(plan[c].grid);
     if (want > 0) {
       size_t freeB = 0, totalB = 0;
       NVMK_HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
       if (want > freeB / 2) {
         const double f = static_cast<double>(freeB / 2) / static_cast<double>(want);
-        for (int c = 0; c <= kGlobal; ++c)
+        for (int c = 0; c <= kGlobal8; ++c)
           if (plan[c].used && plan[c].persistent) plan[c].grid = std::max(1, static_cast<int>(plan[c].grid * f));
       }
     }
@@ -583,7 +599,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // `order` and share their term tables) are dealt round-robin to eight queues, one per XCD — a workgroup takes from the
   // queue of the XCD it runs on (its L2 then holds a handful of molecules' tables) and from the others' once that is empty.
   // Every queue keeps the largest-first order.  Few items, or no shared tables: one queue.
-  for (int c = 0; c <= kGlobal; ++c) {
+  for (int c = 0; c <= kGlobal8; ++c) {
     Plan& P = plan[c];
     if (!P.used || !P.persistent) continue;
     auto&         order = cls[c].order;
@@ -602,7 +618,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     P.queueStart[8] = static_cast<int>(queued.size());
     order.swap(queued);
   }
-  for (int c = 0; c <= kGlobal; ++c) {
+  for (int c = 0; c <= kGlobal8; ++c) {
     Plan& P = plan[c];
     if (!P.used) continue;
     const auto& order = cls[c].order;
@@ -689,13 +705,22 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
         if (b.kind == NVMK_FF_ETK) return go(t128::bfgs_kernel<NVMK_FF_ETK, false, true>);
         return go(t128::bfgs_kernel<NVMK_FF_MMFF, false, true>);
       }
+      if (P.threads == 512) {
+        if (b.kind == NVMK_FF_DG) return go(t512::bfgs_kernel<NVMK_FF_DG, false, true>);
+        if (b.kind == NVMK_FF_ETK) return go(t512::bfgs_kernel<NVMK_FF_ETK, false, true>);
+        return go(t512::bfgs_kernel<NVMK_FF_MMFF, false, true>);
+      }
       if (b.kind == NVMK_FF_DG) return go(t256::bfgs_kernel<NVMK_FF_DG, false, true>);
       if (b.kind == NVMK_FF_ETK) return go(t256::bfgs_kernel<NVMK_FF_ETK, false, true>);
       return go(t256::bfgs_kernel<NVMK_FF_MMFF, false, true>);
     }
     int r = NVMK_OK;
-    if (P.gvec) {
+    if (P.gvec && P.threads == 512) {
+      NVMK_FF_DISPATCH(b.kind, r = go(t512::bfgs_kernel<K, true>));
+    } else if (P.gvec) {
       NVMK_FF_DISPATCH(b.kind, r = go(t256::bfgs_kernel<K, true>));
+    } else if (P.threads == 512) {
+      NVMK_FF_DISPATCH(b.kind, r = go(t512::bfgs_kernel<K, false>));
     } else if (P.threads == 64) {
       NVMK_FF_DISPATCH(b.kind, r = go(t64::bfgs_kernel<K, false>));
     } else if (P.threads == 128) {
@@ -711,7 +736,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // them, instead of one class waiting for the other (a 400-atom distance-geometry minimisation alone takes longer than
   // 4000 drug-sized ones).
   int nUsed = 0, lastUsed = -1;
-  for (int c = 0; c <= kGlobal; ++c)
+  for (int c = 0; c <= kGlobal8; ++c)
     if (plan[c].used) {
       ++nUsed;
       if (lastUsed < 0) lastUsed = c;  // the bin of the smallest systems in use stays on the caller's stream
@@ -723,7 +748,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     for (int w = 0; w < 16; ++w) static_cast<volatile int*>(side->started)[w] = 0;  // [0] started, [1 + c] class c drained
     NVMK_HIP_CHECK(hipEventRecord(side->fork, stream));
     int k = 0, bigWorkgroups = 0, prevClass = -1;
-    for (int c = kGlobal; c >= 0; --c) {
+    for (int c = kGlobal8; c >= 0; --c) {
       if (!plan[c].used) continue;
       if (queueMode && prevClass >= 0 && plan[prevClass].persistent) {
         // Classes one after the other, WITHOUT waiting for a class to finish: the next (smaller) class is launched when the
@@ -762,7 +787,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     }
     for (int j = 0; j < k; ++j) NVMK_HIP_CHECK(hipStreamWaitEvent(stream, side->join[j], 0));
   } else {
-    for (int c = kGlobal; c >= 0; --c) {
+    for (int c = kGlobal8; c >= 0; --c) {
       if (!plan[c].used) continue;
       rc = launch(c, stream);
       if (rc != NVMK_OK) return rc;

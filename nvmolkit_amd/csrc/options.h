@@ -23,6 +23,7 @@ enum Id {
   kBfgsOverlap,     // NVMK_BFGS_OVERLAP     1 | 0 (0: size classes run one after the other on the caller's stream)
   kBfgsWave,        // NVMK_BFGS_WAVE        1 | 0 | n (0: four waves for every system; n: largest system one wave takes)
   kBfgsWave2,       // NVMK_BFGS_WAVE2       n (largest system, in coordinates, that two waves take; 0: none)
+  kBfgsWave8,       // NVMK_BFGS_WAVE8       n (smallest system, in coordinates, that eight waves take; 0: none; default 656)
   kBfgsHessCapMb,   // NVMK_BFGS_HESS_CAP_MB n (tests: inverse-Hessian memory of a one-system-per-workgroup class before it runs persistent; default free / 4)
   kBfgsTimeline,    // NVMK_BFGS_TIMELINE    path (with NVMK_BFGS_PROFILE=1: per-system start / end clocks appended to this file)
   kBfgsSched,       // NVMK_BFGS_SCHED       queue | hw (hw: one workgroup per system, hardware hand-out — rounds 1-3)

@@ -167,7 +167,8 @@ LARGE_SIZES = [300, 500, 1000]
 @pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
 @pytest.mark.parametrize("iters,tol", [(1, 1e-9), (3, 1e-8), (10, 1e-6)])
 def test_trajectory_matches_oracle_at_300_500_1000_atoms(kind, iters, tol):
-    """300 atoms = 1200 (4-D) / 900 (3-D) coordinates: class C / class B; 500 and 1000 atoms: class C for every kind."""
+    """300 atoms = 1200 (4-D) / 900 (3-D) coordinates: eight waves, vectors in HBM / in LDS; 500 and 1000 atoms: eight waves with
+    the vectors in HBM for every kind."""
     systems = systems_of(kind, LARGE_SIZES, 900 + kind)
     a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
     gpu = FlatForcefieldBatch(kind, a_s, groups)
@@ -218,7 +219,9 @@ def test_mixed_size_classes_in_one_call_equal_separate_calls(kind):
     got, e, it = pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy()
     assert it.max() == 12 and it.min() >= 1  # (a system may meet the TOLX test before the cap)
     dim = gpu.dim
-    vec_bytes = lambda n_atoms: 8 * (15 * n_atoms * dim + 40)  # four-wave workgroups: (11 + 4) n-vectors + reduction scratch
+    # four-wave workgroups: (11 + 4) n-vectors + reduction scratch; from 656 coordinates on eight waves: (11 + 8) n-vectors
+    waves = lambda n_atoms: 8 if n_atoms * dim >= 656 else 4
+    vec_bytes = lambda n_atoms: 8 * ((11 + waves(n_atoms)) * n_atoms * dim + 8 * waves(n_atoms) + 8)
     for s, n_atoms in enumerate(sizes):
         if s >= 12 and s not in (12, 52):  # one of each repeated size is enough
             continue
@@ -232,6 +235,41 @@ def test_mixed_size_classes_in_one_call_equal_separate_calls(kind):
             assert e[s] == float(e1[0])
         else:
             assert np.max(np.abs(got[lo:hi] - p1.cpu().numpy())) <= 1e-6, (s, n_atoms)
+
+
+@pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
+def test_eight_wave_class_agrees_with_four_waves_and_is_reproducible(kind):
+    """Systems of 656 coordinates and more are minimised by EIGHT waves (NVMK_BFGS_WAVE8, csrc/minimize.hip): same algorithm, twice
+    the rows of the inverse Hessian in flight.  Both sides of the threshold and both homes of the vectors (LDS up to 1067
+    coordinates, HBM beyond): the trajectories agree with the four-wave kernels' to rounding and with the oracle's, a repeated run
+    of the LDS class gives the same bits, and NVMK_BFGS_WAVE8 moves the threshold."""
+    sizes = [150, 164, 170, 220, 262, 270, 330]      # x 4 (DG) = 600 .. 1320, x 3 = 450 .. 990 coordinates
+    systems = systems_of(kind, sizes, 1500 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    cpu = ffc.Batch(kind, a_s, groups)
+    w0, w1 = W[kind]
+    runs = {}
+    for name, opt in (("eight", None), ("eight again", None), ("four", "0"), ("all eight", "2")):
+        with _native.options(NVMK_BFGS_WAVE8=opt):
+            pos = torch.from_numpy(flat).cuda()
+            e, st, it = gpu.minimize(pos, max_iters=10, grad_tol=1e-14, w0=w0, w1=w1)
+            runs[name] = (pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy())
+    x, ec, stc, itc = cpu.minimize(flat, max_iters=10, grad_tol=1e-14, w0=w0, w1=w1)
+    dim = gpu.dim
+    for name, (got, e, it) in runs.items():
+        assert np.array_equal(it, itc), name
+        assert np.max(np.abs(got - x)) <= 1e-6, (name, np.max(np.abs(got - x)))
+        np.testing.assert_allclose(e, ec, rtol=1e-4, atol=1e-4)
+    for s, n_atoms in enumerate(sizes):
+        lo, hi = a_s[s] * dim, a_s[s + 1] * dim
+        n = n_atoms * dim
+        if n <= 1067:      # vectors in LDS: every sum has one writer and a fixed order
+            assert np.array_equal(runs["eight"][0][lo:hi], runs["eight again"][0][lo:hi]), n
+        if n < 656:        # below the threshold nothing changed ...
+            assert np.array_equal(runs["eight"][0][lo:hi], runs["four"][0][lo:hi]), n
+        else:              # ... above it the waves differ, so the sums' order does
+            assert not np.array_equal(runs["eight"][0][lo:hi], runs["four"][0][lo:hi]), n
 
 
 def _slice_group(g, s):

@@ -2,10 +2,10 @@
 (tests/golden/chembl_10k.smi) that the ingestion accepts — 10 000 molecules, 12 to 1063 atoms with hydrogens, 1052 of them beyond 128
 atoms, 63 beyond 512 — through ETKDG and MMFF94 (real topologies, generic parameters: synthetic.graph_molecule).  The reference's
 benchmarks/etkdg_bench.py feeds the whole file too; its kernels fall back to global memory for the large ones
-(src/minimizer/bfgs_minimize_permol_kernels.cu:796-932), here they run in the four-wave classes B (vectors in one CU's LDS, up to 1320
-coordinates) and C (vectors in HBM).  TWO conformers per molecule instead of the benchmark's ten keep the test to about a minute of
-GPU time (the ten-conformer run takes 125 s, profiles/r05_conformers/chembl_topologies_whole_file.json: a 4252-coordinate triangle is
-72 MB, read and written once per BFGS iteration by ONE workgroup).  Checked like the cut set: counts, distance bounds of sampled
+(src/minimizer/bfgs_minimize_permol_kernels.cu:796-932), here they run in the eight-wave classes (from 656 coordinates on; vectors in one CU's LDS
+up to 1067 coordinates, in HBM beyond).  TWO conformers per molecule instead of the benchmark's ten keep the test to about a minute of
+GPU time (the ten-conformer run takes 88 s, profiles/r05_conformers/chembl_topologies_whole_file_eight_wave_class.json: a
+4252-coordinate triangle is 72 MB, read and written once per BFGS iteration by ONE workgroup).  Checked like the cut set: counts, distance bounds of sampled
 conformers of every size class, energies against the C oracle, no minimisation ending above its start unless the oracle's does too."""
 
 from pathlib import Path

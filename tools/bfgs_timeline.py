@@ -17,6 +17,7 @@ ap.add_argument("file")
 ap.add_argument("--slots", type=int, default=2048)
 ap.add_argument("--wave", type=int, default=176)
 ap.add_argument("--wave2", type=int, default=256)
+ap.add_argument("--wave8", type=int, default=656, help="smallest system of the eight-wave class (NVMK_BFGS_WAVE8); 0: the run had none")
 args = ap.parse_args()
 op = gzip.open if args.file.endswith(".gz") else open
 rec = np.loadtxt(op(args.file, "rt"), dtype=np.int64, ndmin=2)
@@ -62,7 +63,13 @@ for a, b in groups:
 # wall the class spends with fewer workgroups in flight than the chip has CUs (256) / XCDs x 8 (64): that is time in which a system's
 # triangle streams at one CU's bandwidth while the rest of the chip idles — the "tail" a cooperative class would attack; a class that
 # keeps >= 256 workgroups in flight for most of its wall is bound by the chip's bytes instead.
-bounds = [(args.wave, "one wave"), (args.wave2, "two waves"), (655, "four waves A"), (1320, "four waves B"), (1 << 30, "four waves C (HBM vectors)")]
+# (from round 5's eight-wave class on: 656-1067 coordinates eight waves with the vectors in LDS, beyond that in HBM; --wave8 0 gives
+# the four-wave classes B (<= 1320) and C of the runs before it)
+if args.wave8 > 0:
+    bounds = [(args.wave, "one wave"), (args.wave2, "two waves"), (args.wave8 - 1, "four waves A"), (1067, "eight waves (LDS vectors)"),
+              (1 << 30, "eight waves (HBM vectors)")]
+else:
+    bounds = [(args.wave, "one wave"), (args.wave2, "two waves"), (655, "four waves A"), (1320, "four waves B"), (1 << 30, "four waves C (HBM vectors)")]
 out["by_class"] = []
 lo = 0
 for hi, name in bounds:

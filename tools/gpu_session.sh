@@ -15,6 +15,8 @@
 #   table_tests         the table builder's GPU tests + the suites that build batches through it
 #   ab_batch            bench_conformers with the default 16384 attempts per batch against equalised batches (16667 x 6, 14286 x 7)
 #   chembl256_timeline  the ChEMBL topologies of up to 256 atoms with the per-system BFGS timeline, summarised per size class
+#   wave8_tests         BFGS parity + inverse-Hessian update tests (the eight-wave class of round 5)
+#   ab_wave8            ChEMBL topologies of up to 256 atoms with NVMK_BFGS_WAVE8=0 (four waves for every large system) and the default, alternating
 #   chembl_all          every molecule of the ChEMBL file (up to 1063 atoms)
 #   conf10k             tools/bench_conformers.py --mols 10000 (resident tables, and end to end from the host arrays)
 #   pytest_gpu          the whole -m gpu suite (stops at the first failure; pytest_gpu_all: runs on)
@@ -187,6 +189,17 @@ PY
       grep '^{' $O/chembl256_timeline_run.log | tail -1 | cut -c1-600
       python tools/bfgs_timeline.py $O/chembl256_timeline.txt > $O/chembl256_timeline_summary.json && python -c "import json; d=json.load(open('$O/chembl256_timeline_summary.json')); print(json.dumps({k: d[k] for k in ('systems','launch_groups','total_mean_occupancy','total_tail_ms_below_half','wall_ms_first_to_last')})); print(json.dumps(d['by_class'], indent=0))"
       gzip -f $O/chembl256_timeline.txt; rm -f $O/chembl256_timeline.txt.gz
+      ;;
+    wave8_tests)
+      ( time timeout 1200 python -m pytest tests/test_bfgs_parity_gpu.py tests/test_hessian_update_gpu.py -m gpu -q -x ) > $O/wave8_tests.log 2>&1
+      tail -8 $O/wave8_tests.log
+      ;;
+    ab_wave8)
+      : > $O/ab_wave8.txt
+      for W in 0 656 0 656; do
+        echo "NVMK_BFGS_WAVE8=$W" | tee -a $O/ab_wave8.txt
+        NVMK_BFGS_WAVE8=$W timeout 600 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 256 --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | cut -c1-700 | tee -a $O/ab_wave8.txt
+      done
       ;;
     chembl_all)
       timeout 1200 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --end-to-end --cache $CACHE 2> $O/chembl_all.err | tee $O/chembl_all.json | cut -c1-900
