@@ -387,6 +387,13 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
 
         dist.barrier()
     torch.cuda.synchronize()
+    # (the interpreter's cyclic collector stays out of the timed regions, as in timeit: the region allocates ~10^5 small objects
+    # next to a heap of millions, and a full collection that happens to start inside it costs 0.1-0.15 s — it landed in the
+    # ChEMBL block of one closing run of round 5 and in the synthetic block of the next)
+    import gc
+
+    gc.collect()
+    gc.disable()
     # The timed region starts with the molecules as the generator left them (per-molecule numpy term arrays: what an RDKit
     # molecule is to the reference) and holds everything the reference's benchmark times inside EmbedMolecules +
     # MMFFOptimizeMoleculesConfs (benchmarks/etkdg_bench.py:108-124): table assembly on the host threads, uploads, both GPU stages.
@@ -417,6 +424,7 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     wall_resident = time.perf_counter() - r0
     same_bits = bool(torch.equal(opt_r.values.torch(), opt.values.torch()))
     del dev_r, opt_r
+    gc.enable()
     t_flatten = t_molset + t_tables_wait
     n_conf = dev.num_conformers
     converged = int(opt.converged.torch().sum().item())
@@ -795,8 +803,10 @@ def main() -> None:
             try:
                 secondary[name] = fn(*fn_args)
             except Exception as exc:  # noqa: BLE001
+                import gc
                 import traceback
 
+                gc.enable()  # (a block that failed inside its timed region left the collector off)
                 traceback.print_exc()
                 secondary[name] = {"error": f"{type(exc).__name__}: {exc}"}
 

@@ -70,18 +70,33 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> Path
     dep_digest = _digest(_deps()) + hashlib.sha256(os.environ.get("NVMK_EXTRA_HIPCC_FLAGS", "").encode()).hexdigest()
     objs: list[Path] = []
     relink = force or not LIB_PATH.exists()
+    stale: list[tuple[Path, Path, Path, str]] = []
     for src in sources():
         obj = OBJ_DIR / (src.name + ".o")
         stamp = OBJ_DIR / (src.name + ".sha")
         digest = _digest([src]) + dep_digest
         if force or not obj.exists() or not stamp.exists() or stamp.read_text() != digest:
-            cmd = common + (["-x", "hip"] if src.suffix == ".hip" else []) + ["-c", str(src), "-o", str(obj)]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.run(cmd, check=True)
-            stamp.write_text(digest)
-            relink = True
+            stale.append((src, obj, stamp, digest))
         objs.append(obj)
+
+    def compile_one(job: tuple[Path, Path, Path, str]) -> None:
+        src, obj, stamp, digest = job
+        cmd = common + (["-x", "hip"] if src.suffix == ".hip" else []) + ["-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        stamp.write_text(digest)
+
+    if stale:
+        # the translation units are independent: compile them side by side (minimize.hip alone takes minutes — four thread
+        # counts x seven force-field kinds of the fused BFGS kernel); the longest first
+        from concurrent.futures import ThreadPoolExecutor
+
+        stale.sort(key=lambda job: -job[0].stat().st_size if job[0].name != "minimize.hip" else -(1 << 40))
+        jobs = max(1, min(len(stale), int(os.environ.get("NVMK_BUILD_JOBS", "0")) or (os.cpu_count() or 1)))
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            list(pool.map(compile_one, stale))
+        relink = True
     if relink:
         cmd = [
             hipcc,
