@@ -231,6 +231,24 @@ def build_flags() -> int:
     return flags
 
 
+def build_threads(requested: int) -> int:
+    """Host threads for the table builder: the caller's number if positive, else this process's share of the cores it may run
+    on — one process per GPU means LOCAL_WORLD_SIZE processes assemble tables on one host at the same time (torchrun sets it), and
+    eight of them asking for 64 threads each would oversubscribe a 128-core box inside everybody's timed region.  At most 64
+    (the library's own limit)."""
+    if requested > 0:
+        return int(requested)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    try:
+        local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local = 1
+    return max(1, min(64, cores // local))
+
+
 def last_error() -> str:
     msg = lib().nvmk_last_error()
     return msg.decode("utf-8", "replace") if msg else ""

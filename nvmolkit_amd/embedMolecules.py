@@ -92,10 +92,10 @@ class FlatMoleculeSet:
         t1 = time.perf_counter()
         if self.device.type == "cuda":
             with torch.cuda.device(self.device):
-                rc = _native.lib().nvmk_etkdg_molset_build(ctypes.addressof(descs), n, int(preprocessing_threads), flags,
+                rc = _native.lib().nvmk_etkdg_molset_build(ctypes.addressof(descs), n, _native.build_threads(preprocessing_threads), flags,
                                                            _native.stream_ptr(None), ctypes.byref(handle))
         else:
-            rc = _native.lib().nvmk_etkdg_molset_build(ctypes.addressof(descs), n, int(preprocessing_threads),
+            rc = _native.lib().nvmk_etkdg_molset_build(ctypes.addressof(descs), n, _native.build_threads(preprocessing_threads),
                                                        flags | _native.BUILD_HOST, None, ctypes.byref(handle))
         _native.check(rc, "nvmk_etkdg_molset_build")
         self._handle = handle

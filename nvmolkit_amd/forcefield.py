@@ -239,10 +239,10 @@ class MoleculeTermTables:
         flags = _native.build_flags()
         if self.device.type == "cuda":
             with torch.cuda.device(self.device):
-                rc = _native.lib().nvmk_ff_tables_build(self.kind, terms_address, self.n_mols, n_groups, int(preprocessing_threads), flags,
+                rc = _native.lib().nvmk_ff_tables_build(self.kind, terms_address, self.n_mols, n_groups, _native.build_threads(preprocessing_threads), flags,
                                                         _native.stream_ptr(None), ctypes.byref(handle))
         else:
-            rc = _native.lib().nvmk_ff_tables_build(self.kind, terms_address, self.n_mols, n_groups, int(preprocessing_threads),
+            rc = _native.lib().nvmk_ff_tables_build(self.kind, terms_address, self.n_mols, n_groups, _native.build_threads(preprocessing_threads),
                                                     flags | _native.BUILD_HOST, None, ctypes.byref(handle))
         _native.check(rc, "nvmk_ff_tables_build")
         self._handle = handle

@@ -206,3 +206,18 @@ def test_builder_through_the_c_abi_alone():
         == _native.ERR_INVALID_ARGUMENT
     assert lib.nvmk_ff_tables_build(DG, ctypes.addressof(terms), 1, 4, 0, _native.BUILD_HOST, None, ctypes.byref(handle)) == _native.ERR_INVALID_ARGUMENT
     assert lib.nvmk_etkdg_molset_free(None) == 0 and lib.nvmk_ff_tables_free(None) == 0
+
+
+def test_default_builder_threads_are_this_process_share_of_the_host(monkeypatch):
+    """One process per GPU: LOCAL_WORLD_SIZE processes assemble tables on one host at once (bench.py --gpus N, inside every rank's
+    clock), so the default thread count divides the cores this process may run on among them; an explicit count is taken as is."""
+    import os
+
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    cores = len(os.sched_getaffinity(0))
+    assert _native.build_threads(-1) == max(1, min(64, cores)) and _native.build_threads(0) == _native.build_threads(-1)
+    assert _native.build_threads(7) == 7
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert _native.build_threads(-1) == max(1, min(64, cores // 8)) and _native.build_threads(7) == 7
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "nonsense")
+    assert _native.build_threads(-1) == max(1, min(64, cores))
