@@ -15,6 +15,8 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -79,7 +81,11 @@ int acquire_ring(const size_t minSlotBytes, Ring** out) {
     }
     r->busy = true;
   }
-  if (r->lastUse != nullptr) (void)hipEventSynchronize(r->lastUse);
+  if (r->lastUse != nullptr) {  // the previous owner's last uploads out of these slots (an event of ITS device and stream)
+    (void)hipEventSynchronize(r->lastUse);
+    (void)hipEventDestroy(r->lastUse);
+    r->lastUse = nullptr;
+  }
   if (r->slotBytes < minSlotBytes) {
     if (r->base != nullptr) (void)hipHostFree(r->base);
     r->base      = nullptr;
@@ -99,15 +105,34 @@ int acquire_ring(const size_t minSlotBytes, Ring** out) {
   return NVMK_OK;
 }
 
+// `recordUse`: uploads out of the ring may still be in flight on `stream`.  The event is made HERE, under the device that is
+// current for this build (rings are shared by every device of the process, events are not); if it cannot be recorded the stream
+// is drained instead — the next owner must never write into a slot that is still being read.
 void release_ring(Ring* r, hipStream_t stream, const bool recordUse) {
   if (r == nullptr) return;
   if (recordUse) {
-    if (r->lastUse == nullptr) (void)hipEventCreateWithFlags(&r->lastUse, hipEventDisableTiming);
-    if (r->lastUse != nullptr) (void)hipEventRecord(r->lastUse, stream);
+    hipEvent_t ev = nullptr;
+    hipError_t e  = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      if (ev != nullptr) (void)hipEventDestroy(ev);
+      ev = nullptr;
+      (void)hipStreamSynchronize(stream);
+    }
+    r->lastUse = ev;
   }
   const std::lock_guard<std::mutex> lock(g_ringMutex);
   r->busy = false;
 }
+
+// the ring of one build: given back on every way out of run()
+struct RingLease {
+  Ring*       ring      = nullptr;
+  hipStream_t stream    = nullptr;
+  bool        recordUse = true;  // (uploads may have been issued on any path that got as far as holding a ring)
+  ~RingLease() { release_ring(ring, stream, recordUse); }
+};
 
 // ---- the plan: groups, their source descriptors, where every row goes -----------------------------------------------------
 enum Fill { kPlain, kPairOrdered, kMergedNonbonded };
@@ -346,7 +371,9 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
   const int nChunks = static_cast<int>(chunkFirst.size()) - 1;
 
   // 4. destination
-  Ring* ring = nullptr;
+  RingLease lease;
+  Ring*&    ring = lease.ring;
+  lease.stream   = b.stream;
   if (b.onHost) {
     b.block = static_cast<char*>(std::malloc(b.blockBytes));
     NVMK_REQUIRE(b.block != nullptr, "%s: out of host memory (%zu bytes)", what, b.blockBytes);
@@ -386,8 +413,8 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
     NVMK_REQUIRE(b.onHost || o <= slotBytes, "%s: internal: chunk %d does not fit its staging slot", what, c);
     for (int m = m0; m < m1; ++m) chunkOf[static_cast<size_t>(m)] = c;
   }
-  std::atomic<int> nextMol{0}, chunkOpen{b.onHost ? nChunks : std::min(nChunks, kSlots)}, badMol{-1}, badGroup{-1}, abort{0};
-  auto worker = [&]() {
+  std::atomic<int> nextMol{0}, chunkOpen{b.onHost ? nChunks : std::min(nChunks, kSlots)}, badMol{-1}, badGroup{-1}, abort{0}, threw{0};
+  auto worker_body = [&]() {
     Scratch sc;
     for (;;) {
       const int m = nextMol.fetch_add(1);
@@ -421,16 +448,34 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
       chunks[static_cast<size_t>(c)].remaining.fetch_sub(1, std::memory_order_release);
     }
   };
+  // (a worker that runs out of memory in its sort scratch must not take the process down: the build fails instead)
+  auto worker = [&]() {
+    try {
+      worker_body();
+    } catch (...) {
+      threw.store(1);
+      abort.store(1);
+    }
+  };
   int nThreads = nThreadsAsked > 0 ? nThreadsAsked : static_cast<int>(std::thread::hardware_concurrency());
   nThreads     = std::max(1, std::min({nThreads, kMaxThreads, nMols / 8 + 1}));
   std::vector<std::thread> pool;
-  for (int t = 0; t < nThreads; ++t) pool.emplace_back(worker);
+  pool.reserve(static_cast<size_t>(nThreads));
+  for (int t = 0; t < nThreads; ++t) {
+    try {
+      pool.emplace_back(worker);
+    } catch (const std::system_error&) {  // the host refuses more threads: go on with those it gave
+      break;
+    }
+  }
+  NVMK_REQUIRE(!pool.empty(), "%s: could not start a worker thread", what);
   int        rc        = NVMK_OK;
   hipEvent_t slotEvent[kSlots] = {};
   if (!b.onHost) {
     for (int c = 0; c < nChunks && rc == NVMK_OK; ++c) {
       ChunkState& cs = chunks[static_cast<size_t>(c)];
-      while (cs.remaining.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      while (cs.remaining.load(std::memory_order_acquire) > 0 && !abort.load()) std::this_thread::yield();
+      if (abort.load()) break;
       char*     slot = ring->base + static_cast<size_t>(c % kSlots) * ring->slotBytes;
       const int m0 = chunkFirst[static_cast<size_t>(c)], m1 = chunkFirst[static_cast<size_t>(c) + 1];
       for (size_t gi = 0; gi < b.groups.size() && rc == NVMK_OK; ++gi) {
@@ -461,6 +506,10 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
     if (rc != NVMK_OK) abort.store(1);
   }
   for (auto& t : pool) t.join();
+  if (threw.load() && rc == NVMK_OK) {
+    set_last_error("%s: a worker thread ran out of memory", what);
+    rc = NVMK_ERR_OUT_OF_MEMORY;
+  }
   for (hipEvent_t ev : slotEvent)
     if (ev != nullptr) (void)hipEventDestroy(ev);
   if (!b.onHost) {
@@ -472,7 +521,6 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
         rc = NVMK_ERR_HIP;
       }
     }
-    release_ring(ring, b.stream, true);
   }
   if (rc != NVMK_OK) return rc;
   NVMK_REQUIRE(badMol.load() < 0, "%s: molecule %d, term group %d: atom index outside the molecule (or more than 2^24 pair rows)", what,
@@ -518,12 +566,23 @@ struct TablesHandle {
 
 using namespace nvmk::tables;
 
-extern "C" {
+namespace {
 
-int nvmk_etkdg_molset_build(const nvmk_flat_molecule* h_mols, int32_t n_mols, int n_threads, unsigned flags, void* stream, void** handle) {
-  NVMK_MARK_ENTRY();
-  NVMK_REQUIRE(handle != nullptr, "nvmk_etkdg_molset_build: handle is NULL");
-  *handle = nullptr;
+// The C ABI does not let C++ exceptions out: a build that runs out of host memory while planning (vectors of the size of the
+// molecule set) is an error code like any other.
+template <typename F> int no_throw(const char* what, F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    nvmk::set_last_error("%s: out of host memory", what);
+    return NVMK_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    nvmk::set_last_error("%s: %s", what, e.what());
+    return NVMK_ERR_INTERNAL;
+  }
+}
+
+int molset_build(const nvmk_flat_molecule* h_mols, int32_t n_mols, int n_threads, unsigned flags, void* stream, void** handle) {
   NVMK_REQUIRE(n_mols >= 0 && (n_mols == 0 || h_mols != nullptr), "nvmk_etkdg_molset_build: bad molecule array");
   std::unique_ptr<MolsetHandle> h(new MolsetHandle());
   Build&                        b = h->build;
@@ -583,6 +642,17 @@ int nvmk_etkdg_molset_build(const nvmk_flat_molecule* h_mols, int32_t n_mols, in
   return NVMK_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int nvmk_etkdg_molset_build(const nvmk_flat_molecule* h_mols, int32_t n_mols, int n_threads, unsigned flags, void* stream, void** handle) {
+  NVMK_MARK_ENTRY();
+  NVMK_REQUIRE(handle != nullptr, "nvmk_etkdg_molset_build: handle is NULL");
+  *handle = nullptr;
+  return no_throw("nvmk_etkdg_molset_build", [&]() { return molset_build(h_mols, n_mols, n_threads, flags, stream, handle); });
+}
+
 int nvmk_etkdg_molset_view(const void* handle, nvmk_etkdg_molset* out) {
   const MolsetHandle* h = static_cast<const MolsetHandle*>(handle);
   NVMK_REQUIRE(h != nullptr && h->magic == 0x4d4f4c53 && out != nullptr, "nvmk_etkdg_molset_view: not a molecule-set handle");
@@ -619,11 +689,12 @@ int nvmk_etkdg_molset_free(void* handle) {
   return NVMK_OK;
 }
 
-int nvmk_ff_tables_build(int kind, const nvmk_host_terms* h_terms, int32_t n_mols, int n_groups, int n_threads, unsigned flags, void* stream,
-                         void** handle) {
-  NVMK_MARK_ENTRY();
-  NVMK_REQUIRE(handle != nullptr, "nvmk_ff_tables_build: handle is NULL");
-  *handle = nullptr;
+}  // extern "C"
+
+namespace {
+
+int tables_build(int kind, const nvmk_host_terms* h_terms, int32_t n_mols, int n_groups, int n_threads, unsigned flags, void* stream,
+                 void** handle) {
   int               nShapes = 0;
   const GroupShape* shapes  = shapes_of(kind, &nShapes);
   NVMK_REQUIRE(shapes != nullptr, "nvmk_ff_tables_build: kind must be NVMK_FF_DG, _ETK, _MMFF or _UFF");
@@ -664,6 +735,18 @@ int nvmk_ff_tables_build(int kind, const nvmk_host_terms* h_terms, int32_t n_mol
   if (const int rc = run(b, n_threads, "nvmk_ff_tables_build")) return rc;
   *handle = h.release();
   return NVMK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nvmk_ff_tables_build(int kind, const nvmk_host_terms* h_terms, int32_t n_mols, int n_groups, int n_threads, unsigned flags, void* stream,
+                         void** handle) {
+  NVMK_MARK_ENTRY();
+  NVMK_REQUIRE(handle != nullptr, "nvmk_ff_tables_build: handle is NULL");
+  *handle = nullptr;
+  return no_throw("nvmk_ff_tables_build", [&]() { return tables_build(kind, h_terms, n_mols, n_groups, n_threads, flags, stream, handle); });
 }
 
 int nvmk_ff_tables_view(const void* handle, nvmk_ff_group groups[12], int32_t* n_mols) {

@@ -1,9 +1,14 @@
 // The index arithmetic of the kernels, compiled for the HOST from the very headers the kernels include (hipcc, no GPU needed):
 // nvmolkit_amd/csrc/tile_maps.h (workgroup -> tile maps of the matrix-core kernels) and nvmolkit_amd/csrc/hess_pass.h (row
-// offsets of the packed inverse Hessian, LDS layout and residency rule of the BFGS kernels, in their three workgroup sizes).
+// offsets of the packed inverse Hessian, LDS layout and residency rule of the BFGS kernels, in their four workgroup sizes).
 // tests/test_tile_maps.py and tests/test_hess_layout.py drive these entry points.
 #include "../../nvmolkit_amd/csrc/tile_maps.h"
 
+#define NVMK_BFGS_NS t512
+#define NVMK_BFGS_THREADS 512
+#include "../../nvmolkit_amd/csrc/hess_pass.h"
+#undef NVMK_BFGS_NS
+#undef NVMK_BFGS_THREADS
 #define NVMK_BFGS_NS t256
 #define NVMK_BFGS_THREADS 256
 #include "../../nvmolkit_amd/csrc/hess_pass.h"
@@ -46,15 +51,16 @@ int chk_panel_pending_after(int chunksPerTile, int dist, int ch) { return nvmk::
 int64_t chk_hess_row_offset(int64_t r) { return t256::hess_row_offset(r); }
 int     chk_hess_row_offset32(int r) { return t64::hess_row_offset32(r); }
 int64_t chk_lds_vector_doubles(int threads, int64_t n) {
-  return threads == 64 ? t64::lds_vector_doubles(n) : threads == 128 ? t128::lds_vector_doubles(n) : t256::lds_vector_doubles(n);
+  return threads == 64 ? t64::lds_vector_doubles(n) : threads == 128 ? t128::lds_vector_doubles(n) : threads == 512 ? t512::lds_vector_doubles(n) : t256::lds_vector_doubles(n);
 }
 int64_t chk_lds_hessian_doubles(int threads, int64_t ldsDoubles, int64_t n) {
   return threads == 64 ? t64::lds_hessian_doubles(ldsDoubles, n)
          : threads == 128 ? t128::lds_hessian_doubles(ldsDoubles, n)
+         : threads == 512 ? t512::lds_hessian_doubles(ldsDoubles, n)
                           : t256::lds_hessian_doubles(ldsDoubles, n);
 }
 int chk_resident_rows(int threads, int n, int64_t hldsDoubles) {
-  return threads == 64 ? t64::resident_rows(n, hldsDoubles) : threads == 128 ? t128::resident_rows(n, hldsDoubles) : t256::resident_rows(n, hldsDoubles);
+  return threads == 64 ? t64::resident_rows(n, hldsDoubles) : threads == 128 ? t128::resident_rows(n, hldsDoubles) : threads == 512 ? t512::resident_rows(n, hldsDoubles) : t256::resident_rows(n, hldsDoubles);
 }
 int64_t chk_tail_pad_doubles() { return t256::kHessTailPadDoubles; }
 

@@ -114,6 +114,18 @@ def test_single_large_system(tmp_path_factory, tmp_path, dim, identity):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("identity", [True, False])
+@pytest.mark.parametrize("atoms,dim", [(164, 4), (220, 3), (262, 4), (300, 3), (266, 4)])
+def test_single_large_system_with_eight_waves(tmp_path_factory, tmp_path, atoms, dim, identity):
+    """The pass of the eight-wave class (csrc/minimize.hip: systems of 656 coordinates and more, 512 threads): 656 / 660 / 1048 /
+    900 / 1064 coordinates (its eight gradient slabs fit LDS up to 1067), with the vectors alone in LDS and with whatever a whole CU's LDS holds beside them."""
+    rng = np.random.default_rng(11 + atoms + dim + 10 * identity)
+    systems = [random_system(rng, atoms * dim, identity)]
+    for kb in (0, 159):
+        check(systems, [True], run(build(tmp_path_factory, 512), tmp_path, systems, [True], kb), expect_update=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("identity", [True, False])
 @pytest.mark.parametrize("dim", [3, 4])
 @pytest.mark.parametrize("threads,third", [(64, 33), (128, 33), (256, 33), (256, 300)])
 def test_several_systems_one_inactive(tmp_path_factory, tmp_path, threads, third, dim, identity):

@@ -118,7 +118,7 @@ def test_packed_triangle_rows_are_contiguous_even_and_16_byte_aligned(maps):
     assert maps.chk_tail_pad_doubles() >= 256                               # unconditional 1 KB loads past the last rows
 
 
-@pytest.mark.parametrize("threads", [64, 128, 256])
+@pytest.mark.parametrize("threads", [64, 128, 256, 512])
 def test_lds_layout_and_resident_rows(maps, threads):
     nw = threads // 64
     for n in (12, 60, 144, 176, 256, 655, 1320):
