@@ -29,6 +29,9 @@
 #   strong              bench.py strong-scaling conformer mode as one rank over RCCL
 #   butina_tests        the clustering, full-size, benchmark-molecule and sharded-Butina GPU tests
 #   diag_chembl         tools/diag_chembl_energy.py (which conformers end an MMFF minimisation above their starting energy)
+#   ab_half_prune       (with tools/experiments/panel_half_k_prune.patch applied) tools/bench_butina.py at 1M on the product library and on
+#                       lib/libnvmolkit_amd_noprune.so (NVMK_EXTRA_HIPCC_FLAGS=-DNVMK_PANEL_NO_HALF_PRUNE NVMK_BUILD_VARIANT=noprune)
+#   butina_bench        tools/bench_butina.py 1000000 --repeat 3 on the planted clusters and on the wide-popcount-spread set
 #   butina              tools/bench_butina.py + clustering tests (ab_butina: the bench alone, tile against panel kernel)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -263,6 +266,19 @@ PY
     diag_chembl)
       timeout 900 python tools/diag_chembl_energy.py > $O/diag_chembl.log 2>&1; tail -16 $O/diag_chembl.log
       timeout 900 python tools/diag_chembl_energy.py 16384 > $O/diag_chembl_16384.log 2>&1; tail -6 $O/diag_chembl_16384.log
+      ;;
+    ab_half_prune)
+      : > $O/ab_half_prune.txt
+      for i in 1 2; do for L in "" noprune; do
+        LIBP=$ROOT/nvmolkit_amd/lib/libnvmolkit_amd${L:+_$L}.so
+        echo "== ${L:-product}" | tee -a $O/ab_half_prune.txt
+        NVMOLKIT_AMD_LIB=$LIBP timeout 300 python tools/bench_butina.py 1000000 --repeat 3 2>/dev/null | tail -1 | cut -c1-500 | tee -a $O/ab_half_prune.txt
+        NVMOLKIT_AMD_LIB=$LIBP timeout 300 python tools/bench_butina.py 1000000 --spread --repeat 3 2>/dev/null | tail -1 | cut -c1-500 | tee -a $O/ab_half_prune.txt
+      done; done
+      ;;
+    butina_bench)
+      timeout 300 python tools/bench_butina.py 1000000 --repeat 3 2>/dev/null | tail -1 | cut -c1-500 | tee $O/butina_bench.txt
+      timeout 300 python tools/bench_butina.py 1000000 --spread --repeat 3 2>/dev/null | tail -1 | cut -c1-500 | tee -a $O/butina_bench.txt
       ;;
     ab_butina)
       for T in tile panel tile panel; do
