@@ -31,6 +31,7 @@
 #   diag_chembl         tools/diag_chembl_energy.py (which conformers end an MMFF minimisation above their starting energy)
 #   ab_half_prune       (with tools/experiments/panel_half_k_prune.patch applied) tools/bench_butina.py at 1M on the product library and on
 #                       lib/libnvmolkit_amd_noprune.so (NVMK_EXTRA_HIPCC_FLAGS=-DNVMK_PANEL_NO_HALF_PRUNE NVMK_BUILD_VARIANT=noprune)
+#   panel_fetch         tools/profile_panel_fetch.sh: FETCH_SIZE of the row-panel count kernel, product and variant libraries
 #   butina_bench        tools/bench_butina.py 1000000 --repeat 3 on the planted clusters and on the wide-popcount-spread set
 #   butina              tools/bench_butina.py + clustering tests (ab_butina: the bench alone, tile against panel kernel)
 set -u
@@ -275,6 +276,9 @@ PY
         NVMOLKIT_AMD_LIB=$LIBP timeout 300 python tools/bench_butina.py 1000000 --repeat 3 2>/dev/null | tail -1 | cut -c1-500 | tee -a $O/ab_half_prune.txt
         NVMOLKIT_AMD_LIB=$LIBP timeout 300 python tools/bench_butina.py 1000000 --spread --repeat 3 2>/dev/null | tail -1 | cut -c1-500 | tee -a $O/ab_half_prune.txt
       done; done
+      ;;
+    panel_fetch)
+      bash tools/profile_panel_fetch.sh $O 2>&1 | tail -40
       ;;
     butina_bench)
       timeout 300 python tools/bench_butina.py 1000000 --repeat 3 2>/dev/null | tail -1 | cut -c1-500 | tee $O/butina_bench.txt
