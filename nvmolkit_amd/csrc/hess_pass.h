@@ -411,6 +411,75 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __r
   }
 }
 
+// ---- the pass of ONE RANK of a cooperative team (bfgs_team_kernel: several workgroups per system) ---------------------------------
+// The rows of the triangle are dealt over the team's workgroups in contiguous blocks of about equal cost; this workgroup walks
+// rows [Ra, Rb) of the whole triangle in HBM (Hg, row 0 first) and leaves in `part` (n-vectors in its HBM work area) what it
+// contributes to t = H g:  part[i] for its own rows = the diagonal's term + the row's sum,  part[(1 + w) n + i], i < Rb = wave w's
+// mirrored-entry sums.  The vectors themselves (diag, xi, hdg, uu, g) are the workgroup's own full copies in HBM; what a row needs
+// of them (its four coefficients) and the row sums live in LDS for the duration of the pass — `stage`, 5 x (rowsCap + 32)
+// doubles — because in HBM every group of four rows waits for its coefficient loads and its sum's read-modify-write, and the
+// hardware returns loads in order, so that wait also drains the matrix rows requested ahead (the HBM-vector class without a
+// team streams at 12 GB/s per workgroup for this reason).  Blocks taller than rowsCap are walked in several sub-blocks.
+// The diagonal is updated by every rank on its own copy.
+constexpr int kTeamStagePad = 32;  // hess_range reads the coefficients of up to 3 NW rows past a range's end (and never uses them)
+template <bool PREFETCH = true>
+__device__ __forceinline__ void hess_pass_rows(double* __restrict__ diag, double* __restrict__ Hg, const int Ra, const int Rb, const int n,
+                                               const bool pending, const double rfac, const double fad, const double fae,
+                                               const double* __restrict__ xi, const double* __restrict__ hdg,
+                                               const double* __restrict__ uu, const double* __restrict__ g, double* __restrict__ part,
+                                               double* __restrict__ stage, const int rowsCap) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  double*   colsum = part + (1 + wave) * n;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    double d = diag[i];
+    if (pending) {
+      d += rfac * xi[i] * xi[i] - fad * hdg[i] * hdg[i] + fae * uu[i] * uu[i];
+      diag[i] = d;
+    }
+  }
+  const int stride = rowsCap + kTeamStagePad;
+  double *sg = stage, *sx = stage + stride, *sh = stage + 2 * stride, *su = stage + 3 * stride, *ss = stage + 4 * stride;
+  for (int ra = Ra; ra < Rb; ra += rowsCap) {
+    const int rb = min(Rb, ra + rowsCap);
+    __syncthreads();  // the previous sub-block's sums have been taken out of the staging area (and, first time round, whoever used this LDS before is done)
+    for (int i = threadIdx.x; i < rb - ra + kTeamStagePad; i += NT) {
+      const int  r  = ra + i;
+      const bool in = r < rb;
+      sg[i] = in ? g[r] : 0.0;
+      sx[i] = in ? xi[r] : 0.0;
+      sh[i] = in ? hdg[r] : 0.0;
+      su[i] = in ? uu[r] : 0.0;
+      ss[i] = in ? diag[r] * g[r] : 0.0;  // (this thread's own diag entries when i strides like the loop above: rb - ra <= rowsCap, any thread otherwise — hence the barrier below)
+    }
+    __syncthreads();
+    // (the first sub-block also visits the column chunks only later sub-blocks have rows in, so that every column below Rb starts
+    // from zero in this pass)
+    for (int cBase = 0; cBase < (ra == Ra ? Rb : rb); cBase += 256) {
+      HessChunk ck[2];
+      double    col[2][2];
+      hess_chunk_state<2>(ck, col, cBase, lane, n, pending, rfac, fad, fae, xi, hdg, uu, g);
+      const int mid = min(rb, cBase + 129);  // rows before it have no entry in the second chunk
+      {
+        HessChunk(&ck1)[1]  = reinterpret_cast<HessChunk(&)[1]>(ck[0]);
+        double(&col1)[1][2] = reinterpret_cast<double(&)[1][2]>(col[0]);
+        const int lo = max(cBase, ra);
+        if (lo < mid) hess_range<1, PREFETCH, true>(Hg, 0, lo, mid, wave, lane, ck1, pending, sx - ra, sh - ra, su - ra, sg - ra, ss - ra, col1);
+      }
+      const int lo2 = max(mid, ra);
+      if (lo2 < rb) hess_range<2, PREFETCH, true>(Hg, 0, lo2, rb, wave, lane, ck, pending, sx - ra, sh - ra, su - ra, sg - ra, ss - ra, col);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {  // this wave's mirrored-entry sums of its columns: single writer; later sub-blocks add to the first one's
+        const int c0 = ck[k].c0;
+        if (c0 < n) colsum[c0] = (ra == Ra ? 0.0 : colsum[c0]) + col[k][0];
+        if (c0 + 1 < n) colsum[c0 + 1] = (ra == Ra ? 0.0 : colsum[c0 + 1]) + col[k][1];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rb - ra; i += NT) part[ra + i] = ss[i];
+  }
+}
+
 // t = H g from the partial sums of the pass (fixed summation order).
 __device__ __forceinline__ void hess_finish(const int n, const double* part, double* t) {
   if constexpr (NW == 1) {

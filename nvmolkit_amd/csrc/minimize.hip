@@ -32,91 +32,7 @@
 #include "ff_grad.h"
 #include "ff_terms.h"
 
-namespace nvmk {
-namespace minim {
-
-using namespace nvmk::ff;
-
-struct Group {
-  const int32_t* starts;
-  const int32_t* idx;
-  const double*  par;
-};
-struct Batch {
-  int            kind;
-  int            nSystems;
-  const int32_t* atomStarts;
-  Group          g[12];
-  const int32_t* sysMol;      // optional: term tables are per MOLECULE and system s uses row sysMol[s] of every `starts`
-  unsigned       groupMask;   // bit g set = evaluate term group g
-  // ETK only, optional: per-system reference distances for the 1-2 / 1-3 restraints (the reference re-centres
-  // those bounds on the current geometry before the ETK minimisation, etkdg_stage_etk_minimization.cu:32-64)
-  const int32_t* refStarts[2];
-  const double*  ref[2];
-};
-
-// Internal kinds: MMFF / UFF batches that carry constraint groups run separate kernel instantiations, so the common
-// unconstrained kernels keep their register budget (the reference templates its kernels on HasConstraints).
-constexpr int KIND_MMFF_C = 5;
-constexpr int KIND_UFF_C  = 6;
-template <int KIND> struct Dim {
-  static constexpr int value = (KIND == NVMK_FF_DG || KIND == NVMK_FF_QUARTIC) ? 4 : 3;
-};
-
-// ---- fused BFGS -----------------------------------------------------------------------------------
-constexpr double FUNCTOL       = 1.0e-4;
-constexpr double MOVETOL       = 1.0e-7;
-constexpr double TOLX          = 4.0 * 3.0e-8;
-constexpr double EPS_HESS      = 3.0e-8;
-constexpr int    MAX_LS_ITERS  = 1000;
-
-// PROFILE (NVMK_BFGS_PROFILE=1; DG, ETK and MMFF): thread 0 accumulates wall-clock ticks (100 MHz) per phase into
-// prof[sys * 8 + k]: 0 line-search energy evaluations, 1 gradient, 2 pass over H (pending update + H g), 3 update scalars + direction,
-// 4 whole kernel, 5 iterations, 6 energy evaluations.
-//
-// Size classes (the reference switches between shared and global memory per launch, bfgs_minimize_permol_kernels.cu:796-932,
-// bfgs_types.h:36-43; here every launch is split by size, nvmk_bfgs_minimize_two_stages below):
-//   one wave per system up to 176 coordinates (eight per CU), two waves up to 256 (four per CU), four waves beyond —
-//   vectors in LDS while they fit half (two workgroups per CU) or all of it (one), else (GVEC) in a per-workgroup HBM / L2
-//   work area, any size.
-// The one-workgroup-per-CU and the GVEC classes run as persistent workgroups that take systems off a counter (largest
-// first) and keep ONE inverse-Hessian slot each, so the memory a launch needs is bounded by the workgroups in flight, not by
-// the number of large systems (a 1000-atom 4-D system has a 64 MB triangle).
-constexpr int kProfWords = 12;  // per system: 7 phase sums, then the item's first / last clock and its hardware id (timeline)
-struct BfgsArgs {
-  double*                         positions;
-  double                          w0, w1;
-  int                             maxIters;
-  int                             restarts;     // further minimisations of a system that stops at maxIters (each from H = I)
-  // optional second minimisation of every system in the same launch (maxItersB < 0: none)
-  double                          w0b, w1b;
-  int                             maxItersB, restartsB;
-  double*                         posMid;       // coordinates after the first minimisation (same layout as positions)
-  double                          skipAbove;    // >= 0: no second minimisation when the first one's energy per atom exceeds it
-  double                          gradTol;
-  int                             scaleGrads;
-  const uint8_t*                  active;
-  const int64_t*                  hessStarts;   // per-system offsets into `hessians` (slotDoubles == 0)
-  const int32_t*                  order;        // the systems of this launch in hand-out order
-  int                             nItems;
-  int*                            counter;      // persistent launches: eight counters, one per queue (all start at 0); else nullptr
-  int                             queueStart[9]; // persistent launches: queue q holds order[queueStart[q] .. queueStart[q + 1]) — one queue per XCD
-  double*                         hessians;
-  int64_t                         slotDoubles;  // > 0: workgroup k owns hessians[k * slotDoubles ...)
-  double*                         vecWork;      // GVEC: workgroup k owns vecWork[k * vecStride ...)
-  int64_t                         vecStride;
-  double*                         energies;
-  int16_t*                        statuses;
-  int32_t*                        itersOut;
-  int64_t*                        prof;
-  int                             ldsDoubles;
-  unsigned long long*             stats;
-  int*                            started;      // host-visible counter of workgroups that have begun (NULL: not wanted)
-  int*                            drained;      // host-visible flag, set when the LAST item of this launch's queues has been taken (NULL: not wanted)
-};
-
-}  // namespace minim
-}  // namespace nvmk
+#include "bfgs_common.h"
 
 // four waves per system (every size), eight for the largest (one system per CU), two and one for the small ones (four / eight of
 // them share a CU)
@@ -182,17 +98,13 @@ int to_batch(const nvmk_ff_batch* in, Batch& out) {
   return NVMK_OK;
 }
 
-#define NVMK_FF_DISPATCH(kind, CALL)               \
-  switch (kind) {                                  \
-    case NVMK_FF_DG: { constexpr int K = NVMK_FF_DG; CALL; break; }           \
-    case NVMK_FF_ETK: { constexpr int K = NVMK_FF_ETK; CALL; break; }         \
-    case NVMK_FF_MMFF: { constexpr int K = NVMK_FF_MMFF; CALL; break; }       \
-    case NVMK_FF_UFF: { constexpr int K = NVMK_FF_UFF; CALL; break; }         \
-    case KIND_MMFF_C: { constexpr int K = KIND_MMFF_C; CALL; break; }         \
-    case KIND_UFF_C: { constexpr int K = KIND_UFF_C; CALL; break; }           \
-    default: { constexpr int K = NVMK_FF_QUARTIC; CALL; break; }              \
-  }
+}  // namespace minim
+}  // namespace nvmk
 
+namespace nvmk {
+namespace minim {
+// minimize_team.hip: the kernels of the cooperative class (several workgroups per system)
+int launch_team_kernel(int threads, bool profile, unsigned grid, size_t shmem, hipStream_t stream, const Batch& b, const BfgsArgs& A);
 }  // namespace minim
 }  // namespace nvmk
 
@@ -239,7 +151,7 @@ SideStreams* create_side_streams(const int dev) {
          hipEventCreateWithFlags(&t->join[k], hipEventDisableTiming) == hipSuccess;
   }
   ok = ok && hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipHostMalloc(reinterpret_cast<void**>(&t->started), 64, hipHostMallocMapped) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void**>(&t->started), 256, hipHostMallocMapped) == hipSuccess;
   ok = ok && hipHostGetDevicePointer(reinterpret_cast<void**>(&t->startedDev), t->started, 0) == hipSuccess;
   if (!ok) {
     t->destroy();
@@ -422,13 +334,39 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     return (c == 0 || c == kFirst128 || c == kFirst256 || c == kFirst512) ? std::max(firstBudget, bin_budget(c)) : bin_budget(c);
   };
   const int  kGlobal = nBins, kGlobal8 = nBins + 1;  // class indices of the HBM-vector systems: four waves, eight waves
+  // Team classes (several workgroups per system, minimize_team.hip): class kTeam0 + k = teams of 2^(k+1) workgroups.  A system of
+  // NVMK_BFGS_TEAM coordinates or more (default 1068: where the vectors of an eight-wave workgroup stop fitting LDS) joins the
+  // class of the largest power-of-two width that leaves every rank NVMK_BFGS_TEAM_SHARE_KB of the packed inverse Hessian (at
+  // least two workgroups, at most one XCD's CUs); NVMK_BFGS_TEAM_WIDTH sets one width for all of them (tests: any number up to
+  // 256, ranks then count across the XCDs).  The width of a system's team depends on its size only, and so do its results.
+  constexpr int kTeam0 = 14, kTeamClasses = 8, kNumClasses = kTeam0 + kTeamClasses;
+  const long    teamOpt   = opt::get(opt::kBfgsTeam).num(-1);
+  const int     kTeamMinN = teamOpt == 0 ? kNoLimit : teamOpt > 0 ? static_cast<int>(std::min<long>(teamOpt, kNoLimit)) : 1068;
+  const long    teamWidthOpt = opt::get(opt::kBfgsTeamWidth).num(0);
+  const long    teamShareKb  = std::max<long>(1, opt::get(opt::kBfgsTeamShareKb).num(512));
+  const int     teamThreads  = opt::get(opt::kBfgsTeamThreads).num(512) == 256 ? 256 : 512;
+  int           teamWidth[kTeamClasses];
+  for (int k = 0; k < kTeamClasses; ++k) teamWidth[k] = 2 << k;
+  auto team_class_of = [&](const int64_t n64) -> int {
+    if (teamWidthOpt > 0) {
+      const int w = static_cast<int>(std::min<long>(teamWidthOpt, 256));
+      int       k = 0;
+      while (k + 1 < kTeamClasses && (2 << k) < w) ++k;
+      teamWidth[k] = std::max(w, 1);
+      return kTeam0 + k;
+    }
+    const int64_t bytes = hess_row_offset(n64) * 8;
+    int           k     = 0;
+    while (k + 1 < 5 && bytes / (4 << k) >= teamShareKb * 1024) ++k;  // widths 2 .. 32
+    return kTeam0 + k;
+  };
 
   // ---- size classes
   struct Class {
     std::vector<int32_t> order;  // systems, largest first (stable)
     int                  maxN = 0;
   };
-  Class cls[14];
+  Class cls[kNumClasses];
   for (int s = 0; s < b.nSystems; ++s) {
     const int64_t n64 = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
     NVMK_REQUIRE(n64 >= 0, "bfgs: atom_starts must be non-decreasing");
@@ -436,7 +374,9 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
                  static_cast<long long>(n64));
     const bool wave8 = waveClass && n64 >= kWave8MinN;
     int        c     = wave8 ? kGlobal8 : kGlobal;
-    if (!allGlobal) {
+    if (!allGlobal && n64 >= kTeamMinN) {
+      c = team_class_of(n64);
+    } else if (!allGlobal) {
       // thread count by size alone, then the bin by the LDS policy
       const bool wave  = waveClass && n64 <= kWaveMaxN;
       const bool wave2 = !wave && waveClass && n64 <= kWave2MaxN;
@@ -502,9 +442,15 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     bool                 oneQueue = false;
     std::vector<int64_t> hs;  // one-system-per-workgroup bins: per-system offsets (indexed by system), else empty
     StreamScratch        hessMem, startsMem, orderMem, counterMem, vecMem;
+    // team classes: workgroups per team, teams in the launch, the exchange area and control words of the teams
+    int                             teamSize = 0, nTeams = 0;
+    bool                            xcdLocal = false;
+    int64_t                         exchStride = 0, teamVecStride = 0;
+    StreamScratch                   exchMem, ctrlMem;
+    std::vector<unsigned long long> ctrlHost;
   };
-  Plan   plan[14];
-  size_t slotBytes[14] = {};
+  Plan   plan[kNumClasses];
+  size_t slotBytes[kNumClasses] = {};
   for (int c = 0; c <= kGlobal8; ++c) {
     Plan& P = plan[c];
     if (cls[c].order.empty()) continue;
@@ -546,6 +492,43 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       slotBytes[c]  = static_cast<size_t>(P.slotDoubles + P.vecStride) * sizeof(double);
       P.grid        = static_cast<int>(std::min<size_t>(cls[c].order.size(), static_cast<size_t>(nCu) * (P.gvec ? (P.threads == 512 ? 1 : 2) : kBins[c].wgPerCu)));
     }
+  }
+  // Team classes: persistent teams of `width` workgroups, one workgroup per CU (512 threads) or two (256).  The ranks of a team
+  // are the blocks of one XCD (blockIdx % 8, as observed) while a team fits there; wider teams count their ranks across
+  // consecutive blocks.  Memory: one slot for the largest system's packed triangle per TEAM, the HBM vectors per workgroup, the
+  // exchange area (`width` partial vectors, the reduced vector, two rows of scalars) and eight control words per team.
+  for (int c = kTeam0; c < kNumClasses; ++c) {
+    Plan& P = plan[c];
+    if (cls[c].order.empty()) continue;
+    P.used       = true;
+    P.gvec       = true;
+    P.persistent = true;
+    P.threads    = teamThreads;
+    const int maxN     = cls[c].maxN;
+    const int capacity = nCu * (teamThreads == 512 ? 1 : 2);  // workgroups that are resident together
+    int       width    = std::max(1, std::min(teamWidth[c - kTeam0], capacity));
+    const int nItems   = static_cast<int>(cls[c].order.size());
+    P.xcdLocal         = nCu % 8 == 0 && (capacity / 8) % width == 0;
+    if (P.xcdLocal) {
+      const int perXcd = std::max(1, std::min((capacity / 8) / width, (nItems + 7) / 8));
+      P.nTeams         = 8 * perXcd;
+    } else {
+      P.nTeams = std::max(1, std::min(capacity / width, nItems));
+    }
+    P.teamSize = width;
+    P.grid     = P.nTeams * width;
+    // the pass's staging area in LDS: four coefficients and the sum of every row of a rank's block, as much of the block at a
+    // time as the share of a CU holds (a rank's block is at most the whole triangle's rows: width 1)
+    const int rowsLimit = teamThreads == 512 ? 2048 : 1024;
+    const int rowsCap   = std::min((maxN + 3) & ~3, rowsLimit);
+    P.ldsDoubles        = 5 * (rowsCap + 32);
+    P.shmem             = static_cast<size_t>(P.ldsDoubles) * sizeof(double);
+    P.vecStride         = (vec_doubles(P.threads, maxN) + 1) & ~int64_t{1};
+    P.slotDoubles       = ((hess_row_offset(maxN) + kHessTailPadDoubles) + 1) & ~int64_t{1};
+    P.teamVecStride     = (static_cast<int64_t>(maxN) + 2 + 1) & ~int64_t{1};
+    P.exchStride        = ((static_cast<int64_t>(width) + 1) * P.teamVecStride + 2 * width + 1) & ~int64_t{1};
+    for (int q = 0; q <= 8; ++q) P.queueStart[q] = q == 0 ? 0 : nItems;
+    P.oneQueue = true;
   }
   // A one-system-per-workgroup class holds the HBM part of EVERY system's inverse Hessian for the whole launch (16 384
   // attempts of ~150-atom molecules: 20-30 GB).  A class that wants more than a quarter of the free memory runs as a
@@ -607,7 +590,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     const long    g     = opt::get(opt::kBfgsXcdGroup).num(32);
     const int     kXcdGroup = g >= 1 && g <= 4096 ? static_cast<int>(g) : 32;
     for (int q = 0; q <= 8; ++q) P.queueStart[q] = q == 0 ? 0 : static_cast<int>(n);
-    if (P.oneQueue || b.sysMol == nullptr || kXcdGroup <= 1 || n < 16LL * kXcdGroup) continue;
+    if (P.oneQueue || b.sysMol == nullptr || kXcdGroup <= 1 || n < 16LL * kXcdGroup) continue;  // (team classes: one queue)
     std::vector<int32_t> queued;
     queued.reserve(order.size());
     for (int q = 0; q < 8; ++q) {
@@ -618,13 +601,21 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     P.queueStart[8] = static_cast<int>(queued.size());
     order.swap(queued);
   }
-  for (int c = 0; c <= kGlobal8; ++c) {
+  for (int c = 0; c < kNumClasses; ++c) {
     Plan& P = plan[c];
     if (!P.used) continue;
     const auto& order = cls[c].order;
     NVMK_HIP_CHECK(P.orderMem.alloc(order.size() * sizeof(int32_t), stream));
     NVMK_HIP_CHECK(hipMemcpyAsync(P.orderMem.ptr, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    if (!P.persistent) {
+    if (P.teamSize > 0) {
+      NVMK_HIP_CHECK(P.hessMem.alloc(static_cast<size_t>(P.slotDoubles) * static_cast<size_t>(P.nTeams) * sizeof(double), stream));
+      NVMK_HIP_CHECK(P.vecMem.alloc(static_cast<size_t>(P.vecStride) * static_cast<size_t>(P.grid) * sizeof(double), stream));
+      NVMK_HIP_CHECK(P.exchMem.alloc(static_cast<size_t>(P.exchStride) * static_cast<size_t>(P.nTeams) * sizeof(double), stream));
+      NVMK_HIP_CHECK(P.ctrlMem.alloc(static_cast<size_t>(P.nTeams) * kTeamCtrlWords * sizeof(unsigned long long), stream));
+      NVMK_HIP_CHECK(hipMemsetAsync(P.ctrlMem.ptr, 0, static_cast<size_t>(P.nTeams) * kTeamCtrlWords * sizeof(unsigned long long), stream));
+      NVMK_HIP_CHECK(P.counterMem.alloc(9 * sizeof(int), stream));
+      NVMK_HIP_CHECK(hipMemsetAsync(P.counterMem.ptr, 0, 9 * sizeof(int), stream));
+    } else if (!P.persistent) {
       NVMK_HIP_CHECK(P.hessMem.alloc(static_cast<size_t>(P.hs.back() + kHessTailPadDoubles) * sizeof(double), stream));
       NVMK_HIP_CHECK(P.startsMem.alloc(P.hs.size() * sizeof(int64_t), stream));
       NVMK_HIP_CHECK(hipMemcpyAsync(P.startsMem.ptr, P.hs.data(), P.hs.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
@@ -680,11 +671,22 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     A.stats       = g_stats.load();
     A.started     = (on != stream) ? startedDev : nullptr;
     A.drained     = (startedDev != nullptr && P.persistent) ? startedDev + 1 + c : nullptr;
+    A.teamSize       = P.teamSize;
+    A.teamXcdLocal   = P.xcdLocal ? 1 : 0;
+    A.teamExchange   = P.exchMem.as<double>();
+    A.teamExchStride = P.exchStride;
+    A.teamVecStride  = P.teamVecStride;
+    A.teamCtrl       = P.ctrlMem.as<unsigned long long>();
+    A.teamTimeout    = std::max<long>(1, opt::get(opt::kBfgsTeamTimeoutMs).num(60000)) * 100000LL;  // 100 MHz ticks
     char label[96];
     std::snprintf(label, sizeof(label), "BFGS %s: %d systems x %d threads%s", b.kind == NVMK_FF_DG ? "DG" : b.kind == NVMK_FF_ETK ? "ETK"
                   : (b.kind == NVMK_FF_MMFF || b.kind == KIND_MMFF_C) ? "MMFF" : (b.kind == NVMK_FF_UFF || b.kind == KIND_UFF_C) ? "UFF" : "quartic",
                   A.nItems, P.threads, P.gvec ? " (vectors in HBM)" : "");
+    if (P.teamSize > 0) {
+      std::snprintf(label, sizeof(label), "BFGS team class: %d systems, %d teams x %d workgroups x %d threads", A.nItems, P.nTeams, P.teamSize, P.threads);
+    }
     NVMK_MARK(label);  // the launch of this size class
+    if (P.teamSize > 0) return launch_team_kernel(P.threads, profile, static_cast<unsigned>(P.grid), P.shmem, on, b, A);
     auto go = [&](auto kern) -> int {
       if (P.shmem > 64 * 1024) {
         NVMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -736,7 +738,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // them, instead of one class waiting for the other (a 400-atom distance-geometry minimisation alone takes longer than
   // 4000 drug-sized ones).
   int nUsed = 0, lastUsed = -1;
-  for (int c = 0; c <= kGlobal8; ++c)
+  for (int c = 0; c < kNumClasses; ++c)
     if (plan[c].used) {
       ++nUsed;
       if (lastUsed < 0) lastUsed = c;  // the bin of the smallest systems in use stays on the caller's stream
@@ -745,10 +747,10 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     SideStreams* side = sideLease.take(dev);
     NVMK_REQUIRE(side != nullptr, "bfgs: could not create the side streams of device %d", dev);
     startedDev                                      = side->startedDev;
-    for (int w = 0; w < 16; ++w) static_cast<volatile int*>(side->started)[w] = 0;  // [0] started, [1 + c] class c drained
+    for (int w = 0; w < 64; ++w) static_cast<volatile int*>(side->started)[w] = 0;  // [0] started, [1 + c] class c drained
     NVMK_HIP_CHECK(hipEventRecord(side->fork, stream));
     int k = 0, bigWorkgroups = 0, prevClass = -1;
-    for (int c = kGlobal8; c >= 0; --c) {
+    for (int c = kNumClasses - 1; c >= 0; --c) {
       if (!plan[c].used) continue;
       if (queueMode && prevClass >= 0 && plan[prevClass].persistent) {
         // Classes one after the other, WITHOUT waiting for a class to finish: the next (smaller) class is launched when the
@@ -787,12 +789,27 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     }
     for (int j = 0; j < k; ++j) NVMK_HIP_CHECK(hipStreamWaitEvent(stream, side->join[j], 0));
   } else {
-    for (int c = kGlobal8; c >= 0; --c) {
+    for (int c = kNumClasses - 1; c >= 0; --c) {
       if (!plan[c].used) continue;
       rc = launch(c, stream);
       if (rc != NVMK_OK) return rc;
     }
   }
+  // the teams' failure flags (a barrier that gave up) come back with the results
+  for (int c = kTeam0; c < kNumClasses; ++c) {
+    Plan& P = plan[c];
+    if (!P.used) continue;
+    P.ctrlHost.assign(static_cast<size_t>(P.nTeams) * kTeamCtrlWords, 0ull);
+    NVMK_HIP_CHECK(hipMemcpyAsync(P.ctrlHost.data(), P.ctrlMem.ptr, P.ctrlHost.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  }
+  auto teams_ok = [&]() -> int {
+    for (int c = kTeam0; c < kNumClasses; ++c)
+      for (int t = 0; plan[c].used && t < plan[c].nTeams; ++t)
+        NVMK_REQUIRE(plan[c].ctrlHost[static_cast<size_t>(t) * kTeamCtrlWords + 1] == 0ull,
+                     "bfgs: a team of %d workgroups gave up waiting for its members (NVMK_BFGS_TEAM_TIMEOUT_MS); are %d workgroups of %d threads resident together on this device?",
+                     plan[c].teamSize, plan[c].grid, plan[c].threads);
+    return NVMK_OK;
+  };
 
   if (profile) {
     std::vector<int64_t> h(profWords);
@@ -832,10 +849,10 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
                    sum[0] / std::max(sum[5], 1.0) * us, sum[1] / std::max(sum[5], 1.0) * us, sum[2] / std::max(sum[5], 1.0) * us,
                    sum[3] / std::max(sum[5], 1.0) * us);
     }
-    return NVMK_OK;
+    return teams_ok();
   }
   NVMK_HIP_CHECK(hipStreamSynchronize(stream));  // host staging (pageable) must outlive its async copies; scratch is freed in stream order
-  return NVMK_OK;
+  return teams_ok();
 }
 
 }  // extern "C"

@@ -251,7 +251,7 @@ def test_eight_wave_class_agrees_with_four_waves_and_is_reproducible(kind):
     w0, w1 = W[kind]
     runs = {}
     for name, opt in (("eight", None), ("eight again", None), ("four", "0"), ("all eight", "2")):
-        with _native.options(NVMK_BFGS_WAVE8=opt):
+        with _native.options(NVMK_BFGS_WAVE8=opt, NVMK_BFGS_TEAM="0"):  # (teams would take the systems beyond 1067 coordinates)
             pos = torch.from_numpy(flat).cuda()
             e, st, it = gpu.minimize(pos, max_iters=10, grad_tol=1e-14, w0=w0, w1=w1)
             runs[name] = (pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy())
@@ -270,6 +270,148 @@ def test_eight_wave_class_agrees_with_four_waves_and_is_reproducible(kind):
             assert np.array_equal(runs["eight"][0][lo:hi], runs["four"][0][lo:hi]), n
         else:              # ... above it the waves differ, so the sums' order does
             assert not np.array_equal(runs["eight"][0][lo:hi], runs["four"][0][lo:hi]), n
+
+
+# ---- the cooperative class (round 6): several workgroups per system, csrc/bfgs_device.inc `Team`, csrc/minimize_team.hip.  The
+# reference runs systems of any size through global-memory instantiations of its one-block kernel
+# (bfgs_minimize_permol_kernels.cu:796-932); here a system of 1068 coordinates or more is minimised by a TEAM of workgroups that
+# deal the inverse Hessian's rows and the force-field terms among themselves ---------------------------------------------------
+TEAM_WIDTHS = ["2", "3", "8", "32", "40"]  # 3 and 40 do not divide an XCD's CUs: ranks counted across consecutive blocks
+
+
+@pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
+@pytest.mark.parametrize("width", TEAM_WIDTHS)
+def test_team_class_matches_oracle_at_every_size(kind, width):
+    """NVMK_BFGS_TEAM=1 sends EVERY system through the team kernels (NVMK_BFGS_TEAM_WIDTH workgroups each): the oracle's
+    trajectories from 5 to 200 atoms after 1, 3 and 10 iterations — teams wider than a system has rows or terms included —
+    and the same bits when the call is repeated."""
+    systems = systems_of(kind, SIZES, 500 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    cpu = ffc.Batch(kind, a_s, groups)
+    w0, w1 = W[kind]
+    for iters, tol in ((1, 1e-9), (3, 1e-8), (10, 1e-6)):
+        x, ec, stc, itc = cpu.minimize(flat, max_iters=iters, grad_tol=1e-14, w0=w0, w1=w1)
+        runs = []
+        for _ in range(2):
+            pos = torch.from_numpy(flat).cuda()
+            with _native.options(NVMK_BFGS_TEAM="1", NVMK_BFGS_TEAM_WIDTH=width, NVMK_BFGS_TEAM_TIMEOUT_MS="5000"):
+                e, st, it = gpu.minimize(pos, max_iters=iters, grad_tol=1e-14, w0=w0, w1=w1)
+            runs.append((pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy()))
+        got, e, it = runs[0]
+        assert np.array_equal(it, itc)
+        assert np.max(np.abs(got - x)) <= tol, (iters, np.max(np.abs(got - x)))
+        np.testing.assert_allclose(e, ec, rtol=100 * tol, atol=100 * tol)
+        assert all(np.array_equal(a, b) for a, b in zip(runs[0], runs[1])), "a team's sums have a fixed order"
+
+
+@pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
+@pytest.mark.parametrize("threads", ["512", "256"])
+def test_team_class_at_600_to_4000_coordinates(kind, threads):
+    """The sizes the class is for, at the widths the library picks by itself (4 .. 32 workgroups): 150, 400 and 1000 atoms = 600 /
+    1600 / 4000 coordinates in 4-D, 450 / 1200 / 3000 in 3-D (the smallest one stays with the one-workgroup classes unless it
+    reaches 1068 coordinates), one and two workgroups per CU.  Ten iterations against the oracle, and twice for the same bits."""
+    sizes = [150, 400, 1000]
+    systems = systems_of(kind, sizes, 2100 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    cpu = ffc.Batch(kind, a_s, groups)
+    w0, w1 = W[kind]
+    x, ec, stc, itc = cpu.minimize(flat, max_iters=10, grad_tol=1e-14, w0=w0, w1=w1)
+    runs = []
+    for _ in range(2):
+        pos = torch.from_numpy(flat).cuda()
+        with _native.options(NVMK_BFGS_TEAM_THREADS=threads, NVMK_BFGS_TEAM_TIMEOUT_MS="5000"):
+            e, st, it = gpu.minimize(pos, max_iters=10, grad_tol=1e-14, w0=w0, w1=w1)
+        runs.append((pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy()))
+    got, e, it = runs[0]
+    assert np.array_equal(it, itc)
+    for s in range(len(sizes)):
+        lo, hi = a_s[s] * gpu.dim, a_s[s + 1] * gpu.dim
+        assert np.max(np.abs(got[lo:hi] - x[lo:hi])) <= 1e-6, (sizes[s], np.max(np.abs(got[lo:hi] - x[lo:hi])))
+    np.testing.assert_allclose(e, ec, rtol=1e-4, atol=1e-4)
+    assert all(np.array_equal(a, b) for a, b in zip(runs[0], runs[1]))
+
+
+def test_team_results_depend_on_the_system_and_the_width_only():
+    """A team's system gets the same bits alone, among other team systems (teams take several systems one after the other, the
+    slot of inverse-Hessian memory is reused with another deal of the rows) and next to the one-workgroup classes."""
+    sizes = [300, 20, 280, 48, 330, 300, 90, 270, 300]
+    systems = systems_of(DG, sizes, 2300)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(DG, systems)
+    gpu = FlatForcefieldBatch(DG, a_s, groups)
+    with _native.options(NVMK_BFGS_TEAM_WIDTH="32", NVMK_BFGS_TEAM_TIMEOUT_MS="5000"):  # 8 teams for 6 team systems ... and with 16: 1 team per 2
+        pos = torch.from_numpy(flat).cuda()
+        e, st, it = gpu.minimize(pos, max_iters=8, grad_tol=1e-14, w0=0.7, w1=0.3)
+        got = pos.cpu().numpy()
+        for s in (0, 4, 5):
+            one = FlatForcefieldBatch(DG, np.array([0, sizes[s]]), [_slice_group(g, s) for g in groups])
+            lo, hi = a_s[s] * 4, a_s[s + 1] * 4
+            p1 = torch.from_numpy(flat[lo:hi].copy()).cuda()
+            e1, _, it1 = one.minimize(p1, max_iters=8, grad_tol=1e-14, w0=0.7, w1=0.3)
+            assert int(it1[0]) == int(it[s]) and np.array_equal(got[lo:hi], p1.cpu().numpy()) and float(e1[0]) == float(e[s]), s
+    with _native.options(NVMK_BFGS_TEAM_WIDTH="128", NVMK_BFGS_TEAM_TIMEOUT_MS="5000"):  # two teams for six systems: every team takes three
+        pos = torch.from_numpy(flat).cuda()
+        gpu.minimize(pos, max_iters=8, grad_tol=1e-14, w0=0.7, w1=0.3)
+        again = torch.from_numpy(flat).cuda()
+        gpu.minimize(again, max_iters=8, grad_tol=1e-14, w0=0.7, w1=0.3)
+        assert torch.equal(pos, again)
+        assert np.max(np.abs(pos.cpu().numpy() - got)) <= 1e-6 and not np.array_equal(pos.cpu().numpy(), got)
+
+
+@pytest.mark.parametrize("kind", [DG, MMFF])
+def test_team_restarts_and_second_stage_equal_separate_calls(kind):
+    """repeatUntilConverged and the second minimisation inside a team launch (the coordinates stay in the ranks' work areas between
+    the minimisations; only rank 0 writes the caller's array): bit for bit what separate calls give."""
+    import ctypes
+
+    sizes = [12, 30, 60, 130]
+    systems = systems_of(kind, sizes, 1500 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    w0, w1 = W[kind]
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    n_sys = len(sizes)
+    with _native.options(NVMK_BFGS_TEAM="1", NVMK_BFGS_TEAM_WIDTH="4", NVMK_BFGS_TEAM_TIMEOUT_MS="5000"):
+        one = torch.from_numpy(flat).cuda()
+        e1, st1, it1 = gpu.minimize(one, max_iters=7, grad_tol=1e-3, w0=w0, w1=w1, restarts=3)
+        many = torch.from_numpy(flat).cuda()
+        active = torch.ones(n_sys, dtype=torch.uint8, device="cuda")
+        e2 = torch.zeros(n_sys, dtype=torch.float64, device="cuda")
+        st2 = torch.zeros(n_sys, dtype=torch.int16, device="cuda")
+        it2 = torch.zeros(n_sys, dtype=torch.int32, device="cuda")
+        for _ in range(4):
+            e, st, it = gpu.minimize(many, max_iters=7, grad_tol=1e-3, w0=w0, w1=w1, active=active)
+            ran = active.bool()
+            e2[ran], st2[ran], it2[ran] = e[ran], st[ran], it[ran]
+            active = (ran & (st != 0)).to(torch.uint8)
+        assert torch.equal(one, many) and torch.equal(e1, e2) and torch.equal(st1, st2) and torch.equal(it1, it2)
+        if kind != DG:
+            return
+        # second stage in the same launch
+        two = torch.from_numpy(flat).cuda()
+        ea, sta, ita = gpu.minimize(two, max_iters=9, grad_tol=1e-3, w0=1.0, w1=0.1, restarts=2)
+        between = two.clone()
+        eb, stb, itb = gpu.minimize(two, max_iters=6, grad_tol=1e-3, w0=0.2, w1=1.0, restarts=1)
+        per_atom = (ea / torch.from_numpy(np.diff(a_s)).cuda()).cpu().numpy()
+        limit = float(np.median(per_atom))
+        skip = per_atom > limit
+        pos = torch.from_numpy(flat).cuda()
+        mid = torch.zeros_like(pos)
+        energies = torch.zeros(n_sys, dtype=torch.float64, device="cuda")
+        statuses = torch.zeros(n_sys, dtype=torch.int16, device="cuda")
+        iters = torch.zeros(n_sys, dtype=torch.int32, device="cuda")
+        second = _native.BfgsSecondStage(0.2, 1.0, 6, 1, mid.data_ptr(), limit)
+        rc = _native.lib().nvmk_bfgs_minimize_two_stages(ctypes.byref(gpu._c), gpu.atom_starts_host.ctypes.data, 1.0, 0.1, 9, 2,
+                                                          ctypes.byref(second), 1e-3, 1, pos.data_ptr(), None, energies.data_ptr(),
+                                                          statuses.data_ptr(), iters.data_ptr(), None)
+        _native.check(rc, "nvmk_bfgs_minimize_two_stages")
+        torch.cuda.synchronize()
+        assert torch.equal(mid, between)
+        for s in range(n_sys):
+            lo, hi = a_s[s] * 4, a_s[s + 1] * 4
+            want_pos, want = (between, (ea, sta, ita)) if skip[s] else (two, (eb, stb, itb))
+            assert torch.equal(pos[lo:hi], want_pos[lo:hi]), s
+            assert float(energies[s]) == float(want[0][s]) and int(statuses[s]) == int(want[1][s]) and int(iters[s]) == int(want[2][s]), s
 
 
 def _slice_group(g, s):

@@ -32,6 +32,9 @@
 #   ab_half_prune       (with tools/experiments/panel_half_k_prune.patch applied) tools/bench_butina.py at 1M on the product library and on
 #                       lib/libnvmolkit_amd_noprune.so (NVMK_EXTRA_HIPCC_FLAGS=-DNVMK_PANEL_NO_HALF_PRUNE NVMK_BUILD_VARIANT=noprune)
 #   panel_fetch         tools/profile_panel_fetch.sh: FETCH_SIZE of the row-panel count kernel, product and variant libraries
+#   team_tests          the cooperative BFGS class's tests (tests/test_bfgs_parity_gpu.py -k team)
+#   large_profile       the same with NVMK_BFGS_PROFILE=1: the kernels' phase clocks per size
+#   large_systems       tools/bench_large_systems.py: microseconds per BFGS iteration of 300 ... 1063-atom systems, 1 ... 256 copies
 #   butina_bench        tools/bench_butina.py 1000000 --repeat 3 on the planted clusters and on the wide-popcount-spread set
 #   butina              tools/bench_butina.py + clustering tests (ab_butina: the bench alone, tile against panel kernel)
 set -u
@@ -279,6 +282,21 @@ PY
       ;;
     panel_fetch)
       bash tools/profile_panel_fetch.sh $O 2>&1 | tail -40
+      ;;
+    team_tests)
+      ( time timeout 1200 python -m pytest tests/test_bfgs_parity_gpu.py -m gpu -q -x -k "team" ) > $O/team_tests.log 2>&1
+      tail -15 $O/team_tests.log
+      ;;
+    large_profile)
+      for K in dg mmff; do
+        NVMK_BFGS_PROFILE=1 timeout 600 python tools/bench_large_systems.py --kind $K --atoms ${LARGE_ATOMS:-300,500,1063} --copies ${LARGE_COPIES:-1,64} --repeat 1 2>&1 | grep -E "^\{|profile" | tee -a $O/large_profile.txt
+      done
+      ;;
+    large_systems)
+      : > $O/large_systems.jsonl
+      for K in dg mmff; do
+        timeout 900 python tools/bench_large_systems.py --kind $K --atoms ${LARGE_ATOMS:-300,500,800,1063} --copies ${LARGE_COPIES:-1,8,64,256} 2>> $O/large_systems.err | tee -a $O/large_systems.jsonl
+      done
       ;;
     butina_bench)
       timeout 300 python tools/bench_butina.py 1000000 --repeat 3 2>/dev/null | tail -1 | cut -c1-500 | tee $O/butina_bench.txt
