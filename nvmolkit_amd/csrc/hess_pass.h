@@ -413,24 +413,27 @@ __device__ __forceinline__ void hess_pass(double* __restrict__ diag, double* __r
 
 // ---- the pass of ONE RANK of a cooperative team (bfgs_team_kernel: several workgroups per system) ---------------------------------
 // The rows of the triangle are dealt over the team's workgroups in contiguous blocks of about equal cost; this workgroup walks
-// rows [Ra, Rb) of the whole triangle in HBM (Hg, row 0 first) and leaves in `part` (n-vectors in its HBM work area) what it
-// contributes to t = H g:  part[i] for its own rows = the diagonal's term + the row's sum,  part[(1 + w) n + i], i < Rb = wave w's
-// mirrored-entry sums.  The vectors themselves (diag, xi, hdg, uu, g) are the workgroup's own full copies in HBM; what a row needs
-// of them (its four coefficients) and the row sums live in LDS for the duration of the pass — `stage`, 5 x (rowsCap + 32)
-// doubles — because in HBM every group of four rows waits for its coefficient loads and its sum's read-modify-write, and the
-// hardware returns loads in order, so that wait also drains the matrix rows requested ahead (the HBM-vector class without a
-// team streams at 12 GB/s per workgroup for this reason).  Blocks taller than rowsCap are walked in several sub-blocks.
-// The diagonal is updated by every rank on its own copy.
+// rows [Ra, Rb) of the whole triangle in HBM (Hg, row 0 first) and leaves what it contributes to t = H g in LDS:
+//   colTot[i], i < Rb   the mirrored-entry sums of column i over its rows (the waves' sums added in wave order),
+//   rowSum(r), Ra <= r < Rb  the diagonal's term + row r's sum          (team_pass_contribution below reads both).
+// The vectors themselves (diag, xi, hdg, uu, g) are the workgroup's own full copies in HBM; what a ROW needs of them (its four
+// coefficients) and the row sums live in LDS for the duration of the pass, because in HBM every group of four rows waits for its
+// coefficient loads and for its sum's read-modify-write, and the hardware returns loads in order, so that wait also drains the
+// matrix rows requested ahead (the HBM-vector class without a team streams at 12 GB/s per workgroup for this reason).  The waves'
+// mirrored-entry sums of a 256-column chunk meet in LDS too (two scratch blocks in turn, one barrier per chunk) instead of in
+// per-wave n-vectors in HBM.  LDS: colTot = n doubles; stage = 5 x (rowsCap + kTeamStagePad) + 2 x NW x 256 doubles.  Blocks
+// taller than rowsCap are walked in several sub-blocks (the row sums of a sub-block are then moved to `rowOut`, an n-vector in
+// HBM, instead of staying in LDS: `rowsInLds` tells the caller).  The diagonal is updated by every rank on its own copy.
 constexpr int kTeamStagePad = 32;  // hess_range reads the coefficients of up to 3 NW rows past a range's end (and never uses them)
+__host__ __device__ constexpr int team_pass_stage_doubles(const int rowsCap) { return 5 * (rowsCap + kTeamStagePad) + 2 * NW * 256; }
 template <bool PREFETCH = true>
 __device__ __forceinline__ void hess_pass_rows(double* __restrict__ diag, double* __restrict__ Hg, const int Ra, const int Rb, const int n,
                                                const bool pending, const double rfac, const double fad, const double fae,
                                                const double* __restrict__ xi, const double* __restrict__ hdg,
-                                               const double* __restrict__ uu, const double* __restrict__ g, double* __restrict__ part,
-                                               double* __restrict__ stage, const int rowsCap) {
+                                               const double* __restrict__ uu, const double* __restrict__ g, double* __restrict__ colTot,
+                                               double* __restrict__ stage, const int rowsCap, double* __restrict__ rowOut) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  double*   colsum = part + (1 + wave) * n;
   for (int i = threadIdx.x; i < n; i += NT) {
     double d = diag[i];
     if (pending) {
@@ -440,17 +443,20 @@ __device__ __forceinline__ void hess_pass_rows(double* __restrict__ diag, double
   }
   const int stride = rowsCap + kTeamStagePad;
   double *sg = stage, *sx = stage + stride, *sh = stage + 2 * stride, *su = stage + 3 * stride, *ss = stage + 4 * stride;
+  double*   scratch = stage + 5 * stride;  // 2 x NW x 256
+  int       flip    = 0;
   for (int ra = Ra; ra < Rb; ra += rowsCap) {
     const int rb = min(Rb, ra + rowsCap);
-    __syncthreads();  // the previous sub-block's sums have been taken out of the staging area (and, first time round, whoever used this LDS before is done)
+    __syncthreads();  // the previous sub-block's sums have left the staging area (first time round: whoever used this LDS before is done, and every diag entry is written)
     for (int i = threadIdx.x; i < rb - ra + kTeamStagePad; i += NT) {
       const int  r  = ra + i;
       const bool in = r < rb;
-      sg[i] = in ? g[r] : 0.0;
+      const double gr = in ? g[r] : 0.0;
+      sg[i] = gr;
       sx[i] = in ? xi[r] : 0.0;
       sh[i] = in ? hdg[r] : 0.0;
       su[i] = in ? uu[r] : 0.0;
-      ss[i] = in ? diag[r] * g[r] : 0.0;  // (this thread's own diag entries when i strides like the loop above: rb - ra <= rowsCap, any thread otherwise — hence the barrier below)
+      ss[i] = in ? diag[r] * gr : 0.0;
     }
     __syncthreads();
     // (the first sub-block also visits the column chunks only later sub-blocks have rows in, so that every column below Rb starts
@@ -468,16 +474,33 @@ __device__ __forceinline__ void hess_pass_rows(double* __restrict__ diag, double
       }
       const int lo2 = max(mid, ra);
       if (lo2 < rb) hess_range<2, PREFETCH, true>(Hg, 0, lo2, rb, wave, lane, ck, pending, sx - ra, sh - ra, su - ra, sg - ra, ss - ra, col);
+      // the waves' sums of this chunk's 256 columns, added in wave order by the column's thread
+      double* sc = scratch + flip * (NW * 256);
+      flip ^= 1;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {  // this wave's mirrored-entry sums of its columns: single writer; later sub-blocks add to the first one's
-        const int c0 = ck[k].c0;
-        if (c0 < n) colsum[c0] = (ra == Ra ? 0.0 : colsum[c0]) + col[k][0];
-        if (c0 + 1 < n) colsum[c0 + 1] = (ra == Ra ? 0.0 : colsum[c0 + 1]) + col[k][1];
+      for (int k = 0; k < 2; ++k) *reinterpret_cast<double2*>(sc + wave * 256 + 128 * k + 2 * lane) = make_double2(col[k][0], col[k][1]);
+      __syncthreads();  // (one per chunk: the block written two chunks ago was read before the previous chunk's barrier)
+      if (threadIdx.x < 256 && cBase + static_cast<int>(threadIdx.x) < n) {
+        double v = sc[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += sc[w * 256 + threadIdx.x];
+        const int c = cBase + static_cast<int>(threadIdx.x);
+        colTot[c]   = ra == Ra ? v : colTot[c] + v;
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < rb - ra; i += NT) part[ra + i] = ss[i];
+    if (Rb - Ra > rowsCap) {  // several sub-blocks: the row sums move out before the staging area is refilled
+      for (int i = threadIdx.x; i < rb - ra; i += NT) rowOut[ra + i] = ss[i];
+    }
   }
+}
+// What this rank adds to (H g)[i] after hess_pass_rows: the column's sums, and for its own rows the row's.
+__device__ __forceinline__ double team_pass_contribution(const int i, const int Ra, const int Rb, const int rowsCap, const double* __restrict__ colTot,
+                                                         const double* __restrict__ stage, const double* __restrict__ rowOut) {
+  if (i >= Rb) return 0.0;
+  double v = colTot[i];
+  if (i >= Ra) v += (Rb - Ra > rowsCap) ? rowOut[i] : stage[4 * (rowsCap + kTeamStagePad) + (i - Ra)];
+  return v;
 }
 
 // t = H g from the partial sums of the pass (fixed summation order).

@@ -345,6 +345,10 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   const long    teamWidthOpt = opt::get(opt::kBfgsTeamWidth).num(0);
   const long    teamShareKb  = std::max<long>(1, opt::get(opt::kBfgsTeamShareKb).num(512));
   const int     teamThreads  = opt::get(opt::kBfgsTeamThreads).num(512) == 256 ? 256 : 512;
+  // a rank's LDS (trial positions + gradient slabs / the pass's staging area, bfgs_device.inc): all of a CU's for one workgroup of
+  // 512 threads, half of it for each of two workgroups of 256; a system must leave room for one gradient slab behind its positions
+  const int     teamLdsDoubles = teamThreads == 512 ? 19200 : 9600;
+  const int     kTeamMaxN      = teamLdsDoubles / 2;
   int           teamWidth[kTeamClasses];
   for (int k = 0; k < kTeamClasses; ++k) teamWidth[k] = 2 << k;
   auto team_class_of = [&](const int64_t n64) -> int {
@@ -374,7 +378,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
                  static_cast<long long>(n64));
     const bool wave8 = waveClass && n64 >= kWave8MinN;
     int        c     = wave8 ? kGlobal8 : kGlobal;
-    if (!allGlobal && n64 >= kTeamMinN) {
+    if (!allGlobal && n64 >= kTeamMinN && n64 <= kTeamMaxN) {
       c = team_class_of(n64);
     } else if (!allGlobal) {
       // thread count by size alone, then the bin by the LDS policy
@@ -517,11 +521,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     }
     P.teamSize = width;
     P.grid     = P.nTeams * width;
-    // the pass's staging area in LDS: four coefficients and the sum of every row of a rank's block, as much of the block at a
-    // time as the share of a CU holds (a rank's block is at most the whole triangle's rows: width 1)
-    const int rowsLimit = teamThreads == 512 ? 2048 : 1024;
-    const int rowsCap   = std::min((maxN + 3) & ~3, rowsLimit);
-    P.ldsDoubles        = 5 * (rowsCap + 32);
+    P.ldsDoubles        = teamLdsDoubles;
     P.shmem             = static_cast<size_t>(P.ldsDoubles) * sizeof(double);
     P.vecStride         = (vec_doubles(P.threads, maxN) + 1) & ~int64_t{1};
     P.slotDoubles       = ((hess_row_offset(maxN) + kHessTailPadDoubles) + 1) & ~int64_t{1};

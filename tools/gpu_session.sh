@@ -33,6 +33,8 @@
 #                       lib/libnvmolkit_amd_noprune.so (NVMK_EXTRA_HIPCC_FLAGS=-DNVMK_PANEL_NO_HALF_PRUNE NVMK_BUILD_VARIANT=noprune)
 #   panel_fetch         tools/profile_panel_fetch.sh: FETCH_SIZE of the row-panel count kernel, product and variant libraries
 #   team_tests          the cooperative BFGS class's tests (tests/test_bfgs_parity_gpu.py -k team)
+#   ubench_team_pass    tools/ubench_team_pass.hip: the team pass alone, chip-wide, by size / width / threads
+#   team_sweep          bench_large_systems over team widths x threads per workgroup
 #   large_profile       the same with NVMK_BFGS_PROFILE=1: the kernels' phase clocks per size
 #   large_systems       tools/bench_large_systems.py: microseconds per BFGS iteration of 300 ... 1063-atom systems, 1 ... 256 copies
 #   butina_bench        tools/bench_butina.py 1000000 --repeat 3 on the planted clusters and on the wide-popcount-spread set
@@ -286,6 +288,22 @@ PY
     team_tests)
       ( time timeout 1200 python -m pytest tests/test_bfgs_parity_gpu.py -m gpu -q -x -k "team" ) > $O/team_tests.log 2>&1
       tail -15 $O/team_tests.log
+      ;;
+    ubench_team_pass)
+      for T in 512 256; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DUBENCH_THREADS=$T tools/ubench_team_pass.hip -o /tmp/utp_$T 2>/dev/null & done; wait
+      : > $O/ubench_team_pass.jsonl
+      for N in ${UTP_N:-1200 2000 4252}; do for W in ${UTP_W:-1 8 32}; do
+        timeout 120 /tmp/utp_512 $N $W 256 10 >> $O/ubench_team_pass.jsonl
+        timeout 120 /tmp/utp_256 $N $W 512 10 1024 >> $O/ubench_team_pass.jsonl
+      done; done
+      cat $O/ubench_team_pass.jsonl
+      ;;
+    team_sweep)
+      : > $O/team_sweep.txt
+      for T in 512 256; do for W in ${SWEEP_WIDTHS:-4 8 16 32}; do
+        echo "== threads $T width $W" | tee -a $O/team_sweep.txt
+        NVMK_BFGS_TEAM_THREADS=$T NVMK_BFGS_TEAM_WIDTH=$W timeout 300 python tools/bench_large_systems.py --kind ${SWEEP_KIND:-dg} --atoms ${LARGE_ATOMS:-300,500,800,1063} --copies ${LARGE_COPIES:-1,256} --repeat 1 2>/dev/null | cut -c1-220 | tee -a $O/team_sweep.txt
+      done; done
       ;;
     large_profile)
       for K in dg mmff; do
