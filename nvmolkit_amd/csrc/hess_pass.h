@@ -434,11 +434,18 @@ __device__ __forceinline__ void hess_pass_rows(double* __restrict__ diag, double
                                                double* __restrict__ stage, const int rowsCap, double* __restrict__ rowOut) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  for (int i = threadIdx.x; i < n; i += NT) {
-    double d = diag[i];
-    if (pending) {
-      d += rfac * xi[i] * xi[i] - fad * hdg[i] * hdg[i] + fae * uu[i] * uu[i];
-      diag[i] = d;
+  if (pending) {  // (batches of four elements: the loads of a batch are in flight together)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * NT) {
+      double d[4], x[4], h[4], u[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = min(i0 + k * NT, n - 1);
+        d[k] = diag[i], x[k] = xi[i], h[k] = hdg[i], u[k] = uu[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i0 + k * NT < n) diag[i0 + k * NT] = d[k] + (rfac * x[k] * x[k] - fad * h[k] * h[k] + fae * u[k] * u[k]);
+      }
     }
   }
   const int stride = rowsCap + kTeamStagePad;
@@ -448,15 +455,25 @@ __device__ __forceinline__ void hess_pass_rows(double* __restrict__ diag, double
   for (int ra = Ra; ra < Rb; ra += rowsCap) {
     const int rb = min(Rb, ra + rowsCap);
     __syncthreads();  // the previous sub-block's sums have left the staging area (first time round: whoever used this LDS before is done, and every diag entry is written)
-    for (int i = threadIdx.x; i < rb - ra + kTeamStagePad; i += NT) {
-      const int  r  = ra + i;
-      const bool in = r < rb;
-      const double gr = in ? g[r] : 0.0;
-      sg[i] = gr;
-      sx[i] = in ? xi[r] : 0.0;
-      sh[i] = in ? hdg[r] : 0.0;
-      su[i] = in ? uu[r] : 0.0;
-      ss[i] = in ? diag[r] * gr : 0.0;
+    for (int i0 = threadIdx.x; i0 < rb - ra + kTeamStagePad; i0 += 2 * NT) {
+      double v[2][5];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int r = min(ra + i0 + k * NT, rb - 1);
+        v[k][0] = g[r], v[k][1] = xi[r], v[k][2] = hdg[r], v[k][3] = uu[r], v[k][4] = diag[r];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = i0 + k * NT;
+        if (i < rb - ra + kTeamStagePad) {
+          const bool in = ra + i < rb;
+          sg[i] = in ? v[k][0] : 0.0;
+          sx[i] = in ? v[k][1] : 0.0;
+          sh[i] = in ? v[k][2] : 0.0;
+          su[i] = in ? v[k][3] : 0.0;
+          ss[i] = in ? v[k][4] * v[k][0] : 0.0;
+        }
+      }
     }
     __syncthreads();
     // (the first sub-block also visits the column chunks only later sub-blocks have rows in, so that every column below Rb starts

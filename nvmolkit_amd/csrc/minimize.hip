@@ -833,8 +833,9 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
             const int64_t* r = h.data() + static_cast<size_t>(sI) * kProfWords;
             if (r[8] == 0) continue;
             const unsigned hw = static_cast<unsigned>(r[9] & 0xffffffff), xcc = static_cast<unsigned>(r[9] >> 32) & 0xf;
-            std::fprintf(f, "%d %d %lld %lld %u %u %u %lld %lld\n", b.kind, (h_atom_starts[sI + 1] - h_atom_starts[sI]) * dim,
-                         (long long)r[7], (long long)r[8], xcc, (hw >> 8) & 0xf, (hw >> 4) & 0x3, (long long)r[5], (long long)r[4]);
+            std::fprintf(f, "%d %d %lld %lld %u %u %u %lld %lld %lld\n", b.kind, (h_atom_starts[sI + 1] - h_atom_starts[sI]) * dim,
+                         (long long)r[7], (long long)r[8], xcc, (hw >> 8) & 0xf, (hw >> 4) & 0x3, (long long)r[5], (long long)r[4],
+                         (long long)r[10]);  // (last: workgroups of the system's team, 0 = one workgroup)
           }
           std::fclose(f);
         }

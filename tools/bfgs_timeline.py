@@ -22,9 +22,10 @@ args = ap.parse_args()
 op = gzip.open if args.file.endswith(".gz") else open
 rec = np.loadtxt(op(args.file, "rt"), dtype=np.int64, ndmin=2)
 kind, n, t0, t1, iters = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 7]
-waves = np.where(n <= args.wave, 1, np.where(n <= args.wave2, 2, 4))
+team = rec[:, 9] if rec.shape[1] > 9 else np.zeros_like(n)  # workgroups of the system's team (round 6), 0 = one workgroup
+waves = np.where(team > 0, 8 * team, np.where(n <= args.wave, 1, np.where(n <= args.wave2, 2, np.where((args.wave8 > 0) & (n >= args.wave8), 8, 4))))
 order = np.argsort(t0)
-kind, n, t0, t1, waves, iters = kind[order], n[order], t0[order], t1[order], waves[order], iters[order]
+kind, n, t0, t1, waves, iters, team = kind[order], n[order], t0[order], t1[order], waves[order], iters[order], team[order]
 # launch groups: a new group starts where a system begins after everything before it has ended (plus 20 us of slack)
 groups, start, end = [], 0, t1[0]
 for i in range(1, len(t0)):
@@ -42,7 +43,7 @@ for a, b in groups:
     # occupancy curve on a 100-us grid
     edges = np.arange(s, e + 10000, 10000)
     occ = np.zeros(len(edges) - 1)
-    for w in (1, 2, 4):
+    for w in np.unique(waves[a:b]):
         m = waves[a:b] == w
         if not m.any():
             continue
@@ -90,6 +91,18 @@ for hi, name in bounds:
                             "wall_fraction_below_256_in_flight": float(dt[(level > 0) & (level < 256)].sum()) / max(busy_wall, 1.0),
                             "wall_fraction_below_64_in_flight": float(dt[(level > 0) & (level < 64)].sum()) / max(busy_wall, 1.0),
                             "mean_in_flight": float((dt * level).sum()) / max(busy_wall, 1.0)})
+# round 6: the team classes by width — systems, CU-milliseconds (run time x workgroups), iterations, inverse-Hessian bytes per second
+# and CU while a system of the class runs
+out["by_team_width"] = []
+for w in np.unique(team):
+    m = team == w
+    cus = np.maximum(w, 1) if w > 0 else waves[m] / 8.0
+    dur = (t1[m] - t0[m]).astype(np.float64) * 1e-5  # ms
+    nbytes = 8.0 * n[m].astype(np.float64) * (n[m] + 2) * iters[m]
+    out["by_team_width"].append({"workgroups_per_system": int(w), "systems": int(m.sum()), "coordinates_min_max": [int(n[m].min()), int(n[m].max())],
+                                 "cu_ms_total": float((dur * cus).sum()), "longest_system_ms": float(dur.max()), "mean_iterations": float(iters[m].mean()),
+                                 "inverse_hessian_TB": float(nbytes.sum()) * 1e-12,
+                                 "GB_per_s_per_cu_while_running": float(nbytes.sum()) / max(float((dur * cus).sum()) * 1e-3, 1e-9) * 1e-9})
 out["total_span_ms"] = tot_span * 1e-3
 out["total_mean_occupancy"] = tot_busy / (tot_span * args.slots)
 out["total_tail_ms_below_half"] = tot_tail * 1e-3

@@ -17,6 +17,7 @@
 #   chembl256_timeline  the ChEMBL topologies of up to 256 atoms with the per-system BFGS timeline, summarised per size class
 #   wave8_tests         BFGS parity + inverse-Hessian update tests (the eight-wave class of round 5)
 #   ab_wave8            ChEMBL topologies of up to 256 atoms with NVMK_BFGS_WAVE8=0 (four waves for every large system) and the default, alternating
+#   chembl_all_timeline the whole file with the per-system BFGS timeline, summarised per class and team width
 #   chembl_all          every molecule of the ChEMBL file (up to 1063 atoms)
 #   conf10k             tools/bench_conformers.py --mols 10000 (resident tables, and end to end from the host arrays)
 #   pytest_gpu          the whole -m gpu suite (stops at the first failure; pytest_gpu_all: runs on)
@@ -209,6 +210,13 @@ PY
         echo "NVMK_BFGS_WAVE8=$W" | tee -a $O/ab_wave8.txt
         NVMK_BFGS_WAVE8=$W timeout 600 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 256 --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | cut -c1-700 | tee -a $O/ab_wave8.txt
       done
+      ;;
+    chembl_all_timeline)
+      rm -f $O/chembl_all_timeline.txt
+      NVMK_ETKDG_TIMING=1 NVMK_BFGS_PROFILE=1 NVMK_BFGS_TIMELINE=$O/chembl_all_timeline.txt timeout 1500 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --cache $CACHE > $O/chembl_all_timeline_run.log 2>&1
+      grep '^{' $O/chembl_all_timeline_run.log | tail -1 | cut -c1-600
+      python tools/bfgs_timeline.py $O/chembl_all_timeline.txt > $O/chembl_all_timeline_summary.json && python -c "import json; d=json.load(open('$O/chembl_all_timeline_summary.json')); print(json.dumps({k: d[k] for k in ('systems','launch_groups','total_mean_occupancy','total_tail_ms_below_half','wall_ms_first_to_last')})); print(json.dumps(d['by_team_width'], indent=0)); print(json.dumps(d['by_class'], indent=0)); print(json.dumps(sorted(d['groups'], key=lambda g: -g['span_ms'])[:12], indent=0))"
+      gzip -f $O/chembl_all_timeline.txt; rm -f $O/chembl_all_timeline.txt.gz
       ;;
     chembl_all)
       timeout 1200 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --end-to-end --cache $CACHE 2> $O/chembl_all.err | tee $O/chembl_all.json | cut -c1-900
