@@ -142,7 +142,8 @@ def kernel_source_digest(names=("similarity_mfma.hip", "fp4.h", "similarity.hip"
 
 def conformer_source_digest() -> str:
     """sha256 over the conformer kernels' sources (as tools/profile_conformer_traffic.sh computes it)."""
-    return kernel_source_digest(("minimize.hip", "bfgs_device.inc", "hess_pass.h", "ff_terms.h", "ff_grad.h", "etkdg.hip", "table_build.cpp"))
+    return kernel_source_digest(("minimize.hip", "minimize_team.hip", "bfgs_common.h", "bfgs_device.inc", "hess_pass.h", "ff_terms.h", "ff_grad.h",
+                                 "etkdg.hip", "table_build.cpp"))
 
 
 def butina_block(n: int, words: int, device, cpu_seconds: float) -> dict:
@@ -353,7 +354,8 @@ def strong_scaling_share(library, total: int, world: int, rank: int):
 
 def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int, rank: int, cpu_seconds: float,
                     library=None, t_library: float = 0.0, collectives: bool = False, strong_total: int = 0,
-                    data: str | None = None) -> dict:
+                    data: str | None = None, resident_rerun: bool = True, cpu_sample_max_atoms: int | None = None,
+                    use_pmc_traffic: bool = True) -> dict:
     """BASELINE.json configs[2] (and [3] when world > 1: every rank embeds and optimises its own n_mols molecules, no
     data-path collective): ETKDG (`confs` conformers per molecule) DEVICE-chained into MMFF94 on the synthetic drug-like
     set of nvmolkit_amd/synthetic.py.  Roofline = the fused BFGS kernels' inverse-Hessian traffic."""
@@ -414,16 +416,20 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     wall = time.perf_counter() - t0
     _native.check(lib.nvmk_bfgs_set_stats(None))
     # the same job again on the tables that are now resident (rounds 2-4 reported only this figure): same seed, same work
-    torch.cuda.synchronize()
-    r0 = time.perf_counter()
-    dev_r = embed_flat(molset, confs_per_molecule=confs, max_iterations=10, seed=1 + rank, output=CoordinateOutput.DEVICE)
-    torch.cuda.synchronize()
-    r_embed = time.perf_counter() - r0
-    opt_r = mmffOptimization.optimize_device(tables, dev_r, max_iters=mmff_iters)
-    torch.cuda.synchronize()
-    wall_resident = time.perf_counter() - r0
-    same_bits = bool(torch.equal(opt_r.values.torch(), opt.values.torch()))
-    del dev_r, opt_r
+    # (not for the whole benchmark file, whose single run takes most of a minute)
+    wall_resident = r_embed = float("nan")
+    same_bits = None
+    if resident_rerun:
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        dev_r = embed_flat(molset, confs_per_molecule=confs, max_iterations=10, seed=1 + rank, output=CoordinateOutput.DEVICE)
+        torch.cuda.synchronize()
+        r_embed = time.perf_counter() - r0
+        opt_r = mmffOptimization.optimize_device(tables, dev_r, max_iters=mmff_iters)
+        torch.cuda.synchronize()
+        wall_resident = time.perf_counter() - r0
+        same_bits = bool(torch.equal(opt_r.values.torch(), opt.values.torch()))
+        del dev_r, opt_r
     gc.enable()
     t_flatten = t_molset + t_tables_wait
     n_conf = dev.num_conformers
@@ -453,7 +459,7 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs on 2000 molecules of the same set, FETCH_SIZE doubled as the guide's
     # gfx950 note prescribes), scaled by the conformers of this run; only while the kernel sources are the ones measured
     traffic, traffic_src = None, None
-    for pmc in sorted((ROOT / "profiles").glob("r*/pmc_hbm_traffic_conformers.json"), reverse=True):
+    for pmc in sorted((ROOT / "profiles").glob("r*/pmc_hbm_traffic_conformers.json"), reverse=True) if use_pmc_traffic else ():
         c = json.loads(pmc.read_text())
         if c.get("kernel_source_sha256") == conformer_source_digest() and c.get("by_kind"):
             # per kind: (bytes read + bytes written past the L2s) / (bytes the passes requested from HBM) of the PMC run, whose
@@ -477,8 +483,8 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
            "table_assembly_host_seconds": t_molset,            # inside the clock (part of etkdg_seconds): FlatMoleculeSet's host side
            "mmff_tables_wait_seconds": t_tables_wait,          # inside the clock (part of mmff_seconds): MMFF assembly not hidden by ETKDG
            "flatten_and_table_upload_seconds": t_flatten,      # the two above: what of the flattening is on the critical path
-           "resident_tables_value": total_mols / wall_resident,  # the same job with both table sets already resident (rounds 2-4's figure)
-           "resident_tables_seconds": wall_resident, "resident_tables_etkdg_seconds": r_embed,
+           "resident_tables_value": (total_mols / wall_resident) if resident_rerun else None,  # the same job with both table sets already resident (rounds 2-4's figure)
+           "resident_tables_seconds": wall_resident if resident_rerun else None, "resident_tables_etkdg_seconds": r_embed if resident_rerun else None,
            "resident_tables_run_gave_the_same_bits": same_bits,
            "scaling": "strong" if strong_total > 0 else "weak", "per_rank_seconds": per_rank_wall,
            "imbalance_max_over_mean": max(per_rank_wall) / (sum(per_rank_wall) / len(per_rank_wall)),
@@ -501,7 +507,8 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
                         "traffic_over_requested": (traffic / requested) if traffic and requested else None,
                         "traffic_over_algorithmic": (traffic / algo) if traffic and algo else None,
                         "hbm_bytes_requested_by_the_hessian_pass": requested,
-                        "kernel": "nvmk::minim::bfgs_kernel<DG|ETK|MMFF> (> 99 % of the GPU time of this block)",
+                        "kernel": "nvmk::minim::bfgs_kernel<DG|ETK|MMFF> and, for systems of 1068 coordinates or more, bfgs_team_kernel<DG|ETK|MMFF> "
+                                  "(together > 99 % of the GPU time of this block)",
                         "note": "algorithmic bytes = sum over systems of BFGS iterations x 8 n (n + 2) (read + write of the "
                                 "packed inverse Hessian, counted by the kernels themselves: nvmk_bfgs_set_stats), divided by "
                                 "the block's wall time; rows of the inverse Hessian that stay in LDS never reach HBM, so "
@@ -513,7 +520,11 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
 
         threads = oracle.num_threads()
         m = int(min(n_mols, max(16, 2 * threads)))
-        sub = library[:m]
+        # (the ChEMBL blocks: the sample is taken from the molecules of at most cpu_sample_max_atoms atoms — one 500-atom molecule
+        # alone keeps a CPU thread busy for minutes)
+        pool = library if cpu_sample_max_atoms is None else [x for x in library if x["embed"]["n_atoms"] <= cpu_sample_max_atoms]
+        m = min(m, len(pool))
+        sub = pool[:m]
         mols = [FlatMolecule(**x["embed"]) for x in sub]
         c0 = time.perf_counter()
         coords, counts, slots, fails, iters = ffc.etkdg_embed(mols, confs_per_molecule=confs, max_iterations=10, seed=1)
@@ -545,7 +556,8 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
                                "one_thread_sample": f"first {one['molecules']} molecules x {confs} conformers" if one else None,
                                "etkdg_seconds": c_embed, "mmff_seconds": c_mmff, "conformers": int(counts.sum()),
                                "mmff_converged_fraction": float((st_c == 0).mean()),
-                               "sample": f"first {m} molecules of the same set x {confs} conformers, oracle/oracle_ff.c "
+                               "sample": f"first {m} molecules of the same set" + (f" with at most {cpu_sample_max_atoms} atoms" if cpu_sample_max_atoms else "") +
+                                         f" x {confs} conformers, oracle/oracle_ff.c "
                                          f"(same stage pipeline, scheduler, BFGS and term tables — like the GPU it evaluates ALL "
                                          f"N (N - 1) / 2 distance terms of a molecule and a dense inverse Hessian, it is a port of "
                                          f"this path, not RDKit's embedder; OpenMP over attempts / conformers on {threads} "
@@ -553,13 +565,10 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     return out
 
 
-def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int | None = 128) -> dict:
-    """BASELINE.json configs[2] on the reference's own molecules: the 10 000 SMILES of benchmarks/data/chembl_10k.smi through
-    the library's ingestion (benchmarks/etkdg_bench.py:154-161 reads them with RDKit), explicit hydrogens from the valence
-    model (benchmarks/bench_utils/molprep.py:21-55: AddHs), ETKDG + MMFF94 on the REAL topologies with generic parameters
-    (synthetic.graph_molecule).  Molecules beyond ``max_atoms`` atoms are left out and counted (``None``: the whole file, to 1063
-    atoms — two minutes on one MI355X, dominated by a few hundred peptides and macrocycles whose 5 - 72 MB inverse Hessians stream
-    through one workgroup each: --chembl-all, not part of the default line)."""
+def chembl_library():
+    """The reference's benchmark molecules (benchmarks/data/chembl_10k.smi, kept as tests/golden/chembl_10k.smi) through the library's
+    ingestion, explicit hydrogens from the valence model (benchmarks/bench_utils/molprep.py:21-55: AddHs), generic parameters
+    (synthetic.graph_molecule): generated ONCE for both ChEMBL blocks.  Returns (library, seconds, atom counts of the whole file)."""
     from nvmolkit_amd import synthetic
     from nvmolkit_amd.fingerprints import SmilesSet
 
@@ -567,18 +576,30 @@ def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int | None = 12
     t0 = time.perf_counter()
     s = SmilesSet.from_file(str(path))
     totals = np.array([int(s.graph(i)[0][:, 3].sum()) + int(s.n_atoms[i]) for i in range(len(s.status)) if s.status[i] == 0])
-    library, _ = synthetic.smiles_file_library(path, max_atoms=max_atoms)
-    t_library = time.perf_counter() - t0
-    out = conformer_block(len(library), confs, mmff_iters, device, 1, 0, 0.0, library, t_library,
+    library, _ = synthetic.smiles_file_library(path, max_atoms=None)
+    return library, time.perf_counter() - t0, totals
+
+
+def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int | None = 128, cpu_seconds: float = 0.0, prepared=None) -> dict:
+    """BASELINE.json configs[2] on the reference's own molecules: the 10 000 SMILES of benchmarks/data/chembl_10k.smi through
+    the library's ingestion (benchmarks/etkdg_bench.py:154-161 reads them with RDKit), ETKDG + MMFF94 on the REAL topologies with
+    generic parameters.  ``max_atoms`` = 128: the drug-sized 89 % of the file; ``None``: EVERY molecule, to 1063 atoms — what the
+    reference's benchmark feeds by default (benchmarks/etkdg_bench.py:193, --num_mols 0 = all) — whose peptides and macrocycles
+    (10.5 % of the molecules, > 95 % of the work) are minimised by teams of workgroups (csrc/minimize_team.hip)."""
+    library, t_library, totals = prepared if prepared is not None else chembl_library()
+    if max_atoms is not None:
+        library = [m for m in library if m["embed"]["n_atoms"] <= max_atoms]
+    out = conformer_block(len(library), confs, mmff_iters, device, 1, 0, cpu_seconds, library, t_library,
                           data=f"topologies of tests/golden/chembl_10k.smi (the reference's benchmarks/data/chembl_10k.smi) with explicit "
                                f"hydrogens, {'every molecule' if max_atoms is None else f'at most {max_atoms} atoms'}; synthetic (generic) parameters: bounds from covalent radii, hybridisation "
-                               f"and ring-size angles, cis / trans 1-4 windows, triangle smoothing; MMFF94-shaped terms with the same rest values")
+                               f"and ring-size angles, cis / trans 1-4 windows, triangle smoothing; MMFF94-shaped terms with the same rest values",
+                          resident_rerun=max_atoms is not None, cpu_sample_max_atoms=128, use_pmc_traffic=False)
     out["atoms_histogram_of_the_whole_file"] = {"molecules": int(len(totals)), "mean": float(totals.mean()),
                                                 "percentiles_1_10_50_90_99_max": [int(x) for x in np.percentile(totals, [1, 10, 50, 90, 99, 100])],
                                                 "fraction_beyond_the_cut": float((totals > max_atoms).mean()) if max_atoms is not None else 0.0}
     sizes = np.array([m["embed"]["n_atoms"] for m in library])
     out["atoms_percentiles_of_the_run_5_25_50_75_95_max"] = [int(x) for x in np.percentile(sizes, [5, 25, 50, 75, 95, 100])]
-    out.pop("roofline", None)  # the PMC traffic file is for the synthetic set; the block is reported as throughput
+    # the roofline of these blocks divides the bytes the inverse-Hessian passes requested from HBM (the PMC file is for the synthetic set)
     return out
 
 
@@ -607,7 +628,7 @@ def main() -> None:
                          "job, dealt over the ranks by cost (distributed.shard_molecules_by_cost); 0 = weak scaling, --conformer-mols per GPU")
     ap.add_argument("--chembl", type=int, default=1,
                     help="1: also run the conformer block on the ChEMBL topologies of tests/golden/chembl_10k.smi (single GPU), 0: skip")
-    ap.add_argument("--chembl-all", type=int, default=0,
+    ap.add_argument("--chembl-all", type=int, default=1,
                     help="1: also run the conformer block on EVERY molecule of that file (to 1063 atoms; about two minutes), reported as "
                          "secondary.conformers_chembl_all")
     ap.add_argument("--conformer-confs", type=int, default=10)
@@ -825,10 +846,16 @@ def main() -> None:
         if not distributed:
             guarded("conformers", conformer_block, args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank,
                     args.cpu_seconds)
-            if args.chembl:
-                guarded("conformers_chembl", chembl_block, args.conformer_confs, args.mmff_iters, device)
-            if args.chembl_all:
-                guarded("conformers_chembl_all", chembl_block, args.conformer_confs, args.mmff_iters, device, None)
+            prepared = None
+            if args.chembl or args.chembl_all:
+                try:
+                    prepared = chembl_library()
+                except Exception as exc:  # noqa: BLE001
+                    secondary["conformers_chembl"] = {"error": f"{type(exc).__name__}: {exc}"}
+            if args.chembl and prepared is not None:
+                guarded("conformers_chembl", chembl_block, args.conformer_confs, args.mmff_iters, device, 128, args.cpu_seconds, prepared)
+            if args.chembl_all and prepared is not None:
+                guarded("conformers_chembl_all", chembl_block, args.conformer_confs, args.mmff_iters, device, None, args.cpu_seconds, prepared)
         else:  # ranks meet in collectives inside the block: an exception on one rank must end the job, not hang the others
             block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds,
                                     library, t_library, collectives=True, strong_total=args.conformer_total)
@@ -841,6 +868,18 @@ def main() -> None:
         # those of the PMC files it quotes
         result["kernel_source_sha256"] = {"similarity": kernel_source_digest(), "conformers": conformer_source_digest(),
                                           "neighbour_count": kernel_source_digest(("similarity_mfma.hip", "count_panel.inc", "fp4.h", "tile_maps.h"))}
+        # LAST key, compact: both halves of BASELINE.json's metric where a reader of the line's tail finds them
+        def pick(block, *path):
+            node = secondary.get(block, {})
+            for key in path:
+                node = node.get(key) if isinstance(node, dict) else None
+            return round(node, 4) if isinstance(node, float) else node
+
+        result["summary"] = {"tanimoto_pairs_per_s": round(value, 1), "tanimoto_frac": round(result["roofline"]["frac"], 4),
+                             "conformers_mols_per_s": pick("conformers", "value"), "conformers_frac": pick("conformers", "roofline", "frac"),
+                             "chembl128_mols_per_s": pick("conformers_chembl", "value"), "chembl128_frac": pick("conformers_chembl", "roofline", "frac"),
+                             "chembl_all_mols_per_s": pick("conformers_chembl_all", "value"), "chembl_all_frac": pick("conformers_chembl_all", "roofline", "frac"),
+                             "butina_s": pick("fused_butina", "seconds"), "butina_frac": pick("fused_butina", "roofline", "frac")}
         print(json.dumps(result))
     if distributed:
         dist.barrier()

@@ -137,7 +137,14 @@ template <bool LDS_SUMS> __device__ __forceinline__ void add_to_sum(double* __re
 // col[k][0..1] (mirrored-entry sums of the lane's columns) are carried by the caller across ranges.
 // Groups of four rows that lie entirely inside the range take a copy of the group code without the per-row range tests; the
 // last, partial group takes the one with them.
-template <int NCH, bool PREFETCH, bool LDS_SUMS>
+// AHEAD > 0 (the team class, whose rows all come from HBM through one CU's eight waves): beyond the group requested into
+// registers, the groups AHEAD further on are TOUCHED — one 4-byte load per 64-byte sector, L1-bypassing, its result never used —
+// so that they are on their way from HBM to the L2 while the registers can hold no more: bytes in flight per wave without a
+// register per 16 of them.
+#ifndef NVMK_HESS_AHEAD
+#define NVMK_HESS_AHEAD 0
+#endif
+template <int NCH, bool PREFETCH, bool LDS_SUMS, int AHEAD = 0>
 __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBase, const int rFrom, const int rEnd, const int wave,
                                            const int lane, const HessChunk (&ck)[NCH], const bool pending,
                                            const double* __restrict__ xi, const double* __restrict__ hdg,
@@ -201,9 +208,28 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
   };
   int           r0   = rFrom + ((wave - rFrom) % NW + NW) % NW;  // first row of this wave at or after rFrom
   constexpr int STEP = NW * RU;
+  // the sectors of one group: RU rows x NCH KiB = RU * NCH * 16 sectors of 64 bytes, 64 per wave instruction
+  [[maybe_unused]] auto touch_group = [&](const int g0) {
+    if constexpr (AHEAD > 0) {
+      constexpr int kInstr = RU * NCH * 16 / 64;  // RU = 4: NCH instructions
+#pragma unroll
+      for (int j = 0; j < kInstr; ++j) {
+        const int s   = j * 64 + lane;            // sector of the group
+        const int u   = s / (NCH * 16), q = s % (NCH * 16);
+        const int r   = min(g0 + NW * u, rEnd - 1);
+        const double* p = H + (hess_row_offset32(r) - base) + ck[0].c0 - 2 * lane + 8 * q;
+        (void)__hip_atomic_load(reinterpret_cast<const unsigned int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
   if constexpr (PREFETCH) {
     double2 next[RU][NCH];
     if (r0 < rEnd) load_group(r0, next, std::false_type{});
+    if constexpr (AHEAD > 0) {
+#pragma unroll
+      for (int a = 1; a < AHEAD; ++a)
+        if (r0 + a * STEP < rEnd) touch_group(r0 + a * STEP);
+    }
     for (; r0 + NW * (RU - 1) < rEnd; r0 += STEP) {
       double2 hv[RU][NCH];
 #pragma unroll
@@ -212,6 +238,9 @@ __device__ __forceinline__ void hess_range(double* __restrict__ H, const int rBa
         for (int k = 0; k < NCH; ++k) hv[u][k] = next[u][k];
       }
       if (r0 + STEP < rEnd) load_group(r0 + STEP, next, std::false_type{});
+      if constexpr (AHEAD > 0) {
+        if (r0 + (1 + AHEAD) * STEP - STEP < rEnd) touch_group(r0 + AHEAD * STEP);
+      }
       work(r0, hv, std::true_type{});
     }
     if (r0 < rEnd) work(r0, next, std::false_type{});
@@ -487,10 +516,10 @@ __device__ __forceinline__ void hess_pass_rows(double* __restrict__ diag, double
         HessChunk(&ck1)[1]  = reinterpret_cast<HessChunk(&)[1]>(ck[0]);
         double(&col1)[1][2] = reinterpret_cast<double(&)[1][2]>(col[0]);
         const int lo = max(cBase, ra);
-        if (lo < mid) hess_range<1, PREFETCH, true>(Hg, 0, lo, mid, wave, lane, ck1, pending, sx - ra, sh - ra, su - ra, sg - ra, ss - ra, col1);
+        if (lo < mid) hess_range<1, PREFETCH, true, NVMK_HESS_AHEAD>(Hg, 0, lo, mid, wave, lane, ck1, pending, sx - ra, sh - ra, su - ra, sg - ra, ss - ra, col1);
       }
       const int lo2 = max(mid, ra);
-      if (lo2 < rb) hess_range<2, PREFETCH, true>(Hg, 0, lo2, rb, wave, lane, ck, pending, sx - ra, sh - ra, su - ra, sg - ra, ss - ra, col);
+      if (lo2 < rb) hess_range<2, PREFETCH, true, NVMK_HESS_AHEAD>(Hg, 0, lo2, rb, wave, lane, ck, pending, sx - ra, sh - ra, su - ra, sg - ra, ss - ra, col);
       // the waves' sums of this chunk's 256 columns, added in wave order by the column's thread
       double* sc = scratch + flip * (NW * 256);
       flip ^= 1;

@@ -343,7 +343,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   const long    teamOpt   = opt::get(opt::kBfgsTeam).num(-1);
   const int     kTeamMinN = teamOpt == 0 ? kNoLimit : teamOpt > 0 ? static_cast<int>(std::min<long>(teamOpt, kNoLimit)) : 1068;
   const long    teamWidthOpt = opt::get(opt::kBfgsTeamWidth).num(0);
-  const long    teamShareKb  = std::max<long>(1, opt::get(opt::kBfgsTeamShareKb).num(512));
+  const long    teamShareKb  = std::max<long>(1, opt::get(opt::kBfgsTeamShareKb).num(2048));
   const int     teamThreads  = opt::get(opt::kBfgsTeamThreads).num(512) == 256 ? 256 : 512;
   // a rank's LDS (trial positions + gradient slabs / the pass's staging area, bfgs_device.inc): all of a CU's for one workgroup of
   // 512 threads, half of it for each of two workgroups of 256; a system must leave room for one gradient slab behind its positions
@@ -500,7 +500,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // Team classes: persistent teams of `width` workgroups, one workgroup per CU (512 threads) or two (256).  The ranks of a team
   // are the blocks of one XCD (blockIdx % 8, as observed) while a team fits there; wider teams count their ranks across
   // consecutive blocks.  Memory: one slot for the largest system's packed triangle per TEAM, the HBM vectors per workgroup, the
-  // exchange area (`width` partial vectors, the reduced vector, two rows of scalars) and eight control words per team.
+  // exchange area (two blocks of `width` partial vectors, the reduced vector, two rows of scalars) and eight control words per team.
   for (int c = kTeam0; c < kNumClasses; ++c) {
     Plan& P = plan[c];
     if (cls[c].order.empty()) continue;
@@ -526,7 +526,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     P.vecStride         = (vec_doubles(P.threads, maxN) + 1) & ~int64_t{1};
     P.slotDoubles       = ((hess_row_offset(maxN) + kHessTailPadDoubles) + 1) & ~int64_t{1};
     P.teamVecStride     = (static_cast<int64_t>(maxN) + 2 + 1) & ~int64_t{1};
-    P.exchStride        = ((static_cast<int64_t>(width) + 1) * P.teamVecStride + 2 * width + 1) & ~int64_t{1};
+    P.exchStride        = ((2 * static_cast<int64_t>(width) + 1) * P.teamVecStride + 2 * width + 1) & ~int64_t{1};
     for (int q = 0; q <= 8; ++q) P.queueStart[q] = q == 0 ? 0 : nItems;
     P.oneQueue = true;
   }

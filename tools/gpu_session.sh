@@ -218,6 +218,13 @@ PY
       python tools/bfgs_timeline.py $O/chembl_all_timeline.txt > $O/chembl_all_timeline_summary.json && python -c "import json; d=json.load(open('$O/chembl_all_timeline_summary.json')); print(json.dumps({k: d[k] for k in ('systems','launch_groups','total_mean_occupancy','total_tail_ms_below_half','wall_ms_first_to_last')})); print(json.dumps(d['by_team_width'], indent=0)); print(json.dumps(d['by_class'], indent=0)); print(json.dumps(sorted(d['groups'], key=lambda g: -g['span_ms'])[:12], indent=0))"
       gzip -f $O/chembl_all_timeline.txt; rm -f $O/chembl_all_timeline.txt.gz
       ;;
+    chembl_all_share)
+      : > $O/chembl_all_share.txt
+      for K in ${SHARES:-1024 2048}; do
+        echo "== NVMK_BFGS_TEAM_SHARE_KB=$K ${EXTRA_ENV:-}" | tee -a $O/chembl_all_share.txt
+        env NVMK_BFGS_TEAM_SHARE_KB=$K ${EXTRA_ENV:-} timeout 900 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | cut -c1-420 | tee -a $O/chembl_all_share.txt
+      done
+      ;;
     chembl_all)
       timeout 1200 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --end-to-end --cache $CACHE 2> $O/chembl_all.err | tee $O/chembl_all.json | cut -c1-900
       tail -3 $O/chembl_all.err
@@ -296,6 +303,13 @@ PY
     team_tests)
       ( time timeout 1200 python -m pytest tests/test_bfgs_parity_gpu.py -m gpu -q -x -k "team" ) > $O/team_tests.log 2>&1
       tail -15 $O/team_tests.log
+      ;;
+    ubench_team_ahead)
+      for A in ${AHEADS:-0 2 3 4}; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DNVMK_HESS_AHEAD=$A ${UTP_FLAGS:-} tools/ubench_team_pass.hip -o /tmp/utp_a$A 2>/dev/null & done; wait
+      : > $O/ubench_team_ahead.jsonl
+      for N in ${UTP_N:-1200 2000 4252}; do for W in ${UTP_W:-8 32}; do for A in ${AHEADS:-0 2 3 4}; do
+        echo -n "ahead $A " | tee -a $O/ubench_team_ahead.jsonl; timeout 120 /tmp/utp_a$A $N $W 256 10 | tee -a $O/ubench_team_ahead.jsonl
+      done; done; done
       ;;
     ubench_team_pass)
       for T in 512 256; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DUBENCH_THREADS=$T tools/ubench_team_pass.hip -o /tmp/utp_$T 2>/dev/null & done; wait
