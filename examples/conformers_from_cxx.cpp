@@ -133,7 +133,9 @@ int main() {
 
   // 2. the embedding tables; 3. the force-field tables on a second host thread and stream while the embedding runs
   void* molsetHandle = nullptr;
-  NVMK_DO(nvmk_etkdg_molset_build(flat.data(), nMols, /*n_threads=*/0, /*flags=*/0, stream, &molsetHandle));
+  // (NVMK_BUILD_ASYNC: the call returns once the tables are planned; nvmk_etkdg_embed meets their rows batch by batch, so the
+  // tables of batch k + 1 are assembled while batch k is on the GPU — `flat` and the arrays behind it stay alive until then)
+  NVMK_DO(nvmk_etkdg_molset_build(flat.data(), nMols, /*n_threads=*/0, NVMK_BUILD_ASYNC, stream, &molsetHandle));
   nvmk_etkdg_molset molset;
   NVMK_DO(nvmk_etkdg_molset_view(molsetHandle, &molset));
   int device = 0;
@@ -188,7 +190,7 @@ int main() {
     std::fprintf(stderr, "nvmk_ff_tables_build: failed on the side thread\n");
     return 1;
   }
-  HIP_OK(hipStreamSynchronize(side));  // or an event the main stream waits for
+  NVMK_DO(nvmk_ff_tables_wait(tablesHandle, stream));  // built under `side`: the stream the minimisation runs on waits for the uploads
   std::vector<int32_t> atomStarts{0}, systemMol;
   std::vector<double>  pos;
   for (int m = 0; m < nMols; ++m) {

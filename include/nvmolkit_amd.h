@@ -395,6 +395,11 @@ typedef struct nvmk_etkdg_molset {
   const int32_t* num_impropers;    /* DEVICE [n_mols] (planarity tolerance 0.7 * num_impropers) */
   const int32_t* h_etk_d12_counts; /* HOST [n_mols]: terms of etk[2] / etk[3] per molecule */
   const int32_t* h_etk_d13_counts;
+  const void*    build_handle;     /* NULL, or the nvmk_etkdg_molset_build handle these tables belong to (nvmk_etkdg_molset_view sets
+                                      it): nvmk_etkdg_embed then meets the rows batch by batch — before a batch runs it waits
+                                      (nvmk_etkdg_molset_wait) until the rows of the batch's molecules have been uploaded, so a build
+                                      with NVMK_BUILD_ASYNC fills the tables of batch k + 1 while batch k is on the GPU (the
+                                      reference: per-batch host flattening on the batch's OpenMP thread, src/etkdg.cpp:175-191,211-240) */
 } nvmk_etkdg_molset;
 
 typedef struct nvmk_etkdg_params {
@@ -429,9 +434,17 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* mols, const nvmk_etkdg_params* par
  * of sharing atom i; DG g0, ETK g5, MMFF g5 / g6, UFF g4), and for MMFF merge van der Waals and electrostatic pairs into
  * group 11; they write into a ring of pinned staging slots owned by the library, from which the chunks go to ONE device
  * allocation with hipMemcpyAsync on `stream` while the threads fill the next slots (build of chunk k + 1 overlaps the upload
- * of chunk k).  Blocking on the host work; on return the last uploads are still in flight on `stream`: work enqueued on
- * `stream` afterwards sees complete tables, other streams wait for it first.  The handle owns the device memory;
- * nvmk_*_view fills the plain structs the entry points above take (valid until nvmk_*_free, which waits for the uploads).
+ * of chunk k).  The uploads run on a stream of the build's own, forked from `stream`.  Blocking on the host work unless
+ * NVMK_BUILD_ASYNC is set; on return the last uploads are still in flight and `stream` has been made to wait for them: work
+ * enqueued on `stream` afterwards sees complete tables, a consumer on ANOTHER stream calls nvmk_*_wait(handle, ..., its stream)
+ * first (host wait until the rows have been handed to the copy engine + the stream waits for those copies).  The handle owns the
+ * device memory; nvmk_*_view fills the plain structs the entry points above take (valid until nvmk_*_free, which waits for the
+ * uploads).
+ *   NVMK_BUILD_ASYNC           : return once the plan is made (sizes known, device block allocated, views valid): host threads of
+ *                                the build's own fill and upload the rows in molecule order while the caller goes on.  The
+ *                                caller's arrays must stay alive until nvmk_*_wait(handle, -1, ...) or nvmk_*_free has returned;
+ *                                EVERY consumer waits first — nvmk_etkdg_embed does so itself, batch by batch, through
+ *                                nvmk_etkdg_molset.build_handle.  Errors of the fill are reported by the wait.
  *   NVMK_BUILD_KEEP_PAIR_ORDER : pair groups keep the caller's row order (measurements)
  *   NVMK_BUILD_NO_MMFF_MERGE   : no group 11
  *   NVMK_BUILD_HOST            : the tables are written to HOST memory instead (no GPU involved; the views then hold host
@@ -460,10 +473,13 @@ typedef struct nvmk_flat_molecule {
 #define NVMK_BUILD_KEEP_PAIR_ORDER 1u
 #define NVMK_BUILD_NO_MMFF_MERGE 2u
 #define NVMK_BUILD_HOST 4u
+#define NVMK_BUILD_ASYNC 8u
 
 int nvmk_etkdg_molset_build(const nvmk_flat_molecule* h_mols, int32_t n_mols, int n_threads, unsigned flags, void* stream,
                             void** handle);
 int nvmk_etkdg_molset_view(const void* handle, nvmk_etkdg_molset* out);
+/* rows of molecules [0, first_n_mols) (negative: all) uploaded before what `stream` runs next; blocks the host while they are being filled */
+int nvmk_etkdg_molset_wait(const void* handle, int32_t first_n_mols, void* stream);
 int nvmk_etkdg_molset_free(void* handle);
 /* Per-MOLECULE term tables of one force field (kind NVMK_FF_DG / ETK / MMFF / UFF) for nvmk_ff_batch.system_mol batches:
  * h_terms[m * n_groups + g] are molecule m's rows of group g; n_groups = the kind's group count (3 / 6 / 7 / 5), for MMFF and
@@ -473,6 +489,7 @@ int nvmk_etkdg_molset_free(void* handle);
 int nvmk_ff_tables_build(int kind, const nvmk_host_terms* h_terms, int32_t n_mols, int n_groups, int n_threads, unsigned flags,
                          void* stream, void** handle);
 int nvmk_ff_tables_view(const void* handle, nvmk_ff_group groups[12], int32_t* n_mols);
+int nvmk_ff_tables_wait(const void* handle, void* stream); /* as nvmk_etkdg_molset_wait, every molecule */
 int nvmk_ff_tables_free(void* handle);
 
 /* Per-stage wall-clock table of the LAST nvmk_etkdg_embed call of the process that ran with the option NVMK_ETKDG_TIMING=1

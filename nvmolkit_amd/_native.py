@@ -83,6 +83,8 @@ SIGNATURES: dict[str, tuple] = {
     "nvmk_etkdg_embed": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "nvmk_etkdg_molset_build": (_int, [_vp, ctypes.c_int32, _int, ctypes.c_uint, _vp, ctypes.POINTER(ctypes.c_void_p)]),
     "nvmk_etkdg_molset_view": (_int, [_vp, _vp]),
+    "nvmk_etkdg_molset_wait": (_int, [_vp, ctypes.c_int32, _vp]),
+    "nvmk_ff_tables_wait": (_int, [_vp, _vp]),
     "nvmk_etkdg_molset_free": (_int, [_vp]),
     "nvmk_ff_tables_build": (_int, [_int, _vp, ctypes.c_int32, _int, _int, ctypes.c_uint, _vp, ctypes.POINTER(ctypes.c_void_p)]),
     "nvmk_ff_tables_view": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
@@ -138,7 +140,7 @@ class EtkdgMolset(ctypes.Structure):
     _fields_ = [("n_mols", ctypes.c_int32), ("h_n_atoms", ctypes.c_void_p), ("dg", FFGroup * 3), ("etk", FFGroup * 6),
                 ("check_starts", ctypes.c_void_p), ("check_kind", ctypes.c_void_p), ("check_idx", ctypes.c_void_p),
                 ("check_par", ctypes.c_void_p), ("num_impropers", ctypes.c_void_p),
-                ("h_etk_d12_counts", ctypes.c_void_p), ("h_etk_d13_counts", ctypes.c_void_p)]
+                ("h_etk_d12_counts", ctypes.c_void_p), ("h_etk_d13_counts", ctypes.c_void_p), ("build_handle", ctypes.c_void_p)]
 
 
 class EtkdgParams(ctypes.Structure):
@@ -164,7 +166,7 @@ class FlatMoleculeDesc(ctypes.Structure):
                 ("check_par", ctypes.c_void_p)]
 
 
-BUILD_KEEP_PAIR_ORDER, BUILD_NO_MMFF_MERGE, BUILD_HOST = 1, 2, 4
+BUILD_KEEP_PAIR_ORDER, BUILD_NO_MMFF_MERGE, BUILD_HOST, BUILD_ASYNC = 1, 2, 4, 8
 
 CHECK_TETRAHEDRAL, CHECK_CHIRAL_VOLUME, CHECK_CHIRAL_DISTANCE = 0, 1, 2
 CHECK_CHIRAL_CENTER_VOLUME, CHECK_DOUBLE_BOND_STEREO, CHECK_DOUBLE_BOND_GEOMETRY = 3, 4, 5

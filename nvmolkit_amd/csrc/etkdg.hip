@@ -529,6 +529,12 @@ int nvmk_etkdg_embed(const nvmk_etkdg_molset* ms, const nvmk_etkdg_params* prm, 
     // the long jobs must not be the last to get a slot (cost per BFGS iteration grows with atoms^2).
     std::stable_sort(ids.begin(), ids.end(), [&](const int a, const int b) { return ms->h_n_atoms[a] > ms->h_n_atoms[b]; });
     const int nSys = static_cast<int>(ids.size());
+    if (ms->build_handle != nullptr) {  // the tables of this batch's molecules (an asynchronous build fills the later ones meanwhile)
+      int last = 0;
+      for (const int m : ids) last = std::max(last, m);
+      const int rcw = nvmk_etkdg_molset_wait(ms->build_handle, last + 1, stream);
+      if (rcw != NVMK_OK) return rcw;
+    }
     std::vector<int32_t> atomStarts(static_cast<size_t>(nSys) + 1, 0), r12(static_cast<size_t>(nSys) + 1, 0),
       r13(static_cast<size_t>(nSys) + 1, 0);
     for (int s = 0; s < nSys; ++s) {

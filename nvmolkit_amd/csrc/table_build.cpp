@@ -15,7 +15,9 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <chrono>
 #include <new>
+#include <string>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -276,19 +278,43 @@ struct Build {
   char*                block      = nullptr;  // device (hipMalloc) or host (malloc) destination
   bool                 onHost     = false;
   int                  device     = -1;
-  hipStream_t          stream     = nullptr;
+  hipStream_t          stream     = nullptr;  // the caller's
+  hipStream_t          copyStream = nullptr;  // the uploads run on a stream of the build's own, forked from the caller's (ADVICE r05:
+                                              // slot recycling then waits for the chunk's copy, not for whatever else is queued)
   hipEvent_t           done       = nullptr;  // after the last upload
   std::atomic<int>     mergeImpossible{0};
   int                  mergedGroup = -1;
+  // The plan of the fill (run_plan) and, with NVMK_BUILD_ASYNC, the thread that carries it out while the caller goes on: the rows
+  // of the first molsReady molecules have been handed to the copy engine, chunkEvent[c] follows chunk c's copies.
+  std::vector<int>        chunkFirst;      // first molecule of every chunk, then nMols
+  std::vector<int>        chunkOf;         // per molecule
+  std::vector<hipEvent_t> chunkEvent;      // per chunk (device builds)
+  std::vector<std::vector<size_t>> chunkSlotOff;  // per chunk, per group: idx offset, par offset inside the slot
+  size_t                  slotBytes = 0;
+  RingLease               lease;
+  std::thread             builder;
+  std::atomic<int>        molsReady{0};
+  std::atomic<int>        finished{0};
+  int                     asyncRc = NVMK_OK;
+  std::string             asyncError;
 
   int n_atoms_of(const int m) const {
     return nAtoms == nullptr ? -1 : *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(nAtoms) + static_cast<size_t>(m) * nAtomsStride);
   }
   ~Build() {
+    if (builder.joinable()) builder.join();  // (reads the caller's arrays until it is through)
     if (done != nullptr) {
       (void)hipEventSynchronize(done);
       (void)hipEventDestroy(done);
+    } else if (copyStream != nullptr) {
+      (void)hipStreamSynchronize(copyStream);
     }
+    for (hipEvent_t ev : chunkEvent)
+      if (ev != nullptr) (void)hipEventDestroy(ev);
+    lease.stream = copyStream;
+    release_ring(lease.ring, copyStream, lease.ring != nullptr);  // (before the stream goes: the ring's last-use event is recorded on it)
+    lease.ring = nullptr;
+    if (copyStream != nullptr) (void)hipStreamDestroy(copyStream);
     if (block != nullptr) {
       if (onHost) {
         std::free(block);
@@ -307,7 +333,7 @@ int validate_terms(const nvmk_host_terms& t, const int nPar, const char* what, c
   return NVMK_OK;
 }
 
-int run(Build& b, const int nThreadsAsked, const char* what) {
+int run_plan(Build& b, const char* what) {
   const int nMols = b.nMols;
   // 1. starts of every group (and the total size of a molecule's rows, for the chunking)
   std::vector<size_t> molBytes(static_cast<size_t>(nMols), 0);
@@ -356,7 +382,9 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
   const size_t nGroups2  = b.groups.size() * 2;
   const long   slotKb    = opt::get(opt::kBuildSlotKb).num(0);
   const size_t slotBytes = std::max(slotKb > 0 ? static_cast<size_t>(slotKb) << 10 : kSlotBytes, largest + nGroups2 * kAlign);
-  std::vector<int> chunkFirst{0};  // first molecule of every chunk, then nMols
+  b.slotBytes            = slotBytes;
+  std::vector<int>& chunkFirst = b.chunkFirst;
+  chunkFirst.assign(1, 0);
   {
     size_t used = nGroups2 * kAlign;
     for (int m = 0; m < nMols; ++m) {
@@ -369,11 +397,26 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
     chunkFirst.push_back(nMols);
   }
   const int nChunks = static_cast<int>(chunkFirst.size()) - 1;
+  b.chunkOf.assign(static_cast<size_t>(nMols), 0);
+  b.chunkSlotOff.assign(static_cast<size_t>(nChunks), {});
+  for (int c = 0; c < nChunks; ++c) {
+    std::vector<size_t>& so = b.chunkSlotOff[static_cast<size_t>(c)];
+    so.resize(nGroups2);
+    size_t    o  = 0;
+    const int m0 = chunkFirst[static_cast<size_t>(c)], m1 = chunkFirst[static_cast<size_t>(c) + 1];
+    for (size_t gi = 0; gi < b.groups.size(); ++gi) {
+      const Group& g    = b.groups[gi];
+      const size_t rows = static_cast<size_t>(g.starts[static_cast<size_t>(m1)] - g.starts[static_cast<size_t>(m0)]);
+      so[2 * gi]        = o;
+      o                 = (o + rows * g.idx_row() + kAlign - 1) / kAlign * kAlign;
+      so[2 * gi + 1]    = o;
+      o                 = (o + rows * g.par_row() + kAlign - 1) / kAlign * kAlign;
+    }
+    NVMK_REQUIRE(b.onHost || o <= slotBytes, "%s: internal: chunk %d does not fit its staging slot", what, c);
+    for (int m = m0; m < m1; ++m) b.chunkOf[static_cast<size_t>(m)] = c;
+  }
 
-  // 4. destination
-  RingLease lease;
-  Ring*&    ring = lease.ring;
-  lease.stream   = b.stream;
+  // 4. destination; the uploads' own stream, forked from the caller's (what the caller queued before this call precedes them)
   if (b.onHost) {
     b.block = static_cast<char*>(std::malloc(b.blockBytes));
     NVMK_REQUIRE(b.block != nullptr, "%s: out of host memory (%zu bytes)", what, b.blockBytes);
@@ -383,50 +426,50 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
     void* p = nullptr;
     NVMK_HIP_CHECK(hipMalloc(&p, b.blockBytes));
     b.block = static_cast<char*>(p);
-    NVMK_HIP_CHECK(hipMemcpyAsync(b.block, b.header.data(), headerBytes, hipMemcpyHostToDevice, b.stream));  // b.header lives as long as the handle
-    const int rc = acquire_ring(slotBytes, &ring);
+    NVMK_HIP_CHECK(hipStreamCreateWithFlags(&b.copyStream, hipStreamNonBlocking));
+    {
+      hipEvent_t fork = nullptr;
+      NVMK_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+      hipError_t e = hipEventRecord(fork, b.stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(b.copyStream, fork, 0);
+      (void)hipEventDestroy(fork);
+      NVMK_HIP_CHECK(e);
+    }
+    NVMK_HIP_CHECK(hipMemcpyAsync(b.block, b.header.data(), headerBytes, hipMemcpyHostToDevice, b.copyStream));  // b.header lives as long as the handle
+    b.chunkEvent.assign(static_cast<size_t>(nChunks), nullptr);
+    for (int c = 0; c < nChunks; ++c) NVMK_HIP_CHECK(hipEventCreateWithFlags(&b.chunkEvent[static_cast<size_t>(c)], hipEventDisableTiming));
+    NVMK_HIP_CHECK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+    b.lease.stream = b.copyStream;
+    const int rc   = acquire_ring(slotBytes, &b.lease.ring);
     if (rc != NVMK_OK) return rc;
   }
+  return NVMK_OK;
+}
 
-  // 5. fill (worker threads) and upload (this thread), chunk by chunk.  Workers take molecules in order from one counter; a
-  // molecule of chunk c may be written once slot c % kSlots is free again (chunkOpen > c).
-  struct ChunkState {
-    std::atomic<int> remaining{0};
-    std::vector<size_t> slotOff;  // per group: idx offset, par offset inside the slot
-  };
-  std::vector<ChunkState> chunks(static_cast<size_t>(nChunks));
-  std::vector<int>        chunkOf(static_cast<size_t>(nMols), 0);
-  for (int c = 0; c < nChunks; ++c) {
-    ChunkState& cs = chunks[static_cast<size_t>(c)];
-    cs.remaining.store(chunkFirst[static_cast<size_t>(c) + 1] - chunkFirst[static_cast<size_t>(c)]);
-    cs.slotOff.resize(nGroups2);
-    size_t     o  = 0;
-    const int m0 = chunkFirst[static_cast<size_t>(c)], m1 = chunkFirst[static_cast<size_t>(c) + 1];
-    for (size_t gi = 0; gi < b.groups.size(); ++gi) {
-      const Group& g    = b.groups[gi];
-      const size_t rows = static_cast<size_t>(g.starts[static_cast<size_t>(m1)] - g.starts[static_cast<size_t>(m0)]);
-      cs.slotOff[2 * gi] = o;
-      o                  = (o + rows * g.idx_row() + kAlign - 1) / kAlign * kAlign;
-      cs.slotOff[2 * gi + 1] = o;
-      o                      = (o + rows * g.par_row() + kAlign - 1) / kAlign * kAlign;
-    }
-    NVMK_REQUIRE(b.onHost || o <= slotBytes, "%s: internal: chunk %d does not fit its staging slot", what, c);
-    for (int m = m0; m < m1; ++m) chunkOf[static_cast<size_t>(m)] = c;
-  }
+// 5. fill (worker threads) and upload (the calling thread), chunk by chunk.  Workers take molecules in order from one counter; a
+// molecule of chunk c may be written once slot c % kSlots is free again (chunkOpen > c).  After chunk c's copies have been handed
+// to the copy engine its event is recorded and molsReady moves past its molecules: nvmk_*_wait builds on both.
+int run_fill(Build& b, const int nThreadsAsked, const char* what) {
+  const int               nMols      = b.nMols;
+  const std::vector<int>& chunkFirst = b.chunkFirst;
+  const int               nChunks    = static_cast<int>(chunkFirst.size()) - 1;
+  Ring* const             ring       = b.lease.ring;
+  std::vector<std::atomic<int>> remaining(static_cast<size_t>(nChunks));
+  for (int c = 0; c < nChunks; ++c) remaining[static_cast<size_t>(c)].store(chunkFirst[static_cast<size_t>(c) + 1] - chunkFirst[static_cast<size_t>(c)]);
   std::atomic<int> nextMol{0}, chunkOpen{b.onHost ? nChunks : std::min(nChunks, kSlots)}, badMol{-1}, badGroup{-1}, abort{0}, threw{0};
   auto worker_body = [&]() {
     Scratch sc;
     for (;;) {
       const int m = nextMol.fetch_add(1);
       if (m >= nMols) return;
-      const int c = chunkOf[static_cast<size_t>(m)];
+      const int c = b.chunkOf[static_cast<size_t>(m)];
       while (chunkOpen.load(std::memory_order_acquire) <= c) {
         if (abort.load()) return;
         std::this_thread::yield();
       }
-      const ChunkState& cs    = chunks[static_cast<size_t>(c)];
-      const int         m0    = chunkFirst[static_cast<size_t>(c)];
-      const int         atoms = b.n_atoms_of(m);
+      const std::vector<size_t>& so    = b.chunkSlotOff[static_cast<size_t>(c)];
+      const int                  m0    = chunkFirst[static_cast<size_t>(c)];
+      const int                  atoms = b.n_atoms_of(m);
       for (size_t gi = 0; gi < b.groups.size(); ++gi) {
         const Group& g = b.groups[gi];
         int32_t*     dIdx;
@@ -437,15 +480,15 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
         } else {
           char*        slot = ring->base + static_cast<size_t>(c % kSlots) * ring->slotBytes;
           const size_t r0   = static_cast<size_t>(g.starts[static_cast<size_t>(m)] - g.starts[static_cast<size_t>(m0)]);
-          dIdx = reinterpret_cast<int32_t*>(slot + cs.slotOff[2 * gi] + r0 * g.idx_row());
-          dPar = reinterpret_cast<double*>(slot + cs.slotOff[2 * gi + 1] + r0 * g.par_row());
+          dIdx = reinterpret_cast<int32_t*>(slot + so[2 * gi] + r0 * g.idx_row());
+          dPar = reinterpret_cast<double*>(slot + so[2 * gi + 1] + r0 * g.par_row());
         }
         if (!fill_rows(g, m, atoms, b.flags, dIdx, dPar, sc, b.mergeImpossible)) {
           int expected = -1;
           if (badMol.compare_exchange_strong(expected, m)) badGroup.store(static_cast<int>(gi));
         }
       }
-      chunks[static_cast<size_t>(c)].remaining.fetch_sub(1, std::memory_order_release);
+      remaining[static_cast<size_t>(c)].fetch_sub(1, std::memory_order_release);
     }
   };
   // (a worker that runs out of memory in its sort scratch must not take the process down: the build fails instead)
@@ -469,13 +512,12 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
     }
   }
   NVMK_REQUIRE(!pool.empty(), "%s: could not start a worker thread", what);
-  int        rc        = NVMK_OK;
-  hipEvent_t slotEvent[kSlots] = {};
+  int rc = NVMK_OK;
   if (!b.onHost) {
     for (int c = 0; c < nChunks && rc == NVMK_OK; ++c) {
-      ChunkState& cs = chunks[static_cast<size_t>(c)];
-      while (cs.remaining.load(std::memory_order_acquire) > 0 && !abort.load()) std::this_thread::yield();
+      while (remaining[static_cast<size_t>(c)].load(std::memory_order_acquire) > 0 && !abort.load()) std::this_thread::yield();
       if (abort.load()) break;
+      const std::vector<size_t>& so = b.chunkSlotOff[static_cast<size_t>(c)];
       char*     slot = ring->base + static_cast<size_t>(c % kSlots) * ring->slotBytes;
       const int m0 = chunkFirst[static_cast<size_t>(c)], m1 = chunkFirst[static_cast<size_t>(c) + 1];
       for (size_t gi = 0; gi < b.groups.size() && rc == NVMK_OK; ++gi) {
@@ -483,19 +525,19 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
         const size_t r0   = static_cast<size_t>(g.starts[static_cast<size_t>(m0)]);
         const size_t rows = static_cast<size_t>(g.starts[static_cast<size_t>(m1)]) - r0;
         if (rows == 0) continue;
-        hipError_t e = hipMemcpyAsync(b.block + g.idxOff + r0 * g.idx_row(), slot + cs.slotOff[2 * gi], rows * g.idx_row(), hipMemcpyHostToDevice, b.stream);
+        hipError_t e = hipMemcpyAsync(b.block + g.idxOff + r0 * g.idx_row(), slot + so[2 * gi], rows * g.idx_row(), hipMemcpyHostToDevice, b.copyStream);
         if (e == hipSuccess && g.nPar > 0)
-          e = hipMemcpyAsync(b.block + g.parOff + r0 * g.par_row(), slot + cs.slotOff[2 * gi + 1], rows * g.par_row(), hipMemcpyHostToDevice, b.stream);
+          e = hipMemcpyAsync(b.block + g.parOff + r0 * g.par_row(), slot + so[2 * gi + 1], rows * g.par_row(), hipMemcpyHostToDevice, b.copyStream);
         if (e != hipSuccess) {
           set_last_error("%s: upload of chunk %d failed: %s", what, c, hipGetErrorString(e));
           rc = NVMK_ERR_HIP;
         }
       }
-      if (rc == NVMK_OK && c + kSlots < nChunks) {  // the slot is needed again: open chunk c + kSlots once this upload is through
-        hipEvent_t& ev = slotEvent[c % kSlots];
-        hipError_t  e  = ev != nullptr ? hipSuccess : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(ev, b.stream);
-        if (e == hipSuccess) e = hipEventSynchronize(ev);
+      if (rc == NVMK_OK) {
+        hipError_t e = hipEventRecord(b.chunkEvent[static_cast<size_t>(c)], b.copyStream);
+        if (e == hipSuccess) b.molsReady.store(m1, std::memory_order_release);
+        // the slot is needed again: open chunk c + kSlots once this upload is through (its own copies, nothing else is on this stream)
+        if (e == hipSuccess && c + kSlots < nChunks) e = hipEventSynchronize(b.chunkEvent[static_cast<size_t>(c)]);
         if (e != hipSuccess) {
           set_last_error("%s: waiting for the upload of chunk %d failed: %s", what, c, hipGetErrorString(e));
           rc = NVMK_ERR_HIP;
@@ -510,21 +552,67 @@ int run(Build& b, const int nThreadsAsked, const char* what) {
     set_last_error("%s: a worker thread ran out of memory", what);
     rc = NVMK_ERR_OUT_OF_MEMORY;
   }
-  for (hipEvent_t ev : slotEvent)
-    if (ev != nullptr) (void)hipEventDestroy(ev);
-  if (!b.onHost) {
-    if (rc == NVMK_OK) {
-      hipError_t e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventRecord(b.done, b.stream);
-      if (e != hipSuccess) {
-        set_last_error("%s: recording the completion event failed: %s", what, hipGetErrorString(e));
-        rc = NVMK_ERR_HIP;
-      }
+  if (!b.onHost && rc == NVMK_OK) {
+    const hipError_t e = hipEventRecord(b.done, b.copyStream);
+    if (e != hipSuccess) {
+      set_last_error("%s: recording the completion event failed: %s", what, hipGetErrorString(e));
+      rc = NVMK_ERR_HIP;
     }
+  }
+  if (!b.onHost) {  // the staging ring goes back to the pool (its last uploads may still be in flight: the next owner waits for them)
+    release_ring(b.lease.ring, b.copyStream, true);
+    b.lease.ring = nullptr;
   }
   if (rc != NVMK_OK) return rc;
   NVMK_REQUIRE(badMol.load() < 0, "%s: molecule %d, term group %d: atom index outside the molecule (or more than 2^24 pair rows)", what,
                badMol.load(), badGroup.load());
+  b.molsReady.store(nMols, std::memory_order_release);
+  return NVMK_OK;
+}
+
+// Plan, then fill: at once (the caller's stream then waits for the last upload: what it queues afterwards sees complete tables), or
+// — NVMK_BUILD_ASYNC — on a thread of the build's own while the caller goes on; nvmk_*_wait is then how a consumer meets the rows.
+int run(Build& b, const int nThreadsAsked, const char* what) {
+  if (const int rc = run_plan(b, what)) return rc;
+  if ((b.flags & NVMK_BUILD_ASYNC) != 0 && !b.onHost) {
+    Build* self = &b;
+    b.builder   = std::thread([self, nThreadsAsked, what]() {
+      int rc = NVMK_ERR_INTERNAL;
+      try {
+        rc = hipSetDevice(self->device) == hipSuccess ? run_fill(*self, nThreadsAsked, what) : NVMK_ERR_HIP;
+      } catch (...) {
+        set_last_error("%s: the builder thread failed", what);
+      }
+      if (rc != NVMK_OK) self->asyncError = nvmk_last_error();  // (this thread's message)
+      self->asyncRc = rc;
+      self->finished.store(1, std::memory_order_release);
+    });
+    return NVMK_OK;
+  }
+  const int rc = run_fill(b, nThreadsAsked, what);
+  b.asyncRc    = rc;
+  b.finished.store(1, std::memory_order_release);
+  if (rc == NVMK_OK && !b.onHost) NVMK_HIP_CHECK(hipStreamWaitEvent(b.stream, b.done, 0));
+  return rc;
+}
+
+// A consumer on `stream` needs the rows of molecules [0, firstN) (negative: all): wait on the host until their copies have been
+// handed to the copy engine, then let `stream` wait for those copies.
+int build_wait(Build& b, int firstN, hipStream_t stream, const char* what) {
+  firstN = firstN < 0 ? b.nMols : std::min(firstN, b.nMols);
+  while (b.molsReady.load(std::memory_order_acquire) < firstN && b.finished.load(std::memory_order_acquire) == 0) {
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  if (b.finished.load(std::memory_order_acquire) != 0 && b.asyncRc != NVMK_OK) {
+    set_last_error("%s: the table build failed: %s", what, b.asyncError.empty() ? "(no message)" : b.asyncError.c_str());
+    return b.asyncRc;
+  }
+  if (b.onHost || firstN <= 0) return NVMK_OK;
+  if (b.molsReady.load(std::memory_order_acquire) >= b.nMols && b.finished.load(std::memory_order_acquire) != 0) {
+    NVMK_HIP_CHECK(hipStreamWaitEvent(stream, b.done, 0));
+  } else {
+    NVMK_HIP_CHECK(hipStreamWaitEvent(stream, b.chunkEvent[static_cast<size_t>(b.chunkOf[static_cast<size_t>(firstN) - 1])], 0));
+  }
   return NVMK_OK;
 }
 
@@ -677,7 +765,14 @@ int nvmk_etkdg_molset_view(const void* handle, nvmk_etkdg_molset* out) {
     out->check_kind   = k.idx;
   }
   out->num_impropers = reinterpret_cast<const int32_t*>(b.block + b.extraOff[0]);
+  out->build_handle  = b.onHost ? nullptr : handle;  // nvmk_etkdg_embed meets the rows batch by batch (nvmk_etkdg_molset_wait)
   return NVMK_OK;
+}
+
+int nvmk_etkdg_molset_wait(const void* handle, int32_t first_n_mols, void* stream) {
+  MolsetHandle* h = static_cast<MolsetHandle*>(const_cast<void*>(handle));
+  NVMK_REQUIRE(h != nullptr && h->magic == 0x4d4f4c53, "nvmk_etkdg_molset_wait: not a molecule-set handle");
+  return build_wait(h->build, first_n_mols, nvmk::as_stream(stream), "nvmk_etkdg_molset_wait");
 }
 
 int nvmk_etkdg_molset_free(void* handle) {
@@ -758,6 +853,12 @@ int nvmk_ff_tables_view(const void* handle, nvmk_ff_group groups[12], int32_t* n
   if (b.mergedGroup >= 0 && b.mergeImpossible.load() == 0) view_group(b, b.groups[static_cast<size_t>(b.mergedGroup)], &groups[11]);
   if (n_mols != nullptr) *n_mols = b.nMols;
   return NVMK_OK;
+}
+
+int nvmk_ff_tables_wait(const void* handle, void* stream) {
+  TablesHandle* h = static_cast<TablesHandle*>(const_cast<void*>(handle));
+  NVMK_REQUIRE(h != nullptr && h->magic == 0x5441424c, "nvmk_ff_tables_wait: not a term-table handle");
+  return build_wait(h->build, -1, nvmk::as_stream(stream), "nvmk_ff_tables_wait");
 }
 
 int nvmk_ff_tables_free(void* handle) {

@@ -73,9 +73,15 @@ class FlatMoleculeSet:
     ``device``) — the counterpart of the reference's host flattening on ``preprocessingThreads`` threads
     (src/etkdg.cpp:175-191), and like it part of what an ``EmbedMolecules`` call costs.  The Python side only hands over
     pointers into the molecules' own arrays (``_native.pyglue``).  ``device="cpu"`` assembles the same tables in host memory
-    (no GPU involved; the CPU test-suite reads them back through ``self.c``)."""
+    (no GPU involved; the CPU test-suite reads them back through ``self.c``).
 
-    def __init__(self, mols: Sequence[FlatMolecule], device="cuda", preprocessing_threads: int = -1):
+    ``asynchronous`` (default on a GPU): the constructor returns once the tables are PLANNED — sizes known, device block
+    allocated — and the library's threads fill and upload the rows in molecule order while the caller goes on;
+    ``nvmk_etkdg_embed`` waits before every batch for the rows of that batch's molecules, so the tables of batch k + 1 are
+    assembled while batch k is on the GPU (the reference's structure: src/etkdg.cpp:175-191,211-240).  :meth:`wait` blocks until
+    every row is uploaded (and raises what the fill may have failed with); anything that reads the tables directly calls it first."""
+
+    def __init__(self, mols: Sequence[FlatMolecule], device="cuda", preprocessing_threads: int = -1, asynchronous: bool = True):
         t0 = time.perf_counter()
         self.device = torch.device(device)
         self.mols = list(mols)
@@ -91,6 +97,10 @@ class FlatMoleculeSet:
         flags = _native.build_flags()
         t1 = time.perf_counter()
         if self.device.type == "cuda":
+            if asynchronous:
+                flags |= _native.BUILD_ASYNC
+            # (the library's threads read the molecules' arrays and these descriptors until the fill is through)
+            self._alive = (descs, kinds, idx, par, keep)
             with torch.cuda.device(self.device):
                 rc = _native.lib().nvmk_etkdg_molset_build(ctypes.addressof(descs), n, _native.build_threads(preprocessing_threads), flags,
                                                            _native.stream_ptr(None), ctypes.byref(handle))
@@ -105,6 +115,13 @@ class FlatMoleculeSet:
         self.has_etk = bool(self.c.h_etk_d12_counts)
         #: host seconds of the two steps: descriptors from the Python objects (GIL held), the library's assembly + upload calls
         self.timings = {"gather_seconds": t1 - t0, "build_seconds": time.perf_counter() - t1}
+
+    def wait(self, stream=None) -> "FlatMoleculeSet":
+        """Every row uploaded before what ``stream`` (default: the current one) runs next; raises if the fill failed."""
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                _native.check(_native.lib().nvmk_etkdg_molset_wait(self._handle, -1, _native.stream_ptr(stream)), "nvmk_etkdg_molset_wait")
+        return self
 
 
 # Conformer attempts per launch when the caller does not choose (-1, as HardwareOptions.batchSize).  One wave (small systems) or

@@ -97,6 +97,7 @@ class FlatForcefieldBatch:
         else:
             tables = MoleculeTermTables.from_stacked(kind, groups, self.device, n_rows)
         self._keep.append(tables)
+        self._tables = tables
         for g in range(12):
             self._c.groups[g] = tables.view[g]
 
@@ -115,6 +116,12 @@ class FlatForcefieldBatch:
             raise ValueError("positions must be contiguous")
         return pos
 
+    def _meet_tables(self, stream) -> None:
+        """The term tables' uploads precede the kernels of this call, whatever stream it runs on (one hipStreamWaitEvent)."""
+        tables = getattr(self, "_tables", None)
+        if tables is not None:
+            tables.wait(stream)
+
     @staticmethod
     def _mask(active):
         return None if active is None else active.to(torch.uint8).contiguous()
@@ -124,6 +131,7 @@ class FlatForcefieldBatch:
         self._check_pos(pos)
         out = torch.zeros(max(self.n_systems, 0), dtype=torch.float64, device=self.device)
         m = self._mask(active)
+        self._meet_tables(stream)
         with torch.cuda.device(self.device):  # kernels, scratch and the default stream belong to THIS batch's GPU
             rc = _native.lib().nvmk_ff_energy(ctypes.byref(self._c), float(w0), float(w1), pos.data_ptr(),
                                               m.data_ptr() if m is not None else None, out.data_ptr(),
@@ -136,6 +144,7 @@ class FlatForcefieldBatch:
         self._check_pos(pos)
         grad = torch.zeros_like(pos)
         m = self._mask(active)
+        self._meet_tables(stream)
         with torch.cuda.device(self.device):
             rc = _native.lib().nvmk_ff_gradient(ctypes.byref(self._c), float(w0), float(w1), pos.data_ptr(),
                                                 m.data_ptr() if m is not None else None, grad.data_ptr(),
@@ -157,6 +166,7 @@ class FlatForcefieldBatch:
         statuses = torch.full((n,), -1, dtype=torch.int16, device=self.device)
         iters = torch.zeros(n, dtype=torch.int32, device=self.device)
         m = self._mask(active)
+        self._meet_tables(stream)
         with torch.cuda.device(self.device):
             rc = _native.lib().nvmk_bfgs_minimize_repeat(ctypes.byref(self._c), self.atom_starts_host.ctypes.data, float(w0),
                                                          float(w1), int(max_iters), int(restarts), float(grad_tol),
@@ -250,6 +260,15 @@ class MoleculeTermTables:
         self.view = (_native.FFGroup * 12)()
         _native.check(_native.lib().nvmk_ff_tables_view(handle, ctypes.addressof(self.view), None), "nvmk_ff_tables_view")
 
+    def wait(self, stream=None) -> "MoleculeTermTables":
+        """The tables' uploads (on a stream of the build's own) precede what ``stream`` — default: the current stream of the
+        tables' device — runs next.  The stream the tables were built under waits already; a consumer on ANOTHER stream calls
+        this first (the uploads are asynchronous, so build-on-A / run-on-B would read half-uploaded tables)."""
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                _native.check(_native.lib().nvmk_ff_tables_wait(self._handle, _native.stream_ptr(stream)), "nvmk_ff_tables_wait")
+        return self
+
 
 class PendingTermTables:
     """:class:`MoleculeTermTables` under construction on a host thread and a side stream of its own while the caller keeps the
@@ -283,7 +302,7 @@ class PendingTermTables:
         self._thread.join()
         if self._error is not None:
             raise self._error
-        torch.cuda.current_stream(self.device).wait_stream(self._stream)
+        self._tables.wait()  # (the caller's current stream; consumers on other streams wait again for themselves)
         return self._tables
 
 

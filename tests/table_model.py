@@ -155,6 +155,11 @@ def read_molset(molset):
     """FlatMoleculeSet -> dict like :func:`expected_molset`."""
     c, n = molset.c, molset.c.n_mols
     on_device = molset.device.type == "cuda"
+    if on_device:  # (an asynchronous build: every row uploaded before the block is read back)
+        import torch
+
+        molset.wait()
+        torch.cuda.synchronize()
     out = {"n_atoms": np.frombuffer(ctypes.string_at(c.h_n_atoms, 4 * n), dtype=np.int32) if n else np.zeros(0, np.int32),
            "num_impropers": np.frombuffer(_read(c.num_impropers, 4 * n, on_device), dtype=np.int32)}
     out["dg"] = [read_group(c.dg[g], n, *GROUP_LAYOUT[DG][g], on_device) for g in range(3)]
