@@ -116,7 +116,15 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> Path
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
     if not variant:
-        build_pyglue(force=force, verbose=verbose)
+        # The glue needs a C compiler and this interpreter's headers; the similarity, Butina and fingerprint paths do not use it.
+        # A host without them still gets the library: _native.pyglue() raises when the conformer path first asks for the glue.
+        try:
+            build_pyglue(force=force, verbose=verbose)
+        except (RuntimeError, subprocess.CalledProcessError, OSError) as exc:
+            import warnings
+
+            warnings.warn(f"nvmolkit_amd: the CPython glue (pyglue/gather.c) was not built: {exc}; FlatMoleculeSet / MoleculeTermTables "
+                          "from Python molecule lists will raise until it is", RuntimeWarning)
     return LIB_PATH
 
 

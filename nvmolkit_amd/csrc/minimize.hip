@@ -341,7 +341,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // 256, ranks then count across the XCDs).  The width of a system's team depends on its size only, and so do its results.
   constexpr int kTeam0 = 14, kTeamClasses = 8, kNumClasses = kTeam0 + kTeamClasses;
   const long    teamOpt   = opt::get(opt::kBfgsTeam).num(-1);
-  const int     kTeamMinN = teamOpt == 0 ? kNoLimit : teamOpt > 0 ? static_cast<int>(std::min<long>(teamOpt, kNoLimit)) : 1068;
+  const int     kTeamMinN = teamOpt == 0 ? kNoLimit : teamOpt > 0 ? static_cast<int>(std::min<long>(teamOpt, kNoLimit)) : 800;
   const long    teamWidthOpt = opt::get(opt::kBfgsTeamWidth).num(0);
   const long    teamShareKb  = std::max<long>(1, opt::get(opt::kBfgsTeamShareKb).num(2048));
   const int     teamThreads  = opt::get(opt::kBfgsTeamThreads).num(512) == 256 ? 256 : 512;

@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "common.h"
+#include "options.h"
 
 namespace {
 
@@ -127,6 +128,32 @@ extern "C" int nvmk_cross_similarity_host_f64(int metric, const uint32_t* d_a, i
     chunkRows = std::max(minRows, (maxDoubles / increment) * minRows);
     nWorkers  = 2;
   }
+  // Several chunks on the matrix-core path: both operands are expanded to FP4 ONCE (nvmk_fp4_prepare) and every chunk is a launch
+  // on the prepared sets — nvmk_cross_tanimoto_f64 would expand the whole of B again for every chunk of rows.  The
+  // prepared launch wants row offsets that are multiples of 128, so the chunk is rounded down to one (still within the
+  // reference's memory bound); chunks too small for that path keep the per-chunk entry point.
+  struct Prepared {
+    void* a = nullptr;
+    void* b = nullptr;
+    ~Prepared() {
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
+    }
+  } prepared;
+  bool usePrepared = false;
+  if (nWorkers == 2 && chunkRows >= 128 && W >= 4 && nB >= 64 && !nvmk::opt::get(nvmk::opt::kSimPath).is("valu") &&
+      static_cast<double>(chunkRows / 128 * 128) * static_cast<double>(nB) >= 4.0e6) {
+    chunkRows = chunkRows / 128 * 128;
+    if (static_cast<size_t>(nA) > chunkRows) {
+      NVMK_HIP_CHECK(hipMalloc(&prepared.a, nvmk_fp4_workspace_bytes(nA, fp_bits)));
+      NVMK_HIP_CHECK(hipMalloc(&prepared.b, nvmk_fp4_workspace_bytes(nB, fp_bits)));
+      int rc = nvmk_fp4_prepare(d_a, nA, fp_bits, prepared.a, nullptr);
+      if (rc == NVMK_OK) rc = nvmk_fp4_prepare(d_b, nB, fp_bits, prepared.b, nullptr);
+      if (rc != NVMK_OK) return rc;
+      NVMK_HIP_CHECK(hipStreamSynchronize(nullptr));  // the workers' streams do not wait for the null stream
+      usePrepared = true;
+    }
+  }
   const size_t nChunks = (static_cast<size_t>(nA) + chunkRows - 1) / chunkRows;
   nWorkers             = static_cast<int>(std::min<size_t>(nWorkers, nChunks));
 
@@ -145,7 +172,9 @@ extern "C" int nvmk_cross_similarity_host_f64(int metric, const uint32_t* d_a, i
       if (c >= nChunks) break;
       const size_t row0 = c * chunkRows;
       const size_t rows = std::min(chunkRows, static_cast<size_t>(nA) - row0);
-      w.rc = launch_metric(metric, d_a + row0 * W, static_cast<int64_t>(rows), d_b, nB, fp_bits, w.dBuf, w.stream);
+      w.rc = usePrepared ? nvmk_cross_similarity_prepared_f64(metric, prepared.a, nA, static_cast<int64_t>(row0), static_cast<int64_t>(rows),
+                                                              prepared.b, nB, fp_bits, w.dBuf, nB, w.stream)
+                         : launch_metric(metric, d_a + row0 * W, static_cast<int64_t>(rows), d_b, nB, fp_bits, w.dBuf, w.stream);
       if (w.rc != NVMK_OK) break;
       w.rc = drain_to_host(w, w.dBuf, h_out + row0 * static_cast<size_t>(nB), rows * static_cast<size_t>(nB));
     }

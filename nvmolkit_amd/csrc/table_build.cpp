@@ -128,6 +128,42 @@ void release_ring(Ring* r, hipStream_t stream, const bool recordUse) {
   r->busy = false;
 }
 
+// ---- copy streams: one per build in flight, leased from a pool that lives for the process ------------------------------------
+// (never destroyed: the staging rings keep an event recorded on the stream of their last user, and an event must not outlive the
+// stream it was recorded on — a copy stream that died with its build left the next owner of the ring synchronising on such an
+// event: hipErrorCapturedEvent out of nowhere, some hundred builds later)
+struct CopyStream {
+  hipStream_t stream = nullptr;
+  int         device = -1;
+  bool        busy   = false;
+};
+std::vector<CopyStream> g_copyStreams;  // guarded by g_ringMutex
+
+int lease_copy_stream(const int device, hipStream_t* out) {
+  {
+    const std::lock_guard<std::mutex> lock(g_ringMutex);
+    for (CopyStream& c : g_copyStreams) {
+      if (!c.busy && c.device == device) {
+        c.busy = true;
+        *out   = c.stream;
+        return NVMK_OK;
+      }
+    }
+  }
+  hipStream_t s = nullptr;
+  NVMK_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  const std::lock_guard<std::mutex> lock(g_ringMutex);
+  g_copyStreams.push_back({s, device, true});
+  *out = s;
+  return NVMK_OK;
+}
+void return_copy_stream(hipStream_t s) {
+  if (s == nullptr) return;
+  const std::lock_guard<std::mutex> lock(g_ringMutex);
+  for (CopyStream& c : g_copyStreams)
+    if (c.stream == s) c.busy = false;
+}
+
 // the ring of one build: given back on every way out of run()
 struct RingLease {
   Ring*       ring      = nullptr;
@@ -282,6 +318,7 @@ struct Build {
   hipStream_t          copyStream = nullptr;  // the uploads run on a stream of the build's own, forked from the caller's (ADVICE r05:
                                               // slot recycling then waits for the chunk's copy, not for whatever else is queued)
   hipEvent_t           done       = nullptr;  // after the last upload
+  hipEvent_t           fork       = nullptr;  // on the caller's stream when the build began: the copy stream waits for it
   std::atomic<int>     mergeImpossible{0};
   int                  mergedGroup = -1;
   // The plan of the fill (run_plan) and, with NVMK_BUILD_ASYNC, the thread that carries it out while the caller goes on: the rows
@@ -311,10 +348,11 @@ struct Build {
     }
     for (hipEvent_t ev : chunkEvent)
       if (ev != nullptr) (void)hipEventDestroy(ev);
+    if (fork != nullptr) (void)hipEventDestroy(fork);
     lease.stream = copyStream;
     release_ring(lease.ring, copyStream, lease.ring != nullptr);  // (before the stream goes: the ring's last-use event is recorded on it)
     lease.ring = nullptr;
-    if (copyStream != nullptr) (void)hipStreamDestroy(copyStream);
+    return_copy_stream(copyStream);  // (drained above: `done` follows its last copy, or the stream was synchronised)
     if (block != nullptr) {
       if (onHost) {
         std::free(block);
@@ -426,15 +464,10 @@ int run_plan(Build& b, const char* what) {
     void* p = nullptr;
     NVMK_HIP_CHECK(hipMalloc(&p, b.blockBytes));
     b.block = static_cast<char*>(p);
-    NVMK_HIP_CHECK(hipStreamCreateWithFlags(&b.copyStream, hipStreamNonBlocking));
-    {
-      hipEvent_t fork = nullptr;
-      NVMK_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-      hipError_t e = hipEventRecord(fork, b.stream);
-      if (e == hipSuccess) e = hipStreamWaitEvent(b.copyStream, fork, 0);
-      (void)hipEventDestroy(fork);
-      NVMK_HIP_CHECK(e);
-    }
+    if (const int rcs = lease_copy_stream(b.device, &b.copyStream)) return rcs;
+    NVMK_HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
+    NVMK_HIP_CHECK(hipEventRecord(b.fork, b.stream));
+    NVMK_HIP_CHECK(hipStreamWaitEvent(b.copyStream, b.fork, 0));
     NVMK_HIP_CHECK(hipMemcpyAsync(b.block, b.header.data(), headerBytes, hipMemcpyHostToDevice, b.copyStream));  // b.header lives as long as the handle
     b.chunkEvent.assign(static_cast<size_t>(nChunks), nullptr);
     for (int c = 0; c < nChunks; ++c) NVMK_HIP_CHECK(hipEventCreateWithFlags(&b.chunkEvent[static_cast<size_t>(c)], hipEventDisableTiming));

@@ -315,7 +315,9 @@ def embed_flat_molecules(flat_mols: Sequence[FlatMolecule], confs_per_molecule: 
             stream = torch.cuda.Stream(device=device)
             with torch.cuda.stream(stream):
                 # assembled by opts.preprocessingThreads host threads and uploaded on this stream; the embedding is queued behind it
-                molset = FlatMoleculeSet([flat_mols[i] for i in mine], device=device, preprocessing_threads=opts.preprocessingThreads)
+                # (an unset thread count is this PROCESS's share of the cores: the GPUs' builders run side by side — ADVICE r05)
+                threads = opts.preprocessingThreads if opts.preprocessingThreads > 0 else max(1, _native.build_threads(-1) // len(gpu_ids))
+                molset = FlatMoleculeSet([flat_mols[i] for i in mine], device=device, preprocessing_threads=threads)
                 results[slot] = embed_flat(molset, confs_per_molecule, max_iterations,
                                            batch_size=opts.batchSize if opts.batchSize > 0 else -1,
                                            batches_per_gpu=opts.batchesPerGpu, stream=stream, output=output, **kw)

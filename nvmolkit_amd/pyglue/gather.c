@@ -69,6 +69,9 @@ static int terms_of(PyObject* pair, int n_idx, int n_par, PyObject* keep, PyObje
   int         isz = 4, psz = 8;
   int         rc = buffer_of(PySequence_Fast_GET_ITEM(fast, 0), 0, keep, convert, &ip, &il, &isz);
   if (rc == 0 && n_par > 0) rc = buffer_of(PySequence_Fast_GET_ITEM(fast, 1), 1, keep, convert, &pp, &pl, &psz);
+  /* the descriptors point into the arrays this pair owns: the pair stays alive with `keep` (an (idx, par) pair that a
+   * property or an iterator made on the fly would otherwise be gone before the build reads its arrays) */
+  if (rc == 0 && PyList_Append(keep, fast) != 0) rc = -1;
   Py_DECREF(fast);
   if (rc != 0) return -1;
   const Py_ssize_t row = (Py_ssize_t)isz * n_idx;
@@ -108,8 +111,9 @@ static int groups_of(PyObject* seq, const int32_t* n_idx, const int32_t* n_par, 
       return -1;
     }
   }
+  const int kept = PyList_Append(keep, fast);  /* (as above: the sequence of pairs, if it was made for this call) */
   Py_DECREF(fast);
-  return 0;
+  return kept;
 }
 
 static const int32_t DG_IDX[3] = {2, 4, 1}, DG_PAR[3] = {3, 2, 0};

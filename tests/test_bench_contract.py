@@ -8,7 +8,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-COMMITTED_LINE = "r05_final_bench.json"
+COMMITTED_LINE = "r06_final_bench.json"
 
 
 def test_flags_and_defaults():
@@ -70,6 +70,23 @@ def test_committed_bench_line_has_every_field_of_the_contract():
     assert set(morgan) == {"32", "64", "128"} and all(b["mols_per_s"] > 1e6 and b["algorithmic_GB_per_s"] > 0 for b in morgan.values())
     chembl = line["secondary"]["conformers_chembl"]
     assert chembl["molecules"] > 8000 and chembl["value"] > 0.0 and "chembl_10k.smi" in chembl["data"]
+    # round 6: the WHOLE benchmark file is in the default line (the reference's benchmark feeds every molecule,
+    # benchmarks/etkdg_bench.py:193), both ChEMBL blocks carry a roofline (bytes the passes requested from HBM: the PMC file is
+    # for the synthetic set) and a CPU sample, and the line ENDS with a compact summary of both halves of the metric
+    whole = line["secondary"]["conformers_chembl_all"]
+    assert whole["molecules"] == 10000 and whole["value"] >= 200.0 and whole["atoms_percentiles_of_the_run_5_25_50_75_95_max"][-1] == 1063
+    for block in (chembl, whole):
+        assert block["roofline"]["frac_is"] == "frac_hbm_requested" and 0.0 < block["roofline"]["frac"] < 1.0
+        assert block["cpu_baseline"]["kind"] == "port" and "at most 128 atoms" in block["cpu_baseline"]["sample"]
+        assert "table assembly" in block["timed_region"] and block["table_assembly_host_seconds"] < 0.05 * block["per_rank_seconds"][0]
+    assert whole["resident_tables_value"] is None and chembl["resident_tables_run_gave_the_same_bits"] is True
+    assert list(line)[-1] == "summary"
+    summary = line["summary"]
+    assert list(summary) == ["tanimoto_pairs_per_s", "tanimoto_frac", "conformers_mols_per_s", "conformers_frac", "chembl128_mols_per_s",
+                             "chembl128_frac", "chembl_all_mols_per_s", "chembl_all_frac", "butina_s", "butina_frac"]
+    assert all(isinstance(v, float) and v > 0.0 for v in summary.values())
+    assert abs(summary["chembl_all_mols_per_s"] - whole["value"]) < 1e-3 and abs(summary["conformers_mols_per_s"] - conf["value"]) < 1e-3
+    assert len(json.dumps(summary)) < 600   # fits the tail a driver keeps of the line
 
 
 def test_committed_bench_line_quotes_counter_files_of_the_same_kernel_sources():
@@ -84,11 +101,21 @@ def test_committed_bench_line_quotes_counter_files_of_the_same_kernel_sources():
         if roof["traffic"] is None:
             continue
         name = roof["traffic_source"].split(":")[0]
-        assert name.startswith("profiles/r05_"), name
+        assert name.startswith("profiles/r06_"), name
         pmc = json.loads((ROOT / name).read_text())
         assert pmc["kernel_source_sha256"] == digests[which], (name, which)
         quoted += 1
     assert quoted == 2                                   # the round's line has both figures measured
+
+
+def test_committed_sq_counter_file_belongs_to_the_line():
+    """The SQ counters DESIGN.md quotes for the BFGS kernels, the row-panel kernel and the Morgan kernel were collected on the kernel
+    sources of the committed line (round 5's file lagged the final sources by one edit and nothing noticed)."""
+    line = json.loads((ROOT / "profiles" / COMMITTED_LINE).read_text().strip().splitlines()[-1])
+    sq = json.loads((ROOT / "profiles" / "r06_conformers" / "sq_counters_bfgs_panel_and_morgan_kernels.json").read_text())
+    for which in ("conformers", "neighbour_count"):
+        assert sq["kernel_source_sha256"][which] == line["kernel_source_sha256"][which], which
+    assert any(k.startswith("morgan_kernel") for k in sq["kernels"]) and any(k.startswith("bfgs_kernel<DG>") for k in sq["kernels"])
 
 
 def test_committed_bench_line_was_measured_on_the_kernel_sources_in_the_tree():

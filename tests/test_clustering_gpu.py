@@ -197,6 +197,28 @@ def test_butina_dense_properties(size, nl):
     assert np.array_equal(labels, w_labels) and np.array_equal(cent.numpy(), w_cent)
 
 
+def test_neighborlist_max_size_is_a_capacity_of_the_reference_kernels_not_part_of_the_result():
+    """/root/reference/src/butina.cu:79-238: NeighborlistMaxSize is the capacity of the shared-memory neighbour lists the reference
+    switches to once the largest remaining cluster fits them (kernels CountClusterSizeWithNeighborlist /
+    attemptAssignClustersFromNeighborlist); before that point it runs the matrix kernels, and both produce the same greedy
+    assignment.  Here the device rounds work on the whole graph at any cluster size, so the argument is validated and changes
+    nothing: every allowed value gives the oracle's clusters on a set whose clusters are both larger and smaller than every
+    capacity (planted clusters of 3 ... 300 members)."""
+    rng = np.random.default_rng(7)
+    sizes = [300, 150, 130, 70, 40, 20, 9, 3] + [1] * 30
+    centre = np.repeat(np.arange(len(sizes)), sizes)
+    n = len(centre)
+    d = np.where(centre[:, None] == centre[None, :], rng.uniform(0.0, 0.09, (n, n)), rng.uniform(0.3, 1.0, (n, n)))
+    d = np.minimum(d, d.T)
+    np.fill_diagonal(d, 0.0)
+    want_labels, want_cent = oracle.butina_dense(d, 0.1)
+    assert np.bincount(want_labels).max() == 300
+    x = torch.from_numpy(d).cuda()
+    for nl in (8, 16, 24, 32, 64, 128):
+        res, cent = butina(x, 0.1, neighborlist_max_size=nl, return_centroids=True)
+        assert np.array_equal(res.numpy(), want_labels) and np.array_equal(cent.numpy(), want_cent), nl
+
+
 def test_butina_dense_known_answer(golden_dir):
     g = np.load(golden_dir / "butina_10x10.npz")
     res, cent = butina(torch.from_numpy(g["dist"]).cuda(), float(g["cutoff"]), return_centroids=True)

@@ -144,6 +144,23 @@ def test_memory_constrained_paths(metric):
         fn(dev(a), dev(b), max_device_memory_bytes=1024)  # 32 rows do not fit
 
 
+@pytest.mark.parametrize("metric", ["tanimoto", "cosine"])
+def test_memory_constrained_chunks_on_operands_expanded_once(metric):
+    """Several chunks large enough for the matrix-core path (reference: src/similarity.cpp:153-232, the chunk loop): both operands are
+    expanded to FP4 once and every chunk is a launch on the prepared sets at a row offset that is a multiple of 128 — 1000 x 20 000
+    with room for two buffers of 300-odd rows: chunks of 256 rows, the last one short.  Bit for bit the oracle's matrix."""
+    mid = FUNCS[metric][1]
+    fn = crossTanimotoSimilarityMemoryConstrained if metric == "tanimoto" else crossCosineSimilarityMemoryConstrained
+    a = util.random_fingerprints(1000, 8, seed=31)
+    b = util.random_fingerprints(20000, 8, seed=32)
+    want = oracle.cross_similarity(a, b, metric=mid)
+    got = fn(dev(a), dev(b), max_device_memory_bytes=int(2 * 300 * 20000 * 8 / 0.9))
+    if metric == "tanimoto":
+        assert np.array_equal(got, want)
+    else:
+        np.testing.assert_allclose(got, want, rtol=2.3e-16, atol=0)
+
+
 @pytest.mark.parametrize("words", [32, 64, 128])
 def test_prefix_fingerprints_exhaust_all_ratios(words):
     """Row i = the first i bits set: the (F+1) x (F+1) matrix contains EVERY ratio c / u with 0 <= c <= u <= F

@@ -147,6 +147,13 @@ PY
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/pmc_hbm_traffic_conformers_classes_one_after_the_other.json 2>/dev/null
       tail -30 $O/conformer_traffic_seq.log
       ;;
+    chembl256_team)
+      : > $O/chembl256_team.txt
+      for T in ${TEAM_MINS:-1068 656}; do
+        echo "== NVMK_BFGS_TEAM=$T" | tee -a $O/chembl256_team.txt
+        NVMK_BFGS_TEAM=$T timeout 600 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 256 --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | cut -c1-420 | tee -a $O/chembl256_team.txt
+      done
+      ;;
     chembl256)
       timeout 600 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 256 --cache $CACHE 2> $O/chembl256.err | tee $O/chembl256.json | cut -c1-700
       ;;
@@ -164,9 +171,13 @@ PY
       timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD -f csv -d $O/sq_conf_2 -- $CONF > $O/sq_conf_2.log 2>&1
       timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES -f csv -d $O/sq_panel_1 -- $PANEL > $O/sq_panel_1.log 2>&1
       timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE -f csv -d $O/sq_panel_2 -- $PANEL > $O/sq_panel_2.log 2>&1
+      # (round 6: the Morgan kernel once, so that "LDS / latency bound" has a number: LDS instructions, bank conflicts, waits)
+      MORGAN="python $ROOT/tools/bench_morgan.py --mols 1000000"
+      timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES -f csv -d $O/sq_morgan_1 -- $MORGAN > $O/sq_morgan_1.log 2>&1
+      timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD -f csv -d $O/sq_morgan_2 -- $MORGAN > $O/sq_morgan_2.log 2>&1
       cd $ROOT
       python tools/sq_summary.py $O > $O/sq_counters.json && head -c 3500 $O/sq_counters.json
-      rm -rf $O/sq_conf_1 $O/sq_conf_2 $O/sq_panel_1 $O/sq_panel_2
+      rm -rf $O/sq_conf_1 $O/sq_conf_2 $O/sq_panel_1 $O/sq_panel_2 $O/sq_morgan_1 $O/sq_morgan_2
       ;;
     timeline)
       rm -f $O/bfgs_timeline.txt
@@ -180,7 +191,7 @@ PY
       timeout 900 bash tools/profile_conformer_traffic.sh 2000 > $O/conformer_traffic.log 2>&1
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/ 2>/dev/null
       # (bench.py quotes the file from profiles/ while the kernel sources' digest matches: in place for the bench steps of this session)
-      mkdir -p profiles/r05_conformers && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json profiles/r05_conformers/ 2>/dev/null
+      mkdir -p profiles/r06_conformers && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json profiles/r06_conformers/ 2>/dev/null
       tail -30 $O/conformer_traffic.log
       ;;
     table_tests)
@@ -261,7 +272,7 @@ PY
       rm -rf gpurun_out/pmc_traffic/fetch gpurun_out/pmc_traffic/write
       timeout 900 bash tools/profile_bench_traffic.sh > $O/bench_traffic.log 2>&1
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json $O/ 2>/dev/null
-      mkdir -p profiles/r05_similarity && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json profiles/r05_similarity/ 2>/dev/null
+      mkdir -p profiles/r06_similarity && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json profiles/r06_similarity/ 2>/dev/null
       tail -20 $O/bench_traffic.log
       ;;
     markers)

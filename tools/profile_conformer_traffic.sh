@@ -16,10 +16,9 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/conf_write -- $BENCH > $OU
 python - "$OUT" "$MOLS" <<'PY'
 import csv, glob, hashlib, json, os, sys
 out = {"molecules": int(sys.argv[2])}
-h = hashlib.sha256()
-for name in ("minimize.hip", "bfgs_device.inc", "hess_pass.h", "ff_terms.h", "ff_grad.h", "etkdg.hip", "table_build.cpp"):   # = bench.py conformer_source_digest()
-    h.update(open(os.path.join(os.environ["NVMK_ROOT"], "nvmolkit_amd", "csrc", name), "rb").read())
-out["kernel_source_sha256"] = h.hexdigest()
+sys.path.insert(0, os.environ["NVMK_ROOT"])
+import bench  # the digest bench.py puts into its line: conformer_source_digest()
+out["kernel_source_sha256"] = bench.conformer_source_digest()
 for line in open(f"{sys.argv[1]}/conf_fetch.log"):
     if line.startswith("{") and "etkdg_conformers" in line:
         out["conformers"] = json.loads(line)["etkdg_conformers"]
@@ -27,11 +26,11 @@ for name, sub in (("FETCH_SIZE", "conf_fetch"), ("WRITE_SIZE", "conf_write")):
     per = {}
     for f in glob.glob(f"{sys.argv[1]}/{sub}/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "bfgs_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            if ("bfgs_kernel" in r["Kernel_Name"] or "bfgs_team_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == name:
                 k = r["Kernel_Name"].split("(")[0].replace("void nvmk::minim::", "")
                 per[k] = per.get(k, 0.0) + float(r["Counter_Value"])
     out[name] = {"KiB_by_kernel": per, "KiB_total": sum(per.values())}
-    out[name]["bytes_by_kind"] = {kind: sum(v for k, v in per.items() if f"bfgs_kernel<{i}," in k) * 1024.0 * (2.0 if name == "FETCH_SIZE" else 1.0)
+    out[name]["bytes_by_kind"] = {kind: sum(v for k, v in per.items() if f"bfgs_kernel<{i}," in k or f"bfgs_team_kernel<{i}," in k) * 1024.0 * (2.0 if name == "FETCH_SIZE" else 1.0)
                                   for i, kind in enumerate(("dg", "etk", "mmff"))}
 for line in open(f"{sys.argv[1]}/conf_fetch.log"):
     if line.startswith("{") and "bfgs" in line:   # the kernels' own counters of the same run: bytes the passes requested from HBM

@@ -17,9 +17,11 @@ d = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"(t64|t128|t256)::bfgs_kernel<(\d+)", name)
+    m = re.search(r"(t64|t128|t256|t512)::(bfgs_kernel|bfgs_team_kernel)<(\d+)", name)
     if m:
-        return f"bfgs_kernel<{('DG', 'ETK', 'MMFF', 'QUARTIC', 'UFF')[int(m.group(2))] if int(m.group(2)) < 5 else m.group(2)}> {m.group(1)}"
+        return f"{m.group(2)}<{('DG', 'ETK', 'MMFF', 'QUARTIC', 'UFF')[int(m.group(3))] if int(m.group(3)) < 5 else m.group(3)}> {m.group(1)}"
+    if "morgan" in name and "kernel" in name:
+        return "morgan_kernel"
     if "neighbor_count_panel_kernel" in name:
         return "neighbor_count_panel_kernel"
     return None
@@ -36,7 +38,8 @@ def counters(sub):
 out = {"note": "rocprofv3 --pmc (8 SQ counters per pass, two passes per workload; SQ_WAVE_CYCLES in both); counters summed over all dispatches "
                "of a kernel; SQ_* cycle counters are in quad-cycles (MI355X_MICROARCH.md), ratios are to the same pass's SQ_WAVE_CYCLES",
        "workloads": {"conformers": "tools/bench_conformers.py --mols 2000 (ETKDG x 10 + MMFF94, synthetic drug-like set)",
-                     "panel": "tools/bench_butina.py 1000000 --skip-butina (1M x 1M symmetric neighbour-count pass, 2048 bit)"}}
+                     "panel": "tools/bench_butina.py 1000000 --skip-butina (1M x 1M symmetric neighbour-count pass, 2048 bit)",
+                     "morgan": "tools/bench_morgan.py (the Morgan kernel per size bucket on the reference's benchmark molecules)"}}
 try:
     import bench
 
@@ -45,7 +48,7 @@ try:
 except Exception as exc:  # noqa: BLE001
     out["kernel_source_sha256"] = {"error": str(exc)}
 kernels = collections.defaultdict(dict)
-for sub in ("sq_conf_1", "sq_conf_2", "sq_panel_1", "sq_panel_2"):
+for sub in ("sq_conf_1", "sq_conf_2", "sq_panel_1", "sq_panel_2", "sq_morgan_1", "sq_morgan_2"):
     for key, c in counters(sub).items():
         if key is None:
             continue
