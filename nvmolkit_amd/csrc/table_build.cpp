@@ -667,17 +667,18 @@ void add_groups(Build& b, const GroupShape* shapes, const int n, const char* src
   }
 }
 
+// (`build` LAST: members die in reverse order, and an asynchronous build's thread — joined by ~Build — reads the vectors before it)
 struct MolsetHandle {
   uint32_t             magic = 0x4d4f4c53;  // "MOLS"
-  Build                build;
   bool                 hasEtk = false, hasChecks = false;
   std::vector<int32_t> nAtoms, d12, d13;
   std::vector<nvmk_host_terms> checkTerms;  // 2 per molecule: (check_idx, check_par) and (check_kind, -)
+  Build                build;
 };
 struct TablesHandle {
   uint32_t magic = 0x5441424c;  // "TABL"
-  Build    build;
   int      kind = 0, nGroups = 0;
+  Build    build;
 };
 
 }  // namespace
@@ -813,6 +814,7 @@ int nvmk_etkdg_molset_free(void* handle) {
   MolsetHandle* h = static_cast<MolsetHandle*>(handle);
   NVMK_REQUIRE(h->magic == 0x4d4f4c53, "nvmk_etkdg_molset_free: not a molecule-set handle");
   h->magic = 0;
+  if (h->build.builder.joinable()) h->build.builder.join();  // an asynchronous fill reads the handle's arrays (and the caller's) to its end
   delete h;
   return NVMK_OK;
 }
@@ -899,6 +901,7 @@ int nvmk_ff_tables_free(void* handle) {
   TablesHandle* h = static_cast<TablesHandle*>(handle);
   NVMK_REQUIRE(h->magic == 0x5441424c, "nvmk_ff_tables_free: not a term-table handle");
   h->magic = 0;
+  if (h->build.builder.joinable()) h->build.builder.join();
   delete h;
   return NVMK_OK;
 }

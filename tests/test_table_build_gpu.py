@@ -89,3 +89,32 @@ def test_minimisation_on_resident_tables_while_they_are_still_uploading(library)
         with _native.options(NVMK_BUILD_SLOT_KB=64):
             got = mmffOptimization.optimize_device(mmffOptimization.resident_tables(tables), dev, max_iters=30)
         assert torch.equal(got.values.torch(), want.values.torch()) and torch.equal(got.energies.torch(), want.energies.torch())
+
+
+def test_asynchronous_build_fills_under_the_embedding_and_survives_an_early_free(library):
+    """NVMK_BUILD_ASYNC (FlatMoleculeSet's default on a GPU): the constructor returns once the tables are planned, the library's
+    threads fill and upload the rows in molecule order, nvmk_etkdg_embed waits for a batch's molecules before the batch runs
+    (reference structure: src/etkdg.cpp:175-191,211-240).  Same tables and the same conformers as the blocking build — with
+    tiny staging slots so that many chunks are still being filled when the first batch starts, and small batches so that later
+    batches meet later chunks; a consumer on ANOTHER stream waits through .wait(stream); and a set that is dropped while its
+    fill is still running is freed safely (the free joins the fill before the handle's arrays go)."""
+    mols = [FlatMolecule(**m["embed"]) for m in library]
+    want = tm.expected_molset(mols)
+    with _native.options(NVMK_BUILD_SLOT_KB=16):
+        blocking = FlatMoleculeSet(mols, asynchronous=False)
+        ref = embed_flat(blocking, confs_per_molecule=2, max_iterations=10, seed=6, batch_size=40)
+        for _ in range(3):
+            molset = FlatMoleculeSet(mols)
+            res = embed_flat(molset, confs_per_molecule=2, max_iterations=10, seed=6, batch_size=40)  # first batch: molecules 0 .. 19
+            assert np.array_equal(res.conf_counts, ref.conf_counts) and torch.equal(res.coords, ref.coords)
+            _check_molset(tm.read_molset(molset), want)
+        side = torch.cuda.Stream()
+        molset = FlatMoleculeSet(mols)
+        molset.wait(side)
+        with torch.cuda.stream(side):
+            res = embed_flat(molset, confs_per_molecule=2, max_iterations=10, seed=6, batch_size=40, stream=side)
+        side.synchronize()
+        assert torch.equal(res.coords, ref.coords)
+        for _ in range(20):  # dropped at once: the finalizer runs while the fill is in flight
+            FlatMoleculeSet(mols)
+    torch.cuda.synchronize()

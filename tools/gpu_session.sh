@@ -322,6 +322,13 @@ PY
         echo -n "ahead $A " | tee -a $O/ubench_team_ahead.jsonl; timeout 120 /tmp/utp_a$A $N $W 256 10 | tee -a $O/ubench_team_ahead.jsonl
       done; done; done
       ;;
+    ubench_team_occ)
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/ubench_team_pass.hip -o /tmp/utp_occ 2>/dev/null
+      : > $O/ubench_team_occ.jsonl
+      for N in ${UTP_N:-2000 4252}; do for G in ${UTP_G:-32 64 128 256}; do
+        timeout 120 /tmp/utp_occ $N 8 $G 10 | tee -a $O/ubench_team_occ.jsonl
+      done; done
+      ;;
     ubench_team_pass)
       for T in 512 256; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DUBENCH_THREADS=$T tools/ubench_team_pass.hip -o /tmp/utp_$T 2>/dev/null & done; wait
       : > $O/ubench_team_pass.jsonl
