@@ -355,7 +355,7 @@ def strong_scaling_share(library, total: int, world: int, rank: int):
 def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int, rank: int, cpu_seconds: float,
                     library=None, t_library: float = 0.0, collectives: bool = False, strong_total: int = 0,
                     data: str | None = None, resident_rerun: bool = True, cpu_sample_max_atoms: int | None = None,
-                    use_pmc_traffic: bool = True) -> dict:
+                    pmc_file: str | None = "pmc_hbm_traffic_conformers.json") -> dict:
     """BASELINE.json configs[2] (and [3] when world > 1: every rank embeds and optimises its own n_mols molecules, no
     data-path collective): ETKDG (`confs` conformers per molecule) DEVICE-chained into MMFF94 on the synthetic drug-like
     set of nvmolkit_amd/synthetic.py.  Roofline = the fused BFGS kernels' inverse-Hessian traffic."""
@@ -459,7 +459,8 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs on 2000 molecules of the same set, FETCH_SIZE doubled as the guide's
     # gfx950 note prescribes), scaled by the conformers of this run; only while the kernel sources are the ones measured
     traffic, traffic_src = None, None
-    for pmc in sorted((ROOT / "profiles").glob("r*/pmc_hbm_traffic_conformers.json"), reverse=True) if use_pmc_traffic else ():
+    # (pmc_file: the counter file of THIS block's molecule set — the synthetic set's ratios say nothing about the ChEMBL file's teams)
+    for pmc in sorted((ROOT / "profiles").glob(f"r*/{pmc_file}"), reverse=True) if pmc_file else ():
         c = json.loads(pmc.read_text())
         if c.get("kernel_source_sha256") == conformer_source_digest() and c.get("by_kind"):
             # per kind: (bytes read + bytes written past the L2s) / (bytes the passes requested from HBM) of the PMC run, whose
@@ -593,13 +594,15 @@ def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int | None = 12
                           data=f"topologies of tests/golden/chembl_10k.smi (the reference's benchmarks/data/chembl_10k.smi) with explicit "
                                f"hydrogens, {'every molecule' if max_atoms is None else f'at most {max_atoms} atoms'}; synthetic (generic) parameters: bounds from covalent radii, hybridisation "
                                f"and ring-size angles, cis / trans 1-4 windows, triangle smoothing; MMFF94-shaped terms with the same rest values",
-                          resident_rerun=max_atoms is not None, cpu_sample_max_atoms=128, use_pmc_traffic=False)
+                          resident_rerun=max_atoms is not None, cpu_sample_max_atoms=128,
+                          pmc_file=None if max_atoms is not None else "pmc_hbm_traffic_conformers_chembl_whole_file.json")
     out["atoms_histogram_of_the_whole_file"] = {"molecules": int(len(totals)), "mean": float(totals.mean()),
                                                 "percentiles_1_10_50_90_99_max": [int(x) for x in np.percentile(totals, [1, 10, 50, 90, 99, 100])],
                                                 "fraction_beyond_the_cut": float((totals > max_atoms).mean()) if max_atoms is not None else 0.0}
     sizes = np.array([m["embed"]["n_atoms"] for m in library])
     out["atoms_percentiles_of_the_run_5_25_50_75_95_max"] = [int(x) for x in np.percentile(sizes, [5, 25, 50, 75, 95, 100])]
-    # the roofline of these blocks divides the bytes the inverse-Hessian passes requested from HBM (the PMC file is for the synthetic set)
+    # the roofline of the <= 128-atom block divides the bytes the inverse-Hessian passes requested from HBM; the whole-file block has
+    # a counter file of its own (tools/gpu_session.sh ... chembl_all_traffic), quoted while the kernel sources are those it was taken on
     return out
 
 

@@ -301,7 +301,14 @@ int nvmk_ff_gradient(const nvmk_ff_batch* batch, double w0, double w1, const dou
                      double* d_grad, void* stream);
 /* Minimises every active system in place.  h_atom_starts is a HOST copy of atom_starts (sizes the per-system
  * inverse Hessians).  d_statuses[s] = 0 converged / 1 not (reference: statuses_, 0 == converged), d_iters optional.
- * Blocking.  Constants as the reference (FUNCTOL 1e-4, MOVETOL 1e-7, TOLX 1.2e-7, EPS 3e-8, <= 1000 line-search steps). */
+ * Blocking.  Constants as the reference (FUNCTOL 1e-4, MOVETOL 1e-7, TOLX 1.2e-7, EPS 3e-8, <= 1000 line-search steps).
+ * Any system size (the reference: shared-memory and global-memory instantiations, bfgs_minimize_permol_kernels.cu:796-932): a call
+ * is split by size — one, two, four or eight waves per system with the vectors in LDS, and from 800 coordinates on (option
+ * NVMK_BFGS_TEAM) a TEAM of 2 ... 32 workgroups per system that deal the inverse Hessian's rows and the force field's terms among
+ * themselves; a system's results depend on its size class only (bitwise reproducible for every class up to 9600 coordinates).
+ * The workgroups of a team wait for each other inside the launch: calls with team systems take turns per device inside the
+ * library, and a team whose members do not all become resident (another PROCESS holding the device's CUs with a kernel that
+ * never ends) gives up after NVMK_BFGS_TEAM_TIMEOUT_MS and the call returns NVMK_ERR_INVALID_ARGUMENT with that message. */
 int nvmk_bfgs_minimize(const nvmk_ff_batch* batch, const int32_t* h_atom_starts, double w0, double w1, int max_iters,
                        double grad_tol, int scale_grads, double* d_pos, const uint8_t* d_active, double* d_energies,
                        int16_t* d_statuses, int32_t* d_iters, void* stream);

@@ -146,8 +146,16 @@ def build_pyglue(force: bool = False, verbose: bool = False) -> Path:
         cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
         if not cc:
             raise RuntimeError("no C compiler found for nvmolkit_amd/pyglue/gather.c")
+        numpy_flags: list[str] = []
+        try:  # numpy's C API for the array reads (gather.c); without its headers the buffer protocol serves
+            import numpy
+
+            if (Path(numpy.get_include()) / "numpy" / "arrayobject.h").exists():
+                numpy_flags = ["-DNVMK_GLUE_NUMPY", f"-I{numpy.get_include()}"]
+        except Exception:  # noqa: BLE001
+            pass
         cmd = [cc, "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", f"-I{sysconfig.get_paths()['include']}",
-               f"-I{PKG_DIR.parent / 'include'}", str(PYGLUE_SRC), "-o", str(PYGLUE_PATH)]
+               f"-I{PKG_DIR.parent / 'include'}", *numpy_flags, str(PYGLUE_SRC), "-o", str(PYGLUE_PATH)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

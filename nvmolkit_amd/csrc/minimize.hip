@@ -139,6 +139,11 @@ struct SideStreams {
     if (started) (void)hipHostFree(started);
   }
 };
+// One call at a time per device may have team kernels in flight: a team's workgroups wait for each other inside the launch, so two
+// team launches of DIFFERENT calls (concurrent ETKDG batches, several host threads) that each got only part of their workgroups
+// resident would wait for CUs the other one holds.  Inside one call the team classes follow each other safely: a later class's
+// workgroups only wait for CUs, never the other way round.
+std::mutex                 g_teamMutex[64];
 std::mutex                 g_sideMutex;
 std::vector<SideStreams*>  g_sideFree[64];
 SideStreams* create_side_streams(const int dev) {
@@ -635,6 +640,10 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     NVMK_HIP_CHECK(hipMemsetAsync(profMem.ptr, 0, profWords * sizeof(int64_t), stream));
   }
 
+  std::unique_lock<std::mutex> teamLock;  // held from here to the end of the call when it has team classes
+  for (int c = kTeam0; c < kNumClasses; ++c) {
+    if (plan[c].used && !teamLock.owns_lock() && dev >= 0 && dev < 64) teamLock = std::unique_lock<std::mutex>(g_teamMutex[dev]);
+  }
   int*      startedDev = nullptr;  // set when several classes run side by side (see below)
   SideLease sideLease;            // returned to the pool when this call ends (it ends with a stream synchronisation)
   auto launch = [&](const int c, hipStream_t on) -> int {

@@ -54,6 +54,45 @@ def format_stage_timings(rows: list[dict] | None = None) -> str:
     return "\n".join(out)
 
 
+class StereoChecks:
+    """A molecule's stereo checks as three arrays — ``kind`` (n,) int32, ``idx`` (n, 5) int32 (unused slots 0), ``par`` (n, 2)
+    float64 — that still reads like the list of ``(kind, idx, par)`` tuples ``FlatMolecule.checks`` is documented as (len,
+    iteration, indexing).  The table builder's glue copies the arrays with three memcpys instead of walking ~30 tuples per
+    molecule under the GIL (half of the descriptor walk's 67 ms per 10 000 molecules)."""
+
+    __slots__ = ("kind", "idx", "par", "n_idx", "n_par")
+
+    def __init__(self, checks=()):
+        checks = list(checks)
+        n = len(checks)
+        self.kind = np.fromiter((c[0] for c in checks), dtype=np.int32, count=n)
+        self.idx = np.zeros((n, 5), dtype=np.int32)
+        self.par = np.zeros((n, 2), dtype=np.float64)
+        self.n_idx = np.fromiter((len(c[1]) for c in checks), dtype=np.int8, count=n)  # (what a tuple held: iteration gives it back)
+        self.n_par = np.fromiter((len(c[2]) for c in checks), dtype=np.int8, count=n)
+        for k, (_, idx, par) in enumerate(checks):
+            if len(idx) > 5 or len(par) > 2:
+                raise ValueError("a stereo check has at most 5 indices and 2 parameters")
+            self.idx[k, :len(idx)] = idx
+            self.par[k, :len(par)] = par
+
+    def __len__(self) -> int:
+        return len(self.kind)
+
+    def __getitem__(self, k):
+        return (int(self.kind[k]), tuple(int(x) for x in self.idx[k, :self.n_idx[k]]), tuple(float(x) for x in self.par[k, :self.n_par[k]]))
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+    def __getstate__(self):
+        return {name: getattr(self, name) for name in self.__slots__}
+
+    def __setstate__(self, state):
+        for name, value in state.items():
+            setattr(self, name, value)
+
+
 @dataclass
 class FlatMolecule:
     """One molecule in flattened form: term groups with LOCAL atom indices (layouts: include/nvmolkit_amd.h)."""
@@ -61,7 +100,7 @@ class FlatMolecule:
     n_atoms: int
     dg: Sequence[tuple]                       # 3 x (idx (n, n_idx), par (n, n_par))
     etk: Sequence[tuple] | None = None        # 6 x (idx, par) or None when the ETK stage is off
-    checks: Sequence[tuple] = field(default_factory=list)  # (kind, idx[5], par[2])
+    checks: Sequence[tuple] = field(default_factory=list)  # (kind, idx[<= 5], par[<= 2]) tuples, or a StereoChecks (arrays: faster to hand over)
     num_impropers: int = 0
 
 
@@ -87,7 +126,8 @@ class FlatMoleculeSet:
         self.mols = list(mols)
         n = len(self.mols)
         self.n_atoms = np.fromiter((m.n_atoms for m in self.mols), dtype=np.int32, count=n)
-        n_checks = sum(len(m.checks) for m in self.mols)
+        # (capacity of the arrays the glue copies tuple-style checks into; a StereoChecks is referenced where it lies)
+        n_checks = sum(len(m.checks) for m in self.mols if not isinstance(m.checks, StereoChecks))
         descs = (_native.FlatMoleculeDesc * max(n, 1))()
         kinds, idx, par = np.empty(n_checks, np.int32), np.empty((n_checks, 5), np.int32), np.empty((n_checks, 2), np.float64)
         keep: list = []

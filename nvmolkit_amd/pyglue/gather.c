@@ -16,7 +16,38 @@
 
 #include "nvmolkit_amd.h"
 
+/* Where numpy's headers are at hand (NVMK_GLUE_NUMPY, set by _build.py) an ndarray is read through numpy's C API — a handful
+ * of struct fields — instead of the buffer protocol, whose PyBUF_FORMAT request makes numpy build a format string per call:
+ * 18 such calls per molecule were 5 of the 6.4 us the walk took.  The API table is fetched on first use (the glue is loaded
+ * with ctypes.PyDLL, not imported); if that fails the buffer protocol below serves everything, as it does without the headers. */
+#ifdef NVMK_GLUE_NUMPY
+#define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
+#include <numpy/arrayobject.h>
+static int g_numpy = 0; /* 0: not tried, 1: usable, -1: not available */
+static int numpy_ready(void) {
+  if (g_numpy == 0) {
+    g_numpy = _import_array() == 0 ? 1 : -1;
+    if (g_numpy < 0) PyErr_Clear();
+  }
+  return g_numpy > 0;
+}
+#endif
+
 static int buffer_of(PyObject* obj, int is_par, PyObject* keep, PyObject* convert, const void** ptr, Py_ssize_t* len, int* itemsize) {
+#ifdef NVMK_GLUE_NUMPY
+  if (numpy_ready() && PyArray_Check(obj)) {
+    PyArrayObject* arr = (PyArrayObject*)obj;
+    const int      t   = PyArray_TYPE(arr);
+    const int      sz  = (int)PyArray_ITEMSIZE(arr);
+    const int      ok  = is_par ? (t == NPY_DOUBLE) : ((t == NPY_INT || t == NPY_LONG || t == NPY_LONGLONG) && (sz == 4 || sz == 8));
+    if (ok && PyArray_IS_C_CONTIGUOUS(arr) && PyArray_ISNOTSWAPPED(arr) && PyArray_ISALIGNED(arr)) {
+      *ptr      = PyArray_DATA(arr);
+      *len      = (Py_ssize_t)PyArray_NBYTES(arr);
+      *itemsize = sz;
+      return 0;
+    }
+  }
+#endif
   Py_buffer view;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (PyObject_GetBuffer(obj, &view, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0) {
@@ -156,6 +187,40 @@ int64_t nvmk_py_gather_flat_molecules(PyObject* mols, nvmk_flat_molecule* out, i
     if (rc != 0) goto fail;
     a = PyObject_GetAttrString(mol, "checks");
     if (a == NULL) goto fail;
+    if (PyObject_HasAttrString(a, "kind") && PyObject_HasAttrString(a, "idx") && PyObject_HasAttrString(a, "par")) {
+      /* embedMolecules.StereoChecks: kind (n,) int32, idx (n, 5) int32, par (n, 2) float64 — three copies, no tuple walk */
+      PyObject*  parts[3] = {PyObject_GetAttrString(a, "kind"), PyObject_GetAttrString(a, "idx"), PyObject_GetAttrString(a, "par")};
+      Py_buffer  view[3];
+      int        got = 0, bad = 0;
+      for (int k = 0; k < 3 && !bad; ++k) {
+        if (parts[k] == NULL || PyObject_GetBuffer(parts[k], &view[k], PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) {
+          bad = 1;
+        } else {
+          ++got;
+          const char* f = view[k].format ? view[k].format : "B";
+          while (*f == '@' || *f == '=' || *f == '<') ++f;
+          if (k < 2 ? !(f[0] == 'i' && f[1] == 0 && view[k].itemsize == 4) : !(f[0] == 'd' && f[1] == 0 && view[k].itemsize == 8)) bad = 1;
+        }
+      }
+      Py_ssize_t nc = bad ? 0 : view[0].len / 4;
+      if (!bad && (view[1].len != nc * 20 || view[2].len != nc * 16)) bad = 1;
+      if (!bad) { /* the descriptor points INTO the molecule's own arrays (no copy); `keep` holds the object that owns them */
+        d->n_checks   = (int32_t)nc;
+        d->check_kind = (const int32_t*)view[0].buf;
+        d->check_idx  = (const int32_t*)view[1].buf;
+        d->check_par  = (const double*)view[2].buf;
+        if (PyList_Append(keep, a) != 0) bad = 1;
+      }
+      for (int k = 0; k < got; ++k) PyBuffer_Release(&view[k]);
+      for (int k = 0; k < 3; ++k) Py_XDECREF(parts[k]);
+      Py_DECREF(a);
+      if (bad) {
+        if (!PyErr_Occurred())
+          PyErr_Format(PyExc_ValueError, "molecule %zd: StereoChecks needs kind (n,) int32, idx (n, 5) int32, par (n, 2) float64", m);
+        goto fail;
+      }
+      continue;
+    }
     PyObject* checks = PySequence_Fast(a, "FlatMolecule.checks must be a sequence of (kind, idx, par)");
     Py_DECREF(a);
     if (checks == NULL) goto fail;

@@ -36,6 +36,13 @@ def _chain_positions(rng, n, dim):
     return pos
 
 
+def _stereo_checks(checks):
+    """The generators' check lists in array form (embedMolecules.StereoChecks: the table builder copies them without a tuple walk)."""
+    from nvmolkit_amd.embedMolecules import StereoChecks
+
+    return StereoChecks(checks)
+
+
 def random_ff_system(kind: int, n_atoms: int, rng):
     """(pos (n, dim), groups [(idx, par)]) for one synthetic system of the given force-field kind.
     Parameters are drawn from the ranges of real tables; geometry terms straddle their bounds so that both the
@@ -499,7 +506,7 @@ def druglike_molecule(rng, n_atoms: int, with_etk: bool = True, with_mmff: bool 
                fb(tp == 1, 0.01, 100.0, 0.0), fb(tp == 2, 0.01, 100.0, 0.0),
                (angles[lin], np.tile([179.0, 180.0], (int(lin.sum()), 1))),
                fb(tp >= 3, None, 10.0, 0.0)]
-    embed = dict(n_atoms=n, dg=dg, etk=etk, checks=checks, num_impropers=n_imp)
+    embed = dict(n_atoms=n, dg=dg, etk=etk, checks=_stereo_checks(checks), num_impropers=n_imp)
     out = dict(embed=embed, ref=ref, bounds=(pairs, lbp, ubp), bonds=bonds, heavy=hv.copy())
 
     # ---- MMFF94-shaped tables: rest values from the geometry, force constants from the ranges of the real tables --
@@ -837,7 +844,7 @@ def graph_molecule(atoms, bonds, rng, with_etk: bool = True, with_mmff: bool = T
                fb(tp == 1, 0.01, 100.0), fb(tp == 2, 0.01, 100.0),
                (angles[lin], np.tile([179.0, 180.0], (int(lin.sum()), 1))),
                fb(tp >= 3, None, 10.0)]
-    embed = dict(n_atoms=n, dg=dg, etk=etk, checks=checks, num_impropers=n_imp)
+    embed = dict(n_atoms=n, dg=dg, etk=etk, checks=_stereo_checks(checks), num_impropers=n_imp)
     out = dict(embed=embed, bounds=(pairs, lbp, ubp), bonds=bonds_all, heavy=hv.copy(), elements=z.copy())
 
     if with_mmff:

@@ -63,3 +63,45 @@ def test_concurrent_calls_from_host_threads(native_lib):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_concurrent_calls_with_team_systems_take_turns():
+    """The workgroups of a BFGS team wait for each other inside the launch (csrc/bfgs_device.inc `Team`): two calls whose team
+    kernels each got only part of their workgroups resident would wait for CUs the other holds.  Calls with team systems
+    therefore take turns per device inside the library: three host threads minimise three large systems each, at once, with
+    teams as wide as an XCD — every call completes (no barrier gives up) with the bits of the same call made alone."""
+    from nvmolkit_amd.forcefield import DG
+
+    n_threads = 3
+    rng = np.random.default_rng(5)
+    systems = [util.random_ff_system(DG, n, rng) for n in (210, 260, 300)]
+    a_s, flat, groups = util.build_ff_batch_arrays(DG, systems)
+    alone = torch.from_numpy(flat).cuda()
+    with _native.options(NVMK_BFGS_TEAM_WIDTH="32", NVMK_BFGS_TEAM_TIMEOUT_MS="20000"):
+        FlatForcefieldBatch(DG, a_s, groups).minimize(alone, max_iters=6, grad_tol=1e-14, w0=0.7, w1=0.3)
+        errors, results, barrier = [], [None] * n_threads, threading.Barrier(n_threads)
+
+        def work(t):
+            try:
+                torch.cuda.set_device(0)
+                stream = torch.cuda.Stream()
+                with torch.cuda.stream(stream):
+                    batch = FlatForcefieldBatch(DG, a_s, groups)
+                    pos = torch.from_numpy(flat).cuda()
+                    barrier.wait()
+                    for _ in range(3):
+                        p = pos.clone()
+                        batch.minimize(p, max_iters=6, grad_tol=1e-14, w0=0.7, w1=0.3, stream=stream)
+                    stream.synchronize()
+                    results[t] = p.cpu().numpy()
+            except Exception as exc:  # noqa: BLE001
+                errors.append((t, repr(exc)))
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    assert not errors, errors
+    for r in results:
+        assert np.array_equal(r, alone.cpu().numpy())

@@ -36,6 +36,7 @@
 #   team_tests          the cooperative BFGS class's tests (tests/test_bfgs_parity_gpu.py -k team)
 #   ubench_team_pass    tools/ubench_team_pass.hip: the team pass alone, chip-wide, by size / width / threads
 #   team_sweep          bench_large_systems over team widths x threads per workgroup
+#   final               PMC traffic files (dense launches, conformers) and then the bench line that quotes them
 #   large_profile       the same with NVMK_BFGS_PROFILE=1: the kernels' phase clocks per size
 #   large_systems       tools/bench_large_systems.py: microseconds per BFGS iteration of 300 ... 1063-atom systems, 1 ... 256 copies
 #   butina_bench        tools/bench_butina.py 1000000 --repeat 3 on the planted clusters and on the wide-popcount-spread set
@@ -229,6 +230,14 @@ PY
       python tools/bfgs_timeline.py $O/chembl_all_timeline.txt > $O/chembl_all_timeline_summary.json && python -c "import json; d=json.load(open('$O/chembl_all_timeline_summary.json')); print(json.dumps({k: d[k] for k in ('systems','launch_groups','total_mean_occupancy','total_tail_ms_below_half','wall_ms_first_to_last')})); print(json.dumps(d['by_team_width'], indent=0)); print(json.dumps(d['by_class'], indent=0)); print(json.dumps(sorted(d['groups'], key=lambda g: -g['span_ms'])[:12], indent=0))"
       gzip -f $O/chembl_all_timeline.txt; rm -f $O/chembl_all_timeline.txt.gz
       ;;
+    chembl_all_traffic)
+      # FETCH_SIZE / WRITE_SIZE of the BFGS kernels (team kernels included) on the WHOLE benchmark file, separate --pmc passes
+      rm -rf gpurun_out/pmc_traffic/conf_fetch gpurun_out/pmc_traffic/conf_write
+      BENCH_EXTRA="--set chembl --max-atoms 100000" timeout 1500 bash tools/profile_conformer_traffic.sh 10000 > $O/chembl_all_traffic.log 2>&1
+      mkdir -p profiles/r06_conformers
+      cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/pmc_hbm_traffic_conformers_chembl_whole_file.json 2>/dev/null && cp $O/pmc_hbm_traffic_conformers_chembl_whole_file.json profiles/r06_conformers/
+      tail -30 $O/chembl_all_traffic.log
+      ;;
     chembl_all_share)
       : > $O/chembl_all_share.txt
       for K in ${SHARES:-1024 2048}; do
@@ -321,6 +330,19 @@ PY
       for N in ${UTP_N:-1200 2000 4252}; do for W in ${UTP_W:-8 32}; do for A in ${AHEADS:-0 2 3 4}; do
         echo -n "ahead $A " | tee -a $O/ubench_team_ahead.jsonl; timeout 120 /tmp/utp_a$A $N $W 256 10 | tee -a $O/ubench_team_ahead.jsonl
       done; done; done
+      ;;
+    final)
+      # everything a round's closing line is bound to (tests/test_bench_contract.py): the PMC traffic files of the kernel sources as
+      # they are, THEN the bench line that quotes them, the rocprofv3 statistics of the same command, the SQ counters
+      rm -rf gpurun_out/pmc_traffic
+      timeout 900 bash tools/profile_bench_traffic.sh > $O/bench_traffic.log 2>&1
+      mkdir -p profiles/r06_similarity profiles/r06_conformers
+      cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json $O/ 2>/dev/null && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_bench_launch.json profiles/r06_similarity/
+      timeout 900 bash tools/profile_conformer_traffic.sh 2000 > $O/conformer_traffic.log 2>&1
+      cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/ 2>/dev/null && cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json profiles/r06_conformers/
+      tail -5 $O/bench_traffic.log; tail -5 $O/conformer_traffic.log
+      timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err
+      tail -c 1500 $O/bench.json
       ;;
     ubench_team_occ)
       hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/ubench_team_pass.hip -o /tmp/utp_occ 2>/dev/null
