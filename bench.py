@@ -355,7 +355,7 @@ def strong_scaling_share(library, total: int, world: int, rank: int):
 def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int, rank: int, cpu_seconds: float,
                     library=None, t_library: float = 0.0, collectives: bool = False, strong_total: int = 0,
                     data: str | None = None, resident_rerun: bool = True, cpu_sample_max_atoms: int | None = None,
-                    pmc_file: str | None = "pmc_hbm_traffic_conformers.json") -> dict:
+                    pmc_file: str | None = "pmc_hbm_traffic_conformers.json", cpu_shared: dict | None = None) -> dict:
     """BASELINE.json configs[2] (and [3] when world > 1: every rank embeds and optimises its own n_mols molecules, no
     data-path collective): ETKDG (`confs` conformers per molecule) DEVICE-chained into MMFF94 on the synthetic drug-like
     set of nvmolkit_amd/synthetic.py.  Roofline = the fused BFGS kernels' inverse-Hessian traffic."""
@@ -514,13 +514,15 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
                                 "packed inverse Hessian, counted by the kernels themselves: nvmk_bfgs_set_stats), divided by "
                                 "the block's wall time; rows of the inverse Hessian that stay in LDS never reach HBM, so "
                                 "the bytes requested from HBM are the smaller figure beside it"}}
-    if rank == 0 and world == 1 and cpu_seconds > 0:
+    if rank == 0 and world == 1 and cpu_seconds > 0 and cpu_shared is not None and "cpu_baseline" in cpu_shared:
+        out["cpu_baseline"] = cpu_shared["cpu_baseline"]  # (the two ChEMBL blocks share ONE sample: the same molecules, timed once)
+    elif rank == 0 and world == 1 and cpu_seconds > 0:
         from nvmolkit_amd.forcefield import MMFF as KIND_MMFF, stack_molecule_tables
         from oracle import ffc
         import oracle
 
         threads = oracle.num_threads()
-        m = int(min(n_mols, max(16, 2 * threads)))
+        m = int(min(n_mols, max(16, 2 * min(threads, 128))))  # (bounded: ~10-30 s of CPU work whatever the host's thread count)
         # (the ChEMBL blocks: the sample is taken from the molecules of at most cpu_sample_max_atoms atoms — one 500-atom molecule
         # alone keeps a CPU thread busy for minutes)
         pool = library if cpu_sample_max_atoms is None else [x for x in library if x["embed"]["n_atoms"] <= cpu_sample_max_atoms]
@@ -563,6 +565,8 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
                                          f"N (N - 1) / 2 distance terms of a molecule and a dense inverse Hessian, it is a port of "
                                          f"this path, not RDKit's embedder; OpenMP over attempts / conformers on {threads} "
                                          f"threads), {c_embed + c_mmff:.1f} s"}
+        if cpu_shared is not None:
+            cpu_shared["cpu_baseline"] = out["cpu_baseline"]
     return out
 
 
@@ -581,7 +585,8 @@ def chembl_library():
     return library, time.perf_counter() - t0, totals
 
 
-def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int | None = 128, cpu_seconds: float = 0.0, prepared=None) -> dict:
+def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int | None = 128, cpu_seconds: float = 0.0, prepared=None,
+                 cpu_shared: dict | None = None) -> dict:
     """BASELINE.json configs[2] on the reference's own molecules: the 10 000 SMILES of benchmarks/data/chembl_10k.smi through
     the library's ingestion (benchmarks/etkdg_bench.py:154-161 reads them with RDKit), ETKDG + MMFF94 on the REAL topologies with
     generic parameters.  ``max_atoms`` = 128: the drug-sized 89 % of the file; ``None``: EVERY molecule, to 1063 atoms — what the
@@ -595,7 +600,8 @@ def chembl_block(confs: int, mmff_iters: int, device, max_atoms: int | None = 12
                                f"hydrogens, {'every molecule' if max_atoms is None else f'at most {max_atoms} atoms'}; synthetic (generic) parameters: bounds from covalent radii, hybridisation "
                                f"and ring-size angles, cis / trans 1-4 windows, triangle smoothing; MMFF94-shaped terms with the same rest values",
                           resident_rerun=max_atoms is not None, cpu_sample_max_atoms=128,
-                          pmc_file=None if max_atoms is not None else "pmc_hbm_traffic_conformers_chembl_whole_file.json")
+                          pmc_file=None if max_atoms is not None else "pmc_hbm_traffic_conformers_chembl_whole_file.json",
+                          cpu_shared=cpu_shared)
     out["atoms_histogram_of_the_whole_file"] = {"molecules": int(len(totals)), "mean": float(totals.mean()),
                                                 "percentiles_1_10_50_90_99_max": [int(x) for x in np.percentile(totals, [1, 10, 50, 90, 99, 100])],
                                                 "fraction_beyond_the_cut": float((totals > max_atoms).mean()) if max_atoms is not None else 0.0}
@@ -855,10 +861,11 @@ def main() -> None:
                     prepared = chembl_library()
                 except Exception as exc:  # noqa: BLE001
                     secondary["conformers_chembl"] = {"error": f"{type(exc).__name__}: {exc}"}
+            cpu_shared: dict = {}
             if args.chembl and prepared is not None:
-                guarded("conformers_chembl", chembl_block, args.conformer_confs, args.mmff_iters, device, 128, args.cpu_seconds, prepared)
+                guarded("conformers_chembl", chembl_block, args.conformer_confs, args.mmff_iters, device, 128, args.cpu_seconds, prepared, cpu_shared)
             if args.chembl_all and prepared is not None:
-                guarded("conformers_chembl_all", chembl_block, args.conformer_confs, args.mmff_iters, device, None, args.cpu_seconds, prepared)
+                guarded("conformers_chembl_all", chembl_block, args.conformer_confs, args.mmff_iters, device, None, args.cpu_seconds, prepared, cpu_shared)
         else:  # ranks meet in collectives inside the block: an exception on one rank must end the job, not hang the others
             block = conformer_block(args.conformer_mols, args.conformer_confs, args.mmff_iters, device, world, rank, args.cpu_seconds,
                                     library, t_library, collectives=True, strong_total=args.conformer_total)
