@@ -93,7 +93,7 @@ struct BfgsArgs {
   // Cooperative class (bfgs_team_kernel): teamSize workgroups minimise ONE system together — the rows of its inverse Hessian and
   // its force-field terms are dealt over them, the O(n) vector work is replicated, sums cross the team through teamExchange.
   int                             teamSize;       // workgroups per system (0: not a team launch)
-  int                             teamXcdLocal;   // 1: the ranks of a team are the blocks with one blockIdx % 8 (observed: one XCD, one L2); 0: consecutive blocks
+  unsigned*                       teamTickets;    // one word, zeroed before the launch: workgroups draw their (team, rank) in the order they start
   double*                         teamExchange;   // per team: teamExchStride doubles — teamSize partial vectors, the reduced vector, two rows of scalars
   int64_t                         teamExchStride;
   int64_t                         teamVecStride;  // doubles per vector of the exchange area (>= the largest system's coordinates + 1, even)

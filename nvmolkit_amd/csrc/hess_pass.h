@@ -540,6 +540,93 @@ __device__ __forceinline__ void hess_pass_rows(double* __restrict__ diag, double
     }
   }
 }
+// The same pass with the COLUMN vectors in LDS (round 6, second form): where n + 4 (Rb + pad) + the block's rows + the scratch fit
+// the rank's LDS, the four vectors the pass reads — g, xi, H dg, u for columns [0, Rb) — are staged once per pass (in the loop that
+// updates the diagonal anyway) and every wave takes the state of a 256-column chunk from there; the rows' coefficients are entries
+// of the same arrays.  Without it each of the eight waves reads all four vectors from HBM / L2 once per pass: 8 x 4 x 8 n bytes per
+// rank, ~12 % of what the rank streams of the triangle itself, replicated on every rank of the team.
+// LDS: colTot = n doubles; stage = 4 x (Rb + kTeamStagePad) + (Rb - Ra + kTeamStagePad) + 2 x NW x 256 doubles; one sub-block.
+__host__ __device__ constexpr int team_pass_cols_doubles(const int Ra, const int Rb) {
+  return 4 * (Rb + kTeamStagePad) + (Rb - Ra + kTeamStagePad) + 2 * NW * 256;
+}
+template <bool PREFETCH = true>
+__device__ __forceinline__ void hess_pass_rows_cols(double* __restrict__ diag, double* __restrict__ Hg, const int Ra, const int Rb, const int n,
+                                                    const bool pending, const double rfac, const double fad, const double fae,
+                                                    const double* __restrict__ xi, const double* __restrict__ hdg,
+                                                    const double* __restrict__ uu, const double* __restrict__ g,
+                                                    double* __restrict__ colTot, double* __restrict__ stage) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int cs   = Rb + kTeamStagePad;
+  double *cg = stage, *cx = stage + cs, *ch = stage + 2 * cs, *cu = stage + 3 * cs, *ss = stage + 4 * cs;
+  double* scratch = ss + (Rb - Ra + kTeamStagePad);
+  __syncthreads();  // whoever used this LDS before is done
+  // one walk over the vectors: the diagonal's update (every rank, all n), the column vectors and the row sums' first terms into LDS
+  for (int i0 = threadIdx.x; i0 < max(n, cs); i0 += 4 * NT) {
+    double d[4], x[4], h[4], u[4], gg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = min(i0 + k * NT, n - 1);
+      d[k] = diag[i], x[k] = xi[i], h[k] = hdg[i], u[k] = uu[i], gg[k] = g[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * NT;
+      if (i < n) {
+        double dd = d[k];
+        if (pending) {
+          dd += rfac * x[k] * x[k] - fad * h[k] * h[k] + fae * u[k] * u[k];
+          diag[i] = dd;
+        }
+        if (i >= Ra && i < Rb) ss[i - Ra] = dd * gg[k];
+      }
+      if (i < cs) {
+        const bool in = i < Rb;
+        cg[i] = in ? gg[k] : 0.0;
+        cx[i] = in ? x[k] : 0.0;
+        ch[i] = in ? h[k] : 0.0;
+        cu[i] = in ? u[k] : 0.0;
+      }
+    }
+  }
+  if (threadIdx.x < kTeamStagePad) ss[Rb - Ra + threadIdx.x] = 0.0;
+  __syncthreads();
+  int flip = 0;
+  for (int cBase = 0; cBase < Rb; cBase += 256) {
+    HessChunk ck[2];
+    double    col[2][2];
+    hess_chunk_state<2>(ck, col, cBase, lane, Rb, pending, rfac, fad, fae, cx, ch, cu, cg);  // (columns at or beyond Rb have no entry in these rows)
+    const int mid = min(Rb, cBase + 129);
+    {
+      HessChunk(&ck1)[1]  = reinterpret_cast<HessChunk(&)[1]>(ck[0]);
+      double(&col1)[1][2] = reinterpret_cast<double(&)[1][2]>(col[0]);
+      const int lo = max(cBase, Ra);
+      if (lo < mid) hess_range<1, PREFETCH, true, NVMK_HESS_AHEAD>(Hg, 0, lo, mid, wave, lane, ck1, pending, cx, ch, cu, cg, ss - Ra, col1);
+    }
+    const int lo2 = max(mid, Ra);
+    if (lo2 < Rb) hess_range<2, PREFETCH, true, NVMK_HESS_AHEAD>(Hg, 0, lo2, Rb, wave, lane, ck, pending, cx, ch, cu, cg, ss - Ra, col);
+    double* sc = scratch + flip * (NW * 256);
+    flip ^= 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) *reinterpret_cast<double2*>(sc + wave * 256 + 128 * k + 2 * lane) = make_double2(col[k][0], col[k][1]);
+    __syncthreads();
+    if (threadIdx.x < 256 && cBase + static_cast<int>(threadIdx.x) < n) {
+      double v = sc[threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += sc[w * 256 + threadIdx.x];
+      colTot[cBase + static_cast<int>(threadIdx.x)] = v;
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ double team_pass_contribution_cols(const int i, const int Ra, const int Rb, const double* __restrict__ colTot,
+                                                              const double* __restrict__ stage) {
+  if (i >= Rb) return 0.0;
+  double v = colTot[i];
+  if (i >= Ra) v += stage[4 * (Rb + kTeamStagePad) + (i - Ra)];
+  return v;
+}
+
 // What this rank adds to (H g)[i] after hess_pass_rows: the column's sums, and for its own rows the row's.
 __device__ __forceinline__ double team_pass_contribution(const int i, const int Ra, const int Rb, const int rowsCap, const double* __restrict__ colTot,
                                                          const double* __restrict__ stage, const double* __restrict__ rowOut) {

@@ -453,7 +453,6 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     StreamScratch        hessMem, startsMem, orderMem, counterMem, vecMem;
     // team classes: workgroups per team, teams in the launch, the exchange area and control words of the teams
     int                             teamSize = 0, nTeams = 0;
-    bool                            xcdLocal = false;
     int64_t                         exchStride = 0, teamVecStride = 0;
     StreamScratch                   exchMem, ctrlMem;
     std::vector<unsigned long long> ctrlHost;
@@ -502,9 +501,8 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       P.grid        = static_cast<int>(std::min<size_t>(cls[c].order.size(), static_cast<size_t>(nCu) * (P.gvec ? (P.threads == 512 ? 1 : 2) : kBins[c].wgPerCu)));
     }
   }
-  // Team classes: persistent teams of `width` workgroups, one workgroup per CU (512 threads) or two (256).  The ranks of a team
-  // are the blocks of one XCD (blockIdx % 8, as observed) while a team fits there; wider teams count their ranks across
-  // consecutive blocks.  Memory: one slot for the largest system's packed triangle per TEAM, the HBM vectors per workgroup, the
+  // Team classes: persistent teams of `width` workgroups, one workgroup per CU (512 threads) or two (256); the workgroups form
+  // teams in the order they start (bfgs_device.inc: make_team).  Memory: one slot for the largest system's packed triangle per TEAM, the HBM vectors per workgroup, the
   // exchange area (two blocks of `width` partial vectors, the reduced vector, two rows of scalars) and eight control words per team.
   for (int c = kTeam0; c < kNumClasses; ++c) {
     Plan& P = plan[c];
@@ -517,13 +515,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     const int capacity = nCu * (teamThreads == 512 ? 1 : 2);  // workgroups that are resident together
     int       width    = std::max(1, std::min(teamWidth[c - kTeam0], capacity));
     const int nItems   = static_cast<int>(cls[c].order.size());
-    P.xcdLocal         = nCu % 8 == 0 && (capacity / 8) % width == 0;
-    if (P.xcdLocal) {
-      const int perXcd = std::max(1, std::min((capacity / 8) / width, (nItems + 7) / 8));
-      P.nTeams         = 8 * perXcd;
-    } else {
-      P.nTeams = std::max(1, std::min(capacity / width, nItems));
-    }
+    P.nTeams = std::max(1, std::min(capacity / width, nItems));
     P.teamSize = width;
     P.grid     = P.nTeams * width;
     P.ldsDoubles        = teamLdsDoubles;
@@ -616,8 +608,9 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
       NVMK_HIP_CHECK(P.hessMem.alloc(static_cast<size_t>(P.slotDoubles) * static_cast<size_t>(P.nTeams) * sizeof(double), stream));
       NVMK_HIP_CHECK(P.vecMem.alloc(static_cast<size_t>(P.vecStride) * static_cast<size_t>(P.grid) * sizeof(double), stream));
       NVMK_HIP_CHECK(P.exchMem.alloc(static_cast<size_t>(P.exchStride) * static_cast<size_t>(P.nTeams) * sizeof(double), stream));
-      NVMK_HIP_CHECK(P.ctrlMem.alloc(static_cast<size_t>(P.nTeams) * kTeamCtrlWords * sizeof(unsigned long long), stream));
-      NVMK_HIP_CHECK(hipMemsetAsync(P.ctrlMem.ptr, 0, static_cast<size_t>(P.nTeams) * kTeamCtrlWords * sizeof(unsigned long long), stream));
+      // (the teams' control words, then one word of start tickets)
+      NVMK_HIP_CHECK(P.ctrlMem.alloc((static_cast<size_t>(P.nTeams) * kTeamCtrlWords + 1) * sizeof(unsigned long long), stream));
+      NVMK_HIP_CHECK(hipMemsetAsync(P.ctrlMem.ptr, 0, (static_cast<size_t>(P.nTeams) * kTeamCtrlWords + 1) * sizeof(unsigned long long), stream));
       NVMK_HIP_CHECK(P.counterMem.alloc(9 * sizeof(int), stream));
       NVMK_HIP_CHECK(hipMemsetAsync(P.counterMem.ptr, 0, 9 * sizeof(int), stream));
     } else if (!P.persistent) {
@@ -681,7 +674,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     A.started     = (on != stream) ? startedDev : nullptr;
     A.drained     = (startedDev != nullptr && P.persistent) ? startedDev + 1 + c : nullptr;
     A.teamSize       = P.teamSize;
-    A.teamXcdLocal   = P.xcdLocal ? 1 : 0;
+    A.teamTickets    = reinterpret_cast<unsigned*>(P.ctrlMem.as<unsigned long long>() + static_cast<size_t>(P.nTeams) * kTeamCtrlWords);
     A.teamExchange   = P.exchMem.as<double>();
     A.teamExchStride = P.exchStride;
     A.teamVecStride  = P.teamVecStride;
@@ -771,6 +764,9 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
         while (static_cast<volatile int*>(side->started)[1 + prevClass] == 0 &&
                std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20)) {
           std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        if (static_cast<volatile int*>(side->started)[1 + prevClass] == 0) {  // (never seen; the launches below are correct either way)
+          std::fprintf(stderr, "[nvmk bfgs] size class %d had not handed out its last system after 20 s: launching the next class beside it\n", prevClass);
         }
       }
       prevClass = c;

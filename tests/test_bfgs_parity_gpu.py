@@ -276,7 +276,7 @@ def test_eight_wave_class_agrees_with_four_waves_and_is_reproducible(kind):
 # reference runs systems of any size through global-memory instantiations of its one-block kernel
 # (bfgs_minimize_permol_kernels.cu:796-932); here a system of 1068 coordinates or more is minimised by a TEAM of workgroups that
 # deal the inverse Hessian's rows and the force-field terms among themselves ---------------------------------------------------
-TEAM_WIDTHS = ["2", "3", "8", "32", "40"]  # 3 and 40 do not divide an XCD's CUs: ranks counted across consecutive blocks
+TEAM_WIDTHS = ["2", "3", "8", "32", "40"]  # (any width: teams form from the workgroups in the order they start)
 
 
 @pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])

@@ -238,6 +238,17 @@ PY
       cp gpurun_out/pmc_traffic/pmc_hbm_traffic_conformers.json $O/pmc_hbm_traffic_conformers_chembl_whole_file.json 2>/dev/null && cp $O/pmc_hbm_traffic_conformers_chembl_whole_file.json profiles/r06_conformers/
       tail -30 $O/chembl_all_traffic.log
       ;;
+    ab_chembl_all)
+      # the whole ChEMBL file on the product library and on every variant library beside it (nvmolkit_amd/lib/libnvmolkit_amd_<variant>.so), alternating
+      : > $O/ab_chembl_all.txt
+      for i in 1 2; do
+        for L in "" $(ls nvmolkit_amd/lib/ | sed -n 's/^libnvmolkit_amd_\(.*\)\.so$/\1/p'); do
+          LIBP=$ROOT/nvmolkit_amd/lib/libnvmolkit_amd${L:+_$L}.so
+          echo "== ${L:-product}" | tee -a $O/ab_chembl_all.txt
+          NVMOLKIT_AMD_LIB=$LIBP timeout 900 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | cut -c1-420 | tee -a $O/ab_chembl_all.txt
+        done
+      done
+      ;;
     chembl_all_share)
       : > $O/chembl_all_share.txt
       for K in ${SHARES:-1024 2048}; do
