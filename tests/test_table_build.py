@@ -63,6 +63,30 @@ def test_molecule_set_takes_int32_arrays_lists_and_strided_views(library):
     _check_molset(tm.read_molset(FlatMoleculeSet(mols, device="cpu")), want)
 
 
+def test_stereo_checks_as_arrays_and_as_tuples_give_the_same_tables(library):
+    """FlatMolecule.checks is a list of (kind, idx, par) tuples or an embedMolecules.StereoChecks (three arrays the glue references
+    where they lie): both read the same — length, iteration, indexing, pickling — and build the same tables; a set may mix them."""
+    import pickle
+
+    from nvmolkit_amd.embedMolecules import StereoChecks
+
+    with_arrays = [FlatMolecule(**m["embed"]) for m in library[:12]]
+    assert all(isinstance(m.checks, StereoChecks) for m in with_arrays)
+    with_tuples = [FlatMolecule(m.n_atoms, m.dg, m.etk, list(m.checks), m.num_impropers) for m in with_arrays]
+    assert all(isinstance(c, tuple) and len(c) == 3 for m in with_tuples for c in m.checks)
+    one = with_arrays[0].checks
+    assert len(one) == len(with_tuples[0].checks) and one[1] == with_tuples[0].checks[1] and list(one) == with_tuples[0].checks
+    again = pickle.loads(pickle.dumps(one))
+    assert list(again) == list(one) and StereoChecks(list(one)).idx.tolist() == one.idx.tolist()
+    want = tm.expected_molset(with_tuples)
+    _check_molset(tm.read_molset(FlatMoleculeSet(with_arrays, device="cpu")), want)
+    _check_molset(tm.read_molset(FlatMoleculeSet(with_tuples, device="cpu")), want)
+    mixed = [a if k % 2 else t for k, (a, t) in enumerate(zip(with_arrays, with_tuples))]
+    _check_molset(tm.read_molset(FlatMoleculeSet(mixed, device="cpu")), want)
+    with pytest.raises(ValueError):
+        StereoChecks([(0, (0, 1, 2, 3, 4, 5), ())])
+
+
 def test_molecule_set_without_etk_without_checks_and_empty():
     rng = np.random.default_rng(3)
     e, _, _ = synthetic.synthetic_embed_molecule(rng, 9, with_etk=False)
