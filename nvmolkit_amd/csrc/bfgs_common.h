@@ -99,8 +99,17 @@ struct BfgsArgs {
   int64_t                         teamVecStride;  // doubles per vector of the exchange area (>= the largest system's coordinates + 1, even)
   unsigned long long*             teamCtrl;       // per team: kTeamCtrlWords words, zeroed before the launch (arrivals, failure flag, two item slots)
   long long                       teamTimeout;    // wall-clock ticks (100 MHz) a team barrier may wait before the launch gives up
+  // The inverse Hessian of a team's system kept as its HISTORY (bfgs_device.inc: history_product): the (xi, H dGrad) pairs of the
+  // rank-2 updates instead of the packed triangle they add up to.  historyPairs = pairs a minimisation may store (the launch's
+  // largest iteration limit), 0 = every system keeps the triangle; a system takes the history form when 2 historyPairs <= its
+  // coordinates (the pairs then never hold more bytes than the triangle's read + write of ONE iteration) or historyForce is set.
+  int                             historyPairs;
+  int                             historyForce;
 };
 constexpr int kTeamCtrlWords = 8;
+// History form: the three scalars of every pair a rank owns live at the end of the launch's dynamic LDS (3 x kHistOwnedCap doubles,
+// reserved whenever historyPairs > 0): a rank owns every teamSize-th pair, so historyPairs <= kHistOwnedCap x teamSize.
+constexpr int kHistOwnedCap = 200;
 
 int to_batch(const nvmk_ff_batch* in, Batch& out);  // minimize.hip
 

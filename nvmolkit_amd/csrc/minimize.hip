@@ -353,7 +353,14 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   // a rank's LDS (trial positions + gradient slabs / the pass's staging area, bfgs_device.inc): all of a CU's for one workgroup of
   // 512 threads, half of it for each of two workgroups of 256; a system must leave room for one gradient slab behind its positions
   const int     teamLdsDoubles = teamThreads == 512 ? 19200 : 9600;
-  const int     kTeamMaxN      = teamLdsDoubles / 2;
+  // History form of a team system's inverse Hessian (bfgs_device.inc: history_product): NVMK_BFGS_HISTORY auto (default: a system
+  // whose coordinates are at least twice the call's iteration limit) | 0 | 1 (every team system).  A launch that may use it sets
+  // 3 kHistOwnedCap doubles of its LDS aside for the scalars of a rank's pairs.
+  const opt::Text historyOpt  = opt::get(opt::kBfgsHistory);
+  const int       historyK    = historyOpt.is("0") ? 0 : std::max(max_iters, second ? second->max_iters : 0);
+  const bool      historyAll  = historyOpt.is("1");
+  const bool      historyMay  = historyK > 0 && historyK <= kHistOwnedCap * 256;
+  const int     kTeamMaxN      = (teamLdsDoubles - (historyMay ? 3 * kHistOwnedCap : 0)) / 2;
   int           teamWidth[kTeamClasses];
   for (int k = 0; k < kTeamClasses; ++k) teamWidth[k] = 2 << k;
   auto team_class_of = [&](const int64_t n64) -> int {
@@ -452,7 +459,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     std::vector<int64_t> hs;  // one-system-per-workgroup bins: per-system offsets (indexed by system), else empty
     StreamScratch        hessMem, startsMem, orderMem, counterMem, vecMem;
     // team classes: workgroups per team, teams in the launch, the exchange area and control words of the teams
-    int                             teamSize = 0, nTeams = 0;
+    int                             teamSize = 0, nTeams = 0, historyPairs = 0;
     int64_t                         exchStride = 0, teamVecStride = 0;
     StreamScratch                   exchMem, ctrlMem;
     std::vector<unsigned long long> ctrlHost;
@@ -521,7 +528,20 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     P.ldsDoubles        = teamLdsDoubles;
     P.shmem             = static_cast<size_t>(P.ldsDoubles) * sizeof(double);
     P.vecStride         = (vec_doubles(P.threads, maxN) + 1) & ~int64_t{1};
-    P.slotDoubles       = ((hess_row_offset(maxN) + kHessTailPadDoubles) + 1) & ~int64_t{1};
+    // the team's slot: the largest packed triangle among the systems that keep one, or width x the records of a rank's share of
+    // the pairs for the largest system in the history form (a rank's part of the slot: slotDoubles / width)
+    const int ownedCap = historyMay ? (historyK + width - 1) / width : 0;
+    P.historyPairs     = (historyMay && ownedCap <= kHistOwnedCap) ? historyK : 0;
+    int64_t slot       = 0;
+    for (const int32_t s : cls[c].order) {
+      const int64_t n = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
+      if (P.historyPairs > 0 && (historyAll || 2 * static_cast<int64_t>(P.historyPairs) <= n)) {
+        slot = std::max<int64_t>(slot, static_cast<int64_t>(width) * ownedCap * 2 * ((n + 1) & ~int64_t{1}));
+      } else {
+        slot = std::max<int64_t>(slot, hess_row_offset(n) + kHessTailPadDoubles);
+      }
+    }
+    P.slotDoubles       = (slot + 2 * width - 1) / (2 * width) * (2 * width);
     P.teamVecStride     = (static_cast<int64_t>(maxN) + 2 + 1) & ~int64_t{1};
     P.exchStride        = ((2 * static_cast<int64_t>(width) + 1) * P.teamVecStride + 2 * width + 1) & ~int64_t{1};
     for (int q = 0; q <= 8; ++q) P.queueStart[q] = q == 0 ? 0 : nItems;
@@ -680,6 +700,8 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     A.teamVecStride  = P.teamVecStride;
     A.teamCtrl       = P.ctrlMem.as<unsigned long long>();
     A.teamTimeout    = std::max<long>(1, opt::get(opt::kBfgsTeamTimeoutMs).num(60000)) * 100000LL;  // 100 MHz ticks
+    A.historyPairs   = P.historyPairs;
+    A.historyForce   = historyAll ? 1 : 0;
     char label[96];
     std::snprintf(label, sizeof(label), "BFGS %s: %d systems x %d threads%s", b.kind == NVMK_FF_DG ? "DG" : b.kind == NVMK_FF_ETK ? "ETK"
                   : (b.kind == NVMK_FF_MMFF || b.kind == KIND_MMFF_C) ? "MMFF" : (b.kind == NVMK_FF_UFF || b.kind == KIND_UFF_C) ? "UFF" : "quartic",

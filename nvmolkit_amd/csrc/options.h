@@ -36,6 +36,7 @@ enum Id {
   kBfgsTeamShareKb, // NVMK_BFGS_TEAM_SHARE_KB  k (a team has the largest power-of-two width that leaves every rank at least k KiB of the packed inverse Hessian)
   kBfgsTeamThreads, // NVMK_BFGS_TEAM_THREADS 512 | 256 (threads of a team's workgroups: one or two workgroups per CU)
   kBfgsTeamTimeoutMs, // NVMK_BFGS_TEAM_TIMEOUT_MS  t (a team barrier gives up after t ms and the call reports an error; default 60000)
+  kBfgsHistory,     // NVMK_BFGS_HISTORY     auto | 0 | 1 (a team system's inverse Hessian as the pairs of its updates: where twice the iteration limit is at most its coordinates / never / wherever the pairs' scalars fit)
   kNumOptions
 };
 

@@ -30,7 +30,7 @@ const char* const kNames[kNumOptions] = {"NVMK_SIM_PATH",       "NVMK_COUNT_THRE
                                          "NVMK_BFGS_VECTORS",   "NVMK_BFGS_OVERLAP",    "NVMK_BFGS_WAVE",   "NVMK_BFGS_WAVE2",
                                          "NVMK_BFGS_WAVE8",     "NVMK_BFGS_HESS_CAP_MB", "NVMK_BFGS_TIMELINE", "NVMK_BFGS_SCHED", "NVMK_MARKERS", "NVMK_ETKDG_TIMING", "NVMK_ETKDG_PRUNE",
                                          "NVMK_BUILD_SLOT_KB",  "NVMK_BFGS_TEAM",       "NVMK_BFGS_TEAM_WIDTH", "NVMK_BFGS_TEAM_SHARE_KB",
-                                         "NVMK_BFGS_TEAM_THREADS", "NVMK_BFGS_TEAM_TIMEOUT_MS"};
+                                         "NVMK_BFGS_TEAM_THREADS", "NVMK_BFGS_TEAM_TIMEOUT_MS", "NVMK_BFGS_HISTORY"};
 std::mutex g_mutex;
 Text       g_values[kNumOptions];
 bool       g_loaded = false;

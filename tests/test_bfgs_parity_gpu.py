@@ -277,14 +277,20 @@ def test_eight_wave_class_agrees_with_four_waves_and_is_reproducible(kind):
 # (bfgs_minimize_permol_kernels.cu:796-932); here a system of 1068 coordinates or more is minimised by a TEAM of workgroups that
 # deal the inverse Hessian's rows and the force-field terms among themselves ---------------------------------------------------
 TEAM_WIDTHS = ["2", "3", "8", "32", "40"]  # (any width: teams form from the workgroups in the order they start)
+# The inverse Hessian of a team's system is kept as the packed triangle ("0") or as the HISTORY of its rank-2 updates ("1": the
+# (xi, H dGrad) pairs, dealt over the ranks; bfgs_device.inc history_product) — by default ("auto") the history wherever twice the
+# call's iteration limit is at most the system's coordinates.  Same H_k in exact arithmetic, other roundings: both forms are held
+# to the oracle's trajectories.
+HISTORY = ["0", "1"]
 
 
 @pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
 @pytest.mark.parametrize("width", TEAM_WIDTHS)
-def test_team_class_matches_oracle_at_every_size(kind, width):
+@pytest.mark.parametrize("history", HISTORY)
+def test_team_class_matches_oracle_at_every_size(kind, width, history):
     """NVMK_BFGS_TEAM=1 sends EVERY system through the team kernels (NVMK_BFGS_TEAM_WIDTH workgroups each): the oracle's
-    trajectories from 5 to 200 atoms after 1, 3 and 10 iterations — teams wider than a system has rows or terms included —
-    and the same bits when the call is repeated."""
+    trajectories from 5 to 200 atoms after 1, 3 and 10 iterations — teams wider than a system has rows or terms (or pairs)
+    included — and the same bits when the call is repeated."""
     systems = systems_of(kind, SIZES, 500 + kind)
     a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
     gpu = FlatForcefieldBatch(kind, a_s, groups)
@@ -295,7 +301,7 @@ def test_team_class_matches_oracle_at_every_size(kind, width):
         runs = []
         for _ in range(2):
             pos = torch.from_numpy(flat).cuda()
-            with _native.options(NVMK_BFGS_TEAM="1", NVMK_BFGS_TEAM_WIDTH=width, NVMK_BFGS_TEAM_TIMEOUT_MS="5000"):
+            with _native.options(NVMK_BFGS_TEAM="1", NVMK_BFGS_TEAM_WIDTH=width, NVMK_BFGS_TEAM_TIMEOUT_MS="5000", NVMK_BFGS_HISTORY=history):
                 e, st, it = gpu.minimize(pos, max_iters=iters, grad_tol=1e-14, w0=w0, w1=w1)
             runs.append((pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy()))
         got, e, it = runs[0]
@@ -307,10 +313,12 @@ def test_team_class_matches_oracle_at_every_size(kind, width):
 
 @pytest.mark.parametrize("kind", [DG, ETK, MMFF, UFF])
 @pytest.mark.parametrize("threads", ["512", "256"])
-def test_team_class_at_600_to_4000_coordinates(kind, threads):
-    """The sizes the class is for, at the widths the library picks by itself (4 .. 32 workgroups): 150, 400 and 1000 atoms = 600 /
+@pytest.mark.parametrize("history", ["0", "auto"])
+def test_team_class_at_600_to_4000_coordinates(kind, threads, history):
+    """The sizes the class is for, at the widths the library picks by itself (2 .. 32 workgroups): 150, 400 and 1000 atoms = 600 /
     1600 / 4000 coordinates in 4-D, 450 / 1200 / 3000 in 3-D (the smallest one stays with the one-workgroup classes unless it
-    reaches 1068 coordinates), one and two workgroups per CU.  Ten iterations against the oracle, and twice for the same bits."""
+    reaches 800 coordinates), one and two workgroups per CU, the inverse Hessian as the triangle and — "auto": twenty pairs at
+    most against 1200 coordinates or more — as its history.  Ten iterations against the oracle, and twice for the same bits."""
     sizes = [150, 400, 1000]
     systems = systems_of(kind, sizes, 2100 + kind)
     a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
@@ -321,7 +329,7 @@ def test_team_class_at_600_to_4000_coordinates(kind, threads):
     runs = []
     for _ in range(2):
         pos = torch.from_numpy(flat).cuda()
-        with _native.options(NVMK_BFGS_TEAM_THREADS=threads, NVMK_BFGS_TEAM_TIMEOUT_MS="5000"):
+        with _native.options(NVMK_BFGS_TEAM_THREADS=threads, NVMK_BFGS_TEAM_TIMEOUT_MS="5000", NVMK_BFGS_HISTORY=history):
             e, st, it = gpu.minimize(pos, max_iters=10, grad_tol=1e-14, w0=w0, w1=w1)
         runs.append((pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy()))
     got, e, it = runs[0]
@@ -360,9 +368,11 @@ def test_team_results_depend_on_the_system_and_the_width_only():
 
 
 @pytest.mark.parametrize("kind", [DG, MMFF])
-def test_team_restarts_and_second_stage_equal_separate_calls(kind):
+@pytest.mark.parametrize("history", HISTORY)
+def test_team_restarts_and_second_stage_equal_separate_calls(kind, history):
     """repeatUntilConverged and the second minimisation inside a team launch (the coordinates stay in the ranks' work areas between
-    the minimisations; only rank 0 writes the caller's array): bit for bit what separate calls give."""
+    the minimisations; only rank 0 writes the caller's array; a history starts empty every time): bit for bit what separate calls
+    give."""
     import ctypes
 
     sizes = [12, 30, 60, 130]
@@ -371,7 +381,7 @@ def test_team_restarts_and_second_stage_equal_separate_calls(kind):
     w0, w1 = W[kind]
     gpu = FlatForcefieldBatch(kind, a_s, groups)
     n_sys = len(sizes)
-    with _native.options(NVMK_BFGS_TEAM="1", NVMK_BFGS_TEAM_WIDTH="4", NVMK_BFGS_TEAM_TIMEOUT_MS="5000"):
+    with _native.options(NVMK_BFGS_TEAM="1", NVMK_BFGS_TEAM_WIDTH="4", NVMK_BFGS_TEAM_TIMEOUT_MS="5000", NVMK_BFGS_HISTORY=history):
         one = torch.from_numpy(flat).cuda()
         e1, st1, it1 = gpu.minimize(one, max_iters=7, grad_tol=1e-3, w0=w0, w1=w1, restarts=3)
         many = torch.from_numpy(flat).cuda()
@@ -412,6 +422,29 @@ def test_team_restarts_and_second_stage_equal_separate_calls(kind):
             want_pos, want = (between, (ea, sta, ita)) if skip[s] else (two, (eb, stb, itb))
             assert torch.equal(pos[lo:hi], want_pos[lo:hi]), s
             assert float(energies[s]) == float(want[0][s]) and int(statuses[s]) == int(want[1][s]) and int(iters[s]) == int(want[2][s]), s
+
+
+@pytest.mark.parametrize("kind,iters,tol", [(DG, 60, 1e-4), (MMFF, 30, 1e-6)])
+def test_team_history_follows_the_triangle_through_a_long_minimisation(kind, iters, tol):
+    """Sixty (thirty) iterations of a 300- and a 500-atom system — as many pairs, dealt over 2 to 8 ranks, batches of four with a
+    ragged last one — in both forms of the inverse Hessian: the same number of iterations, and coordinates that differ by what the
+    roundings of that many updates grow to (tools/probe_history_depth.py: 2e-5 / 4e-8 here, the same distance either form keeps
+    from the CPU oracle; MMFF minimisations of this size are chaotic from about fifty iterations on) — and differ they must."""
+    sizes = [300, 500]
+    systems = systems_of(kind, sizes, 2500 + kind)
+    a_s, flat, groups = synthetic.build_ff_batch_arrays(kind, systems)
+    gpu = FlatForcefieldBatch(kind, a_s, groups)
+    w0, w1 = W[kind]
+    out = {}
+    for history in ("0", "auto"):
+        with _native.options(NVMK_BFGS_TEAM_TIMEOUT_MS="5000", NVMK_BFGS_HISTORY=history):
+            pos = torch.from_numpy(flat).cuda()
+            e, st, it = gpu.minimize(pos, max_iters=iters, grad_tol=1e-14, w0=w0, w1=w1)
+            out[history] = (pos.cpu().numpy(), e.cpu().numpy(), it.cpu().numpy())
+    assert np.array_equal(out["0"][2], out["auto"][2])
+    assert not np.array_equal(out["0"][0], out["auto"][0])
+    np.testing.assert_allclose(out["auto"][1], out["0"][1], rtol=1e-6)
+    assert np.max(np.abs(out["auto"][0] - out["0"][0])) <= tol
 
 
 def _slice_group(g, s):

@@ -34,6 +34,9 @@
 #                       lib/libnvmolkit_amd_noprune.so (NVMK_EXTRA_HIPCC_FLAGS=-DNVMK_PANEL_NO_HALF_PRUNE NVMK_BUILD_VARIANT=noprune)
 #   panel_fetch         tools/profile_panel_fetch.sh: FETCH_SIZE of the row-panel count kernel, product and variant libraries
 #   team_tests          the cooperative BFGS class's tests (tests/test_bfgs_parity_gpu.py -k team)
+#   history_ab          large systems, 400 iterations, inverse Hessian as the triangle and as the history of its updates
+#   chembl_all_history  the whole ChEMBL file with NVMK_BFGS_HISTORY=auto and 0
+#   trajectory_depth    tools/probe_history_depth.py: how far the two forms of a team's inverse Hessian and the oracle agree, by depth
 #   ubench_team_pass    tools/ubench_team_pass.hip: the team pass alone, chip-wide, by size / width / threads
 #   team_sweep          bench_large_systems over team widths x threads per workgroup
 #   final               PMC traffic files (dense launches, conformers) and then the bench line that quotes them
@@ -330,6 +333,25 @@ PY
       ;;
     panel_fetch)
       bash tools/profile_panel_fetch.sh $O 2>&1 | tail -40
+      ;;
+    history_ab)
+      # the inverse Hessian of a team's system as the packed triangle (0) and as the history of its updates (auto): microseconds per
+      # iteration of large systems over a 400-iteration minimisation, alone and 64 at a time
+      : > $O/history_ab.txt
+      for H in 0 auto; do for K in ${HIST_KINDS:-dg mmff}; do
+        echo "== NVMK_BFGS_HISTORY=$H $K ${EXTRA_ENV:-}" | tee -a $O/history_ab.txt
+        env ${EXTRA_ENV:-} NVMK_BFGS_HISTORY=$H timeout 600 python tools/bench_large_systems.py --kind $K --atoms ${LARGE_ATOMS:-250,400,700,1063} --copies ${LARGE_COPIES:-1,64} --iters ${HIST_ITERS:-400} --repeat 1 2>/dev/null | cut -c1-220 | tee -a $O/history_ab.txt
+      done; done
+      ;;
+    chembl_all_history)
+      : > $O/chembl_all_history.txt
+      for H in ${HIST_MODES:-auto 0}; do
+        echo "== NVMK_BFGS_HISTORY=$H ${EXTRA_ENV:-}" | tee -a $O/chembl_all_history.txt
+        env ${EXTRA_ENV:-} NVMK_BFGS_HISTORY=$H timeout 900 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | cut -c1-1400 | tee -a $O/chembl_all_history.txt
+      done
+      ;;
+    trajectory_depth)
+      timeout 600 python tools/probe_history_depth.py 2>&1 | tail -40 | tee $O/trajectory_depth.txt
       ;;
     team_tests)
       ( time timeout 1200 python -m pytest tests/test_bfgs_parity_gpu.py -m gpu -q -x -k "team" ) > $O/team_tests.log 2>&1
