@@ -59,7 +59,7 @@ constexpr int    MAX_LS_ITERS  = 1000;
 // The one-workgroup-per-CU and the GVEC classes run as persistent workgroups that take systems off a counter (largest
 // first) and keep ONE inverse-Hessian slot each, so the memory a launch needs is bounded by the workgroups in flight, not by
 // the number of large systems (a 1000-atom 4-D system has a 64 MB triangle).
-constexpr int kProfWords = 12;  // per system: 7 phase sums, then the item's first / last clock and its hardware id (timeline)
+constexpr int kProfWords = 16;  // per system: 7 phase sums, then the item's first / last clock, its hardware id and team width (timeline); 12..15: history product — ticks in the batches' loads + dot products, reductions + coefficients, terms; batches
 struct BfgsArgs {
   double*                         positions;
   double                          w0, w1;
@@ -105,11 +105,12 @@ struct BfgsArgs {
   // coordinates (the pairs then never hold more bytes than the triangle's read + write of ONE iteration) or historyForce is set.
   int                             historyPairs;
   int                             historyForce;
+  int                             historyOwned;   // pairs a rank may own: ceil(historyPairs / teamSize) — 3 doubles each at the end of the dynamic LDS
 };
 constexpr int kTeamCtrlWords = 8;
-// History form: the three scalars of every pair a rank owns live at the end of the launch's dynamic LDS (3 x kHistOwnedCap doubles,
-// reserved whenever historyPairs > 0): a rank owns every teamSize-th pair, so historyPairs <= kHistOwnedCap x teamSize.
-constexpr int kHistOwnedCap = 200;
+// History form: the three scalars of every pair a rank owns live at the end of the launch's dynamic LDS (3 x historyOwned doubles):
+// a rank owns every teamSize-th pair, and no launch asks for more than kHistOwnedCap of them per rank.
+constexpr int kHistOwnedCap = 512;
 
 int to_batch(const nvmk_ff_batch* in, Batch& out);  // minimize.hip
 

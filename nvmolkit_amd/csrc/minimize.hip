@@ -339,16 +339,16 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     return (c == 0 || c == kFirst128 || c == kFirst256 || c == kFirst512) ? std::max(firstBudget, bin_budget(c)) : bin_budget(c);
   };
   const int  kGlobal = nBins, kGlobal8 = nBins + 1;  // class indices of the HBM-vector systems: four waves, eight waves
-  // Team classes (several workgroups per system, minimize_team.hip): class kTeam0 + k = teams of 2^(k+1) workgroups.  A system of
-  // NVMK_BFGS_TEAM coordinates or more (default 1068: where the vectors of an eight-wave workgroup stop fitting LDS) joins the
+  // Team classes (several workgroups per system, minimize_team.hip): class kTeam0 + k = teams of 2^k workgroups.  A system of
+  // NVMK_BFGS_TEAM coordinates or more (default 800) joins the
   // class of the largest power-of-two width that leaves every rank NVMK_BFGS_TEAM_SHARE_KB of the packed inverse Hessian (at
-  // least two workgroups, at most one XCD's CUs); NVMK_BFGS_TEAM_WIDTH sets one width for all of them (tests: any number up to
+  // most one XCD's CUs); NVMK_BFGS_TEAM_WIDTH sets one width for all of them (tests: any number up to
   // 256, ranks then count across the XCDs).  The width of a system's team depends on its size only, and so do its results.
-  constexpr int kTeam0 = 14, kTeamClasses = 8, kNumClasses = kTeam0 + kTeamClasses;
+  constexpr int kTeam0 = 14, kTeamClasses = 9, kNumClasses = kTeam0 + kTeamClasses;
   const long    teamOpt   = opt::get(opt::kBfgsTeam).num(-1);
   const int     kTeamMinN = teamOpt == 0 ? kNoLimit : teamOpt > 0 ? static_cast<int>(std::min<long>(teamOpt, kNoLimit)) : 800;
   const long    teamWidthOpt = opt::get(opt::kBfgsTeamWidth).num(0);
-  const long    teamShareKb  = std::max<long>(1, opt::get(opt::kBfgsTeamShareKb).num(2048));
+  const long    teamShareKb  = std::max<long>(1, opt::get(opt::kBfgsTeamShareKb).num(4096));
   const int     teamThreads  = opt::get(opt::kBfgsTeamThreads).num(512) == 256 ? 256 : 512;
   // a rank's LDS (trial positions + gradient slabs / the pass's staging area, bfgs_device.inc): all of a CU's for one workgroup of
   // 512 threads, half of it for each of two workgroups of 256; a system must leave room for one gradient slab behind its positions
@@ -360,21 +360,25 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   const int       historyK    = historyOpt.is("0") ? 0 : std::max(max_iters, second ? second->max_iters : 0);
   const bool      historyAll  = historyOpt.is("1");
   const bool      historyMay  = historyK > 0 && historyK <= kHistOwnedCap * 256;
-  const int     kTeamMaxN      = (teamLdsDoubles - (historyMay ? 3 * kHistOwnedCap : 0)) / 2;
+  const int     kTeamMaxN      = (teamLdsDoubles - (historyMay ? 3 * std::min(historyK, kHistOwnedCap) : 0)) / 2;
+  // class kTeam0 + k: teams of 2^k workgroups.  A "team" of ONE is the same kernel without an exchange (NVMK_BFGS_TEAM_WIDTH=1);
+  // the library itself never picks it: with the history form the whole ChEMBL file takes ETKDG 18.8 / MMFF 4.0 s with teams of
+  // one for the systems below 2 x NVMK_BFGS_TEAM_SHARE_KB, 18.0 / 4.0 s with teams of two (profiles/r06_conformers/history_form_sweeps.txt).
+  const int     minWidthLog2 = 1;
   int           teamWidth[kTeamClasses];
-  for (int k = 0; k < kTeamClasses; ++k) teamWidth[k] = 2 << k;
+  for (int k = 0; k < kTeamClasses; ++k) teamWidth[k] = 1 << k;
   auto team_class_of = [&](const int64_t n64) -> int {
     if (teamWidthOpt > 0) {
       const int w = static_cast<int>(std::min<long>(teamWidthOpt, 256));
       int       k = 0;
-      while (k + 1 < kTeamClasses && (2 << k) < w) ++k;
+      while (k + 1 < kTeamClasses && (1 << k) < w) ++k;
       teamWidth[k] = std::max(w, 1);
       return kTeam0 + k;
     }
     const int64_t bytes = hess_row_offset(n64) * 8;
     int           k     = 0;
-    while (k + 1 < 5 && bytes / (4 << k) >= teamShareKb * 1024) ++k;  // widths 2 .. 32
-    return kTeam0 + k;
+    while (k + 1 < 6 && bytes / (2 << k) >= teamShareKb * 1024) ++k;  // widths 1 .. 32
+    return kTeam0 + std::max(k, minWidthLog2);
   };
 
   // ---- size classes
@@ -536,7 +540,8 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     for (const int32_t s : cls[c].order) {
       const int64_t n = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
       if (P.historyPairs > 0 && (historyAll || 2 * static_cast<int64_t>(P.historyPairs) <= n)) {
-        slot = std::max<int64_t>(slot, static_cast<int64_t>(width) * ownedCap * 2 * ((n + 1) & ~int64_t{1}));
+        // (+ 128 doubles per rank: a DMA chunk reads up to 127 doubles past a vector's end)
+        slot = std::max<int64_t>(slot, static_cast<int64_t>(width) * (static_cast<int64_t>(ownedCap) * 2 * ((n + 1) & ~int64_t{1}) + 128));
       } else {
         slot = std::max<int64_t>(slot, hess_row_offset(n) + kHessTailPadDoubles);
       }
@@ -702,6 +707,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     A.teamTimeout    = std::max<long>(1, opt::get(opt::kBfgsTeamTimeoutMs).num(60000)) * 100000LL;  // 100 MHz ticks
     A.historyPairs   = P.historyPairs;
     A.historyForce   = historyAll ? 1 : 0;
+    A.historyOwned   = P.historyPairs > 0 ? (P.historyPairs + std::max(P.teamSize, 1) - 1) / std::max(P.teamSize, 1) : 0;
     char label[96];
     std::snprintf(label, sizeof(label), "BFGS %s: %d systems x %d threads%s", b.kind == NVMK_FF_DG ? "DG" : b.kind == NVMK_FF_ETK ? "ETK"
                   : (b.kind == NVMK_FF_MMFF || b.kind == KIND_MMFF_C) ? "MMFF" : (b.kind == NVMK_FF_UFF || b.kind == KIND_UFF_C) ? "UFF" : "quartic",
@@ -842,13 +848,14 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     std::vector<int64_t> h(profWords);
     NVMK_HIP_CHECK(hipMemcpyAsync(h.data(), profMem.ptr, profWords * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     NVMK_HIP_CHECK(hipStreamSynchronize(stream));
-    double  sum[7] = {0, 0, 0, 0, 0, 0, 0};
+    double  sum[7] = {0, 0, 0, 0, 0, 0, 0}, hist[4] = {0, 0, 0, 0};
     int64_t ran = 0, longest = 0;
     for (int sI = 0; sI < b.nSystems; ++sI) {
       if (h[static_cast<size_t>(sI) * kProfWords + 4] == 0) continue;
       ++ran;
       longest = std::max(longest, h[static_cast<size_t>(sI) * kProfWords + 4]);
       for (int k = 0; k < 7; ++k) sum[k] += static_cast<double>(h[static_cast<size_t>(sI) * kProfWords + k]);
+      for (int k = 0; k < 4; ++k) hist[k] += static_cast<double>(h[static_cast<size_t>(sI) * kProfWords + 12 + k]);
     }
     // NVMK_BFGS_TIMELINE=path: one line per system that ran — kind, coordinates, first / last clock of its workgroup (100 MHz,
     // chip-wide), XCC and CU — appended; tools/bfgs_timeline.py turns the file into occupancy over time and the launch tails
@@ -860,9 +867,10 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
             const int64_t* r = h.data() + static_cast<size_t>(sI) * kProfWords;
             if (r[8] == 0) continue;
             const unsigned hw = static_cast<unsigned>(r[9] & 0xffffffff), xcc = static_cast<unsigned>(r[9] >> 32) & 0xf;
-            std::fprintf(f, "%d %d %lld %lld %u %u %u %lld %lld %lld\n", b.kind, (h_atom_starts[sI + 1] - h_atom_starts[sI]) * dim,
+            std::fprintf(f, "%d %d %lld %lld %u %u %u %lld %lld %lld %lld %lld %lld %lld %lld\n", b.kind, (h_atom_starts[sI + 1] - h_atom_starts[sI]) * dim,
                          (long long)r[7], (long long)r[8], xcc, (hw >> 8) & 0xf, (hw >> 4) & 0x3, (long long)r[5], (long long)r[4],
-                         (long long)r[10]);  // (last: workgroups of the system's team, 0 = one workgroup)
+                         (long long)r[10],  // (workgroups of the system's team, 0 = one workgroup)
+                         (long long)r[0], (long long)r[1], (long long)r[2], (long long)r[3], (long long)r[6]);  // phase ticks: line-search energies, gradients, H g, update + direction; energy evaluations
           }
           std::fclose(f);
         }
@@ -876,6 +884,10 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
                    b.kind, (long long)ran, sum[4] / ran * us, longest * us, sum[5] / ran, sum[6] / ran,
                    sum[0] / std::max(sum[5], 1.0) * us, sum[1] / std::max(sum[5], 1.0) * us, sum[2] / std::max(sum[5], 1.0) * us,
                    sum[3] / std::max(sum[5], 1.0) * us);
+    }
+    if (hist[3] > 0) {
+      std::fprintf(stderr, "[nvmk bfgs profile] kind %d history product: %.0f batches, per batch: loads + dot products %.2f us, reductions + coefficients %.2f us, terms %.2f us\n",
+                   b.kind, hist[3], hist[0] / hist[3] * 0.01, hist[1] / hist[3] * 0.01, hist[2] / hist[3] * 0.01);
     }
     return teams_ok();
   }

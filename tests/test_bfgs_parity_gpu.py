@@ -276,7 +276,7 @@ def test_eight_wave_class_agrees_with_four_waves_and_is_reproducible(kind):
 # reference runs systems of any size through global-memory instantiations of its one-block kernel
 # (bfgs_minimize_permol_kernels.cu:796-932); here a system of 1068 coordinates or more is minimised by a TEAM of workgroups that
 # deal the inverse Hessian's rows and the force-field terms among themselves ---------------------------------------------------
-TEAM_WIDTHS = ["2", "3", "8", "32", "40"]  # (any width: teams form from the workgroups in the order they start)
+TEAM_WIDTHS = ["1", "2", "3", "8", "32", "40"]  # (any width: teams form from the workgroups in the order they start)
 # The inverse Hessian of a team's system is kept as the packed triangle ("0") or as the HISTORY of its rank-2 updates ("1": the
 # (xi, H dGrad) pairs, dealt over the ranks; bfgs_device.inc history_product) — by default ("auto") the history wherever twice the
 # call's iteration limit is at most the system's coordinates.  Same H_k in exact arithmetic, other roundings: both forms are held

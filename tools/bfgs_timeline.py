@@ -71,6 +71,27 @@ if args.wave8 > 0:
               (1 << 30, "eight waves (HBM vectors)")]
 else:
     bounds = [(args.wave, "one wave"), (args.wave2, "two waves"), (655, "four waves A"), (1320, "four waves B"), (1 << 30, "four waves C (HBM vectors)")]
+# Per kind and size bin (round 6, history form): CU time (a team's workgroups all counted) and how the kernel's own phase clocks split
+# it — line-search energy evaluations, gradients, the product H g (triangle pass or history product), update + direction.
+if rec.shape[1] > 13:
+    ph = rec[order][:, 10:14].astype(np.float64)
+    busy_ticks = rec[order][:, 8].astype(np.float64)
+    out["by_kind_and_size"] = []
+    edges_n = [0, 176, 256, 400, 655, 799, 1100, 1500, 2047, 2900, 1 << 30]
+    for k in np.unique(kind):
+        for lo_n, hi_n in zip(edges_n[:-1], edges_n[1:]):
+            m = (kind == k) & (n > lo_n) & (n <= hi_n)
+            if not m.any():
+                continue
+            width = np.maximum(team[m], 1).astype(np.float64)
+            cu_share = np.where(team[m] > 0, width, waves[m] / 8.0)  # fraction of a CU's wave slots x workgroups
+            cu_ms = float(((t1[m] - t0[m]) * cu_share).sum()) * 1e-5
+            tot = np.maximum(ph[m].sum(), 1.0)
+            out["by_kind_and_size"].append({"kind": int(k), "coordinates": [int(n[m].min()), int(n[m].max())], "systems": int(m.sum()),
+                                            "cu_ms": round(cu_ms, 1), "mean_iterations": round(float(iters[m].mean()), 1),
+                                            "us_per_iteration": round(float(busy_ticks[m].sum()) / max(float(iters[m].sum()), 1.0) * 1e-2, 1),
+                                            "phase_fractions_energy_gradient_product_update": [round(float(ph[m][:, j].sum() / tot), 3) for j in range(4)],
+                                            "phase_us_per_iteration": [round(float(ph[m][:, j].sum()) / max(float(iters[m].sum()), 1.0) * 1e-2, 1) for j in range(4)]})
 out["by_class"] = []
 lo = 0
 for hi, name in bounds:

@@ -230,7 +230,7 @@ PY
       rm -f $O/chembl_all_timeline.txt
       NVMK_ETKDG_TIMING=1 NVMK_BFGS_PROFILE=1 NVMK_BFGS_TIMELINE=$O/chembl_all_timeline.txt timeout 1500 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --cache $CACHE > $O/chembl_all_timeline_run.log 2>&1
       grep '^{' $O/chembl_all_timeline_run.log | tail -1 | cut -c1-600
-      python tools/bfgs_timeline.py $O/chembl_all_timeline.txt > $O/chembl_all_timeline_summary.json && python -c "import json; d=json.load(open('$O/chembl_all_timeline_summary.json')); print(json.dumps({k: d[k] for k in ('systems','launch_groups','total_mean_occupancy','total_tail_ms_below_half','wall_ms_first_to_last')})); print(json.dumps(d['by_team_width'], indent=0)); print(json.dumps(d['by_class'], indent=0)); print(json.dumps(sorted(d['groups'], key=lambda g: -g['span_ms'])[:12], indent=0))"
+      python tools/bfgs_timeline.py $O/chembl_all_timeline.txt > $O/chembl_all_timeline_summary.json && python -c "import json; d=json.load(open('$O/chembl_all_timeline_summary.json')); print(json.dumps({k: d[k] for k in ('systems','launch_groups','total_mean_occupancy','total_tail_ms_below_half','wall_ms_first_to_last')})); print(json.dumps(d['by_team_width'], indent=0)); print(json.dumps(d['by_class'], indent=0)); print(json.dumps(sorted(d['groups'], key=lambda g: -g['span_ms'])[:6], indent=0)); [print(json.dumps(x)) for x in d.get('by_kind_and_size', [])]"
       gzip -f $O/chembl_all_timeline.txt; rm -f $O/chembl_all_timeline.txt.gz
       ;;
     chembl_all_traffic)
