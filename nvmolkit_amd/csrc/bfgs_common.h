@@ -101,8 +101,10 @@ struct BfgsArgs {
   long long                       teamTimeout;    // wall-clock ticks (100 MHz) a team barrier may wait before the launch gives up
   // The inverse Hessian of a team's system kept as its HISTORY (bfgs_device.inc: history_product): the (xi, H dGrad) pairs of the
   // rank-2 updates instead of the packed triangle they add up to.  historyPairs = pairs a minimisation may store (the launch's
-  // largest iteration limit), 0 = every system keeps the triangle; a system takes the history form when 2 historyPairs <= its
-  // coordinates (the pairs then never hold more bytes than the triangle's read + write of ONE iteration) or historyForce is set.
+  // largest iteration limit), 0 = every system keeps the triangle; a system takes the history form when 3 historyPairs <= 2 x its
+  // coordinates (the pairs of a minimisation that runs to the limit then average 3/8 of the triangle's read + write per
+  // iteration, and hold 4/3 of it at the very end; measured on the reference's benchmark file: the form wins from 656
+  // coordinates on at 400 iterations, not from 400) or historyForce is set — and at most 16 x the workgroup's threads.
   int                             historyPairs;
   int                             historyForce;
   int                             historyOwned;   // pairs a rank may own: ceil(historyPairs / teamSize) — 3 doubles each at the end of the dynamic LDS

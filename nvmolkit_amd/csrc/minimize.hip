@@ -340,22 +340,23 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
   };
   const int  kGlobal = nBins, kGlobal8 = nBins + 1;  // class indices of the HBM-vector systems: four waves, eight waves
   // Team classes (several workgroups per system, minimize_team.hip): class kTeam0 + k = teams of 2^k workgroups.  A system of
-  // NVMK_BFGS_TEAM coordinates or more (default 800) joins the
+  // NVMK_BFGS_TEAM coordinates or more (default 656: the systems the eight-wave one-workgroup class used to take) joins the
   // class of the largest power-of-two width that leaves every rank NVMK_BFGS_TEAM_SHARE_KB of the packed inverse Hessian (at
   // most one XCD's CUs); NVMK_BFGS_TEAM_WIDTH sets one width for all of them (tests: any number up to
   // 256, ranks then count across the XCDs).  The width of a system's team depends on its size only, and so do its results.
   constexpr int kTeam0 = 14, kTeamClasses = 9, kNumClasses = kTeam0 + kTeamClasses;
   const long    teamOpt   = opt::get(opt::kBfgsTeam).num(-1);
-  const int     kTeamMinN = teamOpt == 0 ? kNoLimit : teamOpt > 0 ? static_cast<int>(std::min<long>(teamOpt, kNoLimit)) : 800;
+  const int     kTeamMinN = teamOpt == 0 ? kNoLimit : teamOpt > 0 ? static_cast<int>(std::min<long>(teamOpt, kNoLimit)) : 656;
   const long    teamWidthOpt = opt::get(opt::kBfgsTeamWidth).num(0);
   const long    teamShareKb  = std::max<long>(1, opt::get(opt::kBfgsTeamShareKb).num(4096));
   const int     teamThreads  = opt::get(opt::kBfgsTeamThreads).num(512) == 256 ? 256 : 512;
   // a rank's LDS (trial positions + gradient slabs / the pass's staging area, bfgs_device.inc): all of a CU's for one workgroup of
   // 512 threads, half of it for each of two workgroups of 256; a system must leave room for one gradient slab behind its positions
   const int     teamLdsDoubles = teamThreads == 512 ? 19200 : 9600;
-  // History form of a team system's inverse Hessian (bfgs_device.inc: history_product): NVMK_BFGS_HISTORY auto (default: a system
-  // whose coordinates are at least twice the call's iteration limit) | 0 | 1 (every team system).  A launch that may use it sets
-  // 3 kHistOwnedCap doubles of its LDS aside for the scalars of a rank's pairs.
+  // History form of a team system's inverse Hessian (bfgs_device.inc: history_product_held): NVMK_BFGS_HISTORY auto (default: a
+  // system for which three times the call's iteration limit is at most twice its coordinates — every team system of an ETKDG or
+  // MMFF run) | 0 | 1 (every team system).  A launch that uses it sets three doubles per pair a rank may own aside at the end of
+  // its LDS.  Whole ChEMBL file, ten conformers: ETKDG 35.3 -> 16.3 s, MMFF 5.1 -> 4.0 s (profiles/r06_conformers/history_form.txt).
   const opt::Text historyOpt  = opt::get(opt::kBfgsHistory);
   const int       historyK    = historyOpt.is("0") ? 0 : std::max(max_iters, second ? second->max_iters : 0);
   const bool      historyAll  = historyOpt.is("1");
@@ -539,7 +540,7 @@ int nvmk_bfgs_minimize_two_stages(const nvmk_ff_batch* batch, const int32_t* h_a
     int64_t slot       = 0;
     for (const int32_t s : cls[c].order) {
       const int64_t n = static_cast<int64_t>(h_atom_starts[s + 1] - h_atom_starts[s]) * dim;
-      if (P.historyPairs > 0 && (historyAll || 2 * static_cast<int64_t>(P.historyPairs) <= n)) {
+      if (P.historyPairs > 0 && (historyAll || 3 * static_cast<int64_t>(P.historyPairs) <= 2 * n) && n <= 16 * teamThreads) {
         // (+ 128 doubles per rank: a DMA chunk reads up to 127 doubles past a vector's end)
         slot = std::max<int64_t>(slot, static_cast<int64_t>(width) * (static_cast<int64_t>(ownedCap) * 2 * ((n + 1) & ~int64_t{1}) + 128));
       } else {

@@ -31,12 +31,12 @@ enum Id {
   kEtkdgTiming,     // NVMK_ETKDG_TIMING     1 (per-stage wall clock of nvmk_etkdg_embed: a stream synchronisation after every stage)
   kEtkdgPrune,      // NVMK_ETKDG_PRUNE      1 | 0 (0: surplus attempts of a molecule also run the second half of the pipeline)
   kBuildSlotKb,     // NVMK_BUILD_SLOT_KB    n (tests: size of a pinned staging slot of the table builder, default 32768)
-  kBfgsTeam,        // NVMK_BFGS_TEAM        n (smallest system, in coordinates, minimised by a TEAM of workgroups; 0: none; default 1068)
+  kBfgsTeam,        // NVMK_BFGS_TEAM        n (smallest system, in coordinates, minimised by a TEAM of workgroups; 0: none; default 656)
   kBfgsTeamWidth,   // NVMK_BFGS_TEAM_WIDTH  w (workgroups per team for every team system; default: by size, see NVMK_BFGS_TEAM_SHARE_KB)
   kBfgsTeamShareKb, // NVMK_BFGS_TEAM_SHARE_KB  k (a team has the largest power-of-two width that leaves every rank at least k KiB of the packed inverse Hessian)
   kBfgsTeamThreads, // NVMK_BFGS_TEAM_THREADS 512 | 256 (threads of a team's workgroups: one or two workgroups per CU)
   kBfgsTeamTimeoutMs, // NVMK_BFGS_TEAM_TIMEOUT_MS  t (a team barrier gives up after t ms and the call reports an error; default 60000)
-  kBfgsHistory,     // NVMK_BFGS_HISTORY     auto | 0 | 1 (a team system's inverse Hessian as the pairs of its updates: where twice the iteration limit is at most its coordinates / never / wherever the pairs' scalars fit)
+  kBfgsHistory,     // NVMK_BFGS_HISTORY     auto | 0 | 1 (a team system's inverse Hessian as the pairs of its updates: where three times the iteration limit is at most twice its coordinates / never / wherever the pairs' scalars fit)
   kNumOptions
 };
 

@@ -274,12 +274,12 @@ def test_eight_wave_class_agrees_with_four_waves_and_is_reproducible(kind):
 
 # ---- the cooperative class (round 6): several workgroups per system, csrc/bfgs_device.inc `Team`, csrc/minimize_team.hip.  The
 # reference runs systems of any size through global-memory instantiations of its one-block kernel
-# (bfgs_minimize_permol_kernels.cu:796-932); here a system of 1068 coordinates or more is minimised by a TEAM of workgroups that
+# (bfgs_minimize_permol_kernels.cu:796-932); here a system of 656 coordinates or more is minimised by a TEAM of workgroups that
 # deal the inverse Hessian's rows and the force-field terms among themselves ---------------------------------------------------
 TEAM_WIDTHS = ["1", "2", "3", "8", "32", "40"]  # (any width: teams form from the workgroups in the order they start)
 # The inverse Hessian of a team's system is kept as the packed triangle ("0") or as the HISTORY of its rank-2 updates ("1": the
-# (xi, H dGrad) pairs, dealt over the ranks; bfgs_device.inc history_product) — by default ("auto") the history wherever twice the
-# call's iteration limit is at most the system's coordinates.  Same H_k in exact arithmetic, other roundings: both forms are held
+# (xi, H dGrad) pairs, dealt over the ranks; bfgs_device.inc history_product) — by default ("auto") the history wherever three times
+# the call's iteration limit is at most twice the system's coordinates.  Same H_k in exact arithmetic, other roundings: both forms are held
 # to the oracle's trajectories.
 HISTORY = ["0", "1"]
 
@@ -317,7 +317,7 @@ def test_team_class_matches_oracle_at_every_size(kind, width, history):
 def test_team_class_at_600_to_4000_coordinates(kind, threads, history):
     """The sizes the class is for, at the widths the library picks by itself (2 .. 32 workgroups): 150, 400 and 1000 atoms = 600 /
     1600 / 4000 coordinates in 4-D, 450 / 1200 / 3000 in 3-D (the smallest one stays with the one-workgroup classes unless it
-    reaches 800 coordinates), one and two workgroups per CU, the inverse Hessian as the triangle and — "auto": twenty pairs at
+    reaches 656 coordinates), one and two workgroups per CU, the inverse Hessian as the triangle and — "auto": twenty pairs at
     most against 1200 coordinates or more — as its history.  Ten iterations against the oracle, and twice for the same bits."""
     sizes = [150, 400, 1000]
     systems = systems_of(kind, sizes, 2100 + kind)

@@ -121,7 +121,8 @@ if args.end_to_end:
     del molset2, tables2, dev2
 st = stats.cpu().numpy().reshape(8, 8) // max(args.repeat, 1)
 bfgs = {name: {"systems": int(st[k, 0]), "iterations": int(st[k, 1]), "algorithmic_bytes": int(st[k, 2]), "energy_evaluations": int(st[k, 3]),
-               "hbm_requested_bytes": int(st[k, 4])} for k, name in ((0, "dg"), (1, "etk"), (2, "mmff"))}
+               "hbm_requested_bytes": int(st[k, 4]), "packed_triangle_bytes_of_the_same_iterations": int(st[k, 5]),
+               "minimisations_in_history_form": int(st[k, 6])} for k, name in ((0, "dg"), (1, "etk"), (2, "mmff"))}
 if world > 1:  # whole-job numbers: sums of work, max of time
     t = torch.tensor([t_embed, t_mmff], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
