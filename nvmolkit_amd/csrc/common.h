@@ -37,7 +37,7 @@ struct StreamScratch {
   }
   // By default the stream-ordered pool hands freed memory back to the driver at every synchronisation, so each call of a
   // blocking entry point re-acquired its scratch from the OS (measured: 40 ms of a 70 ms fused-Butina call at N = 100k).
-  // Keep up to 8 GiB cached per device — a quarter of the device's memory where that is more (MI355X: 72 of 288 GB; the team
+  // Keep up to 8 GiB cached per device — an eighth of the device's memory where that is more (MI355X: 36 of 288 GB; the team
   // classes of the reference's benchmark file hold several GB of pair records per launch, and a pool that lets go of them at
   // every synchronisation maps them again for every batch: ETKDG 17.8 s in the first whole-file run against 16.0 s in the
   // next); anything beyond is still released.
@@ -50,7 +50,7 @@ struct StreamScratch {
     if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool != nullptr) {
       uint64_t threshold = 8ull << 30;
       size_t   freeB = 0, totalB = 0;
-      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) threshold = std::max<uint64_t>(threshold, static_cast<uint64_t>(totalB) / 4);
+      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) threshold = std::max<uint64_t>(threshold, static_cast<uint64_t>(totalB) / 8);
       (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
     }
   }
