@@ -303,9 +303,12 @@ int nvmk_ff_gradient(const nvmk_ff_batch* batch, double w0, double w1, const dou
  * inverse Hessians).  d_statuses[s] = 0 converged / 1 not (reference: statuses_, 0 == converged), d_iters optional.
  * Blocking.  Constants as the reference (FUNCTOL 1e-4, MOVETOL 1e-7, TOLX 1.2e-7, EPS 3e-8, <= 1000 line-search steps).
  * Any system size (the reference: shared-memory and global-memory instantiations, bfgs_minimize_permol_kernels.cu:796-932): a call
- * is split by size — one, two, four or eight waves per system with the vectors in LDS, and from 800 coordinates on (option
- * NVMK_BFGS_TEAM) a TEAM of 2 ... 32 workgroups per system that deal the inverse Hessian's rows and the force field's terms among
- * themselves; a system's results depend on its size class only (bitwise reproducible for every class up to 9600 coordinates).
+ * is split by size — one, two or four waves per system with the vectors in LDS, and from 656 coordinates on (option
+ * NVMK_BFGS_TEAM) a TEAM of 2 ... 32 workgroups per system that deal the force field's terms among themselves and keep the
+ * inverse Hessian as the history of its rank-2 updates (the (xi, H dGrad) pairs, dealt over the team: where 3 max_iters <=
+ * 2 x coordinates; option NVMK_BFGS_HISTORY=0: the packed triangle, rows dealt over the team — the same H_k in exact
+ * arithmetic, other roundings); a system's results depend on its size, max_iters and the options only (bitwise reproducible
+ * for every class up to 9000 coordinates).
  * The workgroups of a team wait for each other inside the launch: calls with team systems take turns per device inside the
  * library, and a team whose members do not all become resident (another PROCESS holding the device's CUs with a kernel that
  * never ends) gives up after NVMK_BFGS_TEAM_TIMEOUT_MS and the call returns NVMK_ERR_INVALID_ARGUMENT with that message. */
