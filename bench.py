@@ -412,7 +412,10 @@ def conformer_block(n_mols: int, confs: int, mmff_iters: int, device, world: int
     t0 = time.perf_counter()
     molset = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library], device=device)
     t_molset = time.perf_counter() - t0   # host side of the assembly; its last uploads are still in flight
-    pending = mmffOptimization.resident_tables([m["mmff"] for m in library], device, wait=False)
+    # (after=molset: the MMFF assembly — seconds of every host thread on the file with its peptides — starts when the molecule
+    # set's own asynchronous fill is through, which the first ETKDG batch is waiting for; started together, the whole file's
+    # ETKDG took 21.1 s against 18.2 s, tools/experiments/e2e_overlap_probe.py)
+    pending = mmffOptimization.resident_tables([m["mmff"] for m in library], device, wait=False, after=molset)
     dev = embed_flat(molset, confs_per_molecule=confs, max_iterations=10, seed=1 + rank, output=CoordinateOutput.DEVICE)
     torch.cuda.synchronize()
     t_embed = time.perf_counter() - t0

@@ -276,7 +276,10 @@ class PendingTermTables:
     reference hides its per-batch flattening behind the previous batch's kernels (src/minimizer/bfgs_mmff.cpp:139-201).
     ``result()`` joins the thread and makes the caller's current stream wait for the upload."""
 
-    def __init__(self, kind: int, tables, device="cuda", preprocessing_threads: int = -1):
+    def __init__(self, kind: int, tables, device="cuda", preprocessing_threads: int = -1, after=None):
+        """``after``: an object with ``wait(stream)`` — e.g. the :class:`FlatMoleculeSet` of the same molecules, whose own asynchronous
+        fill the first ETKDG batch is waiting for: the tables' assembly (seconds of all host threads on a file with peptides)
+        starts when that fill is through instead of competing with it."""
         import threading
 
         self.device = torch.device(device)
@@ -291,6 +294,8 @@ class PendingTermTables:
                 # caller get into its own blocking library call (which releases the GIL) first, instead of stalling it
                 time.sleep(0.003)
                 with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
+                    if after is not None:
+                        after.wait(self._stream)
                     self._tables = MoleculeTermTables(kind, tables, self.device, preprocessing_threads)
             except BaseException as exc:  # noqa: BLE001 - re-raised in result()
                 self._error = exc

@@ -33,13 +33,13 @@ def optimize_flat(atom_starts, groups, positions: torch.Tensor, max_iters: int =
     return energies, statuses == 0
 
 
-def resident_tables(tables, device="cuda", preprocessing_threads: int = -1, wait: bool = True):
+def resident_tables(tables, device="cuda", preprocessing_threads: int = -1, wait: bool = True, after=None):
     """Assemble and upload the per-molecule MMFF term tables once (see :class:`MoleculeTermTables`); pass the result to
     :func:`optimize_device` instead of ``tables`` when the same molecules are optimised more than once.  ``wait=False`` returns at
     once with a :class:`PendingTermTables`: the tables are put together on a host thread and a side stream while the caller runs
     something else (the ETKDG embedding of the same molecules), and :func:`optimize_device` picks them up when it needs them."""
     if not wait:
-        return PendingTermTables(MMFF, tables, device, preprocessing_threads)
+        return PendingTermTables(MMFF, tables, device, preprocessing_threads, after=after)  # (after: see PendingTermTables)
     return MoleculeTermTables(MMFF, tables, device, preprocessing_threads)
 
 

@@ -108,7 +108,7 @@ if args.end_to_end:
     molset2 = FlatMoleculeSet([FlatMolecule(**m["embed"]) for m in library])
     e_molset = time.perf_counter() - e0
     molset_timings = dict(molset2.timings)
-    pending = mmffOptimization.resident_tables([m["mmff"] for m in library], wait=False)
+    pending = mmffOptimization.resident_tables([m["mmff"] for m in library], wait=False, after=molset2)
     dev2 = embed_flat(molset2, confs_per_molecule=args.confs, max_iterations=10, batch_size=args.batch_size, seed=1,
                       output=CoordinateOutput.DEVICE, batches_per_gpu=args.batches_per_gpu)
     torch.cuda.synchronize()
