@@ -163,9 +163,13 @@ class FlatBatchedForcefield:
         kind: ``forcefield.MMFF`` or ``forcefield.UFF``.
         tables: ``tables[m]`` = the molecule's base term groups ``[(idx, par), ...]`` (include/nvmolkit_amd.h).
         conformers: ``conformers[m]`` = array (n_confs_m, n_atoms_m, 3); updated in place by :meth:`minimize`.
+        gpu_ids: the GPUs :meth:`minimize` deals the conformers over (``HardwareOptions.gpuIds``); energies and gradients
+            are evaluated on ``device``, where the object's tables live — the reference's wrapper is built the same way
+            (nvmolkit/batchedForcefield.cpp:252,270-272: ``cudaGetDevice`` for the persistent state, ``hwOpts_`` for the
+            minimisation).  Empty / one entry: everything on ``device``.
     """
 
-    def __init__(self, kind: int, tables: Sequence, conformers: Sequence[np.ndarray], device="cuda"):
+    def __init__(self, kind: int, tables: Sequence, conformers: Sequence[np.ndarray], device="cuda", gpu_ids: Sequence[int] | None = None):
         if kind not in (MMFF, UFF):
             raise ValueError("kind must be forcefield.MMFF or forcefield.UFF")
         if len(tables) != len(conformers):
@@ -179,7 +183,9 @@ class FlatBatchedForcefield:
         # a counter that every added restraint advances; the device tables remember the count they were made at
         self._edits = 0
         self._restraints = [_MoleculeRestraints(m, int(c.shape[1]), self._edited) for m, c in enumerate(self._conformers)]
-        self._device_tables = None   # (edit count, FlatForcefieldBatch, systems, atom_starts)
+        self._device_tables = None   # (edit count, FlatForcefieldBatch)
+        self._gpu_ids = [int(g) for g in gpu_ids] if gpu_ids else []
+        self._shards = None          # (edit count, [(gpu, systems of the shard, FlatForcefieldBatch), ...]) of a minimisation over several GPUs
         self.num_molecules = n
         self.data_dim = 3
 
@@ -196,15 +202,14 @@ class FlatBatchedForcefield:
         return self._element_type(self._restraints[idx])
 
     # ---- device tables: made on first use, made again after a restraint was added ----
-    def rebuild(self) -> None:
-        """Make the device tables again from the CURRENT coordinates (relative windows and position anchors move with them)."""
-        self._systems = [(m, k) for m, c in enumerate(self._conformers) for k in range(len(c))]
-        sizes = np.array([self._restraints[m].n_atoms for m, _ in self._systems], dtype=np.int64)
-        self._atom_starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    def _stack(self, systems, device) -> FlatForcefieldBatch:
+        """The device tables of ``systems`` (a list of (molecule, conformer)) made from the CURRENT coordinates."""
+        sizes = np.array([self._restraints[m].n_atoms for m, _ in systems], dtype=np.int64)
+        atom_starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
         restrained = any(self._restraints)
         layout = list(GROUP_LAYOUT[self.kind]) + (list(CONSTRAINT_LAYOUT) if restrained else [])
         per_system = [list(self._tables[m]) + (self._restraints[m].rows_for(self._conformers[m][k]) if restrained else [])
-                      for m, k in self._systems]
+                      for m, k in systems]
         stacked = []
         for g, (n_idx, n_par) in enumerate(layout):
             counts = [len(groups[g][0]) for groups in per_system]
@@ -213,7 +218,15 @@ class FlatBatchedForcefield:
             par = (np.concatenate([np.asarray(groups[g][1], dtype=np.float64).reshape(-1, n_par) for groups in per_system])
                    if per_system else np.zeros((0, n_par)))
             stacked.append((np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), idx, par))
-        self._device_tables = (self._edits, FlatForcefieldBatch(self.kind, self._atom_starts, stacked, device=self.device))
+        return FlatForcefieldBatch(self.kind, atom_starts, stacked, device=device)
+
+    def rebuild(self) -> None:
+        """Make the device tables again from the CURRENT coordinates (relative windows and position anchors move with them)."""
+        self._systems = [(m, k) for m, c in enumerate(self._conformers) for k in range(len(c))]
+        sizes = np.array([self._restraints[m].n_atoms for m, _ in self._systems], dtype=np.int64)
+        self._atom_starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        self._device_tables = (self._edits, self._stack(self._systems, self.device))
+        self._shards = None
 
     @property
     def _batch(self) -> FlatForcefieldBatch:
@@ -267,7 +280,10 @@ class FlatBatchedForcefield:
             return [], []
         batch = self._batch
         pos = self._positions()
-        energies, statuses, _ = batch.minimize(pos, max_iters=int(maxIters), grad_tol=float(forceTol), scale_grads=True)
+        if len(self._gpu_ids) > 1:
+            energies, statuses = self._minimize_over_gpus(pos, int(maxIters), float(forceTol))
+        else:
+            energies, statuses, _ = batch.minimize(pos, max_iters=int(maxIters), grad_tol=float(forceTol), scale_grads=True)
         if output == CoordinateOutput.DEVICE:
             gpu = self.device.index if self.device.index is not None else torch.cuda.current_device()
             if targetGpu is not None and int(targetGpu) >= 0 and int(targetGpu) != gpu:
@@ -286,6 +302,60 @@ class FlatBatchedForcefield:
         return (self._nest([float(e) for e in energies.cpu().numpy()]),
                 self._nest([bool(c) for c in (statuses == 0).cpu().numpy()]))
 
+    def _minimize_over_gpus(self, pos: torch.Tensor, max_iters: int, grad_tol: float):
+        """The minimisation of :meth:`minimize` with the conformers dealt over ``gpu_ids`` by modelled cost (largest first, as the
+        optimise drivers deal molecules: distributed.molecule_owners_by_cost), one host thread per entry, no collective; ``pos``
+        (on ``self.device``) receives the minimised coordinates.  A system's result does not depend on which GPU or beside which
+        other systems it ran (its size class is a function of its size), so the results equal the one-GPU call's bit for bit.
+        Reference: nvmolkit/batchedForcefield.cpp:270-272 hands ``hwOpts_`` to MMFFMinimizeMoleculesConfs, whose threads take
+        batches per GPU (src/minimizer/bfgs_mmff.cpp:139-201)."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        from nvmolkit_amd.distributed import molecule_owners_by_cost
+
+        if self._shards is None or self._shards[0] != self._edits:
+            sizes = np.diff(self._atom_starts)
+            owner, _ = molecule_owners_by_cost(sizes, len(self._gpu_ids))
+            shards = []
+            for r, gpu in enumerate(self._gpu_ids):
+                members = np.flatnonzero(owner == r)
+                if len(members):
+                    shards.append((gpu, members, self._stack([self._systems[s] for s in members], torch.device("cuda", gpu))))
+            self._shards = (self._edits, shards)
+        starts = self._atom_starts.astype(np.int64)
+        pos3 = pos.view(-1, 3)
+
+        # every shard's coordinates are gathered on the object's GPU first; a thread then copies its own to its GPU, minimises
+        # there on that device's current stream and brings coordinates, energies and statuses back
+        gathered = []
+        for _, members, _ in self._shards[1]:
+            rows = torch.from_numpy(np.concatenate([np.arange(starts[s], starts[s + 1]) for s in members])).to(self.device)
+            gathered.append((rows, pos3[rows]))
+        torch.cuda.synchronize(self.device)
+
+        def run(k):
+            gpu, _, batch = self._shards[1][k]
+            with torch.cuda.device(gpu):
+                local = gathered[k][1].to(batch.device).reshape(-1)
+                e, st, _ = batch.minimize(local, max_iters=max_iters, grad_tol=grad_tol, scale_grads=True)
+                out = (local.view(-1, 3).to(self.device), e.to(self.device), st.to(self.device))
+                torch.cuda.synchronize(gpu)
+            torch.cuda.synchronize(self.device)
+            return out
+
+        with ThreadPoolExecutor(max_workers=len(self._shards[1])) as pool:
+            done = list(pool.map(run, range(len(self._shards[1]))))
+        energies = torch.empty(len(self._systems), dtype=torch.float64, device=self.device)
+        statuses = None
+        for (_, members, _), (rows, _), (xyz, e, st) in zip(self._shards[1], gathered, done):
+            pos3[rows] = xyz
+            where = torch.from_numpy(members).to(self.device)
+            energies[where] = e
+            if statuses is None:
+                statuses = torch.empty(len(self._systems), dtype=st.dtype, device=self.device)
+            statuses[where] = st
+        return energies, statuses
+
     def _write_back(self) -> None:  # overridden by the RDKit-backed classes
         pass
 
@@ -302,7 +372,8 @@ class _RdkitBacked(FlatBatchedForcefield):
                       if ids else np.zeros((0, m.GetNumAtoms(), 3)) for m, ids in zip(molecules, self._conf_ids)]
         tables = [flatten(i, ids[0] if ids else -1) for i, ids in enumerate(self._conf_ids)]
         gpu_ids = self._hardware_options.gpuIds
-        super().__init__(kind, tables, conformers, device=torch.device("cuda", gpu_ids[0] if gpu_ids else torch.cuda.current_device()))
+        super().__init__(kind, tables, conformers, device=torch.device("cuda", gpu_ids[0] if gpu_ids else torch.cuda.current_device()),
+                         gpu_ids=gpu_ids)
 
     def _write_back(self) -> None:
         for m, ids, confs in zip(self._molecules, self._conf_ids, self._conformers):

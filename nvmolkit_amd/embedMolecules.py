@@ -172,14 +172,19 @@ class FlatMoleculeSet:
 # order the batches finish), and at 16384 attempts it is as fast.  Round 3 sweep, 10 000 molecules x 10 conformers, ETKDG
 # conformers/s (profiles/r03_conformers/batch_sweep_wave176.jsonl): 8192 x 1 37.5k, 16384 x 1 40.5k / 40.2k, 24576 x 1 38.4k,
 # 32768 x 1 36.8k, 4096 x 2 41.0k, 8192 x 2 38.5k, 16384 x 2 37.1k, 4096 x 3 40.6k, 8192 x 3 41.7k.
-AUTO_BATCH_SIZE = 16384
+# Round 6, after the persistent per-XCD queues, the team classes and the per-batch table pipeline, the same job
+# (profiles/r06_conformers/batch_size_sweep.txt, candidates alternating on one box): 6 x 16 667 ETKDG 1.875 / 1.879 s, 3 x 33 334
+# 1.835 / 1.831 s, 2 x 50 000 1.821 / 1.815 s, 1 x 100 000 2.28 s; end to end 3417 / 3519, 3562 / 3552, 3595 / 3554 mol/s; the whole
+# ChEMBL file 16.7 / 16.4, 15.8 / 16.0, 16.0 / 16.1 s (end to end within the boxes' noise).  Three batches: most of the gain, and
+# the first batch still waits for a third of the molecule set's rows only.
+AUTO_BATCH_SIZE = 32768
 AUTO_BATCHES_PER_GPU = 1
 
 
 def auto_batch_size(n_attempts: int) -> int:
     """The automatic batch size for a job of ``n_attempts`` first-round attempts: about AUTO_BATCH_SIZE, but EQUAL batches — the
-    first round of 10 000 molecules x 10 conformers is 6 x 16 384 + 1696, and that last batch is a launch-latency-bound runt that
-    costs as much wall as a quarter of a full one.  Six batches of 16 667 instead: ETKDG 1.99 -> 1.89 s, 3440 -> 3565 mol/s
+    first round of 10 000 molecules x 10 conformers was 6 x 16 384 + 1696 when batches were 16 384 (3 x 32 768 + 1696 now), and
+    that last batch is a launch-latency-bound runt that costs as much wall as a quarter of a full one.  Six batches of 16 667 instead: ETKDG 1.99 -> 1.89 s, 3440 -> 3565 mol/s
     (seven of 14 286: 3557; profiles/r05_conformers/ab_equal_batches.txt).  The scheduler's hand-out order does not depend on where
     the batches are cut (reference sequences: tests/test_scheduler.py)."""
     if n_attempts <= AUTO_BATCH_SIZE:

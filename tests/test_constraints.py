@@ -184,3 +184,46 @@ def test_object_api(kind):
     for k in range(3):
         assert np.linalg.norm(ff._conformers[1][k][2] - confs[1][k][2]) < 0.5
     assert FlatBatchedForcefield(kind, [], []).compute_energy() == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [MMFF, UFF])
+def test_minimize_dealt_over_gpu_ids_equals_the_one_gpu_call(kind):
+    """``HardwareOptions.gpuIds`` with several entries: the reference's wrapper keeps its tables on one GPU and hands the
+    options to the optimise driver for ``minimize`` (nvmolkit/batchedForcefield.cpp:252,270-272).  Here the conformers are
+    dealt over the entries by cost, one host thread each; a box with one GPU lists it twice or three times — the shards,
+    the threads and the way back are the same, and the results must equal the one-GPU call's bit for bit, constraints
+    included, in both output modes."""
+    rng = np.random.default_rng(kind + 77)
+    sizes, n_confs = (6, 14, 9, 30, 11), (2, 1, 3, 2, 4)
+    mols = [util.random_ff_system(kind, n, rng) for n in sizes]
+    if kind == UFF:
+        for _, g in mols:
+            g[3][1][:, 1:] = (1.0, -1.0, 0.0)
+            g[1][1][:, 2] = np.where(g[1][1][:, 2] == 0, 0.0, 3.0)
+    confs = [np.stack([p[:, :3] + 0.05 * rng.normal(size=(len(p), 3)) for _ in range(k)]) for (p, _), k in zip(mols, n_confs)]
+
+    def make(gpu_ids):
+        ff = FlatBatchedForcefield(kind, [g for _, g in mols], [c.copy() for c in confs], gpu_ids=gpu_ids)
+        ff[0].add_distance_constraint(0, 5, False, 0.5, 1.0, 50.0)
+        ff[3].add_position_constraint(2, 0.0, 30.0)
+        ff[4].add_torsion_constraint(0, 1, 2, 3, True, -5.0, 5.0, 0.2)
+        return ff
+
+    one = make(None)
+    e_one, c_one = one.minimize(60, 1e-4)
+    for ids in ([0, 0], [0, 0, 0]):
+        many = make(ids)
+        dev = many.minimize(60, 1e-4, output=CoordinateOutput.DEVICE)
+        assert isinstance(dev, Device3DResult) and dev.num_conformers == sum(n_confs)
+        assert len(many._shards[1]) == len(ids) and sorted(np.concatenate([m for _, m, _ in many._shards[1]]).tolist()) == list(range(sum(n_confs)))
+        flat = dev.values.torch().cpu().numpy()
+        assert np.array_equal(flat, np.concatenate([c.reshape(-1, 3) for c in one._conformers]))
+        assert np.array_equal(dev.energies.torch().cpu().numpy(), np.concatenate([np.asarray(e) for e in e_one]))
+        assert np.array_equal(many._conformers[3], confs[3])  # DEVICE mode leaves the stored coordinates alone
+        e_many, c_many = many.minimize(60, 1e-4)
+        assert e_many == e_one and c_many == c_one
+        for a, b in zip(many._conformers, one._conformers):
+            assert np.array_equal(a, b)
+    # one entry, or none: the one-GPU path
+    assert make([0])._gpu_ids == [0] and make([0]).minimize(5, 1e-4) == make(None).minimize(5, 1e-4)

@@ -20,6 +20,8 @@
 #   chembl_all_timeline the whole file with the per-system BFGS timeline, summarised per class and team width
 #   chembl_all          every molecule of the ChEMBL file (up to 1063 atoms)
 #   conf10k             tools/bench_conformers.py --mols 10000 (resident tables, and end to end from the host arrays)
+#   batch_ab            the same candidates end to end (table assembly inside the clock), alternating, twice
+#   batch_sweep         attempts per ETKDG batch (BATCHES="-1 33334 ...", EXTRA_ENV=...) on the whole ChEMBL file and on the synthetic set, resident tables
 #   pytest_gpu          the whole -m gpu suite (stops at the first failure; pytest_gpu_all: runs on)
 #   smoke               __graft_entry__.smoke()
 #   bench               python bench.py (default flags), plain
@@ -262,6 +264,27 @@ PY
     chembl_all)
       timeout 1200 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --end-to-end --cache $CACHE 2> $O/chembl_all.err | tee $O/chembl_all.json | cut -c1-900
       tail -3 $O/chembl_all.err
+      ;;
+    batch_sweep)
+      : > $O/batch_sweep.txt
+      for B in ${BATCHES:--1 33334 50000}; do
+        echo "== chembl whole file, --batch-size $B ${EXTRA_ENV:-}" | tee -a $O/batch_sweep.txt
+        env ${EXTRA_ENV:-} timeout 900 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --batch-size $B --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | cut -c1-420 | tee -a $O/batch_sweep.txt
+        echo "== synthetic 10000, --batch-size $B ${EXTRA_ENV:-}" | tee -a $O/batch_sweep.txt
+        env ${EXTRA_ENV:-} timeout 600 python tools/bench_conformers.py --mols 10000 --repeat 2 --batch-size $B --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | cut -c1-420 | tee -a $O/batch_sweep.txt
+      done
+      ;;
+    batch_ab)
+      # end to end (table assembly inside the clock), the candidates alternating on one box
+      : > $O/batch_ab.txt
+      for i in 1 2; do
+        for B in ${BATCHES:--1 33334 50000}; do
+          echo "== synthetic 10000 end to end, --batch-size $B" | tee -a $O/batch_ab.txt
+          timeout 600 python tools/bench_conformers.py --mols 10000 --repeat 3 --end-to-end --batch-size $B --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | pick b$B | tee -a $O/batch_ab.txt
+          echo "== chembl whole file end to end, --batch-size $B" | tee -a $O/batch_ab.txt
+          timeout 900 python tools/bench_conformers.py --set chembl --mols 10000 --max-atoms 100000 --end-to-end --batch-size $B --cache $CACHE 2>/dev/null | grep '^{' | tail -1 | pick b$B | tee -a $O/batch_ab.txt
+        done
+      done
       ;;
     conf10k)
       timeout 600 python tools/bench_conformers.py --mols 10000 --repeat 2 --end-to-end --cache $CACHE 2> $O/conf10k.err | tee $O/conf10k.json | pick conf10k
